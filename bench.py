@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Benchmark of the basecalling hot path on MI355X: raw-signal samples/s through
+    normalise -> conv -> GRU stack -> softmax -> prepare_post+log -> k-mer Viterbi (+backtrace) -> paths on host.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model raw_0.98_rgrgr] [--batch 1024]
+
+One "step" = one pass of the hot path over one batch of synthetic 4000-sample chunks already resident in HBM.
+N > 1: launched by torch.distributed.run, one rank per GPU; every rank processes its own batch (reads/chunks are
+independent units: no data-path collective, weak scaling); timing = max over ranks, value = whole-job samples/s.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how `roofline` and `cpu_baseline` are defined).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_*_f32 = the fp32 vector rate
+HBM_PEAK_GBS = 8000.0              # spec; ~6300 achievable
+
+# GEMM-like flops per raw sample -- used for the end-to-end MFMA fraction
+MFMA_STAGES = ("gru_recurrent", "gru_input_gemm", "softmax_gemm", "gemm_bias_act", "conv1d")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="raw_0.98_rgrgr")
+    ap.add_argument("--batch", type=int, default=1024, help="chunks per GPU per step")
+    ap.add_argument("--chunk-len", type=int, default=4000)
+    ap.add_argument("--cpu-chunks", type=int, default=16, help="chunks in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-stage-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(model_name, chunk_len, nchunk):
+    """The oracle (CPU port of the same pipeline) on the host cores, bounded sample."""
+    from oracle import oracle as orc
+    from sloika_amd import models, pipeline
+    orc.build()
+    net = models.randomise_zero_layers(models.build_model(model_name, klen=5, sd=0.5, seed=11))
+    spec = net.spec()
+    chunks = pipeline.synthetic_chunks(nchunk, chunk_len=chunk_len, seed=123)
+    cores = orc.num_threads()
+    t0 = time.perf_counter()
+    x = orc.med_mad_normalise(chunks)
+    post = orc.run_network(spec, np.ascontiguousarray(x.T)[:, :, None])
+    T, B, S = post.shape
+    lp = np.log(np.float32(1e-5) + np.float32(1.0 - 1e-5) * post + np.float32(1e-10))
+    orc.viterbi_batch(lp, 5, skip_pen=0.0)
+    dt = time.perf_counter() - t0
+    return {"value": nchunk * chunk_len / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d chunks x %d samples of the same synthetic workload, oracle C port (OpenMP over chunks), "
+                      "%.1f s" % (nchunk, chunk_len, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    from sloika_amd import _lib, models, pipeline, profiler, shard
+    rank, world, local_rank = shard.dist_info()
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    net = models.randomise_zero_layers(models.build_model(args.model, klen=5, sd=0.5, seed=11))
+    bc = pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0)
+    B, L = args.batch, args.chunk_len
+    # a few distinct batches so that steps do not all hit the same cache lines
+    nbuf = 2
+    host = [pipeline.synthetic_chunks(B, chunk_len=L, seed=0xdeadbeef, first_chunk=(rank * nbuf + i) * B)
+            for i in range(nbuf)]
+    dev = [torch.from_numpy(h).cuda() for h in host]
+    out_host = torch.empty((B, bc.network.layers[0].out_len(L) if hasattr(bc.network.layers[0], "out_len") else L),
+                           dtype=torch.int32).pin_memory()
+
+    def step(i):
+        scores, paths, lens = bc.call_chunks(dev[i % nbuf])
+        out_host[:, : paths.shape[1]].copy_(paths, non_blocking=True)     # paths end up on the host
+        return scores, lens
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    rec = None if args.no_stage_timing else profiler.start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if rec is not None:
+        profiler.stop()
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    samples = world * B * L * args.steps
+    value = samples / dt
+
+    stages = rec.summary() if rec is not None else {}
+    roofline = None
+    if stages:
+        dom = max(stages, key=lambda k: stages[k]["ms_total"])
+        d = stages[dom]
+        if dom in MFMA_STAGES:
+            ach = d["flops"] / d["calls"] / (d["ms_avg"] * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "ms_per_launch": d["ms_avg"], "launches": d["calls"]}
+        else:
+            ach = d["bytes"] / d["calls"] / (d["ms_avg"] * 1e-3) / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": d["ms_avg"],
+                        "launches": d["calls"]}
+    if rank == 0:
+        cpu = None
+        if world == 1 and args.cpu_chunks > 0:
+            cpu = cpu_baseline(args.model, L, args.cpu_chunks)
+        gemm_flops = sum(stages[k]["flops"] for k in stages if k in MFMA_STAGES) / max(1, args.steps)
+        line = {
+            "metric": "raw-signal samples/sec basecalled", "value": value, "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s inference, %d-sample chunks, batch %d per GPU, klen 5 (1025 states), "
+                                   "normalise->conv->GRU->softmax->Viterbi->paths on host" % (args.model, L, B),
+                       "model": args.model, "chunk_len": L, "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "chunks sharded over %d GPU(s), no collective" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())},
+            "e2e_mfma_frac": (gemm_flops / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if stages else None,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

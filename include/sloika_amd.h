@@ -1,0 +1,211 @@
+/*
+ * sloika_amd.h -- C ABI of the MI355X (gfx950) basecalling hot path.
+ *
+ * Drop-in boundary for ONE path of nanoporetech/sloika:
+ *     chunkify/normalise -> conv front end -> stacked GRU/LSTM -> softmax -> k-mer Viterbi decode
+ *     (+ the transducer remap DP).
+ * The reference implements this path in Python/numpy on top of Theano-generated code plus one Cython
+ * function; each entry point below names the reference interface (file:line, relative to the sloika
+ * checkout) it replaces.  INTEGRATION.md shows the binding a sloika maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - ALL pointers are DEVICE pointers (HIP) unless the parameter is documented as host.
+ *     The library never allocates, frees or synchronises; scratch space is passed in by the caller
+ *     (size from the matching *_workspace_bytes function).
+ *   - every call enqueues work on `stream` (a hipStream_t passed as void*; NULL = the null stream)
+ *     and returns immediately.  Safe to capture into a hipGraph.
+ *   - return value: SLK_OK (0) or a negative SLK_ERR_* code; nothing throws.
+ *   - tensors are float32, C order [time][batch][feature] (sloika/layers.py:13-14).
+ *   - thread-safe and re-entrant: no global state.
+ */
+#ifndef SLOIKA_AMD_H
+#define SLOIKA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLK_ABI_VERSION 1
+
+#define SLK_OK 0
+#define SLK_ERR_INVALID_ARG (-1) /* bad shape / null pointer: the reference raises AssertionError here      */
+#define SLK_ERR_UNSUPPORTED (-2) /* valid request this build has no kernel for                               */
+#define SLK_ERR_LAUNCH (-3)      /* HIP reported a launch error                                              */
+#define SLK_ERR_WORKSPACE (-4)   /* workspace pointer null or too small                                      */
+#define SLK_ERR_NO_DEVICE (-5)   /* no HIP device visible to this process                                    */
+
+/* Activation ids: one per function of sloika/activation.py:8-115 (same order as the file).                  */
+enum slk_activation {
+    SLK_ACT_LINEAR = 0,      /* activation.py:8   */
+    SLK_ACT_TANH = 1,        /* activation.py:52  */
+    SLK_ACT_SIGMOID = 2,     /* activation.py:56  */
+    SLK_ACT_ELU = 3,         /* activation.py:38  */
+    SLK_ACT_RELU = 4,        /* activation.py:12  */
+    SLK_ACT_RELU_SMOOTH = 5, /* activation.py:16  */
+    SLK_ACT_SOFTPLUS = 6,    /* activation.py:21  */
+    SLK_ACT_EXP = 7,         /* activation.py:45  */
+    SLK_ACT_ERF = 8,         /* activation.py:60  */
+    SLK_ACT_L1ML2 = 9,       /* activation.py:64  */
+    SLK_ACT_FAIR = 10,       /* activation.py:68  */
+    SLK_ACT_RETU = 11,       /* activation.py:72  */
+    SLK_ACT_TANH_PM = 12,    /* activation.py:81  */
+    SLK_ACT_SIGMOID_PM = 13, /* activation.py:88  */
+    SLK_ACT_BOUNDED_LINEAR = 14, /* activation.py:95 */
+    SLK_ACT_SIN = 15,        /* activation.py:102 */
+    SLK_ACT_CAUCHY = 16,     /* activation.py:106 */
+    SLK_ACT_GEMAN_MCCLURE = 17, /* activation.py:110 */
+    SLK_ACT_WELSH = 18,      /* activation.py:114 */
+    SLK_ACT_COUNT = 19
+};
+
+typedef void *slk_stream_t; /* hipStream_t */
+
+int slk_abi_version(void);
+const char *slk_error_string(int code);
+/* Number of HIP devices visible (host call; does not create a context when 0).                               */
+int slk_device_count(void);
+
+/* Elementwise activation y[i] = act(x[i]) (sloika/activation.py); in place allowed (y == x).                 */
+int slk_activation_f32(const float *x, float *y, size_t count, int act, slk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a1. Chunk front end: per-chunk median/MAD normalisation.
+ * Replaces: sloika/tools/chunkify_raw.py:172-181 ("per-chunk" branch of raw_chunkify), the same maths as
+ * sloika/basecall.py:117-118 and sloika/maths.py:4-27 (factor 1.4826, numpy median semantics).
+ *   signal : [nchunk][chunk_len] float32 (chunk-major, as raw_chunkify's reshape produces it)
+ *   out    : element (c, i) is written at out[c*out_chunk_stride + i*out_sample_stride]
+ *            (out_chunk_stride=chunk_len, out_sample_stride=1 keeps chunk-major;
+ *             out_chunk_stride=1, out_sample_stride=nchunk writes the [T][B][1] network layout of
+ *             bin/train_network.py:304 directly)
+ *   med_out, mad_out : optional [nchunk] (NULL to skip); mad includes the 1.4826 factor.
+ * Results are bit-identical to numpy's float32 evaluation.  chunk_len <= 32768.
+ * ------------------------------------------------------------------------------------------------------- */
+int slk_med_mad_normalise_f32(const float *signal, int nchunk, int chunk_len, float *out,
+                              long out_chunk_stride, long out_sample_stride, float *med_out, float *mad_out,
+                              slk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a3. Convolution.run  (sloika/layers.py:417-419 -> sloika/conv.py:66-77,90-111)
+ *   y[to][b][o] = act( sum_{c,k} xpad[to*stride + k][b][c] * W[o][c][k] + bias[o] ), zero padding
+ *   (pad_l, pad_r) on the time axis, cross-correlation (filter_flip=False).
+ *   x : element (t, b, c) at x[t*x_t_stride + b*x_b_stride + c]   (x_t_stride=B*Cin, x_b_stride=Cin for the
+ *       reference layout; x_t_stride=1, x_b_stride=T reads chunk-major signal when Cin == 1)
+ *   W : [Cout][Cin][winlen]   bias: [Cout] or NULL   y : [Tout][B][Cout], Tout = slk_conv1d_out_len(...)
+ * ------------------------------------------------------------------------------------------------------- */
+int slk_conv1d_out_len(int T, int winlen, int stride, int pad_l, int pad_r);
+int slk_conv1d_f32(const float *x, long x_t_stride, long x_b_stride, const float *W, const float *bias, float *y,
+                   int T, int B, int Cin, int Cout, int winlen, int stride, int pad_l, int pad_r, int act,
+                   slk_stream_t stream);
+
+/* a3b. Window.run (sloika/layers.py:346-351): zero pad w/2 both ends, y[t][b][k*F+f] = xpad[t+k][b][f].      */
+int slk_window_f32(const float *x, float *y, int T, int B, int F, int w, slk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a6. FeedForward.run (sloika/layers.py:157-158) and every other `tensordot(x, W, axes=(2,1)) + b`:
+ *   y[r][j] = act( sum_k x[r][k] * W[j][k] + bias[j] ),  r < M (= T*B rows), j < N, k < K.
+ *   x rows are ldx floats apart, y rows ldy floats apart (lets Parallel/birnn outputs be written straight
+ *   into their slice of the concatenated tensor, sloika/layers.py:1486-1487).  W:[N][K] dense.  fp32 MFMA.
+ * ------------------------------------------------------------------------------------------------------- */
+int slk_gemm_bias_act_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long ldy,
+                          long M, int K, int N, int act, slk_stream_t stream);
+
+/* Softmax.run (sloika/layers.py:309-314): logits = x.W^T + b; p = exp(l - max) / sum.  y:[M][N] dense.      */
+int slk_linear_softmax_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long M, int K,
+                           int N, slk_stream_t stream);
+/* In-place row softmax of y:[M][N] (the second half of the above, exposed for testing).                     */
+int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a4. Gru  (sloika/layers.py:952-1021; step :1010-1021; zero initial state :85-88; Reverse :1449-1450)
+ *   slk_gru_recurrent_f32 consumes the time-parallel input projection
+ *       vI[t][b][g*n + j] = x_t . iW[g*n+j] + b[g*n+j]   (g = 0 z, 1 r, 2 candidate; gate-block layout)
+ *   computed by slk_gemm_bias_act_f32, and runs the sequential part
+ *       z = gate(vI_z + h.sW_z^T)  r = gate(vI_r + h.sW_r^T)
+ *       hbar = act(vI_c + (r*h).sW2^T)   h = z*h + (1-z)*hbar
+ *   over t = 0..T-1 (reverse=0) or t = T-1..0 (reverse=1, implements Reverse(Gru) without copies).
+ *   sW:[2n][n]  sW2:[n][n]  (reference shapes, [out][in]);  h_out element (t,b,j) at
+ *   h_out[(t*B + b)*ldh + j]  (ldh >= n).
+ * slk_gru_f32 = projection + recurrence; workspace >= slk_gru_workspace_bytes(T,B,n).
+ * ------------------------------------------------------------------------------------------------------- */
+int slk_gru_recurrent_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
+                          int n, int reverse, int act, int gate_act, slk_stream_t stream);
+size_t slk_gru_workspace_bytes(int T, int B, int n);
+int slk_gru_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+                float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
+                void *workspace, size_t workspace_bytes, slk_stream_t stream);
+/* Force the portable (non-MFMA) recurrence kernel: 0 = auto, 1 = force generic.  Testing aid; passed per call
+ * through the `_ex` form so that there is still no global state.                                            */
+int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T,
+                             int B, int n, int reverse, int act, int gate_act, int force_generic,
+                             slk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a6b. Lstm (sloika/layers.py:599-697; step :677-691 is authoritative: INTERLEAVED gate layout,
+ *   row = j*4 + g with g = 0 update, 1 input gate, 2 forget gate, 3 output gate; peepholes p:[3][n]).
+ *   vW[t][b][j*4+g] = x_t . iW[j*4+g] + b[j*4+g]  (from slk_gemm_bias_act_f32);  sW:[4n][n];
+ *   p may be NULL (has_peep=False).  Output = the `out` half of the state (layers.py:697).
+ * ------------------------------------------------------------------------------------------------------- */
+int slk_lstm_recurrent_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
+                           int n, int reverse, int act, int gate_act, slk_stream_t stream);
+size_t slk_lstm_workspace_bytes(int T, int B, int n);
+int slk_lstm_f32(const float *x, long ldx, const float *iW, const float *sW, const float *bias, const float *p,
+                 float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
+                 void *workspace, size_t workspace_bytes, slk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a7 + a8. decode.prepare_post (sloika/decode.py:21-36) and decode.viterbi (sloika/decode.py:39-93),
+ * batched over chunks (the reference decodes one [T,1,S] posterior per call, sloika/basecall.py:26-51).
+ *   post : [T][B][nstate] float32, nstate = nbase^klen + 1, state 0 = blank/stay
+ *   input_mode: SLK_POST_RAW   post is a network posterior: lp = log(min_prob + (1-min_prob)*post + 1e-10)
+ *               SLK_POST_PLAIN lp = log(post + 1e-10)                        (decode.viterbi(log=False))
+ *               SLK_POST_LOG   lp = post                                      (decode.viterbi(log=True))
+ *   skip_pen  : decode.viterbi's skip_pen (float32 arithmetic as numpy does for float32 input)
+ *   score_out : [B] best path score (float32)
+ *   path_out  : [B][T] int32 k-mer states in time order, left aligned; entries >= len are -1
+ *   len_out   : [B] path lengths (1 <= len <= T)
+ * Tie-breaking is exactly the reference's: first maximum for step/skip/argmax (np.argmax), step vs skip tie
+ * -> skip (decode.py:76), move vs stay tie -> stay (decode.py:81).  Integer outputs are bit-exact given the
+ * same log-posteriors.  klen >= 3 (decode.py:50), nbase in {4,5} (any nbase with nbase^2 <= 64 works).
+ * slk_log_post_f32 exposes the exact log-posterior transform the decoder applies (for tests).
+ * ------------------------------------------------------------------------------------------------------- */
+#define SLK_POST_RAW 0
+#define SLK_POST_PLAIN 1
+#define SLK_POST_LOG 2
+#define SLK_POST_LN 3 /* slk_log_post_f32 only: lp = log(post), no eta (np.log(trans), sloika/transducer.py:30) */
+size_t slk_viterbi_kmer_workspace_bytes(int T, int B, int nbase, int klen);
+int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, int klen, float skip_pen, int input_mode,
+                         float min_prob, void *workspace, size_t workspace_bytes, float *score_out,
+                         int32_t *path_out, int32_t *len_out, slk_stream_t stream);
+int slk_log_post_f32(const float *post, float *lpost, size_t count, int input_mode, float min_prob,
+                     slk_stream_t stream);
+/* decode.prepare_post on its own: out = min_prob + (1-min_prob)*post (decode.py:36).                        */
+int slk_prepare_post_f32(const float *post, float *out, size_t count, float min_prob, slk_stream_t stream);
+/* decode.argmax (decode.py:5-18), batched: per (b) the states with argmax != blank, minus 1 if
+ * zero_is_blank; same output convention as slk_viterbi_kmer_f32.                                            */
+int slk_argmax_decode_f32(const float *post, int T, int B, int nstate, int zero_is_blank, int32_t *path_out,
+                          int32_t *len_out, slk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * a9. The reference's only true FFI: viterbi_helpers.slip_update (sloika/viterbi_helpers.pyx:12-35), and
+ * its caller transducer.map_to_sequence (sloika/transducer.py:14-73).
+ *   slk_slip_update_f32: x:[n] -> from_score:[n] float32, from_pos:[n] int64; n >= 3.
+ *   slk_map_to_sequence_f32: ltrans:[nev][nst] LOG-space float32, seq:[npos] int32 state indices,
+ *     prior_initial / prior_final: [npos] float64 or NULL (the reference adds float64 priors into the
+ *     float32 score vector, transducer.py:39-41,63-64); score_out:[1]; path_out:[nev] int32.
+ *     workspace >= slk_map_to_sequence_workspace_bytes(nev, npos).  npos >= 3.
+ * ------------------------------------------------------------------------------------------------------- */
+int slk_slip_update_f32(const float *x, int n, float slip, float *from_score, int64_t *from_pos,
+                        slk_stream_t stream);
+size_t slk_map_to_sequence_workspace_bytes(int nev, int npos);
+int slk_map_to_sequence_f32(const float *ltrans, int nev, int nst, const int32_t *seq, int npos, float slip,
+                            const double *prior_initial, const double *prior_final, void *workspace,
+                            size_t workspace_bytes, float *score_out, int32_t *path_out, slk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLOIKA_AMD_H */

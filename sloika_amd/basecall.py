@@ -1,0 +1,88 @@
+"""Worker-level API of the basecalling path (sloika/basecall.py), batched over chunks.
+
+    decode_post(post, kmer_len, transducer, bad, min_prob, skip, ...)   basecall.py:26-51
+    raw_chunk_worker(calc_post, chunks, ...)                            batched counterpart of raw_worker :88-121
+    SeqPrinter                                                          basecall.py:124-163
+"""
+import sys
+
+import numpy as np
+
+from . import bio, decode
+from .variables import DEFAULT_ALPHABET, nstate
+
+
+def decode_post(post, kmer_len, transducer=True, bad=True, min_prob=1e-5, skip=5.0, trans=None, nbase=4,
+                eta=1e-10):
+    """Decode Viterbi state sequence from a [T,1,nstate] posterior (basecall.py:26-51): (score, path)."""
+    if not transducer:
+        raise NotImplementedError("the non-transducer decoder (sloika/olddecode.py) is outside the accelerated "
+                                  "path; bin/basecall_network.py defaults to --transducer")
+    if post.shape[2] != nstate(kmer_len, transducer=transducer, bad_state=bad, nbase=nbase):
+        raise ValueError("posterior does not have nstate(kmer_len) states")        # basecall.py:43
+    if post.shape[1] != 1:
+        raise ValueError("decode_post takes one read: [time, 1, state] (np.squeeze(axis=1), decode.py:30)")
+    scores, paths, lens = decode.viterbi_batch(post, kmer_len, skip_pen=skip, nbase=nbase, min_prob=min_prob)
+    n = int(lens[0].item())
+    return np.float32(scores[0].item()), [int(v) for v in paths[0, :n].cpu().numpy()]
+
+
+def decode_post_batch(post, kmer_len, min_prob=1e-5, skip=5.0, nbase=4, workspace=None):
+    """Batched decode_post over the batch axis of [T,B,nstate]: device (scores[B], paths[B,T], lens[B])."""
+    return decode.viterbi_batch(post, kmer_len, skip_pen=skip, nbase=nbase, min_prob=min_prob, workspace=workspace)
+
+
+def raw_chunk_worker(calc_post, chunks, kmer_len, min_prob=1e-5, skip=5.0, nbase=4, normalisation='per-chunk',
+                     names=None):
+    """Batched counterpart of raw_worker (basecall.py:88-121) for equal-length chunks.
+
+    chunks: [nchunk, chunk_len] raw signal.  Returns a list of (name, score, call, n_samples) tuples, one per
+    chunk, in order -- the tuple the reference's worker returns per read.
+    """
+    from . import batch
+    inmat = batch.normalise_chunks(chunks, normalisation, out_layout='network')     # basecall.py:117-118
+    post = calc_post(inmat)                                                          # basecall.py:119
+    scores, paths, lens = decode_post_batch(post, kmer_len, min_prob=min_prob, skip=skip, nbase=nbase)
+    scores, paths, lens = scores.cpu().numpy(), paths.cpu().numpy(), lens.cpu().numpy()
+    res = []
+    for i in range(paths.shape[0]):
+        name = names[i] if names is not None else "chunk_%d" % i
+        res.append((name, scores[i], [int(v) for v in paths[i, : lens[i]]], int(np.shape(chunks)[1])))
+    return res
+
+
+class SeqPrinter(object):
+    """Formats fasta strings and writes them to stdout or file (basecall.py:124-163).
+
+    :param kmer_len: length of kmer to use for converting states to kmers
+    :param datatype: collective noun for data used as model input, e.g. "events" or "samples"
+    :param transducer: if True then transitions from a kmer back to itself are not allowed when converting
+        kmers to a sequence
+    :param fname: name of output file or None to use sys.stdout
+    :param alphabet: str alphabet (bin/basecall_network.py:93-94 passes a str; the bytes default of the
+        reference raises TypeError inside kmers_to_sequence, so bytes are decoded here)
+    """
+
+    def __init__(self, kmer_len, datatype="events", transducer=False, fname=None, alphabet=DEFAULT_ALPHABET):
+        if isinstance(alphabet, bytes):
+            alphabet = alphabet.decode('utf-8')
+        self.kmers = bio.all_kmers(kmer_len, alphabet=alphabet)
+        self.transducer = transducer
+        self.datatype = datatype
+        if fname is None:
+            self.fh = sys.stdout
+            self.close_fh = False
+        else:
+            self.fh = open(fname, 'w')
+            self.close_fh = True
+
+    def __del__(self):
+        if getattr(self, "close_fh", False):
+            self.fh.close()
+
+    def write(self, read_name, score, call, nev):
+        kmer_path = [self.kmers[i] for i in call]
+        seq = bio.kmers_to_sequence(kmer_path, always_move=self.transducer)
+        self.fh.write(">{} score {:.0f}, {} {} to {} bases\n".format(read_name, score, nev, self.datatype, len(seq)))
+        self.fh.write(seq + '\n')
+        return len(seq)

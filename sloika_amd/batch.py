@@ -1,0 +1,74 @@
+"""Chunk front end of the path (array maths of sloika/batch.py and sloika/tools/chunkify_raw.py), on the device.
+
+    chunkify_signal(signal, chunk_len)             cut a read into [ml, chunk_len] chunks (chunkify_raw.py:172-176)
+    normalise_chunks(chunks, 'per-chunk'|...)      median/MAD normalisation (chunkify_raw.py:178-185)
+    chunks_to_network_input(chunks)                [ml, chunk_len] -> [chunk_len, ml, 1] (bin/train_network.py:304)
+"""
+import numpy as np
+
+from . import _lib, profiler
+
+DEFAULT_NORMALISATION = 'per-read'
+AVAILABLE_NORMALISATIONS = frozenset(['none', 'per-read', 'per-chunk'])
+
+
+def chunkify_signal(signal, chunk_len):
+    """First `ml*chunk_len` samples of `signal` as [ml, chunk_len] (chunkify_raw.py:172-176)."""
+    assert len(signal) >= chunk_len
+    ml = len(signal) // chunk_len
+    return signal[: ml * chunk_len].reshape((ml, chunk_len))
+
+
+def normalise_chunks(chunks, normalisation='per-chunk', out_layout='chunk', return_stats=False):
+    """(x - median) / (1.4826 * MAD), per chunk or over the whole block ('per-read'), float32, bit-identical to
+    the reference's numpy evaluation.
+
+    chunks: [ml, chunk_len] numpy or device tensor.  out_layout 'chunk' -> [ml, chunk_len];
+    'network' -> [chunk_len, ml, 1] (what Layer.run consumes) written directly by the kernel.
+    """
+    import torch
+    from . import device as D
+    assert normalisation in AVAILABLE_NORMALISATIONS
+    cd = D.to_dev(chunks)
+    if cd.dim() != 2:
+        raise ValueError("chunks must be [nchunk, chunk_len]")
+    ml, chunk_len = cd.shape
+    if normalisation == 'none':
+        res = cd if out_layout == 'chunk' else cd.t().contiguous()[:, :, None]
+        return D.like_input(res, chunks)
+    L = _lib.lib()
+    if normalisation == 'per-read':
+        # median / MAD of the whole ml*chunk_len block (chunkify_raw.py:182-183): one "chunk" of that length
+        n_units, unit_len = 1, ml * chunk_len
+    else:
+        n_units, unit_len = ml, chunk_len
+    med = torch.empty(n_units, dtype=torch.float32, device=cd.device)
+    mad = torch.empty(n_units, dtype=torch.float32, device=cd.device)
+    with profiler.region("normalise", 0.0, 8.0 * ml * chunk_len):
+        if out_layout == 'chunk':
+            out = torch.empty((ml, chunk_len), dtype=torch.float32, device=cd.device)
+            rc = L.slk_med_mad_normalise_f32(cd.data_ptr(), n_units, unit_len, out.data_ptr(), unit_len, 1,
+                                             med.data_ptr(), mad.data_ptr(), D.stream_ptr())
+        else:
+            if normalisation == 'per-read':
+                tmp = torch.empty((ml, chunk_len), dtype=torch.float32, device=cd.device)
+                rc = L.slk_med_mad_normalise_f32(cd.data_ptr(), 1, unit_len, tmp.data_ptr(), unit_len, 1,
+                                                 med.data_ptr(), mad.data_ptr(), D.stream_ptr())
+                out = tmp.t().contiguous()[:, :, None]
+            else:
+                out = torch.empty((chunk_len, ml, 1), dtype=torch.float32, device=cd.device)
+                rc = L.slk_med_mad_normalise_f32(cd.data_ptr(), ml, chunk_len, out.data_ptr(), 1, ml,
+                                                 med.data_ptr(), mad.data_ptr(), D.stream_ptr())
+    _lib.check(rc, "normalise_chunks")
+    res = D.like_input(out, chunks)
+    if return_stats:
+        return res, D.like_input(med, chunks), D.like_input(mad, chunks)
+    return res
+
+
+def chunks_to_network_input(chunks):
+    """[ml, chunk_len] -> [chunk_len, ml, 1] (the transpose of bin/train_network.py:304)."""
+    import torch
+    if isinstance(chunks, torch.Tensor):
+        return chunks.t().contiguous()[:, :, None]
+    return np.ascontiguousarray(np.asarray(chunks).T)[:, :, None]

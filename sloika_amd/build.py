@@ -1,0 +1,72 @@
+"""Build recipe for libsloika_amd.so: every csrc/*.hip compiled for gfx950 with hipcc and linked into ONE
+C-ABI shared library kept in-tree (sloika_amd/_build/), next to the sources.
+
+    python -m sloika_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this also serves as the CPU-side "does it build" check.
+"""
+import concurrent.futures
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libsloika_amd.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
+         "-fno-fast-math"]     # IEEE divide/sqrt and no reassociation: the DP / normalisation kernels are bit-exact
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the sloika_amd HIP extension cannot be built")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "sloika_amd.h")]
+    cc = hipcc()
+    jobs = []
+    objs = []
+    for src in srcs:
+        obj = os.path.join(OUT, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([cc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        return cmd, r.returncode, r.stdout
+
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            for cmd, rc, out in ex.map(run, jobs):
+                if rc != 0:
+                    raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
+                if verbose and out.strip():
+                    print(out)
+    if jobs or force or _stale(LIB, objs):
+        cmd, rc, out = run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs)
+        if rc != 0:
+            raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), out))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,73 @@
+// common.h -- shared device helpers for the gfx950 kernels (wave = 64 lanes everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sloika_amd.h"
+
+#define SLK_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int slk_launch_status()
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SLK_OK : SLK_ERR_LAUNCH;
+}
+
+static inline hipStream_t slk_stream(slk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- activations: sloika/activation.py:8-115 ------------------------------------------------------------
+__device__ __forceinline__ float slk_clip(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+__device__ __forceinline__ float slk_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// tanh through one exp: tanh(x) = 1 - 2/(exp(2x)+1); abs error < 2e-7 over the whole range.
+__device__ __forceinline__ float slk_tanh(float x)
+{
+    float e = __expf(2.0f * x);
+    return 1.0f - 2.0f / (e + 1.0f);
+}
+
+template <int ACT>
+__device__ __forceinline__ float slk_act_t(float x)
+{
+    if constexpr (ACT == SLK_ACT_LINEAR) return x;
+    else if constexpr (ACT == SLK_ACT_TANH) return slk_tanh(x);
+    else if constexpr (ACT == SLK_ACT_SIGMOID) return slk_sigmoid(x);
+    else if constexpr (ACT == SLK_ACT_ELU) return x > 0.0f ? x : expm1f(x);
+    else if constexpr (ACT == SLK_ACT_RELU) return fmaxf(x, 0.0f);
+    else return x;
+}
+
+__device__ __forceinline__ float slk_act(int act, float x)
+{
+    switch (act) {
+    case SLK_ACT_LINEAR: return x;
+    case SLK_ACT_TANH: return slk_tanh(x);
+    case SLK_ACT_SIGMOID: return slk_sigmoid(x);
+    case SLK_ACT_ELU: return x > 0.0f ? x : expm1f(x);
+    case SLK_ACT_RELU: return fmaxf(x, 0.0f);
+    case SLK_ACT_RELU_SMOOTH: {
+        float y = slk_clip(x, 0.0f, 1.0f);
+        return y * y - 2.0f * y + x + fabsf(x);
+    }
+    case SLK_ACT_SOFTPLUS: return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+    case SLK_ACT_EXP: return expf(x);
+    case SLK_ACT_ERF: return erff(x);
+    case SLK_ACT_L1ML2: return x / sqrtf(1.0f + 0.5f * x * x);
+    case SLK_ACT_FAIR: return x / (1.0f + fabsf(x) / 1.3998f);
+    case SLK_ACT_RETU: return slk_tanh(fmaxf(x, 0.0f));
+    case SLK_ACT_TANH_PM: return slk_clip(x, -1.0f, 1.0f);
+    case SLK_ACT_SIGMOID_PM: return slk_clip(0.5f + 0.25f * x, 0.0f, 1.0f);
+    case SLK_ACT_BOUNDED_LINEAR: return slk_clip(x, -1.0f, 1.0f);
+    case SLK_ACT_SIN: return sinf(x);
+    case SLK_ACT_CAUCHY: { float u = x / 2.3849f; return x / (1.0f + u * u); }
+    case SLK_ACT_GEMAN_MCCLURE: { float u = 1.0f + x * x; return x / (u * u); }
+    case SLK_ACT_WELSH: { float u = x / 2.9846f; return x * expf(-(u * u)); }
+    default: return x;
+    }
+}
+
+static inline bool slk_act_valid(int act) { return act >= 0 && act < SLK_ACT_COUNT; }

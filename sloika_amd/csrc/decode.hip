@@ -1,0 +1,380 @@
+// decode.hip -- k-mer transducer decoding on gfx950.
+//
+//   decode.prepare_post   sloika/decode.py:21-36
+//   decode.viterbi        sloika/decode.py:39-93     (forward DP :60-82, backtrace :84-91)
+//   decode.argmax         sloika/decode.py:5-18
+//
+// This is integer/float32 max-plus dynamic programming: HBM- and latency-bound, no MFMA.  One 256-thread
+// workgroup walks one chunk through time with the score vector in LDS.  Thread j owns the `nbase` to-states
+// that share the same step predecessor set {a*nkmer/nbase + j}; the 16 (nbase^2) skip predecessors are reduced
+// in two levels (step maxima first), which preserves numpy's first-maximum tie-breaking because the combined
+// key (value desc, a*nbase+b asc) is what np.argmax over the reshaped (nbase^2, nkmer/nbase^2) view selects.
+// Float arithmetic is max / add / sub in float32 only (no contraction possible), so scores are bit-identical
+// to numpy's given the same log-posteriors.  The traceback is stored as ONE BYTE per (t, state):
+//   0..nbase-1 = step from a, nbase..nbase+nbase^2-1 = skip from ab, 255 = stay    (reference: int32 from-state)
+// and walked by a second kernel that stages 64 KB time-blocks of it in LDS.
+#include "common.h"
+
+#define VIT_ETA 1e-10f
+#define VIT_STAY 255
+
+// exact restatement of numpy's float32 evaluation; __fmul_rn/__fadd_rn stop hipcc fusing the pair into an fma
+__device__ __forceinline__ float prepare_post_val(float p, float min_prob, float one_m)
+{
+    return __fadd_rn(min_prob, __fmul_rn(one_m, p));       // decode.py:36
+}
+
+__device__ __forceinline__ float log_post_val(float p, int mode, float min_prob, float one_m)
+{
+    if (mode == SLK_POST_LOG) return p;
+    if (mode == SLK_POST_LN) return logf(p);               // transducer.py:30
+    if (mode == SLK_POST_RAW) p = prepare_post_val(p, min_prob, one_m);
+    return logf(__fadd_rn(p, VIT_ETA));                    // decode.py:56
+}
+
+__global__ void log_post_kernel(const float *__restrict__ post, float *__restrict__ lpost, size_t count, int mode,
+                                float min_prob, float one_m)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        lpost[i] = log_post_val(post[i], mode, min_prob, one_m);
+}
+
+__global__ void prepare_post_kernel(const float *__restrict__ post, float *__restrict__ out, size_t count,
+                                    float min_prob, float one_m)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = prepare_post_val(post[i], min_prob, one_m);
+}
+
+static inline unsigned grid_for(size_t count)
+{
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    return (unsigned)(blocks ? blocks : 1);
+}
+
+// (1.0 - min_prob) is evaluated in double by the reference and THEN cast to float32 (decode.py:36)
+static inline float one_minus(float min_prob_f, double min_prob_d) { (void)min_prob_f; return (float)(1.0 - min_prob_d); }
+
+extern "C" int slk_log_post_f32(const float *post, float *lpost, size_t count, int input_mode, float min_prob,
+                                slk_stream_t stream)
+{
+    if (!post || !lpost || input_mode < 0 || input_mode > SLK_POST_LN) return SLK_ERR_INVALID_ARG;
+    if (!count) return SLK_OK;
+    hipLaunchKernelGGL(log_post_kernel, dim3(grid_for(count)), dim3(256), 0, slk_stream(stream), post, lpost, count,
+                       input_mode, min_prob, one_minus(min_prob, (double)min_prob));
+    return slk_launch_status();
+}
+
+extern "C" int slk_prepare_post_f32(const float *post, float *out, size_t count, float min_prob, slk_stream_t stream)
+{
+    if (!post || !out) return SLK_ERR_INVALID_ARG;
+    if (!count) return SLK_OK;
+    hipLaunchKernelGGL(prepare_post_kernel, dim3(grid_for(count)), dim3(256), 0, slk_stream(stream), post, out, count,
+                       min_prob, one_minus(min_prob, (double)min_prob));
+    return slk_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward DP
+// ------------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__restrict__ post, int T, int B,
+                                                               int nkmer, float skip_pen, int mode, float min_prob,
+                                                               float one_m, uint8_t *__restrict__ tb,
+                                                               int32_t *__restrict__ best_out,
+                                                               float *__restrict__ score_out)
+{
+    constexpr int NB2 = NB * NB;
+    extern __shared__ float sm[];
+    const int nrem1 = nkmer / NB, nrem2 = nkmer / NB2;
+    float *v = sm;                                             // [nkmer] scores of the previous step
+    float *stepmax = sm + nkmer;                               // [nrem1]
+    int *steparg = reinterpret_cast<int *>(stepmax + nrem1);   // [nrem1]
+    float *redv = reinterpret_cast<float *>(steparg + nrem1);  // [16]
+    int *redi = reinterpret_cast<int *>(redv + 16);            // [16]
+    const int b = blockIdx.x, j = threadIdx.x;                 // thread j owns to-states j*NB .. j*NB+NB-1
+    const bool active = j < nrem1;
+    const int jj = active ? j : 0, j2 = jj / NB;
+    const int nst = nkmer + 1;
+    const float *pb = post + (size_t)b * nst;
+    const size_t tstride = (size_t)B * nst;
+    uint8_t *tbb = tb + (size_t)b * T * nkmer;
+
+    // t = 0: v = lpost[0][1:]   (decode.py:57)
+    float raw[NB], raw0;
+#pragma unroll
+    for (int c = 0; c < NB; c++) raw[c] = pb[1 + jj * NB + c];
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) v[jj * NB + c] = log_post_val(raw[c], mode, min_prob, one_m);
+    }
+    if (T > 1) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) raw[c] = pb[tstride + 1 + jj * NB + c];
+        raw0 = pb[tstride];
+    }
+    __syncthreads();
+
+    for (int t = 1; t < T; t++) {
+        // prefetch the next row one full step ahead of its use
+        float nxt[NB], nxt0 = 0.0f;
+        if (t + 1 < T) {
+            const float *pn = pb + (size_t)(t + 1) * tstride;
+#pragma unroll
+            for (int c = 0; c < NB; c++) nxt[c] = pn[1 + jj * NB + c];
+            nxt0 = pn[0];
+        }
+        // ---- step maximum over a (first max wins: np.argmax, decode.py:67-68) ----
+        float sstep = v[jj];
+        int sarg = 0;
+#pragma unroll
+        for (int a = 1; a < NB; a++) {
+            float c = v[a * nrem1 + jj];
+            if (c > sstep) { sstep = c; sarg = a; }
+        }
+        if (active) { stepmax[jj] = sstep; steparg[jj] = sarg; }
+        float lp[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) lp[c] = log_post_val(raw[c], mode, min_prob, one_m);
+        const float lp0 = log_post_val(raw0, mode, min_prob, one_m);
+        __syncthreads();
+        // ---- skip maximum over ab = a*NB + b (first max in ab order wins, decode.py:72-73) ----
+        float kbest = stepmax[j2];
+        int karg = steparg[j2] * NB;
+#pragma unroll
+        for (int bb = 1; bb < NB; bb++) {
+            float c = stepmax[bb * nrem2 + j2];
+            int key = steparg[bb * nrem2 + j2] * NB + bb;
+            if (c > kbest || (c == kbest && key < karg)) { kbest = c; karg = key; }
+        }
+        const float sskip = kbest - skip_pen;                       // decode.py:72
+        const float mx = fmaxf(sstep, sskip);
+        const int code = sstep > sskip ? sarg : NB + karg;          // decode.py:76 (tie -> skip)
+        if (active) {
+            uint8_t codes[NB];
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                const int s = jj * NB + c;
+                const float nv = lp[c] + mx;                        // decode.py:75
+                const float stay = v[s] + lp0;                      // decode.py:80
+                const bool move = nv > stay;                        // decode.py:81 (tie -> stay)
+                codes[c] = move ? (uint8_t)code : (uint8_t)VIT_STAY;
+                v[s] = move ? nv : stay;
+            }
+            uint8_t *dst = tbb + (size_t)t * nkmer + (size_t)jj * NB;
+            if constexpr (NB == 4) {
+                *reinterpret_cast<uint32_t *>(dst) = (uint32_t)codes[0] | ((uint32_t)codes[1] << 8) |
+                                                     ((uint32_t)codes[2] << 16) | ((uint32_t)codes[3] << 24);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NB; c++) dst[c] = codes[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NB; c++) raw[c] = nxt[c];
+        raw0 = nxt0;
+        __syncthreads();
+    }
+    // ---- first argmax of v (np.argmax, decode.py:85) ----
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < NB; c++) {
+            float x = v[jj * NB + c];
+            if (x > bv) { bv = x; bi = jj * NB + c; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(bv, o);
+        int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { redv[threadIdx.x >> 6] = bv; redi[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int w = 1; w < nw; w++)
+            if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
+        score_out[b] = bv;
+        best_out[b] = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backtrace: stage time-blocks of the byte traceback in LDS, one lane walks them; emit right-aligned, then
+// the whole workgroup shifts the path left and pads with -1.
+// ------------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *__restrict__ tb,
+                                                                const int32_t *__restrict__ best, int T, int nkmer,
+                                                                int tblk, int32_t *__restrict__ path_out,
+                                                                int32_t *__restrict__ len_out)
+{
+    constexpr int NB2 = NB * NB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t blk[];   // [tblk*nkmer] bytes + 2 ints
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int nrem1 = nkmer / NB, nrem2 = nkmer / NB2;
+    int &sh_cur = reinterpret_cast<int *>(blk + (((size_t)tblk * nkmer + 15) & ~(size_t)15))[0];
+    int &sh_pos = reinterpret_cast<int *>(blk + (((size_t)tblk * nkmer + 15) & ~(size_t)15))[1];
+    const uint8_t *tbb = tb + (size_t)b * T * nkmer;
+    int32_t *path = path_out + (size_t)b * T;
+    if (tid == 0) {
+        sh_cur = best[b];
+        sh_pos = T - 1;
+        path[T - 1] = sh_cur;
+    }
+    __syncthreads();
+    for (int t1 = T; t1 > 1; t1 -= tblk) {
+        const int t0 = max(1, t1 - tblk);                   // rows [t0, t1)
+        const size_t nbytes = (size_t)(t1 - t0) * nkmer;
+        const uint8_t *src = tbb + (size_t)t0 * nkmer;
+        if ((nbytes & 15) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+            uint4 *d4 = reinterpret_cast<uint4 *>(blk);
+            for (size_t i = tid; i < nbytes / 16; i += nt) d4[i] = s4[i];
+        } else {
+            for (size_t i = tid; i < nbytes; i += nt) blk[i] = src[i];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cur = sh_cur, pos = sh_pos;
+            for (int t = t1 - 1; t >= t0; t--) {
+                int code = blk[(size_t)(t - t0) * nkmer + cur];
+                if (code != VIT_STAY) {
+                    cur = code < NB ? code * nrem1 + cur / NB : (code - NB) * nrem2 + cur / NB2;
+                    path[--pos] = cur;                       // decode.py:88-90
+                }
+            }
+            sh_cur = cur;
+            sh_pos = pos;
+        }
+        __syncthreads();
+    }
+    // shift left by pos (dst < src, ascending blocks with a barrier between read and write are safe)
+    const int pos = sh_pos, len = T - pos;
+    __threadfence_block();
+    __syncthreads();
+    for (int base = 0; base < T; base += nt) {
+        int i = base + tid;
+        int32_t val = (i < len) ? path[pos + i] : -1;
+        __syncthreads();
+        if (i < T) path[i] = val;
+        __syncthreads();
+    }
+    if (tid == 0) len_out[b] = len;
+}
+
+static bool vit_dims(int nbase, int klen, int *nkmer_out)
+{
+    if (klen < 3 || nbase < 2) return false;
+    long nk = 1;
+    for (int i = 0; i < klen; i++) {
+        nk *= nbase;
+        if (nk > 4096) return false;     // one thread per step-predecessor group, <= 1024 threads
+    }
+    *nkmer_out = (int)nk;
+    return true;
+}
+
+extern "C" size_t slk_viterbi_kmer_workspace_bytes(int T, int B, int nbase, int klen)
+{
+    int nkmer;
+    if (T < 1 || B < 1 || !vit_dims(nbase, klen, &nkmer)) return 0;
+    size_t tb = ((size_t)B * T * nkmer + 255) & ~(size_t)255;
+    return tb + sizeof(int32_t) * (size_t)B + 256;
+}
+
+template <int NB>
+static int launch_viterbi(const float *post, int T, int B, int klen, int nkmer, float skip_pen, int mode, float min_prob,
+                          uint8_t *tb, int32_t *best, float *score_out, int32_t *path_out, int32_t *len_out,
+                          hipStream_t s)
+{
+    int nrem1 = nkmer / NB;
+    int threads = nrem1 < 64 ? 64 : (nrem1 > 1024 ? 1024 : ((nrem1 + 63) / 64) * 64);
+    if (nrem1 > 1024) return SLK_ERR_UNSUPPORTED;
+    size_t lds = sizeof(float) * ((size_t)nkmer + nrem1 + 16) + sizeof(int) * ((size_t)nrem1 + 16);
+    float one_m = (float)(1.0 - (double)min_prob);
+    hipLaunchKernelGGL((viterbi_forward_kernel<NB>), dim3(B), dim3(threads), lds, s, post, T, B, nkmer, skip_pen,
+                       mode, min_prob, one_m, tb, best, score_out);
+    int rc = slk_launch_status();
+    if (rc != SLK_OK) return rc;
+    int tblk = (64 * 1024) / nkmer;
+    if (tblk < 1) tblk = 1;
+    if (tblk > T) tblk = T;
+    hipLaunchKernelGGL((viterbi_backtrace_kernel<NB>), dim3(B), dim3(256), (((size_t)tblk * nkmer + 15) & ~(size_t)15) + 16, s, tb, best, T, nkmer,
+                       tblk, path_out, len_out);
+    return slk_launch_status();
+}
+
+extern "C" int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, int klen, float skip_pen,
+                                    int input_mode, float min_prob, void *workspace, size_t workspace_bytes,
+                                    float *score_out, int32_t *path_out, int32_t *len_out, slk_stream_t stream)
+{
+    int nkmer;
+    if (!post || !score_out || !path_out || !len_out || T < 1 || B < 1 || input_mode < 0 || input_mode > 2)
+        return SLK_ERR_INVALID_ARG;
+    if (!vit_dims(nbase, klen, &nkmer)) return SLK_ERR_INVALID_ARG;      // decode.py:50
+    size_t need = slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen);
+    if (!workspace || workspace_bytes < need) return SLK_ERR_WORKSPACE;
+    uint8_t *tb = static_cast<uint8_t *>(workspace);
+    size_t tbbytes = ((size_t)B * T * nkmer + 255) & ~(size_t)255;
+    int32_t *best = reinterpret_cast<int32_t *>(tb + tbbytes);
+    hipStream_t s = slk_stream(stream);
+    switch (nbase) {
+    case 4: return launch_viterbi<4>(post, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
+    case 5: return launch_viterbi<5>(post, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
+    default: return SLK_ERR_UNSUPPORTED;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// decode.argmax (decode.py:5-18), batched: one workgroup per chunk, wave-parallel row argmax.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) argmax_decode_kernel(const float *__restrict__ post, int T, int B, int nst,
+                                                            int zero_is_blank, int32_t *__restrict__ path_out,
+                                                            int32_t *__restrict__ len_out)
+{
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    int32_t *path = path_out + (size_t)b * T;
+    const int blank = zero_is_blank ? 0 : nst - 1;
+    // pass 1: per-time argmax (first max) written to path[t]
+    for (int t = wave; t < T; t += nw) {
+        const float *p = post + ((size_t)t * B + b) * nst;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int s = lane; s < nst; s += 64) {
+            float c = p[s];
+            if (c > bv) { bv = c; bi = s; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(bv, o);
+            int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) path[t] = bi;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // pass 2: compaction by one lane (T is small)
+    if (tid == 0) {
+        int n = 0;
+        for (int t = 0; t < T; t++) {
+            int s = path[t];
+            if (s != blank) path[n++] = zero_is_blank ? s - 1 : s;
+        }
+        for (int t = n; t < T; t++) path[t] = -1;
+        len_out[b] = n;
+    }
+}
+
+extern "C" int slk_argmax_decode_f32(const float *post, int T, int B, int nstate, int zero_is_blank, int32_t *path_out,
+                                     int32_t *len_out, slk_stream_t stream)
+{
+    if (!post || !path_out || !len_out || T < 1 || B < 1 || nstate < 1) return SLK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(argmax_decode_kernel, dim3(B), dim3(256), 0, slk_stream(stream), post, T, B, nstate,
+                       zero_is_blank, path_out, len_out);
+    return slk_launch_status();
+}

@@ -1,0 +1,238 @@
+// gemm.hip -- time-parallel contractions of the network on gfx950 fp32 MFMA:
+//   y = act(x . W^T + b)     FeedForward.run sloika/layers.py:157-158, the input projections of Gru.step /
+//                            Lstm.step (layers.py:1011, :678) hoisted over all T*B rows, Softmax.run's tensordot
+//                            (layers.py:310)
+//   row softmax              layers.py:311-314
+//
+// v_mfma_f32_32x32x2_f32 is exact fp32 (a k-ordered fmaf chain), which is what the 1e-4 layer parity needs;
+// there is no TF32-like path on gfx950.  Tile: 128 rows x (32*NT) columns per 256-thread workgroup, each of the
+// 4 waves owns 32 rows x 32*NT columns (NT accumulators of 16 VGPRs), K staged through LDS in slabs of 32.
+// LDS rows are padded to 36 floats so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte slots.
+// The contraction index is permuted (lane half h takes k = 16h + s) so each lane reads 4 consecutive k per
+// ds_read_b128; A and B use the same permutation, so the sum is unchanged.
+#include "common.h"
+
+#define GEMM_BM 128
+#define GEMM_BK 32
+#define GEMM_LDS_LD 36
+
+template <int NT, bool ALIGNED>
+__global__ void __launch_bounds__(256) gemm_bias_act_kernel(const float *__restrict__ x, long ldx,
+                                                            const float *__restrict__ W,
+                                                            const float *__restrict__ bias, float *__restrict__ y,
+                                                            long ldy, long M, int K, int N, int act, int ntile_n)
+{
+    constexpr int BN = 32 * NT;
+    __shared__ __attribute__((aligned(16))) float xs[GEMM_BM * GEMM_LDS_LD];
+    __shared__ __attribute__((aligned(16))) float ws[BN * GEMM_LDS_LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const long bid = blockIdx.x;
+    const long m0 = (bid / ntile_n) * GEMM_BM;
+    const int n0 = (int)(bid % ntile_n) * BN;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
+
+    for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
+        // ---- stage x[128][32] and W[BN][32] slabs (zero filled outside M/N/K) ----
+#pragma unroll
+        for (int i = 0; i < (GEMM_BM * GEMM_BK / 4) / 256; i++) {
+            int idx = tid + 256 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            long gr = m0 + row;
+            int gk = k0 + c4;
+            if (gr < M) {
+                const float *p = x + gr * ldx + gk;
+                if (ALIGNED && gk + 3 < K) v = *reinterpret_cast<const float4 *>(p);
+                else {
+                    if (gk < K) v.x = p[0];
+                    if (gk + 1 < K) v.y = p[1];
+                    if (gk + 2 < K) v.z = p[2];
+                    if (gk + 3 < K) v.w = p[3];
+                }
+            }
+            *reinterpret_cast<float4 *>(&xs[row * GEMM_LDS_LD + c4]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < (BN * GEMM_BK / 4 + 255) / 256; i++) {
+            int idx = tid + 256 * i;
+            if (idx < BN * GEMM_BK / 4) {
+                int row = idx >> 3, c4 = (idx & 7) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                int gn = n0 + row, gk = k0 + c4;
+                if (gn < N) {
+                    const float *p = W + (size_t)gn * K + gk;
+                    if (ALIGNED && gk + 3 < K) v = *reinterpret_cast<const float4 *>(p);
+                    else {
+                        if (gk < K) v.x = p[0];
+                        if (gk + 1 < K) v.y = p[1];
+                        if (gk + 2 < K) v.z = p[2];
+                        if (gk + 3 < K) v.w = p[3];
+                    }
+                }
+                *reinterpret_cast<float4 *>(&ws[row * GEMM_LDS_LD + c4]) = v;
+            }
+        }
+        __syncthreads();
+        // ---- 16 k-steps of 32x32x2 per accumulator ----
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float4 a4 = *reinterpret_cast<const float4 *>(&xs[(32 * wave + r) * GEMM_LDS_LD + h * 16 + 4 * q]);
+            float4 b4[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++)
+                b4[nt] = *reinterpret_cast<const float4 *>(&ws[(32 * nt + r) * GEMM_LDS_LD + h * 16 + 4 * q]);
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[nt].x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[nt].y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[nt].z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[nt].w, acc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*h][col = lane&31] ----
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        int col = n0 + 32 * nt + r;
+        if (col >= N) continue;
+        float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            long row = m0 + 32 * wave + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (row < M) y[row * ldy + col] = slk_act(act, acc[nt][reg] + bv);
+        }
+    }
+}
+
+template <int NT>
+static int launch_gemm(const float *x, long ldx, const float *W, const float *bias, float *y, long ldy, long M, int K,
+                       int N, int act, hipStream_t s)
+{
+    int ntile_n = (N + 32 * NT - 1) / (32 * NT);
+    long ntile_m = (M + GEMM_BM - 1) / GEMM_BM;
+    long blocks = ntile_m * ntile_n;
+    if (blocks > 0x7fffffffL) return SLK_ERR_UNSUPPORTED;
+    bool aligned = (ldx % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
+    if (aligned)
+        hipLaunchKernelGGL((gemm_bias_act_kernel<NT, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, W, bias, y,
+                           ldy, M, K, N, act, ntile_n);
+    else
+        hipLaunchKernelGGL((gemm_bias_act_kernel<NT, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, W, bias,
+                           y, ldy, M, K, N, act, ntile_n);
+    return slk_launch_status();
+}
+
+extern "C" int slk_gemm_bias_act_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long ldy,
+                                     long M, int K, int N, int act, slk_stream_t stream)
+{
+    if (!x || !W || !y || M < 0 || K < 1 || N < 1 || ldx < K || ldy < N || !slk_act_valid(act)) return SLK_ERR_INVALID_ARG;
+    if (M == 0) return SLK_OK;
+    // pick the column-tile count that wastes the fewest MFMA columns (ties -> wider tile)
+    int best = 3, best_cost = 1 << 30;
+    for (int nt = 3; nt >= 1; nt--) {
+        int cost = ((N + 32 * nt - 1) / (32 * nt)) * nt;
+        if (cost < best_cost) { best_cost = cost; best = nt; }
+    }
+    hipStream_t s = slk_stream(stream);
+    switch (best) {
+    case 1: return launch_gemm<1>(x, ldx, W, bias, y, ldy, M, K, N, act, s);
+    case 2: return launch_gemm<2>(x, ldx, W, bias, y, ldy, M, K, N, act, s);
+    default: return launch_gemm<3>(x, ldx, W, bias, y, ldy, M, K, N, act, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Row softmax, one wave per row, the row held in registers (N <= 64*MAXE) or re-read (generic).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int MAXE>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float *__restrict__ y, long M, int N)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwave = (long)gridDim.x * (blockDim.x >> 6);
+    for (long row = wave0; row < M; row += nwave) {
+        float *p = y + row * N;
+        float v[MAXE];
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < MAXE; e++) {
+            int j = lane + 64 * e;
+            v[e] = j < N ? p[j] : -INFINITY;
+            m = fmaxf(m, v[e]);
+        }
+        m = wave_max(m);
+        float s = 0.0f;
+#pragma unroll
+        for (int e = 0; e < MAXE; e++) {
+            v[e] = __expf(v[e] - m);
+            s += v[e];
+        }
+        s = wave_sum(s);
+#pragma unroll
+        for (int e = 0; e < MAXE; e++) {
+            int j = lane + 64 * e;
+            if (j < N) p[j] = v[e] / s;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) softmax_rows_generic_kernel(float *__restrict__ y, long M, int N)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nwave = (long)gridDim.x * (blockDim.x >> 6);
+    for (long row = wave0; row < M; row += nwave) {
+        float *p = y + row * N;
+        float m = -INFINITY;
+        for (int j = lane; j < N; j += 64) m = fmaxf(m, p[j]);
+        m = wave_max(m);
+        float s = 0.0f;
+        for (int j = lane; j < N; j += 64) {
+            float e = __expf(p[j] - m);
+            p[j] = e;
+            s += e;
+        }
+        s = wave_sum(s);
+        for (int j = lane; j < N; j += 64) p[j] = p[j] / s;
+    }
+}
+
+extern "C" int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream)
+{
+    if (!y || M < 0 || N < 1) return SLK_ERR_INVALID_ARG;
+    if (M == 0) return SLK_OK;
+    long blocks = (M + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t s = slk_stream(stream);
+    if (N <= 64 * 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, y, M, N);
+    else if (N <= 64 * 17) hipLaunchKernelGGL(softmax_rows_kernel<17>, dim3((unsigned)blocks), dim3(256), 0, s, y, M, N);
+    else hipLaunchKernelGGL(softmax_rows_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, M, N);
+    return slk_launch_status();
+}
+
+extern "C" int slk_linear_softmax_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long M,
+                                      int K, int N, slk_stream_t stream)
+{
+    int rc = slk_gemm_bias_act_f32(x, ldx, W, bias, y, N, M, K, N, SLK_ACT_LINEAR, stream);
+    if (rc != SLK_OK) return rc;
+    return slk_softmax_rows_f32(y, M, N, stream);
+}

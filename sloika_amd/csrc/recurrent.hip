@@ -1,0 +1,378 @@
+// recurrent.hip -- the sequential part of Gru / Lstm on gfx950.
+//
+//   Gru.step   sloika/layers.py:1010-1021   (original Cho-style GRU: reset applied BEFORE the recurrent matmul,
+//                                            no recurrent bias -- not the cuDNN/MIOpen variant)
+//   Lstm.step  sloika/layers.py:677-691     (peepholes, interleaved gate layout row = j*4+g)
+//   RNN.run    sloika/layers.py:85-88       (zero initial state, scan over time)
+//   Reverse    sloika/layers.py:1449-1450   (time order flag instead of flipping tensors)
+//
+// Fast path (gru_mfma_kernel): one 256-thread workgroup per tile of 4 chunks, persistent over all T steps.
+//   * The hidden-to-hidden weights live in VGPRs for the whole scan (n/SA + n/SB registers per lane).
+//   * Contractions use v_mfma_f32_4x4x1_16b_f32: 16 independent 4x4 outer products per instruction.
+//       A operand = state h[k][chunk 0..3]   (4 values, broadcast to every block with CBSZ/ABID)
+//       B operand = weights W[out(lane)][k]  (one output neuron per lane)
+//       D[vgpr i][lane] += h[k][chunk i] * W[out(lane)][k]
+//     i.e. a 64-outputs x 4-chunks x 1-k rank-1 update in 8 cycles, exact fp32 (fmaf chain), at the full fp32
+//     matrix rate with a batch tile of only 4 -- which is what lets B=1024 chunks fill all 256 CUs.
+//   * Wave w owns neurons [w*n/4, (w+1)*n/4).  Phase A computes its z|r pre-activations, phase B its candidate.
+//     When the outputs of a phase fill only part of the 64 lanes, the spare lanes take another K-slice of the
+//     same outputs (CBSZ picks one h value per 32/16-lane group) and the slices are summed with two shuffles.
+//   * h and r*h are exchanged between the 4 waves through 2 x n x 16 B of LDS; the packed A-operand image
+//     (lane = 4*block + chunk) is read back with lane-linear, conflict-free ds_read_b32.
+//   * two s_barrier per step; the next step's input projection vI is prefetched a full step ahead.
+//
+// Portable path (gru_generic_kernel / lstm_generic_kernel): one workgroup per chunk, weights streamed from L2,
+// any n and any activation; used for layer sizes the MFMA kernel is not instantiated for.
+#include <utility>
+
+#include "common.h"
+
+// =====================================================================================================
+// generic GRU
+// =====================================================================================================
+__global__ void __launch_bounds__(256) gru_generic_kernel(const float *__restrict__ vI, const float *__restrict__ sW,
+                                                          const float *__restrict__ sW2, float *__restrict__ h_out,
+                                                          long ldh, int T, int B, int n, int reverse, int act,
+                                                          int gate_act)
+{
+    extern __shared__ float sm[];
+    float *h = sm, *rh = sm + n, *z = sm + 2 * n;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    for (int j = tid; j < n; j += nt) h[j] = 0.0f;
+    __syncthreads();
+    for (int s = 0; s < T; s++) {
+        const int t = reverse ? T - 1 - s : s;
+        const float *vt = vI + ((size_t)t * B + b) * 3 * n;
+        for (int o = tid; o < 2 * n; o += nt) {
+            const float *w = sW + (size_t)o * n;
+            float v = vt[o];
+            for (int k = 0; k < n; k++) v = fmaf(h[k], w[k], v);
+            float g = slk_act(gate_act, v);
+            if (o < n) z[o] = g;
+            else rh[o - n] = g * h[o - n];
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += nt) {
+            const float *w = sW2 + (size_t)j * n;
+            float v = vt[2 * n + j];
+            for (int k = 0; k < n; k++) v = fmaf(rh[k], w[k], v);
+            float hbar = slk_act(act, v);
+            float hn = z[j] * h[j] + (1.0f - z[j]) * hbar;
+            h[j] = hn;
+            h_out[((size_t)t * B + b) * ldh + j] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+// =====================================================================================================
+// generic LSTM
+// =====================================================================================================
+__global__ void __launch_bounds__(256) lstm_generic_kernel(const float *__restrict__ vW, const float *__restrict__ sW,
+                                                           const float *__restrict__ p, float *__restrict__ out,
+                                                           long ldo, int T, int B, int n, int reverse, int act,
+                                                           int gate_act)
+{
+    extern __shared__ float sm[];
+    float *o_prev = sm, *cell = sm + n, *sum = sm + 2 * n; // sum: [n][4]
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    for (int j = tid; j < n; j += nt) { o_prev[j] = 0.0f; cell[j] = 0.0f; }
+    __syncthreads();
+    for (int s = 0; s < T; s++) {
+        const int t = reverse ? T - 1 - s : s;
+        const float *vt = vW + ((size_t)t * B + b) * 4 * n;
+        for (int r = tid; r < 4 * n; r += nt) {
+            const float *w = sW + (size_t)r * n;
+            float v = vt[r];
+            for (int k = 0; k < n; k++) v = fmaf(o_prev[k], w[k], v);
+            sum[r] = v;
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += nt) {
+            float st = cell[j];
+            float p0 = p ? p[j] : 0.0f, p1 = p ? p[n + j] : 0.0f, p2 = p ? p[2 * n + j] : 0.0f;
+            float os = st * slk_act(gate_act, sum[j * 4 + 2] + st * p1);                 // forget   layers.py:686
+            os += slk_act(act, sum[j * 4 + 0]) * slk_act(gate_act, sum[j * 4 + 1] + st * p0); // update layers.py:688
+            float o = slk_act(act, os) * slk_act(gate_act, sum[j * 4 + 3] + os * p2);    // output   layers.py:690
+            cell[j] = os;
+            o_prev[j] = o;
+            out[((size_t)t * B + b) * ldo + j] = o;
+        }
+        __syncthreads();
+    }
+}
+
+// =====================================================================================================
+// MFMA GRU
+// =====================================================================================================
+template <int CB, int AB>
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, CB, AB, 0);
+}
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
+// acc0/acc1 alternate so that consecutive MFMAs never depend on each other.
+template <int CB, int G, int... Is>
+__device__ __forceinline__ void mfma_chain(const float *hp, const float *w, f32x4 &acc0, f32x4 &acc1,
+                                           std::integer_sequence<int, Is...>)
+{
+    (((Is & 1) ? (void)(acc1 = mfma4<CB, Is % G>(hp[Is / G], w[Is], acc1))
+               : (void)(acc0 = mfma4<CB, Is % G>(hp[Is / G], w[Is], acc0))),
+     ...);
+}
+
+template <int S>
+__device__ __forceinline__ f32x4 sum_slices(f32x4 v)
+{
+    if constexpr (S >= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] += __shfl_xor(v[i], 16);
+    }
+    if constexpr (S >= 2) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] += __shfl_xor(v[i], 32);
+    }
+    return v;
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_sel(int act, float x)
+{
+    if constexpr (ACT >= 0) return slk_act_t<ACT>(x);
+    else return slk_act(act, x);
+}
+
+// N: layer size (multiple of 16, <= 128).  ACT/GACT: compile-time activation ids, or -1 to use the runtime ids.
+template <int N, int ACT, int GACT>
+__global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restrict__ vI, const float *__restrict__ sW,
+                                                          const float *__restrict__ sW2, float *__restrict__ h_out,
+                                                          long ldh, int T, int B, int reverse, int act, int gate_act)
+{
+    constexpr int NW = N / 4;                                      // neurons per wave
+    constexpr int SA = (2 * NW <= 16) ? 4 : ((2 * NW <= 32) ? 2 : 1); // K-slices, phase A (z|r: 2*NW outputs)
+    constexpr int SB = (NW <= 16) ? 4 : ((NW <= 32) ? 2 : 1);       // K-slices, phase B (NW outputs)
+    constexpr int LPA = 64 / SA, LPB = 64 / SB;                     // lanes per slice
+    constexpr int MA = N / SA, MB = N / SB;                         // MFMAs per phase
+    constexpr int GA = 16 / SA, GB = 16 / SB;                       // blocks per broadcast group
+    constexpr int CBA = 4 - ilog2(SA), CBB = 4 - ilog2(SB);
+    constexpr int NV = N / 16;                                      // packed state registers
+    static_assert(N % 16 == 0 && N <= 128, "unsupported GRU size for the MFMA kernel");
+
+    __shared__ __attribute__((aligned(16))) float hbuf[N * 4];   // h[k][chunk]
+    __shared__ __attribute__((aligned(16))) float rhbuf[N * 4];  // (r*h)[k][chunk]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b0 = blockIdx.x * 4;
+    const int blk = lane >> 2, ci = lane & 3;
+
+    // ---- lane roles ----
+    const int la = lane % LPA, ga = lane / LPA;
+    const bool validA = la < 2 * NW;
+    const bool isR = la >= NW;
+    const int neuronA = wave * NW + (validA ? (la % NW) : 0);
+    const int rowA = isR ? N + neuronA : neuronA;
+    const int lb = lane % LPB, gb = lane / LPB;
+    const bool validB = lb < NW;
+    const int neuronB = wave * NW + (validB ? lb : 0);
+    const bool zlane = lane < NW;                 // holds z, c and the new h of neuron wave*NW + lane
+    const bool rlane = lane >= NW && lane < 2 * NW;
+
+    // ---- weights -> registers (B operands) ----
+    float wA[MA], wB[MB];
+    {
+        const float *pa = sW + (size_t)rowA * N + ga * MA;
+#pragma unroll
+        for (int m = 0; m < MA; m++) wA[m] = validA ? pa[m] : 0.0f;
+        const float *pb = sW2 + (size_t)neuronB * N + gb * MB;
+#pragma unroll
+        for (int m = 0; m < MB; m++) wB[m] = validB ? pb[m] : 0.0f;
+    }
+
+    // packed-operand read addresses (floats): 4*(g*(N/S) + v*G + q) + chunk
+    const int addrA0 = 4 * ((blk / GA) * MA + (blk % GA)) + ci;
+    const int addrB0 = 4 * ((blk / GB) * MB + (blk % GB)) + ci;
+
+    for (int i = tid; i < N * 4; i += 256) hbuf[i] = 0.0f;
+
+    // chunk rows (clamped for a ragged last tile)
+    int bi[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) bi[i] = min(b0 + i, B - 1);
+
+    auto load_vI = [&](int t, float (&zr)[4], float (&c)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float *row = vI + ((size_t)t * B + bi[i]) * (3 * N);
+            zr[i] = (validA && ga == 0) ? row[rowA] : 0.0f;
+            c[i] = zlane ? row[2 * N + neuronB] : 0.0f;
+        }
+    };
+
+    float cur_zr[4], cur_c[4], nxt_zr[4], nxt_c[4];
+    load_vI(reverse ? T - 1 : 0, cur_zr, cur_c);
+    __syncthreads();
+
+    for (int s = 0; s < T; s++) {
+        const int t = reverse ? T - 1 - s : s;
+        if (s + 1 < T) load_vI(reverse ? t - 1 : t + 1, nxt_zr, nxt_c);
+
+        // ---------------- phase A: z | r ----------------
+        float hp[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) hp[v] = hbuf[addrA0 + 4 * v * GA];
+        const f32x4 hown = *reinterpret_cast<const f32x4 *>(&hbuf[4 * neuronA]);
+        f32x4 a0 = {cur_zr[0], cur_zr[1], cur_zr[2], cur_zr[3]}, a1 = {0.f, 0.f, 0.f, 0.f};
+        mfma_chain<CBA, GA>(hp, wA, a0, a1, std::make_integer_sequence<int, MA>{});
+        f32x4 g = sum_slices<SA>(a0 + a1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) g[i] = act_sel<GACT>(gate_act, g[i]);
+        if (rlane) *reinterpret_cast<f32x4 *>(&rhbuf[4 * neuronA]) = g * hown;
+        __syncthreads();
+
+        // ---------------- phase B: candidate ----------------
+        float rp[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) rp[v] = rhbuf[addrB0 + 4 * v * GB];
+        f32x4 c0 = {cur_c[0], cur_c[1], cur_c[2], cur_c[3]}, c1 = {0.f, 0.f, 0.f, 0.f};
+        mfma_chain<CBB, GB>(rp, wB, c0, c1, std::make_integer_sequence<int, MB>{});
+        f32x4 cc = sum_slices<SB>(c0 + c1);
+        if (zlane) {
+            f32x4 hn;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float hbar = act_sel<ACT>(act, cc[i]);
+                hn[i] = g[i] * hown[i] + (1.0f - g[i]) * hbar;      // layers.py:1020
+            }
+            *reinterpret_cast<f32x4 *>(&hbuf[4 * neuronB]) = hn;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (b0 + i < B) h_out[((size_t)t * B + b0 + i) * ldh + neuronB] = hn[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { cur_zr[i] = nxt_zr[i]; cur_c[i] = nxt_c[i]; }
+        __syncthreads();
+    }
+}
+
+template <int N>
+static int launch_gru_mfma(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
+                           int reverse, int act, int gate_act, hipStream_t s)
+{
+    dim3 grid((B + 3) / 4), block(256);
+    if (act == SLK_ACT_TANH && gate_act == SLK_ACT_SIGMOID)
+        hipLaunchKernelGGL((gru_mfma_kernel<N, SLK_ACT_TANH, SLK_ACT_SIGMOID>), grid, block, 0, s, vI, sW, sW2, h_out, ldh,
+                           T, B, reverse, act, gate_act);
+    else
+        hipLaunchKernelGGL((gru_mfma_kernel<N, -1, -1>), grid, block, 0, s, vI, sW, sW2, h_out, ldh, T, B, reverse, act,
+                           gate_act);
+    return slk_launch_status();
+}
+
+extern "C" int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh,
+                                        int T, int B, int n, int reverse, int act, int gate_act, int force_generic,
+                                        slk_stream_t stream)
+{
+    if (!vI || !sW || !sW2 || !h_out || T < 1 || B < 1 || n < 1 || ldh < n || !slk_act_valid(act) ||
+        !slk_act_valid(gate_act))
+        return SLK_ERR_INVALID_ARG;
+    hipStream_t s = slk_stream(stream);
+    if (!force_generic) {
+        switch (n) {
+        case 16: return launch_gru_mfma<16>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
+        case 32: return launch_gru_mfma<32>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
+        case 48: return launch_gru_mfma<48>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
+        case 64: return launch_gru_mfma<64>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
+        case 80: return launch_gru_mfma<80>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
+        case 96: return launch_gru_mfma<96>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
+        case 112: return launch_gru_mfma<112>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
+        case 128: return launch_gru_mfma<128>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
+        default: break;
+        }
+    }
+    size_t lds = sizeof(float) * 3 * (size_t)n;
+    if (lds > 64 * 1024) return SLK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gru_generic_kernel, dim3(B), dim3(256), lds, s, vI, sW, sW2, h_out, ldh, T, B, n, reverse, act,
+                       gate_act);
+    return slk_launch_status();
+}
+
+extern "C" int slk_gru_recurrent_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T,
+                                     int B, int n, int reverse, int act, int gate_act, slk_stream_t stream)
+{
+    return slk_gru_recurrent_f32_ex(vI, sW, sW2, h_out, ldh, T, B, n, reverse, act, gate_act, 0, stream);
+}
+
+extern "C" size_t slk_gru_workspace_bytes(int T, int B, int n)
+{
+    if (T < 1 || B < 1 || n < 1) return 0;
+    return sizeof(float) * (size_t)T * B * 3 * n;
+}
+
+extern "C" int slk_gru_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
+                           const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse, int act,
+                           int gate_act, void *workspace, size_t workspace_bytes, slk_stream_t stream)
+{
+    if (T < 1 || B < 1 || n < 1 || insize < 1) return SLK_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < slk_gru_workspace_bytes(T, B, n)) return SLK_ERR_WORKSPACE;
+    float *vI = static_cast<float *>(workspace);
+    int rc = slk_gemm_bias_act_f32(x, ldx, iW, bias, vI, 3L * n, (long)T * B, insize, 3 * n, SLK_ACT_LINEAR, stream);
+    if (rc != SLK_OK) return rc;
+    return slk_gru_recurrent_f32(vI, sW, sW2, y, ldy, T, B, n, reverse, act, gate_act, stream);
+}
+
+extern "C" int slk_lstm_recurrent_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T,
+                                      int B, int n, int reverse, int act, int gate_act, slk_stream_t stream)
+{
+    if (!vW || !sW || !out || T < 1 || B < 1 || n < 1 || ldo < n || !slk_act_valid(act) || !slk_act_valid(gate_act))
+        return SLK_ERR_INVALID_ARG;
+    size_t lds = sizeof(float) * 6 * (size_t)n;
+    if (lds > 64 * 1024) return SLK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(lstm_generic_kernel, dim3(B), dim3(256), lds, slk_stream(stream), vW, sW, p, out, ldo, T, B, n,
+                       reverse, act, gate_act);
+    return slk_launch_status();
+}
+
+extern "C" size_t slk_lstm_workspace_bytes(int T, int B, int n)
+{
+    if (T < 1 || B < 1 || n < 1) return 0;
+    return sizeof(float) * (size_t)T * B * 4 * n;
+}
+
+extern "C" int slk_lstm_f32(const float *x, long ldx, const float *iW, const float *sW, const float *bias,
+                            const float *p, float *y, long ldy, int T, int B, int insize, int n, int reverse, int act,
+                            int gate_act, void *workspace, size_t workspace_bytes, slk_stream_t stream)
+{
+    if (T < 1 || B < 1 || n < 1 || insize < 1) return SLK_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < slk_lstm_workspace_bytes(T, B, n)) return SLK_ERR_WORKSPACE;
+    float *vW = static_cast<float *>(workspace);
+    int rc = slk_gemm_bias_act_f32(x, ldx, iW, bias, vW, 4L * n, (long)T * B, insize, 4 * n, SLK_ACT_LINEAR, stream);
+    if (rc != SLK_OK) return rc;
+    return slk_lstm_recurrent_f32(vW, sW, p, y, ldy, T, B, n, reverse, act, gate_act, stream);
+}
+
+// =====================================================================================================
+// Hardware-layout probe for v_mfma_f32_4x4x1_16b_f32 (used by tests/test_gpu_mfma_probe.py): returns the raw
+// accumulator so that the operand/broadcast assumptions of gru_mfma_kernel are checked on the device.
+// =====================================================================================================
+template <int CB, int AB>
+__global__ void mfma4_probe_kernel(const float *a, const float *b, float *d)
+{
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = mfma4<CB, AB>(a[threadIdx.x], b[threadIdx.x], c);
+    for (int i = 0; i < 4; i++) d[i * 64 + threadIdx.x] = c[i];
+}
+
+extern "C" int slk_debug_mfma4_probe(const float *a, const float *b, float *d, int cbsz, int abid, slk_stream_t stream)
+{
+    hipStream_t s = slk_stream(stream);
+#define PROBE(CB, AB)                                                                              \
+    if (cbsz == CB && abid == AB) {                                                                \
+        hipLaunchKernelGGL((mfma4_probe_kernel<CB, AB>), dim3(1), dim3(64), 0, s, a, b, d);        \
+        return slk_launch_status();                                                                \
+    }
+    PROBE(0, 0) PROBE(4, 0) PROBE(4, 3) PROBE(4, 15) PROBE(3, 0) PROBE(3, 5) PROBE(2, 1) PROBE(2, 3)
+#undef PROBE
+    return SLK_ERR_UNSUPPORTED;
+}

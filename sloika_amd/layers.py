@@ -1,0 +1,778 @@
+"""Layer / model-file API of the basecalling path: the classes of sloika/layers.py that shipped models use,
+with the same constructor signatures, attribute names and methods, executing on gfx950 HIP kernels through
+the C ABI (include/sloika_amd.h) instead of compiling Theano graphs.
+
+    reference                                   here
+    ---------                                   ----
+    Layer.compile() -> th.function              Layer.compile() -> callable(ndarray|tensor [T,B,F]) -> same kind
+    Layer.run(symbolic)                         Layer.run(device tensor [T,B,F]) -> device tensor [T',B,size]
+    th.shared leaves (.get_value/.set_value)    Shared leaves (same two methods, numpy storage + device mirror)
+    RNN.run = th.scan(step)                     persistent recurrent kernels (csrc/recurrent.hip)
+    Reverse(layer).run = layer.run(x[::-1])[::-1]   time-order flag on the recurrent kernels (no copies)
+    Parallel.run = concatenate(...)             sub-layers write straight into their slice (row stride `ld`)
+
+Convention (sloika/layers.py:13-14): tensors are row major (time, batch, feature), float32.
+There is no CPU fallback: without the HIP library / a GPU, `run` raises.
+"""
+import abc
+from collections import OrderedDict
+from functools import reduce
+
+import numpy as np
+
+from . import _lib, activation, conv, profiler
+from .config import sloika_dtype
+from .variables import DEFAULT_NBASE, nkmer
+
+_FORGET_BIAS = 2.0        # layers.py:17
+
+
+def zeros(size):
+    return np.zeros(size, dtype=sloika_dtype)          # layers.py:21-22
+
+
+class Shared(object):
+    """Stand-in for a Theano shared variable: numpy storage, lazily mirrored to HBM."""
+
+    def __init__(self, value):
+        self._value = np.ascontiguousarray(value, dtype=sloika_dtype)
+        self._dev = None
+
+    def get_value(self, borrow=False):
+        return self._value if borrow else self._value.copy()
+
+    def set_value(self, value, borrow=False):
+        self._value = np.ascontiguousarray(value, dtype=sloika_dtype)
+        self._dev = None
+
+    def dev(self):
+        if self._dev is None:
+            from . import device as D
+            self._dev = D.to_dev(self._value)
+        return self._dev
+
+    @property
+    def shape(self):
+        return self._value.shape
+
+    def __getstate__(self):
+        return {"_value": self._value}
+
+    def __setstate__(self, state):
+        self._value = np.ascontiguousarray(state["_value"], dtype=sloika_dtype)
+        self._dev = None
+
+
+def shared(value):
+    return Shared(value)
+
+
+def _extract(x, shape=None):
+    xv = x.get_value()
+    if shape is not None:
+        xv = xv.reshape(shape)
+    return xv.tolist()
+
+
+def _stream():
+    from . import device as D
+    return D.stream_ptr()
+
+
+def _check_input(x, insize):
+    import torch
+    if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda:
+        raise ValueError("layer input must be a float32 device tensor [time, batch, features]")
+    if x.shape[2] != insize:
+        raise ValueError("layer expects %d input features, got %d" % (insize, x.shape[2]))
+    if x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
+        x = x.contiguous()
+    return x
+
+
+def _row_stride(x):
+    """Row stride (floats) of a [T,B,F] tensor whose (t,b) rows are equally spaced."""
+    return x.stride(1)
+
+
+def _alloc_out(x, T, B, size, out):
+    """Either use the caller's (possibly strided) output slice or allocate a dense one."""
+    import torch
+    if out is not None:
+        assert out.shape == (T, B, size) and out.stride(2) == 1 and out.stride(0) == B * out.stride(1)
+        return out
+    return torch.empty((T, B, size), dtype=torch.float32, device=x.device)
+
+
+class Param(object):
+    """Declarative description of one weight tensor of a layer.
+
+    view      : shape the tensor is shown in by `json(params=True)` (None = as stored)
+    given     : shape `set_params` expects in its `values` dict (None = only the leading size is checked)
+    store     : function(layer, array) -> array in storage layout
+    flag      : name of the boolean attribute that says whether `set_params` touches it (None = always)
+    """
+
+    def __init__(self, name, view=None, given=None, store=None, flag=None):
+        self.name, self.view, self.given, self.store, self.flag = name, view, given, store, flag
+
+
+class Layer(metaclass=abc.ABCMeta):
+    _json_type = None        # 'type' string of the reference's json() for this class
+    _json_fields = ()        # ((key, attribute-or-function), ...) emitted after 'type'
+    _weights = ()            # Param descriptors, in the order json() lists them
+
+    def json(self, params=False):
+        """Description of the layer in the reference's json vocabulary (same keys, same order)."""
+        res = OrderedDict([('type', self._json_type)])
+        for key, src in self._json_fields:
+            val = src(self) if callable(src) else getattr(self, src)
+            res[key] = val
+        if params and self._weights:
+            res['params'] = OrderedDict(
+                (w.name, _extract(getattr(self, w.name), w.view(self) if w.view else None)) for w in self._weights)
+        return res
+
+    def set_params(self, values):
+        """Set parameters from a dictionary of arrays given in the shapes json() shows them in."""
+        for w in self._weights:
+            if w.flag is not None and not getattr(self, w.flag):
+                continue
+            val = values[w.name]
+            if w.given is not None:
+                assert val.shape == w.given(self), "parameter %s has shape %r" % (w.name, val.shape)
+            else:
+                assert val.shape[0] == self.size
+            getattr(self, w.name).set_value(w.store(self, val) if w.store else val)
+
+    def compile(self):
+        """layers.py:34-36.  Returns f(ndarray|tensor [T,B,insize]) -> same kind [T',B,size]."""
+        _lib.lib()      # fail now, loudly, if the extension is missing
+
+        def calc(x):
+            from . import device as D
+            xd = D.to_dev(x)
+            return D.like_input(self.run(xd), x)
+        calc.network = self
+        return calc
+
+    @property
+    def insize(self):
+        return self._insize
+
+    @property
+    def size(self):
+        return self._size
+
+    @property
+    def name(self):
+        return self._name
+
+    @abc.abstractmethod
+    def params(self):
+        """ a list of network parameters """
+        return
+
+    def run(self, inMat):
+        """ Run network layer on a device tensor """
+        return self._forward(_check_input(inMat, self.insize), None, False)
+
+    @abc.abstractmethod
+    def _forward(self, x, out, reverse):
+        """x: device [T,B,insize]; out: optional pre-allocated (possibly strided) [T',B,size] slice;
+        reverse: evaluate as Reverse(self) would (layers.py:1449-1450)."""
+        return
+
+    @abc.abstractmethod
+    def spec(self):
+        """Neutral nested-dict description (type strings of `json()`, weights as numpy arrays in the layout
+        the reference's run/step code reads them) -- what tests hand to the CPU oracle."""
+        return
+
+
+class RNN(Layer):
+    pass
+
+
+def _flip_run(layer, x, out):
+    """Literal Reverse semantics for layers without a time-order flag."""
+    import torch
+    y = layer._forward(torch.flip(x, dims=[0]).contiguous(), None, False)
+    y = torch.flip(y, dims=[0])
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+class Identity(Layer):
+    """layers.py:91-111"""
+
+    def __init__(self, insize, name="Identity"):
+        self._insize = insize
+        self._name = name
+
+    @property
+    def size(self):
+        return self.insize
+
+    def params(self):
+        return []
+
+    def json(self, params=False):
+        return {'type': "identity"}
+
+    def set_params(self, values):
+        return
+
+    def _forward(self, x, out, reverse):
+        if out is not None:
+            out.copy_(x)
+            return out
+        return x
+
+    def spec(self):
+        return {"type": "identity"}
+
+
+class FeedForward(Layer):
+    """  Basic feedforward layer:  out = f( inMat W + b )       (layers.py:114-158)
+
+    :param insize: Size of input to layer
+    :param size: Layer size
+    :param init: function to initialise tensors with
+    :param has_bias: Whether layer has bias
+    :param fun: The activation function.
+    :param name: Name for layer
+    """
+
+    _json_type = "feed-forward"
+    _json_fields = (('activation', lambda self: self.fun.__name__), ('size', 'size'), ('insize', 'insize'),
+                    ('bias', 'has_bias'))
+    _weights = (Param('W', given=lambda self: (self.size, self.insize)), Param('b', flag='has_bias'))
+
+    def __init__(self, insize, size, init=zeros, has_bias=False,
+                 fun=activation.tanh, name="Feed-forward"):
+        self.has_bias = has_bias
+        self.b = shared(has_bias * init(size))
+        self.W = shared(init((size, insize)) / np.sqrt(size + insize))
+        self._insize = insize
+        self._size = size
+        self._name = name
+        self.fun = fun
+
+    def params(self):
+        return [self.W, self.b] if self.has_bias else [self.W]
+
+    def _forward(self, x, out, reverse):
+        T, B, _ = x.shape                       # time-local: Reverse is the identity on it
+        y = _alloc_out(x, T, B, self.size, out)
+        rows = T * B
+        with profiler.region("gemm_bias_act", 2.0 * rows * self.insize * self.size,
+                             4.0 * rows * (self.insize + self.size)):
+            rc = _lib.lib().slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
+                                                  self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), rows,
+                                                  self.insize, self.size, activation.act_id(self.fun), _stream())
+        _lib.check(rc, "FeedForward")
+        return y
+
+    def spec(self):
+        return {"type": "feed-forward", "W": self.W.get_value(), "b": self.b.get_value(),
+                "activation": activation.act_name(self.fun)}
+
+
+class Softmax(Layer):
+    """  Softmax layer: tmp = exp( inmat W + b ); out = row_normalise( tmp )     (layers.py:268-314)
+
+    :param insize: Size of input to layer
+    :param size: Layer size
+    :param init: function to initialise tensors with
+    :param has_bias: Whether layer has bias
+    :param name: Name for layer
+    """
+
+    _json_type = "softmax_old"
+    _json_fields = (('size', 'size'), ('insize', 'insize'), ('bias', 'has_bias'))
+    _weights = (Param('W', given=lambda self: (self.size, self.insize)), Param('b', flag='has_bias'))
+
+    def __init__(self, insize, size, init=zeros, has_bias=False, name="Softmax"):
+        self.has_bias = has_bias
+        self.b = shared(has_bias * init(size))
+        self.W = shared(init((size, insize)) / np.sqrt(size + insize))
+        self._insize = insize
+        self._size = size
+        self._name = name
+
+    def params(self):
+        return [self.W, self.b] if self.has_bias else [self.W]
+
+    def _forward(self, x, out, reverse):
+        import torch
+        T, B, _ = x.shape
+        dense = out is None or out.stride(1) != self.size
+        y = torch.empty((T, B, self.size), dtype=torch.float32, device=x.device) if dense else out
+        rows, L = T * B, _lib.lib()
+        with profiler.region("softmax_gemm", 2.0 * rows * self.insize * self.size,
+                             4.0 * rows * (self.insize + self.size)):
+            rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
+                                         self.b.dev().data_ptr(), y.data_ptr(), self.size, rows, self.insize,
+                                         self.size, 0, _stream())
+        _lib.check(rc, "Softmax")
+        with profiler.region("softmax_rows", 0.0, 8.0 * rows * self.size):
+            rc = L.slk_softmax_rows_f32(y.data_ptr(), rows, self.size, _stream())
+        _lib.check(rc, "Softmax")
+        if out is not None and dense:
+            out.copy_(y)
+            return out
+        return y
+
+    def spec(self):
+        return {"type": "softmax", "W": self.W.get_value(), "b": self.b.get_value()}
+
+
+class SoftmaxTheano(Softmax):
+    """layers.py:222-265: same mathematics through T.nnet.softmax; `json` type differs."""
+
+    def json(self, params=False):
+        res = Softmax.json(self, params)
+        res['type'] = "softmax"
+        return res
+
+
+class Window(Layer):
+    """  Create a sliding window over input      (layers.py:317-351)
+
+    :param w: Size of window
+    :param name: Name for layer
+    """
+
+    def __init__(self, insize, w, name="Window"):
+        assert w > 0, "Window size must be positive"
+        assert w % 2 == 1, 'Window size should be odd'
+        self.w = w
+        self._insize = insize
+        self._name = name
+
+    @property
+    def size(self):
+        return self.w * self.insize
+
+    def params(self):
+        return []
+
+    def json(self, params=False):
+        res = OrderedDict([('type', "window")])
+        if params:
+            res['params'] = OrderedDict([('w', self.w)])
+        return res          # (the reference forgets this return, layers.py:338-341)
+
+    def set_params(self, values):
+        return
+
+    def _forward(self, x, out, reverse):
+        import torch
+        T, B, F = x.shape                      # symmetric padding: commutes with time reversal
+        x = x.contiguous()
+        y = torch.empty((T, B, self.size), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().slk_window_f32(x.data_ptr(), y.data_ptr(), T, B, F, self.w, _stream()), "Window")
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+    def spec(self):
+        return {"type": "window", "w": self.w}
+
+
+class Convolution(Layer):
+    """1D convolution over the first dimension       (layers.py:354-419)
+
+    Takes input of shape [time, batch, features] and produces output of shape
+    [ceil((time + padding) / stride), batch, features]
+
+    :param insize: number of features on input
+    :param size: number of output features
+    :param winlen: size of window over input
+    :param stride: step size between successive windows
+    :param init: function to initialise tensors with
+    :param has_bias: whether layer has bias
+    :param fun: the activation function
+    :param padding_mode: str, int or (int, int); see conv.calculate_padding. Default: 'same'
+    :param name: Name for layer
+    """
+
+    _json_type = "convolution"
+    _json_fields = (("insize", 'insize'), ("size", 'size'), ("winlen", 'winlen'), ("stride", 'stride'),
+                    ("padding_mode", 'padding_mode'), ("padding", 'padding'),
+                    ("activation", lambda self: self.fun.__name__))
+    _weights = (Param('W', given=lambda self: (self.size, self.insize, self.winlen)), Param('b', flag='has_bias'))
+
+    def __init__(self, insize, size, winlen, stride=1, init=zeros,
+                 has_bias=False, fun=activation.tanh, padding_mode='same',
+                 name="Convolution"):
+        self._insize = insize
+        self._size = size
+        self._name = name
+        self.winlen = winlen
+        self.stride = stride
+        self.fun = fun
+        self.has_bias = has_bias
+        self.padding_mode = padding_mode
+        self.padding = conv.calculate_padding(padding_mode, winlen)
+
+        fanin = insize * winlen
+        fanout = (size * winlen) / float(stride)
+        self.W = shared(init((size, insize, winlen)) / np.sqrt(fanin + fanout))
+        self.b = shared(has_bias * init(size))
+
+    def params(self):
+        return [self.W, self.b] if self.has_bias else [self.W]
+
+    def out_len(self, T):
+        return _lib.lib().slk_conv1d_out_len(T, self.winlen, self.stride, self.padding[0], self.padding[1])
+
+    def run_strided(self, x_ptr, T, B, x_t_stride, x_b_stride, device):
+        """Convolve input addressed as x[t*x_t_stride + b*x_b_stride + c] (lets the chunk front end hand over
+        chunk-major signal without a transpose)."""
+        import torch
+        y = torch.empty((self.out_len(T), B, self.size), dtype=torch.float32, device=device)
+        with profiler.region("conv1d", 2.0 * y.numel() * self.insize * self.winlen,
+                             4.0 * (y.numel() + T * B * self.insize)):
+            rc = _lib.lib().slk_conv1d_f32(x_ptr, x_t_stride, x_b_stride, self.W.dev().data_ptr(),
+                                           self.b.dev().data_ptr(), y.data_ptr(), T, B, self.insize, self.size,
+                                           self.winlen, self.stride, self.padding[0], self.padding[1],
+                                           activation.act_id(self.fun), _stream())
+        _lib.check(rc, "Convolution")
+        return y
+
+    def _forward(self, x, out, reverse):
+        if reverse:
+            return _flip_run(self, x, out)
+        T, B, C = x.shape
+        x = x.contiguous()
+        y = self.run_strided(x.data_ptr(), T, B, B * C, C, x.device)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+    def spec(self):
+        return {"type": "convolution", "W": self.W.get_value(), "b": self.b.get_value(), "stride": self.stride,
+                "padding": tuple(self.padding), "activation": activation.act_name(self.fun)}
+
+
+class Lstm(RNN):
+    """ LSTM layer with peepholes (layers.py:599-697).  Step (:677-691):
+        v = [ input_new, output_old ]
+        Pforget = gatefun( v W2 + b2 + state * p1)
+        Pupdate = gatefun( v W1 + b1 + state * p0)
+        Update  = fun( v W0 + b0 )
+        state_new = state_old * Pforget + Update * Pupdate
+        Poutput = gatefun( v W3 + b3 + state * p2)
+        output_new = fun(state) * Poutput
+    Rows of iW / sW / b are interleaved as j*4 + gate (the layout `step` reads; `json`/`set_params` keep the
+    reference's block reshapes verbatim).
+    """
+
+    _json_type = "LSTM"
+    _json_fields = (('activation', lambda self: self.fun.__name__), ('gate', lambda self: self.gatefun.__name__),
+                    ('size', 'size'), ('insize', 'insize'), ('bias', 'has_bias'), ('peep', 'has_peep'))
+    # layers.py:659-675: json()/set_params() present the weights as 4 gate blocks even though step() reads the
+    # rows interleaved; kept as is so that parameter dictionaries round-trip exactly as in the reference.
+    _weights = (Param('iW', view=lambda self: (4, self.size, self.insize), given=lambda self: (4, self.size, self.insize),
+                      store=lambda self, v: v.reshape((self.size * 4, self.insize))),
+                Param('sW', view=lambda self: (4, self.size, self.size), given=lambda self: (4, self.size, self.size),
+                      store=lambda self, v: v.reshape((self.size * 4, self.size))),
+                Param('b', view=lambda self: (4, self.size), given=lambda self: (4, self.size),
+                      store=lambda self, v: v.transpose().reshape(-1), flag='has_bias'),
+                Param('p', view=lambda self: (3, self.size), given=lambda self: (3, self.size), flag='has_peep'))
+
+    def __init__(self, insize, size, init=zeros, has_bias=False, has_peep=False,
+                 fun=activation.tanh, gatefun=activation.sigmoid, name="LSTM"):
+        self._size = size
+        self._insize = insize
+        self._name = name
+        self.has_bias = has_bias
+        self.has_peep = has_peep
+        self.fun = fun
+        self.gatefun = gatefun
+
+        self.b = shared(has_bias * (init(4 * size) + np.repeat([0, 0, _FORGET_BIAS, 0], size).astype(sloika_dtype)))
+        self.p = shared(has_peep * init((3, size)) / np.sqrt(size))
+        self.iW = shared(init((4 * size, insize)) / np.sqrt(insize + size))
+        self.sW = shared(init((4 * size, size)) / np.sqrt(size + size))
+
+    def params(self):
+        params = [self.iW, self.sW]
+        if self.has_bias:
+            params += [self.b]
+        if self.has_peep:
+            params += [self.p]
+        return params
+
+    def _forward(self, x, out, reverse):
+        import torch
+        T, B, _ = x.shape
+        y = _alloc_out(x, T, B, self.size, out)
+        L = _lib.lib()
+        nbytes = L.slk_lstm_workspace_bytes(T, B, self.size)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        rc = L.slk_lstm_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(), self.sW.dev().data_ptr(),
+                            self.b.dev().data_ptr(), self.p.dev().data_ptr(), y.data_ptr(), _row_stride(y), T, B,
+                            self.insize, self.size, int(reverse), activation.act_id(self.fun),
+                            activation.act_id(self.gatefun), ws.data_ptr(), nbytes, _stream())
+        _lib.check(rc, "Lstm")
+        return y
+
+    def spec(self):
+        return {"type": "LSTM", "iW": self.iW.get_value(), "sW": self.sW.get_value(), "b": self.b.get_value(),
+                "p": self.p.get_value(), "activation": activation.act_name(self.fun),
+                "gate": activation.act_name(self.gatefun)}
+
+
+class Gru(RNN):
+    """ Gated Recurrent Unit (layers.py:952-1021).  Step (:1010-1021):
+        vI = x iW^T + b ; vS = h sW^T ; z, r = gatefun(vI[:2n] + vS) ; y = (r*h) sW2^T
+        hbar = fun(vI[2n:] + y) ; h = z*h + (1-z)*hbar
+
+    :param insize: Size of input to layer
+    :param size: Layer size
+    :param init: function to initialise tensors with
+    :param has_bias: Whether layer has bias
+    :param fun: The activation function.
+    :param gatefun: The activation function for gates.
+    :param name: Name for layer
+    """
+
+    _json_type = "GRU"
+    _json_fields = (('activation', lambda self: self.fun.__name__), ('gate', lambda self: self.gatefun.__name__),
+                    ('size', 'size'), ('insize', 'insize'), ('bias', 'has_bias'))
+    _weights = (Param('iW', view=lambda self: (3, self.size, self.insize), given=lambda self: (3, self.size, self.insize),
+                      store=lambda self, v: v.reshape((3 * self.size, self.insize))),
+                Param('sW', view=lambda self: (2, self.size, self.size), given=lambda self: (2, self.size, self.size),
+                      store=lambda self, v: v.reshape((2 * self.size, self.size))),
+                Param('sW2', given=lambda self: (self.size, self.size)),
+                Param('b', view=lambda self: (3, self.size), given=lambda self: (3, self.size),
+                      store=lambda self, v: v.reshape(-1), flag='has_bias'))
+
+    def __init__(self, insize, size, init=zeros, has_bias=False,
+                 fun=activation.tanh, gatefun=activation.sigmoid, name='GRU'):
+        self._size = size
+        self._insize = insize
+        self._name = name
+        self.has_bias = has_bias
+        self.fun = fun
+        self.gatefun = gatefun
+
+        self.b = shared(has_bias * init(3 * size))
+        self.iW = shared(init((3 * size, insize)) / np.sqrt(insize + size))
+        self.sW = shared(init((2 * size, size)) / np.sqrt(size + size))
+        self.sW2 = shared(init((size, size)) / np.sqrt(size + size))
+
+    def params(self):
+        params = [self.iW, self.sW, self.sW2]
+        if self.has_bias:
+            params += [self.b]
+        return params
+
+    def _forward(self, x, out, reverse):
+        import torch
+        T, B, _ = x.shape
+        y = _alloc_out(x, T, B, self.size, out)
+        L = _lib.lib()
+        nbytes = L.slk_gru_workspace_bytes(T, B, self.size)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        n, rows = self.size, T * B
+        with profiler.region("gru_input_gemm", 2.0 * rows * self.insize * 3 * n, 4.0 * rows * (self.insize + 3 * n)):
+            rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
+                                         self.b.dev().data_ptr(), ws.data_ptr(), 3 * n, rows, self.insize, 3 * n, 0,
+                                         _stream())
+        _lib.check(rc, "Gru")
+        with profiler.region("gru_recurrent", 6.0 * rows * n * n, 4.0 * rows * 4 * n):
+            rc = L.slk_gru_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
+                                         y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
+                                         activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
+        _lib.check(rc, "Gru")
+        return y
+
+    def spec(self):
+        return {"type": "GRU", "iW": self.iW.get_value(), "sW": self.sW.get_value(), "sW2": self.sW2.get_value(),
+                "b": self.b.get_value(), "activation": activation.act_name(self.fun),
+                "gate": activation.act_name(self.gatefun)}
+
+
+class Reverse(Layer):
+    """  Runs a recurrent layer in reverse time (backwards)       (layers.py:1420-1450)
+
+    :param layer: A :class:`layer` to reverse
+    :param name: Name for layer
+    """
+
+    def __init__(self, layer, name='Reverse'):
+        self.layer = layer
+        self._name = name
+
+    @property
+    def insize(self):
+        return self.layer.insize
+
+    @property
+    def size(self):
+        return self.layer.size
+
+    def params(self):
+        return self.layer.params()
+
+    def json(self, params=False):
+        return OrderedDict([('type', "reverse"),
+                            ('sublayer', self.layer.json(params))])
+
+    def set_params(self, values):
+        return
+
+    def _forward(self, x, out, reverse):
+        return self.layer._forward(x, out, not reverse)
+
+    def spec(self):
+        return {"type": "reverse", "sublayer": self.layer.spec()}
+
+
+class Parallel(Layer):
+    """ Run multiple layers in parallel (all have same input and outputs are concatenated)   (layers.py:1453-1487)
+
+    :param layers: A list of :class:`layer` to run in parallel
+    :param name: Name for layer
+    """
+
+    def __init__(self, layers, name='Parallel'):
+        assert len(layers) > 0, "A Parallel layer cannot be empty"
+        self.layers = layers
+        self._name = name
+        is_consistent = all(x.insize == self.insize for x in self.layers)
+        assert is_consistent, "Parallel layer has inconsistent sizes"
+
+    @property
+    def insize(self):
+        return self.layers[0].insize
+
+    @property
+    def size(self):
+        return sum(x.size for x in self.layers)
+
+    def params(self):
+        return reduce(lambda x, y: x + y.params(), self.layers, [])
+
+    def json(self, params=False):
+        return OrderedDict([('type', "parallel"),
+                            ('sublayers', [layer.json(params) for layer in self.layers])])
+
+    def set_params(self, values):
+        return
+
+    def _forward(self, x, out, reverse):
+        import torch
+        T, B, _ = x.shape
+        if all(_keeps_time(layer) for layer in self.layers):
+            # every sub-layer writes its slice of the concatenated tensor directly (row stride = self.size)
+            outs = out if out is not None else torch.empty((T, B, self.size), dtype=torch.float32, device=x.device)
+            off = 0
+            for layer in self.layers:
+                layer._forward(x, outs[:, :, off:off + layer.size], reverse)
+                off += layer.size
+            return outs
+        cat = torch.cat([layer._forward(x, None, reverse) for layer in self.layers], dim=2)
+        if out is not None:
+            out.copy_(cat)
+            return out
+        return cat
+
+    def spec(self):
+        return {"type": "parallel", "sublayers": [l.spec() for l in self.layers]}
+
+
+class Serial(Layer):
+    """ Run multiple layers serially: output of a layer is the input for the next layer  (layers.py:1524-1560)
+
+    :param layers: A list of :class:`layer` to run in series
+    :param name: Name for layer
+    """
+
+    def __init__(self, layers, name='Serial'):
+        assert len(layers) > 0, "A Serial layer cannot be empty"
+        self.layers = layers
+        self._name = name
+        is_consistent = all(x.size == y.insize for x, y in zip(layers, layers[1:]))
+        assert is_consistent, "Serial layer has inconistent sizes"
+
+    @property
+    def insize(self):
+        return self.layers[0].insize
+
+    @property
+    def size(self):
+        return self.layers[-1].size
+
+    def params(self):
+        return reduce(lambda x, y: x + y.params(), self.layers, [])
+
+    def json(self, params=False):
+        return OrderedDict([('type', "serial"),
+                            ('sublayers', [layer.json(params) for layer in self.layers])])
+
+    def set_params(self, values):
+        return
+
+    def _forward(self, x, out, reverse):
+        if reverse:
+            return _flip_run(self, x, out)
+        tmp = x
+        last = len(self.layers) - 1
+        for i, layer in enumerate(self.layers):
+            tmp = layer._forward(tmp, out if i == last else None, False)
+        return tmp
+
+    def spec(self):
+        return {"type": "serial", "sublayers": [l.spec() for l in self.layers]}
+
+
+def _keeps_time(layer):
+    """True for layers whose output has the input's time length and that can write a strided slice."""
+    if isinstance(layer, Reverse):
+        return _keeps_time(layer.layer)
+    return isinstance(layer, (RNN, FeedForward))
+
+
+def birnn(forward, backward, name='BiRNN'):
+    """  Creates a bidirectional RNN from two RNNs      (layers.py:1622-1629)
+
+    :param forward: A :class:`layer` to run forwards
+    :param backward: A :class:`layer` to run backwards
+    :param name: Name for layer
+    """
+    return Parallel([forward, Reverse(backward)], name=name)
+
+
+def _unsupported(cls_name, where):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError(
+            "sloika_amd: layer %s (sloika/layers.py:%s) is outside the accelerated basecalling path -- no shipped "
+            "model uses it (see DESIGN.md, 'Out of scope')" % (cls_name, where))
+    return type(cls_name, (object,), {"__init__": __init__})
+
+
+# Exotic cells of the reference that no model in models/ uses: named so that `from sloika.layers import *`
+# resolves, but constructing one fails loudly instead of silently running somewhere else.
+Studentise = _unsupported("Studentise", "161-187")
+NormaliseL1 = _unsupported("NormaliseL1", "190-219")
+MaxPool = _unsupported("MaxPool", "422-465")
+Recurrent = _unsupported("Recurrent", "468-520")
+Scrn = _unsupported("Scrn", "523-596")
+LstmCIFG = _unsupported("LstmCIFG", "700-798")
+LstmO = _unsupported("LstmO", "801-883")
+Forget = _unsupported("Forget", "886-949")
+Mut1 = _unsupported("Mut1", "1024-1117")
+Mut2 = _unsupported("Mut2", "1120-1224")
+Mut3 = _unsupported("Mut3", "1227-1331")
+Genmut = _unsupported("Genmut", "1334-1417")
+Residual = _unsupported("Residual", "1490-1521")
+Decode = _unsupported("Decode", "1563-1619")

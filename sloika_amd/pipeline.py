@@ -1,0 +1,72 @@
+"""The hot path end to end, resident on one GPU:
+
+    raw chunks [B, chunk_len] (HBM)  --normalise-->  --conv-->  --GRU/LSTM stack-->  --softmax-->
+    --prepare_post + log + k-mer Viterbi + backtrace-->  (scores[B], paths[B,T'], lens[B])
+
+This is the batched restatement of bin/basecall_network.py `raw` (sloika/basecall.py:88-121, 26-51) that
+BASELINE.json's metric is quoted on.  All arithmetic happens in the HIP kernels behind include/sloika_amd.h;
+torch only owns the buffers and the stream.
+"""
+import numpy as np
+
+from . import _lib, batch, decode, layers
+
+
+class Basecaller(object):
+    def __init__(self, network, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, normalisation='per-chunk'):
+        """skip default 0.0 is the CLI default (bin/basecall_network.py:38)."""
+        if not isinstance(network, layers.Layer):
+            raise TypeError("network must be a sloika_amd.layers.Layer")
+        self.network = network
+        self.kmer_len, self.nbase, self.min_prob, self.skip = kmer_len, nbase, min_prob, skip
+        self.normalisation = normalisation
+        self._ws = decode.ViterbiWorkspace()
+        _lib.lib()
+
+    def posteriors(self, chunks):
+        """[B, chunk_len] device signal -> [T', B, nstate] posteriors (network layout)."""
+        import torch
+        from . import device as D
+        cd = D.to_dev(chunks)
+        net = self.network
+        first = net.layers[0] if isinstance(net, layers.Serial) else None
+        if (self.normalisation == 'per-chunk' and isinstance(first, layers.Convolution) and first.insize == 1
+                and len(net.layers) > 1):
+            # the conv front end reads the chunk-major normalised signal directly: no [T,B,1] transpose
+            norm = batch.normalise_chunks(cd, 'per-chunk', out_layout='chunk')
+            B, T = norm.shape
+            x = first.run_strided(norm.data_ptr(), T, B, 1, T, norm.device)
+            for layer in net.layers[1:]:
+                x = layer._forward(x, None, False)
+            return x
+        inmat = batch.normalise_chunks(cd, self.normalisation, out_layout='network')
+        return net.run(inmat)
+
+    def call_chunks(self, chunks):
+        """-> device tensors (scores float32 [B], paths int32 [B, T'] (-1 padded), lens int32 [B])."""
+        post = self.posteriors(chunks)
+        return decode.viterbi_batch(post, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
+                                    min_prob=self.min_prob, workspace=self._ws)
+
+    def call_chunks_host(self, chunks):
+        scores, paths, lens = self.call_chunks(chunks)
+        scores, paths, lens = scores.cpu().numpy(), paths.cpu().numpy(), lens.cpu().numpy()
+        return scores, [paths[i, : lens[i]].tolist() for i in range(len(lens))]
+
+
+def synthetic_chunks(nchunk, chunk_len=4000, seed=0xdeadbeef, dwell=10.0, noise=0.15, first_chunk=0):
+    """Synthetic raw signal: per chunk, piecewise-constant levels ~N(0,1) with geometric dwell
+    (mean `dwell` samples) plus N(0, noise^2), RandomState(seed + chunk_id), scaled to a pA-like range so that
+    normalisation does real work.  float32 [nchunk, chunk_len]."""
+    out = np.empty((nchunk, chunk_len), dtype=np.float32)
+    for c in range(nchunk):
+        rs = np.random.RandomState((seed + first_chunk + c) % (2 ** 32))
+        nseg = int(chunk_len / dwell * 2) + 16
+        d = rs.geometric(1.0 / dwell, size=nseg)
+        while d.sum() < chunk_len:
+            d = np.concatenate([d, rs.geometric(1.0 / dwell, size=nseg)])
+        levels = rs.normal(size=len(d))
+        sig = np.repeat(levels, d)[:chunk_len]
+        sig = sig + rs.normal(scale=noise, size=chunk_len)
+        out[c] = (sig * 12.0 + 90.0).astype(np.float32)
+    return out

@@ -1,0 +1,55 @@
+"""Per-stage device timing with HIP events on the launch stream (torch's current stream is the stream every
+C-ABI call is enqueued on).  Disabled by default: `region()` is then a no-op context manager.
+
+Each region carries the ALGORITHMIC flops and bytes of the launches inside it (see DESIGN.md "Kernels"), so that
+bench.py can turn the measured duration into a roofline fraction.
+"""
+import contextlib
+
+_active = None
+
+
+class Recorder(object):
+    def __init__(self):
+        self.records = []          # (name, start_event, end_event, flops, bytes)
+
+    def summary(self):
+        """name -> dict(calls, ms_total, ms_avg, flops, bytes) ; call after torch.cuda.synchronize()."""
+        out = {}
+        for name, e0, e1, flops, nbytes in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms_total": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["calls"] += 1
+            d["ms_total"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        for d in out.values():
+            d["ms_avg"] = d["ms_total"] / d["calls"]
+        return out
+
+
+def start():
+    global _active
+    _active = Recorder()
+    return _active
+
+
+def stop():
+    global _active
+    rec, _active = _active, None
+    return rec
+
+
+@contextlib.contextmanager
+def region(name, flops=0.0, nbytes=0.0):
+    if _active is None:
+        yield
+        return
+    import torch
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    try:
+        yield
+    finally:
+        e1.record()
+        _active.records.append((name, e0, e1, float(flops), float(nbytes)))

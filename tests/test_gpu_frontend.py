@@ -1,0 +1,104 @@
+"""GPU parity: chunk normalisation (bit exact), conv1d, window, activations -- through the C ABI."""
+import numpy as np
+import pytest
+
+from tests.gpu_util import need_gpu, dev, stream
+
+pytestmark = pytest.mark.gpu
+
+
+def test_normalise_bit_exact_vs_golden_and_oracle(oracle, golden_signal):
+    need_gpu()
+    from sloika_amd import batch
+    g = golden_signal
+    chunks = g["chunks_none"]
+    out = batch.normalise_chunks(chunks, 'per-chunk')
+    assert np.array_equal(out, g["chunks_per_chunk"])                       # reference raw_chunkify output
+    out2, med, mad = batch.normalise_chunks(chunks, 'per-read', return_stats=True)
+    assert np.array_equal(out2, g["chunks_per_read"])
+    net = batch.normalise_chunks(chunks, 'per-chunk', out_layout='network')
+    assert net.shape == (4000, 5, 1)
+    assert np.array_equal(net[:, :, 0].T, g["chunks_per_chunk"])
+    net2 = batch.normalise_chunks(chunks, 'per-read', out_layout='network')
+    assert np.array_equal(net2[:, :, 0].T, g["chunks_per_read"])
+    assert np.array_equal(batch.normalise_chunks(chunks, 'none'), chunks)
+
+
+@pytest.mark.parametrize("n,clen", [(1, 1), (3, 2), (7, 3), (4, 63), (5, 64), (3, 65), (2, 1000), (9, 4096), (2, 5000)])
+def test_normalise_ragged_sizes_vs_oracle(oracle, n, clen):
+    need_gpu()
+    from sloika_amd import batch
+    rs = np.random.RandomState(n * 1000 + clen)
+    x = (rs.normal(size=(n, clen)) * 10 + 80).astype(np.float32)
+    if clen > 8:
+        x[0, :clen // 2] = x[0, 0]                     # many duplicates -> ties in the sort
+    with np.errstate(all="ignore"):
+        ref, rmed, rmad = oracle.med_mad_normalise(x, return_stats=True)
+    out, med, mad = batch.normalise_chunks(x, 'per-chunk', return_stats=True)
+    assert np.array_equal(med, rmed) and np.array_equal(mad, rmad)
+    assert np.array_equal(out, ref, equal_nan=True)
+
+
+def test_normalise_rejects_bad_shapes():
+    need_gpu()
+    from sloika_amd import batch
+    with pytest.raises(ValueError):
+        batch.normalise_chunks(np.zeros(10, dtype=np.float32))
+
+
+@pytest.mark.parametrize("T,B,Cin,Cout,w,s,mode,act", [
+    (100, 3, 1, 8, 11, 5, 'same', "elu"),
+    (4000, 4, 1, 96, 11, 5, 'same', "elu"),            # rgrgr front end
+    (4000, 3, 1, 64, 11, 2, 'same', "tanh"),           # baseline_raw_gru front end
+    (100, 20, 12, 32, 11, 5, 'same', "tanh"),          # test_layers.py Convolution(12,32,11,5) on [100,20,12]
+    (30, 2, 3, 4, 4, 1, 'same', "linear"),
+    (30, 2, 3, 4, 4, 1, 'same_left', "linear"),
+    (30, 1, 2, 3, 5, 3, 'valid', "relu"),
+    (17, 2, 2, 3, 5, 1, 'full', "sigmoid"),
+    (64, 2, 128, 200, 11, 3, 'half', "tanh"),          # filter too large for LDS -> global path
+])
+def test_conv1d_vs_oracle(oracle, T, B, Cin, Cout, w, s, mode, act):
+    need_gpu()
+    from sloika_amd import layers, activation
+    rs = np.random.RandomState(T + Cin + Cout)
+    x = rs.normal(size=(T, B, Cin)).astype(np.float32)
+    layer = layers.Convolution(Cin, Cout, w, s, has_bias=True, fun=getattr(activation, act), padding_mode=mode)
+    layer.set_params({"W": (rs.normal(size=(Cout, Cin, w)) * 0.3).astype(np.float32),
+                      "b": rs.normal(size=Cout).astype(np.float32)})
+    y = layer.compile()(x)
+    ref = oracle.run_network(layer.spec(), x)
+    assert y.shape == ref.shape
+    np.testing.assert_allclose(y, ref, atol=2e-5)
+
+
+def test_conv1d_chunk_major_input_equals_network_layout(oracle):
+    torch = need_gpu()
+    from sloika_amd import layers, activation
+    rs = np.random.RandomState(5)
+    chunks = rs.normal(size=(6, 500)).astype(np.float32)
+    layer = layers.Convolution(1, 16, 11, 5, has_bias=True, fun=activation.elu)
+    layer.set_params({"W": rs.normal(size=(16, 1, 11)).astype(np.float32) * 0.3, "b": rs.normal(size=16).astype(np.float32)})
+    cd = dev(chunks)
+    y1 = layer.run_strided(cd.data_ptr(), 500, 6, 1, 500, cd.device)
+    y2 = layer.run(dev(np.ascontiguousarray(chunks.T)[:, :, None]))
+    assert torch.equal(y1, y2)
+
+
+def test_window_exact(oracle):
+    need_gpu()
+    from sloika_amd import layers
+    x = np.random.RandomState(1).normal(size=(25, 2, 3)).astype(np.float32)
+    for w in (1, 3, 5):
+        y = layers.Window(3, w).compile()(x)
+        assert np.array_equal(y, oracle.window(x, w))
+    with pytest.raises(AssertionError):
+        layers.Window(3, 2)                            # layers.py:328-329
+
+
+def test_all_activations_vs_oracle(oracle):
+    need_gpu()
+    from sloika_amd import activation
+    x = np.linspace(-6, 6, 193).astype(np.float32)
+    for name in oracle.ACTIVATIONS:
+        y = getattr(activation, name)(x)
+        np.testing.assert_allclose(y, oracle.activation(name, x), rtol=2e-6, atol=2e-6, err_msg=name)

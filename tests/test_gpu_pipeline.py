@@ -1,0 +1,112 @@
+"""GPU parity of whole networks and of the end-to-end hot path, stage by stage against the oracle.
+
+Stage 1: posteriors within 1e-4 absolute of the oracle (north_star tolerance on fp32 layer outputs).
+Stage 2: the decoder run on the GPU's own posteriors is bit-identical to the oracle's decoder on the same numbers.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import GOLDEN
+from tests.gpu_util import need_gpu, dev, stream
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _check_end_to_end(oracle, net, chunks, klen=5, skip=0.0, tol=TOL):
+    torch = need_gpu()
+    from sloika_amd import _lib, pipeline
+    bc = pipeline.Basecaller(net, kmer_len=klen, skip=skip)
+    cd = dev(chunks)
+    post = bc.posteriors(cd)
+    x = oracle.med_mad_normalise(chunks)
+    ref = oracle.run_network(net.spec(), np.ascontiguousarray(x.T)[:, :, None])
+    assert post.shape == ref.shape
+    err = np.abs(post.cpu().numpy() - ref).max()
+    assert err < tol, "posterior max abs err %g" % err
+    scores, paths, lens = bc.call_chunks(cd)
+    lp = torch.empty_like(post)
+    _lib.check(_lib.lib().slk_log_post_f32(post.data_ptr(), lp.data_ptr(), post.numel(), _lib.POST_RAW, 1e-5, stream()))
+    o_scores, o_paths, o_lens = oracle.viterbi_batch(lp.cpu().numpy(), klen, skip_pen=skip)
+    assert np.array_equal(lens.cpu().numpy(), o_lens)
+    assert np.array_equal(paths.cpu().numpy(), o_paths)
+    assert np.array_equal(scores.cpu().numpy(), o_scores)
+    return err
+
+
+@pytest.mark.parametrize("name,nchunk,chunk_len", [("raw_0.98_rgrgr", 6, 1000), ("baseline_raw_gru", 5, 600),
+                                                   ("bigger_raw_gru", 3, 400), ("raw_1.00_rGr", 2, 300)])
+def test_raw_models_end_to_end(oracle, name, nchunk, chunk_len):
+    from sloika_amd import models, pipeline
+    net = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=21))
+    chunks = pipeline.synthetic_chunks(nchunk, chunk_len=chunk_len, seed=3)
+    _check_end_to_end(oracle, net, chunks)
+
+
+def test_pretrained_rgr_end_to_end(oracle):
+    """Trained weights of models/pretrained.pkl (|w| up to 6): the hard case for fp32 parity."""
+    from sloika_amd import models, pipeline
+    net = models.from_weights_npz(os.path.join(GOLDEN, "pretrained_weights.npz"))
+    chunks = pipeline.synthetic_chunks(4, chunk_len=1500, seed=5)
+    _check_end_to_end(oracle, net, chunks, skip=0.0)
+
+
+@pytest.mark.parametrize("name", ["tiny_gru", "baseline_gru", "baseline_lstm"])
+def test_event_models_posteriors(oracle, name):
+    """Events route (config 0 plumbing): Window front end, birnn, [T,1,4] features."""
+    need_gpu()
+    from sloika_amd import models
+    net = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=5))
+    x = np.random.RandomState(2).normal(size=(120, 2, 4)).astype(np.float32)
+    y = net.compile()(x)
+    ref = oracle.run_network(net.spec(), x)
+    assert y.shape == (120, 2, 1025)
+    np.testing.assert_allclose(y, ref, atol=TOL)
+    assert np.allclose(y.sum(axis=2), 1.0, atol=1e-5)
+
+
+def test_compile_contract_numpy_and_tensor(oracle):
+    """Layer.compile() -> callable(ndarray [T,B,F]) -> ndarray [T',B,size]  (layers.py:34-36)."""
+    torch = need_gpu()
+    from sloika_amd import models
+    net = models.build_model("raw_0.98_rgrgr", seed=2)
+    f = net.compile()
+    x = np.random.RandomState(0).normal(size=(250, 3, 1)).astype(np.float32)
+    y = f(x)
+    assert isinstance(y, np.ndarray) and y.dtype == np.float32 and y.shape == (50, 3, 1025)
+    yt = f(torch.from_numpy(x).cuda())
+    assert isinstance(yt, torch.Tensor) and yt.is_cuda
+    assert np.array_equal(yt.cpu().numpy(), y)
+
+
+def test_raw_chunk_worker_and_seqprinter(oracle, golden_bio, golden_decode):
+    """Worker tuple (name, score, call, n) of sloika/basecall.py:88-121 + SeqPrinter text (basecall.py:157-163)."""
+    import io
+    need_gpu()
+    from sloika_amd import models, pipeline, basecall
+    net = models.build_model("raw_0.98_rgrgr", seed=4)
+    chunks = pipeline.synthetic_chunks(3, chunk_len=500, seed=9)
+    res = basecall.raw_chunk_worker(net.compile(), chunks, 5, min_prob=1e-5, skip=0.0)
+    assert len(res) == 3 and all(len(r) == 4 and r[3] == 500 for r in res)
+    sp = basecall.SeqPrinter(5, datatype="samples", transducer=True, alphabet="ACGT")
+    sp.fh = io.StringIO()
+    g = golden_bio["seqprinter"]
+    nb = sp.write(g["read_name"], g["score"], [int(v) for v in golden_decode[g["path_key"]]], g["nev"])
+    assert sp.fh.getvalue() == g["text"] and nb == g["nbases"]
+
+
+def test_full_size_batch_properties():
+    """BASELINE config shape (4000-sample chunks, rgrgr) at B=64: results do not depend on batch composition
+    (each chunk decoded alone == decoded inside the batch), which is what makes read sharding exact."""
+    torch = need_gpu()
+    from sloika_amd import models, pipeline
+    net = models.build_model("raw_0.98_rgrgr", seed=8)
+    bc = pipeline.Basecaller(net)
+    chunks = pipeline.synthetic_chunks(64, chunk_len=4000, seed=1)
+    s_all, p_all, l_all = bc.call_chunks(dev(chunks))
+    assert p_all.shape == (64, 800)
+    for lo, hi in ((0, 4), (13, 14), (60, 64)):
+        s, p, l = bc.call_chunks(dev(chunks[lo:hi]))
+        assert torch.equal(p, p_all[lo:hi]) and torch.equal(l, l_all[lo:hi]) and torch.equal(s, s_all[lo:hi])

@@ -1,0 +1,115 @@
+"""GPU parity: Gru (MFMA 4x4x1 kernel and portable kernel) and Lstm vs the oracle, through the C ABI.
+
+Tolerance: 1e-4 absolute on layer outputs (BASELINE.json north_star); observed errors are ~1e-6.
+"""
+import numpy as np
+import pytest
+
+from tests.gpu_util import need_gpu, dev, stream
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _gru_params(rs, I, n, bias=True, scale=1.0):
+    iW = (rs.normal(size=(3 * n, I)) / np.sqrt(I + n)).astype(np.float32)
+    sW = (scale * rs.normal(size=(2 * n, n)) / np.sqrt(2 * n)).astype(np.float32)
+    sW2 = (scale * rs.normal(size=(n, n)) / np.sqrt(2 * n)).astype(np.float32)
+    b = rs.normal(size=3 * n).astype(np.float32) if bias else None
+    return iW, sW, sW2, b
+
+
+@pytest.mark.parametrize("n", [16, 32, 48, 64, 80, 96, 112, 128])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_gru_mfma_all_sizes(oracle, n, reverse):
+    torch = need_gpu()
+    from sloika_amd import _lib
+    rs = np.random.RandomState(n + reverse)
+    T, B = 23, 9                                  # ragged last tile of 4 chunks
+    iW, sW, sW2, b = _gru_params(rs, 12, n, scale=2.0)
+    x = rs.normal(size=(T, B, 12)).astype(np.float32)
+    vI = (x.astype(np.float64) @ iW.astype(np.float64).T + b).astype(np.float32)
+    ref = oracle.gru(x, iW, sW, sW2, b, reverse=reverse)
+    L = _lib.lib()
+    for force_generic in (0, 1):
+        y = torch.full((T, B, n), np.nan, dtype=torch.float32, device="cuda")
+        rc = L.slk_gru_recurrent_f32_ex(dev(vI).data_ptr(), dev(sW).data_ptr(), dev(sW2).data_ptr(), y.data_ptr(), n,
+                                        T, B, n, int(reverse), 1, 2, force_generic, stream())
+        assert rc == 0
+        np.testing.assert_allclose(y.cpu().numpy(), ref, atol=TOL, err_msg="generic=%d" % force_generic)
+
+
+@pytest.mark.parametrize("I,n,B,T", [(96, 96, 8, 60), (64, 64, 4, 50), (128, 112, 5, 40), (112, 144, 3, 30),
+                                     (144, 112, 3, 30), (128, 110, 2, 20), (12, 4, 2, 25), (7, 5, 1, 9)])
+def test_gru_layer_vs_oracle(oracle, I, n, B, T):
+    need_gpu()
+    from sloika_amd import layers
+    rs = np.random.RandomState(I + n)
+    iW, sW, sW2, b = _gru_params(rs, I, n, scale=2.0)
+    x = rs.normal(size=(T, B, I)).astype(np.float32)
+    g = layers.Gru(I, n, has_bias=True)
+    g.set_params({"iW": iW.reshape(3, n, I), "sW": sW.reshape(2, n, n), "sW2": sW2, "b": b.reshape(3, n)})
+    for net in (g, layers.Reverse(g)):
+        y = net.compile()(x)
+        ref = oracle.run_network(net.spec(), x)
+        np.testing.assert_allclose(y, ref, atol=TOL)
+
+
+def test_gru_other_activations_and_no_bias(oracle):
+    need_gpu()
+    from sloika_amd import layers, activation
+    rs = np.random.RandomState(9)
+    I, n, T, B = 10, 32, 15, 4
+    iW, sW, sW2, _ = _gru_params(rs, I, n, bias=False)
+    x = rs.normal(size=(T, B, I)).astype(np.float32)
+    g = layers.Gru(I, n, has_bias=False, fun=activation.retu, gatefun=activation.sigmoid_pm)
+    g.set_params({"iW": iW.reshape(3, n, I), "sW": sW.reshape(2, n, n), "sW2": sW2})
+    np.testing.assert_allclose(g.compile()(x), oracle.run_network(g.spec(), x), atol=TOL)
+
+
+def test_gru_strided_output_slice(oracle):
+    """birnn writes both directions into one concatenated tensor (layers.py:1486-1487, 1622-1629)."""
+    need_gpu()
+    from sloika_amd import layers
+    rs = np.random.RandomState(4)
+    I, n, T, B = 16, 64, 30, 6
+    x = rs.normal(size=(T, B, I)).astype(np.float32)
+    gs = []
+    for _ in range(2):
+        iW, sW, sW2, b = _gru_params(rs, I, n, scale=1.5)
+        g = layers.Gru(I, n, has_bias=True)
+        g.set_params({"iW": iW.reshape(3, n, I), "sW": sW.reshape(2, n, n), "sW2": sW2, "b": b.reshape(3, n)})
+        gs.append(g)
+    net = layers.birnn(gs[0], gs[1])
+    y = net.compile()(x)
+    assert y.shape == (T, B, 2 * n)
+    np.testing.assert_allclose(y, oracle.run_network(net.spec(), x), atol=TOL)
+
+
+@pytest.mark.parametrize("I,n,bias,peep", [(12, 64, True, True), (5, 16, False, False), (64, 96, True, False), (3, 7, True, True)])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_lstm_vs_oracle(oracle, I, n, bias, peep, reverse):
+    need_gpu()
+    from sloika_amd import layers
+    rs = np.random.RandomState(I * 10 + n)
+    T, B = 20, 3
+    x = rs.normal(size=(T, B, I)).astype(np.float32)
+    l = layers.Lstm(I, n, has_bias=bias, has_peep=peep)
+    l.iW.set_value((rs.normal(size=(4 * n, I)) / np.sqrt(I + n)).astype(np.float32))
+    l.sW.set_value((rs.normal(size=(4 * n, n)) / np.sqrt(2 * n)).astype(np.float32))
+    if bias:
+        l.b.set_value(rs.normal(size=4 * n).astype(np.float32))
+    if peep:
+        l.p.set_value((rs.normal(size=(3, n)) / np.sqrt(n)).astype(np.float32))
+    net = layers.Reverse(l) if reverse else l
+    np.testing.assert_allclose(net.compile()(x), oracle.run_network(net.spec(), x), atol=TOL)
+
+
+def test_layer_input_validation():
+    torch = need_gpu()
+    from sloika_amd import layers
+    g = layers.Gru(4, 16)
+    with pytest.raises(ValueError):
+        g.run(torch.zeros((5, 2, 3), device="cuda"))           # wrong feature count
+    with pytest.raises(ValueError):
+        g.run(torch.zeros((5, 2, 4)))                          # not on the device
