@@ -58,7 +58,8 @@ def test_gemm_bias_act_vs_float64(M, K, N, act):
     W = (rs.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
     b = rs.normal(size=N).astype(np.float32)
     y = torch.empty((M, N), dtype=torch.float32, device="cuda")
-    rc = _lib.lib().slk_gemm_bias_act_f32(dev(x).data_ptr(), K, dev(W).data_ptr(), dev(b).data_ptr(), y.data_ptr(), N,
+    xd, Wd, bd = dev(x), dev(W), dev(b)            # keep the device buffers alive across the call
+    rc = _lib.lib().slk_gemm_bias_act_f32(xd.data_ptr(), K, Wd.data_ptr(), bd.data_ptr(), y.data_ptr(), N,
                                           M, K, N, {"linear": 0, "tanh": 1, "sigmoid": 2}[act], stream())
     assert rc == 0
     ref = oracle_np.ACT[act](x.astype(np.float64) @ W.astype(np.float64).T + b)
@@ -72,10 +73,10 @@ def test_gemm_strided_rows_and_no_bias():
     M, K, N = 70, 40, 50
     xbig = rs.normal(size=(M, K + 24)).astype(np.float32)
     W = rs.normal(size=(N, K)).astype(np.float32)
-    xd = dev(xbig)
+    xd, Wd = dev(xbig), dev(W)
     ybig = torch.full((M, N + 14), -7.0, dtype=torch.float32, device="cuda")
     # read columns [8, 8+K) of x, write columns [6, 6+N) of y
-    rc = _lib.lib().slk_gemm_bias_act_f32(xd.data_ptr() + 8 * 4, K + 24, dev(W).data_ptr(), None,
+    rc = _lib.lib().slk_gemm_bias_act_f32(xd.data_ptr() + 8 * 4, K + 24, Wd.data_ptr(), None,
                                           ybig.data_ptr() + 6 * 4, N + 14, M, K, N, 0, stream())
     assert rc == 0
     out = ybig.cpu().numpy()

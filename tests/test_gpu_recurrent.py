@@ -31,9 +31,10 @@ def test_gru_mfma_all_sizes(oracle, n, reverse):
     vI = (x.astype(np.float64) @ iW.astype(np.float64).T + b).astype(np.float32)
     ref = oracle.gru(x, iW, sW, sW2, b, reverse=reverse)
     L = _lib.lib()
+    vId, sWd, sW2d = dev(vI), dev(sW), dev(sW2)   # keep the device buffers alive across the calls
     for force_generic in (0, 1):
         y = torch.full((T, B, n), np.nan, dtype=torch.float32, device="cuda")
-        rc = L.slk_gru_recurrent_f32_ex(dev(vI).data_ptr(), dev(sW).data_ptr(), dev(sW2).data_ptr(), y.data_ptr(), n,
+        rc = L.slk_gru_recurrent_f32_ex(vId.data_ptr(), sWd.data_ptr(), sW2d.data_ptr(), y.data_ptr(), n,
                                         T, B, n, int(reverse), 1, 2, force_generic, stream())
         assert rc == 0
         np.testing.assert_allclose(y.cpu().numpy(), ref, atol=TOL, err_msg="generic=%d" % force_generic)
