@@ -16,7 +16,33 @@
 #define GEMM_BK 32
 #define GEMM_LDS_LD 36
 
-template <int NT, bool ALIGNED>
+// 4 consecutive k of one row, zero beyond K or when !ok.  `row` must point at a readable row.
+template <bool ALIGNED>
+__device__ __forceinline__ float4 load_row4(const float *row, int gk, int K, bool ok)
+{
+    float4 v;
+    if (ALIGNED) {                       // K % 4 == 0: a float4 is entirely inside or entirely outside
+        bool in = ok && gk < K;
+        v = *reinterpret_cast<const float4 *>(row + (gk < K ? gk : 0));
+        if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bool in = ok && gk + j < K;
+            float t = row[gk + j < K ? gk + j : 0];
+            e[j] = in ? t : 0.0f;
+        }
+        v = make_float4(e[0], e[1], e[2], e[3]);
+    }
+    return v;
+}
+
+// out-of-line so that the rarely used activations are not inlined 48 times into every epilogue
+__device__ __noinline__ float gemm_act_generic(int act, float x) { return slk_act(act, x); }
+
+// ACT: compile-time activation id for the common cases, -1 = runtime `act` through gemm_act_generic
+template <int NT, bool ALIGNED, int ACT>
 __global__ void __launch_bounds__(256) gemm_bias_act_kernel(const float *__restrict__ x, long ldx,
                                                             const float *__restrict__ W,
                                                             const float *__restrict__ bias, float *__restrict__ y,
@@ -38,43 +64,34 @@ __global__ void __launch_bounds__(256) gemm_bias_act_kernel(const float *__restr
 
     for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
         // ---- stage x[128][32] and W[BN][32] slabs (zero filled outside M/N/K) ----
+        // All global loads are issued back to back from clamped (always valid) addresses and masked afterwards:
+        // no branches, so the compiler keeps every load in flight instead of waiting on each one in turn.
+        constexpr int XL = (GEMM_BM * GEMM_BK / 4) / 256;               // float4 loads per thread for x
+        constexpr int WL = (BN * GEMM_BK / 4 + 255) / 256;              // ... for W
+        float4 xv[XL], wv[WL];
 #pragma unroll
-        for (int i = 0; i < (GEMM_BM * GEMM_BK / 4) / 256; i++) {
+        for (int i = 0; i < XL; i++) {
             int idx = tid + 256 * i, row = idx >> 3, c4 = (idx & 7) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             long gr = m0 + row;
             int gk = k0 + c4;
-            if (gr < M) {
-                const float *p = x + gr * ldx + gk;
-                if (ALIGNED && gk + 3 < K) v = *reinterpret_cast<const float4 *>(p);
-                else {
-                    if (gk < K) v.x = p[0];
-                    if (gk + 1 < K) v.y = p[1];
-                    if (gk + 2 < K) v.z = p[2];
-                    if (gk + 3 < K) v.w = p[3];
-                }
-            }
-            *reinterpret_cast<float4 *>(&xs[row * GEMM_LDS_LD + c4]) = v;
+            xv[i] = load_row4<ALIGNED>(x + (gr < M ? gr : M - 1) * ldx, gk, K, gr < M);
         }
 #pragma unroll
-        for (int i = 0; i < (BN * GEMM_BK / 4 + 255) / 256; i++) {
-            int idx = tid + 256 * i;
-            if (idx < BN * GEMM_BK / 4) {
-                int row = idx >> 3, c4 = (idx & 7) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                int gn = n0 + row, gk = k0 + c4;
-                if (gn < N) {
-                    const float *p = W + (size_t)gn * K + gk;
-                    if (ALIGNED && gk + 3 < K) v = *reinterpret_cast<const float4 *>(p);
-                    else {
-                        if (gk < K) v.x = p[0];
-                        if (gk + 1 < K) v.y = p[1];
-                        if (gk + 2 < K) v.z = p[2];
-                        if (gk + 3 < K) v.w = p[3];
-                    }
-                }
-                *reinterpret_cast<float4 *>(&ws[row * GEMM_LDS_LD + c4]) = v;
-            }
+        for (int i = 0; i < WL; i++) {
+            int idx = tid + 256 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+            int gn = n0 + row, gk = k0 + c4;
+            bool ok = idx < BN * GEMM_BK / 4 && gn < N;
+            wv[i] = load_row4<ALIGNED>(W + (size_t)(gn < N ? gn : N - 1) * K, gk, K, ok);
+        }
+#pragma unroll
+        for (int i = 0; i < XL; i++) {
+            int idx = tid + 256 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+            *reinterpret_cast<float4 *>(&xs[row * GEMM_LDS_LD + c4]) = xv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WL; i++) {
+            int idx = tid + 256 * i, row = idx >> 3, c4 = (idx & 7) * 4;
+            if (idx < BN * GEMM_BK / 4) *reinterpret_cast<float4 *>(&ws[row * GEMM_LDS_LD + c4]) = wv[i];
         }
         __syncthreads();
         // ---- 16 k-steps of 32x32x2 per accumulator ----
@@ -104,7 +121,12 @@ __global__ void __launch_bounds__(256) gemm_bias_act_kernel(const float *__restr
 #pragma unroll
         for (int reg = 0; reg < 16; reg++) {
             long row = m0 + 32 * wave + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            if (row < M) y[row * ldy + col] = slk_act(act, acc[nt][reg] + bv);
+            if (row < M) {
+                float v = acc[nt][reg] + bv;
+                if constexpr (ACT >= 0) v = slk_act_t<ACT>(v);
+                else v = gemm_act_generic(act, v);
+                y[row * ldy + col] = v;
+            }
         }
     }
 }
@@ -119,12 +141,19 @@ static int launch_gemm(const float *x, long ldx, const float *W, const float *bi
     if (blocks > 0x7fffffffL) return SLK_ERR_UNSUPPORTED;
     bool aligned = (ldx % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(W) & 15) == 0);
-    if (aligned)
-        hipLaunchKernelGGL((gemm_bias_act_kernel<NT, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, W, bias, y,
-                           ldy, M, K, N, act, ntile_n);
-    else
-        hipLaunchKernelGGL((gemm_bias_act_kernel<NT, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, W, bias,
-                           y, ldy, M, K, N, act, ntile_n);
+#define GEMM_LAUNCH(AL, AC)                                                                                   \
+    hipLaunchKernelGGL((gemm_bias_act_kernel<NT, AL, AC>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, W, bias, y, \
+                       ldy, M, K, N, act, ntile_n)
+    if (aligned) {
+        if (act == SLK_ACT_LINEAR) GEMM_LAUNCH(true, SLK_ACT_LINEAR);
+        else if (act == SLK_ACT_TANH) GEMM_LAUNCH(true, SLK_ACT_TANH);
+        else GEMM_LAUNCH(true, -1);
+    } else {
+        if (act == SLK_ACT_LINEAR) GEMM_LAUNCH(false, SLK_ACT_LINEAR);
+        else if (act == SLK_ACT_TANH) GEMM_LAUNCH(false, SLK_ACT_TANH);
+        else GEMM_LAUNCH(false, -1);
+    }
+#undef GEMM_LAUNCH
     return slk_launch_status();
 }
 

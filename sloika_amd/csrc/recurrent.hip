@@ -113,14 +113,27 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
 
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
-// acc0/acc1 alternate so that consecutive MFMAs never depend on each other.
+// Four accumulators in rotation: a 4x4x1 MFMA occupies the pipe for 8 cycles but its result is only readable as
+// the next SrcC a few wait states later; with 4 independent chains no s_nop padding is needed.
 template <int CB, int G, int... Is>
-__device__ __forceinline__ void mfma_chain(const float *hp, const float *w, f32x4 &acc0, f32x4 &acc1,
+__device__ __forceinline__ void mfma_chain(const float *hp, const float *w, f32x4 (&acc)[4],
                                            std::integer_sequence<int, Is...>)
 {
-    (((Is & 1) ? (void)(acc1 = mfma4<CB, Is % G>(hp[Is / G], w[Is], acc1))
-               : (void)(acc0 = mfma4<CB, Is % G>(hp[Is / G], w[Is], acc0))),
-     ...);
+    ((acc[Is & 3] = mfma4<CB, Is % G>(hp[Is / G], w[Is], acc[Is & 3])), ...);
+}
+
+// Workgroup barrier for the LDS state exchange that does NOT drain global memory traffic: __syncthreads() would
+// emit s_waitcnt vmcnt(0) and stall every step on the h_out stores and on the vI prefetch issued for the next step.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// lane l and lane l^32 exchanged with one VALU op (v_permlane32_swap) instead of a ds_bpermute round trip
+__device__ __forceinline__ float xor32_sum(float v)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 template <int S>
@@ -132,7 +145,7 @@ __device__ __forceinline__ f32x4 sum_slices(f32x4 v)
     }
     if constexpr (S >= 2) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] += __shfl_xor(v[i], 32);
+        for (int i = 0; i < 4; i++) v[i] = xor32_sum(v[i]);
     }
     return v;
 }
@@ -145,7 +158,7 @@ __device__ __forceinline__ float act_sel(int act, float x)
 }
 
 // N: layer size (multiple of 16, <= 128).  ACT/GACT: compile-time activation ids, or -1 to use the runtime ids.
-template <int N, int ACT, int GACT>
+template <int N, int ACT, int GACT, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restrict__ vI, const float *__restrict__ sW,
                                                           const float *__restrict__ sW2, float *__restrict__ h_out,
                                                           long ldh, int T, int B, int reverse, int act, int gate_act)
@@ -201,58 +214,79 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
 #pragma unroll
     for (int i = 0; i < 4; i++) bi[i] = min(b0 + i, B - 1);
 
+    // Raw prefetch: every lane loads from an always-valid address and NOTHING touches the values until the next
+    // step (the lane-role masks are applied at the point of use), so the loads stay in flight for a whole step.
     auto load_vI = [&](int t, float (&zr)[4], float (&c)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const float *row = vI + ((size_t)t * B + bi[i]) * (3 * N);
-            zr[i] = (validA && ga == 0) ? row[rowA] : 0.0f;
-            c[i] = zlane ? row[2 * N + neuronB] : 0.0f;
+            zr[i] = row[rowA];
+            c[i] = row[2 * N + neuronB];
         }
     };
+    const float mask_zr = (validA && ga == 0) ? 1.0f : 0.0f;   // K-slice lanes start their accumulators at 0
+    const float mask_c = zlane ? 1.0f : 0.0f;
 
-    float cur_zr[4], cur_c[4], nxt_zr[4], nxt_c[4];
-    load_vI(reverse ? T - 1 : 0, cur_zr, cur_c);
+    // Global-memory schedule of one step (all vector memory ops share one in-order counter on gfx950):
+    //   top of step s:  consume vI(s)   -> the only vmcnt wait of the step; everything it can wait on (the prefetch
+    //                                      and the h store issued at the top of step s-1) is a full step old
+    //                   store  h(s-1)   -> delayed by one step so that it is never younger than a needed load
+    //                   prefetch vI(s+1)
+    float pre_zr[4], pre_c[4];
+    load_vI(reverse ? T - 1 : 0, pre_zr, pre_c);
+    f32x4 h_prev = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     for (int s = 0; s < T; s++) {
         const int t = reverse ? T - 1 - s : s;
-        if (s + 1 < T) load_vI(reverse ? t - 1 : t + 1, nxt_zr, nxt_c);
+        f32x4 a0 = {pre_zr[0] * mask_zr, pre_zr[1] * mask_zr, pre_zr[2] * mask_zr, pre_zr[3] * mask_zr};
+        f32x4 c0 = {pre_c[0] * mask_c, pre_c[1] * mask_c, pre_c[2] * mask_c, pre_c[3] * mask_c};
+        // compiler fence: the consumption above stays above, the store/prefetch below stay below
+        asm volatile("" : "+v"(a0), "+v"(c0)::"memory");
+        if (s > 0 && zlane && ABL != 2) {
+            const int tp = reverse ? t + 1 : t - 1;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (b0 + i < B) h_out[((size_t)tp * B + b0 + i) * ldh + neuronB] = h_prev[i];
+        }
+        if (s + 1 < T && ABL != 1) load_vI(reverse ? t - 1 : t + 1, pre_zr, pre_c);
+        asm volatile("" ::: "memory");
 
         // ---------------- phase A: z | r ----------------
         float hp[NV];
 #pragma unroll
         for (int v = 0; v < NV; v++) hp[v] = hbuf[addrA0 + 4 * v * GA];
         const f32x4 hown = *reinterpret_cast<const f32x4 *>(&hbuf[4 * neuronA]);
-        f32x4 a0 = {cur_zr[0], cur_zr[1], cur_zr[2], cur_zr[3]}, a1 = {0.f, 0.f, 0.f, 0.f};
-        mfma_chain<CBA, GA>(hp, wA, a0, a1, std::make_integer_sequence<int, MA>{});
-        f32x4 g = sum_slices<SA>(a0 + a1);
+        f32x4 accA[4] = {a0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        mfma_chain<CBA, GA>(hp, wA, accA, std::make_integer_sequence<int, MA>{});
+        f32x4 g = sum_slices<SA>((accA[0] + accA[1]) + (accA[2] + accA[3]));
 #pragma unroll
         for (int i = 0; i < 4; i++) g[i] = act_sel<GACT>(gate_act, g[i]);
         if (rlane) *reinterpret_cast<f32x4 *>(&rhbuf[4 * neuronA]) = g * hown;
-        __syncthreads();
+        lds_barrier();
 
         // ---------------- phase B: candidate ----------------
         float rp[NV];
 #pragma unroll
         for (int v = 0; v < NV; v++) rp[v] = rhbuf[addrB0 + 4 * v * GB];
-        f32x4 c0 = {cur_c[0], cur_c[1], cur_c[2], cur_c[3]}, c1 = {0.f, 0.f, 0.f, 0.f};
-        mfma_chain<CBB, GB>(rp, wB, c0, c1, std::make_integer_sequence<int, MB>{});
-        f32x4 cc = sum_slices<SB>(c0 + c1);
+        f32x4 accB[4] = {c0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        mfma_chain<CBB, GB>(rp, wB, accB, std::make_integer_sequence<int, MB>{});
+        f32x4 cc = sum_slices<SB>((accB[0] + accB[1]) + (accB[2] + accB[3]));
         if (zlane) {
-            f32x4 hn;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float hbar = act_sel<ACT>(act, cc[i]);
-                hn[i] = g[i] * hown[i] + (1.0f - g[i]) * hbar;      // layers.py:1020
+                h_prev[i] = g[i] * hown[i] + (1.0f - g[i]) * hbar;      // layers.py:1020
             }
-            *reinterpret_cast<f32x4 *>(&hbuf[4 * neuronB]) = hn;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (b0 + i < B) h_out[((size_t)t * B + b0 + i) * ldh + neuronB] = hn[i];
+            *reinterpret_cast<f32x4 *>(&hbuf[4 * neuronB]) = h_prev;
         }
+        lds_barrier();
+    }
+    if (zlane) {
+        const int tl = reverse ? 0 : T - 1;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { cur_zr[i] = nxt_zr[i]; cur_c[i] = nxt_c[i]; }
-        __syncthreads();
+        for (int i = 0; i < 4; i++)
+            if (b0 + i < B) h_out[((size_t)tl * B + b0 + i) * ldh + neuronB] = h_prev[i];
     }
 }
 
@@ -278,6 +312,16 @@ extern "C" int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const 
         !slk_act_valid(gate_act))
         return SLK_ERR_INVALID_ARG;
     hipStream_t s = slk_stream(stream);
+    if (force_generic >= 2 && n == 96) {      // timing-only ablations (wrong results): 2 = no vI prefetch, 3 = no h store
+        dim3 grid((B + 3) / 4), block(256);
+        if (force_generic == 2)
+            hipLaunchKernelGGL((gru_mfma_kernel<96, SLK_ACT_TANH, SLK_ACT_SIGMOID, 1>), grid, block, 0, s, vI, sW, sW2, h_out,
+                               ldh, T, B, reverse, act, gate_act);
+        else
+            hipLaunchKernelGGL((gru_mfma_kernel<96, SLK_ACT_TANH, SLK_ACT_SIGMOID, 2>), grid, block, 0, s, vI, sW, sW2, h_out,
+                               ldh, T, B, reverse, act, gate_act);
+        return slk_launch_status();
+    }
     if (!force_generic) {
         switch (n) {
         case 16: return launch_gru_mfma<16>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
