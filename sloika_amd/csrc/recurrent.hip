@@ -158,7 +158,7 @@ __device__ __forceinline__ float act_sel(int act, float x)
 }
 
 // N: layer size (multiple of 16, <= 128).  ACT/GACT: compile-time activation ids, or -1 to use the runtime ids.
-template <int N, int ACT, int GACT, int ABL = 0>
+template <int N, int ACT, int GACT>
 __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restrict__ vI, const float *__restrict__ sW,
                                                           const float *__restrict__ sW2, float *__restrict__ h_out,
                                                           long ldh, int T, int B, int reverse, int act, int gate_act)
@@ -173,8 +173,16 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
     constexpr int NV = N / 16;                                      // packed state registers
     static_assert(N % 16 == 0 && N <= 128, "unsupported GRU size for the MFMA kernel");
 
-    __shared__ __attribute__((aligned(16))) float hbuf[N * 4];   // h[k][chunk]
-    __shared__ __attribute__((aligned(16))) float rhbuf[N * 4];  // (r*h)[k][chunk]
+    constexpr int KB = 8;                       // time steps of vI staged per LDS block
+    constexpr int ROWF4 = 3 * N / 4;            // float4 per (step, chunk) row of vI
+    constexpr int BLKF4 = KB * 4 * ROWF4;       // float4 per staged block (a multiple of 64)
+    constexpr int NDMA = (BLKF4 / 64 + 3) / 4;  // 1-KiB LDS-DMA instructions per wave per block
+    constexpr int BLKF = KB * 4 * 3 * N;        // floats per block
+
+    __shared__ __attribute__((aligned(16))) float vbuf[2 * BLKF];          // vI[2][step in block][chunk][3N]
+    __shared__ __attribute__((aligned(16))) float obuf[2 * KB * 4 * N];    // h_out[2][step in block][chunk][N]
+    __shared__ __attribute__((aligned(16))) float hbuf[N * 4];             // h[k][chunk]
+    __shared__ __attribute__((aligned(16))) float rhbuf[N * 4];            // (r*h)[k][chunk]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
@@ -209,53 +217,70 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
 
     for (int i = tid; i < N * 4; i += 256) hbuf[i] = 0.0f;
 
-    // chunk rows (clamped for a ragged last tile)
-    int bi[4];
+    // The input projection vI is streamed HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+    // instruction, no registers), one block of KB time steps at a time into a 2-deep ring; block k+2 is issued as
+    // soon as block k has been consumed, so a whole block of compute (KB steps) hides the HBM latency and nothing
+    // on the per-step path touches global memory except the h_out stores.
+    auto dma_block = [&](int s0, int slot) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) bi[i] = min(b0 + i, B - 1);
-
-    // Raw prefetch: every lane loads from an always-valid address and NOTHING touches the values until the next
-    // step (the lane-role masks are applied at the point of use), so the loads stay in flight for a whole step.
-    auto load_vI = [&](int t, float (&zr)[4], float (&c)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float *row = vI + ((size_t)t * B + bi[i]) * (3 * N);
-            zr[i] = row[rowA];
-            c[i] = row[2 * N + neuronB];
+        for (int j = 0; j < NDMA; j++) {
+            const int piece = j * 4 + wave;                    // 64 float4 = 1 KiB of the block image
+            if (piece * 64 < BLKF4) {                          // wave-uniform
+                const int idx = piece * 64 + lane;
+                const int kk = idx / (4 * ROWF4), r = idx % (4 * ROWF4), c = r / ROWF4, f4 = r % ROWF4;
+                const int ss = min(s0 + kk, T - 1);
+                const int tt = reverse ? T - 1 - ss : ss;
+                const int bc = min(b0 + c, B - 1);
+                const float *src = vI + ((size_t)tt * B + bc) * (3 * N) + 4 * f4;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)&vbuf[slot * BLKF + piece * 256],
+                                                 16, 0, 0);
+            }
         }
     };
+    // h_out goes the other way through a second 2-deep LDS ring: per step each owner lane drops its 4 values into
+    // the ring (4 ds_write_b32), and once per KB steps the whole workgroup flushes the finished block with 16-byte
+    // coalesced stores -- instead of 16 partial-line store instructions per workgroup on every step.
+    auto flush_block = [&](int s0, int slot) {
+        constexpr int OF4 = KB * 4 * N / 4;                    // float4 per output block
+#pragma unroll
+        for (int j = 0; j < (OF4 + 255) / 256; j++) {
+            const int idx = tid + 256 * j;
+            const int kk = idx / N, r = idx % N, c = r / (N / 4), f4 = r % (N / 4);
+            const int ss = s0 + kk;
+            if (idx < OF4 && ss < T && b0 + c < B) {
+                const int tt = reverse ? T - 1 - ss : ss;
+                const float4 v = *reinterpret_cast<const float4 *>(&obuf[slot * (KB * 4 * N) + 4 * idx]);
+                float *dst = h_out + ((size_t)tt * B + b0 + c) * ldh + 4 * f4;
+                if (vec_store) *reinterpret_cast<float4 *>(dst) = v;
+                else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+            }
+        }
+    };
+    const bool vec_store = (ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
     const float mask_zr = (validA && ga == 0) ? 1.0f : 0.0f;   // K-slice lanes start their accumulators at 0
     const float mask_c = zlane ? 1.0f : 0.0f;
 
-    // Global-memory schedule of one step (all vector memory ops share one in-order counter on gfx950):
-    //   top of step s:  consume vI(s)   -> the only vmcnt wait of the step; everything it can wait on (the prefetch
-    //                                      and the h store issued at the top of step s-1) is a full step old
-    //                   store  h(s-1)   -> delayed by one step so that it is never younger than a needed load
-    //                   prefetch vI(s+1)
-    float pre_zr[4], pre_c[4];
-    load_vI(reverse ? T - 1 : 0, pre_zr, pre_c);
-    f32x4 h_prev = {0.f, 0.f, 0.f, 0.f};
+    dma_block(0, 0);
+    if (T > KB) dma_block(KB, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int s = 0; s < T; s++) {
-        const int t = reverse ? T - 1 - s : s;
-        f32x4 a0 = {pre_zr[0] * mask_zr, pre_zr[1] * mask_zr, pre_zr[2] * mask_zr, pre_zr[3] * mask_zr};
-        f32x4 c0 = {pre_c[0] * mask_c, pre_c[1] * mask_c, pre_c[2] * mask_c, pre_c[3] * mask_c};
-        // compiler fence: the consumption above stays above, the store/prefetch below stay below
-        asm volatile("" : "+v"(a0), "+v"(c0)::"memory");
-        if (s > 0 && zlane && ABL != 2) {
-            const int tp = reverse ? t + 1 : t - 1;
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (b0 + i < B) h_out[((size_t)tp * B + b0 + i) * ldh + neuronB] = h_prev[i];
-        }
-        if (s + 1 < T && ABL != 1) load_vI(reverse ? t - 1 : t + 1, pre_zr, pre_c);
-        asm volatile("" ::: "memory");
+        const int kk = s % KB, kb = s / KB;
+        const float *vrow = vbuf + (kb & 1) * BLKF + kk * (4 * 3 * N);
+        if (kk == 0 && s > 0) flush_block(s - KB, (kb - 1) & 1);     // previous block is complete and published
 
         // ---------------- phase A: z | r ----------------
         float hp[NV];
 #pragma unroll
         for (int v = 0; v < NV; v++) hp[v] = hbuf[addrA0 + 4 * v * GA];
+        f32x4 a0, c0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            a0[i] = vrow[i * 3 * N + rowA] * mask_zr;
+            c0[i] = vrow[i * 3 * N + 2 * N + neuronB] * mask_c;
+        }
         const f32x4 hown = *reinterpret_cast<const f32x4 *>(&hbuf[4 * neuronA]);
         f32x4 accA[4] = {a0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         mfma_chain<CBA, GA>(hp, wA, accA, std::make_integer_sequence<int, MA>{});
@@ -263,7 +288,10 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
 #pragma unroll
         for (int i = 0; i < 4; i++) g[i] = act_sel<GACT>(gate_act, g[i]);
         if (rlane) *reinterpret_cast<f32x4 *>(&rhbuf[4 * neuronA]) = g * hown;
+        if (kk == KB - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next block's DMA (issued KB steps ago) landed
         lds_barrier();
+        // every wave has finished reading the current block: its ring slot takes the block after next
+        if (kk == KB - 1 && s + 1 + KB < T) dma_block(s + 1 + KB, kb & 1);
 
         // ---------------- phase B: candidate ----------------
         float rp[NV];
@@ -273,21 +301,20 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
         mfma_chain<CBB, GB>(rp, wB, accB, std::make_integer_sequence<int, MB>{});
         f32x4 cc = sum_slices<SB>((accB[0] + accB[1]) + (accB[2] + accB[3]));
         if (zlane) {
+            f32x4 hn;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float hbar = act_sel<ACT>(act, cc[i]);
-                h_prev[i] = g[i] * hown[i] + (1.0f - g[i]) * hbar;      // layers.py:1020
+                hn[i] = g[i] * hown[i] + (1.0f - g[i]) * hbar;      // layers.py:1020
             }
-            *reinterpret_cast<f32x4 *>(&hbuf[4 * neuronB]) = h_prev;
+            *reinterpret_cast<f32x4 *>(&hbuf[4 * neuronB]) = hn;
+            float *orow = obuf + (kb & 1) * (KB * 4 * N) + kk * (4 * N) + neuronB;
+#pragma unroll
+            for (int i = 0; i < 4; i++) orow[i * N] = hn[i];
         }
         lds_barrier();
     }
-    if (zlane) {
-        const int tl = reverse ? 0 : T - 1;
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (b0 + i < B) h_out[((size_t)tl * B + b0 + i) * ldh + neuronB] = h_prev[i];
-    }
+    flush_block(((T - 1) / KB) * KB, ((T - 1) / KB) & 1);
 }
 
 template <int N>
@@ -312,16 +339,6 @@ extern "C" int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const 
         !slk_act_valid(gate_act))
         return SLK_ERR_INVALID_ARG;
     hipStream_t s = slk_stream(stream);
-    if (force_generic >= 2 && n == 96) {      // timing-only ablations (wrong results): 2 = no vI prefetch, 3 = no h store
-        dim3 grid((B + 3) / 4), block(256);
-        if (force_generic == 2)
-            hipLaunchKernelGGL((gru_mfma_kernel<96, SLK_ACT_TANH, SLK_ACT_SIGMOID, 1>), grid, block, 0, s, vI, sW, sW2, h_out,
-                               ldh, T, B, reverse, act, gate_act);
-        else
-            hipLaunchKernelGGL((gru_mfma_kernel<96, SLK_ACT_TANH, SLK_ACT_SIGMOID, 2>), grid, block, 0, s, vI, sW, sW2, h_out,
-                               ldh, T, B, reverse, act, gate_act);
-        return slk_launch_status();
-    }
     if (!force_generic) {
         switch (n) {
         case 16: return launch_gru_mfma<16>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);

@@ -39,7 +39,7 @@ def main():
         sW = torch.randn(2 * n, n, device="cuda") / np.sqrt(2 * n)
         sW2 = torch.randn(n, n, device="cuda") / np.sqrt(2 * n)
         y = torch.empty(T, B, n, device="cuda")
-        for generic in (0, 2, 3):
+        for generic in (0,):
             ms = timeit(lambda: L.slk_gru_recurrent_f32_ex(vI.data_ptr(), sW.data_ptr(), sW2.data_ptr(), y.data_ptr(), n, T, B,
                                                            n, 0, 1, 2, generic, st))
             fl = 6.0 * T * B * n * n
