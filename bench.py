@@ -37,30 +37,37 @@ def parse():
     ap.add_argument("--model", default="raw_0.98_rgrgr")
     ap.add_argument("--batch", type=int, default=1024, help="chunks per GPU per step")
     ap.add_argument("--chunk-len", type=int, default=4000)
-    ap.add_argument("--cpu-chunks", type=int, default=16, help="chunks in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-chunks", type=int, default=256,
+                    help="chunks per slab of the CPU-baseline sample (slabs repeat until ~12 s; 0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(model_name, chunk_len, nchunk):
-    """The oracle (CPU port of the same pipeline) on the host cores, bounded sample."""
+def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
+    """The oracle (CPU port of the same pipeline: C + OpenMP over chunks) on the host cores of this box.
+    Bounded sample: slabs of `slab` chunks of the same synthetic workload until ~budget_s seconds of CPU work."""
     from oracle import oracle as orc
     from sloika_amd import models, pipeline
     orc.build()
     net = models.randomise_zero_layers(models.build_model(model_name, klen=5, sd=0.5, seed=11))
     spec = net.spec()
-    chunks = pipeline.synthetic_chunks(nchunk, chunk_len=chunk_len, seed=123)
     cores = orc.num_threads()
-    t0 = time.perf_counter()
-    x = orc.med_mad_normalise(chunks)
-    post = orc.run_network(spec, np.ascontiguousarray(x.T)[:, :, None])
-    T, B, S = post.shape
-    lp = np.log(np.float32(1e-5) + np.float32(1.0 - 1e-5) * post + np.float32(1e-10))
-    orc.viterbi_batch(lp, 5, skip_pen=0.0)
-    dt = time.perf_counter() - t0
-    return {"value": nchunk * chunk_len / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d chunks x %d samples of the same synthetic workload, oracle C port (OpenMP over chunks), "
-                      "%.1f s" % (nchunk, chunk_len, dt)}
+    done, spent = 0, 0.0
+    for i in range(max_slabs):
+        chunks = pipeline.synthetic_chunks(slab, chunk_len=chunk_len, seed=123, first_chunk=i * slab)
+        t0 = time.perf_counter()
+        x = orc.med_mad_normalise(chunks)
+        post = orc.run_network(spec, np.ascontiguousarray(x.T)[:, :, None])
+        lp = np.log(np.float32(1e-5) + np.float32(1.0 - 1e-5) * post + np.float32(1e-10))
+        orc.viterbi_batch(lp, 5, skip_pen=0.0)
+        spent += time.perf_counter() - t0
+        done += slab
+        del post, lp
+        if spent >= budget_s:
+            break
+    return {"value": done * chunk_len / spent, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d chunks x %d samples of the same synthetic workload through the oracle C port "
+                      "(OpenMP over chunks, %d threads), %.1f s" % (done, chunk_len, cores, spent)}
 
 
 def main():
