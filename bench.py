@@ -26,7 +26,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_*_f32 = the
 HBM_PEAK_GBS = 8000.0              # spec; ~6300 achievable
 
 # GEMM-like flops per raw sample -- used for the end-to-end MFMA fraction
-MFMA_STAGES = ("gru_recurrent", "gru_input_gemm", "softmax_gemm", "gemm_bias_act", "conv1d")
+MFMA_STAGES = ("gru_fused", "gru_recurrent", "gru_input_gemm", "softmax_gemm", "gemm_bias_act", "conv1d")
 
 
 def parse():

@@ -137,6 +137,12 @@ size_t slk_gru_workspace_bytes(int T, int B, int n);
 int slk_gru_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                 float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                 void *workspace, size_t workspace_bytes, slk_stream_t stream);
+/* Whole layer in one persistent kernel (projection waves + recurrent waves, csrc/gru_fused.hip): no workspace, the
+ * projection never touches HBM.  Returns SLK_ERR_UNSUPPORTED when (insize, n, activations, alignment) has no fused
+ * instantiation; slk_gru_f32 tries it first and falls back to projection GEMM + slk_gru_recurrent_f32.            */
+int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+                      float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
+                      slk_stream_t stream);
 /* Force the portable (non-MFMA) recurrence kernel: 0 = auto, 1 = force generic.  Testing aid; passed per call
  * through the `_ex` form so that there is still no global state.                                            */
 int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T,

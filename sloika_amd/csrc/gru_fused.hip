@@ -1,0 +1,285 @@
+// gru_fused.hip -- a whole Gru layer (input projection + recurrence, sloika/layers.py:1010-1021) in ONE persistent
+// kernel on gfx950.
+//
+// The recurrence of one 4-chunk tile is a serial chain (LDS exchange -> barrier -> gates -> LDS exchange -> barrier)
+// that keeps the MFMA pipe busy only about half of each step.  The time-parallel input projection x.iW^T + b of the
+// same layer is independent work of the same size, so it is computed IN the same workgroup by four extra waves:
+//
+//   waves 0-3 "rec" : exactly the roles of gru_mfma_kernel (recurrent.hip): z|r phase, candidate phase, two barriers
+//   waves 4-7 "proj": vI(s+2) = x(s+2).iW^T + b for the tile, written to a 4-slot LDS ring that the rec waves read
+//
+// Both groups share each SIMD's matrix pipe (two waves per SIMD), so the projection MFMAs run in the gaps of the
+// recurrence.  vI never exists in HBM (the unfused path writes and re-reads 3n floats per (t, chunk)); x arrives by
+// LDS-DMA as an image of 16-byte pieces [k/4][chunk][k%4] that the packed MFMA A-operand reads without conflicts.
+//
+// All eight waves execute the same two s_barrier per step.  Exact fp32 (v_mfma_f32_4x4x1_16b_f32).
+#include "mfma4.h"
+
+constexpr int pow2_slices(int outputs, int cap)
+{
+    // largest power of two S <= cap with S * outputs <= 64 lanes
+    int s = 1;
+    while (s * 2 <= cap && s * 2 * outputs <= 64) s *= 2;
+    return s;
+}
+
+template <int I, int N, int ACT, int GACT>
+__global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restrict__ x, long ldx,
+                                                           const float *__restrict__ iW, const float *__restrict__ bias,
+                                                           const float *__restrict__ sW, const float *__restrict__ sW2,
+                                                           float *__restrict__ h_out, long ldh, int T, int B, int reverse,
+                                                           int act, int gate_act)
+{
+    static_assert(I % 16 == 0 && N % 16 == 0 && N <= 128, "unsupported size for the fused GRU kernel");
+    // ---------------- recurrent role constants (as in gru_mfma_kernel) ----------------
+    constexpr int NW = N / 4;
+    constexpr int SA = (2 * NW <= 16) ? 4 : ((2 * NW <= 32) ? 2 : 1);
+    constexpr int SB = (NW <= 16) ? 4 : ((NW <= 32) ? 2 : 1);
+    constexpr int LPA = 64 / SA, LPB = 64 / SB;
+    constexpr int MA = N / SA, MB = N / SB;
+    constexpr int GA = 16 / SA, GB = 16 / SB;
+    constexpr int CBA = 4 - ilog2(SA), CBB = 4 - ilog2(SB);
+    constexpr int NV = N / 16;
+    // ---------------- projection role constants ----------------
+    constexpr int OW = 3 * N / 4;                        // vI rows per proj wave
+    constexpr int P0 = OW < 64 ? OW : 64;                // rows in accumulator set 0
+    constexpr int S0 = pow2_slices(P0, 4);
+    constexpr int P1 = OW - P0;                          // rows in accumulator set 1 (0 = unused)
+    constexpr int S1 = P1 ? pow2_slices(P1, 8) : 1;
+    constexpr int LP0 = 64 / S0, LP1 = 64 / S1;
+    constexpr int M0 = I / S0, M1 = P1 ? I / S1 : 0;
+    constexpr int G0 = 16 / S0, G1 = 16 / S1;
+    constexpr int CB0 = 4 - ilog2(S0), CB1 = 4 - ilog2(S1);
+    constexpr int NVI = I / 16;
+    static_assert(I % (4 * S0) == 0 && (P1 == 0 || I % (2 * S1) == 0), "K-slices must divide the input size");
+    // ---------------- LDS ----------------
+    constexpr int KB = 8, R = 4;
+    constexpr int XIMG = 4 * I;                          // floats of one step's x image: [k/4][chunk][k%4]
+    constexpr int XPIECES = KB * I;                      // 16-byte pieces per x block
+    constexpr int NDMA = (XPIECES / 64 + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float xbuf[2 * KB * XIMG];
+    __shared__ __attribute__((aligned(16))) float vbuf[R * 3 * N * 4];      // vI[slot][row][chunk]
+    __shared__ __attribute__((aligned(16))) float obuf[2 * KB * 4 * N];     // h_out[2][step][chunk][N]
+    __shared__ __attribute__((aligned(16))) float hbuf[N * 4];
+    __shared__ __attribute__((aligned(16))) float rhbuf[N * 4];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b0 = blockIdx.x * 4;
+    const int blk = lane >> 2, ci = lane & 3;
+    const bool is_rec = wave < 4;
+
+    for (int i = tid; i < N * 4; i += 512) hbuf[i] = 0.0f;
+
+    if (is_rec) {
+        // =================================================================================================
+        // recurrent waves
+        // =================================================================================================
+        const int la = lane % LPA, ga = lane / LPA;
+        const bool validA = la < 2 * NW;
+        const bool isR = la >= NW;
+        const int neuronA = wave * NW + (validA ? (la % NW) : 0);
+        const int rowA = isR ? N + neuronA : neuronA;
+        const int lb = lane % LPB, gb = lane / LPB;
+        const bool validB = lb < NW;
+        const int neuronB = wave * NW + (validB ? lb : 0);
+        const bool zlane = lane < NW;
+        const bool rlane = lane >= NW && lane < 2 * NW;
+        float wA[MA], wB[MB];
+        {
+            const float *pa = sW + (size_t)rowA * N + ga * MA;
+#pragma unroll
+            for (int m = 0; m < MA; m++) wA[m] = validA ? pa[m] : 0.0f;
+            const float *pb = sW2 + (size_t)neuronB * N + gb * MB;
+#pragma unroll
+            for (int m = 0; m < MB; m++) wB[m] = validB ? pb[m] : 0.0f;
+        }
+        const int addrA0 = 4 * ((blk / GA) * MA + (blk % GA)) + ci;
+        const int addrB0 = 4 * ((blk / GB) * MB + (blk % GB)) + ci;
+        const float mask_zr = (validA && ga == 0) ? 1.0f : 0.0f;
+        const float mask_c = zlane ? 1.0f : 0.0f;
+        const bool vec_store = (ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
+        auto flush_block = [&](int s0, int slot) {
+            constexpr int OF4 = KB * 4 * N / 4;
+#pragma unroll
+            for (int j = 0; j < (OF4 + 255) / 256; j++) {
+                const int idx = tid + 256 * j;
+                const int kk = idx / N, r = idx % N, c = r / (N / 4), f4 = r % (N / 4);
+                const int ss = s0 + kk;
+                if (idx < OF4 && ss < T && b0 + c < B) {
+                    const int tt = reverse ? T - 1 - ss : ss;
+                    const float4 v = *reinterpret_cast<const float4 *>(&obuf[slot * (KB * 4 * N) + 4 * idx]);
+                    float *dst = h_out + ((size_t)tt * B + b0 + c) * ldh + 4 * f4;
+                    if (vec_store) *reinterpret_cast<float4 *>(dst) = v;
+                    else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+                }
+            }
+        };
+
+        // prologue: the proj waves stage x and produce vI(0), vI(1)
+        __syncthreads();     // (P1) x blocks landed
+        __syncthreads();     // (P2) vI(0), vI(1) published
+
+        for (int s = 0; s < T; s++) {
+            const int kk = s % KB, kb = s / KB;
+            const float *vrow = vbuf + (s % R) * (3 * N * 4);
+            if (kk == 0 && s > 0) flush_block(s - KB, (kb - 1) & 1);
+
+            // ---------------- phase A: z | r ----------------
+            float hp[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) hp[v] = hbuf[addrA0 + 4 * v * GA];
+            f32x4 a0 = *reinterpret_cast<const f32x4 *>(&vrow[4 * rowA]);
+            f32x4 c0 = *reinterpret_cast<const f32x4 *>(&vrow[4 * (2 * N + neuronB)]);
+            a0 *= mask_zr;
+            c0 *= mask_c;
+            const f32x4 hown = *reinterpret_cast<const f32x4 *>(&hbuf[4 * neuronA]);
+            f32x4 accA[4] = {a0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mfma_chain<CBA, GA>(hp, wA, accA, std::make_integer_sequence<int, MA>{});
+            f32x4 g = sum_slices<SA>((accA[0] + accA[1]) + (accA[2] + accA[3]));
+#pragma unroll
+            for (int i = 0; i < 4; i++) g[i] = act_sel<GACT>(gate_act, g[i]);
+            if (rlane) *reinterpret_cast<f32x4 *>(&rhbuf[4 * neuronA]) = g * hown;
+            lds_barrier();
+
+            // ---------------- phase B: candidate ----------------
+            float rp[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) rp[v] = rhbuf[addrB0 + 4 * v * GB];
+            f32x4 accB[4] = {c0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mfma_chain<CBB, GB>(rp, wB, accB, std::make_integer_sequence<int, MB>{});
+            f32x4 cc = sum_slices<SB>((accB[0] + accB[1]) + (accB[2] + accB[3]));
+            if (zlane) {
+                f32x4 hn;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float hbar = act_sel<ACT>(act, cc[i]);
+                    hn[i] = g[i] * hown[i] + (1.0f - g[i]) * hbar;      // layers.py:1020
+                }
+                *reinterpret_cast<f32x4 *>(&hbuf[4 * neuronB]) = hn;
+                float *orow = obuf + (kb & 1) * (KB * 4 * N) + kk * (4 * N) + neuronB;
+#pragma unroll
+                for (int i = 0; i < 4; i++) orow[i * N] = hn[i];
+            }
+            lds_barrier();
+        }
+        flush_block(((T - 1) / KB) * KB, ((T - 1) / KB) & 1);
+    } else {
+        // =================================================================================================
+        // projection waves
+        // =================================================================================================
+        const int pw = wave - 4;
+        // accumulator set 0: rows pw*OW + [0, P0), S0 K-slices; set 1: rows pw*OW + 64 + [0, P1), S1 K-slices
+        const int l0 = lane % LP0, g0 = lane / LP0;
+        const bool valid0 = l0 < P0;
+        const int row0 = pw * OW + (valid0 ? l0 : 0);
+        const int l1 = lane % LP1, g1 = lane / LP1;
+        const bool valid1 = P1 > 0 && l1 < P1;
+        const int row1 = pw * OW + (P1 ? 64 : 0) + (valid1 ? l1 : 0);
+        float w0[M0], w1[M1 ? M1 : 1];
+        {
+            const float *p0 = iW + (size_t)row0 * I + g0 * M0;
+#pragma unroll
+            for (int m = 0; m < M0; m++) w0[m] = valid0 ? p0[m] : 0.0f;
+            const float *p1 = iW + (size_t)row1 * I + g1 * M1;
+#pragma unroll
+            for (int m = 0; m < M1; m++) w1[m] = valid1 ? p1[m] : 0.0f;
+        }
+        const float bias0 = (bias && valid0 && g0 == 0) ? bias[row0] : 0.0f;
+        const float bias1 = (bias && valid1 && g1 == 0) ? bias[row1] : 0.0f;
+        // packed A-operand addresses into one step's x image: element x[chunk][k] sits at 16*(k>>2) + 4*chunk + (k&3)
+        int xa0[NVI], xa1[NVI];
+#pragma unroll
+        for (int v = 0; v < NVI; v++) {
+            const int k0 = (blk / G0) * M0 + v * G0 + (blk % G0);
+            xa0[v] = 16 * (k0 >> 2) + 4 * ci + (k0 & 3);
+            const int k1 = (blk / G1) * (P1 ? M1 : I) + v * G1 + (blk % G1);
+            xa1[v] = 16 * (k1 >> 2) + 4 * ci + (k1 & 3);
+        }
+        const bool x_ok = true;
+        auto dma_block = [&](int s0, int slot) {
+#pragma unroll
+            for (int j = 0; j < NDMA; j++) {
+                const int piece0 = (j * 4 + pw) * 64;
+                if (piece0 < XPIECES) {
+                    const int p = piece0 + lane;
+                    const int kk = p / I, pp = p % I, q = pp >> 2, c = pp & 3;
+                    const int ss = min(s0 + kk, T - 1);
+                    const int tt = reverse ? T - 1 - ss : ss;
+                    const int bc = min(b0 + c, B - 1);
+                    const float *src = x + ((size_t)tt * B + bc) * ldx + 4 * q;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)&xbuf[slot * (KB * XIMG) + piece0 * 4],
+                                                     16, 0, 0);
+                }
+            }
+        };
+        auto project = [&](int sp) {
+            const float *img = xbuf + ((sp / KB) & 1) * (KB * XIMG) + (sp % KB) * XIMG;
+            float xp[NVI];
+#pragma unroll
+            for (int v = 0; v < NVI; v++) xp[v] = img[xa0[v]];
+            f32x4 acc[4] = {{bias0, bias0, bias0, bias0}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mfma_chain<CB0, G0>(xp, w0, acc, std::make_integer_sequence<int, M0>{});
+            f32x4 r0 = sum_slices<S0>((acc[0] + acc[1]) + (acc[2] + acc[3]));
+            float *vdst = vbuf + (sp % R) * (3 * N * 4);
+            if (valid0 && g0 == 0) *reinterpret_cast<f32x4 *>(&vdst[4 * row0]) = r0;
+            if constexpr (P1 > 0) {
+                float xq[NVI];
+#pragma unroll
+                for (int v = 0; v < NVI; v++) xq[v] = img[xa1[v]];
+                f32x4 acc1[4] = {{bias1, bias1, bias1, bias1}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                mfma_chain<CB1, G1>(xq, w1, acc1, std::make_integer_sequence<int, M1>{});
+                f32x4 r1 = sum_slices<S1>((acc1[0] + acc1[1]) + (acc1[2] + acc1[3]));
+                if (valid1 && g1 == 0) *reinterpret_cast<f32x4 *>(&vdst[4 * row1]) = r1;
+            }
+        };
+        (void)x_ok;
+
+        dma_block(0, 0);
+        if (T > KB) dma_block(KB, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();     // (P1)
+        project(0);
+        if (T > 1) project(1);
+        __syncthreads();     // (P2)
+
+        for (int s = 0; s < T; s++) {
+            const int sp = s + 2;
+            if (sp < T) project(sp);
+            const bool last_of_block = (sp % KB == KB - 1);
+            // the block after this one must have landed before anyone reads it at the next step
+            if (last_of_block) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            // every proj wave is past its reads of the block that just ended: refill its slot two blocks ahead
+            if (last_of_block && (sp / KB + 2) * KB < T) dma_block((sp / KB + 2) * KB, (sp / KB) & 1);
+            lds_barrier();
+        }
+    }
+}
+
+template <int I, int N>
+static int launch_fused(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
+                        float *y, long ldy, int T, int B, int reverse, hipStream_t s)
+{
+    hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID>), dim3((B + 3) / 4), dim3(512), 0, s, x, ldx,
+                       iW, bias, sW, sW2, y, ldy, T, B, reverse, SLK_ACT_TANH, SLK_ACT_SIGMOID);
+    return slk_launch_status();
+}
+
+// Returns SLK_ERR_UNSUPPORTED when no fused instantiation covers the request (the caller then uses
+// projection GEMM + gru_mfma_kernel).
+extern "C" int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
+                                 const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse,
+                                 int act, int gate_act, slk_stream_t stream)
+{
+    if (!x || !iW || !sW || !sW2 || !y || T < 1 || B < 1 || insize < 1 || n < 1 || ldx < insize || ldy < n)
+        return SLK_ERR_INVALID_ARG;
+    if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
+    if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;   // 16-byte DMA pieces
+    hipStream_t s = slk_stream(stream);
+#define FUSED(II, NN) \
+    if (insize == II && n == NN) return launch_fused<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, s);
+    FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(128, 96) FUSED(128, 112) FUSED(144, 112) FUSED(16, 16) FUSED(48, 32)
+#undef FUSED
+    return SLK_ERR_UNSUPPORTED;
+}

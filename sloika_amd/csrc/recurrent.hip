@@ -23,9 +23,7 @@
 //
 // Portable path (gru_generic_kernel / lstm_generic_kernel): one workgroup per chunk, weights streamed from L2,
 // any n and any activation; used for layer sizes the MFMA kernel is not instantiated for.
-#include <utility>
-
-#include "common.h"
+#include "mfma4.h"
 
 // =====================================================================================================
 // generic GRU
@@ -105,58 +103,6 @@ __global__ void __launch_bounds__(256) lstm_generic_kernel(const float *__restri
 // =====================================================================================================
 // MFMA GRU
 // =====================================================================================================
-template <int CB, int AB>
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
-{
-    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, CB, AB, 0);
-}
-
-constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
-
-// Four accumulators in rotation: a 4x4x1 MFMA occupies the pipe for 8 cycles but its result is only readable as
-// the next SrcC a few wait states later; with 4 independent chains no s_nop padding is needed.
-template <int CB, int G, int... Is>
-__device__ __forceinline__ void mfma_chain(const float *hp, const float *w, f32x4 (&acc)[4],
-                                           std::integer_sequence<int, Is...>)
-{
-    ((acc[Is & 3] = mfma4<CB, Is % G>(hp[Is / G], w[Is], acc[Is & 3])), ...);
-}
-
-// Workgroup barrier for the LDS state exchange that does NOT drain global memory traffic: __syncthreads() would
-// emit s_waitcnt vmcnt(0) and stall every step on the h_out stores and on the vI prefetch issued for the next step.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// lane l and lane l^32 exchanged with one VALU op (v_permlane32_swap) instead of a ds_bpermute round trip
-__device__ __forceinline__ float xor32_sum(float v)
-{
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-template <int S>
-__device__ __forceinline__ f32x4 sum_slices(f32x4 v)
-{
-    if constexpr (S >= 4) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) v[i] += __shfl_xor(v[i], 16);
-    }
-    if constexpr (S >= 2) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = xor32_sum(v[i]);
-    }
-    return v;
-}
-
-template <int ACT>
-__device__ __forceinline__ float act_sel(int act, float x)
-{
-    if constexpr (ACT >= 0) return slk_act_t<ACT>(x);
-    else return slk_act(act, x);
-}
-
 // N: layer size (multiple of 16, <= 128).  ACT/GACT: compile-time activation ids, or -1 to use the runtime ids.
 template <int N, int ACT, int GACT>
 __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restrict__ vI, const float *__restrict__ sW,
@@ -241,6 +187,7 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
     // h_out goes the other way through a second 2-deep LDS ring: per step each owner lane drops its 4 values into
     // the ring (4 ds_write_b32), and once per KB steps the whole workgroup flushes the finished block with 16-byte
     // coalesced stores -- instead of 16 partial-line store instructions per workgroup on every step.
+    const bool vec_store = (ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
     auto flush_block = [&](int s0, int slot) {
         constexpr int OF4 = KB * 4 * N / 4;                    // float4 per output block
 #pragma unroll
@@ -257,7 +204,6 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
             }
         }
     };
-    const bool vec_store = (ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
     const float mask_zr = (validA && ga == 0) ? 1.0f : 0.0f;   // K-slice lanes start their accumulators at 0
     const float mask_c = zlane ? 1.0f : 0.0f;
 
@@ -376,9 +322,11 @@ extern "C" int slk_gru_f32(const float *x, long ldx, const float *iW, const floa
                            int gate_act, void *workspace, size_t workspace_bytes, slk_stream_t stream)
 {
     if (T < 1 || B < 1 || n < 1 || insize < 1) return SLK_ERR_INVALID_ARG;
+    int rc = slk_gru_fused_f32(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse, act, gate_act, stream);
+    if (rc != SLK_ERR_UNSUPPORTED) return rc;
     if (!workspace || workspace_bytes < slk_gru_workspace_bytes(T, B, n)) return SLK_ERR_WORKSPACE;
     float *vI = static_cast<float *>(workspace);
-    int rc = slk_gemm_bias_act_f32(x, ldx, iW, bias, vI, 3L * n, (long)T * B, insize, 3 * n, SLK_ACT_LINEAR, stream);
+    rc = slk_gemm_bias_act_f32(x, ldx, iW, bias, vI, 3L * n, (long)T * B, insize, 3 * n, SLK_ACT_LINEAR, stream);
     if (rc != SLK_OK) return rc;
     return slk_gru_recurrent_f32(vI, sW, sW2, y, ldy, T, B, n, reverse, act, gate_act, stream);
 }

@@ -39,17 +39,28 @@ def stop():
     return rec
 
 
+class _Region(object):
+    def __init__(self):
+        self.cancelled = False
+
+    def cancel(self):
+        """Drop this region (e.g. the call inside turned out to be a no-op that fell back to another path)."""
+        self.cancelled = True
+
+
 @contextlib.contextmanager
 def region(name, flops=0.0, nbytes=0.0):
     if _active is None:
-        yield
+        yield None
         return
     import torch
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
+    reg = _Region()
     e0.record()
     try:
-        yield
+        yield reg
     finally:
         e1.record()
-        _active.records.append((name, e0, e1, float(flops), float(nbytes)))
+        if not reg.cancelled:
+            _active.records.append((name, e0, e1, float(flops), float(nbytes)))

@@ -114,3 +114,45 @@ def test_layer_input_validation():
         g.run(torch.zeros((5, 2, 3), device="cuda"))           # wrong feature count
     with pytest.raises(ValueError):
         g.run(torch.zeros((5, 2, 4)))                          # not on the device
+
+
+@pytest.mark.parametrize("I,n", [(96, 96), (64, 64), (32, 96), (128, 96), (128, 112), (144, 112), (16, 16), (48, 32)])
+@pytest.mark.parametrize("T,B,reverse", [(23, 9, False), (8, 4, True), (3, 2, False), (1, 1, True), (41, 5, True)])
+def test_gru_fused_layer_kernel(oracle, I, n, T, B, reverse):
+    """Projection + recurrence in one persistent kernel (csrc/gru_fused.hip) vs the oracle."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    rs = np.random.RandomState(I + n + T)
+    iW, sW, sW2, b = _gru_params(rs, I, n, scale=2.0)
+    x = rs.normal(size=(T, B, I)).astype(np.float32)
+    ref = oracle.gru(x, iW, sW, sW2, b, reverse=reverse)
+    xd, iWd, sWd, sW2d, bd = dev(x), dev(iW), dev(sW), dev(sW2), dev(b)
+    y = torch.full((T, B, n), np.nan, dtype=torch.float32, device="cuda")
+    rc = _lib.lib().slk_gru_fused_f32(xd.data_ptr(), I, iWd.data_ptr(), sWd.data_ptr(), sW2d.data_ptr(), bd.data_ptr(),
+                                      y.data_ptr(), n, T, B, I, n, int(reverse), 1, 2, stream())
+    assert rc == 0
+    np.testing.assert_allclose(y.cpu().numpy(), ref, atol=TOL)
+    # no bias + strided input/output rows (slices of wider tensors)
+    xw = torch.zeros((T, B, I + 16), device="cuda")
+    xw[:, :, 8:8 + I] = xd
+    yw = torch.full((T, B, n + 8), -5.0, device="cuda")
+    rc = _lib.lib().slk_gru_fused_f32(xw.data_ptr() + 8 * 4, I + 16, iWd.data_ptr(), sWd.data_ptr(), sW2d.data_ptr(), None,
+                                      yw.data_ptr() + 4 * 4, n + 8, T, B, I, n, int(reverse), 1, 2, stream())
+    assert rc in (0, _lib.SLK_ERR_UNSUPPORTED)
+    if rc == 0:
+        ref_nb = oracle.gru(x, iW, sW, sW2, None, reverse=reverse)
+        out = yw.cpu().numpy()
+        np.testing.assert_allclose(out[:, :, 4:4 + n], ref_nb, atol=TOL)
+        assert (out[:, :, :4] == -5.0).all() and (out[:, :, 4 + n:] == -5.0).all()
+
+
+def test_gru_fused_unsupported_falls_back(oracle):
+    need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    z = dev(np.zeros((4, 4), dtype=np.float32))
+    # sizes with no fused instantiation report UNSUPPORTED (slk_gru_f32 then takes the two-kernel path)
+    assert L.slk_gru_fused_f32(z.data_ptr(), 7, z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), 5, 1, 1, 7, 5,
+                               0, 1, 2, stream()) == _lib.SLK_ERR_UNSUPPORTED
+    assert L.slk_gru_fused_f32(z.data_ptr(), 96, z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), 96, 1, 1, 96,
+                               96, 0, 3, 2, stream()) == _lib.SLK_ERR_UNSUPPORTED

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--T", type=int, default=800)
     ap.add_argument("--B", type=int, default=1024)
     ap.add_argument("--n", type=int, default=96)
-    ap.add_argument("--what", default="gru,gemm,softmax,viterbi")
+    ap.add_argument("--what", default="gru,gruf,gemm,softmax,viterbi")
     a = ap.parse_args()
     L = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
@@ -44,6 +44,19 @@ def main():
                                                            n, 0, 1, 2, generic, st))
             fl = 6.0 * T * B * n * n
             print("gru_recurrent n=%d B=%d T=%d generic=%d: %.3f ms  %.1f TF  %.0f ns/step" % (n, B, T, generic, ms, fl / ms / 1e9, ms * 1e6 / T))
+    if "gruf" in what:
+        I = n
+        x = torch.randn(T, B, I, device="cuda")
+        iW = torch.randn(3 * n, I, device="cuda") / np.sqrt(I + n)
+        bb = torch.randn(3 * n, device="cuda")
+        sW = torch.randn(2 * n, n, device="cuda") / np.sqrt(2 * n)
+        sW2 = torch.randn(n, n, device="cuda") / np.sqrt(2 * n)
+        y = torch.empty(T, B, n, device="cuda")
+        rc = L.slk_gru_fused_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B, I, n, 0, 1, 2, st)
+        assert rc == 0, rc
+        ms = timeit(lambda: L.slk_gru_fused_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B, I, n, 0, 1, 2, st))
+        fl = 6.0 * T * B * n * n + 6.0 * T * B * n * I
+        print("gru_fused I=%d n=%d B=%d T=%d: %.3f ms  %.1f TF  %.0f ns/step" % (I, n, B, T, ms, fl / ms / 1e9, ms * 1e6 / T))
     if "gemm" in what:
         for (K, N) in ((n, 3 * n), (n, 1025)):
             M = T * B
