@@ -118,6 +118,10 @@ int slk_linear_softmax_f32(const float *x, long ldx, const float *W, const float
                            int N, slk_stream_t stream);
 /* In-place row softmax of y:[M][N] (the second half of the above, exposed for testing).                     */
 int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream);
+/* Row statistics only: stats[r] = (max_j logits[r][j], 1 / sum_j exp(logits[r][j] - max)); the posterior
+ * exp(l - max) * inv_sum rebuilt from them is bit-identical to what slk_softmax_rows_f32 writes.  Lets the decoder
+ * consume logits directly so the normalised posterior is never written (slk_viterbi_kmer_logits_f32).            */
+int slk_softmax_rowstats_f32(const float *logits, long M, int N, float *stats /* [M][2] */, slk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * a4. Gru  (sloika/layers.py:952-1021; step :1010-1021; zero initial state :85-88; Reverse :1449-1450)
@@ -188,6 +192,15 @@ int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, int klen, f
                          int32_t *path_out, int32_t *len_out, slk_stream_t stream);
 int slk_log_post_f32(const float *post, float *lpost, size_t count, int input_mode, float min_prob,
                      slk_stream_t stream);
+/* Softmax.run + decode_post in one pass over the LOGITS (sloika/layers.py:309-314 + sloika/basecall.py:26-51):
+ * logits:[T][B][nstate] = x.W^T + b,  stats:[T*B][2] from slk_softmax_rowstats_f32.  Same outputs as
+ * slk_viterbi_kmer_f32(SLK_POST_RAW) on the normalised posterior, bit for bit.  slk_log_post_logits_f32 exposes the
+ * log-posterior it decodes (for tests).                                                                          */
+int slk_viterbi_kmer_logits_f32(const float *logits, const float *stats, int T, int B, int nbase, int klen,
+                                float skip_pen, float min_prob, void *workspace, size_t workspace_bytes,
+                                float *score_out, int32_t *path_out, int32_t *len_out, slk_stream_t stream);
+int slk_log_post_logits_f32(const float *logits, const float *stats, float *lpost, size_t rows, int nstate,
+                            float min_prob, slk_stream_t stream);
 /* decode.prepare_post on its own: out = min_prob + (1-min_prob)*post (decode.py:36).                        */
 int slk_prepare_post_f32(const float *post, float *out, size_t count, float min_prob, slk_stream_t stream);
 /* decode.argmax (decode.py:5-18), batched: per (b) the states with argmax != blank, minus 1 if

@@ -24,12 +24,24 @@ __device__ __forceinline__ float prepare_post_val(float p, float min_prob, float
     return __fadd_rn(min_prob, __fmul_rn(one_m, p));       // decode.py:36
 }
 
+// natural log through v_log_f32 (log2) * ln2: ~1e-7 relative, 2 instructions instead of ~20 -- the decoder evaluates
+// it once per (t, chunk, state), i.e. 840 M times per B=1024 batch
+__device__ __forceinline__ float fast_logf(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
 __device__ __forceinline__ float log_post_val(float p, int mode, float min_prob, float one_m)
 {
     if (mode == SLK_POST_LOG) return p;
-    if (mode == SLK_POST_LN) return logf(p);               // transducer.py:30
+    if (mode == SLK_POST_LN) return fast_logf(p);          // transducer.py:30
     if (mode == SLK_POST_RAW) p = prepare_post_val(p, min_prob, one_m);
-    return logf(__fadd_rn(p, VIT_ETA));                    // decode.py:56
+    return fast_logf(__fadd_rn(p, VIT_ETA));               // decode.py:56
+}
+
+// SLK_POST_LOGITS: the posterior is rebuilt from (logit, row max, 1/row sum) exactly as softmax_rows_kernel writes it
+// (sloika/layers.py:311-314), then treated as SLK_POST_RAW.
+__device__ __forceinline__ float log_logit_val(float l, float2 st, float min_prob, float one_m)
+{
+    const float p = __expf(l - st.x) * st.y;
+    return fast_logf(__fadd_rn(prepare_post_val(p, min_prob, one_m), VIT_ETA));
 }
 
 __global__ void log_post_kernel(const float *__restrict__ post, float *__restrict__ lpost, size_t count, int mode,
@@ -37,6 +49,14 @@ __global__ void log_post_kernel(const float *__restrict__ post, float *__restric
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
         lpost[i] = log_post_val(post[i], mode, min_prob, one_m);
+}
+
+__global__ void log_logits_kernel(const float *__restrict__ logits, const float2 *__restrict__ stats,
+                                  float *__restrict__ lpost, size_t rows, int nst, float min_prob, float one_m)
+{
+    const size_t count = rows * nst;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        lpost[i] = log_logit_val(logits[i], stats[i / nst], min_prob, one_m);
 }
 
 __global__ void prepare_post_kernel(const float *__restrict__ post, float *__restrict__ out, size_t count,
@@ -66,6 +86,17 @@ extern "C" int slk_log_post_f32(const float *post, float *lpost, size_t count, i
     return slk_launch_status();
 }
 
+extern "C" int slk_log_post_logits_f32(const float *logits, const float *stats, float *lpost, size_t rows, int nstate,
+                                       float min_prob, slk_stream_t stream)
+{
+    if (!logits || !stats || !lpost || nstate < 1) return SLK_ERR_INVALID_ARG;
+    if (!rows) return SLK_OK;
+    hipLaunchKernelGGL(log_logits_kernel, dim3(grid_for(rows * nstate)), dim3(256), 0, slk_stream(stream), logits,
+                       reinterpret_cast<const float2 *>(stats), lpost, rows, nstate, min_prob,
+                       one_minus(min_prob, (double)min_prob));
+    return slk_launch_status();
+}
+
 extern "C" int slk_prepare_post_f32(const float *post, float *out, size_t count, float min_prob, slk_stream_t stream)
 {
     if (!post || !out) return SLK_ERR_INVALID_ARG;
@@ -78,8 +109,9 @@ extern "C" int slk_prepare_post_f32(const float *post, float *out, size_t count,
 // ------------------------------------------------------------------------------------------------------
 // forward DP
 // ------------------------------------------------------------------------------------------------------
-template <int NB>
-__global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__restrict__ post, int T, int B,
+template <int NB, bool LOGITS>
+__global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__restrict__ post,
+                                                               const float2 *__restrict__ stats, int T, int B,
                                                                int nkmer, float skip_pen, int mode, float min_prob,
                                                                float one_m, uint8_t *__restrict__ tb,
                                                                int32_t *__restrict__ best_out,
@@ -101,29 +133,37 @@ __global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__re
     const size_t tstride = (size_t)B * nst;
     uint8_t *tbb = tb + (size_t)b * T * nkmer;
 
+    auto xform = [&](float val, float2 st) {
+        return LOGITS ? log_logit_val(val, st, min_prob, one_m) : log_post_val(val, mode, min_prob, one_m);
+    };
     // t = 0: v = lpost[0][1:]   (decode.py:57)
     float raw[NB], raw0;
+    float2 rst = make_float2(0.f, 1.f);
+    if (LOGITS) rst = stats[b];
 #pragma unroll
     for (int c = 0; c < NB; c++) raw[c] = pb[1 + jj * NB + c];
     if (active) {
 #pragma unroll
-        for (int c = 0; c < NB; c++) v[jj * NB + c] = log_post_val(raw[c], mode, min_prob, one_m);
+        for (int c = 0; c < NB; c++) v[jj * NB + c] = xform(raw[c], rst);
     }
     if (T > 1) {
 #pragma unroll
         for (int c = 0; c < NB; c++) raw[c] = pb[tstride + 1 + jj * NB + c];
         raw0 = pb[tstride];
+        if (LOGITS) rst = stats[(size_t)B + b];
     }
     __syncthreads();
 
     for (int t = 1; t < T; t++) {
         // prefetch the next row one full step ahead of its use
         float nxt[NB], nxt0 = 0.0f;
+        float2 nst2 = make_float2(0.f, 1.f);
         if (t + 1 < T) {
             const float *pn = pb + (size_t)(t + 1) * tstride;
 #pragma unroll
             for (int c = 0; c < NB; c++) nxt[c] = pn[1 + jj * NB + c];
             nxt0 = pn[0];
+            if (LOGITS) nst2 = stats[(size_t)(t + 1) * B + b];
         }
         // ---- step maximum over a (first max wins: np.argmax, decode.py:67-68) ----
         float sstep = v[jj];
@@ -136,8 +176,8 @@ __global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__re
         if (active) { stepmax[jj] = sstep; steparg[jj] = sarg; }
         float lp[NB];
 #pragma unroll
-        for (int c = 0; c < NB; c++) lp[c] = log_post_val(raw[c], mode, min_prob, one_m);
-        const float lp0 = log_post_val(raw0, mode, min_prob, one_m);
+        for (int c = 0; c < NB; c++) lp[c] = xform(raw[c], rst);
+        const float lp0 = xform(raw0, rst);
         __syncthreads();
         // ---- skip maximum over ab = a*NB + b (first max in ab order wins, decode.py:72-73) ----
         float kbest = stepmax[j2];
@@ -174,6 +214,7 @@ __global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__re
 #pragma unroll
         for (int c = 0; c < NB; c++) raw[c] = nxt[c];
         raw0 = nxt0;
+        rst = nst2;
         __syncthreads();
     }
     // ---- first argmax of v (np.argmax, decode.py:85) ----
@@ -288,7 +329,7 @@ extern "C" size_t slk_viterbi_kmer_workspace_bytes(int T, int B, int nbase, int 
 }
 
 template <int NB>
-static int launch_viterbi(const float *post, int T, int B, int klen, int nkmer, float skip_pen, int mode, float min_prob,
+static int launch_viterbi(const float *post, const float *stats, int T, int B, int klen, int nkmer, float skip_pen, int mode, float min_prob,
                           uint8_t *tb, int32_t *best, float *score_out, int32_t *path_out, int32_t *len_out,
                           hipStream_t s)
 {
@@ -297,8 +338,13 @@ static int launch_viterbi(const float *post, int T, int B, int klen, int nkmer, 
     if (nrem1 > 1024) return SLK_ERR_UNSUPPORTED;
     size_t lds = sizeof(float) * ((size_t)nkmer + nrem1 + 16) + sizeof(int) * ((size_t)nrem1 + 16);
     float one_m = (float)(1.0 - (double)min_prob);
-    hipLaunchKernelGGL((viterbi_forward_kernel<NB>), dim3(B), dim3(threads), lds, s, post, T, B, nkmer, skip_pen,
-                       mode, min_prob, one_m, tb, best, score_out);
+    if (stats)
+        hipLaunchKernelGGL((viterbi_forward_kernel<NB, true>), dim3(B), dim3(threads), lds, s, post,
+                           reinterpret_cast<const float2 *>(stats), T, B, nkmer, skip_pen, mode, min_prob, one_m, tb, best,
+                           score_out);
+    else
+        hipLaunchKernelGGL((viterbi_forward_kernel<NB, false>), dim3(B), dim3(threads), lds, s, post, nullptr, T, B, nkmer,
+                           skip_pen, mode, min_prob, one_m, tb, best, score_out);
     int rc = slk_launch_status();
     if (rc != SLK_OK) return rc;
     int tblk = (64 * 1024) / nkmer;
@@ -309,9 +355,9 @@ static int launch_viterbi(const float *post, int T, int B, int klen, int nkmer, 
     return slk_launch_status();
 }
 
-extern "C" int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, int klen, float skip_pen,
-                                    int input_mode, float min_prob, void *workspace, size_t workspace_bytes,
-                                    float *score_out, int32_t *path_out, int32_t *len_out, slk_stream_t stream)
+static int viterbi_entry(const float *post, const float *stats, int T, int B, int nbase, int klen, float skip_pen,
+                         int input_mode, float min_prob, void *workspace, size_t workspace_bytes, float *score_out,
+                         int32_t *path_out, int32_t *len_out, slk_stream_t stream)
 {
     int nkmer;
     if (!post || !score_out || !path_out || !len_out || T < 1 || B < 1 || input_mode < 0 || input_mode > 2)
@@ -324,10 +370,27 @@ extern "C" int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, 
     int32_t *best = reinterpret_cast<int32_t *>(tb + tbbytes);
     hipStream_t s = slk_stream(stream);
     switch (nbase) {
-    case 4: return launch_viterbi<4>(post, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
-    case 5: return launch_viterbi<5>(post, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
+    case 4: return launch_viterbi<4>(post, stats, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
+    case 5: return launch_viterbi<5>(post, stats, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
     default: return SLK_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, int klen, float skip_pen,
+                                    int input_mode, float min_prob, void *workspace, size_t workspace_bytes,
+                                    float *score_out, int32_t *path_out, int32_t *len_out, slk_stream_t stream)
+{
+    return viterbi_entry(post, nullptr, T, B, nbase, klen, skip_pen, input_mode, min_prob, workspace, workspace_bytes,
+                         score_out, path_out, len_out, stream);
+}
+
+extern "C" int slk_viterbi_kmer_logits_f32(const float *logits, const float *stats, int T, int B, int nbase, int klen,
+                                           float skip_pen, float min_prob, void *workspace, size_t workspace_bytes,
+                                           float *score_out, int32_t *path_out, int32_t *len_out, slk_stream_t stream)
+{
+    if (!stats) return SLK_ERR_INVALID_ARG;
+    return viterbi_entry(logits, stats, T, B, nbase, klen, skip_pen, SLK_POST_RAW, min_prob, workspace, workspace_bytes,
+                         score_out, path_out, len_out, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

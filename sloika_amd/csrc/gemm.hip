@@ -192,8 +192,11 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-template <int MAXE>
-__global__ void __launch_bounds__(256) softmax_rows_kernel(float *__restrict__ y, long M, int N)
+// One code path for the row statistics so that the posterior written by softmax_rows and the one the decoder rebuilds
+// from (logit, max, 1/sum) are bit-identical:  p = expf(l - m) * (1 / s)   with s summed in lane-strided order.
+template <int MAXE, bool STATS_ONLY>
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float *__restrict__ y, long M, int N,
+                                                           float2 *__restrict__ stats)
 {
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -216,15 +219,22 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float *__restrict__ y
             s += v[e];
         }
         s = wave_sum(s);
+        const float r = 1.0f / s;
+        if (STATS_ONLY) {
+            if (lane == 0) stats[row] = make_float2(m, r);
+        } else {
 #pragma unroll
-        for (int e = 0; e < MAXE; e++) {
-            int j = lane + 64 * e;
-            if (j < N) p[j] = v[e] / s;
+            for (int e = 0; e < MAXE; e++) {
+                int j = lane + 64 * e;
+                if (j < N) p[j] = v[e] * r;
+            }
         }
     }
 }
 
-__global__ void __launch_bounds__(256) softmax_rows_generic_kernel(float *__restrict__ y, long M, int N)
+template <bool STATS_ONLY>
+__global__ void __launch_bounds__(256) softmax_rows_generic_kernel(float *__restrict__ y, long M, int N,
+                                                                   float2 *__restrict__ stats)
 {
     const int lane = threadIdx.x & 63;
     const long wave0 = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -235,27 +245,43 @@ __global__ void __launch_bounds__(256) softmax_rows_generic_kernel(float *__rest
         for (int j = lane; j < N; j += 64) m = fmaxf(m, p[j]);
         m = wave_max(m);
         float s = 0.0f;
-        for (int j = lane; j < N; j += 64) {
-            float e = __expf(p[j] - m);
-            p[j] = e;
-            s += e;
-        }
+        for (int j = lane; j < N; j += 64) s += __expf(p[j] - m);
         s = wave_sum(s);
-        for (int j = lane; j < N; j += 64) p[j] = p[j] / s;
+        const float r = 1.0f / s;
+        if (STATS_ONLY) {
+            if (lane == 0) stats[row] = make_float2(m, r);
+        } else {
+            for (int j = lane; j < N; j += 64) p[j] = __expf(p[j] - m) * r;
+        }
     }
+}
+
+template <bool STATS_ONLY>
+static int launch_softmax(float *y, long M, int N, float2 *stats, hipStream_t s)
+{
+    long blocks = (M + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (N <= 64 * 4)
+        hipLaunchKernelGGL((softmax_rows_kernel<4, STATS_ONLY>), dim3((unsigned)blocks), dim3(256), 0, s, y, M, N, stats);
+    else if (N <= 64 * 17)
+        hipLaunchKernelGGL((softmax_rows_kernel<17, STATS_ONLY>), dim3((unsigned)blocks), dim3(256), 0, s, y, M, N, stats);
+    else
+        hipLaunchKernelGGL((softmax_rows_generic_kernel<STATS_ONLY>), dim3((unsigned)blocks), dim3(256), 0, s, y, M, N, stats);
+    return slk_launch_status();
 }
 
 extern "C" int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream)
 {
     if (!y || M < 0 || N < 1) return SLK_ERR_INVALID_ARG;
     if (M == 0) return SLK_OK;
-    long blocks = (M + 3) / 4;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipStream_t s = slk_stream(stream);
-    if (N <= 64 * 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, y, M, N);
-    else if (N <= 64 * 17) hipLaunchKernelGGL(softmax_rows_kernel<17>, dim3((unsigned)blocks), dim3(256), 0, s, y, M, N);
-    else hipLaunchKernelGGL(softmax_rows_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, M, N);
-    return slk_launch_status();
+    return launch_softmax<false>(y, M, N, nullptr, slk_stream(stream));
+}
+
+extern "C" int slk_softmax_rowstats_f32(const float *logits, long M, int N, float *stats, slk_stream_t stream)
+{
+    if (!logits || !stats || M < 0 || N < 1) return SLK_ERR_INVALID_ARG;
+    if (M == 0) return SLK_OK;
+    return launch_softmax<true>(const_cast<float *>(logits), M, N, reinterpret_cast<float2 *>(stats), slk_stream(stream));
 }
 
 extern "C" int slk_linear_softmax_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long M,

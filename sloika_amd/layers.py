@@ -326,6 +326,26 @@ class Softmax(Layer):
             return out
         return y
 
+    def logits_and_stats(self, x):
+        """tmp = x.W^T + b (layers.py:310) as [T,B,size] plus per-row (max, 1/sum exp) [T*B,2]: what the decoder needs to
+        rebuild the posterior on the fly, so the normalised tensor is never written (decode.viterbi_logits_batch)."""
+        import torch
+        x = _check_input(x, self.insize)
+        T, B, _ = x.shape
+        rows, L = T * B, _lib.lib()
+        y = torch.empty((T, B, self.size), dtype=torch.float32, device=x.device)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        with profiler.region("softmax_gemm", 2.0 * rows * self.insize * self.size,
+                             4.0 * rows * (self.insize + self.size)):
+            rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
+                                         self.b.dev().data_ptr(), y.data_ptr(), self.size, rows, self.insize,
+                                         self.size, 0, _stream())
+        _lib.check(rc, "Softmax")
+        with profiler.region("softmax_rowstats", 0.0, 4.0 * rows * self.size):
+            rc = L.slk_softmax_rowstats_f32(y.data_ptr(), rows, self.size, stats.data_ptr(), _stream())
+        _lib.check(rc, "Softmax")
+        return y, stats
+
     def spec(self):
         return {"type": "softmax", "W": self.W.get_value(), "b": self.b.get_value()}
 

@@ -23,27 +23,45 @@ class Basecaller(object):
         self._ws = decode.ViterbiWorkspace()
         _lib.lib()
 
-    def posteriors(self, chunks):
-        """[B, chunk_len] device signal -> [T', B, nstate] posteriors (network layout)."""
-        import torch
+    def _hidden(self, chunks, upto):
+        """Run the network on [B, chunk_len] device signal up to (not including) layer index `upto`."""
         from . import device as D
         cd = D.to_dev(chunks)
         net = self.network
-        first = net.layers[0] if isinstance(net, layers.Serial) else None
+        seq = net.layers if isinstance(net, layers.Serial) else [net]
+        first = seq[0]
         if (self.normalisation == 'per-chunk' and isinstance(first, layers.Convolution) and first.insize == 1
-                and len(net.layers) > 1):
+                and len(seq) > 1):
             # the conv front end reads the chunk-major normalised signal directly: no [T,B,1] transpose
             norm = batch.normalise_chunks(cd, 'per-chunk', out_layout='chunk')
             B, T = norm.shape
             x = first.run_strided(norm.data_ptr(), T, B, 1, T, norm.device)
-            for layer in net.layers[1:]:
-                x = layer._forward(x, None, False)
-            return x
-        inmat = batch.normalise_chunks(cd, self.normalisation, out_layout='network')
-        return net.run(inmat)
+            rest = seq[1:upto]
+        else:
+            x = batch.normalise_chunks(cd, self.normalisation, out_layout='network')
+            rest = seq[:upto]
+        for layer in rest:
+            x = layer._forward(x, None, False)
+        return x
+
+    def posteriors(self, chunks):
+        """[B, chunk_len] device signal -> [T', B, nstate] posteriors (network layout)."""
+        net = self.network
+        n = len(net.layers) if isinstance(net, layers.Serial) else 1
+        return self._hidden(chunks, n)
 
     def call_chunks(self, chunks):
-        """-> device tensors (scores float32 [B], paths int32 [B, T'] (-1 padded), lens int32 [B])."""
+        """-> device tensors (scores float32 [B], paths int32 [B, T'] (-1 padded), lens int32 [B]).
+
+        When the network ends in a Softmax layer the decoder consumes its logits + row statistics, so the normalised
+        posterior (3.4 GB at B=1024) is never written; the result is bit-identical to decoding `posteriors()`."""
+        net = self.network
+        last = net.layers[-1] if isinstance(net, layers.Serial) else None
+        if type(last) is layers.Softmax and len(net.layers) > 1:
+            hid = self._hidden(chunks, len(net.layers) - 1)
+            logits, stats = last.logits_and_stats(hid)
+            return decode.viterbi_logits_batch(logits, stats, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
+                                               min_prob=self.min_prob, workspace=self._ws)
         post = self.posteriors(chunks)
         return decode.viterbi_batch(post, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
                                     min_prob=self.min_prob, workspace=self._ws)

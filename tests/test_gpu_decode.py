@@ -48,7 +48,7 @@ def test_viterbi_post_modes_match_oracle_on_device_log(oracle, golden_decode):
                                                float(min_prob or 0.0), stream()))
         lph = lp.cpu().numpy()
         ref_in = post if min_prob is None else oracle.prepare_post(post[:, None, :], min_prob)
-        np.testing.assert_allclose(lph, np.log(ref_in + np.float32(1e-10)), rtol=3e-7, atol=1e-6)
+        np.testing.assert_allclose(lph, np.log(ref_in + np.float32(1e-10)), rtol=1e-6, atol=2e-6)
         for skip in (0.0, 3.0):
             scores, paths, lens = decode.viterbi_batch(pd[:, None, :], 5, skip_pen=skip, min_prob=min_prob)
             o_score, o_path = oracle.viterbi(lph, 5, skip_pen=skip, log=True)
@@ -131,3 +131,36 @@ def test_viterbi_argument_errors():
         decode.viterbi(np.ones((4, 17), dtype=np.float32), 2)              # decode.py:50
     with pytest.raises(ValueError):
         decode.viterbi(np.ones((4, 66), dtype=np.float32), 3)              # decode.py:52 nstate mismatch
+
+
+def test_viterbi_on_logits_equals_viterbi_on_posterior(oracle):
+    """Softmax + prepare_post + log + Viterbi in one pass over the logits == the same stages run separately,
+    bit for bit, and == the oracle decoder on the log-posterior the device derives from the logits."""
+    torch = need_gpu()
+    from sloika_amd import _lib, decode
+    rs = np.random.RandomState(5)
+    T, B, S = 90, 6, 1025
+    logits = (rs.normal(size=(T, B, S)) * 3.0).astype(np.float32)
+    logits[10] = 2.0                      # a flat row: every state ties
+    logits[20, :, 0] = 60.0               # a dominant blank
+    ld = dev(logits)
+    L = _lib.lib()
+    stats = torch.empty((T * B, 2), dtype=torch.float32, device="cuda")
+    assert L.slk_softmax_rowstats_f32(ld.data_ptr(), T * B, S, stats.data_ptr(), stream()) == 0
+    post = ld.clone()
+    assert L.slk_softmax_rows_f32(post.data_ptr(), T * B, S, stream()) == 0
+    np.testing.assert_allclose(post.cpu().numpy().sum(axis=2), 1.0, atol=1e-5)
+    m = logits.max(axis=2).reshape(-1)
+    np.testing.assert_array_equal(stats[:, 0].cpu().numpy(), m)
+    for skip in (0.0, 4.0):
+        s1, p1, l1 = decode.viterbi_logits_batch(ld, stats, 5, skip_pen=skip, min_prob=1e-5)
+        s2, p2, l2 = decode.viterbi_batch(post, 5, skip_pen=skip, min_prob=1e-5)
+        assert torch.equal(p1, p2) and torch.equal(l1, l2) and torch.equal(s1, s2)
+        lp = torch.empty_like(ld)
+        assert L.slk_log_post_logits_f32(ld.data_ptr(), stats.data_ptr(), lp.data_ptr(), T * B, S, 1e-5, stream()) == 0
+        o_s, o_p, o_l = oracle.viterbi_batch(lp.cpu().numpy(), 5, skip_pen=skip)
+        assert np.array_equal(p1.cpu().numpy(), o_p) and np.array_equal(l1.cpu().numpy(), o_l)
+        assert np.array_equal(s1.cpu().numpy(), o_s)
+    # and the log-posterior itself is the reference transform of the softmax within float32 rounding
+    ref = np.log(np.float32(1e-5) + np.float32(1 - 1e-5) * post.cpu().numpy() + np.float32(1e-10))
+    np.testing.assert_allclose(lp.cpu().numpy(), ref, rtol=1e-6, atol=2e-6)

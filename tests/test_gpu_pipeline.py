@@ -17,7 +17,7 @@ TOL = 1e-4
 
 def _check_end_to_end(oracle, net, chunks, klen=5, skip=0.0, tol=TOL):
     torch = need_gpu()
-    from sloika_amd import _lib, pipeline
+    from sloika_amd import _lib, pipeline, decode
     bc = pipeline.Basecaller(net, kmer_len=klen, skip=skip)
     cd = dev(chunks)
     post = bc.posteriors(cd)
@@ -26,7 +26,9 @@ def _check_end_to_end(oracle, net, chunks, klen=5, skip=0.0, tol=TOL):
     assert post.shape == ref.shape
     err = np.abs(post.cpu().numpy() - ref).max()
     assert err < tol, "posterior max abs err %g" % err
-    scores, paths, lens = bc.call_chunks(cd)
+    scores, paths, lens = bc.call_chunks(cd)                       # logits path: posterior never materialised
+    s2, p2, l2 = decode.viterbi_batch(post, klen, skip_pen=skip, min_prob=1e-5)   # posterior path
+    assert torch.equal(paths, p2) and torch.equal(lens, l2) and torch.equal(scores, s2)
     lp = torch.empty_like(post)
     _lib.check(_lib.lib().slk_log_post_f32(post.data_ptr(), lp.data_ptr(), post.numel(), _lib.POST_RAW, 1e-5, stream()))
     o_scores, o_paths, o_lens = oracle.viterbi_batch(lp.cpu().numpy(), klen, skip_pen=skip)
