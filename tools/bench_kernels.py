@@ -54,9 +54,22 @@ def main():
         y = torch.empty(T, B, n, device="cuda")
         rc = L.slk_gru_fused_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B, I, n, 0, 1, 2, st)
         assert rc == 0, rc
-        ms = timeit(lambda: L.slk_gru_fused_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B, I, n, 0, 1, 2, st))
         fl = 6.0 * T * B * n * n + 6.0 * T * B * n * I
-        print("gru_fused I=%d n=%d B=%d T=%d: %.3f ms  %.1f TF  %.0f ns/step" % (I, n, B, T, ms, fl / ms / 1e9, ms * 1e6 / T))
+        for rnd in range(2):
+            for variant in (0, 1):
+                ms = timeit(lambda: L.slk_gru_fused_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B, I, n, variant * 2, 1, 2, st))
+                import ctypes
+                clk = (ctypes.c_ulonglong * 2)()
+                L.slk_debug_read_clock.argtypes = [ctypes.c_void_p]
+                L.slk_debug_read_clock(clk)
+                ghz = clk[0] / (clk[1] * 10.0) if clk[1] else 0.0
+                if variant & 1:
+                    stp = (ctypes.c_ulonglong * 16)()
+                    L.slk_debug_read_stamps.argtypes = [ctypes.c_void_p]
+                    L.slk_debug_read_stamps(stp)
+                    names = ["flush/top", "lds reads A", "mfma A+sum", "gates+write", "barrier1", "lds reads B", "mfma B+sum", "tanh+update+write", "barrier2"]
+                    print("   per-step cycles (wave0/wg0): " + ", ".join("%s=%.0f" % (nm, stp[i] / T) for i, nm in enumerate(names)))
+                print("gru_fused v%d I=%d n=%d B=%d T=%d: %.3f ms  %.1f TF  %.0f ns/step | wg0: %d cycles, %.2f GHz, %.0f cycles/step" % (variant, I, n, B, T, ms, fl / ms / 1e9, ms * 1e6 / T, clk[0], ghz, clk[0] / T))
     if "gemm" in what:
         for (K, N) in ((n, 3 * n), (n, 1025)):
             M = T * B
