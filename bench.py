@@ -122,18 +122,28 @@ def main():
 
     stages = rec.summary() if rec is not None else {}
     roofline = None
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/collect_pmc.sh);
+    # only quoted when the file describes the configuration being run.
+    traffic_by_stage = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("workload") == [args.model, args.batch, args.chunk_len]:
+            traffic_by_stage = pmc.get("stage_bytes_per_launch", {})
+    except (OSError, ValueError):
+        pass
     if stages:
         dom = max(stages, key=lambda k: stages[k]["ms_total"])
         d = stages[dom]
         if dom in MFMA_STAGES:
             ach = d["flops"] / d["calls"] / (d["ms_avg"] * 1e-3) / 1e12
             roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                        "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic_by_stage.get(dom),
                         "ms_per_launch": d["ms_avg"], "launches": d["calls"]}
         else:
             ach = d["bytes"] / d["calls"] / (d["ms_avg"] * 1e-3) / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "ms_per_launch": d["ms_avg"],
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic_by_stage.get(dom), "ms_per_launch": d["ms_avg"],
                         "launches": d["calls"]}
     if rank == 0:
         cpu = None

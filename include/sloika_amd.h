@@ -116,6 +116,13 @@ int slk_gemm_bias_act_f32(const float *x, long ldx, const float *W, const float 
 /* Softmax.run (sloika/layers.py:309-314): logits = x.W^T + b; p = exp(l - max) / sum.  y:[M][N] dense.      */
 int slk_linear_softmax_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long M, int K,
                            int N, slk_stream_t stream);
+/* x-stationary variant for wide outputs (csrc/gemm_rows.hip): logits y[r][j] = x[r].W[j] + b[j] with row stride ldy,
+ * plus (when stats != NULL) stats[r] = (max_j, 1 / sum_j exp(y[r][j] - max_j)) accumulated on the fly.  K <= 128, else
+ * SLK_ERR_UNSUPPORTED.  slk_softmax_from_stats_f32 turns (logits, stats) into the posterior exp(l - max) * inv_sum.    */
+int slk_linear_rowstats_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long ldy, long M, int K,
+                            int N, float *stats /* [M][2] or NULL */, slk_stream_t stream);
+int slk_softmax_from_stats_f32(const float *logits, long ld_in, const float *stats, float *post, long ld_out, long M,
+                               int N, slk_stream_t stream);
 /* In-place row softmax of y:[M][N] (the second half of the above, exposed for testing).                     */
 int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream);
 /* Row statistics only: stats[r] = (max_j logits[r][j], 1 / sum_j exp(logits[r][j] - max)); the posterior
@@ -193,14 +200,16 @@ int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, int klen, f
 int slk_log_post_f32(const float *post, float *lpost, size_t count, int input_mode, float min_prob,
                      slk_stream_t stream);
 /* Softmax.run + decode_post in one pass over the LOGITS (sloika/layers.py:309-314 + sloika/basecall.py:26-51):
- * logits:[T][B][nstate] = x.W^T + b,  stats:[T*B][2] from slk_softmax_rowstats_f32.  Same outputs as
+ * logits: rows (t,b) of nstate floats, `ld` floats apart, = x.W^T + b;  stats:[T*B][2] from slk_linear_rowstats_f32
+ * (or slk_softmax_rowstats_f32 for dense logits).  Same outputs as
  * slk_viterbi_kmer_f32(SLK_POST_RAW) on the normalised posterior, bit for bit.  slk_log_post_logits_f32 exposes the
  * log-posterior it decodes (for tests).                                                                          */
-int slk_viterbi_kmer_logits_f32(const float *logits, const float *stats, int T, int B, int nbase, int klen,
-                                float skip_pen, float min_prob, void *workspace, size_t workspace_bytes,
-                                float *score_out, int32_t *path_out, int32_t *len_out, slk_stream_t stream);
-int slk_log_post_logits_f32(const float *logits, const float *stats, float *lpost, size_t rows, int nstate,
-                            float min_prob, slk_stream_t stream);
+int slk_viterbi_kmer_logits_f32(const float *logits, long ld /* floats between rows, >= nstate */, const float *stats,
+                                int T, int B, int nbase, int klen, float skip_pen, float min_prob, void *workspace,
+                                size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out,
+                                slk_stream_t stream);
+int slk_log_post_logits_f32(const float *logits, long ld, const float *stats, float *lpost /* dense [rows][nstate] */,
+                            size_t rows, int nstate, float min_prob, slk_stream_t stream);
 /* decode.prepare_post on its own: out = min_prob + (1-min_prob)*post (decode.py:36).                        */
 int slk_prepare_post_f32(const float *post, float *out, size_t count, float min_prob, slk_stream_t stream);
 /* decode.argmax (decode.py:5-18), batched: per (b) the states with argmax != blank, minus 1 if

@@ -31,10 +31,12 @@ PROTOTYPES = {
     "slk_window_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "slk_gemm_bias_act_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
     "slk_linear_softmax_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _vp]),
+    "slk_linear_rowstats_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _l, _i, _i, _vp, _vp]),
+    "slk_softmax_from_stats_f32": (_i, [_vp, _l, _vp, _vp, _l, _l, _i, _vp]),
     "slk_softmax_rows_f32": (_i, [_vp, _l, _i, _vp]),
     "slk_softmax_rowstats_f32": (_i, [_vp, _l, _i, _vp, _vp]),
-    "slk_viterbi_kmer_logits_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _sz, _vp, _vp, _vp, _vp]),
-    "slk_log_post_logits_f32": (_i, [_vp, _vp, _vp, _sz, _i, _f, _vp]),
+    "slk_viterbi_kmer_logits_f32": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _f, _f, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "slk_log_post_logits_f32": (_i, [_vp, _l, _vp, _vp, _sz, _i, _f, _vp]),
     "slk_gru_recurrent_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_gru_recurrent_f32_ex": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_gru_workspace_bytes": (_sz, [_i, _i, _i]),

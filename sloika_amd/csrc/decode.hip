@@ -51,12 +51,14 @@ __global__ void log_post_kernel(const float *__restrict__ post, float *__restric
         lpost[i] = log_post_val(post[i], mode, min_prob, one_m);
 }
 
-__global__ void log_logits_kernel(const float *__restrict__ logits, const float2 *__restrict__ stats,
+__global__ void log_logits_kernel(const float *__restrict__ logits, long ld, const float2 *__restrict__ stats,
                                   float *__restrict__ lpost, size_t rows, int nst, float min_prob, float one_m)
 {
     const size_t count = rows * nst;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
-        lpost[i] = log_logit_val(logits[i], stats[i / nst], min_prob, one_m);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / nst;
+        lpost[i] = log_logit_val(logits[row * ld + (i - row * nst)], stats[row], min_prob, one_m);
+    }
 }
 
 __global__ void prepare_post_kernel(const float *__restrict__ post, float *__restrict__ out, size_t count,
@@ -86,12 +88,12 @@ extern "C" int slk_log_post_f32(const float *post, float *lpost, size_t count, i
     return slk_launch_status();
 }
 
-extern "C" int slk_log_post_logits_f32(const float *logits, const float *stats, float *lpost, size_t rows, int nstate,
-                                       float min_prob, slk_stream_t stream)
+extern "C" int slk_log_post_logits_f32(const float *logits, long ld, const float *stats, float *lpost, size_t rows,
+                                       int nstate, float min_prob, slk_stream_t stream)
 {
-    if (!logits || !stats || !lpost || nstate < 1) return SLK_ERR_INVALID_ARG;
+    if (!logits || !stats || !lpost || nstate < 1 || ld < nstate) return SLK_ERR_INVALID_ARG;
     if (!rows) return SLK_OK;
-    hipLaunchKernelGGL(log_logits_kernel, dim3(grid_for(rows * nstate)), dim3(256), 0, slk_stream(stream), logits,
+    hipLaunchKernelGGL(log_logits_kernel, dim3(grid_for(rows * nstate)), dim3(256), 0, slk_stream(stream), logits, ld,
                        reinterpret_cast<const float2 *>(stats), lpost, rows, nstate, min_prob,
                        one_minus(min_prob, (double)min_prob));
     return slk_launch_status();
@@ -111,7 +113,7 @@ extern "C" int slk_prepare_post_f32(const float *post, float *out, size_t count,
 // ------------------------------------------------------------------------------------------------------
 template <int NB, bool LOGITS>
 __global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__restrict__ post,
-                                                               const float2 *__restrict__ stats, int T, int B,
+                                                               const float2 *__restrict__ stats, long ld, int T, int B,
                                                                int nkmer, float skip_pen, int mode, float min_prob,
                                                                float one_m, uint8_t *__restrict__ tb,
                                                                int32_t *__restrict__ best_out,
@@ -128,9 +130,8 @@ __global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__re
     const int b = blockIdx.x, j = threadIdx.x;                 // thread j owns to-states j*NB .. j*NB+NB-1
     const bool active = j < nrem1;
     const int jj = active ? j : 0, j2 = jj / NB;
-    const int nst = nkmer + 1;
-    const float *pb = post + (size_t)b * nst;
-    const size_t tstride = (size_t)B * nst;
+    const float *pb = post + (size_t)b * ld;            // rows (t, b) are `ld` floats apart (ld >= nkmer + 1)
+    const size_t tstride = (size_t)B * ld;
     uint8_t *tbb = tb + (size_t)b * T * nkmer;
 
     auto xform = [&](float val, float2 st) {
@@ -329,7 +330,7 @@ extern "C" size_t slk_viterbi_kmer_workspace_bytes(int T, int B, int nbase, int 
 }
 
 template <int NB>
-static int launch_viterbi(const float *post, const float *stats, int T, int B, int klen, int nkmer, float skip_pen, int mode, float min_prob,
+static int launch_viterbi(const float *post, const float *stats, long ld, int T, int B, int klen, int nkmer, float skip_pen, int mode, float min_prob,
                           uint8_t *tb, int32_t *best, float *score_out, int32_t *path_out, int32_t *len_out,
                           hipStream_t s)
 {
@@ -340,10 +341,10 @@ static int launch_viterbi(const float *post, const float *stats, int T, int B, i
     float one_m = (float)(1.0 - (double)min_prob);
     if (stats)
         hipLaunchKernelGGL((viterbi_forward_kernel<NB, true>), dim3(B), dim3(threads), lds, s, post,
-                           reinterpret_cast<const float2 *>(stats), T, B, nkmer, skip_pen, mode, min_prob, one_m, tb, best,
+                           reinterpret_cast<const float2 *>(stats), ld, T, B, nkmer, skip_pen, mode, min_prob, one_m, tb, best,
                            score_out);
     else
-        hipLaunchKernelGGL((viterbi_forward_kernel<NB, false>), dim3(B), dim3(threads), lds, s, post, nullptr, T, B, nkmer,
+        hipLaunchKernelGGL((viterbi_forward_kernel<NB, false>), dim3(B), dim3(threads), lds, s, post, nullptr, ld, T, B, nkmer,
                            skip_pen, mode, min_prob, one_m, tb, best, score_out);
     int rc = slk_launch_status();
     if (rc != SLK_OK) return rc;
@@ -355,7 +356,7 @@ static int launch_viterbi(const float *post, const float *stats, int T, int B, i
     return slk_launch_status();
 }
 
-static int viterbi_entry(const float *post, const float *stats, int T, int B, int nbase, int klen, float skip_pen,
+static int viterbi_entry(const float *post, const float *stats, long ld, int T, int B, int nbase, int klen, float skip_pen,
                          int input_mode, float min_prob, void *workspace, size_t workspace_bytes, float *score_out,
                          int32_t *path_out, int32_t *len_out, slk_stream_t stream)
 {
@@ -363,6 +364,8 @@ static int viterbi_entry(const float *post, const float *stats, int T, int B, in
     if (!post || !score_out || !path_out || !len_out || T < 1 || B < 1 || input_mode < 0 || input_mode > 2)
         return SLK_ERR_INVALID_ARG;
     if (!vit_dims(nbase, klen, &nkmer)) return SLK_ERR_INVALID_ARG;      // decode.py:50
+    if (ld == 0) ld = nkmer + 1;
+    if (ld < nkmer + 1) return SLK_ERR_INVALID_ARG;
     size_t need = slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen);
     if (!workspace || workspace_bytes < need) return SLK_ERR_WORKSPACE;
     uint8_t *tb = static_cast<uint8_t *>(workspace);
@@ -370,8 +373,8 @@ static int viterbi_entry(const float *post, const float *stats, int T, int B, in
     int32_t *best = reinterpret_cast<int32_t *>(tb + tbbytes);
     hipStream_t s = slk_stream(stream);
     switch (nbase) {
-    case 4: return launch_viterbi<4>(post, stats, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
-    case 5: return launch_viterbi<5>(post, stats, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
+    case 4: return launch_viterbi<4>(post, stats, ld, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
+    case 5: return launch_viterbi<5>(post, stats, ld, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
     default: return SLK_ERR_UNSUPPORTED;
     }
 }
@@ -380,16 +383,16 @@ extern "C" int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, 
                                     int input_mode, float min_prob, void *workspace, size_t workspace_bytes,
                                     float *score_out, int32_t *path_out, int32_t *len_out, slk_stream_t stream)
 {
-    return viterbi_entry(post, nullptr, T, B, nbase, klen, skip_pen, input_mode, min_prob, workspace, workspace_bytes,
+    return viterbi_entry(post, nullptr, 0, T, B, nbase, klen, skip_pen, input_mode, min_prob, workspace, workspace_bytes,
                          score_out, path_out, len_out, stream);
 }
 
-extern "C" int slk_viterbi_kmer_logits_f32(const float *logits, const float *stats, int T, int B, int nbase, int klen,
+extern "C" int slk_viterbi_kmer_logits_f32(const float *logits, long ld, const float *stats, int T, int B, int nbase, int klen,
                                            float skip_pen, float min_prob, void *workspace, size_t workspace_bytes,
                                            float *score_out, int32_t *path_out, int32_t *len_out, slk_stream_t stream)
 {
     if (!stats) return SLK_ERR_INVALID_ARG;
-    return viterbi_entry(logits, stats, T, B, nbase, klen, skip_pen, SLK_POST_RAW, min_prob, workspace, workspace_bytes,
+    return viterbi_entry(logits, stats, ld, T, B, nbase, klen, skip_pen, SLK_POST_RAW, min_prob, workspace, workspace_bytes,
                          score_out, path_out, len_out, stream);
 }
 

@@ -99,17 +99,18 @@ def viterbi_batch(post, klen, skip_pen=0.0, log=False, nbase=4, min_prob=None, w
     return scores, paths, lens
 
 
-def viterbi_logits_batch(logits, stats, klen, skip_pen=0.0, nbase=4, min_prob=1e-5, workspace=None):
-    """basecall.decode_post over the batch axis, fed with the Softmax layer's LOGITS [T,B,nstate] and their row
-    statistics (layers.Softmax.logits_and_stats): softmax, prepare_post, log and Viterbi in one pass over the logits.
+def viterbi_logits_batch(logits, stats, klen, T, B, ld=None, skip_pen=0.0, nbase=4, min_prob=1e-5, workspace=None):
+    """basecall.decode_post over the batch axis, fed with the Softmax layer's LOGITS (rows (t,b) of nstate floats, `ld`
+    floats apart) and their row statistics (layers.Softmax.logits_and_stats): softmax, prepare_post, log and Viterbi in one pass over the logits.
     Bit-identical to viterbi_batch(softmax(logits), min_prob=min_prob)."""
     import torch
     from . import device as D
-    T, B, S = logits.shape
     if klen < 3:
         raise ValueError("Kmer not long enough to apply Viterbi with skips")
-    if sv.nstate(klen, transducer=True, nbase=nbase) != S:
-        raise ValueError("logits have %d states, klen=%d nbase=%d needs %d" % (S, klen, nbase, sv.nstate(klen, nbase=nbase)))
+    S = sv.nstate(klen, transducer=True, nbase=nbase)
+    ld = S if ld is None else ld
+    if ld < S or logits.numel() < T * B * ld:
+        raise ValueError("logits buffer too small for T=%d B=%d ld=%d" % (T, B, ld))
     L = _lib.lib()
     nbytes = L.slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen)
     if nbytes == 0:
@@ -120,7 +121,7 @@ def viterbi_logits_batch(logits, stats, klen, skip_pen=0.0, nbase=4, min_prob=1e
     lens = torch.empty(B, dtype=torch.int32, device=logits.device)
     nk = nbase ** klen
     with profiler.region("viterbi", 0.0, float(T) * B * (4.0 * S + 2.0 * nk)):
-        rc = L.slk_viterbi_kmer_logits_f32(logits.data_ptr(), stats.data_ptr(), T, B, nbase, klen, float(skip_pen),
+        rc = L.slk_viterbi_kmer_logits_f32(logits.data_ptr(), ld, stats.data_ptr(), T, B, nbase, klen, float(skip_pen),
                                            float(min_prob), ws.data_ptr(), nbytes, scores.data_ptr(), paths.data_ptr(),
                                            lens.data_ptr(), D.stream_ptr())
     _lib.check(rc, "decode.viterbi_logits")

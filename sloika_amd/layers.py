@@ -306,45 +306,51 @@ class Softmax(Layer):
     def params(self):
         return [self.W, self.b] if self.has_bias else [self.W]
 
-    def _forward(self, x, out, reverse):
+    def _logits(self, x, ld):
+        """tmp = x.W^T + b (layers.py:310) with rows `ld` floats apart, and per-row (max, 1/sum exp) [T*B,2]."""
         import torch
         T, B, _ = x.shape
-        dense = out is None or out.stride(1) != self.size
-        y = torch.empty((T, B, self.size), dtype=torch.float32, device=x.device) if dense else out
         rows, L = T * B, _lib.lib()
-        with profiler.region("softmax_gemm", 2.0 * rows * self.insize * self.size,
-                             4.0 * rows * (self.insize + self.size)):
-            rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
-                                         self.b.dev().data_ptr(), y.data_ptr(), self.size, rows, self.insize,
-                                         self.size, 0, _stream())
-        _lib.check(rc, "Softmax")
-        with profiler.region("softmax_rows", 0.0, 8.0 * rows * self.size):
-            rc = L.slk_softmax_rows_f32(y.data_ptr(), rows, self.size, _stream())
-        _lib.check(rc, "Softmax")
-        if out is not None and dense:
-            out.copy_(y)
-            return out
-        return y
-
-    def logits_and_stats(self, x):
-        """tmp = x.W^T + b (layers.py:310) as [T,B,size] plus per-row (max, 1/sum exp) [T*B,2]: what the decoder needs to
-        rebuild the posterior on the fly, so the normalised tensor is never written (decode.viterbi_logits_batch)."""
-        import torch
-        x = _check_input(x, self.insize)
-        T, B, _ = x.shape
-        rows, L = T * B, _lib.lib()
-        y = torch.empty((T, B, self.size), dtype=torch.float32, device=x.device)
+        y = torch.empty((rows, ld), dtype=torch.float32, device=x.device)
         stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
         with profiler.region("softmax_gemm", 2.0 * rows * self.insize * self.size,
                              4.0 * rows * (self.insize + self.size)):
-            rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
-                                         self.b.dev().data_ptr(), y.data_ptr(), self.size, rows, self.insize,
-                                         self.size, 0, _stream())
-        _lib.check(rc, "Softmax")
-        with profiler.region("softmax_rowstats", 0.0, 4.0 * rows * self.size):
-            rc = L.slk_softmax_rowstats_f32(y.data_ptr(), rows, self.size, stats.data_ptr(), _stream())
+            rc = L.slk_linear_rowstats_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
+                                           self.b.dev().data_ptr(), y.data_ptr(), ld, rows, self.insize, self.size,
+                                           stats.data_ptr(), _stream())
+            if rc == _lib.SLK_ERR_UNSUPPORTED:
+                # insize > 128: tiled GEMM, then a statistics pass over the (dense) logits
+                if ld != self.size:
+                    raise _lib.SloikaAmdError("internal: the statistics pass needs dense logits")
+                rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
+                                             self.b.dev().data_ptr(), y.data_ptr(), ld, rows, self.insize, self.size,
+                                             0, _stream())
+                _lib.check(rc, "Softmax")
+                rc = L.slk_softmax_rowstats_f32(y.data_ptr(), rows, self.size, stats.data_ptr(), _stream())
         _lib.check(rc, "Softmax")
         return y, stats
+
+    def logits_and_stats(self, x):
+        """What the decoder needs to rebuild the posterior on the fly (decode.viterbi_logits_batch): logits with a
+        128-byte aligned row stride plus the row statistics.  The normalised posterior is never written."""
+        x = _check_input(x, self.insize)
+        ld = self.size if self.insize > 128 else ((self.size + 31) // 32) * 32
+        y, stats = self._logits(x, ld)
+        return y, stats, ld
+
+    def _forward(self, x, out, reverse):
+        T, B, _ = x.shape
+        logits, stats = self._logits(x, self.size)
+        y = out if (out is not None and out.stride(1) == self.size) else logits.view(T, B, self.size)
+        rows = T * B
+        with profiler.region("softmax_normalise", 0.0, 8.0 * rows * self.size):
+            rc = _lib.lib().slk_softmax_from_stats_f32(logits.data_ptr(), self.size, stats.data_ptr(), y.data_ptr(),
+                                                       self.size, rows, self.size, _stream())
+        _lib.check(rc, "Softmax")
+        if out is not None and y is not out:
+            out.copy_(y)
+            return out
+        return y
 
     def spec(self):
         return {"type": "softmax", "W": self.W.get_value(), "b": self.b.get_value()}

@@ -59,9 +59,10 @@ class Basecaller(object):
         last = net.layers[-1] if isinstance(net, layers.Serial) else None
         if type(last) is layers.Softmax and len(net.layers) > 1:
             hid = self._hidden(chunks, len(net.layers) - 1)
-            logits, stats = last.logits_and_stats(hid)
-            return decode.viterbi_logits_batch(logits, stats, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
-                                               min_prob=self.min_prob, workspace=self._ws)
+            logits, stats, ld = last.logits_and_stats(hid)
+            T, B = hid.shape[0], hid.shape[1]
+            return decode.viterbi_logits_batch(logits, stats, self.kmer_len, T, B, ld=ld, skip_pen=self.skip,
+                                               nbase=self.nbase, min_prob=self.min_prob, workspace=self._ws)
         post = self.posteriors(chunks)
         return decode.viterbi_batch(post, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
                                     min_prob=self.min_prob, workspace=self._ws)

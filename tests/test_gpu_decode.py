@@ -135,32 +135,50 @@ def test_viterbi_argument_errors():
 
 def test_viterbi_on_logits_equals_viterbi_on_posterior(oracle):
     """Softmax + prepare_post + log + Viterbi in one pass over the logits == the same stages run separately,
-    bit for bit, and == the oracle decoder on the log-posterior the device derives from the logits."""
+    bit for bit, and == the oracle decoder on the log-posterior the device derives from the logits.
+    Both the fused projection+statistics kernel (padded row stride) and the stand-alone statistics pass are covered."""
     torch = need_gpu()
     from sloika_amd import _lib, decode
     rs = np.random.RandomState(5)
-    T, B, S = 90, 6, 1025
-    logits = (rs.normal(size=(T, B, S)) * 3.0).astype(np.float32)
-    logits[10] = 2.0                      # a flat row: every state ties
-    logits[20, :, 0] = 60.0               # a dominant blank
-    ld = dev(logits)
+    T, B, S, K = 90, 6, 1025, 96
+    x = rs.normal(size=(T * B, K)).astype(np.float32)
+    W = (rs.normal(size=(S, K)) * 0.6).astype(np.float32)
+    b = rs.normal(size=S).astype(np.float32)
+    b[0] += 3.0
+    x[10 * B:11 * B] = 0.0                 # rows whose logits are just the bias
+    xd, Wd, bd = dev(x), dev(W), dev(b)
     L = _lib.lib()
-    stats = torch.empty((T * B, 2), dtype=torch.float32, device="cuda")
-    assert L.slk_softmax_rowstats_f32(ld.data_ptr(), T * B, S, stats.data_ptr(), stream()) == 0
-    post = ld.clone()
-    assert L.slk_softmax_rows_f32(post.data_ptr(), T * B, S, stream()) == 0
-    np.testing.assert_allclose(post.cpu().numpy().sum(axis=2), 1.0, atol=1e-5)
-    m = logits.max(axis=2).reshape(-1)
-    np.testing.assert_array_equal(stats[:, 0].cpu().numpy(), m)
-    for skip in (0.0, 4.0):
-        s1, p1, l1 = decode.viterbi_logits_batch(ld, stats, 5, skip_pen=skip, min_prob=1e-5)
-        s2, p2, l2 = decode.viterbi_batch(post, 5, skip_pen=skip, min_prob=1e-5)
-        assert torch.equal(p1, p2) and torch.equal(l1, l2) and torch.equal(s1, s2)
-        lp = torch.empty_like(ld)
-        assert L.slk_log_post_logits_f32(ld.data_ptr(), stats.data_ptr(), lp.data_ptr(), T * B, S, 1e-5, stream()) == 0
-        o_s, o_p, o_l = oracle.viterbi_batch(lp.cpu().numpy(), 5, skip_pen=skip)
-        assert np.array_equal(p1.cpu().numpy(), o_p) and np.array_equal(l1.cpu().numpy(), o_l)
-        assert np.array_equal(s1.cpu().numpy(), o_s)
-    # and the log-posterior itself is the reference transform of the softmax within float32 rounding
-    ref = np.log(np.float32(1e-5) + np.float32(1 - 1e-5) * post.cpu().numpy() + np.float32(1e-10))
-    np.testing.assert_allclose(lp.cpu().numpy(), ref, rtol=1e-6, atol=2e-6)
+    for ld in (1056, 1025):
+        logits = torch.full((T * B, ld), np.nan, dtype=torch.float32, device="cuda")
+        stats = torch.empty((T * B, 2), dtype=torch.float32, device="cuda")
+        assert L.slk_linear_rowstats_f32(xd.data_ptr(), K, Wd.data_ptr(), bd.data_ptr(), logits.data_ptr(), ld, T * B, K, S,
+                                         stats.data_ptr(), stream()) == 0
+        lg = logits[:, :S].cpu().numpy()
+        ref_l = x.astype(np.float64) @ W.astype(np.float64).T + b
+        np.testing.assert_allclose(lg, ref_l, atol=2e-5)
+        np.testing.assert_array_equal(stats[:, 0].cpu().numpy(), lg.max(axis=1))
+        np.testing.assert_allclose(1.0 / stats[:, 1].cpu().numpy(),
+                                   np.exp(lg - lg.max(axis=1, keepdims=True)).astype(np.float64).sum(axis=1), rtol=2e-6)
+        post = torch.empty((T, B, S), dtype=torch.float32, device="cuda")
+        assert L.slk_softmax_from_stats_f32(logits.data_ptr(), ld, stats.data_ptr(), post.data_ptr(), S, T * B, S, stream()) == 0
+        np.testing.assert_allclose(post.cpu().numpy().sum(axis=2), 1.0, atol=1e-5)
+        lp = torch.empty((T, B, S), dtype=torch.float32, device="cuda")
+        assert L.slk_log_post_logits_f32(logits.data_ptr(), ld, stats.data_ptr(), lp.data_ptr(), T * B, S, 1e-5, stream()) == 0
+        for skip in (0.0, 4.0):
+            s1, p1, l1 = decode.viterbi_logits_batch(logits, stats, 5, T, B, ld=ld, skip_pen=skip, min_prob=1e-5)
+            s2, p2, l2 = decode.viterbi_batch(post, 5, skip_pen=skip, min_prob=1e-5)
+            assert torch.equal(p1, p2) and torch.equal(l1, l2) and torch.equal(s1, s2)
+            o_s, o_p, o_l = oracle.viterbi_batch(lp.cpu().numpy(), 5, skip_pen=skip)
+            assert np.array_equal(p1.cpu().numpy(), o_p) and np.array_equal(l1.cpu().numpy(), o_l)
+            assert np.array_equal(s1.cpu().numpy(), o_s)
+        ref = np.log(np.float32(1e-5) + np.float32(1 - 1e-5) * post.cpu().numpy() + np.float32(1e-10))
+        np.testing.assert_allclose(lp.cpu().numpy(), ref, rtol=1e-6, atol=2e-6)
+    # stand-alone statistics pass over dense logits (the K > 128 fallback) agrees with the in-place softmax kernel
+    dense = logits[:, :S].contiguous()
+    st2 = torch.empty((T * B, 2), dtype=torch.float32, device="cuda")
+    assert L.slk_softmax_rowstats_f32(dense.data_ptr(), T * B, S, st2.data_ptr(), stream()) == 0
+    p_a = torch.empty((T * B, S), dtype=torch.float32, device="cuda")
+    assert L.slk_softmax_from_stats_f32(dense.data_ptr(), S, st2.data_ptr(), p_a.data_ptr(), S, T * B, S, stream()) == 0
+    p_b = dense.clone()
+    assert L.slk_softmax_rows_f32(p_b.data_ptr(), T * B, S, stream()) == 0
+    assert torch.equal(p_a, p_b)

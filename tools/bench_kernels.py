@@ -80,6 +80,19 @@ def main():
             ms = timeit(lambda: L.slk_gemm_bias_act_f32(x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), N, M, K, N, 0, st), reps=5)
             print("gemm M=%d K=%d N=%d: %.3f ms  %.1f TF" % (M, K, N, ms, 2.0 * M * K * N / ms / 1e9))
             del x, W, y
+    if "gemmrows" in what:
+        M, K, N = T * B, n, 1025
+        x = torch.randn(M, K, device="cuda")
+        W = torch.randn(N, K, device="cuda") * 0.3
+        b = torch.randn(N, device="cuda")
+        for ld in (1025, 1056):
+            y = torch.empty(M, ld, device="cuda")
+            stats = torch.empty(M, 2, device="cuda")
+            for rnd in range(2):
+                ms0 = timeit(lambda: L.slk_linear_rowstats_f32(x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), ld, M, K, N, None, st), reps=5)
+                ms1 = timeit(lambda: L.slk_linear_rowstats_f32(x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), ld, M, K, N, stats.data_ptr(), st), reps=5)
+                print("gemm_rows M=%d K=%d N=%d ld=%d: no-stats %.3f ms (%.1f TF)  with-stats %.3f ms (%.1f TF)" % (M, K, N, ld, ms0, 2.0 * M * K * N / ms0 / 1e9, ms1, 2.0 * M * K * N / ms1 / 1e9))
+            del y
     if "softmax" in what:
         M, N = T * B, 1025
         y = torch.randn(M, N, device="cuda")

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM bytes per launch.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM): both counters are in KiB; FETCH_SIZE reports exactly half of the bytes of
+a wide coalesced streaming read (128-B requests tallied at 64 B) -> doubled; WRITE_SIZE is exact for 16-B-per-lane
+streaming stores.  Other access widths are uncalibrated, so the figures are upper-level estimates, not exact bytes.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(d):
+    out = collections.defaultdict(list)
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            out[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    fetch, write = load(sys.argv[1]), load(sys.argv[2])
+    res = {}
+    for k in sorted(set(fetch) | set(write)):
+        f = sum(fetch.get(k, [0])) / max(1, len(fetch.get(k, [])))
+        w = sum(write.get(k, [0])) / max(1, len(write.get(k, [])))
+        res[k] = {"launches_sampled": len(fetch.get(k, [])), "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w,
+                  "hbm_read_bytes": 2.0 * f * 1024.0, "hbm_write_bytes": w * 1024.0,
+                  "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+    json.dump({"note": "bytes per launch; FETCH_SIZE doubled per the gfx950 correction", "kernels": res}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
