@@ -79,44 +79,95 @@ extern "C" int slk_med_mad_normalise_f32(const float *signal, int nchunk, int ch
 }
 
 // ------------------------------------------------------------------------------------------------------
-// conv1d.  Thread <-> one output element, Cout fastest so that stores are fully coalesced; the filter is
-// staged transposed in LDS (Wt[c][k][o]) so that lanes read consecutive words; the Cin*winlen input taps
-// of one (to, b) are shared by the Cout lanes computing it and come from L1/L2.
+// conv1d.  threadIdx.x <-> output feature (so stores are fully coalesced), threadIdx.y <-> one of PPB (to, b)
+// positions handled per block iteration; the filter is staged transposed in LDS (Wt[c][k][o]) so lanes read
+// consecutive words; the Cin*winlen input taps of a position are the same address for every lane of a row of the
+// block (a broadcast load).  All index arithmetic is 32-bit (one divide per position, none per output element).
 // ------------------------------------------------------------------------------------------------------
 template <bool W_IN_LDS>
-__global__ void __launch_bounds__(256) conv1d_kernel(const float *__restrict__ x, long xs_t, long xs_b,
+__global__ void __launch_bounds__(512) conv1d_kernel(const float *__restrict__ x, long xs_t, long xs_b,
                                                      const float *__restrict__ W, const float *__restrict__ bias,
                                                      float *__restrict__ y, int T, int B, int Cin, int Cout,
                                                      int winlen, int stride, int pad_l, int Tout, int act)
 {
     extern __shared__ float wt[];
     const int ckn = Cin * winlen;
+    const int nthreads = blockDim.x * blockDim.y, tid = threadIdx.y * blockDim.x + threadIdx.x;
     if (W_IN_LDS) {
-        for (int i = threadIdx.x; i < ckn * Cout; i += blockDim.x) {
+        for (int i = tid; i < ckn * Cout; i += nthreads) {
             int o = i / ckn, ck = i - o * ckn;
             wt[ck * Cout + o] = W[i];
         }
         __syncthreads();
     }
-    const size_t total = (size_t)Tout * B * Cout;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        int o = (int)(idx % Cout);
-        size_t tb = idx / Cout;
-        int b = (int)(tb % B);
-        int to = (int)(tb / B);
+    const unsigned npos = (unsigned)Tout * (unsigned)B;
+    for (unsigned p = blockIdx.x * blockDim.y + threadIdx.y; p < npos; p += gridDim.x * blockDim.y) {
+        const int to = (int)(p / (unsigned)B), b = (int)(p - (unsigned)to * (unsigned)B);
         const float *xb = x + (size_t)b * xs_b;
-        float s = 0.0f;
-        for (int c = 0; c < Cin; c++) {
-            for (int k = 0; k < winlen; k++) {
-                int ti = to * stride + k - pad_l;
-                if (ti < 0 || ti >= T) continue;
-                float xv = xb[(size_t)ti * xs_t + c];
-                float wv = W_IN_LDS ? wt[(c * winlen + k) * Cout + o] : W[((size_t)o * Cin + c) * winlen + k];
-                s = fmaf(xv, wv, s);
+        float *yp = y + (size_t)p * Cout;
+        const int t0 = to * stride - pad_l;
+        for (int o = threadIdx.x; o < Cout; o += blockDim.x) {
+            float s = 0.0f;
+            for (int c = 0; c < Cin; c++) {
+                for (int k = 0; k < winlen; k++) {
+                    const int ti = t0 + k;
+                    if (ti < 0 || ti >= T) continue;
+                    const float xv = xb[(size_t)ti * xs_t + c];
+                    const float wv = W_IN_LDS ? wt[(c * winlen + k) * Cout + o] : W[((size_t)o * Cin + c) * winlen + k];
+                    s = fmaf(xv, wv, s);
+                }
+            }
+            if (bias) s += bias[o];
+            yp[o] = slk_act(act, s);
+        }
+    }
+}
+
+// Single-input-channel specialisation (every raw-signal front end: Cin = 1, winlen = 11, stride 2 or 5).
+// One WAVE handles a run of consecutive output steps of ONE chunk: the 64 lanes load 128 consecutive input samples
+// with two coalesced loads, every tap is then handed to all lanes with v_readlane (a scalar operand of the FMA), and
+// the lanes -- one output feature each, filter taps in registers -- emit up to 24 output rows from those two loads.
+// (The generic kernel issues winlen broadcast loads per output row and is latency bound: 0.8 ms vs HBM time 0.06 ms.)
+template <int WMAX>
+__global__ void __launch_bounds__(256) conv1d_cin1_kernel(const float *__restrict__ x, long xs_t, long xs_b,
+                                                          const float *__restrict__ W, const float *__restrict__ bias,
+                                                          float *__restrict__ y, int T, int B, int Cout, int winlen,
+                                                          int stride, int pad_l, int Tout, int act, int npos_run)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned runs_per_chunk = (unsigned)((Tout + npos_run - 1) / npos_run);
+    const unsigned nrun = runs_per_chunk * (unsigned)B, nwave = gridDim.x * 4u;
+    for (int o0 = 0; o0 < Cout; o0 += 64) {
+        const int o = o0 + lane;
+        const bool ok = o < Cout;
+        float w[WMAX];
+#pragma unroll
+        for (int k = 0; k < WMAX; k++) w[k] = (ok && k < winlen) ? W[(size_t)o * winlen + k] : 0.0f;
+        const float bv = (bias && ok) ? bias[o] : 0.0f;
+        for (unsigned run = blockIdx.x * 4u + wave; run < nrun; run += nwave) {
+            // consecutive runs walk the batch first so that neighbouring waves write neighbouring rows of y
+            const int b = (int)(run % (unsigned)B), to0 = (int)(run / (unsigned)B) * npos_run;
+            const int t0 = to0 * stride - pad_l;                   // input sample of tap 0 of the first position
+            const float *xb = x + (size_t)b * xs_b;
+            const int ta = t0 + lane, tb2 = t0 + 64 + lane;
+            const float v0 = (ta >= 0 && ta < T) ? xb[(size_t)ta * xs_t] : 0.0f;
+            const float v1 = (tb2 >= 0 && tb2 < T) ? xb[(size_t)tb2 * xs_t] : 0.0f;
+            const int npos = min(npos_run, Tout - to0);
+            for (int j = 0; j < npos; j++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int k = 0; k < WMAX; k++) {
+                    if (k < winlen) {
+                        const int i = j * stride + k;              // wave-uniform sample index within the 128 loaded
+                        const float xv = i < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), i))
+                                                : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v1), i - 64));
+                        s = fmaf(xv, w[k], s);
+                    }
+                }
+                if (ok) y[((size_t)(to0 + j) * B + b) * Cout + o] = slk_act(act, s + bv);
             }
         }
-        if (bias) s += bias[o];
-        y[idx] = slk_act(act, s);
     }
 }
 
@@ -137,15 +188,27 @@ extern "C" int slk_conv1d_f32(const float *x, long x_t_stride, long x_b_stride, 
         return SLK_ERR_INVALID_ARG;
     int Tout = slk_conv1d_out_len(T, winlen, stride, pad_l, pad_r);
     if (Tout <= 0) return SLK_ERR_INVALID_ARG;
-    size_t total = (size_t)Tout * B * Cout;
-    size_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if ((size_t)Tout * B > 0x7fffffffu) return SLK_ERR_UNSUPPORTED;
+    if (Cin == 1 && winlen <= 16 && stride <= 16) {
+        int npos_run = (128 - winlen) / stride + 1;               // output steps covered by 128 loaded samples
+        size_t nrun = (size_t)((Tout + npos_run - 1) / npos_run) * B, blocks = (nrun + 3) / 4;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(conv1d_cin1_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, slk_stream(stream), x, x_t_stride,
+                           x_b_stride, W, bias, y, T, B, Cout, winlen, stride, pad_l, Tout, act, npos_run);
+        return slk_launch_status();
+    }
+    // block = (features rounded up to a multiple of 32, up to 128) x (positions): 256..512 threads
+    int bx = Cout >= 128 ? 128 : ((Cout + 31) / 32) * 32;
+    int by = 512 / bx;
+    size_t npos = (size_t)Tout * B;
+    size_t blocks = (npos + by - 1) / by;
+    if (blocks > 256 * 8) blocks = 256 * 8;
     size_t wbytes = (size_t)Cin * winlen * Cout * sizeof(float);
     if (wbytes <= 64 * 1024)
-        hipLaunchKernelGGL(conv1d_kernel<true>, dim3((unsigned)blocks), dim3(256), wbytes, slk_stream(stream), x,
+        hipLaunchKernelGGL(conv1d_kernel<true>, dim3((unsigned)blocks), dim3(bx, by), wbytes, slk_stream(stream), x,
                            x_t_stride, x_b_stride, W, bias, y, T, B, Cin, Cout, winlen, stride, pad_l, Tout, act);
     else
-        hipLaunchKernelGGL(conv1d_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, slk_stream(stream), x,
+        hipLaunchKernelGGL(conv1d_kernel<false>, dim3((unsigned)blocks), dim3(bx, by), 0, slk_stream(stream), x,
                            x_t_stride, x_b_stride, W, bias, y, T, B, Cin, Cout, winlen, stride, pad_l, Tout, act);
     return slk_launch_status();
 }

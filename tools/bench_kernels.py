@@ -80,6 +80,19 @@ def main():
             ms = timeit(lambda: L.slk_gemm_bias_act_f32(x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), N, M, K, N, 0, st), reps=5)
             print("gemm M=%d K=%d N=%d: %.3f ms  %.1f TF" % (M, K, N, ms, 2.0 * M * K * N / ms / 1e9))
             del x, W, y
+    if "conv" in what:
+        Tin, Cout = 4000, n
+        xs = torch.randn(B, Tin, device="cuda")
+        Wc = torch.randn(Cout, 1, 11, device="cuda") * 0.3
+        bc = torch.randn(Cout, device="cuda")
+        Tout = L.slk_conv1d_out_len(Tin, 11, 5, 5, 5)
+        yc = torch.empty(Tout, B, Cout, device="cuda")
+        for act in (0, 1, 3):
+            ms = timeit(lambda: L.slk_conv1d_f32(xs.data_ptr(), 1, Tin, Wc.data_ptr(), bc.data_ptr(), yc.data_ptr(), Tin, B, 1, Cout, 11, 5, 5, 5, act, st), reps=5)
+            print("conv1d chunk-major B=%d Cout=%d act=%d: %.3f ms  %.0f GB/s written" % (B, Cout, act, ms, 4.0 * Tout * B * Cout / ms / 1e6))
+        xt = xs.t().contiguous()
+        ms = timeit(lambda: L.slk_conv1d_f32(xt.data_ptr(), B, 1, Wc.data_ptr(), bc.data_ptr(), yc.data_ptr(), Tin, B, 1, Cout, 11, 5, 5, 5, 3, st), reps=5)
+        print("conv1d [T,B,1] layout act=3: %.3f ms" % ms)
     if "gemmrows" in what:
         M, K, N = T * B, n, 1025
         x = torch.randn(M, K, device="cuda")
