@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                 }
             }
         };
-        constexpr int M0a = (M0 / 2 / 4) * 4;
+        constexpr int M0a = (M0 * 2 / 3 / 4) * 4;           // part b also carries set 1 and the LDS writes
         float xp[NVI];
         f32x4 acc[4];
         auto project_a = [&](int sp) {

@@ -36,11 +36,21 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// lane l and lane l^32 exchanged with one VALU op (v_permlane32_swap) instead of a ds_bpermute round trip
+// K-slice sums without LDS round trips: lane l (+)= lane l^32 / l^16 with the gfx950 row-swap instructions,
+// lane l (+)= lane l^8 with a DPP rotate inside the 16-lane row.  Every lane ends up with the full sum.
 __device__ __forceinline__ float xor32_sum(float v)
 {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_sum(float v)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor8_sum(float v)
+{
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
 }
 
 template <int S>
@@ -48,11 +58,11 @@ __device__ __forceinline__ f32x4 sum_slices(f32x4 v)
 {
     if constexpr (S >= 8) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] += __shfl_xor(v[i], 8);
+        for (int i = 0; i < 4; i++) v[i] = xor8_sum(v[i]);
     }
     if constexpr (S >= 4) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] += __shfl_xor(v[i], 16);
+        for (int i = 0; i < 4; i++) v[i] = xor16_sum(v[i]);
     }
     if constexpr (S >= 2) {
 #pragma unroll
