@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--cpu-chunks", type=int, default=256,
                     help="chunks per slab of the CPU-baseline sample (slabs repeat until ~12 s; 0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams per GPU; with 2, consecutive batches overlap (batch i decodes while batch i+1 "
+                         "runs its recurrent layers)")
     return ap.parse_args()
 
 
@@ -82,19 +85,24 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world)
     net = models.randomise_zero_layers(models.build_model(args.model, klen=5, sd=0.5, seed=11))
-    bc = pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0)
+    nstream = max(1, args.streams)
+    bcs = [pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0) for _ in range(nstream)]
+    bc = bcs[0]
+    streams = [torch.cuda.Stream() for _ in range(nstream)] if nstream > 1 else [torch.cuda.current_stream()]
     B, L = args.batch, args.chunk_len
     # a few distinct batches so that steps do not all hit the same cache lines
     nbuf = 2
     host = [pipeline.synthetic_chunks(B, chunk_len=L, seed=0xdeadbeef, first_chunk=(rank * nbuf + i) * B)
             for i in range(nbuf)]
     dev = [torch.from_numpy(h).cuda() for h in host]
-    out_host = torch.empty((B, bc.network.layers[0].out_len(L) if hasattr(bc.network.layers[0], "out_len") else L),
-                           dtype=torch.int32).pin_memory()
+    tout = bc.network.layers[0].out_len(L) if hasattr(bc.network.layers[0], "out_len") else L
+    out_host = [torch.empty((B, tout), dtype=torch.int32).pin_memory() for _ in range(nstream)]
 
     def step(i):
-        scores, paths, lens = bc.call_chunks(dev[i % nbuf])
-        out_host[:, : paths.shape[1]].copy_(paths, non_blocking=True)     # paths end up on the host
+        k = i % nstream
+        with torch.cuda.stream(streams[k]):
+            scores, paths, lens = bcs[k].call_chunks(dev[i % nbuf])
+            out_host[k][:, : paths.shape[1]].copy_(paths, non_blocking=True)     # paths end up on the host
         return scores, lens
 
     def barrier():
@@ -157,7 +165,7 @@ def main():
             "config": {"workload": "%s inference, %d-sample chunks, batch %d per GPU, klen 5 (1025 states), "
                                    "normalise->conv->GRU->softmax->Viterbi->paths on host" % (args.model, L, B),
                        "model": args.model, "chunk_len": L, "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": "chunks sharded over %d GPU(s), no collective" % world},
+                       "parallelism": "chunks sharded over %d GPU(s), no collective" % world, "streams_per_gpu": nstream},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())},

@@ -15,6 +15,7 @@ Convention (sloika/layers.py:13-14): tensors are row major (time, batch, feature
 There is no CPU fallback: without the HIP library / a GPU, `run` raises.
 """
 import abc
+import os
 from collections import OrderedDict
 from functools import reduce
 
@@ -306,6 +307,29 @@ class Softmax(Layer):
     def params(self):
         return [self.W, self.b] if self.has_bias else [self.W]
 
+    #: evaluate the projection on the FP16 matrix pipe with operands split in two halves (x.w = hi.hi + hi.lo + lo.hi,
+    #: float32 accumulation; error a few float32 ulps, ~5x the fp32-MFMA rate).  Set False for plain fp32 MFMA.
+    split_f16 = os.environ.get("SLOIKA_AMD_EXACT_F32", "0") != "1"
+
+    def _split_weights(self):
+        """fp16 hi/lo parts of W on the device, re-made whenever W changes."""
+        import torch
+        wd = self.W.dev()
+        cache = getattr(self, "_w16", None)
+        if cache is None or cache[0] is not wd:
+            kp = (self.insize + 15) // 16 * 16
+            hi = torch.empty((self.size, kp), dtype=torch.float16, device=wd.device)
+            lo = torch.empty((self.size, kp), dtype=torch.float16, device=wd.device)
+            _lib.check(_lib.lib().slk_split_f16x2_f32(wd.data_ptr(), self.size, self.insize, hi.data_ptr(),
+                                                      lo.data_ptr(), _stream()), "Softmax.split")
+            self._w16 = cache = (wd, hi, lo)
+        return cache[1], cache[2]
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_w16", None)          # device cache: never pickled
+        return d
+
     def _logits(self, x, ld):
         """tmp = x.W^T + b (layers.py:310) with rows `ld` floats apart, and per-row (max, 1/sum exp) [T*B,2]."""
         import torch
@@ -315,9 +339,15 @@ class Softmax(Layer):
         stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
         with profiler.region("softmax_gemm", 2.0 * rows * self.insize * self.size,
                              4.0 * rows * (self.insize + self.size)):
-            rc = L.slk_linear_rowstats_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
-                                           self.b.dev().data_ptr(), y.data_ptr(), ld, rows, self.insize, self.size,
-                                           stats.data_ptr(), _stream())
+            if self.split_f16 and self.insize <= 128:
+                hi, lo = self._split_weights()
+                rc = L.slk_linear_rowstats_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(),
+                                                 self.b.dev().data_ptr(), y.data_ptr(), ld, rows, self.insize,
+                                                 self.size, stats.data_ptr(), _stream())
+            else:
+                rc = L.slk_linear_rowstats_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
+                                               self.b.dev().data_ptr(), y.data_ptr(), ld, rows, self.insize,
+                                               self.size, stats.data_ptr(), _stream())
             if rc == _lib.SLK_ERR_UNSUPPORTED:
                 # insize > 128: tiled GEMM, then a statistics pass over the (dense) logits
                 if ld != self.size:

@@ -109,3 +109,63 @@ def test_softmax_vs_oracle(oracle, T, B, I, N):
     ref = oracle.run_network(sm.spec(), x)
     np.testing.assert_allclose(y, ref, atol=2e-6, rtol=1e-5)
     assert np.allclose(y.sum(axis=2), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,K,N,ld", [(1, 1, 1, 1), (130, 96, 1025, 1056), (257, 64, 126, 126), (64, 33, 97, 100),
+                                      (300, 128, 200, 224), (129, 112, 1025, 1025), (5, 7, 3, 8)])
+@pytest.mark.parametrize("kernel", ["f32", "f16x3"])
+def test_linear_rowstats_kernels_vs_float64(M, K, N, ld, kernel):
+    """x-stationary projection + online softmax statistics: plain fp32 MFMA and the 3-term fp16 split.  Both must sit
+    within a few float32 ulps of a float64 evaluation (trained-weight magnitudes: |w| up to 6)."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    rs = np.random.RandomState(M + K + N)
+    x = np.tanh(rs.normal(size=(M, K))).astype(np.float32)
+    W = (rs.normal(size=(N, K)) * 1.5).astype(np.float32)
+    W[0, :] *= 4.0
+    b = rs.normal(size=N).astype(np.float32)
+    xd, Wd, bd = dev(x), dev(W), dev(b)
+    y = torch.full((M, ld), np.nan, dtype=torch.float32, device="cuda")
+    stats = torch.empty((M, 2), dtype=torch.float32, device="cuda")
+    L = _lib.lib()
+    if kernel == "f32":
+        rc = L.slk_linear_rowstats_f32(xd.data_ptr(), K, Wd.data_ptr(), bd.data_ptr(), y.data_ptr(), ld, M, K, N,
+                                       stats.data_ptr(), stream())
+    else:
+        KP = (K + 15) // 16 * 16
+        hi = torch.empty((N, KP), dtype=torch.float16, device="cuda")
+        lo = torch.empty((N, KP), dtype=torch.float16, device="cuda")
+        assert L.slk_split_f16x2_f32(Wd.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), stream()) == 0
+        # the two halves reproduce W to ~2^-22 relative
+        back = hi[:, :K].float() + lo[:, :K].float()
+        assert ((back - Wd).abs() <= 3e-7 * Wd.abs() + 1e-7).all()
+        rc = L.slk_linear_rowstats_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), bd.data_ptr(), y.data_ptr(), ld, M,
+                                         K, N, stats.data_ptr(), stream())
+    assert rc == 0
+    out = y.cpu().numpy()
+    ref = x.astype(np.float64) @ W.astype(np.float64).T + b
+    scale = np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b)
+    assert (np.abs(out[:, :N] - ref) <= 6e-7 * scale + 1e-6).all()
+    if ld > N:
+        assert np.isnan(out[:, N:]).all()                 # padding columns are never written
+    m = out[:, :N].max(axis=1)
+    np.testing.assert_array_equal(stats[:, 0].cpu().numpy(), m)
+    s = np.exp(out[:, :N].astype(np.float64) - m[:, None]).sum(axis=1)
+    np.testing.assert_allclose(1.0 / stats[:, 1].cpu().numpy().astype(np.float64), s, rtol=3e-6)
+    # no-statistics form writes the same logits
+    y2 = torch.empty((M, ld), dtype=torch.float32, device="cuda")
+    if kernel == "f32":
+        rc = L.slk_linear_rowstats_f32(xd.data_ptr(), K, Wd.data_ptr(), bd.data_ptr(), y2.data_ptr(), ld, M, K, N, None, stream())
+    else:
+        rc = L.slk_linear_rowstats_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), bd.data_ptr(), y2.data_ptr(), ld, M, K,
+                                         N, None, stream())
+    assert rc == 0
+    assert torch.equal(y2[:, :N], y[:, :N])
+
+
+def test_linear_rowstats_unsupported_k():
+    need_gpu()
+    from sloika_amd import _lib
+    z = dev(np.zeros((4, 200), dtype=np.float32))
+    assert _lib.lib().slk_linear_rowstats_f32(z.data_ptr(), 200, z.data_ptr(), None, z.data_ptr(), 200, 4, 200, 4, None,
+                                              stream()) == _lib.SLK_ERR_UNSUPPORTED

@@ -106,6 +106,32 @@ def main():
                 ms1 = timeit(lambda: L.slk_linear_rowstats_f32(x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y.data_ptr(), ld, M, K, N, stats.data_ptr(), st), reps=5)
                 print("gemm_rows M=%d K=%d N=%d ld=%d: no-stats %.3f ms (%.1f TF)  with-stats %.3f ms (%.1f TF)" % (M, K, N, ld, ms0, 2.0 * M * K * N / ms0 / 1e9, ms1, 2.0 * M * K * N / ms1 / 1e9))
             del y
+    if "f16x3" in what:
+        M, K, N = T * B, n, 1025
+        x = torch.tanh(torch.randn(M, K, device="cuda"))
+        W = torch.randn(N, K, device="cuda") * 0.5
+        b = torch.randn(N, device="cuda")
+        KP = (K + 15) // 16 * 16
+        hi = torch.empty(N, KP, dtype=torch.float16, device="cuda")
+        lo = torch.empty(N, KP, dtype=torch.float16, device="cuda")
+        assert L.slk_split_f16x2_f32(W.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), st) == 0
+        ld = 1056
+        y = torch.empty(M, ld, device="cuda")
+        y2 = torch.empty(M, ld, device="cuda")
+        stats = torch.empty(M, 2, device="cuda")
+        stats2 = torch.empty(M, 2, device="cuda")
+        for rnd in range(2):
+            ms0 = timeit(lambda: L.slk_linear_rowstats_f16x3(x.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), b.data_ptr(), y.data_ptr(), ld, M, K, N, None, st), reps=5)
+            ms1 = timeit(lambda: L.slk_linear_rowstats_f16x3(x.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), b.data_ptr(), y.data_ptr(), ld, M, K, N, stats.data_ptr(), st), reps=5)
+            print("gemm_rows_f16x3 M=%d K=%d N=%d: no-stats %.3f ms (%.1f TF-equiv)  with-stats %.3f ms (%.1f TF-equiv, %.0f GB/s written)" % (M, K, N, ms0, 2.0 * M * K * N / ms0 / 1e9, ms1, 2.0 * M * K * N / ms1 / 1e9, 4.0 * M * N / ms1 / 1e6))
+        L.slk_linear_rowstats_f32(x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y2.data_ptr(), ld, M, K, N, stats2.data_ptr(), st)
+        torch.cuda.synchronize()
+        sub = slice(0, 20000)
+        ref = x[sub].double() @ W.double().t() + b.double()
+        e16 = (y[sub, :N].double() - ref).abs().max().item()
+        e32 = (y2[sub, :N].double() - ref).abs().max().item()
+        print("max |logit error| vs float64: f16x3 %.3e   fp32 MFMA %.3e   (|logit| max %.1f)" % (e16, e32, ref.abs().max().item()))
+        print("stats max rel diff (1/sum): %.3e" % ((stats[:, 1] - stats2[:, 1]).abs() / stats2[:, 1]).max().item())
     if "softmax" in what:
         M, N = T * B, 1025
         y = torch.randn(M, N, device="cuda")
