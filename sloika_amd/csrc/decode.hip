@@ -256,11 +256,14 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
                                                                 int32_t *__restrict__ len_out)
 {
     constexpr int NB2 = NB * NB;
-    extern __shared__ __attribute__((aligned(16))) uint8_t blk[];   // [tblk*nkmer] bytes + 2 ints
+    // two staging buffers of tblk*nkmer bytes each + 2 ints: while lane 0 walks block i in LDS, the other 255 threads
+    // fetch block i-1 (earlier in time) into the other buffer
+    extern __shared__ __attribute__((aligned(16))) uint8_t blk[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int nrem1 = nkmer / NB, nrem2 = nkmer / NB2;
-    int &sh_cur = reinterpret_cast<int *>(blk + (((size_t)tblk * nkmer + 15) & ~(size_t)15))[0];
-    int &sh_pos = reinterpret_cast<int *>(blk + (((size_t)tblk * nkmer + 15) & ~(size_t)15))[1];
+    const size_t bufbytes = ((size_t)tblk * nkmer + 15) & ~(size_t)15;
+    int &sh_cur = reinterpret_cast<int *>(blk + 2 * bufbytes)[0];
+    int &sh_pos = reinterpret_cast<int *>(blk + 2 * bufbytes)[1];
     const uint8_t *tbb = tb + (size_t)b * T * nkmer;
     int32_t *path = path_out + (size_t)b * T;
     if (tid == 0) {
@@ -268,23 +271,40 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
         sh_pos = T - 1;
         path[T - 1] = sh_cur;
     }
-    __syncthreads();
-    for (int t1 = T; t1 > 1; t1 -= tblk) {
-        const int t0 = max(1, t1 - tblk);                   // rows [t0, t1)
+    // rows [t0, t1) of block i, counting blocks from the end of the chunk
+    auto bounds = [&](int i, int &t0, int &t1) {
+        t1 = T - i * tblk;
+        t0 = max(1, t1 - tblk);
+    };
+    auto stage = [&](int i, int first_thread) {
+        int t0, t1;
+        bounds(i, t0, t1);
+        if (t1 <= 1) return;
         const size_t nbytes = (size_t)(t1 - t0) * nkmer;
         const uint8_t *src = tbb + (size_t)t0 * nkmer;
+        uint8_t *dst = blk + (i & 1) * bufbytes;
+        const int nthr = nt - first_thread, me = tid - first_thread;
+        if (me < 0) return;
         if ((nbytes & 15) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
             const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-            uint4 *d4 = reinterpret_cast<uint4 *>(blk);
-            for (size_t i = tid; i < nbytes / 16; i += nt) d4[i] = s4[i];
+            uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+            for (size_t k = me; k < nbytes / 16; k += nthr) d4[k] = s4[k];
         } else {
-            for (size_t i = tid; i < nbytes; i += nt) blk[i] = src[i];
+            for (size_t k = me; k < nbytes; k += nthr) dst[k] = src[k];
         }
-        __syncthreads();
+    };
+    const int nblocks = (T - 1 + tblk - 1) / tblk;          // rows 1..T-1
+    stage(0, 0);
+    __syncthreads();
+    for (int i = 0; i < nblocks; i++) {
+        if (i + 1 < nblocks) stage(i + 1, 64);              // waves 1-3 prefetch; wave 0 walks
         if (tid == 0) {
+            int t0, t1;
+            bounds(i, t0, t1);
+            const uint8_t *cur_blk = blk + (i & 1) * bufbytes;
             int cur = sh_cur, pos = sh_pos;
             for (int t = t1 - 1; t >= t0; t--) {
-                int code = blk[(size_t)(t - t0) * nkmer + cur];
+                int code = cur_blk[(size_t)(t - t0) * nkmer + cur];
                 if (code != VIT_STAY) {
                     cur = code < NB ? code * nrem1 + cur / NB : (code - NB) * nrem2 + cur / NB2;
                     path[--pos] = cur;                       // decode.py:88-90
@@ -348,11 +368,11 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
                            skip_pen, mode, min_prob, one_m, tb, best, score_out);
     int rc = slk_launch_status();
     if (rc != SLK_OK) return rc;
-    int tblk = (64 * 1024) / nkmer;
+    int tblk = (24 * 1024) / nkmer;                          // 2 x 24 KB buffers: 3 workgroups per CU
     if (tblk < 1) tblk = 1;
     if (tblk > T) tblk = T;
-    hipLaunchKernelGGL((viterbi_backtrace_kernel<NB>), dim3(B), dim3(256), (((size_t)tblk * nkmer + 15) & ~(size_t)15) + 16, s, tb, best, T, nkmer,
-                       tblk, path_out, len_out);
+    hipLaunchKernelGGL((viterbi_backtrace_kernel<NB>), dim3(B), dim3(256),
+                       2 * (((size_t)tblk * nkmer + 15) & ~(size_t)15) + 16, s, tb, best, T, nkmer, tblk, path_out, len_out);
     return slk_launch_status();
 }
 
