@@ -82,7 +82,8 @@ int slk_activation_f32(const float *x, float *y, size_t count, int act, slk_stre
  *             out_chunk_stride=1, out_sample_stride=nchunk writes the [T][B][1] network layout of
  *             bin/train_network.py:304 directly)
  *   med_out, mad_out : optional [nchunk] (NULL to skip); mad includes the 1.4826 factor.
- * Results are bit-identical to numpy's float32 evaluation.  chunk_len <= 32768.
+ * Results are bit-identical to numpy's float32 evaluation.  Any chunk_len (LDS sort up to 32768 samples, exact radix
+ * selection beyond: whole reads).  -0.0 and +0.0 are distinct keys in the selection; NaNs are not supported.
  * ------------------------------------------------------------------------------------------------------- */
 int slk_med_mad_normalise_f32(const float *signal, int nchunk, int chunk_len, float *out,
                               long out_chunk_stride, long out_sample_stride, float *med_out, float *mad_out,

@@ -51,6 +51,23 @@ def raw_chunk_worker(calc_post, chunks, kmer_len, min_prob=1e-5, skip=5.0, nbase
     return res
 
 
+def raw_read_worker(calc_post, signal, trim=(200, 10), open_pore_fraction=0.0, kmer_len=5, min_prob=1e-5, skip=5.0,
+                    nbase=4, name="read"):
+    """The array part of raw_worker (basecall.py:110-121) for ONE whole read held in memory (the reference reads it
+    from a fast5 file first): trim_open_pore, trim_array, per-read median/MAD normalisation, calc_post on [T,1,1],
+    decode_post.  Returns (name, score, call, n_samples) or None for an empty read, like the reference."""
+    from . import batch, util
+    signal = batch.trim_open_pore(signal, open_pore_fraction)              # basecall.py:111
+    signal = util.trim_array(signal, *trim)                                 # basecall.py:112
+    if len(signal) == 0:
+        sys.stderr.write("Read too short in {}\n".format(name))
+        return None
+    inmat = batch.normalise_chunks(signal.reshape(1, -1), 'per-chunk', out_layout='network')   # basecall.py:117-118
+    post = calc_post(inmat)
+    score, call = decode_post(post, kmer_len, True, True, min_prob, skip=skip, nbase=nbase)
+    return name, score, call, int(inmat.shape[0])
+
+
 class SeqPrinter(object):
     """Formats fasta strings and writes them to stdout or file (basecall.py:124-163).
 

@@ -66,6 +66,41 @@ def normalise_chunks(chunks, normalisation='per-chunk', out_layout='chunk', retu
     return res
 
 
+TRIM_OPEN_PORE_LOCAL_VAR_METHODS = frozenset(['mad', 'std'])
+
+
+def trim_open_pore(signal, max_op_fraction=0.3, var_method='mad', window_size=100):
+    """Locate raw read in signal by thresholding local variance (sloika/batch.py:194-220).
+
+    The per-window MADs (the array maths of the reference: `maths.mad(sig_chunks, axis=1)`) are computed on the device
+    by the normalisation kernel; the percentile threshold over those few hundred numbers and the slicing are host
+    logic, as in the reference.  Returns a view of `signal`.
+
+    :param signal: raw data containing a read (1D float32, numpy or device tensor)
+    :param max_op_fraction: maximum expected fraction of signal that consists of open pore
+    :param var_method: only 'mad' (the default of the reference) is implemented
+    :param window_size: size of patches used to estimate local variance
+    """
+    import torch
+    from . import device as D
+    assert var_method in TRIM_OPEN_PORE_LOCAL_VAR_METHODS, "var_method not understood: {}".format(var_method)
+    if var_method != 'mad':
+        raise NotImplementedError("trim_open_pore: only var_method='mad' (the reference default) is implemented")
+    ml = len(signal) // window_size
+    ub = ml * window_size
+    sd = D.to_dev(signal)
+    if sd.dim() != 1:
+        raise ValueError("trim_open_pore expects a 1D signal")
+    windows = sd[:ub].reshape(ml, window_size)
+    _, _, local_var = normalise_chunks(windows, 'per-chunk', return_stats=True)
+    local_var = local_var.cpu().numpy() if isinstance(local_var, torch.Tensor) else np.asarray(local_var)
+    probably_read = (local_var > np.percentile(local_var, 100 * max_op_fraction))
+    ix = np.arange(local_var.shape[0])[probably_read]
+    start = ix.min() * window_size
+    end = (ix.max() + 1) * window_size
+    return signal[start:end]
+
+
 def chunks_to_network_input(chunks):
     """[ml, chunk_len] -> [chunk_len, ml, 1] (the transpose of bin/train_network.py:304)."""
     import torch

@@ -59,13 +59,97 @@ __global__ void __launch_bounds__(512) med_mad_kernel(const float *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Long chunks / whole reads (chunk_len > 32768: does not fit the LDS sort): exact order statistics by radix
+// selection.  Float keys are mapped to unsigned integers that sort the same way; four passes of 8 bits each narrow
+// the bucket that contains the wanted rank (histogram in LDS, one workgroup per chunk).  The median of an even count
+// needs ranks n/2-1 and n/2; MAD repeats the selection on |x - med| recomputed on the fly (no scratch memory).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2key(float f)
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// value of rank `rank` (0-based) among f(sig[i]), f = identity or |x - med|
+template <bool ABSDEV>
+__device__ float radix_select(const float *__restrict__ sig, int n, float med, unsigned rank, unsigned *hist,
+                              unsigned *sh)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    unsigned prefix = 0, mask = 0;
+    for (int pass = 3; pass >= 0; pass--) {
+        const int shift = 8 * pass;
+        for (int i = tid; i < 256; i += nt) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            float v = sig[i];
+            if (ABSDEV) v = fabsf(v - med);
+            const unsigned k = f2key(v);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0, bin = 0;
+            for (; bin < 256; bin++) {
+                if (acc + hist[bin] > rank) break;
+                acc += hist[bin];
+            }
+            sh[0] = bin;
+            sh[1] = rank - acc;
+        }
+        __syncthreads();
+        prefix |= sh[0] << shift;
+        mask |= 0xffu << shift;
+        rank = sh[1];
+        __syncthreads();
+    }
+    return key2f(prefix);
+}
+
+template <bool ABSDEV>
+__device__ float radix_median(const float *__restrict__ sig, int n, float med, unsigned *hist, unsigned *sh)
+{
+    if (n & 1) return radix_select<ABSDEV>(sig, n, med, (unsigned)(n >> 1), hist, sh);
+    const float a = radix_select<ABSDEV>(sig, n, med, (unsigned)(n >> 1) - 1, hist, sh);
+    const float b = radix_select<ABSDEV>(sig, n, med, (unsigned)(n >> 1), hist, sh);
+    return (a + b) / 2.0f;
+}
+
+__global__ void __launch_bounds__(1024) med_mad_radix_kernel(const float *__restrict__ signal, int chunk_len,
+                                                             float *__restrict__ out, long out_chunk_stride,
+                                                             long out_sample_stride, float *__restrict__ med_out,
+                                                             float *__restrict__ mad_out)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh[2];
+    const int c = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const float *sig = signal + (size_t)c * chunk_len;
+    const float med = radix_median<false>(sig, chunk_len, 0.0f, hist, sh);
+    const float mad = 1.4826f * radix_median<true>(sig, chunk_len, med, hist, sh);
+    float *o = out + (size_t)c * out_chunk_stride;
+    for (int i = tid; i < chunk_len; i += nt) o[(size_t)i * out_sample_stride] = (sig[i] - med) / mad;
+    if (tid == 0) {
+        if (med_out) med_out[c] = med;
+        if (mad_out) mad_out[c] = mad;
+    }
+}
+
 extern "C" int slk_med_mad_normalise_f32(const float *signal, int nchunk, int chunk_len, float *out,
                                          long out_chunk_stride, long out_sample_stride, float *med_out,
                                          float *mad_out, slk_stream_t stream)
 {
     if (!signal || !out || nchunk < 0 || chunk_len < 1) return SLK_ERR_INVALID_ARG;
-    if (chunk_len > 32768) return SLK_ERR_UNSUPPORTED;   // one chunk must fit the CU's LDS (128 KiB of sort keys)
     if (nchunk == 0) return SLK_OK;
+    if (chunk_len > 32768) {      // whole reads: radix selection, any length
+        hipLaunchKernelGGL(med_mad_radix_kernel, dim3(nchunk), dim3(1024), 0, slk_stream(stream), signal, chunk_len, out,
+                           out_chunk_stride, out_sample_stride, med_out, mad_out);
+        return slk_launch_status();
+    }
     int npow2 = 1;
     while (npow2 < chunk_len) npow2 <<= 1;
     int threads = npow2 / 2 < 64 ? 64 : (npow2 / 2 > 512 ? 512 : npow2 / 2);

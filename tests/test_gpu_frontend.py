@@ -102,3 +102,56 @@ def test_all_activations_vs_oracle(oracle):
     for name in oracle.ACTIVATIONS:
         y = getattr(activation, name)(x)
         np.testing.assert_allclose(y, oracle.activation(name, x), rtol=2e-6, atol=2e-6, err_msg=name)
+
+
+def test_trim_open_pore_matches_reference(golden_signal):
+    """batch.trim_open_pore (sloika/batch.py:194-220): slice bounds equal the reference's."""
+    need_gpu()
+    from sloika_amd import batch
+    g = golden_signal
+    sig = g["signal"]
+    for frac in (0.0, 0.3):
+        lo, hi = g["trim_open_pore_%g" % frac]
+        out = batch.trim_open_pore(sig, frac)
+        assert out.base is sig or out.base is sig.base or np.shares_memory(out, sig)
+        assert len(out) == hi - lo and np.array_equal(out, sig[lo:hi])
+    with pytest.raises(NotImplementedError):
+        batch.trim_open_pore(sig, 0.3, var_method='std')
+
+
+@pytest.mark.parametrize("n", [32769, 70001, 114400])
+def test_whole_read_normalisation_radix_select(oracle, n):
+    """Reads longer than the LDS sort (e.g. data/reads/read1: 114400 samples, test_fast5.py:103) take the exact
+    radix-selection path; bit-identical to the numpy semantics restated by the oracle."""
+    need_gpu()
+    from sloika_amd import batch
+    rs = np.random.RandomState(n)
+    sig = (rs.normal(size=n) * 12 + 90).astype(np.float32)
+    sig[: n // 3] = np.round(sig[: n // 3])            # many duplicates
+    sig[5] = -3.5                                       # negative keys too
+    ref, rmed, rmad = oracle.med_mad_normalise(sig[None, :], return_stats=True)
+    out, med, mad = batch.normalise_chunks(sig[None, :], 'per-chunk', return_stats=True)
+    assert med[0] == rmed[0] and mad[0] == rmad[0]
+    assert np.array_equal(out, ref)
+
+
+def test_raw_read_worker_whole_read(oracle):
+    """Whole-read path of sloika/basecall.py:110-121 (batch 1, per-read normalisation) against the oracle."""
+    torch = need_gpu()
+    from sloika_amd import models, basecall, util, pipeline
+    net = models.build_model("raw_0.98_rgrgr", seed=6)
+    sig = pipeline.synthetic_chunks(1, chunk_len=6210, seed=12)[0]
+    res = basecall.raw_read_worker(net.compile(), sig, trim=(200, 10), open_pore_fraction=0.0, kmer_len=5, skip=0.0,
+                                   name="r1")
+    from sloika_amd import batch
+    trimmed = util.trim_array(batch.trim_open_pore(sig, 0.0), 200, 10)      # bounds pinned by the golden test above
+    assert res is not None and res[0] == "r1" and res[3] == len(trimmed) and 5900 <= len(trimmed) <= 6000
+    x = oracle.med_mad_normalise(trimmed[None, :])
+    post = oracle.run_network(net.spec(), np.ascontiguousarray(x.T)[:, :, None])
+    assert post.shape == ((len(trimmed) + 4) // 5, 1, 1025)
+    # decode of the oracle posterior gives (almost always) the same call; scores agree to float32 accuracy
+    o_score, o_call = oracle.viterbi(oracle.prepare_post(post, 1e-5), 5, skip_pen=0.0)
+    assert abs(float(res[1]) - float(o_score)) < 1e-2 * max(1.0, abs(float(o_score)) * 1e-3)
+    same = sum(a == b for a, b in zip(res[2], o_call))
+    assert len(res[2]) == len(o_call) and same >= 0.99 * len(o_call)
+    assert basecall.raw_read_worker(net.compile(), sig[:205], trim=(200, 10)) is None
