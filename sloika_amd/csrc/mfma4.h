@@ -20,6 +20,13 @@ __device__ __forceinline__ void mfma_chain(const float *hp, const float *w, f32x
 {
     ((acc[Is & 3] = mfma4<CB, Is % G>(hp[Is / G], w[Is], acc[Is & 3])), ...);
 }
+// two-accumulator form for register-starved instantiations (more waves per SIMD hide the dependent-issue gaps)
+template <int CB, int G, int... Is>
+__device__ __forceinline__ void mfma_chain2(const float *hp, const float *w, f32x4 (&acc)[2],
+                                            std::integer_sequence<int, Is...>)
+{
+    ((acc[Is & 1] = mfma4<CB, Is % G>(hp[Is / G], w[Is], acc[Is & 1])), ...);
+}
 
 // Same, for the MFMAs OFF .. OFF+len(Is)-1 of a chain (lets a chain be issued in two parts).
 template <int CB, int G, int OFF, int... Is>

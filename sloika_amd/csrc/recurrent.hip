@@ -103,13 +103,16 @@ __global__ void __launch_bounds__(256) lstm_generic_kernel(const float *__restri
 // =====================================================================================================
 // MFMA GRU
 // =====================================================================================================
-// N: layer size (multiple of 16, <= 128).  ACT/GACT: compile-time activation ids, or -1 to use the runtime ids.
-template <int N, int ACT, int GACT>
-__global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restrict__ vI, const float *__restrict__ sW,
+// N: layer size (multiple of 16).  NWAVES waves share the neurons (N / NWAVES each, a multiple of 4, at most 32):
+// 4 waves up to N = 128; N = 144 (the middle layer of models/pretrained.pkl) runs on 12 waves of 12 neurons.
+// ACT/GACT: compile-time activation ids, or -1 to use the runtime ids.
+template <int N, int ACT, int GACT, int NWAVES = 4>
+__global__ void __launch_bounds__(64 * NWAVES, (NWAVES + 3) / 4) gru_mfma_kernel(const float *__restrict__ vI, const float *__restrict__ sW,
                                                           const float *__restrict__ sW2, float *__restrict__ h_out,
                                                           long ldh, int T, int B, int reverse, int act, int gate_act)
 {
-    constexpr int NW = N / 4;                                      // neurons per wave
+    constexpr int NW = N / NWAVES;                                 // neurons per wave
+    constexpr int NT = 64 * NWAVES;                                // threads per workgroup
     constexpr int SA = (2 * NW <= 16) ? 4 : ((2 * NW <= 32) ? 2 : 1); // K-slices, phase A (z|r: 2*NW outputs)
     constexpr int SB = (NW <= 16) ? 4 : ((NW <= 32) ? 2 : 1);       // K-slices, phase B (NW outputs)
     constexpr int LPA = 64 / SA, LPB = 64 / SB;                     // lanes per slice
@@ -117,12 +120,12 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
     constexpr int GA = 16 / SA, GB = 16 / SB;                       // blocks per broadcast group
     constexpr int CBA = 4 - ilog2(SA), CBB = 4 - ilog2(SB);
     constexpr int NV = N / 16;                                      // packed state registers
-    static_assert(N % 16 == 0 && N <= 128, "unsupported GRU size for the MFMA kernel");
+    static_assert(N % 16 == 0 && N % NWAVES == 0 && NW % 4 == 0 && NW <= 32, "unsupported GRU size for the MFMA kernel");
 
-    constexpr int KB = 8;                       // time steps of vI staged per LDS block
+    constexpr int KB = N <= 128 ? 8 : 4;        // time steps of vI staged per LDS block (LDS budget)
     constexpr int ROWF4 = 3 * N / 4;            // float4 per (step, chunk) row of vI
     constexpr int BLKF4 = KB * 4 * ROWF4;       // float4 per staged block (a multiple of 64)
-    constexpr int NDMA = (BLKF4 / 64 + 3) / 4;  // 1-KiB LDS-DMA instructions per wave per block
+    constexpr int NDMA = (BLKF4 / 64 + NWAVES - 1) / NWAVES;   // 1-KiB LDS-DMA instructions per wave per block
     constexpr int BLKF = KB * 4 * 3 * N;        // floats per block
 
     __shared__ __attribute__((aligned(16))) float vbuf[2 * BLKF];          // vI[2][step in block][chunk][3N]
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
     const int addrA0 = 4 * ((blk / GA) * MA + (blk % GA)) + ci;
     const int addrB0 = 4 * ((blk / GB) * MB + (blk % GB)) + ci;
 
-    for (int i = tid; i < N * 4; i += 256) hbuf[i] = 0.0f;
+    for (int i = tid; i < N * 4; i += NT) hbuf[i] = 0.0f;
 
     // The input projection vI is streamed HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
     // instruction, no registers), one block of KB time steps at a time into a 2-deep ring; block k+2 is issued as
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
     auto dma_block = [&](int s0, int slot) {
 #pragma unroll
         for (int j = 0; j < NDMA; j++) {
-            const int piece = j * 4 + wave;                    // 64 float4 = 1 KiB of the block image
+            const int piece = j * NWAVES + wave;               // 64 float4 = 1 KiB of the block image
             if (piece * 64 < BLKF4) {                          // wave-uniform
                 const int idx = piece * 64 + lane;
                 const int kk = idx / (4 * ROWF4), r = idx % (4 * ROWF4), c = r / ROWF4, f4 = r % ROWF4;
@@ -191,8 +194,8 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
     auto flush_block = [&](int s0, int slot) {
         constexpr int OF4 = KB * 4 * N / 4;                    // float4 per output block
 #pragma unroll
-        for (int j = 0; j < (OF4 + 255) / 256; j++) {
-            const int idx = tid + 256 * j;
+        for (int j = 0; j < (OF4 + NT - 1) / NT; j++) {
+            const int idx = tid + NT * j;
             const int kk = idx / N, r = idx % N, c = r / (N / 4), f4 = r % (N / 4);
             const int ss = s0 + kk;
             if (idx < OF4 && ss < T && b0 + c < B) {
@@ -221,16 +224,20 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
         float hp[NV];
 #pragma unroll
         for (int v = 0; v < NV; v++) hp[v] = hbuf[addrA0 + 4 * v * GA];
-        f32x4 a0, c0;
+        f32x4 a0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            a0[i] = vrow[i * 3 * N + rowA] * mask_zr;
-            c0[i] = vrow[i * 3 * N + 2 * N + neuronB] * mask_c;
-        }
+        for (int i = 0; i < 4; i++) a0[i] = vrow[i * 3 * N + rowA] * mask_zr;
         const f32x4 hown = *reinterpret_cast<const f32x4 *>(&hbuf[4 * neuronA]);
-        f32x4 accA[4] = {a0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        mfma_chain<CBA, GA>(hp, wA, accA, std::make_integer_sequence<int, MA>{});
-        f32x4 g = sum_slices<SA>((accA[0] + accA[1]) + (accA[2] + accA[3]));
+        f32x4 g;
+        if constexpr (NWAVES <= 4) {
+            f32x4 accA[4] = {a0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mfma_chain<CBA, GA>(hp, wA, accA, std::make_integer_sequence<int, MA>{});
+            g = sum_slices<SA>((accA[0] + accA[1]) + (accA[2] + accA[3]));
+        } else {
+            f32x4 accA[2] = {a0, {0.f, 0.f, 0.f, 0.f}};
+            mfma_chain2<CBA, GA>(hp, wA, accA, std::make_integer_sequence<int, MA>{});
+            g = sum_slices<SA>(accA[0] + accA[1]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) g[i] = act_sel<GACT>(gate_act, g[i]);
         if (rlane) *reinterpret_cast<f32x4 *>(&rhbuf[4 * neuronA]) = g * hown;
@@ -243,15 +250,27 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
         float rp[NV];
 #pragma unroll
         for (int v = 0; v < NV; v++) rp[v] = rhbuf[addrB0 + 4 * v * GB];
-        f32x4 accB[4] = {c0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        mfma_chain<CBB, GB>(rp, wB, accB, std::make_integer_sequence<int, MB>{});
-        f32x4 cc = sum_slices<SB>((accB[0] + accB[1]) + (accB[2] + accB[3]));
+        f32x4 c0;                                   // read here, not at the top: 4 fewer registers live through phase A
+#pragma unroll
+        for (int i = 0; i < 4; i++) c0[i] = vrow[i * 3 * N + 2 * N + neuronB] * mask_c;
+        f32x4 cc;
+        if constexpr (NWAVES <= 4) {
+            f32x4 accB[4] = {c0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mfma_chain<CBB, GB>(rp, wB, accB, std::make_integer_sequence<int, MB>{});
+            cc = sum_slices<SB>((accB[0] + accB[1]) + (accB[2] + accB[3]));
+        } else {
+            f32x4 accB[2] = {c0, {0.f, 0.f, 0.f, 0.f}};
+            mfma_chain2<CBB, GB>(rp, wB, accB, std::make_integer_sequence<int, MB>{});
+            cc = sum_slices<SB>(accB[0] + accB[1]);
+        }
         if (zlane) {
+            // register-starved instantiations re-read the old state instead of keeping it live across the barrier
+            const f32x4 hold = NWAVES <= 4 ? hown : *reinterpret_cast<const f32x4 *>(&hbuf[4 * neuronB]);
             f32x4 hn;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 float hbar = act_sel<ACT>(act, cc[i]);
-                hn[i] = g[i] * hown[i] + (1.0f - g[i]) * hbar;      // layers.py:1020
+                hn[i] = g[i] * hold[i] + (1.0f - g[i]) * hbar;      // layers.py:1020
             }
             *reinterpret_cast<f32x4 *>(&hbuf[4 * neuronB]) = hn;
             float *orow = obuf + (kb & 1) * (KB * 4 * N) + kk * (4 * N) + neuronB;
@@ -261,6 +280,17 @@ __global__ void __launch_bounds__(256, 1) gru_mfma_kernel(const float *__restric
         lds_barrier();
     }
     flush_block(((T - 1) / KB) * KB, ((T - 1) / KB) & 1);
+}
+
+// N = 144 (the middle layer of models/pretrained.pkl) needs 12 waves; only the tanh/sigmoid instantiation fits the
+// 170-register budget of 3 waves/SIMD without scratch, so other activations return false and take the generic kernel.
+static bool launch_gru_mfma144(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
+                               int reverse, int act, int gate_act, hipStream_t s)
+{
+    if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return false;
+    hipLaunchKernelGGL((gru_mfma_kernel<144, SLK_ACT_TANH, SLK_ACT_SIGMOID, 12>), dim3((B + 3) / 4), dim3(64 * 12), 0, s,
+                       vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act);
+    return true;
 }
 
 template <int N>
@@ -295,6 +325,9 @@ extern "C" int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const 
         case 96: return launch_gru_mfma<96>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
         case 112: return launch_gru_mfma<112>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
         case 128: return launch_gru_mfma<128>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
+        case 144:
+            if (launch_gru_mfma144(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s)) return slk_launch_status();
+            break;
         default: break;
         }
     }

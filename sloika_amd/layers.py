@@ -631,9 +631,53 @@ class Gru(RNN):
             params += [self.b]
         return params
 
+    def _padded(self):
+        """Zero-padded copy of this layer with input and output sizes rounded up to multiples of 16 (what the MFMA
+        kernels are instantiated for).  Padding neurons see zero weights and zero bias, so their state stays exactly 0
+        (h0 = 0, candidate = fun(0) = 0 for tanh-like fun) and padded input columns multiply zero weights: the first
+        `size` outputs are those of the unpadded layer.  Cached until a parameter changes."""
+        key = tuple(id(p.dev()) for p in (self.iW, self.sW, self.sW2, self.b))
+        cache = getattr(self, "_pad_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        n, i = self.size, self.insize
+        n16, i16 = (n + 15) // 16 * 16, (i + 15) // 16 * 16
+        twin = Gru(i16, n16, has_bias=True, fun=self.fun, gatefun=self.gatefun, name=self.name)
+        iW = np.zeros((3, n16, i16), dtype=sloika_dtype)
+        iW[:, :n, :i] = self.iW.get_value().reshape(3, n, i)
+        sW = np.zeros((2, n16, n16), dtype=sloika_dtype)
+        sW[:, :n, :n] = self.sW.get_value().reshape(2, n, n)
+        sW2 = np.zeros((n16, n16), dtype=sloika_dtype)
+        sW2[:n, :n] = self.sW2.get_value()
+        b = np.zeros((3, n16), dtype=sloika_dtype)
+        b[:, :n] = self.b.get_value().reshape(3, n)
+        twin.set_params({"iW": iW, "sW": sW, "sW2": sW2, "b": b})
+        self._pad_cache = (key, twin)
+        return twin
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_pad_cache", None)
+        return d
+
     def _forward(self, x, out, reverse):
         import torch
         T, B, _ = x.shape
+        n = self.size
+        if ((n % 16) or (self.insize % 16 and n > 16)) and n <= 144 and activation.act_name(self.fun) in ("tanh", "linear"):
+            # odd sizes (e.g. models/raw_1.00_rGr.py: 110 / 142): run the padded twin on the MFMA kernels
+            twin = self._padded()
+            if twin.insize != self.insize:
+                xp = torch.zeros((T, B, twin.insize), dtype=torch.float32, device=x.device)
+                xp[:, :, :self.insize] = x
+            else:
+                xp = x
+            yp = twin._forward(xp, None, reverse)
+            y = yp[:, :, :n]
+            if out is not None:
+                out.copy_(y)
+                return out
+            return y
         y = _alloc_out(x, T, B, self.size, out)
         L = _lib.lib()
         n, rows = self.size, T * B

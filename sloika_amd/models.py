@@ -30,6 +30,7 @@ MODEL_DEFAULTS = {
     "bigger_raw_gru": dict(nfeature=1, winlen=11, stride=2, size=(32, 96, 128)),
     "raw_0.98_rgrgr": dict(nfeature=1, winlen=11, stride=5),
     "raw_1.00_rGr": dict(nfeature=1, winlen=11, stride=2),
+    "pretrained": dict(nfeature=1, winlen=11, stride=5),
 }
 
 
@@ -65,6 +66,8 @@ def build_model(name, klen=5, sd=0.5, nbase=smt.DEFAULT_NBASE, seed=None, **over
         return _uni_stack(nf, w, s, 96, smt.elu, [96] * 5, nstate, init)
     if name == "raw_1.00_rGr":
         return _uni_stack(nf, w, s, 128, smt.tanh, [110, 142, 110], nstate, init)
+    if name == "pretrained":    # architecture of the shipped pickle, random weights (trained ones: from_weights_npz)
+        return _uni_stack(nf, w, s, 128, smt.elu, [112, 144, 112], nstate, init)
     size = cfg["size"]
     if name == "tiny_gru":
         assert s == 1, "Model only supports stride of 1"
