@@ -1,18 +1,24 @@
 // gru_fused.hip -- a whole Gru layer (input projection + recurrence, sloika/layers.py:1010-1021) in ONE persistent
 // kernel on gfx950.
 //
-// The recurrence of one 4-chunk tile is a serial chain (LDS exchange -> barrier -> gates -> LDS exchange -> barrier)
-// that keeps the MFMA pipe busy only about half of each step.  The time-parallel input projection x.iW^T + b of the
-// same layer is independent work of the same size, so it is computed IN the same workgroup by four extra waves:
+// The recurrence of one 4-chunk tile is a serial chain (state exchange -> gates -> state exchange -> update) that keeps
+// the MFMA pipe busy well under half of each step.  The time-parallel input projection x.iW^T + b of the same layer is
+// independent work of the same size, so it is computed IN the same workgroup by four extra waves:
 //
-//   waves 0-3 "rec" : exactly the roles of gru_mfma_kernel (recurrent.hip): z|r phase, candidate phase, two barriers
-//   waves 4-7 "proj": vI(s+2) = x(s+2).iW^T + b for the tile, written to a 4-slot LDS ring that the rec waves read
+//   waves 0-3 "rec" : z|r phase, candidate phase (the roles of gru_mfma_kernel in recurrent.hip), raised priority
+//   waves 4-7 "proj": vI(sp) = x(sp).iW^T + b for the tile, a few steps ahead, into an LDS ring the rec waves read;
+//                     they also stream x in (LDS-DMA) and copy finished state blocks out to h_out
 //
-// Both groups share each SIMD's matrix pipe (two waves per SIMD), so the projection MFMAs run in the gaps of the
-// recurrence.  vI never exists in HBM (the unfused path writes and re-reads 3n floats per (t, chunk)); x arrives by
-// LDS-DMA as an image of 16-byte pieces [k/4][chunk][k%4] that the packed MFMA A-operand reads without conflicts.
-//
-// All eight waves execute the same two s_barrier per step.  Exact fp32 (v_mfma_f32_4x4x1_16b_f32).
+// The two groups share each SIMD's matrix pipe (two waves per SIMD).  They are NOT coupled by s_barrier: a hardware
+// barrier would make the recurrence wait for whatever the projection wave happens to be doing twice per step
+// (measured: ~700 of 3800 cycles per step).  Instead every wave publishes progress counters in LDS and consumers poll
+// them; LDS operations of one wave execute in order, so "data write, then counter write" on the producer and "counter
+// read, then data read" on the consumer is a release/acquire pair without any fence, and the consumer issues its data
+// reads together with the counter read (one LDS round trip per exchange, retried in the rare case the counter was
+// not there yet).  vI never exists in HBM; x arrives as an image of 16-byte pieces [k/4][chunk][k%4] that the packed
+// MFMA A-operand reads without conflicts.  Exact fp32 (v_mfma_f32_4x4x1_16b_f32).
+#include <limits.h>
+
 #include "mfma4.h"
 
 // Diagnostic: shader-clock cycles and 100 MHz wall ticks spent by workgroup 0 in the last fused launch
@@ -49,6 +55,26 @@ constexpr int pow2_slices(int outputs, int cap)
     return s;
 }
 
+// progress counters (LDS ints).  flags[0..3]  fA[w]   : rec wave w finished phase A of steps < value (rh published)
+//                                 flags[4..7]  fB[w]   : rec wave w finished steps < value (h published)
+//                                 flags[8..11] vready[p]: proj wave p published vI rows of steps < value
+//                                 flags[12..15] flushed[p]: proj wave p copied state blocks < value to h_out
+//                                 xflags[0..3] xready[p]: proj wave p's share of x blocks < value has landed
+//                                 xflags[4..7] xdone[p] : proj wave p finished reading x blocks < value
+__device__ __forceinline__ void publish(int *flags, int idx, int value, int lane)
+{
+    asm volatile("" ::: "memory");          // the data writes stay ahead of the counter write in program order
+    if (lane == 0) *(volatile int *)&flags[idx] = value;
+    asm volatile("" ::: "memory");
+}
+// true when every watched counter (lane l watches flags[l & 15]) has reached the lane's `need`
+__device__ __forceinline__ bool reached(const int *flags, int lane, int need)
+{
+    const int v = *(volatile const int *)&flags[lane & 15];
+    asm volatile("" ::: "memory");          // data reads issued after this stay after it
+    return __builtin_amdgcn_ballot_w64(v < need) == 0;
+}
+
 template <int I, int N, int ACT, int GACT>
 __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restrict__ x, long ldx,
                                                            const float *__restrict__ iW, const float *__restrict__ bias,
@@ -79,24 +105,32 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
     constexpr int NVI = I / 16;
     static_assert(I % (4 * S0) == 0 && (P1 == 0 || I % (2 * S1) == 0), "K-slices must divide the input size");
     // ---------------- LDS ----------------
-    constexpr int KB = 8, R = 4;
+    constexpr int KB = 8;                                // steps per x block / per h_out block
+    constexpr int R = 4;                                 // vI ring: the projection runs at most R-1 steps ahead
     constexpr int XIMG = 4 * I;                          // floats of one step's x image: [k/4][chunk][k%4]
     constexpr int XPIECES = KB * I;                      // 16-byte pieces per x block
     constexpr int NDMA = (XPIECES / 64 + 3) / 4;
+    // state history: h(s) lives in slot s % HSLOTS as the packed A-operand image [neuron][chunk]; step s reads slot
+    // s-1 and writes slot s, and the proj waves copy finished 8-step blocks to h_out (no separate output staging)
+    constexpr int HSLOTS = 3 * KB, HIMG = 4 * N;
     __shared__ __attribute__((aligned(16))) float xbuf[2 * KB * XIMG];
     __shared__ __attribute__((aligned(16))) float vbuf[R * 3 * N * 4];      // vI[slot][row][chunk]
-    __shared__ __attribute__((aligned(16))) float obuf[2 * KB * 4 * N];     // h_out[2][step][chunk][N]
-    __shared__ __attribute__((aligned(16))) float hbuf[N * 4];
+    __shared__ __attribute__((aligned(16))) float hring[HSLOTS * HIMG];
     __shared__ __attribute__((aligned(16))) float rhbuf[N * 4];
+    __shared__ __attribute__((aligned(64))) int flags[16];
+    __shared__ __attribute__((aligned(64))) int xflags[16];
 
-    const int variant = diag ? 4 : 0;      // bit 2: per-phase s_memtime stamps (diagnostic launches only)
+    const int variant = ((diag & 1) ? 4 : 0) | ((diag & 2) ? 8 : 0);   // 4: s_memtime stamps, 8: skip projection MFMAs
     const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
     const int blk = lane >> 2, ci = lane & 3;
     const bool is_rec = wave < 4;
+    const int cls = (lane & 15) >> 2;                    // which counter group this lane watches when polling
 
-    for (int i = tid; i < N * 4; i += 512) hbuf[i] = 0.0f;
+    for (int i = tid; i < HIMG; i += 512) hring[(HSLOTS - 1) * HIMG + i] = 0.0f;      // h(-1) = 0
+    if (tid < 16) { flags[tid] = 0; xflags[tid] = 0; }
+    __syncthreads();                                     // the only hardware barrier
 
     if (is_rec) {
         // =================================================================================================
@@ -125,45 +159,33 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
         const int addrB0 = 4 * ((blk / GB) * MB + (blk % GB)) + ci;
         const float mask_zr = (validA && ga == 0) ? 1.0f : 0.0f;
         const float mask_c = zlane ? 1.0f : 0.0f;
-        const bool vec_store = (ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
-        auto flush_block = [&](int s0, int slot) {
-            constexpr int OF4 = KB * 4 * N / 4;
-#pragma unroll
-            for (int j = 0; j < (OF4 + 255) / 256; j++) {
-                const int idx = tid + 256 * j;
-                const int kk = idx / N, r = idx % N, c = r / (N / 4), f4 = r % (N / 4);
-                const int ss = s0 + kk;
-                if (idx < OF4 && ss < T && b0 + c < B) {
-                    const int tt = reverse ? T - 1 - ss : ss;
-                    const float4 v = *reinterpret_cast<const float4 *>(&obuf[slot * (KB * 4 * N) + 4 * idx]);
-                    float *dst = h_out + ((size_t)tt * B + b0 + c) * ldh + 4 * f4;
-                    if (vec_store) *reinterpret_cast<float4 *>(dst) = v;
-                    else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
-                }
-            }
-        };
+        __builtin_amdgcn_s_setprio(3);      // the serial chain goes first; projection MFMAs fill its gaps
 
-        // prologue: the proj waves stage x and produce vI(0), vI(1)
-        __syncthreads();     // (P1) x blocks landed
-        __syncthreads();     // (P2) vI(0), vI(1) published
         unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
         if (variant & 4) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
 
         for (int s = 0; s < T; s++) {
-            const int kk = s % KB, kb = s / KB;
             const float *vrow = vbuf + (s % R) * (3 * N * 4);
-            if (kk == 0 && s > 0) flush_block(s - KB, (kb - 1) & 1);
+            const float *hprev = hring + ((s + HSLOTS - 1) % HSLOTS) * HIMG;
+            float *hcur = hring + (s % HSLOTS) * HIMG;
+            // h(s-1) from every rec wave, vI(s) from every proj wave, and the slot h(s) will overwrite copied out
+            const int needA = cls == 1 ? s : (cls == 2 ? s + 1 : (cls == 3 ? s / KB - 2 : INT_MIN));
             STAMP(0)
 
             // ---------------- phase A: z | r ----------------
             float hp[NV];
+            f32x4 a0, c0, hown;
+            for (;;) {
+                const bool ok = reached(flags, lane, needA);
 #pragma unroll
-            for (int v = 0; v < NV; v++) hp[v] = hbuf[addrA0 + 4 * v * GA];
-            f32x4 a0 = *reinterpret_cast<const f32x4 *>(&vrow[4 * rowA]);
-            f32x4 c0 = *reinterpret_cast<const f32x4 *>(&vrow[4 * (2 * N + neuronB)]);
+                for (int v = 0; v < NV; v++) hp[v] = hprev[addrA0 + 4 * v * GA];
+                a0 = *reinterpret_cast<const f32x4 *>(&vrow[4 * rowA]);
+                c0 = *reinterpret_cast<const f32x4 *>(&vrow[4 * (2 * N + neuronB)]);
+                hown = *reinterpret_cast<const f32x4 *>(&hprev[4 * neuronA]);
+                if (ok) break;
+            }
             a0 *= mask_zr;
             c0 *= mask_c;
-            const f32x4 hown = *reinterpret_cast<const f32x4 *>(&hbuf[4 * neuronA]);
             STAMP(1)
             f32x4 accA[4] = {a0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             mfma_chain<CBA, GA>(hp, wA, accA, std::make_integer_sequence<int, MA>{});
@@ -172,19 +194,23 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
 #pragma unroll
             for (int i = 0; i < 4; i++) g[i] = act_sel<GACT>(gate_act, g[i]);
             if (rlane) *reinterpret_cast<f32x4 *>(&rhbuf[4 * neuronA]) = g * hown;
+            publish(flags, wave, s + 1, lane);
             STAMP(3)
-            lds_barrier();
-            STAMP(4)
 
             // ---------------- phase B: candidate ----------------
+            const int needB = cls == 0 ? s + 1 : INT_MIN;
             float rp[NV];
+            for (;;) {
+                const bool ok = reached(flags, lane, needB);
 #pragma unroll
-            for (int v = 0; v < NV; v++) rp[v] = rhbuf[addrB0 + 4 * v * GB];
-            STAMP(5)
+                for (int v = 0; v < NV; v++) rp[v] = rhbuf[addrB0 + 4 * v * GB];
+                if (ok) break;
+            }
+            STAMP(4)
             f32x4 accB[4] = {c0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             mfma_chain<CBB, GB>(rp, wB, accB, std::make_integer_sequence<int, MB>{});
             f32x4 cc = sum_slices<SB>((accB[0] + accB[1]) + (accB[2] + accB[3]));
-            STAMP(6)
+            STAMP(5)
             if (zlane) {
                 f32x4 hn;
 #pragma unroll
@@ -192,18 +218,13 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                     float hbar = act_sel<ACT>(act, cc[i]);
                     hn[i] = g[i] * hown[i] + (1.0f - g[i]) * hbar;      // layers.py:1020
                 }
-                *reinterpret_cast<f32x4 *>(&hbuf[4 * neuronB]) = hn;
-                float *orow = obuf + (kb & 1) * (KB * 4 * N) + kk * (4 * N) + neuronB;
-#pragma unroll
-                for (int i = 0; i < 4; i++) orow[i * N] = hn[i];
+                *reinterpret_cast<f32x4 *>(&hcur[4 * neuronB]) = hn;
             }
-            STAMP(7)
-            lds_barrier();
-            STAMP(8)
+            publish(flags, 4 + wave, s + 1, lane);
+            STAMP(6)
         }
         if ((variant & 4) && blockIdx.x == 0 && tid == 0)
             for (int i = 0; i < 9; i++) slk_dbg_stamp[i] = stamp_acc[i];
-        flush_block(((T - 1) / KB) * KB, ((T - 1) / KB) & 1);
     } else {
         // =================================================================================================
         // projection waves
@@ -236,7 +257,6 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
             const int k1 = (blk / G1) * (P1 ? M1 : I) + v * G1 + (blk % G1);
             xa1[v] = 16 * (k1 >> 2) + 4 * ci + (k1 & 3);
         }
-        const bool x_ok = true;
         auto dma_block = [&](int s0, int slot) {
 #pragma unroll
             for (int j = 0; j < NDMA; j++) {
@@ -254,59 +274,91 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                 }
             }
         };
-        constexpr int M0a = (M0 * 2 / 3 / 4) * 4;           // part b also carries set 1 and the LDS writes
-        float xp[NVI];
-        f32x4 acc[4];
-        auto project_a = [&](int sp) {
+        // h_out: part j of a finished 8-step block = 256 float4 (step kk, chunk c, neurons 4*f4..4*f4+3), gathered from
+        // the [neuron][chunk] images with four ds_read_b32 (4-way bank conflicts, off the critical path) and stored as
+        // 4 x 256-byte runs per wave
+        const bool vec_store = (ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
+        constexpr int OF4 = KB * N;                         // float4s per block
+        constexpr int NFL = (OF4 + 255) / 256;              // parts per block
+        constexpr int FLUSH_AT = 4;                         // block kb is copied out at proj steps KB*(kb+1) + FLUSH_AT + j
+        static_assert(FLUSH_AT + NFL <= KB, "flush parts must fit in one block of steps");
+        auto flush_part = [&](int kb, int j) {
+            const int idx = (tid - 256) + 256 * j;
+            const int c = idx & 3, rest = idx >> 2, f4 = rest % (N / 4), kk = rest / (N / 4);
+            const int ss = kb * KB + kk;
+            if (idx < OF4 && ss < T && b0 + c < B) {
+                const float *src = hring + (ss % HSLOTS) * HIMG + 16 * f4 + c;
+                const float v0 = src[0], v1 = src[4], v2 = src[8], v3 = src[12];
+                const int tt = reverse ? T - 1 - ss : ss;
+                float *dst = h_out + ((size_t)tt * B + b0 + c) * ldh + 4 * f4;
+                if (vec_store) *reinterpret_cast<float4 *>(dst) = make_float4(v0, v1, v2, v3);
+                else { dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; }
+            }
+        };
+        auto wait_flags = [&](int group, int value) {       // every counter of `group` (0 fA, 1 fB) >= value
+            const int need = cls == group ? value : INT_MIN;
+            while (!reached(flags, lane, need)) __builtin_amdgcn_s_sleep(1);
+        };
+        auto wait_xflags = [&](int group, int value) {      // group 0 xready, 1 xdone (lanes watch xflags[l & 15], 8..15 stay 0)
+            const int need = cls == group ? value : INT_MIN;
+            while (!reached(xflags, lane, need)) __builtin_amdgcn_s_sleep(1);
+        };
+
+        dma_block(0, 0);
+        for (int sp = 0; sp < T; sp++) {
+            if (sp % KB == 0) {
+                const int xb = sp / KB;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my share of block xb (issued a block ago) landed
+                publish(xflags, pw, xb + 1, lane);
+                publish(xflags, 4 + pw, xb, lane);                      // and I am done reading block xb-1
+                if ((xb + 1) * KB < T) {
+                    wait_xflags(1, xb);                                 // slot (xb+1)&1 held block xb-1: everyone past it
+                    dma_block((xb + 1) * KB, (xb + 1) & 1);
+                }
+                wait_xflags(0, xb + 1);
+            }
             const float *img = xbuf + ((sp / KB) & 1) * (KB * XIMG) + (sp % KB) * XIMG;
+            float xp[NVI];
 #pragma unroll
             for (int v = 0; v < NVI; v++) xp[v] = img[xa0[v]];
-            acc[0] = f32x4{bias0, bias0, bias0, bias0};
-            acc[1] = acc[2] = acc[3] = f32x4{0.f, 0.f, 0.f, 0.f};
-            mfma_chain_range<CB0, G0, 0>(xp, w0, acc, std::make_integer_sequence<int, M0a>{});
-        };
-        auto project_b = [&](int sp) {
-            const float *img = xbuf + ((sp / KB) & 1) * (KB * XIMG) + (sp % KB) * XIMG;
-            mfma_chain_range<CB0, G0, M0a>(xp, w0, acc, std::make_integer_sequence<int, M0 - M0a>{});
-            f32x4 r0 = sum_slices<S0>((acc[0] + acc[1]) + (acc[2] + acc[3]));
-            float *vdst = vbuf + (sp % R) * (3 * N * 4);
-            if (valid0 && g0 == 0) *reinterpret_cast<f32x4 *>(&vdst[4 * row0]) = r0;
+            f32x4 acc[4] = {{bias0, bias0, bias0, bias0}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            f32x4 r0 = acc[0], r1 = acc[0];
+            if (!(variant & 8)) {
+                mfma_chain<CB0, G0>(xp, w0, acc, std::make_integer_sequence<int, M0>{});
+                r0 = sum_slices<S0>((acc[0] + acc[1]) + (acc[2] + acc[3]));
+            }
             if constexpr (P1 > 0) {
                 float xq[NVI];
 #pragma unroll
                 for (int v = 0; v < NVI; v++) xq[v] = img[xa1[v]];
                 f32x4 acc1[4] = {{bias1, bias1, bias1, bias1}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                mfma_chain<CB1, G1>(xq, w1, acc1, std::make_integer_sequence<int, M1>{});
-                f32x4 r1 = sum_slices<S1>((acc1[0] + acc1[1]) + (acc1[2] + acc1[3]));
+                if (!(variant & 8)) {
+                    mfma_chain<CB1, G1>(xq, w1, acc1, std::make_integer_sequence<int, M1>{});
+                    r1 = sum_slices<S1>((acc1[0] + acc1[1]) + (acc1[2] + acc1[3]));
+                }
+            }
+            // ring slot sp % R was last read by phase A of step sp - R
+            if (sp >= R) wait_flags(0, sp - R + 1);
+            float *vdst = vbuf + (sp % R) * (3 * N * 4);
+            if (valid0 && g0 == 0) *reinterpret_cast<f32x4 *>(&vdst[4 * row0]) = r0;
+            if constexpr (P1 > 0) {
                 if (valid1 && g1 == 0) *reinterpret_cast<f32x4 *>(&vdst[4 * row1]) = r1;
             }
-        };
-        auto project = [&](int sp) { project_a(sp); project_b(sp); };
-        (void)x_ok;
-
-        dma_block(0, 0);
-        if (T > KB) dma_block(KB, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();     // (P1)
-        project(0);
-        if (T > 1) project(1);
-        __syncthreads();     // (P2)
-
-        for (int s = 0; s < T; s++) {
-            const int sp = s + 2;
-            // the step's projection is cut in two around the first barrier so that neither half makes the
-            // recurrent waves wait long (measured with the stamps: 3985 -> 3766 cycles per step)
-            if (sp < T) project_a(sp);
-            const bool last_of_block = (sp % KB == KB - 1);
-            // the block after this one must have landed before anyone reads it at the next step
-            if (last_of_block) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_barrier();
-            if (sp < T) project_b(sp);
-            lds_barrier();
-            // every proj wave is past ALL its reads (both halves) of the block that just ended: refill its slot two
-            // blocks ahead
-            if (last_of_block && (sp / KB + 2) * KB < T) dma_block((sp / KB + 2) * KB, (sp / KB) & 1);
+            publish(flags, 8 + pw, sp + 1, lane);
+            // copy a finished block of states out, one part per step
+            const int fj = sp % KB - FLUSH_AT, fkb = sp / KB - 1;
+            if (fkb >= 0 && fj >= 0 && fj < NFL) {
+                if (fj == 0) wait_flags(1, (fkb + 1) * KB);
+                flush_part(fkb, fj);
+                if (fj == NFL - 1) publish(flags, 12 + pw, fkb + 1, lane);
+            }
         }
+        // what the loop did not reach: the tail of the second-to-last block and the last block
+        wait_flags(1, T);
+        const int kbl = (T - 1) / KB;
+        for (int kb = kbl > 0 ? kbl - 1 : 0; kb <= kbl; kb++)
+            for (int j = 0; j < NFL; j++)
+                if (KB * (kb + 1) + FLUSH_AT + j >= T) flush_part(kb, j);
     }
     if (blockIdx.x == 0 && tid == 0) {
         slk_dbg_clock[0] = clock64() - clk0;
@@ -319,7 +371,7 @@ static int launch_fused(const float *x, long ldx, const float *iW, const float *
                         float *y, long ldy, int T, int B, int reverse, hipStream_t s)
 {
     hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID>), dim3((B + 3) / 4), dim3(512), 0, s, x, ldx,
-                       iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, (reverse >> 1) & 1);
+                       iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, (reverse >> 1) & 3);
     return slk_launch_status();
 }
 

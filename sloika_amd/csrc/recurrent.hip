@@ -243,8 +243,6 @@ __global__ void __launch_bounds__(64 * NWAVES, (NWAVES + 3) / 4) gru_mfma_kernel
         if (rlane) *reinterpret_cast<f32x4 *>(&rhbuf[4 * neuronA]) = g * hown;
         if (kk == KB - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next block's DMA (issued KB steps ago) landed
         lds_barrier();
-        // every wave has finished reading the current block: its ring slot takes the block after next
-        if (kk == KB - 1 && s + 1 + KB < T) dma_block(s + 1 + KB, kb & 1);
 
         // ---------------- phase B: candidate ----------------
         float rp[NV];
@@ -278,6 +276,9 @@ __global__ void __launch_bounds__(64 * NWAVES, (NWAVES + 3) / 4) gru_mfma_kernel
             for (int i = 0; i < 4; i++) orow[i * N] = hn[i];
         }
         lds_barrier();
+        // every wave has finished reading the current block (phase B still reads its candidate rows, so not before this
+        // barrier): its ring slot takes the block after next
+        if (kk == KB - 1 && s + 1 + KB < T) dma_block(s + 1 + KB, kb & 1);
     }
     flush_block(((T - 1) / KB) * KB, ((T - 1) / KB) & 1);
 }

@@ -146,6 +146,43 @@ def test_gru_fused_layer_kernel(oracle, I, n, T, B, reverse):
         assert (out[:, :, :4] == -5.0).all() and (out[:, :, 4 + n:] == -5.0).all()
 
 
+@pytest.mark.parametrize("I,n", [(96, 96), (128, 96), (112, 112), (64, 64), (112, 144), (128, 128)])
+def test_gru_kernels_agree_under_load(I, n):
+    """Race screen: many tiles, several hundred steps (dozens of LDS ring turnovers), every CU busy, repeated.  The
+    portable kernel, the MFMA recurrence and (where instantiated) the fused layer kernel must agree; any slot reused
+    too early shows up as a large error in some chunk."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    T, B = 333, 1021
+    g = torch.Generator(device="cuda").manual_seed(I * n)
+    x = torch.randn((T, B, I), device="cuda", generator=g)
+    iW = torch.randn((3 * n, I), device="cuda", generator=g) / np.sqrt(I + n)
+    sW = 2.0 * torch.randn((2 * n, n), device="cuda", generator=g) / np.sqrt(2 * n)
+    sW2 = 2.0 * torch.randn((n, n), device="cuda", generator=g) / np.sqrt(2 * n)
+    b = torch.randn(3 * n, device="cuda", generator=g)
+    vI = torch.empty((T, B, 3 * n), device="cuda")
+    assert L.slk_gemm_bias_act_f32(x.data_ptr(), I, iW.data_ptr(), b.data_ptr(), vI.data_ptr(), 3 * n, T * B, I, 3 * n, 0,
+                                   stream()) == 0
+    for reverse in (0, 1):
+        ref = torch.empty((T, B, n), device="cuda")
+        assert L.slk_gru_recurrent_f32_ex(vI.data_ptr(), sW.data_ptr(), sW2.data_ptr(), ref.data_ptr(), n, T, B, n, reverse,
+                                          1, 2, 1, stream()) == 0
+        for rep in range(3):
+            y = torch.full((T, B, n), float("nan"), device="cuda")
+            assert L.slk_gru_recurrent_f32_ex(vI.data_ptr(), sW.data_ptr(), sW2.data_ptr(), y.data_ptr(), n, T, B, n,
+                                              reverse, 1, 2, 0, stream()) == 0
+            err = (y - ref).abs().max().item()
+            assert err < TOL, "recurrent kernel, reverse=%d rep=%d: %g" % (reverse, rep, err)
+            y.fill_(float("nan"))
+            rc = L.slk_gru_fused_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), b.data_ptr(),
+                                     y.data_ptr(), n, T, B, I, n, reverse, 1, 2, stream())
+            assert rc in (0, _lib.SLK_ERR_UNSUPPORTED)
+            if rc == 0:
+                err = (y - ref).abs().max().item()
+                assert err < TOL, "fused kernel, reverse=%d rep=%d: %g" % (reverse, rep, err)
+
+
 def test_gru_fused_unsupported_falls_back(oracle):
     need_gpu()
     from sloika_amd import _lib

@@ -56,7 +56,7 @@ def main():
         assert rc == 0, rc
         fl = 6.0 * T * B * n * n + 6.0 * T * B * n * I
         for rnd in range(2):
-            for variant in (0, 1):
+            for variant in (0, 1, 3):
                 ms = timeit(lambda: L.slk_gru_fused_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B, I, n, variant * 2, 1, 2, st))
                 import ctypes
                 clk = (ctypes.c_ulonglong * 2)()
@@ -67,7 +67,7 @@ def main():
                     stp = (ctypes.c_ulonglong * 16)()
                     L.slk_debug_read_stamps.argtypes = [ctypes.c_void_p]
                     L.slk_debug_read_stamps(stp)
-                    names = ["flush/top", "lds reads A", "mfma A+sum", "gates+write", "barrier1", "lds reads B", "mfma B+sum", "tanh+update+write", "barrier2"]
+                    names = ["top", "wait h+vI, reads A", "mfma A+sum", "gates+publish", "wait rh, reads B", "mfma B+sum", "tanh+update+publish"]
                     print("   per-step cycles (wave0/wg0): " + ", ".join("%s=%.0f" % (nm, stp[i] / T) for i, nm in enumerate(names)))
                 print("gru_fused v%d I=%d n=%d B=%d T=%d: %.3f ms  %.1f TF  %.0f ns/step | wg0: %d cycles, %.2f GHz, %.0f cycles/step" % (variant, I, n, B, T, ms, fl / ms / 1e9, ms * 1e6 / T, clk[0], ghz, clk[0] / T))
     if "gemm" in what:
