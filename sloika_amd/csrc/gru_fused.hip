@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                                                            int act, int gate_act, int diag)
 {
     static_assert(I % 16 == 0 && N % 16 == 0 && N <= 128, "unsupported size for the fused GRU kernel");
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     // ---------------- recurrent role constants (as in gru_mfma_kernel) ----------------
     constexpr int NW = N / 4;
     constexpr int SA = (2 * NW <= 16) ? 4 : ((2 * NW <= 32) ? 2 : 1);
@@ -93,20 +94,17 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
     constexpr int CBA = 4 - ilog2(SA), CBB = 4 - ilog2(SB);
     constexpr int NV = N / 16;
     // ---------------- projection role constants ----------------
-    constexpr int OW = 3 * N / 4;                        // vI rows per proj wave
-    constexpr int P0 = OW < 64 ? OW : 64;                // rows in accumulator set 0
-    constexpr int S0 = pow2_slices(P0, 4);
-    constexpr int P1 = OW - P0;                          // rows in accumulator set 1 (0 = unused)
-    constexpr int S1 = P1 ? pow2_slices(P1, 8) : 1;
-    constexpr int LP0 = 64 / S0, LP1 = 64 / S1;
-    constexpr int M0 = I / S0, M1 = P1 ? I / S1 : 0;
-    constexpr int G0 = 16 / S0, G1 = 16 / S1;
-    constexpr int CB0 = 4 - ilog2(S0), CB1 = 4 - ilog2(S1);
-    constexpr int NVI = I / 16;
-    static_assert(I % (4 * S0) == 0 && (P1 == 0 || I % (2 * S1) == 0), "K-slices must divide the input size");
+    // vI rows in tiles of 16, K in blocks of 32, four time steps x four chunks = the 16 rows of one
+    // v_mfma_f32_16x16x32_f16; every float32 operand is split v = hi + lo into two halves and the product evaluated as
+    // hi.hi + hi.lo + lo.hi with float32 accumulation (see gemm_rows_f16x3.hip): float32-grade accuracy at a fifth of
+    // the matrix-pipe time of the fp32 MFMA, which matters here because the pipe is shared with the recurrence
+    constexpr int NT16 = 3 * N / 16;                     // tiles of vI rows
+    constexpr int NTW = (NT16 + 3) / 4;                  // tiles per proj wave (tile pw + 4*i; the last may be absent)
+    constexpr int KBLK = (I + 31) / 32;
+    constexpr int GS = 4;                                // time steps per projection group
     // ---------------- LDS ----------------
     constexpr int KB = 8;                                // steps per x block / per h_out block
-    constexpr int R = 4;                                 // vI ring: the projection runs at most R-1 steps ahead
+    constexpr int R = 2 * GS;                            // vI ring: the projection works one group of steps ahead
     constexpr int XIMG = 4 * I;                          // floats of one step's x image: [k/4][chunk][k%4]
     constexpr int XPIECES = KB * I;                      // 16-byte pieces per x block
     constexpr int NDMA = (XPIECES / 64 + 3) / 4;
@@ -117,6 +115,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
     __shared__ __attribute__((aligned(16))) float vbuf[R * 3 * N * 4];      // vI[slot][row][chunk]
     __shared__ __attribute__((aligned(16))) float hring[HSLOTS * HIMG];
     __shared__ __attribute__((aligned(16))) float rhbuf[N * 4];
+    __shared__ float bias_lds[3 * N];
     __shared__ __attribute__((aligned(64))) int flags[16];
     __shared__ __attribute__((aligned(64))) int xflags[16];
 
@@ -129,6 +128,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
     const int cls = (lane & 15) >> 2;                    // which counter group this lane watches when polling
 
     for (int i = tid; i < HIMG; i += 512) hring[(HSLOTS - 1) * HIMG + i] = 0.0f;      // h(-1) = 0
+    for (int i = tid; i < 3 * N; i += 512) bias_lds[i] = bias ? bias[i] : 0.0f;
     if (tid < 16) { flags[tid] = 0; xflags[tid] = 0; }
     __syncthreads();                                     // the only hardware barrier
 
@@ -230,33 +230,34 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
         // projection waves
         // =================================================================================================
         const int pw = wave - 4;
-        // accumulator set 0: rows pw*OW + [0, P0), S0 K-slices; set 1: rows pw*OW + 64 + [0, P1), S1 K-slices
-        const int l0 = lane % LP0, g0 = lane / LP0;
-        const bool valid0 = l0 < P0;
-        const int row0 = pw * OW + (valid0 ? l0 : 0);
-        const int l1 = lane % LP1, g1 = lane / LP1;
-        const bool valid1 = P1 > 0 && l1 < P1;
-        const int row1 = pw * OW + (P1 ? 64 : 0) + (valid1 ? l1 : 0);
-        float w0[M0], w1[M1 ? M1 : 1];
-        {
-            const float *p0 = iW + (size_t)row0 * I + g0 * M0;
+        const int col = lane & 15, kq = lane >> 4;
+        constexpr bool LAST_MAYBE = (NT16 % 4) != 0;        // the last tile slot exists only for some waves
+        const bool last_ok = pw + 4 * (NTW - 1) < NT16;
+        // B operands: lane holds vI row 16*t + col, k = 32*kb + 8*kq + 0..7, as fp16 hi and lo parts
+        half8 whi[NTW][KBLK], wlo[NTW][KBLK];
 #pragma unroll
-            for (int m = 0; m < M0; m++) w0[m] = valid0 ? p0[m] : 0.0f;
-            const float *p1 = iW + (size_t)row1 * I + g1 * M1;
+        for (int i = 0; i < NTW; i++) {
+            const bool ok = (i < NTW - 1) || !LAST_MAYBE || last_ok;
+            const int row = ok ? 16 * (pw + 4 * i) + col : 0;
 #pragma unroll
-            for (int m = 0; m < M1; m++) w1[m] = valid1 ? p1[m] : 0.0f;
+            for (int kb = 0; kb < KBLK; kb++) {
+                const int k0 = 32 * kb + 8 * kq;
+                const bool kok = ok && (I % 32 == 0 || k0 < I);
+                const float *src = iW + (size_t)row * I + (kok ? k0 : 0);
+                const float4 u0 = *reinterpret_cast<const float4 *>(src), u1 = *reinterpret_cast<const float4 *>(src + 4);
+                const float u[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float v = kok ? u[j] : 0.0f;
+                    const _Float16 h = (_Float16)v;
+                    whi[i][kb][j] = h;
+                    wlo[i][kb][j] = (_Float16)(v - (float)h);
+                }
+            }
         }
-        const float bias0 = (bias && valid0 && g0 == 0) ? bias[row0] : 0.0f;
-        const float bias1 = (bias && valid1 && g1 == 0) ? bias[row1] : 0.0f;
-        // packed A-operand addresses into one step's x image: element x[chunk][k] sits at 16*(k>>2) + 4*chunk + (k&3)
-        int xa0[NVI], xa1[NVI];
-#pragma unroll
-        for (int v = 0; v < NVI; v++) {
-            const int k0 = (blk / G0) * M0 + v * G0 + (blk % G0);
-            xa0[v] = 16 * (k0 >> 2) + 4 * ci + (k0 & 3);
-            const int k1 = (blk / G1) * (P1 ? M1 : I) + v * G1 + (blk % G1);
-            xa1[v] = 16 * (k1 >> 2) + 4 * ci + (k1 & 3);
-        }
+        // A operands: lane supplies row m = lane & 15 = (step in group, chunk) and k = 32*kb + 8*kq + 0..7 from the
+        // step's x image, where element x[chunk][k] sits at 16*(k>>2) + 4*chunk + (k&3)
+        const int a_step = col >> 2, a_chunk = col & 3;
         auto dma_block = [&](int s0, int slot) {
 #pragma unroll
             for (int j = 0; j < NDMA; j++) {
@@ -280,8 +281,6 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
         const bool vec_store = (ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
         constexpr int OF4 = KB * N;                         // float4s per block
         constexpr int NFL = (OF4 + 255) / 256;              // parts per block
-        constexpr int FLUSH_AT = 4;                         // block kb is copied out at proj steps KB*(kb+1) + FLUSH_AT + j
-        static_assert(FLUSH_AT + NFL <= KB, "flush parts must fit in one block of steps");
         auto flush_part = [&](int kb, int j) {
             const int idx = (tid - 256) + 256 * j;
             const int c = idx & 3, rest = idx >> 2, f4 = rest % (N / 4), kk = rest / (N / 4);
@@ -305,9 +304,10 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
         };
 
         dma_block(0, 0);
-        for (int sp = 0; sp < T; sp++) {
-            if (sp % KB == 0) {
-                const int xb = sp / KB;
+        const int NG = (T + GS - 1) / GS;
+        for (int q = 0; q < NG; q++) {
+            if ((q & 1) == 0) {                                         // KB = 2 groups: a new x block starts here
+                const int xb = q / 2;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my share of block xb (issued a block ago) landed
                 publish(xflags, pw, xb + 1, lane);
                 publish(xflags, 4 + pw, xb, lane);                      // and I am done reading block xb-1
@@ -316,49 +316,65 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                     dma_block((xb + 1) * KB, (xb + 1) & 1);
                 }
                 wait_xflags(0, xb + 1);
+            } else if (q >= 3) {
+                // copy a finished block of states out (the recurrence does not need this wave for a while: vI is
+                // published through step 4q-1 and block fkb ends at step 4q-5)
+                const int fkb = (q - 3) / 2;
+                wait_flags(1, (fkb + 1) * KB);
+                for (int j = 0; j < NFL; j++) flush_part(fkb, j);
+                publish(flags, 12 + pw, fkb + 1, lane);
             }
-            const float *img = xbuf + ((sp / KB) & 1) * (KB * XIMG) + (sp % KB) * XIMG;
-            float xp[NVI];
+            // ---- per K block: the group's A operands (x split into halves on the fly), then every tile's three MFMAs ----
+            f32x4 acc[NTW];
 #pragma unroll
-            for (int v = 0; v < NVI; v++) xp[v] = img[xa0[v]];
-            f32x4 acc[4] = {{bias0, bias0, bias0, bias0}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            f32x4 r0 = acc[0], r1 = acc[0];
-            if (!(variant & 8)) {
-                mfma_chain<CB0, G0>(xp, w0, acc, std::make_integer_sequence<int, M0>{});
-                r0 = sum_slices<S0>((acc[0] + acc[1]) + (acc[2] + acc[3]));
+            for (int i = 0; i < NTW; i++) {
+                const float tb = bias_lds[(i < NTW - 1 || !LAST_MAYBE || last_ok) ? 16 * (pw + 4 * i) + col : 0];
+                acc[i] = f32x4{tb, tb, tb, tb};
             }
-            if constexpr (P1 > 0) {
-                float xq[NVI];
+            const float *img = xbuf + ((q >> 1) & 1) * (KB * XIMG) + (GS * (q & 1) + a_step) * XIMG + 4 * a_chunk;
 #pragma unroll
-                for (int v = 0; v < NVI; v++) xq[v] = img[xa1[v]];
-                f32x4 acc1[4] = {{bias1, bias1, bias1, bias1}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            for (int kb = 0; kb < KBLK; kb++) {
+                const int k0 = 32 * kb + 8 * kq;
+                const bool kok = (I % 32 == 0) || k0 < I;
+                const float *src = img + 4 * (kok ? k0 : 0);           // 16 * (k0 / 4)
+                const f32x4 u0 = *reinterpret_cast<const f32x4 *>(src), u1 = *reinterpret_cast<const f32x4 *>(src + 16);
+                half8 ahi, alo;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float v = kok ? (j < 4 ? u0[j & 3] : u1[j & 3]) : 0.0f;
+                    const _Float16 h = (_Float16)v;
+                    ahi[j] = h;
+                    alo[j] = (_Float16)(v - (float)h);
+                }
                 if (!(variant & 8)) {
-                    mfma_chain<CB1, G1>(xq, w1, acc1, std::make_integer_sequence<int, M1>{});
-                    r1 = sum_slices<S1>((acc1[0] + acc1[1]) + (acc1[2] + acc1[3]));
+#pragma unroll
+                    for (int i = 0; i < NTW; i++) {
+                        if (i < NTW - 1 || !LAST_MAYBE || last_ok) {
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, whi[i][kb], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wlo[i][kb], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, whi[i][kb], acc[i], 0, 0, 0);
+                        }
+                    }
                 }
             }
-            // ring slot sp % R was last read by phase A of step sp - R
-            if (sp >= R) wait_flags(0, sp - R + 1);
-            float *vdst = vbuf + (sp % R) * (3 * N * 4);
-            if (valid0 && g0 == 0) *reinterpret_cast<f32x4 *>(&vdst[4 * row0]) = r0;
-            if constexpr (P1 > 0) {
-                if (valid1 && g1 == 0) *reinterpret_cast<f32x4 *>(&vdst[4 * row1]) = r1;
+            // the group's ring slots were last read by phase A of steps GS*q - R ... GS*q + GS-1 - R
+            if (GS * q + GS > R) wait_flags(0, GS * q + GS - R);
+            // D: lane holds the four chunks of (step GS*q + kq, vI row 16*t + col) = one 16-byte entry of vbuf
+            const int st = GS * q + kq;
+            if (st < T) {
+                float *vdst = vbuf + (st % R) * (3 * N * 4) + 4 * col;
+#pragma unroll
+                for (int i = 0; i < NTW; i++)
+                    if (i < NTW - 1 || !LAST_MAYBE || last_ok) *reinterpret_cast<f32x4 *>(&vdst[64 * (pw + 4 * i)]) = acc[i];
             }
-            publish(flags, 8 + pw, sp + 1, lane);
-            // copy a finished block of states out, one part per step
-            const int fj = sp % KB - FLUSH_AT, fkb = sp / KB - 1;
-            if (fkb >= 0 && fj >= 0 && fj < NFL) {
-                if (fj == 0) wait_flags(1, (fkb + 1) * KB);
-                flush_part(fkb, fj);
-                if (fj == NFL - 1) publish(flags, 12 + pw, fkb + 1, lane);
-            }
+            publish(flags, 8 + pw, GS * q + GS, lane);
         }
-        // what the loop did not reach: the tail of the second-to-last block and the last block
+        // blocks of states the loop did not copy out
         wait_flags(1, T);
         const int kbl = (T - 1) / KB;
-        for (int kb = kbl > 0 ? kbl - 1 : 0; kb <= kbl; kb++)
-            for (int j = 0; j < NFL; j++)
-                if (KB * (kb + 1) + FLUSH_AT + j >= T) flush_part(kb, j);
+        for (int kb = 0; kb <= kbl; kb++)
+            if (2 * kb + 3 >= NG)
+                for (int j = 0; j < NFL; j++) flush_part(kb, j);
     }
     if (blockIdx.x == 0 && tid == 0) {
         slk_dbg_clock[0] = clock64() - clk0;
@@ -392,7 +408,7 @@ extern "C" int slk_gru_fused_f32(const float *x, long ldx, const float *iW, cons
     if (insize == II && n == NN) return launch_fused<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, s);
     // only shapes whose two roles fit 256 VGPRs without spilling are instantiated (e.g. 128->112 / 144->112 spill
     // > 1 KB per lane and run far slower than the two-kernel path)
-    FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(128, 96) FUSED(16, 16) FUSED(48, 32) FUSED(112, 112) FUSED(64, 96)
+    FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(128, 96) FUSED(16, 16) FUSED(48, 32) FUSED(64, 96)
 #undef FUSED
     return SLK_ERR_UNSUPPORTED;
 }
