@@ -26,7 +26,7 @@
 __device__ unsigned long long slk_dbg_clock[2];
 __device__ unsigned long long slk_dbg_stamp[16];
 #define STAMP(i)                                                                                   \
-    if (variant & 4) {                                                                             \
+    if (DIAG && (variant & 4)) {                                                                             \
         unsigned long long tnow;                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");                \
@@ -61,21 +61,42 @@ constexpr int pow2_slices(int outputs, int cap)
 //                                 flags[12..15] flushed[p]: proj wave p copied state blocks < value to h_out
 //                                 xflags[0..3] xready[p]: proj wave p's share of x blocks < value has landed
 //                                 xflags[4..7] xdone[p] : proj wave p finished reading x blocks < value
+typedef __attribute__((address_space(3))) int lds_int_t;
+
 __device__ __forceinline__ void publish(int *flags, int idx, int value, int lane)
 {
     asm volatile("" ::: "memory");          // the data writes stay ahead of the counter write in program order
-    if (lane == 0) *(volatile int *)&flags[idx] = value;
+    if (lane == 0) *(volatile lds_int_t *)(lds_int_t *)&flags[idx] = value;
     asm volatile("" ::: "memory");
 }
-// true when every watched counter (lane l watches flags[l & 15]) has reached the lane's `need`
-__device__ __forceinline__ bool reached(const int *flags, int lane, int need)
+// Polling is split in two so that the consumer's data reads travel with the counter read (one LDS round trip):
+//   poll_issue  -- ds_read of the watched counter (lane l watches flags[l & 15]), NOT waited for
+//   ... the caller issues its data reads ...
+//   poll_result -- waits for everything and tells whether every watched counter had reached the lane's `need`
+// (LDS executes a wave's operations in order, so data read after a counter that had arrived is valid data).
+__device__ __forceinline__ int poll_issue(const int *flags, int lane)
 {
-    const int v = *(volatile const int *)&flags[lane & 15];
-    asm volatile("" ::: "memory");          // data reads issued after this stay after it
+    int v;
+    const unsigned addr = (unsigned)(uintptr_t)(lds_int_t *)&flags[lane & 15];
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ bool poll_result(int v, int need)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory");
     return __builtin_amdgcn_ballot_w64(v < need) == 0;
 }
+__device__ __forceinline__ bool reached(const int *flags, int lane, int need)
+{
+    return poll_result(poll_issue(flags, lane), need);
+}
+// keeps values loaded inside a retry loop from being sunk out of it
+__device__ __forceinline__ void keep(f32x4 &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void keep(float &v) { asm volatile("" : "+v"(v)); }
 
-template <int I, int N, int ACT, int GACT>
+// DIAG: diagnostic instantiation (per-phase s_memtime stamps, optional skipping of the projection MFMAs); the production
+// instantiation carries none of those branches -- a taken branch costs a lone wave an instruction refetch.
+template <int I, int N, int ACT, int GACT, bool DIAG>
 __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restrict__ x, long ldx,
                                                            const float *__restrict__ iW, const float *__restrict__ bias,
                                                            const float *__restrict__ sW, const float *__restrict__ sW2,
@@ -119,7 +140,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
     __shared__ __attribute__((aligned(64))) int flags[16];
     __shared__ __attribute__((aligned(64))) int xflags[16];
 
-    const int variant = ((diag & 1) ? 4 : 0) | ((diag & 2) ? 8 : 0);   // 4: s_memtime stamps, 8: skip projection MFMAs
+    const int variant = DIAG ? (((diag & 1) ? 4 : 0) | ((diag & 2) ? 8 : 0)) : 0;   // 4: s_memtime stamps, 8: skip projection MFMAs
     const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
@@ -160,34 +181,50 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
         const float mask_zr = (validA && ga == 0) ? 1.0f : 0.0f;
         const float mask_c = zlane ? 1.0f : 0.0f;
         __builtin_amdgcn_s_setprio(3);      // the serial chain goes first; projection MFMAs fill its gaps
+        // what this lane's watched counter must reach, as step + offset (branch-free in the loop); unwatched counters
+        // get a huge negative offset.  Phase A: fB >= s.  Phase B: fA >= s+1.  Prefetch of vI(s+1): vready >= s+2 and
+        // the state slot of step s+1 copied out (flushed >= (s+1)/KB - 2).
+        constexpr int NOWATCH = INT_MIN / 2;
+        const int offA = cls == 1 ? 0 : NOWATCH;
+        const int offB = cls == 0 ? 1 : NOWATCH;
+        const bool watch_flush = cls == 3;
+        const int offV = cls == 2 ? 2 : NOWATCH;
 
         unsigned long long stamp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-        if (variant & 4) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
+        if (DIAG && (variant & 4)) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
+
+        f32x4 a0, c0;                                        // vI(s) rows of this lane's outputs, read one step ahead
+        for (;;) {                                           // vI(0)
+            const int f = poll_issue(flags, lane);
+            a0 = *reinterpret_cast<const f32x4 *>(&vbuf[4 * rowA]);
+            c0 = *reinterpret_cast<const f32x4 *>(&vbuf[4 * (2 * N + neuronB)]);
+            const bool ok = poll_result(f, cls == 2 ? 1 : NOWATCH);
+            keep(a0); keep(c0);
+            if (ok) break;
+        }
 
         for (int s = 0; s < T; s++) {
-            const float *vrow = vbuf + (s % R) * (3 * N * 4);
             const float *hprev = hring + ((s + HSLOTS - 1) % HSLOTS) * HIMG;
             float *hcur = hring + (s % HSLOTS) * HIMG;
-            // h(s-1) from every rec wave, vI(s) from every proj wave, and the slot h(s) will overwrite copied out
-            const int needA = cls == 1 ? s : (cls == 2 ? s + 1 : (cls == 3 ? s / KB - 2 : INT_MIN));
+            const int needA = s + offA, needB = s + offB;
+            const int needV = watch_flush ? (s + 1) / KB - 2 : s + offV;
             STAMP(0)
 
             // ---------------- phase A: z | r ----------------
+            // this wave's own neurons need no handshake (LDS keeps a wave's operations in order)
+            const f32x4 hown = *reinterpret_cast<const f32x4 *>(&hprev[4 * neuronA]);
             float hp[NV];
-            f32x4 a0, c0, hown;
             for (;;) {
-                const bool ok = reached(flags, lane, needA);
+                const int f = poll_issue(flags, lane);
 #pragma unroll
                 for (int v = 0; v < NV; v++) hp[v] = hprev[addrA0 + 4 * v * GA];
-                a0 = *reinterpret_cast<const f32x4 *>(&vrow[4 * rowA]);
-                c0 = *reinterpret_cast<const f32x4 *>(&vrow[4 * (2 * N + neuronB)]);
-                hown = *reinterpret_cast<const f32x4 *>(&hprev[4 * neuronA]);
+                const bool ok = poll_result(f, needA);
+#pragma unroll
+                for (int v = 0; v < NV; v++) keep(hp[v]);
                 if (ok) break;
             }
-            a0 *= mask_zr;
-            c0 *= mask_c;
             STAMP(1)
-            f32x4 accA[4] = {a0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            f32x4 accA[4] = {a0 * mask_zr, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             mfma_chain<CBA, GA>(hp, wA, accA, std::make_integer_sequence<int, MA>{});
             f32x4 g = sum_slices<SA>((accA[0] + accA[1]) + (accA[2] + accA[3]));
             STAMP(2)
@@ -198,18 +235,41 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
             STAMP(3)
 
             // ---------------- phase B: candidate ----------------
-            const int needB = cls == 0 ? s + 1 : INT_MIN;
             float rp[NV];
             for (;;) {
-                const bool ok = reached(flags, lane, needB);
+                const int f = poll_issue(flags, lane);
 #pragma unroll
                 for (int v = 0; v < NV; v++) rp[v] = rhbuf[addrB0 + 4 * v * GB];
+                const bool ok = poll_result(f, needB);
+#pragma unroll
+                for (int v = 0; v < NV; v++) keep(rp[v]);
                 if (ok) break;
             }
             STAMP(4)
-            f32x4 accB[4] = {c0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            // vI(s+1), one step ahead (its latency disappears behind the candidate chain)
+            const float *vnext = vbuf + ((s + 1) % R) * (3 * N * 4);
+            const bool more = s + 1 < T;
+            int fv = 0;
+            f32x4 a0n = a0, c0n = c0;
+            if (more) {
+                fv = poll_issue(flags, lane);
+                a0n = *reinterpret_cast<const f32x4 *>(&vnext[4 * rowA]);
+                c0n = *reinterpret_cast<const f32x4 *>(&vnext[4 * (2 * N + neuronB)]);
+            }
+            f32x4 accB[4] = {c0 * mask_c, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             mfma_chain<CBB, GB>(rp, wB, accB, std::make_integer_sequence<int, MB>{});
             f32x4 cc = sum_slices<SB>((accB[0] + accB[1]) + (accB[2] + accB[3]));
+            if (more) {                                      // long since answered; checked before the writes below queue up
+                bool ok = poll_result(fv, needV);
+                keep(a0n); keep(c0n);
+                while (!ok) {
+                    const int f2 = poll_issue(flags, lane);
+                    a0n = *reinterpret_cast<const f32x4 *>(&vnext[4 * rowA]);
+                    c0n = *reinterpret_cast<const f32x4 *>(&vnext[4 * (2 * N + neuronB)]);
+                    ok = poll_result(f2, needV);
+                    keep(a0n); keep(c0n);
+                }
+            }
             STAMP(5)
             if (zlane) {
                 f32x4 hn;
@@ -221,9 +281,11 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                 *reinterpret_cast<f32x4 *>(&hcur[4 * neuronB]) = hn;
             }
             publish(flags, 4 + wave, s + 1, lane);
+            a0 = a0n;
+            c0 = c0n;
             STAMP(6)
         }
-        if ((variant & 4) && blockIdx.x == 0 && tid == 0)
+        if (DIAG && (variant & 4) && blockIdx.x == 0 && tid == 0)
             for (int i = 0; i < 9; i++) slk_dbg_stamp[i] = stamp_acc[i];
     } else {
         // =================================================================================================
@@ -346,7 +408,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                     ahi[j] = h;
                     alo[j] = (_Float16)(v - (float)h);
                 }
-                if (!(variant & 8)) {
+                if (!(DIAG && (variant & 8))) {
 #pragma unroll
                     for (int i = 0; i < NTW; i++) {
                         if (i < NTW - 1 || !LAST_MAYBE || last_ok) {
@@ -376,7 +438,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
             if (2 * kb + 3 >= NG)
                 for (int j = 0; j < NFL; j++) flush_part(kb, j);
     }
-    if (blockIdx.x == 0 && tid == 0) {
+    if (DIAG && blockIdx.x == 0 && tid == 0) {
         slk_dbg_clock[0] = clock64() - clk0;
         slk_dbg_clock[1] = wall_clock64() - wall0;
     }
@@ -386,12 +448,20 @@ template <int I, int N>
 static int launch_fused(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
                         float *y, long ldy, int T, int B, int reverse, hipStream_t s)
 {
-    hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID>), dim3((B + 3) / 4), dim3(512), 0, s, x, ldx,
-                       iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, (reverse >> 1) & 3);
+    const int diag = (reverse >> 1) & 3;
+    if constexpr (I == 96 && N == 96) {
+        if (diag) {
+            hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, true>), dim3((B + 3) / 4), dim3(512), 0, s,
+                               x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, diag);
+            return slk_launch_status();
+        }
+    }
+    hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>), dim3((B + 3) / 4), dim3(512), 0, s, x,
+                       ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, 0);
     return slk_launch_status();
 }
 
-// (bit 1 of `reverse` requests a diagnostic launch that fills the s_memtime stamps read by slk_debug_read_stamps;
+// (bits 1-2 of `reverse` request a diagnostic launch (96 -> 96 only) that fills the s_memtime stamps read by slk_debug_read_stamps;
 //  undocumented in the public header on purpose -- tools/bench_kernels.py uses it.)
 // Returns SLK_ERR_UNSUPPORTED when no fused instantiation covers the request (the caller then uses
 // projection GEMM + gru_mfma_kernel).

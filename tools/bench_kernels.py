@@ -67,7 +67,7 @@ def main():
                     stp = (ctypes.c_ulonglong * 16)()
                     L.slk_debug_read_stamps.argtypes = [ctypes.c_void_p]
                     L.slk_debug_read_stamps(stp)
-                    names = ["top", "wait h+vI, reads A", "mfma A+sum", "gates+publish", "wait rh, reads B", "mfma B+sum", "tanh+update+publish"]
+                    names = ["top", "wait h, reads A", "mfma A+sum", "gates+publish", "wait rh, reads B", "mfma B+sum", "tanh+update+publish"]
                     print("   per-step cycles (wave0/wg0): " + ", ".join("%s=%.0f" % (nm, stp[i] / T) for i, nm in enumerate(names)))
                 print("gru_fused v%d I=%d n=%d B=%d T=%d: %.3f ms  %.1f TF  %.0f ns/step | wg0: %d cycles, %.2f GHz, %.0f cycles/step" % (variant, I, n, B, T, ms, fl / ms / 1e9, ms * 1e6 / T, clk[0], ghz, clk[0] / T))
     if "gemm" in what:
