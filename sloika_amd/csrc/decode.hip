@@ -246,6 +246,368 @@ __global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------------------
+// forward DP, nbase = 4 (the DNA/RNA models): one barrier per step.
+//   * scores ping-pong between two LDS vectors, so a step needs a single barrier (the generic kernel above publishes
+//     the step maxima through LDS and needs two);
+//   * thread j = 4q + c owns to-states 4j..4j+3.  Their 16 skip predecessors (a, b) are shared by the quad q: thread c
+//     reduces the four with b = c, then the quad combines the partial (value, key = a*4 + b) pairs with two DPP
+//     exchanges -- same first-maximum rule as np.argmax over the flattened (a, b) axis (decode.py:72-73);
+//   * the blank column's log-posterior is the same for every thread: it is evaluated once per workgroup, a block of
+//     blockDim.x steps at a time, instead of once per thread and step.
+// ------------------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) unaligned_f4 { float x, y, z, w; };
+#define VIT_TBS 16
+
+template <bool LOGITS>
+__global__ void __launch_bounds__(1024) viterbi_forward4_kernel(const float *__restrict__ post,
+                                                                const float2 *__restrict__ stats, long ld, int T, int B,
+                                                                int nkmer, float skip_pen, int mode, float min_prob,
+                                                                float one_m, uint8_t *__restrict__ tb,
+                                                                int32_t *__restrict__ best_out,
+                                                                float *__restrict__ score_out)
+{
+    constexpr int NB = 4;
+    extern __shared__ float sm[];
+    const int nrem1 = nkmer / 4, nrem2 = nkmer / 16;
+    const int b = blockIdx.x, j = threadIdx.x, nt = blockDim.x;
+    float *vbuf0 = sm, *vbuf1 = sm + nkmer;                    // scores of even / odd steps
+    float *lp0buf = sm + 2 * nkmer;                            // [nt] blank log-posteriors of the current block of steps
+    float *redv = lp0buf + nt;                                 // [16]
+    int *redi = reinterpret_cast<int *>(redv + 16);            // [16]
+    // traceback codes of VIT_TBS steps are staged in LDS as an image of the global layout and copied out with 16-byte
+    // stores: a store every step would make the loop-top wait for the prefetched row (vmcnt) also wait for that store
+    uint32_t *tbs = reinterpret_cast<uint32_t *>(redi + 16);   // [VIT_TBS][nrem1] words
+    const bool active = j < nrem1;
+    const int jj = active ? j : 0, q = jj >> 2, c = jj & 3;
+    const float *pb = post + (size_t)b * ld;                   // rows (t, b) are `ld` floats apart (ld >= nkmer + 1)
+    const size_t tstride = (size_t)B * ld;
+    uint8_t *tbb = tb + (size_t)b * T * nkmer;
+
+    auto xform = [&](float val, float2 st) {
+        return LOGITS ? log_logit_val(val, st, min_prob, one_m) : log_post_val(val, mode, min_prob, one_m);
+    };
+    auto load_row = [&](int t) { return *reinterpret_cast<const unaligned_f4 *>(pb + (size_t)t * tstride + 1 + 4 * jj); };
+    auto row_stats = [&](int t) { return LOGITS ? stats[(size_t)t * B + b] : make_float2(0.f, 1.f); };
+    // blank column of step t0 + j (one step per thread)
+    auto load_blank = [&](int t0, float &r0, float2 &st0) {
+        const int tt = min(t0 + j, T - 1);
+        r0 = pb[(size_t)tt * tstride];
+        st0 = row_stats(tt);
+    };
+
+    // t = 0: v = lpost[0][1:]   (decode.py:57)
+    unaligned_f4 raw = load_row(0);
+    float2 rst = row_stats(0);
+    float blank_raw;
+    float2 blank_st;
+    load_blank(0, blank_raw, blank_st);
+    if (active)
+        *reinterpret_cast<float4 *>(&vbuf0[4 * jj]) = make_float4(xform(raw.x, rst), xform(raw.y, rst), xform(raw.z, rst), xform(raw.w, rst));
+    lp0buf[j] = xform(blank_raw, blank_st);
+    if (T > nt) load_blank(nt, blank_raw, blank_st);           // next block, converted when it starts
+    // Two row buffers that swap roles statically (time loop unrolled by two): copying a just-requested row into the
+    // "current" registers would make every step wait for that request.  During step t `use` holds row t, `fill` gets t+1.
+    unaligned_f4 rowA = raw, rowB = raw;
+    float2 stA = rst, stB = rst;
+    if (T > 1) { rowA = load_row(1); stA = row_stats(1); }
+    __syncthreads();
+
+    auto step = [&](int t, const unaligned_f4 &raw, const float2 &rst, unaligned_f4 &fill, float2 &st_fill) {
+        const int tl = t % nt;
+        if (tl == 0) {                                         // every thread is past the previous block (end-of-step barrier)
+            lp0buf[j] = xform(blank_raw, blank_st);
+            __syncthreads();
+            if (t + nt < T) load_blank(t + nt, blank_raw, blank_st);
+        }
+        // prefetch the next row one full step ahead of its use (the tail re-reads the last row)
+        fill = load_row(t + 1 < T ? t + 1 : T - 1);
+        st_fill = row_stats(t + 1 < T ? t + 1 : T - 1);
+        const float *vold = (t & 1) ? vbuf0 : vbuf1;
+        float *vnew = (t & 1) ? vbuf1 : vbuf0;
+        // ---- step maximum over a (first max wins: np.argmax, decode.py:67-68) ----
+        float sstep = vold[jj];
+        int sarg = 0;
+#pragma unroll
+        for (int a = 1; a < NB; a++) {
+            const float x = vold[a * nrem1 + jj];
+            if (x > sstep) { sstep = x; sarg = a; }
+        }
+        // ---- skip maximum over ab = a*4 + b: this thread's share is b = c ----
+        float kbest = vold[c * nrem2 + q];
+        int karg = c;
+#pragma unroll
+        for (int a = 1; a < NB; a++) {
+            const float x = vold[a * nrem1 + c * nrem2 + q];
+            if (x > kbest) { kbest = x; karg = a * NB + c; }
+        }
+        const float4 own = *reinterpret_cast<const float4 *>(&vold[4 * jj]);
+        const float lp0 = lp0buf[tl];
+        const float lp[4] = {xform(raw.x, rst), xform(raw.y, rst), xform(raw.z, rst), xform(raw.w, rst)};
+        // quad exchange: lane ^ 1, then lane ^ 2 (first maximum in ab order wins, decode.py:72-73)
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int ctl = r == 0 ? 0xB1 : 0x4E;              // quad_perm [1,0,3,2] / [2,3,0,1]
+            const float ov = r == 0 ? __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(kbest), 0xB1, 0xf, 0xf, false))
+                                    : __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(kbest), 0x4E, 0xf, 0xf, false));
+            const int ok = r == 0 ? __builtin_amdgcn_update_dpp(0, karg, 0xB1, 0xf, 0xf, false)
+                                  : __builtin_amdgcn_update_dpp(0, karg, 0x4E, 0xf, 0xf, false);
+            (void)ctl;
+            const bool take = (ov > kbest) | ((ov == kbest) & (ok < karg));     // branch-free
+            kbest = take ? ov : kbest;
+            karg = take ? ok : karg;
+        }
+        const float sskip = kbest - skip_pen;                       // decode.py:72
+        const float mx = fmaxf(sstep, sskip);
+        const int code = sstep > sskip ? sarg : NB + karg;          // decode.py:76 (tie -> skip)
+        if (active) {
+            const float ownv[4] = {own.x, own.y, own.z, own.w};
+            float nw[4];
+            uint32_t packed = 0;
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                const float nv = lp[cc] + mx;                       // decode.py:75
+                const float stay = ownv[cc] + lp0;                  // decode.py:80
+                const bool move = nv > stay;                        // decode.py:81 (tie -> stay)
+                packed |= (uint32_t)(move ? code : VIT_STAY) << (8 * cc);
+                nw[cc] = move ? nv : stay;
+            }
+            *reinterpret_cast<float4 *>(&vnew[4 * jj]) = make_float4(nw[0], nw[1], nw[2], nw[3]);
+            tbs[(t % VIT_TBS) * nrem1 + jj] = packed;
+        }
+        __syncthreads();
+        if ((t % VIT_TBS) == VIT_TBS - 1 || t == T - 1) {
+            // rows t0..t of the traceback are complete in LDS (t0 = first step of this block, >= 1)
+            const int t0 = t - (t % VIT_TBS);
+            const int first = t0 < 1 ? 1 : t0;
+            const int nwords = (t - first + 1) * nrem1;
+            const uint32_t *src = tbs + (first - t0) * nrem1;
+            uint32_t *dst = reinterpret_cast<uint32_t *>(tbb + (size_t)first * nkmer);
+            if ((nrem1 & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+                for (int k = j; k < nwords / 4; k += nt)
+                    reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
+            } else {
+                for (int k = j; k < nwords; k += nt) dst[k] = src[k];
+            }
+            __syncthreads();               // the staging rows are rewritten from the next step on
+        }
+    };
+    for (int t = 1; t < T; t += 2) {
+        step(t, rowA, stA, rowB, stB);
+        if (t + 1 < T) step(t + 1, rowB, stB, rowA, stA);
+    }
+    // ---- first argmax of v (np.argmax, decode.py:85) ----
+    const float *v = ((T - 1) & 1) ? vbuf1 : vbuf0;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    if (active) {
+#pragma unroll
+        for (int cc = 0; cc < NB; cc++) {
+            float x = v[jj * NB + cc];
+            if (x > bv) { bv = x; bi = jj * NB + cc; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(bv, o);
+        int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { redv[threadIdx.x >> 6] = bv; redi[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nwv = blockDim.x >> 6;
+        for (int w = 1; w < nwv; w++)
+            if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
+        score_out[b] = bv;
+        best_out[b] = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward DP, nbase = 4, up to 1024 k-mers: ONE WAVE per chunk, no barriers at all.
+//   Lane q owns the 16 to-states 16q..16q+15, i.e. the four step groups j = 4q..4q+3, which all share the same 16 skip
+//   predecessors (a, b) -> v[a*nkmer/4 + b*nkmer/16 + q]: the skip arg-max is evaluated once per 16 states instead of
+//   once per 4, the per-thread fixed work (addressing, row statistics, blank column) is amortised over 16 states, and
+//   waves of different chunks drift freely, hiding each other's memory latency (4 waves per SIMD at B = 1024).
+//   Scores live in LDS (one vector per wave: a wave reads every predecessor before it writes, in program order).
+//   About half the vector instructions per (chunk, step) of the one-barrier workgroup kernel above.
+// ------------------------------------------------------------------------------------------------------
+template <bool LOGITS>
+__global__ void __launch_bounds__(256) viterbi_forward4_wave_kernel(const float *__restrict__ post,
+                                                                    const float2 *__restrict__ stats, long ld, int T, int B,
+                                                                    int nkmer, float skip_pen, int mode, float min_prob,
+                                                                    float one_m, uint8_t *__restrict__ tb,
+                                                                    int32_t *__restrict__ best_out,
+                                                                    float *__restrict__ score_out)
+{
+    constexpr int NB = 4;
+    extern __shared__ float sm[];
+    // the chunk index is wave-uniform: keeping it in a scalar register makes the row statistics scalar loads
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= B) return;                                        // whole wave leaves together; nothing below synchronises waves
+    const int nrem1 = nkmer / 4, nrem2 = nkmer / 16;
+    float *v = sm + wave * (nkmer + 64);                       // [nkmer] scores, then [64] blank log-posteriors
+    float *lp0buf = v + nkmer;
+    const bool active = lane < nrem2;
+    const int q = active ? lane : 0;
+    const float *pb = post + (size_t)b * ld;
+    const size_t tstride = (size_t)B * ld;
+    uint8_t *tbb = tb + (size_t)b * T * nkmer;
+
+    auto xform = [&](float val, float2 st) {
+        return LOGITS ? log_logit_val(val, st, min_prob, one_m) : log_post_val(val, mode, min_prob, one_m);
+    };
+    auto row_stats = [&](int t) { return LOGITS ? stats[(size_t)t * B + b] : make_float2(0.f, 1.f); };
+    struct row16 { unaligned_f4 g[4]; };
+    auto load_row = [&](int t) {
+        row16 r;
+        const float *p = pb + (size_t)t * tstride + 1 + 16 * q;
+#pragma unroll
+        for (int i = 0; i < 4; i++) r.g[i] = *reinterpret_cast<const unaligned_f4 *>(p + 4 * i);
+        return r;
+    };
+    auto load_blank = [&](int t0, float &r0, float2 &st0) {      // blank column of step t0 + lane
+        const int tt = min(t0 + lane, T - 1);
+        r0 = pb[(size_t)tt * tstride];
+        st0 = row_stats(tt);
+    };
+
+    // Software pipeline: the log-posteriors of step t+1 are evaluated during step t (they do not depend on the scores,
+    // so their exp/log work fills the waits of the dependent max-plus chain -- with one wave per SIMD nothing else
+    // would), from a row that was requested during step t-1.
+    auto xform_row = [&](const row16 &r, float2 st, float (&lp)[16]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            lp[4 * i + 0] = xform(r.g[i].x, st);
+            lp[4 * i + 1] = xform(r.g[i].y, st);
+            lp[4 * i + 2] = xform(r.g[i].z, st);
+            lp[4 * i + 3] = xform(r.g[i].w, st);
+        }
+    };
+    // t = 0: v = lpost[0][1:]   (decode.py:57)
+    float lp[16];
+    {
+        const row16 r0 = load_row(0);
+        xform_row(r0, row_stats(0), lp);
+    }
+    float blank_raw;
+    float2 blank_st;
+    load_blank(0, blank_raw, blank_st);
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            *reinterpret_cast<float4 *>(&v[16 * q + 4 * i]) = make_float4(lp[4 * i], lp[4 * i + 1], lp[4 * i + 2], lp[4 * i + 3]);
+    }
+    lp0buf[lane] = xform(blank_raw, blank_st);
+    if (T > 64) load_blank(64, blank_raw, blank_st);           // next block of 64 steps, converted when it starts
+    // Two row buffers in rotation, WITHOUT register copies: a copy of a just-requested row would force the wave to wait
+    // for that request (the whole memory latency, every step), so the time loop is unrolled by two and the buffers swap
+    // roles statically.  While step t runs: `use` holds row t+1 (requested during step t-1), `fill` receives row t+2.
+    row16 rowA, rowB;
+    float2 stA, stB;
+    if (T > 1) {
+        const row16 r1 = load_row(1);
+        xform_row(r1, row_stats(1), lp);
+    }
+    rowA = load_row(T > 2 ? 2 : T - 1);
+    stA = row_stats(T > 2 ? 2 : T - 1);
+
+    auto step = [&](int t, const row16 &use, const float2 &st_use, row16 &fill, float2 &st_fill) {
+        const int tl = t & 63;
+        if (tl == 0) {
+            lp0buf[lane] = xform(blank_raw, blank_st);
+            if (t + 64 < T) load_blank(t + 64, blank_raw, blank_st);
+        }
+        const int tf = t + 2 < T ? t + 2 : T - 1;               // clamped: the tail re-reads the last row
+        fill = load_row(tf);
+        st_fill = row_stats(tf);
+        // ---- skip maximum over ab = a*4 + b, first maximum wins (decode.py:72-73) ----
+        float kbest = v[q];
+        int karg = 0;
+#pragma unroll
+        for (int ab = 1; ab < 16; ab++) {
+            const float x = v[(ab >> 2) * nrem1 + (ab & 3) * nrem2 + q];
+            const bool take = x > kbest;
+            kbest = take ? x : kbest;
+            karg = take ? ab : karg;
+        }
+        const float sskip = kbest - skip_pen;                       // decode.py:72
+        const float lp0 = lp0buf[tl];
+        // ---- the four step groups j = 4q + c ----
+        float4 pred[4];                                              // pred[a] = v[a*nrem1 + 4q .. +3]
+#pragma unroll
+        for (int a = 0; a < 4; a++) pred[a] = *reinterpret_cast<const float4 *>(&v[a * nrem1 + 4 * q]);
+        float4 own[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) own[c] = *reinterpret_cast<const float4 *>(&v[16 * q + 4 * c]);
+        float4 out[4];
+        uint32_t codes[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float pa[4] = {c == 0 ? pred[0].x : c == 1 ? pred[0].y : c == 2 ? pred[0].z : pred[0].w,
+                                 c == 0 ? pred[1].x : c == 1 ? pred[1].y : c == 2 ? pred[1].z : pred[1].w,
+                                 c == 0 ? pred[2].x : c == 1 ? pred[2].y : c == 2 ? pred[2].z : pred[2].w,
+                                 c == 0 ? pred[3].x : c == 1 ? pred[3].y : c == 2 ? pred[3].z : pred[3].w};
+            float sstep = pa[0];                                     // first max wins: np.argmax, decode.py:67-68
+            int sarg = 0;
+#pragma unroll
+            for (int a = 1; a < 4; a++) {
+                const bool take = pa[a] > sstep;
+                sstep = take ? pa[a] : sstep;
+                sarg = take ? a : sarg;
+            }
+            const float mx = fmaxf(sstep, sskip);
+            const int code = sstep > sskip ? sarg : NB + karg;      // decode.py:76 (tie -> skip)
+            const float ownv[4] = {own[c].x, own[c].y, own[c].z, own[c].w};
+            float nw[4];
+            uint32_t packed = 0;
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                const float nv = lp[4 * c + cc] + mx;               // decode.py:75
+                const float stay = ownv[cc] + lp0;                  // decode.py:80
+                const bool move = nv > stay;                        // decode.py:81 (tie -> stay)
+                packed |= (uint32_t)(move ? code : VIT_STAY) << (8 * cc);
+                nw[cc] = move ? nv : stay;
+            }
+            out[c] = make_float4(nw[0], nw[1], nw[2], nw[3]);
+            codes[c] = packed;
+        }
+        if (active) {
+            // every read of the old scores above precedes these writes in program order (one wave, in-order LDS)
+#pragma unroll
+            for (int c = 0; c < 4; c++) *reinterpret_cast<float4 *>(&v[16 * q + 4 * c]) = out[c];
+            *reinterpret_cast<uint4 *>(tbb + (size_t)t * nkmer + 16 * (size_t)q) = make_uint4(codes[0], codes[1], codes[2], codes[3]);
+        }
+        xform_row(use, st_use, lp);                                  // log-posteriors of step t+1
+    };
+    for (int t = 1; t < T; t += 2) {
+        step(t, rowA, stA, rowB, stB);
+        if (t + 1 < T) step(t + 1, rowB, stB, rowA, stA);
+    }
+    // ---- first argmax of v (np.argmax, decode.py:85) ----
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    if (active) {
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++) {
+            const float x = v[16 * q + cc];
+            if (x > bv) { bv = x; bi = 16 * q + cc; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ov = __shfl_xor(bv, o);
+        int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        score_out[b] = bv;
+        best_out[b] = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // backtrace: stage time-blocks of the byte traceback in LDS, one lane walks them; emit right-aligned, then
 // the whole workgroup shifts the path left and pads with -1.
 // ------------------------------------------------------------------------------------------------------
@@ -359,7 +721,28 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
     if (nrem1 > 1024) return SLK_ERR_UNSUPPORTED;
     size_t lds = sizeof(float) * ((size_t)nkmer + nrem1 + 16) + sizeof(int) * ((size_t)nrem1 + 16);
     float one_m = (float)(1.0 - (double)min_prob);
-    if (stats)
+    if (NB == 4 && nkmer <= 1024 && nkmer >= 64 && B >= 1536) {
+        // one wave per chunk, four chunks per workgroup: fewer instructions per (chunk, step), but a lone wave per SIMD
+        // cannot hide its own dependent-issue and memory latency -- it wins once there are ~2 chunks per SIMD (1024 SIMDs)
+        const size_t ldsw = sizeof(float) * 4 * ((size_t)nkmer + 64);
+        const dim3 grid((B + 3) / 4), block(256);
+        if (stats)
+            hipLaunchKernelGGL((viterbi_forward4_wave_kernel<true>), grid, block, ldsw, s, post,
+                               reinterpret_cast<const float2 *>(stats), ld, T, B, nkmer, skip_pen, mode, min_prob, one_m, tb,
+                               best, score_out);
+        else
+            hipLaunchKernelGGL((viterbi_forward4_wave_kernel<false>), grid, block, ldsw, s, post, nullptr, ld, T, B, nkmer,
+                               skip_pen, mode, min_prob, one_m, tb, best, score_out);
+    } else if constexpr (NB == 4) {
+        const size_t lds4 = sizeof(float) * (2 * (size_t)nkmer + threads + 32 + (size_t)VIT_TBS * nrem1);
+        if (stats)
+            hipLaunchKernelGGL((viterbi_forward4_kernel<true>), dim3(B), dim3(threads), lds4, s, post,
+                               reinterpret_cast<const float2 *>(stats), ld, T, B, nkmer, skip_pen, mode, min_prob, one_m, tb,
+                               best, score_out);
+        else
+            hipLaunchKernelGGL((viterbi_forward4_kernel<false>), dim3(B), dim3(threads), lds4, s, post, nullptr, ld, T, B,
+                               nkmer, skip_pen, mode, min_prob, one_m, tb, best, score_out);
+    } else if (stats)
         hipLaunchKernelGGL((viterbi_forward_kernel<NB, true>), dim3(B), dim3(threads), lds, s, post,
                            reinterpret_cast<const float2 *>(stats), ld, T, B, nkmer, skip_pen, mode, min_prob, one_m, tb, best,
                            score_out);

@@ -75,6 +75,27 @@ def test_viterbi_batch_vs_oracle(oracle, T, B, klen, nbase, skip):
     assert np.array_equal(scores.cpu().numpy(), o_scores)
 
 
+@pytest.mark.parametrize("klen,skip", [(5, 0.0), (4, 2.0), (3, 0.5)])
+def test_viterbi_large_batch_kernel_equals_small_batch_kernel(oracle, klen, skip):
+    """Batches of >= 1536 chunks take the wave-per-chunk forward kernel, smaller ones the workgroup-per-chunk kernel:
+    same chunks through both must agree bit for bit (and with the oracle on a sample), ties included."""
+    torch = need_gpu()
+    from sloika_amd import decode
+    T, B, nst = 33, 1600, 4 ** klen + 1
+    g = torch.Generator(device="cuda").manual_seed(klen)
+    lp = torch.log_softmax(3.0 * torch.randn((T, B, nst), device="cuda", generator=g), dim=2)
+    lp[T // 2] = lp[T // 2, :, :1]                     # a fully tied row
+    lp[5, :, 1:] = lp[5, :, 1:2]                       # all k-mers tied, blank different
+    s_all, p_all, l_all = decode.viterbi_batch(lp, klen, skip_pen=skip, log=True)
+    for lo, hi in ((0, 800), (800, 1600)):
+        s_h, p_h, l_h = decode.viterbi_batch(lp[:, lo:hi].contiguous(), klen, skip_pen=skip, log=True)
+        assert torch.equal(p_all[lo:hi], p_h) and torch.equal(l_all[lo:hi], l_h) and torch.equal(s_all[lo:hi], s_h)
+    sub = [0, 1, 799, 1599]
+    o_s, o_p, o_l = oracle.viterbi_batch(lp[:, sub].cpu().numpy(), klen, skip_pen=skip)
+    assert np.array_equal(p_all[sub].cpu().numpy(), o_p) and np.array_equal(l_all[sub].cpu().numpy(), o_l)
+    assert np.array_equal(s_all[sub].cpu().numpy(), o_s)
+
+
 def test_viterbi_full_size_properties():
     """BASELINE size (T'=800, 1025 states): size-independent properties instead of a CPU re-run of every chunk:
     (1) replicating a chunk across the batch gives identical results in every slot, (2) the returned score
