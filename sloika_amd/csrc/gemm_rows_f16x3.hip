@@ -6,8 +6,8 @@
 // (the fp32-input MFMA runs at 1/16 of the fp16 rate on gfx950 and there is no TF32 path), i.e. ~5x the fp32 MFMA
 // throughput at an error of a few float32 ulps -- far inside the 1e-4 layer tolerance (tests/test_gpu_gemm.py).
 //
-// Structure = gemm_rows.hip (x-stationary, 128 rows x all N columns per 512-thread workgroup, weight tiles double
-// buffered in LDS, row statistics accumulated online); the weights arrive pre-split (slk_split_f16x2_f32).
+// x-stationary like gemm_rows.hip (128 rows x all N columns per workgroup, row statistics accumulated online); the weights
+// arrive pre-split (slk_split_f16x2_f32).
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -41,167 +41,200 @@ extern "C" int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, vo
     return slk_launch_status();
 }
 
+// Kernel structure
+//   * 128 rows x all N columns per workgroup; the MFMA computes the TRANSPOSED 64-column tile D[W column][x row]
+//     (A = weights from LDS, B = x held in registers for the whole row block): a lane then owns 16 columns of ONE output
+//     row, four of them consecutive per accumulator quad, so the logits leave as 16-byte stores straight from the
+//     accumulators and the online softmax statistics are two scalars per lane.
+//   * waves 0-7 compute; wave 8 does nothing but stream the weight tiles into a 3-slot LDS ring with LDS-DMA
+//     (global_load_lds_dwordx4), two tiles ahead.  The split exists because of vmcnt: it counts loads AND stores and
+//     they complete out of order with respect to each other, so a wave that has logit stores in flight can only wait
+//     for a weight load with vmcnt(0) -- i.e. for a full store round trip (microseconds) on every tile.  The compute
+//     waves issue no loads in the loop, hence never wait on memory; the loader wave has no stores.
+//   * one s_barrier per tile (LDS counter only: __syncthreads() would drain vmcnt as well).
 template <int KS, bool STATS>
-__global__ void __launch_bounds__(512, 2) gemm_rows_f16x3_kernel(const float *__restrict__ x, long ldx,
-                                                                 const _Float16 *__restrict__ Whi,
-                                                                 const _Float16 *__restrict__ Wlo,
-                                                                 const float *__restrict__ bias, float *__restrict__ y,
-                                                                 long ldy, long M, int K, int N,
-                                                                 float2 *__restrict__ stats)
+__global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__restrict__ x, long ldx,
+                                                              const _Float16 *__restrict__ Whi,
+                                                              const _Float16 *__restrict__ Wlo,
+                                                              const float *__restrict__ bias, float *__restrict__ y,
+                                                              long ldy, long M, int K, int N,
+                                                              float2 *__restrict__ stats)
 {
     constexpr int KP = 16 * KS;                    // padded K (halves per weight row in Whi/Wlo)
     constexpr int LD = KP + 8;                     // LDS row stride in halves: (KP+8)*2 B = odd multiple of 16 B
-    __shared__ __attribute__((aligned(16))) _Float16 wsh[2][GH_BN * LD];
-    __shared__ __attribute__((aligned(16))) _Float16 wsl[2][GH_BN * LD];
+    constexpr int RING = 3;
+    constexpr int PPR = KP / 8 + 1;                // 16-byte pieces per LDS row (the last one is padding)
+    constexpr int BIAS_MAX = 2048 + GH_BN;
+    __shared__ __attribute__((aligned(16))) _Float16 wsh[RING][GH_BN * LD];
+    __shared__ __attribute__((aligned(16))) _Float16 wsl[RING][GH_BN * LD];
     __shared__ float2 red[2][GH_BM];
-    // per-wave 32x32 staging tile for the epilogue: the accumulator (lane = column, register = row) is turned into
-    // 16-byte row segments so that the logits leave as dwordx4 stores (4 per wave and tile instead of 16 dword
-    // stores -- the dword form is store-issue bound at ~2 TB/s)
-    constexpr int EPLD = 36;
-    __shared__ __attribute__((aligned(16))) float eps[8][32 * EPLD];
+    __shared__ __attribute__((aligned(16))) float bias_lds[BIAS_MAX];   // zero padded to whole tiles
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     const long m0 = (long)blockIdx.x * GH_BM;
     const int ntiles = (N + GH_BN - 1) / GH_BN;
+    auto tile_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    // ---- A fragments: x[row][16s + 8h + j], split into hi/lo halves ----
+    for (int i = tid; i < ntiles * GH_BN; i += 576) bias_lds[i] = (bias && i < N) ? bias[i] : 0.0f;
+
+    if (wave == 8) {
+        // =============================== loader wave ===============================
+        // one tile = 64 rows x PPR pieces per array = PPR chunks of 64 pieces (1 KiB) each, contiguous in LDS;
+        // columns beyond N re-read row N-1 (their products are never stored nor counted)
+        auto dma_tile = [&](int nt) {
+            const int slot = nt % RING;
+#pragma unroll
+            for (int arr = 0; arr < 2; arr++) {
+                const _Float16 *W = arr ? Wlo : Whi;
+                _Float16 *dst = arr ? wsl[slot] : wsh[slot];
+#pragma unroll
+                for (int ch = 0; ch < PPR; ch++) {
+                    const int P = 64 * ch + lane, c = P / PPR, pc = P % PPR;
+                    const int gn = min(nt * GH_BN + c, N - 1);
+                    const _Float16 *src = W + (size_t)gn * KP + 8 * (pc < PPR - 1 ? pc : 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(dst + 512 * ch), 16, 0, 0);
+                }
+            }
+        };
+        dma_tile(0);
+        if (ntiles > 1) dma_tile(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tile_barrier();                                            // (P) tiles 0 and 1 are in LDS, bias staged
+        for (int nt = 0; nt < ntiles; nt++) {
+            // slot (nt+2) % 3 held tile nt-1, which every compute wave finished before the previous barrier
+            if (nt + 2 < ntiles) dma_tile(nt + 2);
+            // tile nt+1 (requested an iteration ago) must be complete before the compute waves pass this barrier;
+            // the requests just issued may stay in flight: they are the PPR*2 youngest, loads complete in order
+            if (nt + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tile_barrier();
+        }
+        if (STATS) tile_barrier();                                 // the statistics reduction's barrier
+        return;
+    }
+
+    // =============================== compute waves ===============================
+    const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+    // ---- x fragments: x[row][16s + 8h + j], split into hi/lo halves ----
     half8 ahi[KS], alo[KS];
+    const long row = m0 + 32 * wm + r;
+    const bool rowok = row < M;
     {
-        const long row = m0 + 32 * wm + r;
-        const float *xr = x + (row < M ? row : M - 1) * ldx;
+        const float *xr = x + (rowok ? row : M - 1) * ldx;
+        // 16-byte loads, all in flight together (element-wise conditional loads serialise: one memory round trip each)
+        const bool fast = (K % 8 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+        float xv[KS][8];
+        if (fast) {
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const int k0 = 16 * s + 8 * h;
+                const float *src = xr + (k0 < K ? k0 : 0);
+                const float4 u0 = *reinterpret_cast<const float4 *>(src), u1 = *reinterpret_cast<const float4 *>(src + 4);
+                const bool ok = rowok && (k0 < K);
+                xv[s][0] = ok ? u0.x : 0.0f; xv[s][1] = ok ? u0.y : 0.0f; xv[s][2] = ok ? u0.z : 0.0f; xv[s][3] = ok ? u0.w : 0.0f;
+                xv[s][4] = ok ? u1.x : 0.0f; xv[s][5] = ok ? u1.y : 0.0f; xv[s][6] = ok ? u1.z : 0.0f; xv[s][7] = ok ? u1.w : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = 16 * s + 8 * h + j;
+                    const float v = xr[k < K ? k : 0];
+                    xv[s][j] = (rowok && k < K) ? v : 0.0f;
+                }
+            }
+        }
 #pragma unroll
         for (int s = 0; s < KS; s++) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const int k = 16 * s + 8 * h + j;
-                float v = xr[k < K ? k : 0];
-                v = (row < M && k < K) ? v : 0.0f;
-                const _Float16 hv = (_Float16)v;
+                const _Float16 hv = (_Float16)xv[s][j];
                 ahi[s][j] = hv;
-                alo[s][j] = (_Float16)(v - (float)hv);
+                alo[s][j] = (_Float16)(xv[s][j] - (float)hv);
             }
         }
     }
-    // ---- weight tile staging: 64 rows x KP halves for hi and lo, as 16-byte pieces ----
-    constexpr int PPR = KP / 8;                                // pieces per row
-    constexpr int PIECES = GH_BN * PPR;                        // per array
-    constexpr int NLD = (2 * PIECES + 511) / 512;
-    uint4 wreg[NLD];
-    int st_off[NLD], st_src[NLD];
-    bool st_lo[NLD], st_ok[NLD];
-#pragma unroll
-    for (int j = 0; j < NLD; j++) {
-        const int idx = tid + 512 * j;
-        st_ok[j] = idx < 2 * PIECES;
-        st_lo[j] = idx >= PIECES;
-        const int p = st_lo[j] ? idx - PIECES : idx;
-        const int c = p / PPR, k8 = (p % PPR) * 8;
-        st_off[j] = c * LD + k8;
-        st_src[j] = c * KP + k8;
-    }
-    auto load_tile = [&](int nt) {
-#pragma unroll
-        for (int j = 0; j < NLD; j++) {
-            const int c = st_off[j] / LD;
-            const int gn = nt * GH_BN + c;
-            const _Float16 *base = st_lo[j] ? Wlo : Whi;
-            const size_t off = (size_t)(gn < N ? nt * GH_BN : 0) * KP + (gn < N ? st_src[j] : 0);
-            uint4 v = *reinterpret_cast<const uint4 *>(base + (st_ok[j] ? off : 0));
-            if (!(st_ok[j] && gn < N)) v = make_uint4(0u, 0u, 0u, 0u);
-            wreg[j] = v;
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < NLD; j++)
-            if (st_ok[j]) *reinterpret_cast<uint4 *>(&(st_lo[j] ? wsl : wsh)[buf][st_off[j]]) = wreg[j];
-    };
-
-    float *const ywave = y + (m0 + 32 * wm) * ldy + 32 * wn;
-    const long rows_left = M - (m0 + 32 * wm);
-    float *const ep = eps[wave];
-    // read-back role of this lane: 4 passes, pass q covers rows 8q..8q+7; lane -> (row 8q + lane/8, columns 4*(lane%8)..+3)
-    const int er = lane >> 3, ec = (lane & 7) * 4;
+    // this lane's output row and the 16 columns it holds per 64-column tile: 32*wn + 8*q + 4*h + (0..3), q = 0..3
+    float *const yrow = y + (rowok ? row : 0) * ldy + 32 * wn + 4 * h;
     const bool vec_ok = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-    float rm[16], rs[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { rm[i] = -INFINITY; rs[i] = 0.0f; }
+    float rmax = -INFINITY, rsum = 0.0f;           // online softmax statistics of this lane's share of the row
 
-    load_tile(0);
-    store_tile(0);
-    if (ntiles > 1) load_tile(1);
-    __syncthreads();
-
+    tile_barrier();                                                // (P)
     for (int nt = 0; nt < ntiles; nt++) {
-        const _Float16 *th = &wsh[nt & 1][(32 * wn + r) * LD + 8 * h];
-        const _Float16 *tl = &wsl[nt & 1][(32 * wn + r) * LD + 8 * h];
+        const _Float16 *th = &wsh[nt % RING][(32 * wn + r) * LD + 8 * h];
+        const _Float16 *tl = &wsl[nt % RING][(32 * wn + r) * LD + 8 * h];
+        const int cbase = nt * GH_BN + 32 * wn + 4 * h;            // column of acc[0]; acc[4q+i] is column cbase + 8q + i
+        // accumulators start from the bias
         f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+        for (int q = 0; q < 4; q++) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(&bias_lds[cbase + 8 * q]);
+            acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+        }
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             const half8 bh = *reinterpret_cast<const half8 *>(th + 16 * s);
             const half8 bl = *reinterpret_cast<const half8 *>(tl + 16 * s);
-            // small terms first so that they are not absorbed by the large one
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[s], bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[s], bh, acc, 0, 0, 0);
+            // D[m = W column][n = x row]; small terms first so that they are not absorbed by the large one
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, alo[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ahi[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ahi[s], acc, 0, 0, 0);
         }
-        if (nt + 1 < ntiles) store_tile((nt + 1) & 1);
-        if (nt + 2 < ntiles) load_tile(nt + 2);
-        // ---- epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*h][col = r] ----
-        const int col = nt * GH_BN + 32 * wn + r;
-        const bool colok = col < N;
-        const float bv = (bias && colok) ? bias[col] : 0.0f;
-        float *const ytile = ywave + nt * GH_BN;
+        // ---- epilogue: acc[reg] = logit(row, column cbase + 8*(reg>>2) + (reg&3)) ----
+        const bool tile_full = (nt + 1) * GH_BN <= N;              // workgroup-uniform: every column of the tile exists
+        const bool full = tile_full || cbase + 27 < N;             // all 16 columns of this lane exist
+        if (tile_full && vec_ok) {
+            if (rowok) {
 #pragma unroll
-        for (int reg = 0; reg < 16; reg++) {
-            const int rloc = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const float v = acc[reg] + bv;
-            ep[rloc * EPLD + r] = v;
-            if (STATS && colok) {
-                const float e = __expf(-fabsf(v - rm[reg]));
-                rs[reg] = (v <= rm[reg]) ? rs[reg] + e : rs[reg] * e + 1.0f;
-                rm[reg] = fmaxf(rm[reg], v);
+                for (int q = 0; q < 4; q++)
+                    *reinterpret_cast<float4 *>(yrow + nt * GH_BN + 8 * q) =
+                        make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        } else if (rowok) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float *dst = yrow + nt * GH_BN + 8 * q;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (cbase + 8 * q + i < N) dst[i] = acc[4 * q + i];
             }
         }
-        // same wave wrote and reads: only the LDS counter has to drain (no barrier)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int cbase = nt * GH_BN + 32 * wn + ec;               // first of this lane's 4 columns
+        if (STATS) {
+            // tile maximum first, then one exp per element against the new running maximum
+            float tm = -INFINITY;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int rloc = 8 * q + er;
-            const float4 v4 = *reinterpret_cast<const float4 *>(&ep[rloc * EPLD + ec]);
-            if (rloc < rows_left) {
-                float *dst = ytile + (size_t)rloc * ldy + ec;
-                if (vec_ok && cbase + 3 < N) *reinterpret_cast<float4 *>(dst) = v4;
-                else {
-                    if (cbase + 0 < N) dst[0] = v4.x;
-                    if (cbase + 1 < N) dst[1] = v4.y;
-                    if (cbase + 2 < N) dst[2] = v4.z;
-                    if (cbase + 3 < N) dst[3] = v4.w;
+            for (int reg = 0; reg < 16; reg++) {
+                const bool ok = full || (cbase + 8 * (reg >> 2) + (reg & 3) < N);
+                tm = fmaxf(tm, ok ? acc[reg] : -INFINITY);
+            }
+            const float mn = fmaxf(rmax, tm);
+            if (mn > -INFINITY) {
+                float sum = (rmax == -INFINITY) ? 0.0f : rsum * __expf(rmax - mn);
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const bool ok = full || (cbase + 8 * (reg >> 2) + (reg & 3) < N);
+                    sum += ok ? __expf(acc[reg] - mn) : 0.0f;
                 }
+                rsum = sum;
+                rmax = mn;
             }
         }
-        __syncthreads();
+        tile_barrier();
     }
     if (STATS) {
-#pragma unroll
-        for (int reg = 0; reg < 16; reg++) {
-            float m = rm[reg], s = rs[reg];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                const float om = __shfl_xor(m, o), os = __shfl_xor(s, o);
-                const float mn = fmaxf(m, om);
-                const float sa = (m == -INFINITY) ? 0.0f : s * __expf(m - mn);
-                const float sb = (om == -INFINITY) ? 0.0f : os * __expf(om - mn);
-                s = sa + sb;
-                m = mn;
-            }
-            if (r == 0) red[wn][32 * wm + (reg & 3) + 8 * (reg >> 2) + 4 * h] = make_float2(m, s);
+        // combine the two column halves (lanes l and l^32 hold the same row), then the two column waves
+        {
+            const float om = __shfl_xor(rmax, 32), os = __shfl_xor(rsum, 32);
+            const float mn = fmaxf(rmax, om);
+            const float sa = (rmax == -INFINITY) ? 0.0f : rsum * __expf(rmax - mn);
+            const float sb = (om == -INFINITY) ? 0.0f : os * __expf(om - mn);
+            rsum = sa + sb;
+            rmax = mn;
         }
-        __syncthreads();
+        if (h == 0) red[wn][32 * wm + r] = make_float2(rmax, rsum);
+        tile_barrier();
         if (tid < GH_BM && m0 + tid < M) {
             const float2 p0 = red[0][tid], p1 = red[1][tid];
             const float mn = fmaxf(p0.x, p1.x);
@@ -216,7 +249,7 @@ template <int KS>
 static int launch_f16x3(const float *x, long ldx, const _Float16 *hi, const _Float16 *lo, const float *bias, float *y,
                         long ldy, long M, int K, int N, float2 *stats, hipStream_t s)
 {
-    dim3 grid((unsigned)((M + GH_BM - 1) / GH_BM)), block(512);
+    dim3 grid((unsigned)((M + GH_BM - 1) / GH_BM)), block(576);
     if (stats) hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, true>), grid, block, 0, s, x, ldx, hi, lo, bias, y, ldy, M, K, N, stats);
     else hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, false>), grid, block, 0, s, x, ldx, hi, lo, bias, y, ldy, M, K, N, stats);
     return slk_launch_status();
@@ -228,7 +261,7 @@ extern "C" int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W
 {
     if (!x || !W_hi || !W_lo || !y || M < 0 || K < 1 || N < 1 || ldx < K || ldy < N) return SLK_ERR_INVALID_ARG;
     if (M == 0) return SLK_OK;
-    if ((M + GH_BM - 1) / GH_BM > 0x7fffffffL) return SLK_ERR_UNSUPPORTED;
+    if ((M + GH_BM - 1) / GH_BM > 0x7fffffffL || N > 2048) return SLK_ERR_UNSUPPORTED;   // bias vector is staged in LDS
     const _Float16 *hi = static_cast<const _Float16 *>(W_hi), *lo = static_cast<const _Float16 *>(W_lo);
     float2 *st = reinterpret_cast<float2 *>(stats);
     hipStream_t s = slk_stream(stream);

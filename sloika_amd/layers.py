@@ -339,7 +339,7 @@ class Softmax(Layer):
         stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
         with profiler.region("softmax_gemm", 2.0 * rows * self.insize * self.size,
                              4.0 * rows * (self.insize + self.size)):
-            if self.split_f16 and self.insize <= 128:
+            if self.split_f16 and self.insize <= 128 and self.size <= 2048:
                 hi, lo = self._split_weights()
                 rc = L.slk_linear_rowstats_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(),
                                                  self.b.dev().data_ptr(), y.data_ptr(), ld, rows, self.insize,
