@@ -337,9 +337,11 @@ class Softmax(Layer):
         rows, L = T * B, _lib.lib()
         y = torch.empty((rows, ld), dtype=torch.float32, device=x.device)
         stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        use_f16 = self.split_f16 and self.insize <= 128 and self.size <= 2048
         with profiler.region("softmax_gemm", 2.0 * rows * self.insize * self.size,
-                             4.0 * rows * (self.insize + self.size)):
-            if self.split_f16 and self.insize <= 128 and self.size <= 2048:
+                             4.0 * rows * (self.insize + self.size),
+                             f16x3_flops=2.0 * rows * self.insize * self.size if use_f16 else 0.0):
+            if use_f16:
                 hi, lo = self._split_weights()
                 rc = L.slk_linear_rowstats_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(),
                                                  self.b.dev().data_ptr(), y.data_ptr(), ld, rows, self.insize,
@@ -682,7 +684,8 @@ class Gru(RNN):
         L = _lib.lib()
         n, rows = self.size, T * B
         # one persistent kernel (projection waves + recurrent waves) where an instantiation exists ...
-        with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n)) as reg:
+        with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
+                             f16x3_flops=6.0 * rows * n * self.insize) as reg:
             rc = L.slk_gru_fused_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(), self.sW.dev().data_ptr(),
                                      self.sW2.dev().data_ptr(), self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y),
                                      T, B, self.insize, n, int(reverse), activation.act_id(self.fun),

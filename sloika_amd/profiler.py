@@ -11,17 +11,18 @@ _active = None
 
 class Recorder(object):
     def __init__(self):
-        self.records = []          # (name, start_event, end_event, flops, bytes)
+        self.records = []          # (name, start_event, end_event, flops, bytes, flops executed as 3-term fp16 split)
 
     def summary(self):
-        """name -> dict(calls, ms_total, ms_avg, flops, bytes) ; call after torch.cuda.synchronize()."""
+        """name -> dict(calls, ms_total, ms_avg, flops, f16x3_flops, bytes) ; call after torch.cuda.synchronize()."""
         out = {}
-        for name, e0, e1, flops, nbytes in self.records:
-            d = out.setdefault(name, {"calls": 0, "ms_total": 0.0, "flops": 0.0, "bytes": 0.0})
+        for name, e0, e1, flops, nbytes, f16 in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms_total": 0.0, "flops": 0.0, "bytes": 0.0, "f16x3_flops": 0.0})
             d["calls"] += 1
             d["ms_total"] += e0.elapsed_time(e1)
             d["flops"] += flops
             d["bytes"] += nbytes
+            d["f16x3_flops"] += f16
         for d in out.values():
             d["ms_avg"] = d["ms_total"] / d["calls"]
         return out
@@ -49,7 +50,9 @@ class _Region(object):
 
 
 @contextlib.contextmanager
-def region(name, flops=0.0, nbytes=0.0):
+def region(name, flops=0.0, nbytes=0.0, f16x3_flops=0.0):
+    """`f16x3_flops`: the part of `flops` that the kernel evaluates as three fp16 MFMAs per product (fp32-grade split
+    arithmetic on the fp16 pipe) -- bench.py prices that part against the fp16 matrix peak, the rest against the fp32 one."""
     if _active is None:
         yield None
         return
@@ -63,4 +66,4 @@ def region(name, flops=0.0, nbytes=0.0):
     finally:
         e1.record()
         if not reg.cancelled:
-            _active.records.append((name, e0, e1, float(flops), float(nbytes)))
+            _active.records.append((name, e0, e1, float(flops), float(nbytes), float(f16x3_flops)))
