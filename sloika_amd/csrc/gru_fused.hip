@@ -157,6 +157,9 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
         // =================================================================================================
         // recurrent waves
         // =================================================================================================
+        constexpr bool OWN_FIRST = (SA == 1) && (NW % 4 == 0);
+        constexpr int NVO = (NW + 15) / 16;                  // operand registers that hold own-neuron state
+        const int rot = OWN_FIRST ? NW * wave : 0;
         const int la = lane % LPA, ga = lane / LPA;
         const bool validA = la < 2 * NW;
         const bool isR = la >= NW;
@@ -169,14 +172,22 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
         const bool rlane = lane >= NW && lane < 2 * NW;
         float wA[MA], wB[MB];
         {
+            // OWN_FIRST (one K-slice): this wave's phase-A chain runs over k in the rotated order rot, rot+1, ... so that
+            // its first NW products use the wave's own neurons, whose state needs no handshake
             const float *pa = sW + (size_t)rowA * N + ga * MA;
 #pragma unroll
-            for (int m = 0; m < MA; m++) wA[m] = validA ? pa[m] : 0.0f;
+            for (int m = 0; m < MA; m++) {
+                const int k = OWN_FIRST ? (m + rot) % N : m;
+                wA[m] = validA ? pa[k] : 0.0f;
+            }
             const float *pb = sW2 + (size_t)neuronB * N + gb * MB;
 #pragma unroll
             for (int m = 0; m < MB; m++) wB[m] = validB ? pb[m] : 0.0f;
         }
         const int addrA0 = 4 * ((blk / GA) * MA + (blk % GA)) + ci;
+        int addrA[NV];                                       // operand register v, this lane's block: k = 16*v + blk (+ rot)
+#pragma unroll
+        for (int v = 0; v < NV; v++) addrA[v] = OWN_FIRST ? 4 * ((16 * v + blk + rot) % N) + ci : addrA0 + 4 * v * GA;
         const int addrB0 = 4 * ((blk / GB) * MB + (blk % GB)) + ci;
         const float mask_zr = (validA && ga == 0) ? 1.0f : 0.0f;
         const float mask_c = zlane ? 1.0f : 0.0f;
@@ -214,18 +225,51 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
             // this wave's own neurons need no handshake (LDS keeps a wave's operations in order)
             const f32x4 hown = *reinterpret_cast<const f32x4 *>(&hprev[4 * neuronA]);
             float hp[NV];
-            for (;;) {
-                const int f = poll_issue(flags, lane);
-#pragma unroll
-                for (int v = 0; v < NV; v++) hp[v] = hprev[addrA0 + 4 * v * GA];
-                const bool ok = poll_result(f, needA);
-#pragma unroll
-                for (int v = 0; v < NV; v++) keep(hp[v]);
-                if (ok) break;
-            }
-            STAMP(1)
             f32x4 accA[4] = {a0 * mask_zr, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            mfma_chain<CBA, GA>(hp, wA, accA, std::make_integer_sequence<int, MA>{});
+            if constexpr (OWN_FIRST) {
+                // own quarter first: its operands are this wave's own (ordered) writes; the other waves' state is
+                // requested at the same time and checked after the first NW MFMAs, which hide the round trip
+                float ho[NVO];
+#pragma unroll
+                for (int v = 0; v < NVO; v++) ho[v] = hprev[addrA[v]];
+                // the request for the other waves' state goes out as late as its round trip allows (~16 MFMAs): the
+                // later the counters are sampled, the likelier every wave has published
+                constexpr int LATE = 0;           // (sampling the counters later, after NW-16 MFMAs, measured no better)
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chain_range<CBA, GA, 0>(ho, wA, accA, std::make_integer_sequence<int, LATE>{});
+                __builtin_amdgcn_sched_barrier(0);
+                int f = poll_issue(flags, lane);
+#pragma unroll
+                for (int v = NW / 16; v < NV; v++) hp[v] = hprev[addrA[v]];
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_chain_range<CBA, GA, LATE>(ho, wA, accA, std::make_integer_sequence<int, NW - LATE>{});
+                __builtin_amdgcn_sched_barrier(0);
+                bool ok = poll_result(f, needA);
+#pragma unroll
+                for (int v = NW / 16; v < NV; v++) keep(hp[v]);
+                while (!ok) {
+                    f = poll_issue(flags, lane);
+#pragma unroll
+                    for (int v = NW / 16; v < NV; v++) hp[v] = hprev[addrA[v]];
+                    ok = poll_result(f, needA);
+#pragma unroll
+                    for (int v = NW / 16; v < NV; v++) keep(hp[v]);
+                }
+                STAMP(1)
+                mfma_chain_range<CBA, GA, NW>(hp, wA, accA, std::make_integer_sequence<int, MA - NW>{});
+            } else {
+                for (;;) {
+                    const int f = poll_issue(flags, lane);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) hp[v] = hprev[addrA[v]];
+                    const bool ok = poll_result(f, needA);
+#pragma unroll
+                    for (int v = 0; v < NV; v++) keep(hp[v]);
+                    if (ok) break;
+                }
+                STAMP(1)
+                mfma_chain<CBA, GA>(hp, wA, accA, std::make_integer_sequence<int, MA>{});
+            }
             f32x4 g = sum_slices<SA>((accA[0] + accA[1]) + (accA[2] + accA[3]));
             STAMP(2)
 #pragma unroll
