@@ -255,6 +255,72 @@ __global__ void __launch_bounds__(256) conv1d_cin1_kernel(const float *__restric
     }
 }
 
+// Cin = 1, Cout a multiple of 4 (the shipped raw models: 32/64/96/128 features): the lane owns FOUR consecutive output
+// features of one position, 64 / (Cout/4) positions are computed side by side, and a row segment leaves as one 16-byte
+// store (the one-feature-per-lane kernel above issues a dword store per lane and row: store-issue bound at ~1 TB/s).
+// The 128 samples a run needs are parked in LDS (one 512-byte slot per wave); every tap is a broadcast ds_read.
+template <int WMAX, int ACT>
+__global__ void __launch_bounds__(256) conv1d_cin1_vec4_kernel(const float *__restrict__ x, long xs_t, long xs_b,
+                                                               const float *__restrict__ W, const float *__restrict__ bias,
+                                                               float *__restrict__ y, int T, int B, int Cout, int winlen,
+                                                               int stride, int pad_l, int Tout, int act, int npos_run)
+{
+    __shared__ float xs[4][128];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int FQ = Cout >> 2, PP = 64 / FQ;                        // feature quads, positions side by side
+    const int fq = lane % FQ, pp = lane / FQ;
+    const bool lane_ok = pp < PP;
+    float w[4][WMAX];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int k = 0; k < WMAX; k++) w[i][k] = k < winlen ? W[(size_t)(4 * fq + i) * winlen + k] : 0.0f;
+    }
+    float bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) bv[i] = bias ? bias[4 * fq + i] : 0.0f;
+    const unsigned runs_per_chunk = (unsigned)((Tout + npos_run - 1) / npos_run);
+    const unsigned nrun = runs_per_chunk * (unsigned)B, nwave = gridDim.x * 4u;
+    float *xw = xs[wave];
+    for (unsigned run = blockIdx.x * 4u + wave; run < nrun; run += nwave) {
+        // consecutive runs walk the batch first so that neighbouring waves write neighbouring rows of y
+        const int b = (int)(run % (unsigned)B), to0 = (int)(run / (unsigned)B) * npos_run;
+        const int t0 = to0 * stride - pad_l;                       // input sample of tap 0 of the first position
+        const float *xb = x + (size_t)b * xs_b;
+        const int ta = t0 + lane, tb2 = t0 + 64 + lane;
+        const float v0 = (ta >= 0 && ta < T) ? xb[(size_t)ta * xs_t] : 0.0f;
+        const float v1 = (tb2 >= 0 && tb2 < T) ? xb[(size_t)tb2 * xs_t] : 0.0f;
+        xw[lane] = v0;                                             // same wave writes and reads: in-order LDS, no barrier
+        xw[64 + lane] = v1;
+        const int npos = min(npos_run, Tout - to0);
+        for (int j0 = 0; j0 < npos; j0 += PP) {
+            const int j = j0 + pp;
+            const float *xp = xw + (lane_ok && j < npos ? j : 0) * stride;
+            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < WMAX; k++) {
+                if (k < winlen) {
+                    const float xv = xp[k];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) s[i] = fmaf(xv, w[i][k], s[i]);
+                }
+            }
+            // taps first, bias last, as conv.py:107-110 (same order as the one-feature-per-lane kernel)
+            if (lane_ok && j < npos) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) s[i] += bv[i];
+                float4 o;
+                o.x = ACT >= 0 ? slk_act_t<ACT>(s[0]) : slk_act(act, s[0]);
+                o.y = ACT >= 0 ? slk_act_t<ACT>(s[1]) : slk_act(act, s[1]);
+                o.z = ACT >= 0 ? slk_act_t<ACT>(s[2]) : slk_act(act, s[2]);
+                o.w = ACT >= 0 ? slk_act_t<ACT>(s[3]) : slk_act(act, s[3]);
+                *reinterpret_cast<float4 *>(&y[((size_t)(to0 + j) * B + b) * Cout + 4 * fq]) = o;
+            }
+        }
+    }
+}
+
 extern "C" int slk_conv1d_out_len(int T, int winlen, int stride, int pad_l, int pad_r)
 {
     if (winlen < 1 || stride < 1) return 0;
@@ -277,6 +343,22 @@ extern "C" int slk_conv1d_f32(const float *x, long x_t_stride, long x_b_stride, 
         int npos_run = (128 - winlen) / stride + 1;               // output steps covered by 128 loaded samples
         size_t nrun = (size_t)((Tout + npos_run - 1) / npos_run) * B, blocks = (nrun + 3) / 4;
         if (blocks > 256 * 16) blocks = 256 * 16;
+        if (Cout % 4 == 0 && Cout <= 256 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+            const dim3 grid((unsigned)blocks), block(256);
+            hipStream_t st = slk_stream(stream);
+#define CONV_VEC4(A)                                                                                                    \
+    hipLaunchKernelGGL((conv1d_cin1_vec4_kernel<16, A>), grid, block, 0, st, x, x_t_stride, x_b_stride, W, bias, y, T, B, \
+                       Cout, winlen, stride, pad_l, Tout, act, npos_run)
+            switch (act) {
+            case SLK_ACT_TANH: CONV_VEC4(SLK_ACT_TANH); break;
+            case SLK_ACT_ELU: CONV_VEC4(SLK_ACT_ELU); break;
+            case SLK_ACT_RELU: CONV_VEC4(SLK_ACT_RELU); break;
+            case SLK_ACT_LINEAR: CONV_VEC4(SLK_ACT_LINEAR); break;
+            default: CONV_VEC4(-1); break;
+            }
+#undef CONV_VEC4
+            return slk_launch_status();
+        }
         hipLaunchKernelGGL(conv1d_cin1_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, slk_stream(stream), x, x_t_stride,
                            x_b_stride, W, bias, y, T, B, Cout, winlen, stride, pad_l, Tout, act, npos_run);
         return slk_launch_status();
