@@ -608,24 +608,29 @@ __global__ void __launch_bounds__(256) viterbi_forward4_wave_kernel(const float 
 }
 
 // ------------------------------------------------------------------------------------------------------
-// backtrace: stage time-blocks of the byte traceback in LDS, one lane walks them; emit right-aligned, then
-// the whole workgroup shifts the path left and pads with -1.
+// backtrace: one lane walks the byte traceback from the last step to the first (decode.py:84-91).  The walk is a chain
+// of dependent 1-byte LDS reads (~120 cycles per step), so everything else must stay out of its way: waves 1-3 stream
+// the traceback into a ring of VBT_RING LDS buffers of VBT_BLOCK bytes by LDS-DMA (global_load_lds), VBT_RING-1 blocks
+// ahead of the walker, which hides the memory latency of a block behind the walk of the previous ones (the earlier
+// 2-buffer version copied through registers and made the walker wait for a memory round trip per block).  Those waves
+// issue loads only -- exactly VBT_BLOCK/1024/3 per wave and block -- so vmcnt(n) tells them which block has landed; the
+// walker's wave owns the path stores.  The path is emitted right-aligned, then shifted left and padded with -1.
 // ------------------------------------------------------------------------------------------------------
+#define VBT_RING 3
+#define VBT_BLOCK 12288            /* bytes; a multiple of 3 KiB (three stager waves) and of every 4^k k-mer count <= 4096 */
 template <int NB>
 __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *__restrict__ tb,
                                                                 const int32_t *__restrict__ best, int T, int nkmer,
-                                                                int tblk, int32_t *__restrict__ path_out,
+                                                                int tblk, int dma, int32_t *__restrict__ path_out,
                                                                 int32_t *__restrict__ len_out)
 {
     constexpr int NB2 = NB * NB;
-    // two staging buffers of tblk*nkmer bytes each + 2 ints: while lane 0 walks block i in LDS, the other 255 threads
-    // fetch block i-1 (earlier in time) into the other buffer
-    extern __shared__ __attribute__((aligned(16))) uint8_t blk[];
+    constexpr int PER_WAVE = VBT_BLOCK / 1024 / 3;
+    __shared__ __attribute__((aligned(16))) uint8_t blk[VBT_RING * VBT_BLOCK];
+    __shared__ int sh_cur, sh_pos;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nrem1 = nkmer / NB, nrem2 = nkmer / NB2;
-    const size_t bufbytes = ((size_t)tblk * nkmer + 15) & ~(size_t)15;
-    int &sh_cur = reinterpret_cast<int *>(blk + 2 * bufbytes)[0];
-    int &sh_pos = reinterpret_cast<int *>(blk + 2 * bufbytes)[1];
     const uint8_t *tbb = tb + (size_t)b * T * nkmer;
     int32_t *path = path_out + (size_t)b * T;
     if (tid == 0) {
@@ -638,42 +643,68 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
         t1 = T - i * tblk;
         t0 = max(1, t1 - tblk);
     };
-    auto stage = [&](int i, int first_thread) {
+    auto walk = [&](int i, const uint8_t *rows) {             // lane 0 of wave 0
         int t0, t1;
         bounds(i, t0, t1);
-        if (t1 <= 1) return;
-        const size_t nbytes = (size_t)(t1 - t0) * nkmer;
-        const uint8_t *src = tbb + (size_t)t0 * nkmer;
-        uint8_t *dst = blk + (i & 1) * bufbytes;
-        const int nthr = nt - first_thread, me = tid - first_thread;
-        if (me < 0) return;
-        if ((nbytes & 15) == 0 && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
-            const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-            uint4 *d4 = reinterpret_cast<uint4 *>(dst);
-            for (size_t k = me; k < nbytes / 16; k += nthr) d4[k] = s4[k];
-        } else {
-            for (size_t k = me; k < nbytes; k += nthr) dst[k] = src[k];
+        // one lane walks: keeping the state in scalar registers (readfirstlane) moves the index arithmetic of this
+        // dependent chain to the scalar unit
+        int cur = __builtin_amdgcn_readfirstlane(sh_cur), pos = __builtin_amdgcn_readfirstlane(sh_pos);
+        for (int t = t1 - 1; t >= t0; t--) {
+            const int code = __builtin_amdgcn_readfirstlane((int)rows[(t - t0) * nkmer + cur]);
+            if (code != VIT_STAY) {
+                cur = code < NB ? code * nrem1 + cur / NB : (code - NB) * nrem2 + cur / NB2;
+                path[--pos] = cur;                             // decode.py:88-90
+            }
         }
+        sh_cur = cur;
+        sh_pos = pos;
     };
-    const int nblocks = (T - 1 + tblk - 1) / tblk;          // rows 1..T-1
-    stage(0, 0);
-    __syncthreads();
-    for (int i = 0; i < nblocks; i++) {
-        if (i + 1 < nblocks) stage(i + 1, 64);              // waves 1-3 prefetch; wave 0 walks
-        if (tid == 0) {
+    const int nblocks = (T - 1 + tblk - 1) / tblk;           // rows 1..T-1
+    if (dma) {
+        // block i -> ring slot i % VBT_RING; PER_WAVE 1-KiB instructions per stager wave, pieces past the block's end
+        // re-read its first bytes into the unused tail of the slot
+        auto request = [&](int i) {
             int t0, t1;
             bounds(i, t0, t1);
-            const uint8_t *cur_blk = blk + (i & 1) * bufbytes;
-            int cur = sh_cur, pos = sh_pos;
-            for (int t = t1 - 1; t >= t0; t--) {
-                int code = cur_blk[(size_t)(t - t0) * nkmer + cur];
-                if (code != VIT_STAY) {
-                    cur = code < NB ? code * nrem1 + cur / NB : (code - NB) * nrem2 + cur / NB2;
-                    path[--pos] = cur;                       // decode.py:88-90
-                }
+            const int nbytes = (t1 - t0) * nkmer;
+            const uint8_t *src = tbb + (size_t)t0 * nkmer;
+            uint8_t *dst = blk + (i % VBT_RING) * VBT_BLOCK;
+#pragma unroll
+            for (int k = 0; k < PER_WAVE; k++) {
+                const int piece = k * 3 + (wave - 1);
+                const int off = piece * 1024 + 16 * lane;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (off + 16 <= nbytes ? off : 0)),
+                                                 (__attribute__((address_space(3))) void *)(dst + piece * 1024), 16, 0, 0);
             }
-            sh_cur = cur;
-            sh_pos = pos;
+        };
+        if (wave > 0)
+            for (int i = 0; i < VBT_RING - 1 && i < nblocks; i++) request(i);
+        for (int i = 0; i < nblocks; i++) {
+            if (wave > 0) {
+                // block i must have landed before the barrier; the (up to RING-2) younger requests stay in flight
+                const int younger = min(VBT_RING - 2, nblocks - 1 - i);
+                if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_WAVE) : "memory");
+                else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // LDS-only barrier (block i is in LDS; the walker is done with block i-1): __syncthreads() would also make
+            // the walker's wave wait for its path stores to be acknowledged, a memory round trip per block
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // slot (i + RING-1) % RING = slot of block i-1: free now
+            if (wave > 0 && i + VBT_RING - 1 < nblocks) request(i + VBT_RING - 1);
+            if (tid == 0) walk(i, blk + (i % VBT_RING) * VBT_BLOCK);
+        }
+        __syncthreads();
+    } else {
+        // generic staging (k-mer counts that do not divide the block size, unaligned buffers): one block at a time
+        for (int i = 0; i < nblocks; i++) {
+            int t0, t1;
+            bounds(i, t0, t1);
+            __syncthreads();
+            const int nbytes = (t1 - t0) * nkmer;
+            for (int k = tid; k < nbytes; k += nt) blk[k] = tbb[(size_t)t0 * nkmer + k];
+            __syncthreads();
+            if (tid == 0) walk(i, blk);
         }
         __syncthreads();
     }
@@ -751,11 +782,12 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
                            skip_pen, mode, min_prob, one_m, tb, best, score_out);
     int rc = slk_launch_status();
     if (rc != SLK_OK) return rc;
-    int tblk = (24 * 1024) / nkmer;                          // 2 x 24 KB buffers: 3 workgroups per CU
-    if (tblk < 1) tblk = 1;
+    int tblk = VBT_BLOCK / nkmer;                            // rows per staged block
+    if (tblk < 1) return SLK_ERR_UNSUPPORTED;
+    const int dma = (VBT_BLOCK % nkmer == 0) && (nkmer % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
     if (tblk > T) tblk = T;
-    hipLaunchKernelGGL((viterbi_backtrace_kernel<NB>), dim3(B), dim3(256),
-                       2 * (((size_t)tblk * nkmer + 15) & ~(size_t)15) + 16, s, tb, best, T, nkmer, tblk, path_out, len_out);
+    hipLaunchKernelGGL((viterbi_backtrace_kernel<NB>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+                       len_out);
     return slk_launch_status();
 }
 
