@@ -6,8 +6,8 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------------
-// median / MAD.  One workgroup per chunk; the chunk is sorted in LDS with a bitonic network (padding
-// with +inf up to a power of two), twice: once for the median, once for the median absolute deviation.
+// median / MAD.  One workgroup per chunk; the chunk is sorted ONCE in LDS with a bitonic network (padding
+// with +inf up to a power of two); the median absolute deviation comes from the same sorted array.
 // numpy semantics: even count -> (a + b) / 2 in float32; mad = float32(1.4826) * median(|x - med|);
 // out = (x - med) / mad with IEEE division (hipcc's default correctly rounded fp32 divide).
 // ------------------------------------------------------------------------------------------------------
@@ -46,11 +46,32 @@ __global__ void __launch_bounds__(512) med_mad_kernel(const float *__restrict__ 
     __syncthreads();
     bitonic_sort_lds(srt, npow2, tid, nt);
     const float med = median_sorted(srt, chunk_len);
+    // No second sort: |x - med| over the sorted samples is two monotone runs (the samples below the median, walked
+    // downwards, and those above it, walked upwards; float32 rounding is monotone), so the order statistics of the
+    // deviations are order statistics of the merge of two sorted sequences -- a binary search.
+    __shared__ float mad_sh;
+    if (tid == 0) {
+        const int n = chunk_len, p = n >> 1, nA = p, nB = n - p;        // A[j] = |s[p-1-j] - med|, B[j] = |s[p+j] - med|
+        auto A = [&](int j) { return fabsf(srt[p - 1 - j] - med); };
+        auto Bv = [&](int j) { return fabsf(srt[p + j] - med); };
+        auto kth = [&](int r) {                                          // value of rank r (0-based) in the merge
+            int lo = max(0, r + 1 - nB), hi = min(r + 1, nA);
+            while (lo < hi) {
+                const int a = (lo + hi) >> 1, b = r + 1 - a;             // a < hi <= nA, b >= 1
+                if (A(a) < Bv(b - 1)) lo = a + 1;
+                else hi = a;
+            }
+            const int a = lo, b = r + 1 - a;
+            float v = -INFINITY;
+            if (a > 0) v = A(a - 1);
+            if (b > 0) v = fmaxf(v, Bv(b - 1));
+            return v;
+        };
+        const float dm = (n & 1) ? kth(n >> 1) : (kth((n >> 1) - 1) + kth(n >> 1)) / 2.0f;
+        mad_sh = 1.4826f * dm;
+    }
     __syncthreads();
-    for (int i = tid; i < npow2; i += nt) srt[i] = i < chunk_len ? fabsf(sig[i] - med) : INFINITY;
-    __syncthreads();
-    bitonic_sort_lds(srt, npow2, tid, nt);
-    const float mad = 1.4826f * median_sorted(srt, chunk_len);
+    const float mad = mad_sh;
     float *o = out + (size_t)c * out_chunk_stride;
     for (int i = tid; i < chunk_len; i += nt) o[(size_t)i * out_sample_stride] = (sig[i] - med) / mad;
     if (tid == 0) {
