@@ -488,6 +488,20 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
     }
 }
 
+// One workgroup per CU: the kernel is a latency-bound serial chain, and two of these workgroups on one CU (possible for
+// the small shapes, e.g. when the two directions of a birnn run on separate streams) slow each other down while other
+// CUs idle.  Asking for enough dynamic LDS that two cannot share a CU makes the dispatcher spread them.
+template <typename K>
+static size_t exclusive_cu_lds(K kernel)
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) != hipSuccess) return 0;
+    const size_t half_cu = 80 * 1024 + 512;                         // 160 KB of LDS per CU
+    const size_t dyn = attr.sharedSizeBytes >= half_cu ? 0 : half_cu - attr.sharedSizeBytes;
+    if (dyn) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    return dyn;
+}
+
 template <int I, int N>
 static int launch_fused(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
                         float *y, long ldy, int T, int B, int reverse, hipStream_t s)
@@ -500,8 +514,9 @@ static int launch_fused(const float *x, long ldx, const float *iW, const float *
             return slk_launch_status();
         }
     }
-    hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>), dim3((B + 3) / 4), dim3(512), 0, s, x,
-                       ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, 0);
+    static const size_t dyn_lds = exclusive_cu_lds(gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>);
+    hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>), dim3((B + 3) / 4), dim3(512), dyn_lds, s,
+                       x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, 0);
     return slk_launch_status();
 }
 

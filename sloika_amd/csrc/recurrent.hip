@@ -365,11 +365,18 @@ extern "C" int slk_gru_f32(const float *x, long ldx, const float *iW, const floa
     return slk_gru_recurrent_f32(vI, sW, sW2, y, ldy, T, B, n, reverse, act, gate_act, stream);
 }
 
+int slk_lstm_mfma_dispatch(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B, int n,
+                           int reverse, int act, int gate_act, hipStream_t s);          // lstm_mfma.hip
+
 extern "C" int slk_lstm_recurrent_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T,
                                       int B, int n, int reverse, int act, int gate_act, slk_stream_t stream)
 {
     if (!vW || !sW || !out || T < 1 || B < 1 || n < 1 || ldo < n || !slk_act_valid(act) || !slk_act_valid(gate_act))
         return SLK_ERR_INVALID_ARG;
+    {
+        const int rc = slk_lstm_mfma_dispatch(vW, sW, p, out, ldo, T, B, n, reverse, act, gate_act, slk_stream(stream));
+        if (rc != SLK_ERR_UNSUPPORTED) return rc;               // lstm_mfma.hip: sizes 16..64, tanh / sigmoid
+    }
     size_t lds = sizeof(float) * 6 * (size_t)n;
     if (lds > 64 * 1024) return SLK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(lstm_generic_kernel, dim3(B), dim3(256), lds, slk_stream(stream), vW, sW, p, out, ldo, T, B, n,

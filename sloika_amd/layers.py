@@ -790,9 +790,30 @@ class Parallel(Layer):
         if all(_keeps_time(layer) for layer in self.layers):
             # every sub-layer writes its slice of the concatenated tensor directly (row stride = self.size)
             outs = out if out is not None else torch.empty((T, B, self.size), dtype=torch.float32, device=x.device)
+            streams = self._side_streams(x, B)
             off = 0
-            for layer in self.layers:
-                layer._forward(x, outs[:, :, off:off + layer.size], reverse)
+            if streams is None:
+                for layer in self.layers:
+                    layer._forward(x, outs[:, :, off:off + layer.size], reverse)
+                    off += layer.size
+                return outs
+            # The sub-layers are independent (same input, disjoint output slices).  A recurrent layer occupies one
+            # workgroup per 4 chunks for the whole scan, so at small batches most CUs idle: run the directions of a
+            # birnn side by side on their own HIP streams (the reference runs them one after the other inside one
+            # Theano function, layers.py:1486-1487).
+            main = torch.cuda.current_stream(x.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for i, layer in enumerate(self.layers):
+                st = main if i == 0 else streams[i - 1]
+                if st is not main:
+                    st.wait_event(ready)
+                with torch.cuda.stream(st):
+                    layer._forward(x, outs[:, :, off:off + layer.size], reverse)
+                if st is not main:
+                    done = torch.cuda.Event()
+                    done.record(st)
+                    main.wait_event(done)
                 off += layer.size
             return outs
         cat = torch.cat([layer._forward(x, None, reverse) for layer in self.layers], dim=2)
@@ -800,6 +821,26 @@ class Parallel(Layer):
             out.copy_(cat)
             return out
         return cat
+
+    _streams_cache = {}
+
+    def _side_streams(self, x, B):
+        """HIP streams for sub-layers 1.. when running them concurrently pays: all sub-layers recurrent and their
+        workgroups (one per 4 chunks each) fit the device's CUs together."""
+        import torch
+        if len(self.layers) < 2:
+            return None
+        for layer in self.layers:
+            inner = layer.layer if isinstance(layer, Reverse) else layer
+            if not isinstance(inner, (Gru, Lstm)):
+                return None
+        ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+        if ((B + 3) // 4) * len(self.layers) > ncu:
+            return None
+        key = (x.device.index, len(self.layers))
+        if key not in Parallel._streams_cache:
+            Parallel._streams_cache[key] = [torch.cuda.Stream(device=x.device) for _ in range(len(self.layers) - 1)]
+        return Parallel._streams_cache[key]
 
     def spec(self):
         return {"type": "parallel", "sublayers": [l.spec() for l in self.layers]}

@@ -87,13 +87,16 @@ def test_gru_strided_output_slice(oracle):
     np.testing.assert_allclose(y, oracle.run_network(net.spec(), x), atol=TOL)
 
 
-@pytest.mark.parametrize("I,n,bias,peep", [(12, 64, True, True), (5, 16, False, False), (64, 96, True, False), (3, 7, True, True)])
+@pytest.mark.parametrize("I,n,bias,peep,T,B", [(12, 64, True, True, 20, 3), (5, 16, False, False, 20, 3),
+                                               (64, 96, True, False, 20, 3), (3, 7, True, True, 20, 3),
+                                               (12, 64, True, True, 61, 9), (8, 32, True, True, 33, 5),
+                                               (9, 48, False, True, 1, 1), (64, 64, True, False, 2, 4)])
 @pytest.mark.parametrize("reverse", [False, True])
-def test_lstm_vs_oracle(oracle, I, n, bias, peep, reverse):
+def test_lstm_vs_oracle(oracle, I, n, bias, peep, T, B, reverse):
+    """Sizes 16/32/48/64 take the MFMA kernel (csrc/lstm_mfma.hip), the others the portable one."""
     need_gpu()
     from sloika_amd import layers
     rs = np.random.RandomState(I * 10 + n)
-    T, B = 20, 3
     x = rs.normal(size=(T, B, I)).astype(np.float32)
     l = layers.Lstm(I, n, has_bias=bias, has_peep=peep)
     l.iW.set_value((rs.normal(size=(4 * n, I)) / np.sqrt(I + n)).astype(np.float32))
