@@ -573,12 +573,18 @@ class Lstm(RNN):
         T, B, _ = x.shape
         y = _alloc_out(x, T, B, self.size, out)
         L = _lib.lib()
-        nbytes = L.slk_lstm_workspace_bytes(T, B, self.size)
+        n, rows = self.size, T * B
+        nbytes = L.slk_lstm_workspace_bytes(T, B, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        rc = L.slk_lstm_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(), self.sW.dev().data_ptr(),
-                            self.b.dev().data_ptr(), self.p.dev().data_ptr(), y.data_ptr(), _row_stride(y), T, B,
-                            self.insize, self.size, int(reverse), activation.act_id(self.fun),
-                            activation.act_id(self.gatefun), ws.data_ptr(), nbytes, _stream())
+        # the two halves of slk_lstm_f32, timed separately: projection GEMM into the workspace, then the recurrence
+        with profiler.region("lstm_input_gemm", 2.0 * rows * self.insize * 4 * n, 4.0 * rows * (self.insize + 4 * n)):
+            rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(), self.b.dev().data_ptr(),
+                                         ws.data_ptr(), 4 * n, rows, self.insize, 4 * n, 0, _stream())
+        _lib.check(rc, "Lstm")
+        with profiler.region("lstm_recurrent", 8.0 * rows * n * n, 4.0 * rows * 5 * n):
+            rc = L.slk_lstm_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(), y.data_ptr(),
+                                          _row_stride(y), T, B, n, int(reverse), activation.act_id(self.fun),
+                                          activation.act_id(self.gatefun), _stream())
         _lib.check(rc, "Lstm")
         return y
 
