@@ -255,7 +255,7 @@ static int launch_f16x3(const float *x, long ldx, const _Float16 *hi, const _Flo
     return slk_launch_status();
 }
 
-// logits = x.W^T + b from pre-split weights (slk_split_f16x2_f32), optional softmax row statistics.  K <= 128.
+// logits = x.W^T + b from pre-split weights (slk_split_f16x2_f32), optional softmax row statistics.  K <= 144, N <= 2048.
 extern "C" int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias,
                                          float *y, long ldy, long M, int K, int N, float *stats, slk_stream_t stream)
 {
@@ -274,6 +274,7 @@ extern "C" int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W
     case 6: return launch_f16x3<6>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
     case 7: return launch_f16x3<7>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
     case 8: return launch_f16x3<8>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
+    case 9: return launch_f16x3<9>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
     default: return SLK_ERR_UNSUPPORTED;
     }
 }

@@ -80,6 +80,45 @@ def _stream():
     return D.stream_ptr()
 
 
+#: Time-parallel projections (softmax, and the input projections of recurrent layers that have no fused kernel) run on the
+#: FP16 matrix pipe as a 3-term split of every float32 operand (csrc/gemm_rows_f16x3.hip: float32 accumulation, error a few
+#: float32 ulps, ~5x the fp32-MFMA rate).  SLOIKA_AMD_EXACT_F32=1 selects plain fp32 MFMA everywhere.
+SPLIT_F16 = os.environ.get("SLOIKA_AMD_EXACT_F32", "0") != "1"
+
+
+def _split_f16_cached(owner, attr, param, rows, k):
+    """fp16 hi/lo parts of the [rows][k] weight `param` on the device, re-made whenever the parameter changes."""
+    import torch
+    wd = param.dev()
+    cache = owner.__dict__.get(attr)
+    if cache is None or cache[0] is not wd:
+        kp = (k + 15) // 16 * 16
+        hi = torch.empty((rows, kp), dtype=torch.float16, device=wd.device)
+        lo = torch.empty((rows, kp), dtype=torch.float16, device=wd.device)
+        _lib.check(_lib.lib().slk_split_f16x2_f32(wd.data_ptr(), rows, k, hi.data_ptr(), lo.data_ptr(), _stream()),
+                   "split_f16")
+        owner.__dict__[attr] = cache = (wd, hi, lo)
+    return cache[1], cache[2]
+
+
+def _projection(owner, x, W, b, ws_ptr, rows, k, n_out, stage, name):
+    """ws[rows][n_out] = x.W^T + b for a recurrent layer's input projection: fp16x3 kernel where it applies
+    (k <= 144, n_out <= 2048), else the fp32 MFMA GEMM."""
+    L = _lib.lib()
+    use_f16 = SPLIT_F16 and k <= 144 and n_out <= 2048
+    with profiler.region(stage, 2.0 * rows * k * n_out, 4.0 * rows * (k + n_out),
+                         f16x3_flops=2.0 * rows * k * n_out if use_f16 else 0.0):
+        rc = _lib.SLK_ERR_UNSUPPORTED
+        if use_f16:
+            hi, lo = _split_f16_cached(owner, "_iw16", W, n_out, k)
+            rc = L.slk_linear_rowstats_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(), b.dev().data_ptr(),
+                                             ws_ptr, n_out, rows, k, n_out, None, _stream())
+        if rc == _lib.SLK_ERR_UNSUPPORTED:
+            rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), W.dev().data_ptr(), b.dev().data_ptr(), ws_ptr,
+                                         n_out, rows, k, n_out, 0, _stream())
+    _lib.check(rc, name)
+
+
 def _check_input(x, insize):
     import torch
     if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda:
@@ -568,6 +607,11 @@ class Lstm(RNN):
             params += [self.p]
         return params
 
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_iw16", None)         # device cache: never pickled
+        return d
+
     def _forward(self, x, out, reverse):
         import torch
         T, B, _ = x.shape
@@ -577,10 +621,7 @@ class Lstm(RNN):
         nbytes = L.slk_lstm_workspace_bytes(T, B, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         # the two halves of slk_lstm_f32, timed separately: projection GEMM into the workspace, then the recurrence
-        with profiler.region("lstm_input_gemm", 2.0 * rows * self.insize * 4 * n, 4.0 * rows * (self.insize + 4 * n)):
-            rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(), self.b.dev().data_ptr(),
-                                         ws.data_ptr(), 4 * n, rows, self.insize, 4 * n, 0, _stream())
-        _lib.check(rc, "Lstm")
+        _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 4 * n, "lstm_input_gemm", "Lstm")
         with profiler.region("lstm_recurrent", 8.0 * rows * n * n, 4.0 * rows * 5 * n):
             rc = L.slk_lstm_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(), y.data_ptr(),
                                           _row_stride(y), T, B, n, int(reverse), activation.act_id(self.fun),
@@ -666,6 +707,7 @@ class Gru(RNN):
     def __getstate__(self):
         d = dict(self.__dict__)
         d.pop("_pad_cache", None)
+        d.pop("_iw16", None)         # device caches: never pickled
         return d
 
     def _forward(self, x, out, reverse):
@@ -704,11 +746,7 @@ class Gru(RNN):
         # ... otherwise projection GEMM into a workspace, then the recurrence kernel
         nbytes = L.slk_gru_workspace_bytes(T, B, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        with profiler.region("gru_input_gemm", 2.0 * rows * self.insize * 3 * n, 4.0 * rows * (self.insize + 3 * n)):
-            rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
-                                         self.b.dev().data_ptr(), ws.data_ptr(), 3 * n, rows, self.insize, 3 * n, 0,
-                                         _stream())
-        _lib.check(rc, "Gru")
+        _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 3 * n, "gru_input_gemm", "Gru")
         with profiler.region("gru_recurrent", 6.0 * rows * n * n, 4.0 * rows * 4 * n):
             rc = L.slk_gru_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
                                          y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
