@@ -55,6 +55,7 @@ PROTOTYPES = {
     "slk_slip_update_f32": (_i, [_vp, _i, _f, _vp, _vp, _vp]),
     "slk_map_to_sequence_workspace_bytes": (_sz, [_i, _i]),
     "slk_map_to_sequence_f32": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "slk_map_to_sequence_batch_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "slk_activation_f32": (_i, [_vp, _vp, _sz, _i, _vp]),
 }
 

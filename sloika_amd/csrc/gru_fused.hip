@@ -47,20 +47,6 @@ extern "C" int slk_debug_read_clock(unsigned long long *host_out)
                                                                                                                : SLK_ERR_LAUNCH;
 }
 
-constexpr int pow2_slices(int outputs, int cap)
-{
-    // largest power of two S <= cap with S * outputs <= 64 lanes
-    int s = 1;
-    while (s * 2 <= cap && s * 2 * outputs <= 64) s *= 2;
-    return s;
-}
-
-// progress counters (LDS ints).  flags[0..3]  fA[w]   : rec wave w finished phase A of steps < value (rh published)
-//                                 flags[4..7]  fB[w]   : rec wave w finished steps < value (h published)
-//                                 flags[8..11] vready[p]: proj wave p published vI rows of steps < value
-//                                 flags[12..15] flushed[p]: proj wave p copied state blocks < value to h_out
-//                                 xflags[0..3] xready[p]: proj wave p's share of x blocks < value has landed
-//                                 xflags[4..7] xdone[p] : proj wave p finished reading x blocks < value
 typedef __attribute__((address_space(3))) int lds_int_t;
 
 __device__ __forceinline__ void publish(int *flags, int idx, int value, int lane)
@@ -498,7 +484,9 @@ static size_t exclusive_cu_lds(K kernel)
     if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) != hipSuccess) return 0;
     const size_t half_cu = 80 * 1024 + 512;                         // 160 KB of LDS per CU
     const size_t dyn = attr.sharedSizeBytes >= half_cu ? 0 : half_cu - attr.sharedSizeBytes;
-    if (dyn) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (dyn && hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)dyn) != hipSuccess)
+        return 0;
     return dyn;
 }
 

@@ -53,15 +53,13 @@ extern "C" int slk_slip_update_f32(const float *x, int n, float slip, float *fro
     return slk_launch_status();
 }
 
-// One workgroup per call.  LDS: pscore, cscore, fs (float) and fp (int) of length npos.
-__global__ void __launch_bounds__(256) map_to_sequence_kernel(const float *__restrict__ ltrans, int nev, int nst,
-                                                              const int32_t *__restrict__ seq, int npos, float slip,
-                                                              const double *__restrict__ prior_initial,
-                                                              const double *__restrict__ prior_final,
-                                                              int32_t *__restrict__ vmat, float *__restrict__ score_out,
-                                                              int32_t *__restrict__ path_out)
+// One workgroup per read.  LDS: pscore, cscore, fs (float), fp and the sequence (int), each of length npos.
+__device__ __forceinline__ void map_to_sequence_body(float *sm, const float *__restrict__ ltrans, int nev, int nst,
+                                                     const int32_t *__restrict__ seq, int npos, float slip,
+                                                     const double *__restrict__ prior_initial,
+                                                     const double *__restrict__ prior_final, int32_t *__restrict__ vmat,
+                                                     float *__restrict__ score_out, int32_t *__restrict__ path_out)
 {
-    extern __shared__ float sm[];
     float *pscore = sm, *cscore = sm + npos, *fs = sm + 2 * npos;
     int *fp = reinterpret_cast<int *>(sm + 3 * npos);
     int *sq = fp + npos;
@@ -116,6 +114,43 @@ __global__ void __launch_bounds__(256) map_to_sequence_kernel(const float *__res
     }
 }
 
+__global__ void __launch_bounds__(256) map_to_sequence_kernel(const float *__restrict__ ltrans, int nev, int nst,
+                                                              const int32_t *__restrict__ seq, int npos, float slip,
+                                                              const double *__restrict__ prior_initial,
+                                                              const double *__restrict__ prior_final,
+                                                              int32_t *__restrict__ vmat, float *__restrict__ score_out,
+                                                              int32_t *__restrict__ path_out)
+{
+    extern __shared__ float sm[];
+    map_to_sequence_body(sm, ltrans, nev, nst, seq, npos, slip, prior_initial, prior_final, vmat, score_out, path_out);
+}
+
+// Batched remap (the reference maps reads one at a time, bin/chunkify.py remap -> transducer.map_to_sequence): reads of
+// different lengths are concatenated; read b owns events ev_off[b]..ev_off[b+1] of ltrans / path_out, positions
+// pos_off[b]..pos_off[b+1] of seq and the priors, and ws_off[b].. of the traceback workspace.  One workgroup per read.
+__global__ void __launch_bounds__(256) map_to_sequence_batch_kernel(const float *__restrict__ ltrans, int nst,
+                                                                    const int64_t *__restrict__ ev_off,
+                                                                    const int32_t *__restrict__ seq,
+                                                                    const int64_t *__restrict__ pos_off, float slip,
+                                                                    const double *__restrict__ prior_initial,
+                                                                    const double *__restrict__ prior_final,
+                                                                    int32_t *__restrict__ vmat,
+                                                                    const int64_t *__restrict__ ws_off,
+                                                                    float *__restrict__ score_out,
+                                                                    int32_t *__restrict__ path_out)
+{
+    extern __shared__ float sm[];
+    const int b = blockIdx.x;
+    const int64_t e0 = ev_off[b], p0 = pos_off[b];
+    const int nev = (int)(ev_off[b + 1] - e0), npos = (int)(pos_off[b + 1] - p0);
+    if (nev < 1 || npos < 3) {                       // empty read: nothing to map (score -inf, no path)
+        if (threadIdx.x == 0) score_out[b] = -INFINITY;
+        return;
+    }
+    map_to_sequence_body(sm, ltrans + e0 * nst, nev, nst, seq + p0, npos, slip, prior_initial ? prior_initial + p0 : nullptr,
+                         prior_final ? prior_final + p0 : nullptr, vmat + ws_off[b], score_out + b, path_out + e0);
+}
+
 extern "C" size_t slk_map_to_sequence_workspace_bytes(int nev, int npos)
 {
     if (nev < 1 || npos < 1) return 0;
@@ -132,5 +167,22 @@ extern "C" int slk_map_to_sequence_f32(const float *ltrans, int nev, int nst, co
     if (lds > 64 * 1024) return SLK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(map_to_sequence_kernel, dim3(1), dim3(256), lds, slk_stream(stream), ltrans, nev, nst, seq, npos,
                        slip, prior_initial, prior_final, static_cast<int32_t *>(workspace), score_out, path_out);
+    return slk_launch_status();
+}
+
+extern "C" int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *ev_off, const int32_t *seq,
+                                             const int64_t *pos_off, int nread, int max_npos, float slip,
+                                             const double *prior_initial, const double *prior_final, void *workspace,
+                                             const int64_t *ws_off, float *score_out, int32_t *path_out,
+                                             slk_stream_t stream)
+{
+    if (!ltrans || !ev_off || !seq || !pos_off || !workspace || !ws_off || !score_out || !path_out || nst < 1 || nread < 1 ||
+        max_npos < 3)
+        return SLK_ERR_INVALID_ARG;
+    size_t lds = (size_t)max_npos * 5 * sizeof(float);
+    if (lds > 64 * 1024) return SLK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(map_to_sequence_batch_kernel, dim3(nread), dim3(256), lds, slk_stream(stream), ltrans, nst, ev_off, seq,
+                       pos_off, slip, prior_initial, prior_final, static_cast<int32_t *>(workspace), ws_off, score_out,
+                       path_out);
     return slk_launch_status();
 }

@@ -52,3 +52,44 @@ def test_map_to_sequence_device_log_close(golden_cases, golden_transducer):
     assert (path == g["map_path_m100_post"]).mean() > 0.95
     with pytest.raises(ValueError):
         transducer.map_to_sequence(g["map_trans_m100_post"], g["map_seq_m100_post"], slip=None)
+
+
+def test_map_to_sequence_batch_equals_goldens_and_single_calls(oracle, golden_cases, golden_transducer):
+    """Ragged batch in one launch: every read must reproduce the reference's golden path and score bit for bit
+    (cases without priors share a batch; a second batch carries priors for every read)."""
+    need_gpu()
+    from sloika_amd import transducer
+    g = golden_transducer
+    plain = [c for c in golden_cases["map_cases"] if not c["has_pi"] and not c["has_pf"]]
+    by_slip = {}
+    for c in plain:
+        by_slip.setdefault((c["slip"], _map_input(c, g).shape[1]), []).append(c)
+    checked = 0
+    for (slip, nst), cases in by_slip.items():
+        trans = []
+        for c in cases:
+            t = _map_input(c, g)
+            trans.append(t if c["log"] else np.log(t))
+        seqs = [g["map_seq_" + c["name"]] for c in cases]
+        scores, paths = transducer.map_to_sequence_batch(trans, seqs, slip)
+        for c, sc, pa in zip(cases, scores, paths):
+            assert np.array_equal(pa, g["map_path_" + c["name"]]), c["name"]
+            assert float(sc) == float.fromhex(c["score_hex"]), c["name"]
+            checked += 1
+    assert checked == len(plain) and checked >= 2
+    # ragged random batch with priors vs the oracle, read by read
+    rs = np.random.RandomState(11)
+    trans, seqs, pis, pfs = [], [], [], []
+    for nev, npos in ((40, 17), (3, 3), (120, 64), (75, 9)):
+        trans.append(np.log(rs.dirichlet(np.ones(65) * 0.4, size=nev)).astype(np.float32))
+        seqs.append(rs.randint(1, 65, size=npos).astype(np.int32))
+        pis.append(rs.normal(size=npos) * 2.0)
+        pfs.append(rs.normal(size=npos) * 2.0)
+    scores, paths = transducer.map_to_sequence_batch(trans, seqs, 2.5, prior_initial=pis, prior_final=pfs)
+    for b in range(len(trans)):
+        o_score, o_path = oracle.map_to_sequence(trans[b], seqs[b], 2.5, prior_initial=pis[b], prior_final=pfs[b])
+        assert np.array_equal(paths[b], o_path) and float(scores[b]) == float(o_score)
+        s1, p1 = transducer.map_to_sequence(trans[b], seqs[b], slip=2.5, prior_initial=pis[b], prior_final=pfs[b])
+        assert np.array_equal(paths[b], p1) and float(scores[b]) == float(s1)
+    with pytest.raises(ValueError):
+        transducer.map_to_sequence_batch(trans, seqs[:2], 2.5)
