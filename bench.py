@@ -34,8 +34,8 @@ MFMA_STAGES = ("gru_fused", "gru_recurrent", "gru_input_gemm", "lstm_recurrent",
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="raw_0.98_rgrgr")
     ap.add_argument("--batch", type=int, default=1024, help="chunks per GPU per step")
     ap.add_argument("--chunk-len", type=int, default=4000)
