@@ -731,18 +731,20 @@ class Gru(RNN):
         y = _alloc_out(x, T, B, self.size, out)
         L = _lib.lib()
         n, rows = self.size, T * B
-        # one persistent kernel (projection waves + recurrent waves) where an instantiation exists ...
-        with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
-                             f16x3_flops=6.0 * rows * n * self.insize) as reg:
-            rc = L.slk_gru_fused_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(), self.sW.dev().data_ptr(),
-                                     self.sW2.dev().data_ptr(), self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y),
-                                     T, B, self.insize, n, int(reverse), activation.act_id(self.fun),
-                                     activation.act_id(self.gatefun), _stream())
-            if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
-                reg.cancel()
-        if rc != _lib.SLK_ERR_UNSUPPORTED:
-            _lib.check(rc, "Gru")
-            return y
+        # one persistent kernel (projection waves + recurrent waves) where an instantiation exists (its projection half
+        # runs as an fp16 3-term split, so SLOIKA_AMD_EXACT_F32=1 takes the two-kernel all-fp32 path instead) ...
+        if SPLIT_F16:
+            with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
+                                 f16x3_flops=6.0 * rows * n * self.insize) as reg:
+                rc = L.slk_gru_fused_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
+                                         self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
+                                         y.data_ptr(), _row_stride(y), T, B, self.insize, n, int(reverse),
+                                         activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
+                if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
+                    reg.cancel()
+            if rc != _lib.SLK_ERR_UNSUPPORTED:
+                _lib.check(rc, "Gru")
+                return y
         # ... otherwise projection GEMM into a workspace, then the recurrence kernel
         nbytes = L.slk_gru_workspace_bytes(T, B, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
