@@ -525,7 +525,7 @@ extern "C" int slk_gru_fused_f32(const float *x, long ldx, const float *iW, cons
     if (insize == II && n == NN) return launch_fused<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, s);
     // only shapes whose two roles fit 256 VGPRs without spilling are instantiated (e.g. 128->112 / 144->112 spill
     // > 1 KB per lane and run far slower than the two-kernel path)
-    FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(128, 96) FUSED(16, 16) FUSED(48, 32) FUSED(64, 96)
+    FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(128, 96) FUSED(16, 16) FUSED(48, 32) FUSED(64, 96) FUSED(16, 64)
 #undef FUSED
     return SLK_ERR_UNSUPPORTED;
 }
