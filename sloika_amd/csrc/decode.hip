@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(1024) viterbi_forward4_kernel(const float *__r
     __syncthreads();
 
     auto step = [&](int t, const unaligned_f4 &raw, const float2 &rst, unaligned_f4 &fill, float2 &st_fill) {
-        const int tl = t % nt;
+        const int tl = t & (nt - 1);                           // blockDim.x is a power of two here (64 .. 1024)
         if (tl == 0) {                                         // every thread is past the previous block (end-of-step barrier)
             lp0buf[j] = xform(blank_raw, blank_st);
             __syncthreads();
