@@ -127,10 +127,14 @@ int slk_softmax_from_stats_f32(const float *logits, long ld_in, const float *sta
 /* Same contraction on the FP16 matrix pipe with float32-grade accuracy (csrc/gemm_rows_f16x3.hip): operands split
  * v = hi + lo in fp16, x.w ~= x_hi.w_hi + x_hi.w_lo + x_lo.w_hi accumulated in float32 -- ~5x the fp32-MFMA
  * throughput, error a few float32 ulps.  Weights are split once with slk_split_f16x2_f32 into two fp16 matrices
- * [N][KP], KP = K rounded up to 16 (2*N*KP bytes each).  K <= 128.                                                  */
+ * [N][KP], KP = K rounded up to 16 (2*N*KP bytes each).                                                            */
 int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, void *lo, slk_stream_t stream);
 int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias, float *y,
                               long ldy, long M, int K, int N, float *stats /* [M][2] or NULL */, slk_stream_t stream);
+/* FeedForward.run (sloika/layers.py:157-158) on the same kernel: y = act(x.W^T + b); act one of linear / tanh / sigmoid /
+ * relu / elu, otherwise SLK_ERR_UNSUPPORTED (use slk_gemm_bias_act_f32).  Both: K <= 192, N <= 2048.                  */
+int slk_gemm_bias_act_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias, float *y,
+                            long ldy, long M, int K, int N, int act, slk_stream_t stream);
 /* In-place row softmax of y:[M][N] (the second half of the above, exposed for testing).                     */
 int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream);
 /* Row statistics only: stats[r] = (max_j logits[r][j], 1 / sum_j exp(logits[r][j] - max)); the posterior

@@ -52,7 +52,9 @@ extern "C" int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, vo
 //     for a weight load with vmcnt(0) -- i.e. for a full store round trip (microseconds) on every tile.  The compute
 //     waves issue no loads in the loop, hence never wait on memory; the loader wave has no stores.
 //   * one s_barrier per tile (LDS counter only: __syncthreads() would drain vmcnt as well).
-template <int KS, bool STATS>
+// ACT: activation applied to the stored values (SLK_ACT_LINEAR for logits; FeedForward layers use tanh etc.); the row
+// statistics (STATS) are those of the pre-activation values and only make sense with SLK_ACT_LINEAR.
+template <int KS, bool STATS, int ACT>
 __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__restrict__ x, long ldx,
                                                               const _Float16 *__restrict__ Whi,
                                                               const _Float16 *__restrict__ Wlo,
@@ -62,7 +64,7 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
 {
     constexpr int KP = 16 * KS;                    // padded K (halves per weight row in Whi/Wlo)
     constexpr int LD = KP + 8;                     // LDS row stride in halves: (KP+8)*2 B = odd multiple of 16 B
-    constexpr int RING = 3;
+    constexpr int RING = KS <= 9 ? 3 : 2;          // weight-tile slots (a tile is 64 x (KP+8) halves, twice): LDS budget
     constexpr int PPR = KP / 8 + 1;                // 16-byte pieces per LDS row (the last one is padding)
     constexpr int BIAS_MAX = 2048 + GH_BN;
     __shared__ __attribute__((aligned(16))) _Float16 wsh[RING][GH_BN * LD];
@@ -98,15 +100,15 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
             }
         };
         dma_tile(0);
-        if (ntiles > 1) dma_tile(1);
+        if (RING > 2 && ntiles > 1) dma_tile(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tile_barrier();                                            // (P) tiles 0 and 1 are in LDS, bias staged
+        tile_barrier();                                            // (P) the first RING-1 tiles are in LDS, bias staged
         for (int nt = 0; nt < ntiles; nt++) {
-            // slot (nt+2) % 3 held tile nt-1, which every compute wave finished before the previous barrier
-            if (nt + 2 < ntiles) dma_tile(nt + 2);
-            // tile nt+1 (requested an iteration ago) must be complete before the compute waves pass this barrier;
-            // the requests just issued may stay in flight: they are the PPR*2 youngest, loads complete in order
-            if (nt + 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPR) : "memory");
+            // slot (nt+RING-1) % RING held tile nt-1, which every compute wave finished before the previous barrier
+            if (nt + RING - 1 < ntiles) dma_tile(nt + RING - 1);
+            // tile nt+1 must be complete before the compute waves pass this barrier; with three slots the requests
+            // just issued (the PPR*2 youngest; loads complete in order) may stay in flight
+            if (RING > 2 && nt + 2 < ntiles && 2 * PPR <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPR <= 63 ? 2 * PPR : 0) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             tile_barrier();
         }
@@ -185,12 +187,17 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
         // ---- epilogue: acc[reg] = logit(row, column cbase + 8*(reg>>2) + (reg&3)) ----
         const bool tile_full = (nt + 1) * GH_BN <= N;              // workgroup-uniform: every column of the tile exists
         const bool full = tile_full || cbase + 27 < N;             // all 16 columns of this lane exist
+        f32x16 o = acc;
+        if constexpr (ACT != SLK_ACT_LINEAR) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) o[reg] = slk_act_t<ACT>(acc[reg]);
+        }
         if (tile_full && vec_ok) {
             if (rowok) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
                     *reinterpret_cast<float4 *>(yrow + nt * GH_BN + 8 * q) =
-                        make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                        make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
             }
         } else if (rowok) {
 #pragma unroll
@@ -198,7 +205,7 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
                 float *dst = yrow + nt * GH_BN + 8 * q;
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    if (cbase + 8 * q + i < N) dst[i] = acc[4 * q + i];
+                    if (cbase + 8 * q + i < N) dst[i] = o[4 * q + i];
             }
         }
         if (STATS) {
@@ -247,34 +254,61 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
 
 template <int KS>
 static int launch_f16x3(const float *x, long ldx, const _Float16 *hi, const _Float16 *lo, const float *bias, float *y,
-                        long ldy, long M, int K, int N, float2 *stats, hipStream_t s)
+                        long ldy, long M, int K, int N, float2 *stats, int act, hipStream_t s)
 {
     dim3 grid((unsigned)((M + GH_BM - 1) / GH_BM)), block(576);
-    if (stats) hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, true>), grid, block, 0, s, x, ldx, hi, lo, bias, y, ldy, M, K, N, stats);
-    else hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, false>), grid, block, 0, s, x, ldx, hi, lo, bias, y, ldy, M, K, N, stats);
+#define F16X3_LAUNCH(ST, A) \
+    hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, ST, A>), grid, block, 0, s, x, ldx, hi, lo, bias, y, ldy, M, K, N, stats)
+    if (stats) F16X3_LAUNCH(true, SLK_ACT_LINEAR);
+    else if (act == SLK_ACT_LINEAR) F16X3_LAUNCH(false, SLK_ACT_LINEAR);
+    else if (act == SLK_ACT_TANH) F16X3_LAUNCH(false, SLK_ACT_TANH);
+    else if (act == SLK_ACT_SIGMOID) F16X3_LAUNCH(false, SLK_ACT_SIGMOID);
+    else if (act == SLK_ACT_RELU) F16X3_LAUNCH(false, SLK_ACT_RELU);
+    else if (act == SLK_ACT_ELU) F16X3_LAUNCH(false, SLK_ACT_ELU);
+    else return SLK_ERR_UNSUPPORTED;
+#undef F16X3_LAUNCH
     return slk_launch_status();
 }
 
-// logits = x.W^T + b from pre-split weights (slk_split_f16x2_f32), optional softmax row statistics.  K <= 144, N <= 2048.
-extern "C" int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias,
-                                         float *y, long ldy, long M, int K, int N, float *stats, slk_stream_t stream)
+static int dispatch_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias, float *y, long ldy,
+                          long M, int K, int N, float *stats, int act, slk_stream_t stream)
 {
-    if (!x || !W_hi || !W_lo || !y || M < 0 || K < 1 || N < 1 || ldx < K || ldy < N) return SLK_ERR_INVALID_ARG;
+    if (!x || !W_hi || !W_lo || !y || M < 0 || K < 1 || N < 1 || ldx < K || ldy < N || !slk_act_valid(act))
+        return SLK_ERR_INVALID_ARG;
+    if (stats && act != SLK_ACT_LINEAR) return SLK_ERR_INVALID_ARG;
     if (M == 0) return SLK_OK;
     if ((M + GH_BM - 1) / GH_BM > 0x7fffffffL || N > 2048) return SLK_ERR_UNSUPPORTED;   // bias vector is staged in LDS
     const _Float16 *hi = static_cast<const _Float16 *>(W_hi), *lo = static_cast<const _Float16 *>(W_lo);
     float2 *st = reinterpret_cast<float2 *>(stats);
     hipStream_t s = slk_stream(stream);
     switch ((K + 15) / 16) {
-    case 1: return launch_f16x3<1>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
-    case 2: return launch_f16x3<2>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
-    case 3: return launch_f16x3<3>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
-    case 4: return launch_f16x3<4>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
-    case 5: return launch_f16x3<5>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
-    case 6: return launch_f16x3<6>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
-    case 7: return launch_f16x3<7>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
-    case 8: return launch_f16x3<8>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
-    case 9: return launch_f16x3<9>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, s);
+    case 1: return launch_f16x3<1>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 2: return launch_f16x3<2>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 3: return launch_f16x3<3>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 4: return launch_f16x3<4>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 5: return launch_f16x3<5>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 6: return launch_f16x3<6>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 7: return launch_f16x3<7>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 8: return launch_f16x3<8>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 9: return launch_f16x3<9>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 10: return launch_f16x3<10>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 11: return launch_f16x3<11>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 12: return launch_f16x3<12>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
     default: return SLK_ERR_UNSUPPORTED;
     }
+}
+
+// logits = x.W^T + b from pre-split weights (slk_split_f16x2_f32), optional softmax row statistics.  K <= 192, N <= 2048.
+extern "C" int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias,
+                                         float *y, long ldy, long M, int K, int N, float *stats, slk_stream_t stream)
+{
+    return dispatch_f16x3(x, ldx, W_hi, W_lo, bias, y, ldy, M, K, N, stats, SLK_ACT_LINEAR, stream);
+}
+
+// y = act(x.W^T + b) from pre-split weights: FeedForward.run (sloika/layers.py:157-158) on the fp16 pipe.
+// act: linear, tanh, sigmoid, relu or elu (others: SLK_ERR_UNSUPPORTED -> use slk_gemm_bias_act_f32).
+extern "C" int slk_gemm_bias_act_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias,
+                                       float *y, long ldy, long M, int K, int N, int act, slk_stream_t stream)
+{
+    return dispatch_f16x3(x, ldx, W_hi, W_lo, bias, y, ldy, M, K, N, nullptr, act, stream);
 }

@@ -103,9 +103,9 @@ def _split_f16_cached(owner, attr, param, rows, k):
 
 def _projection(owner, x, W, b, ws_ptr, rows, k, n_out, stage, name):
     """ws[rows][n_out] = x.W^T + b for a recurrent layer's input projection: fp16x3 kernel where it applies
-    (k <= 144, n_out <= 2048), else the fp32 MFMA GEMM."""
+    (k <= 192, n_out <= 2048), else the fp32 MFMA GEMM."""
     L = _lib.lib()
-    use_f16 = SPLIT_F16 and k <= 144 and n_out <= 2048
+    use_f16 = SPLIT_F16 and k <= 192 and n_out <= 2048
     with profiler.region(stage, 2.0 * rows * k * n_out, 4.0 * rows * (k + n_out),
                          f16x3_flops=2.0 * rows * k * n_out if use_f16 else 0.0):
         rc = _lib.SLK_ERR_UNSUPPORTED
@@ -304,15 +304,31 @@ class FeedForward(Layer):
     def params(self):
         return [self.W, self.b] if self.has_bias else [self.W]
 
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_w16", None)          # device cache: never pickled
+        return d
+
     def _forward(self, x, out, reverse):
         T, B, _ = x.shape                       # time-local: Reverse is the identity on it
         y = _alloc_out(x, T, B, self.size, out)
         rows = T * B
+        L = _lib.lib()
+        act = activation.act_id(self.fun)
+        use_f16 = SPLIT_F16 and self.insize <= 192 and self.size <= 2048
         with profiler.region("gemm_bias_act", 2.0 * rows * self.insize * self.size,
-                             4.0 * rows * (self.insize + self.size)):
-            rc = _lib.lib().slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
-                                                  self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), rows,
-                                                  self.insize, self.size, activation.act_id(self.fun), _stream())
+                             4.0 * rows * (self.insize + self.size),
+                             f16x3_flops=2.0 * rows * self.insize * self.size if use_f16 else 0.0) as reg:
+            rc = _lib.SLK_ERR_UNSUPPORTED
+            if use_f16:
+                hi, lo = _split_f16_cached(self, "_w16", self.W, self.size, self.insize)
+                rc = L.slk_gemm_bias_act_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(),
+                                               self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), rows, self.insize,
+                                               self.size, act, _stream())
+            if rc == _lib.SLK_ERR_UNSUPPORTED:           # activation or size the fp16x3 kernel does not cover
+                rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), self.W.dev().data_ptr(),
+                                             self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), rows, self.insize,
+                                             self.size, act, _stream())
         _lib.check(rc, "FeedForward")
         return y
 

@@ -169,3 +169,37 @@ def test_linear_rowstats_unsupported_k():
     z = dev(np.zeros((4, 200), dtype=np.float32))
     assert _lib.lib().slk_linear_rowstats_f32(z.data_ptr(), 200, z.data_ptr(), None, z.data_ptr(), 200, 4, 200, 4, None,
                                               stream()) == _lib.SLK_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("K,N,act", [(192, 128, "tanh"), (128, 64, "tanh"), (8, 4, "tanh"), (96, 1025, "linear"),
+                                     (176, 70, "sigmoid"), (33, 65, "relu"), (144, 336, "elu")])
+def test_gemm_bias_act_f16x3_vs_float64(K, N, act):
+    """FeedForward on the fp16 pipe (3-term split): every supported activation, K up to 192, ragged N and M, strided rows."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(K + N)
+    M = 1000 + K
+    x = rs.normal(size=(M, K)).astype(np.float32)
+    W = (rs.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rs.normal(size=N).astype(np.float32)
+    z = x.astype(np.float64) @ W.astype(np.float64).T + b
+    ref = {"tanh": np.tanh, "linear": lambda v: v, "sigmoid": lambda v: 1.0 / (1.0 + np.exp(-v)),
+           "relu": lambda v: np.maximum(v, 0.0), "elu": lambda v: np.where(v > 0, v, np.expm1(v))}[act](z)
+    aid = {"linear": 0, "tanh": 1, "sigmoid": 2, "elu": 3, "relu": 4}[act]
+    xd, Wd, bd = dev(x), dev(W), dev(b)
+    kp = (K + 15) // 16 * 16
+    hi = torch.empty((N, kp), dtype=torch.float16, device="cuda")
+    lo = torch.empty((N, kp), dtype=torch.float16, device="cuda")
+    assert L.slk_split_f16x2_f32(Wd.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), stream()) == 0
+    ld = N + 5
+    y = torch.full((M, ld), -7.0, dtype=torch.float32, device="cuda")
+    rc = L.slk_gemm_bias_act_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), bd.data_ptr(), y.data_ptr(), ld, M, K, N,
+                                   aid, stream())
+    assert rc == 0
+    out = y.cpu().numpy()
+    np.testing.assert_allclose(out[:, :N], ref, atol=2e-5)
+    assert (out[:, N:] == -7.0).all()
+    # unsupported activation -> caller falls back to the fp32 kernel
+    assert L.slk_gemm_bias_act_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), bd.data_ptr(), y.data_ptr(), ld, M, K, N,
+                                     7, stream()) == _lib.SLK_ERR_UNSUPPORTED
