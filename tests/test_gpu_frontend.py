@@ -56,6 +56,13 @@ def test_normalise_rejects_bad_shapes():
     (30, 1, 2, 3, 5, 3, 'valid', "relu"),
     (17, 2, 2, 3, 5, 1, 'full', "sigmoid"),
     (64, 2, 128, 200, 11, 3, 'half', "tanh"),          # filter too large for LDS -> global path
+    (4000, 2, 1, 128, 11, 5, (5, 5), "elu"),           # pretrained.pkl front end, explicit padding (vec4 kernel, 32 quads)
+    (4000, 2, 1, 32, 11, 2, 'same', "tanh"),           # bigger_raw_gru front end (vec4 kernel, 8 quads -> 8 positions/step)
+    (333, 3, 1, 4, 16, 16, 'valid', "relu"),           # one quad, widest window and stride the Cin=1 kernels take
+    (57, 2, 1, 256, 3, 1, 'full', "sigmoid"),          # 64 quads = one position per step
+    (41, 2, 1, 20, 7, 3, 'same_left', "softplus"),     # vec4 kernel with a run-time activation
+    (41, 2, 1, 10, 7, 3, 'same', "tanh"),              # Cout not a multiple of 4 -> one-feature-per-lane kernel
+    (5, 1, 1, 12, 11, 5, 'same', "linear"),            # shorter than the window
 ])
 def test_conv1d_vs_oracle(oracle, T, B, Cin, Cout, w, s, mode, act):
     need_gpu()
