@@ -70,9 +70,25 @@ def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
         del post, lp
         if spent >= budget_s:
             break
-    return {"value": done * chunk_len / spent, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d chunks x %d samples of the same synthetic workload through the oracle C port "
-                      "(OpenMP over chunks, %d threads), %.1f s" % (done, chunk_len, cores, spent)}
+    out = {"value": done * chunk_len / spent, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": "%d chunks x %d samples of the same synthetic workload through the oracle C port "
+                     "(OpenMP over chunks, %d threads), %.1f s" % (done, chunk_len, cores, spent)}
+    # the same port on ONE core (SURVEY.md 8d asks for both): a dozen chunks, ~5 s
+    try:
+        orc.set_num_threads(1)
+        n1 = 12
+        chunks = pipeline.synthetic_chunks(n1, chunk_len=chunk_len, seed=123, first_chunk=0)
+        t0 = time.perf_counter()
+        x = orc.med_mad_normalise(chunks)
+        post = orc.run_network(spec, np.ascontiguousarray(x.T)[:, :, None])
+        lp = np.log(np.float32(1e-5) + np.float32(1.0 - 1e-5) * post + np.float32(1e-10))
+        orc.viterbi_batch(lp, 5, skip_pen=0.0)
+        t1 = time.perf_counter() - t0
+        out["single_core"] = {"value": n1 * chunk_len / t1, "unit": "samples/s",
+                              "sample": "%d chunks, 1 thread, %.1f s" % (n1, t1)}
+    finally:
+        orc.set_num_threads(cores)
+    return out
 
 
 def main():
