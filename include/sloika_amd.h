@@ -161,8 +161,11 @@ int slk_gru_f32(const float *x, long ldx, const float *iW, const float *sW, cons
                 float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                 void *workspace, size_t workspace_bytes, slk_stream_t stream);
 /* Whole layer in one persistent kernel (projection waves + recurrent waves, csrc/gru_fused.hip): no workspace, the
- * projection never touches HBM.  Returns SLK_ERR_UNSUPPORTED when (insize, n, activations, alignment) has no fused
- * instantiation; slk_gru_f32 tries it first and falls back to projection GEMM + slk_gru_recurrent_f32.            */
+ * projection never touches HBM.  The recurrence is exact float32 MFMA; the input projection is evaluated as a 3-term
+ * fp16 split with float32 accumulation (error a few float32 ulps, as slk_linear_rowstats_f16x3) -- callers that need
+ * plain fp32 arithmetic throughout use slk_gemm_bias_act_f32 + slk_gru_recurrent_f32.  Returns SLK_ERR_UNSUPPORTED
+ * when (insize, n, activations, alignment) has no fused instantiation; slk_gru_f32 tries it first and falls back to
+ * projection GEMM + slk_gru_recurrent_f32.                                                                          */
 int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                       float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                       slk_stream_t stream);
