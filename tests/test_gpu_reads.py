@@ -56,3 +56,26 @@ def test_trained_model_on_real_reads_agrees_with_stored_basecall(n):
     rs = np.random.RandomState(n)
     shuffled = "".join(rs.permutation(list(stored)))
     assert 1.0 - edit_distance(seq, shuffled) / max(len(seq), len(shuffled)) < 0.62
+
+
+def test_fp16_split_projections_do_not_change_the_call():
+    """The time-parallel projections run as 3-term fp16 splits (float32 accumulation); forcing plain fp32 MFMA everywhere
+    (what SLOIKA_AMD_EXACT_F32=1 selects) must give the same bases on a real read -- scores agree to ~1e-6 relative."""
+    need_gpu()
+    from sloika_amd import basecall, bio, layers, models
+    g = np.load(os.path.join(GOLDEN, "reads.npz"))
+    calc_post = models.from_weights_npz(os.path.join(GOLDEN, "pretrained_weights.npz")).compile()
+    dig, off, rng, _rate = g["meta_5"]
+    signal = (g["adc_5"].astype(np.float64) + off) * (rng / dig)
+    kmers = bio.all_kmers(5)
+    saved = (layers.SPLIT_F16, layers.Softmax.split_f16)
+    out = []
+    try:
+        for split in (True, False):
+            layers.SPLIT_F16 = layers.Softmax.split_f16 = split
+            _, score, call, _ = basecall.raw_read_worker(calc_post, signal, kmer_len=5, skip=5.0, name="read5")
+            out.append((float(score), bio.kmers_to_sequence([kmers[i] for i in call], always_move=True)))
+    finally:
+        layers.SPLIT_F16, layers.Softmax.split_f16 = saved
+    assert out[0][1] == out[1][1]
+    assert out[0][0] == pytest.approx(out[1][0], rel=1e-5) and out[0][0] != 0.0

@@ -27,8 +27,20 @@ def main():
     net = models.from_weights_npz(os.path.join(ROOT, "tests", "golden", "pretrained_weights.npz"))
     calc_post = net.compile()
     kmers = bio.all_kmers(5)
+    from sloika_amd import layers
     for n in (5, 3):
         dig, off, rng, rate = g["meta_%d" % n]
+        sig0 = (g["adc_%d" % n].astype(np.float64) + off) * (rng / dig)
+        both = []
+        for split in (True, False):                       # fp16x3 projections vs plain fp32 MFMA everywhere
+            layers.SPLIT_F16 = split
+            layers.Softmax.split_f16 = split
+            _, sc, call, _ = basecall.raw_read_worker(calc_post, sig0, kmer_len=5, skip=5.0, name="read%d" % n)
+            both.append((sc, bio.kmers_to_sequence([kmers[i] for i in call], always_move=True)))
+        layers.SPLIT_F16 = layers.Softmax.split_f16 = True
+        print("read%d: fp16x3 vs all-fp32 arithmetic: scores %.4f / %.4f, sequences %s (edit distance %d of %d)" % (
+            n, both[0][0], both[1][0], "identical" if both[0][1] == both[1][1] else "differ",
+            edit_distance(both[0][1], both[1][1]), len(both[0][1])))
         signal = (g["adc_%d" % n].astype(np.float64) + off) * (rng / dig)
         stored = g["called_%d" % n].tobytes().decode()
         for skip in (0.0, 5.0):
