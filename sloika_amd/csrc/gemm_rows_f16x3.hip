@@ -164,12 +164,14 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
     float rmax = -INFINITY, rsum = 0.0f;           // online softmax statistics of this lane's share of the row
 
     tile_barrier();                                                // (P)
-    for (int nt = 0; nt < ntiles; nt++) {
+    // Software pipeline: the epilogue of tile nt-1 (stores, statistics) is in the same straight-line block as the MFMA
+    // chain of tile nt, so the scheduler can slot its stores and VALU work between the dependent MFMAs, and the logit
+    // stores of a workgroup spread over the whole tile time instead of arriving as a burst after every barrier.
+    auto mma = [&](int nt) {
         const _Float16 *th = &wsh[nt % RING][(32 * wn + r) * LD + 8 * h];
         const _Float16 *tl = &wsl[nt % RING][(32 * wn + r) * LD + 8 * h];
         const int cbase = nt * GH_BN + 32 * wn + 4 * h;            // column of acc[0]; acc[4q+i] is column cbase + 8q + i
-        // accumulators start from the bias
-        f32x16 acc;
+        f32x16 acc;                                                // accumulators start from the bias
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const float4 b4 = *reinterpret_cast<const float4 *>(&bias_lds[cbase + 8 * q]);
@@ -184,7 +186,11 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ahi[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ahi[s], acc, 0, 0, 0);
         }
-        // ---- epilogue: acc[reg] = logit(row, column cbase + 8*(reg>>2) + (reg&3)) ----
+        return acc;
+    };
+    // acc[reg] = logit(row, column cbase + 8*(reg>>2) + (reg&3))
+    auto epilogue = [&](int nt, const f32x16 &acc) {
+        const int cbase = nt * GH_BN + 32 * wn + 4 * h;
         const bool tile_full = (nt + 1) * GH_BN <= N;              // workgroup-uniform: every column of the tile exists
         const bool full = tile_full || cbase + 27 < N;             // all 16 columns of this lane exist
         f32x16 o = acc;
@@ -228,8 +234,74 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
                 rmax = mn;
             }
         }
-        tile_barrier();
+    };
+    // Straight-line epilogue for the common case (whole workgroup inside M, aligned rows, every column of the tile
+    // exists): no branch, so that it shares a scheduling region with the next tile's MFMA chain.
+    auto epilogue_fast = [&](int nt, const f32x16 &acc) {
+        f32x16 o = acc;
+        if constexpr (ACT != SLK_ACT_LINEAR) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) o[reg] = slk_act_t<ACT>(acc[reg]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            *reinterpret_cast<float4 *>(yrow + nt * GH_BN + 8 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        if (STATS) {
+            float tm = acc[0];
+#pragma unroll
+            for (int reg = 1; reg < 16; reg++) tm = fmaxf(tm, acc[reg]);
+            const float mn = fmaxf(rmax, tm);
+            const float ms = fmaxf(mn, -3.0e38f);                  // all -inf so far: exp(-inf - ms) = 0, no NaN
+            float sum = rsum * __expf(fmaxf(rmax, -3.0e38f) - ms);  // rsum = 0 while rmax = -inf
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) sum += __expf(acc[reg] - ms);
+            rsum = sum;
+            rmax = mn;
+        }
+    };
+    // ask the scheduler to slot the epilogue between the dependent MFMAs: per MFMA a few VALU ops and one transcendental
+    auto interleave_hint = [] {
+#pragma unroll
+        for (int i = 0; i < 3 * KS; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, STATS ? 5 : 1, 0);   // VALU
+            if (STATS) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);    // one transcendental
+        }
+    };
+    // two accumulator sets swap roles statically (loop unrolled by two): no register copies between tiles
+    const bool wg_fast = vec_ok && (m0 + GH_BM <= M);
+    const int nfull = N / GH_BN;                                   // tiles whose 64 columns all exist
+    f32x16 accA = mma(0), accB = accA;
+    tile_barrier();
+    int nt = 1;
+    if (wg_fast) {
+        // epilogues of full tiles 0 .. nfast-1 next to the MFMAs of tiles 1 .. nfast
+        const int nfast = nfull < ntiles - 1 ? nfull : ntiles - 1;
+        for (; nt + 1 <= nfast; nt += 2) {
+            accB = mma(nt);
+            epilogue_fast(nt - 1, accA);
+            interleave_hint();
+            tile_barrier();
+            accA = mma(nt + 1);
+            epilogue_fast(nt, accB);
+            interleave_hint();
+            tile_barrier();
+        }
     }
+    // everything else (ragged workgroups, the partial last tile, an odd tile left over): the guarded epilogue
+    for (; nt < ntiles; nt += 2) {
+        accB = mma(nt);
+        epilogue(nt - 1, accA);
+        tile_barrier();
+        if (nt + 1 < ntiles) {
+            accA = mma(nt + 1);
+            epilogue(nt, accB);
+            tile_barrier();
+        } else {
+            accA = accB;                                           // the last tile's results, for the epilogue below
+        }
+    }
+    epilogue(ntiles - 1, accA);
     if (STATS) {
         // combine the two column halves (lanes l and l^32 hold the same row), then the two column waves
         {
