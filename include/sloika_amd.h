@@ -169,6 +169,15 @@ int slk_gru_f32(const float *x, long ldx, const float *iW, const float *sW, cons
 int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                       float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                       slk_stream_t stream);
+/* Ragged batches (whole reads of different lengths, zero-padded to T steps; the reference calls reads one at a time,
+ * sloika/basecall.py:88-121): lens[b] in [1, T] (int32, device) is the number of valid steps of chunk b.  Steps
+ * t >= lens[b] of y / h_out are left untouched, and with reverse = 1 the scan of chunk b starts at ITS last step,
+ * i.e. each chunk gets exactly what a call on the unpadded chunk alone would produce.                                */
+int slk_gru_fused_ragged_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
+                             const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse, int act,
+                             int gate_act, const int32_t *lens, slk_stream_t stream);
+int slk_gru_recurrent_ragged_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
+                                 int n, int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream);
 /* Force the portable (non-MFMA) recurrence kernel: 0 = auto, 1 = force generic.  Testing aid; passed per call
  * through the `_ex` form so that there is still no global state.                                            */
 int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T,
@@ -223,6 +232,12 @@ int slk_viterbi_kmer_logits_f32(const float *logits, long ld /* floats between r
                                 int T, int B, int nbase, int klen, float skip_pen, float min_prob, void *workspace,
                                 size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out,
                                 slk_stream_t stream);
+/* Ragged form (see slk_gru_fused_ragged_f32): chunk b is decoded over its first lens[b] steps only; path_out rows keep
+ * the padded length T.                                                                                               */
+int slk_viterbi_kmer_logits_ragged_f32(const float *logits, long ld, const float *stats, int T, int B, int nbase, int klen,
+                                       float skip_pen, float min_prob, const int32_t *lens, void *workspace,
+                                       size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out,
+                                       slk_stream_t stream);
 int slk_log_post_logits_f32(const float *logits, long ld, const float *stats, float *lpost /* dense [rows][nstate] */,
                             size_t rows, int nstate, float min_prob, slk_stream_t stream);
 /* decode.prepare_post on its own: out = min_prob + (1-min_prob)*post (decode.py:36).                        */

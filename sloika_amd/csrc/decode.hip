@@ -117,10 +117,12 @@ __global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__re
                                                                int nkmer, float skip_pen, int mode, float min_prob,
                                                                float one_m, uint8_t *__restrict__ tb,
                                                                int32_t *__restrict__ best_out,
-                                                               float *__restrict__ score_out)
+                                                               float *__restrict__ score_out, const int *__restrict__ lens)
 {
     constexpr int NB2 = NB * NB;
     extern __shared__ float sm[];
+    const int Tpad = T;                                        // row stride of the traceback; T = this chunk's own length
+    if (lens) T = min(max(lens[blockIdx.x], 1), Tpad);
     const int nrem1 = nkmer / NB, nrem2 = nkmer / NB2;
     float *v = sm;                                             // [nkmer] scores of the previous step
     float *stepmax = sm + nkmer;                               // [nrem1]
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(1024) viterbi_forward_kernel(const float *__re
     const int jj = active ? j : 0, j2 = jj / NB;
     const float *pb = post + (size_t)b * ld;            // rows (t, b) are `ld` floats apart (ld >= nkmer + 1)
     const size_t tstride = (size_t)B * ld;
-    uint8_t *tbb = tb + (size_t)b * T * nkmer;
+    uint8_t *tbb = tb + (size_t)b * Tpad * nkmer;
 
     auto xform = [&](float val, float2 st) {
         return LOGITS ? log_logit_val(val, st, min_prob, one_m) : log_post_val(val, mode, min_prob, one_m);
@@ -264,10 +266,12 @@ __global__ void __launch_bounds__(1024) viterbi_forward4_kernel(const float *__r
                                                                 int nkmer, float skip_pen, int mode, float min_prob,
                                                                 float one_m, uint8_t *__restrict__ tb,
                                                                 int32_t *__restrict__ best_out,
-                                                                float *__restrict__ score_out)
+                                                                float *__restrict__ score_out, const int *__restrict__ lens)
 {
     constexpr int NB = 4;
     extern __shared__ float sm[];
+    const int Tpad = T;                                        // row stride of the traceback; T = this chunk's own length
+    if (lens) T = min(max(lens[blockIdx.x], 1), Tpad);
     const int nrem1 = nkmer / 4, nrem2 = nkmer / 16;
     const int b = blockIdx.x, j = threadIdx.x, nt = blockDim.x;
     float *vbuf0 = sm, *vbuf1 = sm + nkmer;                    // scores of even / odd steps
@@ -281,7 +285,7 @@ __global__ void __launch_bounds__(1024) viterbi_forward4_kernel(const float *__r
     const int jj = active ? j : 0, q = jj >> 2, c = jj & 3;
     const float *pb = post + (size_t)b * ld;                   // rows (t, b) are `ld` floats apart (ld >= nkmer + 1)
     const size_t tstride = (size_t)B * ld;
-    uint8_t *tbb = tb + (size_t)b * T * nkmer;
+    uint8_t *tbb = tb + (size_t)b * Tpad * nkmer;
 
     auto xform = [&](float val, float2 st) {
         return LOGITS ? log_logit_val(val, st, min_prob, one_m) : log_post_val(val, mode, min_prob, one_m);
@@ -438,14 +442,16 @@ __global__ void __launch_bounds__(256) viterbi_forward4_wave_kernel(const float 
                                                                     int nkmer, float skip_pen, int mode, float min_prob,
                                                                     float one_m, uint8_t *__restrict__ tb,
                                                                     int32_t *__restrict__ best_out,
-                                                                    float *__restrict__ score_out)
+                                                                    float *__restrict__ score_out, const int *__restrict__ lens)
 {
     constexpr int NB = 4;
     extern __shared__ float sm[];
+    const int Tpad = T;                                        // row stride of the traceback
     // the chunk index is wave-uniform: keeping it in a scalar register makes the row statistics scalar loads
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + wave;
     if (b >= B) return;                                        // whole wave leaves together; nothing below synchronises waves
+    if (lens) T = min(max(lens[b], 1), Tpad);                  // ragged batch: this chunk's own length (wave-uniform)
     const int nrem1 = nkmer / 4, nrem2 = nkmer / 16;
     float *v = sm + wave * (nkmer + 64);                       // [nkmer] scores, then [64] blank log-posteriors
     float *lp0buf = v + nkmer;
@@ -453,7 +459,7 @@ __global__ void __launch_bounds__(256) viterbi_forward4_wave_kernel(const float 
     const int q = active ? lane : 0;
     const float *pb = post + (size_t)b * ld;
     const size_t tstride = (size_t)B * ld;
-    uint8_t *tbb = tb + (size_t)b * T * nkmer;
+    uint8_t *tbb = tb + (size_t)b * Tpad * nkmer;
 
     auto xform = [&](float val, float2 st) {
         return LOGITS ? log_logit_val(val, st, min_prob, one_m) : log_post_val(val, mode, min_prob, one_m);
@@ -622,17 +628,19 @@ template <int NB>
 __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *__restrict__ tb,
                                                                 const int32_t *__restrict__ best, int T, int nkmer,
                                                                 int tblk, int dma, int32_t *__restrict__ path_out,
-                                                                int32_t *__restrict__ len_out)
+                                                                int32_t *__restrict__ len_out, const int *__restrict__ lens)
 {
     constexpr int NB2 = NB * NB;
     constexpr int PER_WAVE = VBT_BLOCK / 1024 / 3;
+    const int Tpad = T;                                        // row strides of tb / path_out; T = this chunk's own length
+    if (lens) T = min(max(lens[blockIdx.x], 1), Tpad);
     __shared__ __attribute__((aligned(16))) uint8_t blk[VBT_RING * VBT_BLOCK];
     __shared__ int sh_cur, sh_pos;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nrem1 = nkmer / NB, nrem2 = nkmer / NB2;
-    const uint8_t *tbb = tb + (size_t)b * T * nkmer;
-    int32_t *path = path_out + (size_t)b * T;
+    const uint8_t *tbb = tb + (size_t)b * Tpad * nkmer;
+    int32_t *path = path_out + (size_t)b * Tpad;
     if (tid == 0) {
         sh_cur = best[b];
         sh_pos = T - 1;
@@ -712,11 +720,11 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
     const int pos = sh_pos, len = T - pos;
     __threadfence_block();
     __syncthreads();
-    for (int base = 0; base < T; base += nt) {
+    for (int base = 0; base < Tpad; base += nt) {
         int i = base + tid;
         int32_t val = (i < len) ? path[pos + i] : -1;
         __syncthreads();
-        if (i < T) path[i] = val;
+        if (i < Tpad) path[i] = val;
         __syncthreads();
     }
     if (tid == 0) len_out[b] = len;
@@ -745,7 +753,7 @@ extern "C" size_t slk_viterbi_kmer_workspace_bytes(int T, int B, int nbase, int 
 template <int NB>
 static int launch_viterbi(const float *post, const float *stats, long ld, int T, int B, int klen, int nkmer, float skip_pen, int mode, float min_prob,
                           uint8_t *tb, int32_t *best, float *score_out, int32_t *path_out, int32_t *len_out,
-                          hipStream_t s)
+                          const int *lens, hipStream_t s)
 {
     int nrem1 = nkmer / NB;
     int threads = nrem1 < 64 ? 64 : (nrem1 > 1024 ? 1024 : ((nrem1 + 63) / 64) * 64);
@@ -760,26 +768,26 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
         if (stats)
             hipLaunchKernelGGL((viterbi_forward4_wave_kernel<true>), grid, block, ldsw, s, post,
                                reinterpret_cast<const float2 *>(stats), ld, T, B, nkmer, skip_pen, mode, min_prob, one_m, tb,
-                               best, score_out);
+                               best, score_out, lens);
         else
             hipLaunchKernelGGL((viterbi_forward4_wave_kernel<false>), grid, block, ldsw, s, post, nullptr, ld, T, B, nkmer,
-                               skip_pen, mode, min_prob, one_m, tb, best, score_out);
+                               skip_pen, mode, min_prob, one_m, tb, best, score_out, lens);
     } else if constexpr (NB == 4) {
         const size_t lds4 = sizeof(float) * (2 * (size_t)nkmer + threads + 32 + (size_t)VIT_TBS * nrem1);
         if (stats)
             hipLaunchKernelGGL((viterbi_forward4_kernel<true>), dim3(B), dim3(threads), lds4, s, post,
                                reinterpret_cast<const float2 *>(stats), ld, T, B, nkmer, skip_pen, mode, min_prob, one_m, tb,
-                               best, score_out);
+                               best, score_out, lens);
         else
             hipLaunchKernelGGL((viterbi_forward4_kernel<false>), dim3(B), dim3(threads), lds4, s, post, nullptr, ld, T, B,
-                               nkmer, skip_pen, mode, min_prob, one_m, tb, best, score_out);
+                               nkmer, skip_pen, mode, min_prob, one_m, tb, best, score_out, lens);
     } else if (stats)
         hipLaunchKernelGGL((viterbi_forward_kernel<NB, true>), dim3(B), dim3(threads), lds, s, post,
                            reinterpret_cast<const float2 *>(stats), ld, T, B, nkmer, skip_pen, mode, min_prob, one_m, tb, best,
-                           score_out);
+                           score_out, lens);
     else
         hipLaunchKernelGGL((viterbi_forward_kernel<NB, false>), dim3(B), dim3(threads), lds, s, post, nullptr, ld, T, B, nkmer,
-                           skip_pen, mode, min_prob, one_m, tb, best, score_out);
+                           skip_pen, mode, min_prob, one_m, tb, best, score_out, lens);
     int rc = slk_launch_status();
     if (rc != SLK_OK) return rc;
     int tblk = VBT_BLOCK / nkmer;                            // rows per staged block
@@ -787,13 +795,13 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
     const int dma = (VBT_BLOCK % nkmer == 0) && (nkmer % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
     if (tblk > T) tblk = T;
     hipLaunchKernelGGL((viterbi_backtrace_kernel<NB>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
-                       len_out);
+                       len_out, lens);
     return slk_launch_status();
 }
 
 static int viterbi_entry(const float *post, const float *stats, long ld, int T, int B, int nbase, int klen, float skip_pen,
                          int input_mode, float min_prob, void *workspace, size_t workspace_bytes, float *score_out,
-                         int32_t *path_out, int32_t *len_out, slk_stream_t stream)
+                         int32_t *path_out, int32_t *len_out, const int32_t *lens, slk_stream_t stream)
 {
     int nkmer;
     if (!post || !score_out || !path_out || !len_out || T < 1 || B < 1 || input_mode < 0 || input_mode > 2)
@@ -808,8 +816,8 @@ static int viterbi_entry(const float *post, const float *stats, long ld, int T, 
     int32_t *best = reinterpret_cast<int32_t *>(tb + tbbytes);
     hipStream_t s = slk_stream(stream);
     switch (nbase) {
-    case 4: return launch_viterbi<4>(post, stats, ld, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
-    case 5: return launch_viterbi<5>(post, stats, ld, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, s);
+    case 4: return launch_viterbi<4>(post, stats, ld, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, lens, s);
+    case 5: return launch_viterbi<5>(post, stats, ld, T, B, klen, nkmer, skip_pen, input_mode, min_prob, tb, best, score_out, path_out, len_out, lens, s);
     default: return SLK_ERR_UNSUPPORTED;
     }
 }
@@ -819,7 +827,7 @@ extern "C" int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, 
                                     float *score_out, int32_t *path_out, int32_t *len_out, slk_stream_t stream)
 {
     return viterbi_entry(post, nullptr, 0, T, B, nbase, klen, skip_pen, input_mode, min_prob, workspace, workspace_bytes,
-                         score_out, path_out, len_out, stream);
+                         score_out, path_out, len_out, nullptr, stream);
 }
 
 extern "C" int slk_viterbi_kmer_logits_f32(const float *logits, long ld, const float *stats, int T, int B, int nbase, int klen,
@@ -828,7 +836,19 @@ extern "C" int slk_viterbi_kmer_logits_f32(const float *logits, long ld, const f
 {
     if (!stats) return SLK_ERR_INVALID_ARG;
     return viterbi_entry(logits, stats, ld, T, B, nbase, klen, skip_pen, SLK_POST_RAW, min_prob, workspace, workspace_bytes,
-                         score_out, path_out, len_out, stream);
+                         score_out, path_out, len_out, nullptr, stream);
+}
+
+// Ragged batch (whole reads of different lengths padded to T steps): lens[b] in [1, T]; chunk b is decoded over its own
+// first lens[b] steps, exactly as a call with T = lens[b] on that chunk alone would; path_out rows stay T long (-1 padded).
+extern "C" int slk_viterbi_kmer_logits_ragged_f32(const float *logits, long ld, const float *stats, int T, int B, int nbase,
+                                                  int klen, float skip_pen, float min_prob, const int32_t *lens,
+                                                  void *workspace, size_t workspace_bytes, float *score_out,
+                                                  int32_t *path_out, int32_t *len_out, slk_stream_t stream)
+{
+    if (!stats || !lens) return SLK_ERR_INVALID_ARG;
+    return viterbi_entry(logits, stats, ld, T, B, nbase, klen, skip_pen, SLK_POST_RAW, min_prob, workspace, workspace_bytes,
+                         score_out, path_out, len_out, lens, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                                                            const float *__restrict__ iW, const float *__restrict__ bias,
                                                            const float *__restrict__ sW, const float *__restrict__ sW2,
                                                            float *__restrict__ h_out, long ldh, int T, int B, int reverse,
-                                                           int act, int gate_act, int diag)
+                                                           int act, int gate_act, int diag, const int *__restrict__ lens)
 {
     static_assert(I % 16 == 0 && N % 16 == 0 && N <= 128, "unsupported size for the fused GRU kernel");
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -357,9 +357,12 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                 if (piece0 < XPIECES) {
                     const int p = piece0 + lane;
                     const int kk = p / I, pp = p % I, q = pp >> 2, c = pp & 3;
-                    const int ss = min(s0 + kk, T - 1);
-                    const int tt = reverse ? T - 1 - ss : ss;
                     const int bc = min(b0 + c, B - 1);
+                    // ragged batch: chunk bc is Tc <= T steps long; a reversed scan starts at ITS last step, and the
+                    // steps past the end re-read the last valid row (their results are never stored)
+                    const int Tc = lens ? min(max(lens[bc], 1), T) : T;
+                    const int ss = min(s0 + kk, Tc - 1);
+                    const int tt = reverse ? Tc - 1 - ss : ss;
                     const float *src = x + ((size_t)tt * B + bc) * ldx + 4 * q;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                      (__attribute__((address_space(3))) void *)&xbuf[slot * (KB * XIMG) + piece0 * 4],
@@ -377,10 +380,11 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
             const int idx = (tid - 256) + 256 * j;
             const int c = idx & 3, rest = idx >> 2, f4 = rest % (N / 4), kk = rest / (N / 4);
             const int ss = kb * KB + kk;
-            if (idx < OF4 && ss < T && b0 + c < B) {
+            const int Tc = (lens && b0 + c < B) ? min(max(lens[b0 + c], 1), T) : T;
+            if (idx < OF4 && ss < Tc && b0 + c < B) {
                 const float *src = hring + (ss % HSLOTS) * HIMG + 16 * f4 + c;
                 const float v0 = src[0], v1 = src[4], v2 = src[8], v3 = src[12];
-                const int tt = reverse ? T - 1 - ss : ss;
+                const int tt = reverse ? Tc - 1 - ss : ss;
                 float *dst = h_out + ((size_t)tt * B + b0 + c) * ldh + 4 * f4;
                 if (vec_store) *reinterpret_cast<float4 *>(dst) = make_float4(v0, v1, v2, v3);
                 else { dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; }
@@ -492,19 +496,19 @@ static size_t exclusive_cu_lds(K kernel)
 
 template <int I, int N>
 static int launch_fused(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
-                        float *y, long ldy, int T, int B, int reverse, hipStream_t s)
+                        float *y, long ldy, int T, int B, int reverse, const int *lens, hipStream_t s)
 {
     const int diag = (reverse >> 1) & 3;
     if constexpr (I == 96 && N == 96) {
         if (diag) {
             hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, true>), dim3((B + 3) / 4), dim3(512), 0, s,
-                               x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, diag);
+                               x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, diag, lens);
             return slk_launch_status();
         }
     }
     static const size_t dyn_lds = exclusive_cu_lds(gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>);
     hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>), dim3((B + 3) / 4), dim3(512), dyn_lds, s,
-                       x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, 0);
+                       x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, 0, lens);
     return slk_launch_status();
 }
 
@@ -512,9 +516,9 @@ static int launch_fused(const float *x, long ldx, const float *iW, const float *
 //  undocumented in the public header on purpose -- tools/bench_kernels.py uses it.)
 // Returns SLK_ERR_UNSUPPORTED when no fused instantiation covers the request (the caller then uses
 // projection GEMM + gru_mfma_kernel).
-extern "C" int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
-                                 const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse,
-                                 int act, int gate_act, slk_stream_t stream)
+static int gru_fused_entry(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+                           float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
+                           const int32_t *lens, slk_stream_t stream)
 {
     if (!x || !iW || !sW || !sW2 || !y || T < 1 || B < 1 || insize < 1 || n < 1 || ldx < insize || ldy < n)
         return SLK_ERR_INVALID_ARG;
@@ -522,10 +526,27 @@ extern "C" int slk_gru_fused_f32(const float *x, long ldx, const float *iW, cons
     if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;   // 16-byte DMA pieces
     hipStream_t s = slk_stream(stream);
 #define FUSED(II, NN) \
-    if (insize == II && n == NN) return launch_fused<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, s);
+    if (insize == II && n == NN) return launch_fused<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, s);
     // only shapes whose two roles fit 256 VGPRs without spilling are instantiated (e.g. 128->112 / 144->112 spill
     // > 1 KB per lane and run far slower than the two-kernel path)
     FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(128, 96) FUSED(16, 16) FUSED(48, 32) FUSED(64, 96) FUSED(16, 64)
 #undef FUSED
     return SLK_ERR_UNSUPPORTED;
+}
+
+extern "C" int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
+                                 const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse,
+                                 int act, int gate_act, slk_stream_t stream)
+{
+    return gru_fused_entry(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse, act, gate_act, nullptr, stream);
+}
+
+// Ragged batch (reads of different lengths padded to T): lens[b] in [1, T] = valid steps of chunk b.  Rows t >= lens[b] of
+// y are left untouched; with reverse = 1 the scan of chunk b starts at ITS last step (Reverse(Gru) on the unpadded read).
+extern "C" int slk_gru_fused_ragged_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
+                                        const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse,
+                                        int act, int gate_act, const int32_t *lens, slk_stream_t stream)
+{
+    if (!lens) return SLK_ERR_INVALID_ARG;
+    return gru_fused_entry(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse & 1, act, gate_act, lens, stream);
 }

@@ -31,11 +31,12 @@
 __global__ void __launch_bounds__(256) gru_generic_kernel(const float *__restrict__ vI, const float *__restrict__ sW,
                                                           const float *__restrict__ sW2, float *__restrict__ h_out,
                                                           long ldh, int T, int B, int n, int reverse, int act,
-                                                          int gate_act)
+                                                          int gate_act, const int *__restrict__ lens)
 {
     extern __shared__ float sm[];
     float *h = sm, *rh = sm + n, *z = sm + 2 * n;
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (lens) T = min(max(lens[b], 1), T);                       // ragged batch: this chunk's own length
     for (int j = tid; j < n; j += nt) h[j] = 0.0f;
     __syncthreads();
     for (int s = 0; s < T; s++) {
@@ -109,7 +110,8 @@ __global__ void __launch_bounds__(256) lstm_generic_kernel(const float *__restri
 template <int N, int ACT, int GACT, int NWAVES = 4>
 __global__ void __launch_bounds__(64 * NWAVES, (NWAVES + 3) / 4) gru_mfma_kernel(const float *__restrict__ vI, const float *__restrict__ sW,
                                                           const float *__restrict__ sW2, float *__restrict__ h_out,
-                                                          long ldh, int T, int B, int reverse, int act, int gate_act)
+                                                          long ldh, int T, int B, int reverse, int act, int gate_act,
+                                                          const int *__restrict__ lens)
 {
     constexpr int NW = N / NWAVES;                                 // neurons per wave
     constexpr int NT = 64 * NWAVES;                                // threads per workgroup
@@ -177,9 +179,10 @@ __global__ void __launch_bounds__(64 * NWAVES, (NWAVES + 3) / 4) gru_mfma_kernel
             if (piece * 64 < BLKF4) {                          // wave-uniform
                 const int idx = piece * 64 + lane;
                 const int kk = idx / (4 * ROWF4), r = idx % (4 * ROWF4), c = r / ROWF4, f4 = r % ROWF4;
-                const int ss = min(s0 + kk, T - 1);
-                const int tt = reverse ? T - 1 - ss : ss;
                 const int bc = min(b0 + c, B - 1);
+                const int Tc = lens ? min(max(lens[bc], 1), T) : T;      // ragged batch: see gru_fused.hip
+                const int ss = min(s0 + kk, Tc - 1);
+                const int tt = reverse ? Tc - 1 - ss : ss;
                 const float *src = vI + ((size_t)tt * B + bc) * (3 * N) + 4 * f4;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)&vbuf[slot * BLKF + piece * 256],
@@ -198,8 +201,9 @@ __global__ void __launch_bounds__(64 * NWAVES, (NWAVES + 3) / 4) gru_mfma_kernel
             const int idx = tid + NT * j;
             const int kk = idx / N, r = idx % N, c = r / (N / 4), f4 = r % (N / 4);
             const int ss = s0 + kk;
-            if (idx < OF4 && ss < T && b0 + c < B) {
-                const int tt = reverse ? T - 1 - ss : ss;
+            const int Tc = (lens && b0 + c < B) ? min(max(lens[b0 + c], 1), T) : T;
+            if (idx < OF4 && ss < Tc && b0 + c < B) {
+                const int tt = reverse ? Tc - 1 - ss : ss;
                 const float4 v = *reinterpret_cast<const float4 *>(&obuf[slot * (KB * 4 * N) + 4 * idx]);
                 float *dst = h_out + ((size_t)tt * B + b0 + c) * ldh + 4 * f4;
                 if (vec_store) *reinterpret_cast<float4 *>(dst) = v;
@@ -286,31 +290,31 @@ __global__ void __launch_bounds__(64 * NWAVES, (NWAVES + 3) / 4) gru_mfma_kernel
 // N = 144 (the middle layer of models/pretrained.pkl) needs 12 waves; only the tanh/sigmoid instantiation fits the
 // 170-register budget of 3 waves/SIMD without scratch, so other activations return false and take the generic kernel.
 static bool launch_gru_mfma144(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
-                               int reverse, int act, int gate_act, hipStream_t s)
+                               int reverse, int act, int gate_act, const int *lens, hipStream_t s)
 {
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return false;
     hipLaunchKernelGGL((gru_mfma_kernel<144, SLK_ACT_TANH, SLK_ACT_SIGMOID, 12>), dim3((B + 3) / 4), dim3(64 * 12), 0, s,
-                       vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act);
+                       vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, lens);
     return true;
 }
 
 template <int N>
 static int launch_gru_mfma(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
-                           int reverse, int act, int gate_act, hipStream_t s)
+                           int reverse, int act, int gate_act, const int *lens, hipStream_t s)
 {
     dim3 grid((B + 3) / 4), block(256);
     if (act == SLK_ACT_TANH && gate_act == SLK_ACT_SIGMOID)
         hipLaunchKernelGGL((gru_mfma_kernel<N, SLK_ACT_TANH, SLK_ACT_SIGMOID>), grid, block, 0, s, vI, sW, sW2, h_out, ldh,
-                           T, B, reverse, act, gate_act);
+                           T, B, reverse, act, gate_act, lens);
     else
         hipLaunchKernelGGL((gru_mfma_kernel<N, -1, -1>), grid, block, 0, s, vI, sW, sW2, h_out, ldh, T, B, reverse, act,
-                           gate_act);
+                           gate_act, lens);
     return slk_launch_status();
 }
 
-extern "C" int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh,
-                                        int T, int B, int n, int reverse, int act, int gate_act, int force_generic,
-                                        slk_stream_t stream)
+static int gru_recurrent_entry(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
+                               int n, int reverse, int act, int gate_act, int force_generic, const int32_t *lens,
+                               slk_stream_t stream)
 {
     if (!vI || !sW || !sW2 || !h_out || T < 1 || B < 1 || n < 1 || ldh < n || !slk_act_valid(act) ||
         !slk_act_valid(gate_act))
@@ -318,16 +322,16 @@ extern "C" int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const 
     hipStream_t s = slk_stream(stream);
     if (!force_generic) {
         switch (n) {
-        case 16: return launch_gru_mfma<16>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
-        case 32: return launch_gru_mfma<32>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
-        case 48: return launch_gru_mfma<48>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
-        case 64: return launch_gru_mfma<64>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
-        case 80: return launch_gru_mfma<80>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
-        case 96: return launch_gru_mfma<96>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
-        case 112: return launch_gru_mfma<112>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
-        case 128: return launch_gru_mfma<128>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s);
+        case 16: return launch_gru_mfma<16>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, lens, s);
+        case 32: return launch_gru_mfma<32>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, lens, s);
+        case 48: return launch_gru_mfma<48>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, lens, s);
+        case 64: return launch_gru_mfma<64>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, lens, s);
+        case 80: return launch_gru_mfma<80>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, lens, s);
+        case 96: return launch_gru_mfma<96>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, lens, s);
+        case 112: return launch_gru_mfma<112>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, lens, s);
+        case 128: return launch_gru_mfma<128>(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, lens, s);
         case 144:
-            if (launch_gru_mfma144(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, s)) return slk_launch_status();
+            if (launch_gru_mfma144(vI, sW, sW2, h_out, ldh, T, B, reverse, act, gate_act, lens, s)) return slk_launch_status();
             break;
         default: break;
         }
@@ -335,8 +339,24 @@ extern "C" int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const 
     size_t lds = sizeof(float) * 3 * (size_t)n;
     if (lds > 64 * 1024) return SLK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(gru_generic_kernel, dim3(B), dim3(256), lds, s, vI, sW, sW2, h_out, ldh, T, B, n, reverse, act,
-                       gate_act);
+                       gate_act, lens);
     return slk_launch_status();
+}
+
+extern "C" int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh,
+                                        int T, int B, int n, int reverse, int act, int gate_act, int force_generic,
+                                        slk_stream_t stream)
+{
+    return gru_recurrent_entry(vI, sW, sW2, h_out, ldh, T, B, n, reverse, act, gate_act, force_generic, nullptr, stream);
+}
+
+// Ragged batch: lens[b] in [1, T] valid steps of chunk b (see slk_gru_fused_ragged_f32).
+extern "C" int slk_gru_recurrent_ragged_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh,
+                                            int T, int B, int n, int reverse, int act, int gate_act, const int32_t *lens,
+                                            slk_stream_t stream)
+{
+    if (!lens) return SLK_ERR_INVALID_ARG;
+    return gru_recurrent_entry(vI, sW, sW2, h_out, ldh, T, B, n, reverse, act, gate_act, 0, lens, stream);
 }
 
 extern "C" int slk_gru_recurrent_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T,

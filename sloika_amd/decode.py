@@ -99,10 +99,12 @@ def viterbi_batch(post, klen, skip_pen=0.0, log=False, nbase=4, min_prob=None, w
     return scores, paths, lens
 
 
-def viterbi_logits_batch(logits, stats, klen, T, B, ld=None, skip_pen=0.0, nbase=4, min_prob=1e-5, workspace=None):
+def viterbi_logits_batch(logits, stats, klen, T, B, ld=None, skip_pen=0.0, nbase=4, min_prob=1e-5, workspace=None,
+                         lengths=None):
     """basecall.decode_post over the batch axis, fed with the Softmax layer's LOGITS (rows (t,b) of nstate floats, `ld`
     floats apart) and their row statistics (layers.Softmax.logits_and_stats): softmax, prepare_post, log and Viterbi in one pass over the logits.
-    Bit-identical to viterbi_batch(softmax(logits), min_prob=min_prob)."""
+    Bit-identical to viterbi_batch(softmax(logits), min_prob=min_prob).  `lengths`: optional int32 device tensor [B] for a
+    ragged batch (chunk b decoded over its first lengths[b] steps only)."""
     import torch
     from . import device as D
     if klen < 3:
@@ -121,9 +123,17 @@ def viterbi_logits_batch(logits, stats, klen, T, B, ld=None, skip_pen=0.0, nbase
     lens = torch.empty(B, dtype=torch.int32, device=logits.device)
     nk = nbase ** klen
     with profiler.region("viterbi", 0.0, float(T) * B * (4.0 * S + 2.0 * nk)):
-        rc = L.slk_viterbi_kmer_logits_f32(logits.data_ptr(), ld, stats.data_ptr(), T, B, nbase, klen, float(skip_pen),
-                                           float(min_prob), ws.data_ptr(), nbytes, scores.data_ptr(), paths.data_ptr(),
-                                           lens.data_ptr(), D.stream_ptr())
+        if lengths is None:
+            rc = L.slk_viterbi_kmer_logits_f32(logits.data_ptr(), ld, stats.data_ptr(), T, B, nbase, klen, float(skip_pen),
+                                               float(min_prob), ws.data_ptr(), nbytes, scores.data_ptr(),
+                                               paths.data_ptr(), lens.data_ptr(), D.stream_ptr())
+        else:
+            if lengths.dtype != torch.int32 or lengths.numel() != B or not lengths.is_cuda:
+                raise ValueError("lengths must be an int32 device tensor with one entry per chunk")
+            rc = L.slk_viterbi_kmer_logits_ragged_f32(logits.data_ptr(), ld, stats.data_ptr(), T, B, nbase, klen,
+                                                      float(skip_pen), float(min_prob), lengths.data_ptr(), ws.data_ptr(),
+                                                      nbytes, scores.data_ptr(), paths.data_ptr(), lens.data_ptr(),
+                                                      D.stream_ptr())
     _lib.check(rc, "decode.viterbi_logits")
     return scores, paths, lens
 

@@ -119,6 +119,28 @@ def _projection(owner, x, W, b, ws_ptr, rows, k, n_out, stage, name):
     _lib.check(rc, name)
 
 
+class ragged(object):
+    """Context for a ragged batch: `with ragged(lengths): net.run(x)` runs a zero-padded batch [T, B, F] whose chunk b is
+    only lengths[b] steps long (whole reads of different lengths).  Time-local layers are unaffected (they compute the
+    padding too), Convolution maps the lengths through its stride, and recurrent layers in reverse time start every chunk
+    at ITS last step -- so each chunk gets exactly what a run on the unpadded chunk alone would produce; rows beyond a
+    chunk's length hold unspecified values."""
+    current = None               # int32 device tensor [B] of the tensor currently flowing through the network, or None
+
+    def __init__(self, lengths):
+        import torch
+        from . import device as D
+        self.lengths = torch.as_tensor(np.ascontiguousarray(lengths, dtype=np.int32)).to(D.device())
+
+    def __enter__(self):
+        self.saved, ragged.current = ragged.current, self.lengths
+        return self
+
+    def __exit__(self, *exc):
+        ragged.current = self.saved
+        return False
+
+
 def _check_input(x, insize):
     import torch
     if not isinstance(x, torch.Tensor) or x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda:
@@ -556,6 +578,11 @@ class Convolution(Layer):
                                            self.winlen, self.stride, self.padding[0], self.padding[1],
                                            activation.act_id(self.fun), _stream())
         _lib.check(rc, "Convolution")
+        if ragged.current is not None:
+            # zero padding past a chunk's end is what the unpadded convolution would have seen, so its first
+            # out_len(length) output steps are exact; map the lengths through the stride (conv.py:66-77)
+            ragged.current = ((ragged.current + (self.padding[0] + self.padding[1] - self.winlen)) // self.stride + 1
+                              ).clamp_(min=1).to(ragged.current.dtype)
         return y
 
     def _forward(self, x, out, reverse):
@@ -634,6 +661,8 @@ class Lstm(RNN):
         y = _alloc_out(x, T, B, self.size, out)
         L = _lib.lib()
         n, rows = self.size, T * B
+        if reverse and ragged.current is not None:
+            raise NotImplementedError("ragged batches through a reversed Lstm are not supported (use Gru or equal lengths)")
         nbytes = L.slk_lstm_workspace_bytes(T, B, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         # the two halves of slk_lstm_f32, timed separately: projection GEMM into the workspace, then the recurrence
@@ -747,15 +776,26 @@ class Gru(RNN):
         y = _alloc_out(x, T, B, self.size, out)
         L = _lib.lib()
         n, rows = self.size, T * B
+        # ragged batch: only a reversed scan needs to know where each chunk ends (forward scans are causal)
+        lens = ragged.current if reverse else None
+        if lens is not None and (lens.numel() != B or lens.device != x.device):
+            raise ValueError("ragged lengths do not match the batch")
         # one persistent kernel (projection waves + recurrent waves) where an instantiation exists (its projection half
         # runs as an fp16 3-term split, so SLOIKA_AMD_EXACT_F32=1 takes the two-kernel all-fp32 path instead) ...
         if SPLIT_F16:
             with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
                                  f16x3_flops=6.0 * rows * n * self.insize) as reg:
-                rc = L.slk_gru_fused_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
-                                         self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
-                                         y.data_ptr(), _row_stride(y), T, B, self.insize, n, int(reverse),
-                                         activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
+                if lens is None:
+                    rc = L.slk_gru_fused_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
+                                             self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
+                                             y.data_ptr(), _row_stride(y), T, B, self.insize, n, int(reverse),
+                                             activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
+                else:
+                    rc = L.slk_gru_fused_ragged_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
+                                                    self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
+                                                    self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), T, B,
+                                                    self.insize, n, int(reverse), activation.act_id(self.fun),
+                                                    activation.act_id(self.gatefun), lens.data_ptr(), _stream())
                 if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
                     reg.cancel()
             if rc != _lib.SLK_ERR_UNSUPPORTED:
@@ -766,9 +806,15 @@ class Gru(RNN):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 3 * n, "gru_input_gemm", "Gru")
         with profiler.region("gru_recurrent", 6.0 * rows * n * n, 4.0 * rows * 4 * n):
-            rc = L.slk_gru_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
-                                         y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
-                                         activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
+            if lens is None:
+                rc = L.slk_gru_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
+                                             y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
+                                             activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
+            else:
+                rc = L.slk_gru_recurrent_ragged_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
+                                                    y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
+                                                    activation.act_id(self.fun), activation.act_id(self.gatefun),
+                                                    lens.data_ptr(), _stream())
         _lib.check(rc, "Gru")
         return y
 

@@ -67,6 +67,39 @@ class Basecaller(object):
         return decode.viterbi_batch(post, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
                                     min_prob=self.min_prob, workspace=self._ws)
 
+    def call_reads(self, signals, trim=(0, 0), open_pore_fraction=0.0):
+        """Whole reads of different lengths in ONE batch (the reference calls them one at a time, basecall.py:88-121):
+        `signals` is a list of 1-D float arrays (already scaled, e.g. fast5.Fast5.get_read()); each is trimmed as raw_worker does, median/MAD
+        normalised over its own length, zero-padded to the longest, and the network + decoder run on the padded batch
+        with per-read lengths (layers.ragged), so every read gets exactly what a batch-1 call would give.
+        -> device tensors (scores [B], paths [B, T'max] (-1 padded), lens [B]) and the per-read sample counts."""
+        import torch
+        from . import device as D, util
+        net = self.network
+        if not isinstance(net, layers.Serial) or type(net.layers[-1]) is not layers.Softmax:
+            raise ValueError("call_reads needs a Serial network ending in a Softmax layer")
+        # basecall.py:111-112: trim_open_pore (which also cuts the read to whole 100-sample windows), then trim_array
+        sigs = [util.trim_array(np.asarray(batch.trim_open_pore(np.asarray(s, dtype=np.float32), open_pore_fraction)), *trim)
+                for s in signals]
+        nsamp = [len(s) for s in sigs]
+        if min(nsamp) < 1:
+            raise ValueError("empty read after trimming")
+        B, lmax = len(sigs), max(nsamp)
+        x = torch.zeros((lmax, B, 1), dtype=torch.float32, device=D.device())
+        for b, sig in enumerate(sigs):                       # per-read normalisation (basecall.py:117-118)
+            x[:nsamp[b], b:b + 1, :] = batch.normalise_chunks(D.to_dev(sig).reshape(1, -1), 'per-chunk', out_layout='network')
+        with layers.ragged(nsamp) as ctx:
+            hid = x
+            for layer in net.layers[:-1]:
+                hid = layer._forward(hid, None, False)
+            lengths = layers.ragged.current
+            logits, stats, ld = net.layers[-1].logits_and_stats(hid)
+        T = hid.shape[0]
+        scores, paths, lens = decode.viterbi_logits_batch(logits, stats, self.kmer_len, T, B, ld=ld, skip_pen=self.skip,
+                                                          nbase=self.nbase, min_prob=self.min_prob, workspace=self._ws,
+                                                          lengths=lengths.contiguous())
+        return scores, paths, lens, nsamp
+
     def call_chunks_host(self, chunks):
         scores, paths, lens = self.call_chunks(chunks)
         scores, paths, lens = scores.cpu().numpy(), paths.cpu().numpy(), lens.cpu().numpy()

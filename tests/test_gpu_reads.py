@@ -79,3 +79,54 @@ def test_fp16_split_projections_do_not_change_the_call():
         layers.SPLIT_F16, layers.Softmax.split_f16 = saved
     assert out[0][1] == out[1][1]
     assert out[0][0] == pytest.approx(out[1][0], rel=1e-5) and out[0][0] != 0.0
+
+
+def test_ragged_batch_of_reads_equals_one_by_one():
+    """Whole reads of different lengths in one padded batch (pipeline.Basecaller.call_reads: per-read lengths through the
+    conv stride, reversed GRU scans starting at each read's own end, per-read Viterbi) must reproduce, bit for bit, what
+    every read gets on its own in whole-read mode (basecall.raw_read_worker = the reference's raw_worker, batch 1)."""
+    need_gpu()
+    from sloika_amd import basecall, models, pipeline
+    g = np.load(os.path.join(GOLDEN, "reads.npz"))
+    net = models.from_weights_npz(os.path.join(GOLDEN, "pretrained_weights.npz"))
+    calc_post = net.compile()
+    sig = {}
+    for n in (5, 3):
+        dig, off, rng, _rate = g["meta_%d" % n]
+        sig[n] = ((g["adc_%d" % n].astype(np.float64) + off) * (rng / dig)).astype(np.float32)
+    reads = [sig[5], sig[3][1000:7777], sig[5][:9001], sig[3], sig[5][20000:20640], sig[3][30000:33003]]
+    bc = pipeline.Basecaller(net, kmer_len=5, min_prob=1e-5, skip=5.0)
+    scores, paths, lens, nsamp = bc.call_reads(reads)
+    scores, paths, lens = scores.cpu().numpy(), paths.cpu().numpy(), lens.cpu().numpy()
+    assert nsamp == [len(r) - len(r) % 100 for r in reads]          # trim_open_pore keeps whole 100-sample windows
+    for b, r in enumerate(reads):
+        _, score1, call1, n1 = basecall.raw_read_worker(calc_post, r, trim=(0, 0), kmer_len=5, skip=5.0, name="r%d" % b)
+        assert n1 == nsamp[b]
+        assert int(lens[b]) == len(call1), b
+        assert paths[b, :lens[b]].tolist() == [int(c) for c in call1], b
+        assert (paths[b, lens[b]:] == -1).all()
+        assert float(scores[b]) == float(score1), b
+    # the same reads in another order and batch composition give the same calls
+    scores2, paths2, lens2, _ = bc.call_reads([reads[3], reads[0]])
+    assert paths2.cpu().numpy()[1, :int(lens2[1])].tolist() == paths[0, :lens[0]].tolist()
+    assert float(scores2[0]) == float(scores[3])
+
+
+@pytest.mark.parametrize("model", ["raw_0.98_rgrgr", "baseline_raw_gru", "raw_1.00_rGr"])
+def test_ragged_batch_other_architectures(model):
+    """Same property through the fused GRU layer kernel (rgrgr: five 96-wide layers of alternating direction), through
+    birnn stacks with FeedForward layers in between (stride 2), and through the zero-padded 110/142-wide layers."""
+    need_gpu()
+    from sloika_amd import basecall, models, pipeline
+    net = models.randomise_zero_layers(models.build_model(model, klen=5, sd=0.5, seed=7))
+    calc_post = net.compile()
+    chunks = pipeline.synthetic_chunks(5, chunk_len=4000, seed=99)
+    reads = [chunks[0], chunks[1][:1700], chunks[2][:3333], chunks[3][:800], np.concatenate([chunks[4], chunks[0][:1234]])]
+    bc = pipeline.Basecaller(net, kmer_len=5, min_prob=1e-5, skip=0.0)
+    scores, paths, lens, nsamp = bc.call_reads(reads)
+    scores, paths, lens = scores.cpu().numpy(), paths.cpu().numpy(), lens.cpu().numpy()
+    for b, r in enumerate(reads):
+        _, score1, call1, n1 = basecall.raw_read_worker(calc_post, r, trim=(0, 0), kmer_len=5, skip=0.0, name="r%d" % b)
+        assert n1 == nsamp[b] and int(lens[b]) == len(call1), (model, b)
+        assert paths[b, :lens[b]].tolist() == [int(c) for c in call1], (model, b)
+        assert float(scores[b]) == float(score1), (model, b)

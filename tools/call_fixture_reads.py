@@ -53,5 +53,37 @@ def main():
                 n, skip, nsamp, len(seq), len(stored), dt, d, 1.0 - d / max(len(seq), len(stored)), seq[:50]))
 
 
+def ragged_throughput():
+    """Whole reads one at a time (the reference's mode) vs the same reads as one ragged batch."""
+    import torch
+    from sloika_amd import basecall, models, pipeline
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reads.npz"))
+    net = models.from_weights_npz(os.path.join(ROOT, "tests", "golden", "pretrained_weights.npz"))
+    calc_post = net.compile()
+    sig = {}
+    for n in (5, 3):
+        dig, off, rng, rate = g["meta_%d" % n]
+        sig[n] = ((g["adc_%d" % n].astype(np.float64) + off) * (rng / dig)).astype(np.float32)
+    rs = np.random.RandomState(1)
+    reads = []
+    for i in range(64):                                   # 64 reads of 8k..51k samples cut from the two example reads
+        src = sig[3] if i % 2 else sig[5]
+        n = int(rs.randint(8000, len(src)))
+        reads.append(src[:n])
+    total = sum(len(r) - len(r) % 100 for r in reads)
+    bc = pipeline.Basecaller(net, kmer_len=5, min_prob=1e-5, skip=5.0)
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for r in reads:
+            basecall.raw_read_worker(calc_post, r, trim=(0, 0), kmer_len=5, skip=5.0)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        out = bc.call_reads(reads)
+        out[1].cpu()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("64 whole reads, %d samples: one by one %.3f s (%.2f M samples/s), one ragged batch %.3f s (%.2f M samples/s)" % (
+        total, t1 - t0, total / (t1 - t0) / 1e6, t2 - t1, total / (t2 - t1) / 1e6))
+
+
 if __name__ == "__main__":
     main()
+    ragged_throughput()
