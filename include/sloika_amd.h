@@ -192,6 +192,9 @@ int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2,
  * ------------------------------------------------------------------------------------------------------- */
 int slk_lstm_recurrent_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
                            int n, int reverse, int act, int gate_act, slk_stream_t stream);
+int slk_lstm_recurrent_ragged_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
+                                  int n, int reverse, int act, int gate_act, const int32_t *lens /* see slk_gru_fused_ragged_f32 */,
+                                  slk_stream_t stream);
 size_t slk_lstm_workspace_bytes(int T, int B, int n);
 int slk_lstm_f32(const float *x, long ldx, const float *iW, const float *sW, const float *bias, const float *p,
                  float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,

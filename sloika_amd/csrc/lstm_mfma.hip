@@ -39,7 +39,7 @@ __device__ __forceinline__ float scatter_sum4(f32x4 a, int slice)
 template <int N>
 __global__ void __launch_bounds__(256) lstm_mfma_kernel(const float *__restrict__ vW, const float *__restrict__ sW,
                                                         const float *__restrict__ peep, float *__restrict__ out, long ldo,
-                                                        int T, int B, int reverse)
+                                                        int T, int B, int reverse, const int *__restrict__ lens)
 {
     static_assert(N % 16 == 0 && N <= 64, "lstm_mfma_kernel: sizes 16, 32, 48, 64");
     constexpr int NW = N / 4;                                   // neurons per wave (<= 16)
@@ -87,9 +87,10 @@ __global__ void __launch_bounds__(256) lstm_mfma_kernel(const float *__restrict_
         for (int j = 0; j < NDMA; j++) {
             const int idx = (j * 4 + wave) * 64 + lane;          // float4 index inside the block image
             const int kk = idx / (4 * ROWF4), r = idx % (4 * ROWF4), c = r / ROWF4, f4 = r % ROWF4;
-            const int ss = min(s0 + kk, T - 1);
-            const int tt = reverse ? T - 1 - ss : ss;
             const int bc = min(b0 + c, B - 1);
+            const int Tc = lens ? min(max(lens[bc], 1), T) : T;          // ragged batch: see gru_fused.hip
+            const int ss = min(s0 + kk, Tc - 1);
+            const int tt = reverse ? Tc - 1 - ss : ss;
             const float *src = vW + ((size_t)tt * B + bc) * (4 * N) + 4 * f4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)&vbuf[slot][(j * 4 + wave) * 256], 16, 0, 0);
@@ -103,8 +104,9 @@ __global__ void __launch_bounds__(256) lstm_mfma_kernel(const float *__restrict_
             const int idx = tid + 256 * j;
             const int kk = idx / N, r = idx % N, c = r / (N / 4), f4 = r % (N / 4);
             const int ss = s0 + kk;
-            if (idx < OF4 && ss < T && b0 + c < B) {
-                const int tt = reverse ? T - 1 - ss : ss;
+            const int Tc = (lens && b0 + c < B) ? min(max(lens[b0 + c], 1), T) : T;
+            if (idx < OF4 && ss < Tc && b0 + c < B) {
+                const int tt = reverse ? Tc - 1 - ss : ss;
                 const float4 v = *reinterpret_cast<const float4 *>(&obuf[slot][4 * idx]);
                 float *dst = out + ((size_t)tt * B + b0 + c) * ldo + 4 * f4;
                 if (vec_store) *reinterpret_cast<float4 *>(dst) = v;
@@ -162,23 +164,23 @@ __global__ void __launch_bounds__(256) lstm_mfma_kernel(const float *__restrict_
 
 template <int N>
 static int launch_lstm_mfma(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
-                            int reverse, hipStream_t s)
+                            int reverse, const int *lens, hipStream_t s)
 {
-    hipLaunchKernelGGL((lstm_mfma_kernel<N>), dim3((B + 3) / 4), dim3(256), 0, s, vW, sW, p, out, ldo, T, B, reverse);
+    hipLaunchKernelGGL((lstm_mfma_kernel<N>), dim3((B + 3) / 4), dim3(256), 0, s, vW, sW, p, out, ldo, T, B, reverse, lens);
     return slk_launch_status();
 }
 
 // Returns SLK_ERR_UNSUPPORTED when the portable kernel has to be used.
 int slk_lstm_mfma_dispatch(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B, int n,
-                           int reverse, int act, int gate_act, hipStream_t s)
+                           int reverse, int act, int gate_act, const int *lens, hipStream_t s)
 {
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(vW) & 15) != 0) return SLK_ERR_UNSUPPORTED;
     switch (n) {
-    case 16: return launch_lstm_mfma<16>(vW, sW, p, out, ldo, T, B, reverse, s);
-    case 32: return launch_lstm_mfma<32>(vW, sW, p, out, ldo, T, B, reverse, s);
-    case 48: return launch_lstm_mfma<48>(vW, sW, p, out, ldo, T, B, reverse, s);
-    case 64: return launch_lstm_mfma<64>(vW, sW, p, out, ldo, T, B, reverse, s);
+    case 16: return launch_lstm_mfma<16>(vW, sW, p, out, ldo, T, B, reverse, lens, s);
+    case 32: return launch_lstm_mfma<32>(vW, sW, p, out, ldo, T, B, reverse, lens, s);
+    case 48: return launch_lstm_mfma<48>(vW, sW, p, out, ldo, T, B, reverse, lens, s);
+    case 64: return launch_lstm_mfma<64>(vW, sW, p, out, ldo, T, B, reverse, lens, s);
     default: return SLK_ERR_UNSUPPORTED;
     }
 }

@@ -70,11 +70,12 @@ __global__ void __launch_bounds__(256) gru_generic_kernel(const float *__restric
 __global__ void __launch_bounds__(256) lstm_generic_kernel(const float *__restrict__ vW, const float *__restrict__ sW,
                                                            const float *__restrict__ p, float *__restrict__ out,
                                                            long ldo, int T, int B, int n, int reverse, int act,
-                                                           int gate_act)
+                                                           int gate_act, const int *__restrict__ lens)
 {
     extern __shared__ float sm[];
     float *o_prev = sm, *cell = sm + n, *sum = sm + 2 * n; // sum: [n][4]
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    if (lens) T = min(max(lens[b], 1), T);                   // ragged batch: this chunk's own length
     for (int j = tid; j < n; j += nt) { o_prev[j] = 0.0f; cell[j] = 0.0f; }
     __syncthreads();
     for (int s = 0; s < T; s++) {
@@ -386,22 +387,37 @@ extern "C" int slk_gru_f32(const float *x, long ldx, const float *iW, const floa
 }
 
 int slk_lstm_mfma_dispatch(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B, int n,
-                           int reverse, int act, int gate_act, hipStream_t s);          // lstm_mfma.hip
+                           int reverse, int act, int gate_act, const int *lens, hipStream_t s);          // lstm_mfma.hip
 
-extern "C" int slk_lstm_recurrent_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T,
-                                      int B, int n, int reverse, int act, int gate_act, slk_stream_t stream)
+static int lstm_recurrent_entry(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B, int n,
+                                int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream)
 {
     if (!vW || !sW || !out || T < 1 || B < 1 || n < 1 || ldo < n || !slk_act_valid(act) || !slk_act_valid(gate_act))
         return SLK_ERR_INVALID_ARG;
     {
-        const int rc = slk_lstm_mfma_dispatch(vW, sW, p, out, ldo, T, B, n, reverse, act, gate_act, slk_stream(stream));
+        const int rc = slk_lstm_mfma_dispatch(vW, sW, p, out, ldo, T, B, n, reverse, act, gate_act, lens, slk_stream(stream));
         if (rc != SLK_ERR_UNSUPPORTED) return rc;               // lstm_mfma.hip: sizes 16..64, tanh / sigmoid
     }
     size_t lds = sizeof(float) * 6 * (size_t)n;
     if (lds > 64 * 1024) return SLK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(lstm_generic_kernel, dim3(B), dim3(256), lds, slk_stream(stream), vW, sW, p, out, ldo, T, B, n,
-                       reverse, act, gate_act);
+                       reverse, act, gate_act, lens);
     return slk_launch_status();
+}
+
+extern "C" int slk_lstm_recurrent_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T,
+                                      int B, int n, int reverse, int act, int gate_act, slk_stream_t stream)
+{
+    return lstm_recurrent_entry(vW, sW, p, out, ldo, T, B, n, reverse, act, gate_act, nullptr, stream);
+}
+
+// Ragged batch: lens[b] in [1, T] valid steps of chunk b (see slk_gru_fused_ragged_f32).
+extern "C" int slk_lstm_recurrent_ragged_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T,
+                                             int B, int n, int reverse, int act, int gate_act, const int32_t *lens,
+                                             slk_stream_t stream)
+{
+    if (!lens) return SLK_ERR_INVALID_ARG;
+    return lstm_recurrent_entry(vW, sW, p, out, ldo, T, B, n, reverse, act, gate_act, lens, stream);
 }
 
 extern "C" size_t slk_lstm_workspace_bytes(int T, int B, int n)

@@ -661,16 +661,21 @@ class Lstm(RNN):
         y = _alloc_out(x, T, B, self.size, out)
         L = _lib.lib()
         n, rows = self.size, T * B
-        if reverse and ragged.current is not None:
-            raise NotImplementedError("ragged batches through a reversed Lstm are not supported (use Gru or equal lengths)")
+        lens = ragged.current if reverse else None       # a reversed scan starts every chunk at its own last step
         nbytes = L.slk_lstm_workspace_bytes(T, B, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         # the two halves of slk_lstm_f32, timed separately: projection GEMM into the workspace, then the recurrence
         _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 4 * n, "lstm_input_gemm", "Lstm")
         with profiler.region("lstm_recurrent", 8.0 * rows * n * n, 4.0 * rows * 5 * n):
-            rc = L.slk_lstm_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(), y.data_ptr(),
-                                          _row_stride(y), T, B, n, int(reverse), activation.act_id(self.fun),
-                                          activation.act_id(self.gatefun), _stream())
+            if lens is None:
+                rc = L.slk_lstm_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(),
+                                              y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
+                                              activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
+            else:
+                rc = L.slk_lstm_recurrent_ragged_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(),
+                                                     y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
+                                                     activation.act_id(self.fun), activation.act_id(self.gatefun),
+                                                     lens.data_ptr(), _stream())
         _lib.check(rc, "Lstm")
         return y
 

@@ -109,6 +109,34 @@ def test_lstm_vs_oracle(oracle, I, n, bias, peep, T, B, reverse):
     np.testing.assert_allclose(net.compile()(x), oracle.run_network(net.spec(), x), atol=TOL)
 
 
+@pytest.mark.parametrize("n", [64, 32, 7])
+def test_lstm_ragged_reverse_vs_oracle(oracle, n):
+    """Ragged batch through a bidirectional Lstm: chunk b, padded to T, must see exactly what it sees alone at its own
+    length (the reversed scan starts at the chunk's own last step); steps past the end are not compared."""
+    torch = need_gpu()
+    from sloika_amd import layers
+    rs = np.random.RandomState(n)
+    I, T = 6, 37
+    lens = [37, 1, 20, 8, 36, 9, 2]
+    x = np.zeros((T, len(lens), I), dtype=np.float32)
+    for b, tb in enumerate(lens):
+        x[:tb, b] = rs.normal(size=(tb, I))
+    ls = []
+    for _ in range(2):
+        l = layers.Lstm(I, n)
+        l.iW.set_value((rs.normal(size=(4 * n, I)) / np.sqrt(I + n)).astype(np.float32))
+        l.sW.set_value((rs.normal(size=(4 * n, n)) / np.sqrt(2 * n)).astype(np.float32))
+        l.b.set_value(rs.normal(size=4 * n).astype(np.float32))
+        l.p.set_value((rs.normal(size=(3, n)) / np.sqrt(n)).astype(np.float32))
+        ls.append(l)
+    net = layers.birnn(ls[0], ls[1])
+    with layers.ragged(lens):
+        y = net.run(torch.from_numpy(x).cuda()).cpu().numpy()
+    for b, tb in enumerate(lens):
+        want = oracle.run_network(net.spec(), x[:tb, b:b + 1])
+        np.testing.assert_allclose(y[:tb, b:b + 1], want, atol=TOL, err_msg="chunk %d" % b)
+
+
 def test_layer_input_validation():
     torch = need_gpu()
     from sloika_amd import layers
