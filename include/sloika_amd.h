@@ -277,6 +277,55 @@ int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *e
                                   const double *prior_initial, const double *prior_final, void *workspace,
                                   const int64_t *ws_off, float *score_out, int32_t *path_out, slk_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * f2. The training step: bin/train_network.py:124-142 (`wrap_network`: loss, accuracy, th.grad, updates.adam) and
+ * sloika/updates.py:9-103.  The reference crosses into Theano once per batch (`fg(indata, labels, weights, rate)`,
+ * train_network.py:308); its gradient comes from automatic differentiation, here the reverse pass of Convolution
+ * (layers.py:417-419), Gru.step (layers.py:1010-1021) and Softmax (layers.py:309-314) is explicit (csrc/train.hip).
+ * Rows are m = t*B + b throughout.
+ *
+ * Gate recompute (forward values the reverse scan needs, recomputed time-parallel from the finished forward pass):
+ *   slk_train_pack_xh_f32:  xh[m] = [x[m] (I) | h_prev[m] (N)], h_prev = h at the previous scan step, 0 at the scan start
+ *   slk_train_pack_xrh_f32: xrh[m] = [x[m] | r[m] * h_prev[m]] with zr[m] = [z | r] ([M][2N])
+ *   then zr = sigmoid(xh . [iW[:2n] | sW]^T + b[:2n]) and c = tanh(xrh . [iW[2n:] | sW2]^T + b[2n:]) are plain
+ *   slk_gemm_bias_act_f16x3 / slk_gemm_bias_act_f32 calls.
+ * slk_gru_backward_f32: the reverse scan.  dy:[T][B] rows lddy apart = dL/dh from the layer above; writes
+ *   da:[M][3n] = dL/dvI = [daz | dar | dac].  n in {16,32,48,64,96,112,128,144}, tanh / sigmoid, else SLK_ERR_UNSUPPORTED.
+ *   Weight gradients follow as contractions over m (slk_gemm_tn_f32): diW = da^T x, dsW = da[:, :2n]^T h_prev,
+ *   dsW2 = da[:, 2n:]^T (r*h_prev), db = da^T 1; and dL/dx = da . iW (slk_gemm_bias_act_f32 with iW^T).
+ * slk_softmax_xent_grad_f32: loss terms and dL/dlogits of train_network.py:128-136, in place over the logits written by
+ *   slk_linear_rowstats_* (stats:[M][2] = max, 1/sum).  loss_rows[m] and correct_rows[m] are already divided by the
+ *   number of counted positions (T - 2 drop) * B, so their sums are the data term of the loss and the accuracy.
+ *   Columns nstate..ld-1 of every row are set to zero.  labels must lie in [0, nstate).
+ * slk_reduce_sum_f32: out[0] = sum x (square = 0) or sum x^2 (square = 1: updates.param_sqr), float64, fixed order.
+ * slk_gemm_tn_f32: C[N1][N2] (rows ldc apart) = A^T B, A:[M][N1] rows lda apart, B:[M][N2] rows ldb apart.
+ * slk_act_backward_f32: out = dy * fun'(pre-activation) written through the OUTPUT y; linear/tanh/sigmoid/relu/elu.
+ * slk_train_im2col_cin1_f32: window rows of a one-feature Convolution, cols:[Tout*B][winlen] (dW = dpre^T cols).
+ * slk_adamski_update_f32: updates.py:77-87 over flat buffers with this step's lr_t / momentum_decay (updates.py:73-76);
+ *   g = clip(grad * gscale + 2 l2 param).   slk_sgd_update_f32: updates.py:9-33.
+ * ------------------------------------------------------------------------------------------------------- */
+int slk_train_pack_xh_f32(const float *x, long ldx, const float *h, long ldh, float *xh, int T, int B, int insize, int n,
+                          int reverse, slk_stream_t stream);
+int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *xrh, long M, int insize, int n, slk_stream_t stream);
+int slk_gru_backward_f32(const float *dy, long lddy, const float *xh, int insize, const float *zr, const float *c,
+                         const float *sW, const float *sW2, float *da, int T, int B, int n, int reverse, int act,
+                         int gate_act, slk_stream_t stream);
+int slk_softmax_xent_grad_f32(float *logits, long ld, const float *stats, const int32_t *labels, const float *weights, int T,
+                              int B, int nstate, int drop, float min_prob, float *loss_rows, float *correct_rows,
+                              slk_stream_t stream);
+int slk_reduce_sum_f32(const float *x, size_t n, int square, double *out, slk_stream_t stream);
+size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2);
+int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
+                    void *workspace, size_t workspace_bytes, slk_stream_t stream);
+int slk_act_backward_f32(const float *dy, const float *y, float *out, size_t n, int act, slk_stream_t stream);
+int slk_train_im2col_cin1_f32(const float *x, long x_t_stride, long x_b_stride, int T, int B, int winlen, int stride,
+                              int pad_lo, int pad_hi, float *cols, slk_stream_t stream);
+int slk_adamski_update_f32(float *param, const float *grad, float *momentum, float *variance, size_t n, float lr_t,
+                           float momentum_decay, float decay1, float decay2, float epsilon, float clip, float l2,
+                           float gscale, slk_stream_t stream);
+int slk_sgd_update_f32(float *param, const float *grad, float *vel, size_t n, float rate, float momentum, float clip,
+                       float l2, float gscale, slk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

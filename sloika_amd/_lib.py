@@ -62,6 +62,17 @@ PROTOTYPES = {
     "slk_map_to_sequence_f32": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "slk_map_to_sequence_batch_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "slk_activation_f32": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "slk_train_pack_xh_f32": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp]),
+    "slk_train_pack_xrh_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "slk_gru_backward_f32": (_i, [_vp, _l, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "slk_softmax_xent_grad_f32": (_i, [_vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "slk_reduce_sum_f32": (_i, [_vp, _sz, _i, _vp, _vp]),
+    "slk_gemm_tn_workspace_bytes": (_sz, [_l, _i, _i]),
+    "slk_gemm_tn_f32": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _vp, _sz, _vp]),
+    "slk_act_backward_f32": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "slk_train_im2col_cin1_f32": (_i, [_vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "slk_adamski_update_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _f, _f, _vp]),
+    "slk_sgd_update_f32": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp]),
 }
 
 _lib = None

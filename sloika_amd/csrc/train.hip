@@ -1,0 +1,497 @@
+// train.hip -- the training step of bin/train_network.py:124-142 (`wrap_network`: loss, accuracy, th.grad of the loss,
+// updates.adam) on gfx950.  SURVEY.md section 8 row f2.
+//
+// The reference gets its gradient from Theano's automatic differentiation; here the reverse pass is written out for the
+// three layer types of the raw models (Convolution layers.py:417-419, Gru.step layers.py:1010-1021, Softmax layers.py:
+// 309-314).  Design:
+//   * the forward pass IS the inference path (conv kernel, gru_fused.hip, gemm_rows_f16x3.hip) -- nothing is saved
+//     inside the recurrent kernel.  What the reverse scan needs (gates z, r and candidate c of every step) is a
+//     function of (x_t, h_{t-1}) only, and every h_{t-1} is known once the forward scan has finished, so the gates of
+//     ALL steps are recomputed as two time-parallel GEMMs over packed rows [x_t | h_{t-1}] and [x_t | r*h_{t-1}]
+//     (slk_train_pack_xh_f32 / slk_train_pack_xrh_f32 + slk_gemm_bias_act_f16x3);
+//   * the only sequential part is gru_backward_kernel: per step two dependent matrix-vector products with sW2^T and
+//     sW^T (float32 FMA, weights held in registers, one workgroup per chunk) producing the pre-activation gradients
+//     da = dL/d(vI) for every step;
+//   * every weight gradient is then a time-parallel contraction over all T*B rows, C = A^T B (gemm_tn_kernel, float32
+//     MFMA 32x32x2 reading both operands straight from their row-major layout, split over M with a deterministic
+//     second-stage sum), bias gradients are the same contraction against a column of ones, and dL/dx of a layer is
+//     slk_gemm_bias_act_f32 with the transposed weight;
+//   * softmax + weighted cross-entropy + its gradient is one pass over the logits (softmax_xent_grad_kernel), in place;
+//   * ADAMski (updates.py:36-89) is one element-wise kernel over the flat parameter / gradient / moment buffers; the
+//     data-parallel all-reduce of the flat gradient (RCCL) happens on the host side between the two.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Packed rows for the gate recompute: xh[m] = [x[m] | h_prev[m]], h_prev(t, b) = h at the previous SCAN step (zero at
+// the scan start: layers.py:85-88), the scan running backwards in time when `reverse` (layers.py:1449-1450).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_xh_kernel(const float *__restrict__ x, long ldx, const float *__restrict__ h,
+                                                      long ldh, float *__restrict__ xh, int T, int B, int I, int N,
+                                                      int reverse)
+{
+    const int W = I + N;
+    const size_t total = (size_t)T * B * W;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t m = e / W;
+        const int j = (int)(e - m * W);
+        float v;
+        if (j < I) {
+            v = x[m * ldx + j];
+        } else {
+            const int t = (int)(m / B), b = (int)(m - (size_t)t * B);
+            const int tp = reverse ? t + 1 : t - 1;
+            v = (tp >= 0 && tp < T) ? h[((size_t)tp * B + b) * ldh + (j - I)] : 0.0f;
+        }
+        xh[e] = v;
+    }
+}
+
+// xrh[m] = [x[m] | r[m] * h_prev[m]] from xh and the gates zr[m] = [z | r]
+__global__ void __launch_bounds__(256) pack_xrh_kernel(const float *__restrict__ xh, const float *__restrict__ zr,
+                                                       float *__restrict__ xrh, size_t M, int I, int N)
+{
+    const int W = I + N;
+    const size_t total = M * W;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t m = e / W;
+        const int j = (int)(e - m * W);
+        float v = xh[e];
+        if (j >= I) v *= zr[m * (2 * (size_t)N) + N + (j - I)];
+        xrh[e] = v;
+    }
+}
+
+static unsigned elementwise_grid(size_t total)
+{
+    size_t blocks = (total + 255) / 256;
+    return (unsigned)(blocks < 1 ? 1 : (blocks > 65536 ? 65536 : blocks));
+}
+
+extern "C" int slk_train_pack_xh_f32(const float *x, long ldx, const float *h, long ldh, float *xh, int T, int B, int I,
+                                     int N, int reverse, slk_stream_t stream)
+{
+    if (!x || !h || !xh || T < 1 || B < 1 || I < 1 || N < 1 || ldx < I || ldh < N) return SLK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pack_xh_kernel, dim3(elementwise_grid((size_t)T * B * (I + N))), dim3(256), 0, slk_stream(stream), x,
+                       ldx, h, ldh, xh, T, B, I, N, reverse);
+    return slk_launch_status();
+}
+
+extern "C" int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *xrh, long M, int I, int N,
+                                      slk_stream_t stream)
+{
+    if (!xh || !zr || !xrh || M < 1 || I < 1 || N < 1) return SLK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pack_xrh_kernel, dim3(elementwise_grid((size_t)M * (I + N))), dim3(256), 0, slk_stream(stream), xh,
+                       zr, xrh, (size_t)M, I, N);
+    return slk_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Reverse scan of one Gru layer.  Forward step (layers.py:1010-1021), h = h_{t-1}:
+//     z, r = sigmoid(vI[:2n] + h sW^T) ; c = tanh(vI[2n:] + (r*h) sW2^T) ; h_t = z*h + (1-z)*c
+// Reverse step, g = dL/dh_t (from the layer above) + the carry from step t+1:
+//     dac = g (1-z) (1-c^2) ; daz = g (h-c) z (1-z) ; drh = dac sW2 ; dar = drh h r (1-r)
+//     carry = g z + drh r + [daz dar] sW ;  da = [daz dar dac] is dL/dvI of this step.
+// One workgroup per chunk, 4*N threads: thread (i, q) holds column i of the K-quarter q of sW2 and of sW in registers
+// (N/4 + 2N/4 floats) and produces a partial sum; the N "owner" threads (q = 0) do the element-wise part.  Operands of
+// the next step are loaded while the current one computes (their addresses do not depend on the recursion).
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+__global__ void __launch_bounds__(4 * N) gru_backward_kernel(const float *__restrict__ dy, long lddy,
+                                                             const float *__restrict__ xh, int I,
+                                                             const float *__restrict__ zr, const float *__restrict__ c,
+                                                             const float *__restrict__ sW, const float *__restrict__ sW2,
+                                                             float *__restrict__ da, int T, int B, int reverse)
+{
+    constexpr int Q2 = N / 4, Q1 = 2 * N / 4;
+    __shared__ float v_dac[N], v_dzr[2 * N], part[4][N];
+    const int tid = threadIdx.x, i = tid % N, q = tid / N, b = blockIdx.x;
+    const bool owner = q == 0;
+    float w2[Q2], w1[Q1];
+#pragma unroll
+    for (int j = 0; j < Q2; j++) w2[j] = sW2[(size_t)(q * Q2 + j) * N + i];      // drh[i] = sum_k dac[k] sW2[k][i]
+#pragma unroll
+    for (int j = 0; j < Q1; j++) w1[j] = sW[(size_t)(q * Q1 + j) * N + i];       // carry[i] += sum_k dzr[k] sW[k][i]
+    const long ldxh = I + N;
+    float carry = 0.0f;
+    // operands of scan step s (owner threads only)
+    auto row = [&](int s) { return (size_t)(reverse ? T - 1 - s : s) * B + b; };
+    float n_g = 0.f, n_z = 0.f, n_r = 0.f, n_c = 0.f, n_h = 0.f;
+    auto fetch = [&](int s) {
+        const size_t m = row(s);
+        n_g = dy[m * lddy + i];
+        n_z = zr[m * (2 * N) + i];
+        n_r = zr[m * (2 * N) + N + i];
+        n_c = c[m * N + i];
+        n_h = xh[m * ldxh + I + i];
+    };
+    if (owner) fetch(T - 1);
+    for (int s = T - 1; s >= 0; s--) {
+        float g = 0.f, z = 0.f, r = 0.f, cc = 0.f, h = 0.f, daz = 0.f;
+        if (owner) {
+            g = n_g + carry; z = n_z; r = n_r; cc = n_c; h = n_h;
+            if (s > 0) fetch(s - 1);
+            const float dac = g * (1.0f - z) * (1.0f - cc * cc);
+            daz = g * (h - cc) * z * (1.0f - z);
+            v_dac[i] = dac;
+            v_dzr[i] = daz;
+            da[row(s) * (3 * N) + 2 * N + i] = dac;
+            da[row(s) * (3 * N) + i] = daz;
+        }
+        __syncthreads();
+        {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < Q2; j++) acc = fmaf(v_dac[q * Q2 + j], w2[j], acc);
+            part[q][i] = acc;
+        }
+        __syncthreads();
+        float keep = 0.0f;
+        if (owner) {
+            const float drh = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+            const float dar = drh * h * r * (1.0f - r);
+            v_dzr[N + i] = dar;
+            da[row(s) * (3 * N) + N + i] = dar;
+            keep = g * z + drh * r;
+        }
+        __syncthreads();
+        {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < Q1; j++) acc = fmaf(v_dzr[q * Q1 + j], w1[j], acc);
+            part[q][i] = acc;
+        }
+        __syncthreads();
+        if (owner) carry = keep + ((part[0][i] + part[1][i]) + (part[2][i] + part[3][i]));
+        // the next iteration writes v_dac / v_dzr[0:N] (read in this iteration before the last two barriers) and part[]
+        // only after its own first barrier, which every reader of part[] above has to reach first: no barrier needed here
+    }
+}
+
+template <int N>
+static int launch_gru_backward(const float *dy, long lddy, const float *xh, int I, const float *zr, const float *c,
+                               const float *sW, const float *sW2, float *da, int T, int B, int reverse, hipStream_t s)
+{
+    hipLaunchKernelGGL((gru_backward_kernel<N>), dim3(B), dim3(4 * N), 0, s, dy, lddy, xh, I, zr, c, sW, sW2, da, T, B,
+                       reverse);
+    return slk_launch_status();
+}
+
+extern "C" int slk_gru_backward_f32(const float *dy, long lddy, const float *xh, int insize, const float *zr, const float *c,
+                                    const float *sW, const float *sW2, float *da, int T, int B, int n, int reverse, int act,
+                                    int gate_act, slk_stream_t stream)
+{
+    if (!dy || !xh || !zr || !c || !sW || !sW2 || !da || T < 1 || B < 1 || n < 1 || insize < 1 || lddy < n)
+        return SLK_ERR_INVALID_ARG;
+    if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
+    hipStream_t s = slk_stream(stream);
+    switch (n) {
+#define GRU_BWD_CASE(NN) case NN: return launch_gru_backward<NN>(dy, lddy, xh, insize, zr, c, sW, sW2, da, T, B, reverse, s)
+        GRU_BWD_CASE(16); GRU_BWD_CASE(32); GRU_BWD_CASE(48); GRU_BWD_CASE(64); GRU_BWD_CASE(96); GRU_BWD_CASE(112);
+        GRU_BWD_CASE(128); GRU_BWD_CASE(144);
+#undef GRU_BWD_CASE
+    default: return SLK_ERR_UNSUPPORTED;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Loss of train_network.py:128-136 and its gradient with respect to the logits, in place.  One wave per row (t, b):
+//     p = exp(l - max) * inv_sum ; post = min_prob + (1 - min_prob) p ; row loss = -w log(post[label]) / count
+//     dl_j = (w / count) (1 - min_prob) p[label] / post[label] * (p_j - [j == label])
+// for drop <= t < T - drop, zero gradient and zero loss outside; count = (T - 2 drop) B (the T.mean).  correct[m] = 1
+// when the first maximum of the row is the label (T.argmax/T.eq, :134).  Columns nstate..ld-1 are zeroed so the
+// gradient can be contracted with a padded row length.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) softmax_xent_grad_kernel(float *__restrict__ logits, long ld,
+                                                                const float *__restrict__ stats,
+                                                                const int32_t *__restrict__ labels,
+                                                                const float *__restrict__ weights, int T, int B, int nstate,
+                                                                int drop, float min_prob, float *__restrict__ loss_rows,
+                                                                float *__restrict__ correct_rows)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t m = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= (size_t)T * B) return;
+    const int t = (int)(m / B);
+    const bool counted = t >= drop && t < T - drop;
+    float *row = logits + m * ld;
+    const float mx = stats[2 * m], inv = stats[2 * m + 1];
+    const int label = labels[m];
+    const float count = (float)(T - 2 * drop) * (float)B;
+    const float p_lab = __expf(row[label] - mx) * inv;
+    const float post_lab = min_prob + (1.0f - min_prob) * p_lab;
+    const float w = counted ? weights[m] / count : 0.0f;
+    const float coef = w * (1.0f - min_prob) * p_lab / post_lab;
+    int first = 0x7fffffff;
+    for (int j = lane; j < (int)ld; j += 64) {
+        float d = 0.0f;
+        if (j < nstate) {
+            const float l = row[j];
+            if (l == mx && j < first) first = j;
+            d = coef * (__expf(l - mx) * inv - (j == label ? 1.0f : 0.0f));
+        }
+        row[j] = d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+    if (lane == 0) {
+        loss_rows[m] = counted ? -w * logf(post_lab) : 0.0f;
+        correct_rows[m] = (counted && first == label) ? 1.0f / count : 0.0f;
+    }
+}
+
+extern "C" int slk_softmax_xent_grad_f32(float *logits, long ld, const float *stats, const int32_t *labels,
+                                         const float *weights, int T, int B, int nstate, int drop, float min_prob,
+                                         float *loss_rows, float *correct_rows, slk_stream_t stream)
+{
+    if (!logits || !stats || !labels || !weights || !loss_rows || !correct_rows || T < 1 || B < 1 || nstate < 1 ||
+        ld < nstate || drop < 0 || 2 * drop >= T || !(min_prob >= 0.0f && min_prob < 1.0f))
+        return SLK_ERR_INVALID_ARG;
+    const size_t M = (size_t)T * B;
+    hipLaunchKernelGGL(softmax_xent_grad_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, slk_stream(stream), logits, ld,
+                       stats, labels, weights, T, B, nstate, drop, min_prob, loss_rows, correct_rows);
+    return slk_launch_status();
+}
+
+// sum of x[0..n) (square = 0) or of x^2 (square = 1: updates.param_sqr, updates.py:92-103), accumulated in float64 in a
+// fixed order: one workgroup, result in out[0]
+__global__ void __launch_bounds__(1024) reduce_sum_kernel(const float *__restrict__ x, size_t n, int square,
+                                                          double *__restrict__ out)
+{
+    __shared__ double part[1024];
+    double acc = 0.0;
+    for (size_t e = threadIdx.x; e < n; e += 1024) {
+        const double v = x[e];
+        acc += square ? v * v : v;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
+}
+
+extern "C" int slk_reduce_sum_f32(const float *x, size_t n, int square, double *out, slk_stream_t stream)
+{
+    if (!x || !out) return SLK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, slk_stream(stream), x, n, square, out);
+    return slk_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// C[N1][N2] = A^T B over M rows (A:[M][N1], B:[M][N2], row-major): every weight gradient of the reverse pass.
+// v_mfma_f32_32x32x2_f32 contracts over k = the ROW index m, and both operands want "32 consecutive columns of one row
+// per half-wave": exactly what row-major A and B give, so operands go from global memory to the MFMA without LDS or
+// transposes.  One wave per workgroup owns a 96 x 96 block of C (3 x 3 accumulators) for one slice of TN_ROWS rows and
+// writes a partial block; tn_reduce_kernel adds the slices in a fixed order (deterministic, unlike atomics).
+// ---------------------------------------------------------------------------------------------------------------
+#define TN_ROWS 2048
+#define TN_BLK 96
+#define TN_UNROLL 8
+
+__global__ void __launch_bounds__(64) gemm_tn_kernel(const float *__restrict__ A, long lda, const float *__restrict__ Bm,
+                                                     long ldb, float *__restrict__ partial, long M, int N1, int N2)
+{
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int n1_0 = blockIdx.y * TN_BLK, n2_0 = blockIdx.z * TN_BLK;
+    const long m_lo = (long)blockIdx.x * TN_ROWS, m_hi = min(m_lo + TN_ROWS, M);
+    const int ta = min(3, (N1 - n1_0 + 31) / 32), tb = min(3, (N2 - n2_0 + 31) / 32);    // live 32-wide tiles (uniform)
+    int ca[3], cb[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ca[i] = min(n1_0 + 32 * i + r, N1 - 1);
+        cb[i] = min(n2_0 + 32 * i + r, N2 - 1);
+    }
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    for (long m0 = m_lo; m0 < m_hi; m0 += 2 * TN_UNROLL) {
+        float av[TN_UNROLL][3], bv[TN_UNROLL][3];
+#pragma unroll
+        for (int u = 0; u < TN_UNROLL; u++) {
+            const long m = m0 + 2 * u + h, mc = min(m, M - 1);
+            const float live = m < m_hi ? 1.0f : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                av[u][i] = i < ta ? A[mc * lda + ca[i]] * live : 0.0f;
+                bv[u][i] = i < tb ? Bm[mc * ldb + cb[i]] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TN_UNROLL; u++)
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+                    if (i < ta && j < tb)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+    }
+    // partial[slice][N1][N2]; D[row = (e&3) + 8*(e>>2) + 4*h][col = r]; columns clamped above are dropped here
+    float *out = partial + (size_t)blockIdx.x * N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int col = n2_0 + 32 * j + r;
+            if (i < ta && j < tb && col < N2) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int rowc = n1_0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (rowc < N1) out[(size_t)rowc * N2 + col] = acc[i][j][e];
+                }
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256) tn_reduce_kernel(const float *__restrict__ partial, int nslice, int N1, int N2,
+                                                        float *__restrict__ C, long ldc)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)N1 * N2;
+    if (e >= total) return;
+    double acc = 0.0;
+    for (int s = 0; s < nslice; s++) acc += partial[(size_t)s * total + e];
+    C[(e / N2) * ldc + (e % N2)] = (float)acc;
+}
+
+extern "C" size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2)
+{
+    if (M < 1 || N1 < 1 || N2 < 1) return 0;
+    return (size_t)((M + TN_ROWS - 1) / TN_ROWS) * N1 * N2 * sizeof(float);
+}
+
+extern "C" int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
+                               void *workspace, size_t workspace_bytes, slk_stream_t stream)
+{
+    if (!A || !B || !C || M < 1 || N1 < 1 || N2 < 1 || lda < N1 || ldb < N2 || ldc < N2) return SLK_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < slk_gemm_tn_workspace_bytes(M, N1, N2)) return SLK_ERR_WORKSPACE;
+    const long nslice = (M + TN_ROWS - 1) / TN_ROWS;
+    const int g1 = (N1 + TN_BLK - 1) / TN_BLK, g2 = (N2 + TN_BLK - 1) / TN_BLK;
+    if (nslice > 0x7fffffffL || g1 > 65535 || g2 > 65535) return SLK_ERR_UNSUPPORTED;
+    hipStream_t s = slk_stream(stream);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)nslice, g1, g2), dim3(64), 0, s, A, lda, B, ldb, (float *)workspace, M,
+                       N1, N2);
+    const size_t total = (size_t)N1 * N2;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)workspace,
+                       (int)nslice, N1, N2, C, ldc);
+    return slk_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dL/d(pre-activation) = dL/dy * fun'(.) written in terms of the layer OUTPUT y (what the forward pass keeps):
+// tanh 1-y^2, sigmoid y(1-y), linear 1, relu [y>0], elu (y>0 ? 1 : y+1)    (activation.py:8-57)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) act_backward_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                           float *__restrict__ out, size_t n, int act)
+{
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const float v = y[e];
+        float d;
+        switch (act) {
+        case SLK_ACT_TANH: d = 1.0f - v * v; break;
+        case SLK_ACT_SIGMOID: d = v * (1.0f - v); break;
+        case SLK_ACT_RELU: d = v > 0.0f ? 1.0f : 0.0f; break;
+        case SLK_ACT_ELU: d = v > 0.0f ? 1.0f : v + 1.0f; break;
+        default: d = 1.0f; break;
+        }
+        out[e] = dy[e] * d;
+    }
+}
+
+extern "C" int slk_act_backward_f32(const float *dy, const float *y, float *out, size_t n, int act, slk_stream_t stream)
+{
+    if (!dy || !y || !out) return SLK_ERR_INVALID_ARG;
+    if (act != SLK_ACT_TANH && act != SLK_ACT_SIGMOID && act != SLK_ACT_RELU && act != SLK_ACT_ELU && act != SLK_ACT_LINEAR)
+        return SLK_ERR_UNSUPPORTED;
+    if (n == 0) return SLK_OK;
+    hipLaunchKernelGGL(act_backward_kernel, dim3(elementwise_grid(n)), dim3(256), 0, slk_stream(stream), dy, y, out, n, act);
+    return slk_launch_status();
+}
+
+// Window rows of a one-feature convolution (conv.py:66-111 with insize 1): cols[(t*B + b)][k] = x(b, t*stride + k - pad_lo),
+// zero outside the signal; x addressed as x[t*x_t_stride + b*x_b_stride] like slk_conv1d_f32.  dL/dW = dpre^T cols.
+__global__ void __launch_bounds__(256) im2col_cin1_kernel(const float *__restrict__ x, long xts, long xbs, int T, int B,
+                                                          int Tout, int winlen, int stride, int pad_lo,
+                                                          float *__restrict__ cols)
+{
+    const size_t total = (size_t)Tout * B * winlen;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t m = e / winlen;
+        const int k = (int)(e - m * winlen), t = (int)(m / B), b = (int)(m - (size_t)t * B);
+        const int src = t * stride + k - pad_lo;
+        cols[e] = (src >= 0 && src < T) ? x[(size_t)src * xts + (size_t)b * xbs] : 0.0f;
+    }
+}
+
+extern "C" int slk_train_im2col_cin1_f32(const float *x, long x_t_stride, long x_b_stride, int T, int B, int winlen,
+                                         int stride, int pad_lo, int pad_hi, float *cols, slk_stream_t stream)
+{
+    if (!x || !cols || T < 1 || B < 1 || winlen < 1 || stride < 1 || pad_lo < 0 || pad_hi < 0) return SLK_ERR_INVALID_ARG;
+    const int Tout = slk_conv1d_out_len(T, winlen, stride, pad_lo, pad_hi);
+    if (Tout < 1) return SLK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(im2col_cin1_kernel, dim3(elementwise_grid((size_t)Tout * B * winlen)), dim3(256), 0,
+                       slk_stream(stream), x, x_t_stride, x_b_stride, T, B, Tout, winlen, stride, pad_lo, cols);
+    return slk_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// updates.adam ("ADAMski", updates.py:77-87) over flat buffers; lr_t and momentum_decay are this step's scalars
+// (updates.py:73-76, computed on the host in float32 like the reference's shared variables).  `l2` adds the gradient of
+// the penalty l2 * param_sqr (train_network.py:130), `gscale` scales the incoming gradient (1/world after a sum
+// all-reduce); the clip is applied to the result, as th.grad of the whole loss is clipped in the reference.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adamski_kernel(float *__restrict__ param, const float *__restrict__ grad,
+                                                      float *__restrict__ momentum, float *__restrict__ variance, size_t n,
+                                                      float lr_t, float momentum_decay, float decay1, float decay2,
+                                                      float epsilon, float clip, float l2, float gscale)
+{
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const float p = param[e];
+        const float g = slk_clip(grad[e] * gscale + 2.0f * l2 * p, -clip, clip);
+        const float mo = momentum_decay * momentum[e] + (1.0f - decay1) * g;
+        const float va = decay2 * variance[e] + (1.0f - decay2) * g * g;
+        momentum[e] = mo;
+        variance[e] = va;
+        param[e] = p - lr_t * mo / (sqrtf(va) + epsilon);
+    }
+}
+
+extern "C" int slk_adamski_update_f32(float *param, const float *grad, float *momentum, float *variance, size_t n, float lr_t,
+                                      float momentum_decay, float decay1, float decay2, float epsilon, float clip, float l2,
+                                      float gscale, slk_stream_t stream)
+{
+    if (!param || !grad || !momentum || !variance) return SLK_ERR_INVALID_ARG;
+    if (n == 0) return SLK_OK;
+    hipLaunchKernelGGL(adamski_kernel, dim3(elementwise_grid(n)), dim3(256), 0, slk_stream(stream), param, grad, momentum,
+                       variance, n, lr_t, momentum_decay, decay1, decay2, epsilon, clip, l2, gscale);
+    return slk_launch_status();
+}
+
+// updates.sgd (updates.py:9-33): vel = momentum vel - rate clip(g) ; param += vel
+__global__ void __launch_bounds__(256) sgd_kernel(float *__restrict__ param, const float *__restrict__ grad,
+                                                  float *__restrict__ vel, size_t n, float rate, float momentum, float clip,
+                                                  float l2, float gscale)
+{
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const float p = param[e];
+        const float g = slk_clip(grad[e] * gscale + 2.0f * l2 * p, -clip, clip);
+        const float v = momentum * vel[e] - rate * g;
+        vel[e] = v;
+        param[e] = p + v;
+    }
+}
+
+extern "C" int slk_sgd_update_f32(float *param, const float *grad, float *vel, size_t n, float rate, float momentum,
+                                  float clip, float l2, float gscale, slk_stream_t stream)
+{
+    if (!param || !grad || !vel || momentum < 0.0f) return SLK_ERR_INVALID_ARG;
+    if (n == 0) return SLK_OK;
+    hipLaunchKernelGGL(sgd_kernel, dim3(elementwise_grid(n)), dim3(256), 0, slk_stream(stream), param, grad, vel, n, rate,
+                       momentum, clip, l2, gscale);
+    return slk_launch_status();
+}

@@ -1,0 +1,375 @@
+"""The training step of the reference on the HIP kernels.
+
+Mirrors bin/train_network.py:124-142: `wrap_network(network, min_prob, l2, drop)` returns `fg(x, labels, weights, rate)
+-> (loss, acc)` which also applies one ADAMski update (sloika/updates.py:36-89) to the network's parameters, exactly
+like the Theano function the reference compiles.  Device side: csrc/train.hip (reverse scan of the GRU layers, A^T B
+contractions for the weight gradients, softmax cross-entropy, the optimiser) on top of the inference kernels, which
+ARE the forward pass.  There is no CPU fallback.
+
+Supported networks: Serial([Convolution(insize=1, ...)] + [Gru | Reverse(Gru)]* + [Softmax]) -- the raw-signal models
+models/raw_0.98_rgrgr.py and relatives; anything else raises NotImplementedError (the reference differentiates any
+layer through Theano; only the recurrent raw-signal path is accelerated here).
+
+Data parallel (BASELINE.json configs[4]): with torch.distributed initialised (backend "nccl" = RCCL over xGMI) every
+rank runs the same step on its own chunks, the flat float32 gradient is summed with ONE all-reduce and divided by the
+world size, and every rank applies the identical update -- the loss of the global batch is the mean of the ranks'
+losses because every rank counts the same number of positions.
+"""
+import numpy as np
+
+from . import _lib, activation, layers
+from .config import sloika_dtype
+
+
+def remove_blanks(labels):
+    """train_network.py:116-121"""
+    for lbl_ch in labels:
+        for i in range(1, len(lbl_ch)):
+            if lbl_ch[i] == 0:
+                lbl_ch[i] = lbl_ch[i - 1]
+    return labels
+
+
+class ExponentialSmoother(object):
+    """train_network.py:100-113"""
+
+    def __init__(self, factor, val=0.0, weight=1e-30):
+        assert 0.0 <= factor <= 1.0, "Smoothing factor was {}, should be between 0.0 and 1.0.\n".format(factor)
+        self.factor = factor
+        self.val = val
+        self.weight = weight
+
+    @property
+    def value(self):
+        return self.val / self.weight
+
+    def update(self, val, weight=1.0):
+        self.val = self.factor * self.val + (1.0 - self.factor) * val
+        self.weight = self.factor * self.weight + (1.0 - self.factor) * weight
+
+
+def adamski_scalars(t, rate, decay, mrate=0.0005):
+    """(lr_t, momentum_decay, t + 1) of the step that starts at counter `t` (updates.py:54-76), in float32 like the
+    reference's shared variables."""
+    f32 = np.float32
+    if mrate is not None:
+        m_rate = -f32(mrate)
+        m_p = np.exp(m_rate)
+        m_k = f32((1.0 - decay[0]) * decay[0] * m_p / (1.0 - m_p * decay[0]))
+    else:
+        m_rate, m_k = -f32(1e30), f32(0.0)
+    ldecay = np.log(np.array(decay), dtype=np.float32)
+    t = f32(t)
+    t_new = f32(t + f32(1.0))
+    with np.errstate(over="ignore"):
+        momentum_factor = f32(m_k * np.expm1(f32(t * f32(ldecay[0] + m_rate))) - np.expm1(f32(t_new * ldecay[0])))
+        lr_t = f32(f32(rate) * np.sqrt(-np.expm1(f32(t_new * ldecay[1]))) / momentum_factor)
+        momentum_decay = f32(-f32(decay[0]) * np.expm1(f32(t_new * m_rate)))
+    return float(lr_t), float(momentum_decay), float(t_new)
+
+
+def allreduce_mean_(tensor):
+    """Sum `tensor` over the ranks in place (one collective) and return the factor that turns the sum into the mean.
+    A no-op returning 1.0 when torch.distributed is not initialised or there is one rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 1.0
+    dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+    return 1.0 / dist.get_world_size()
+
+
+def _plan(network):
+    """[(kind, layer, reverse)] for the supported architecture, or NotImplementedError."""
+    subs = network.layers if isinstance(network, layers.Serial) else [network]
+    plan = []
+    for pos, layer in enumerate(subs):
+        rev = False
+        while isinstance(layer, layers.Reverse):
+            layer, rev = layer.layer, not rev
+        if isinstance(layer, layers.Convolution) and pos == 0 and layer.insize == 1 and not rev:
+            kind = "conv"
+        elif isinstance(layer, layers.Gru):
+            kind = "gru"
+        elif isinstance(layer, layers.Softmax) and pos == len(subs) - 1:
+            kind = "softmax"
+        else:
+            raise NotImplementedError(
+                "training on the GPU path covers Serial([Convolution(insize=1)] + Gru/Reverse(Gru)... + Softmax); "
+                "layer %d (%s) is outside it" % (pos, type(layer).__name__))
+        plan.append((kind, layer, rev))
+    if not plan or plan[-1][0] != "softmax":
+        raise NotImplementedError("the training loss needs a Softmax output layer (train_network.py:128-133)")
+    return plan
+
+
+class TrainingStep(object):
+    """fg(x, labels, weights, rate) -> (loss, acc): one forward/backward pass and one optimiser update.
+
+    x       : [T, B, nfeature] float32 (numpy or device tensor), time-major like train_network.py:304
+    labels  : [T', B] int32, T' = the network's output length (train_network.py:305)
+    weights : [T', B] float32 (train_network.py:306)
+    rate    : learning rate of this step (train_network.py:289)
+    """
+
+    def __init__(self, network, min_prob=0.0, l2=0.0, drop=0, decay=(0.9, 0.999), epsilon=1e-8, clip=5.0, mrate=0.0005,
+                 optimiser="adam", momentum=0.9):
+        import torch
+        _lib.require_gpu()
+        assert 0.0 < decay[0] < 1.0 and 0.0 < decay[1] < 1.0, "Decay must lie strictly between zero and one"   # updates.py:51-52
+        assert mrate is None or mrate > 0.0, "Rate of momentum increase must be positive"                      # updates.py:53
+        assert optimiser in ("adam", "sgd")
+        self.network, self.plan = network, _plan(network)
+        self.min_prob, self.l2, self.drop = float(min_prob), float(l2), int(drop)
+        self.decay, self.epsilon, self.clip, self.mrate = tuple(decay), float(epsilon), float(clip), mrate
+        self.optimiser, self.sgd_momentum = optimiser, float(momentum)
+        self.t = 0.0
+        from . import device as D
+        dev = D.device()
+        # one flat parameter buffer; every Shared's device mirror becomes a view into it, so the forward kernels read the
+        # optimiser's output directly and the gradient can be all-reduced as one message
+        self.shared = network.params()
+        sizes = [int(np.prod(p.shape)) for p in self.shared]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        total = int(self.offsets[-1])
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        for p, off, n in zip(self.shared, self.offsets, sizes):
+            self.flat[off:off + n].copy_(torch.from_numpy(p.get_value(borrow=True).reshape(-1)))
+            p._dev = self.flat[off:off + n].view(p.shape)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.momentum = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.variance = torch.zeros(total, dtype=torch.float32, device=dev) if optimiser == "adam" else None
+        self._index = {id(p): i for i, p in enumerate(self.shared)}
+        self._ws = None
+        self._ones = None
+        self._scalars = torch.zeros(3, dtype=torch.float64, device=dev)
+        self._drop_caches()
+
+    # ---- plumbing -------------------------------------------------------------------------------------------------
+    def _grad_of(self, shared_param):
+        i = self._index[id(shared_param)]
+        return self.grad[self.offsets[i]:self.offsets[i + 1]]
+
+    def _drop_caches(self):
+        """Device copies derived from the parameters (fp16 splits, padded twins) are keyed on the identity of the
+        parameter's device tensor, which no longer changes when the optimiser writes in place: forget them."""
+        for _, layer, _ in self.plan:
+            for attr in ("_w16", "_iw16", "_pad_cache"):
+                layer.__dict__.pop(attr, None)
+
+    def sync_host(self):
+        """Copy the trained parameters back into the layers' numpy storage (what pickling a network saves:
+        train_network.py:145-152)."""
+        host = self.flat.cpu().numpy()
+        for p, off, nxt in zip(self.shared, self.offsets[:-1], self.offsets[1:]):
+            p._value = np.ascontiguousarray(host[off:nxt].reshape(p.shape), dtype=sloika_dtype)
+
+    def _workspace(self, nbytes):
+        import torch
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.flat.device)
+        return self._ws
+
+    def _tn(self, A, lda, Bm, ldb, C, ldc, M, n1, n2):
+        """C[n1][n2] = A^T B over M rows."""
+        L = _lib.lib()
+        nbytes = L.slk_gemm_tn_workspace_bytes(M, n1, n2)
+        ws = self._workspace(nbytes)
+        _lib.check(L.slk_gemm_tn_f32(A, lda, Bm, ldb, C, ldc, M, n1, n2, ws.data_ptr(), nbytes, layers._stream()), "gemm_tn")
+
+    def _colsum(self, A, lda, C, M, n1):
+        import torch
+        if self._ones is None or self._ones.numel() < M:
+            self._ones = torch.ones(M, dtype=torch.float32, device=self.flat.device)
+        self._tn(A, lda, self._ones.data_ptr(), 1, C, 1, M, n1, 1)
+
+    def _gemm(self, x, ldx, W, bias, y, ldy, M, K, N, act):
+        """y = act(x . W^T + b), W:[N][K] -- fp16 3-term split where it applies, else float32 MFMA."""
+        import torch
+        L = _lib.lib()
+        rc = _lib.SLK_ERR_UNSUPPORTED
+        if layers.SPLIT_F16 and K <= 192 and N <= 2048:
+            kp = (K + 15) // 16 * 16
+            hi = torch.empty((N, kp), dtype=torch.float16, device=W.device)
+            lo = torch.empty((N, kp), dtype=torch.float16, device=W.device)
+            _lib.check(L.slk_split_f16x2_f32(W.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), layers._stream()), "split")
+            rc = L.slk_gemm_bias_act_f16x3(x, ldx, hi.data_ptr(), lo.data_ptr(), bias, y, ldy, M, K, N, act, layers._stream())
+        if rc == _lib.SLK_ERR_UNSUPPORTED:
+            rc = L.slk_gemm_bias_act_f32(x, ldx, W.data_ptr(), bias, y, ldy, M, K, N, act, layers._stream())
+        _lib.check(rc, "gemm")
+
+    # ---- the step ---------------------------------------------------------------------------------------------------
+    def __call__(self, x, labels, weights, rate):
+        loss, acc = self.forward_backward(x, labels, weights)
+        self.update(rate)
+        return loss, acc
+
+    def forward_backward(self, x, labels, weights):
+        """Loss and accuracy of the batch; leaves d loss / d params (without the l2 term, which the update adds) in
+        self.grad, already averaged over the ranks."""
+        import torch
+        from . import device as D
+        L = _lib.lib()
+        st = layers._stream
+        x = D.to_dev(x)
+        if x.dim() != 3 or x.shape[2] != self.network.insize:
+            raise ValueError("x must be [T, B, %d]" % self.network.insize)
+        T, B = int(x.shape[0]), int(x.shape[1])
+        # ---- forward: the inference kernels, keeping every layer's output -------------------------------------------
+        acts = [x]
+        for kind, layer, rev in self.plan[:-1]:
+            acts.append(layer._forward(acts[-1], None, rev))
+        sm = self.plan[-1][1]
+        h_top = acts[-1]
+        To = int(h_top.shape[0])
+        M = To * B
+        logits, stats, ld = sm.logits_and_stats(h_top)
+        labels = D.to_dev(np.ascontiguousarray(labels) if not isinstance(labels, torch.Tensor) else labels, torch.int32)
+        weights = D.to_dev(weights)
+        if tuple(labels.shape) != (To, B) or tuple(weights.shape) != (To, B):
+            raise ValueError("labels and weights must be [%d, %d] (the network's output length x batch)" % (To, B))
+        if 2 * self.drop >= To:
+            raise ValueError("drop=%d leaves nothing of %d output steps" % (self.drop, To))
+        if int(labels.min()) < 0 or int(labels.max()) >= sm.size:
+            raise ValueError("labels must lie in [0, %d)" % sm.size)
+        # ---- loss, accuracy, d loss / d logits (in place) -------------------------------------------------------------
+        rows = torch.empty((2, M), dtype=torch.float32, device=x.device)
+        _lib.check(L.slk_softmax_xent_grad_f32(logits.data_ptr(), ld, stats.data_ptr(), labels.data_ptr(),
+                                               weights.data_ptr(), To, B, sm.size, self.drop, self.min_prob,
+                                               rows[0].data_ptr(), rows[1].data_ptr(), st()), "softmax_xent")
+        sc = self._scalars
+        _lib.check(L.slk_reduce_sum_f32(rows[0].data_ptr(), M, 0, sc[0:].data_ptr(), st()), "reduce")
+        _lib.check(L.slk_reduce_sum_f32(rows[1].data_ptr(), M, 0, sc[1:].data_ptr(), st()), "reduce")
+        _lib.check(L.slk_reduce_sum_f32(self.flat.data_ptr(), self.flat.numel(), 1, sc[2:].data_ptr(), st()), "reduce")
+        # ---- softmax layer ---------------------------------------------------------------------------------------------
+        n_in = sm.insize
+        self._tn(logits.data_ptr(), ld, h_top.data_ptr(), layers._row_stride(h_top), self._grad_of(sm.W).data_ptr(), n_in, M,
+                 sm.size, n_in)
+        if sm.has_bias:
+            self._colsum(logits.data_ptr(), ld, self._grad_of(sm.b).data_ptr(), M, sm.size)
+        dy = None
+        if len(self.plan) > 1:
+            wt = torch.zeros((n_in, ld), dtype=torch.float32, device=x.device)          # W^T, rows padded like the logits
+            wt[:, :sm.size] = sm.W.dev().t()
+            dy = torch.empty((To, B, n_in), dtype=torch.float32, device=x.device)
+            _lib.check(L.slk_gemm_bias_act_f32(logits.data_ptr(), ld, wt.data_ptr(), None, dy.data_ptr(), n_in, M, ld, n_in,
+                                               0, st()), "softmax dx")
+        del logits
+        # ---- recurrent layers, top down -------------------------------------------------------------------------------
+        for pos in range(len(self.plan) - 2, -1, -1):
+            kind, layer, rev = self.plan[pos]
+            xin, yout = acts[pos], acts[pos + 1]
+            if kind == "gru":
+                dy = self._gru_backward(layer, rev, xin, yout, dy, need_dx=pos > 0)
+            else:
+                self._conv_backward(layer, xin, yout, dy)
+                dy = None
+            acts[pos + 1] = None
+        # ---- data-parallel average --------------------------------------------------------------------------------------
+        self.gscale = allreduce_mean_(self.grad)
+        if self.gscale != 1.0:
+            allreduce_mean_(sc[:2])
+        s = sc.cpu().numpy()
+        loss = float(s[0]) * self.gscale + self.l2 * float(s[2])
+        return loss, float(s[1]) * self.gscale
+
+    def _gru_backward(self, layer, rev, xin, h, dy, need_dx):
+        import torch
+        L = _lib.lib()
+        st = layers._stream
+        T, B, n = int(h.shape[0]), int(h.shape[1]), layer.size
+        i_sz, M, K = layer.insize, int(h.shape[0]) * int(h.shape[1]), layer.insize + layer.size
+        act, gact = activation.act_id(layer.fun), activation.act_id(layer.gatefun)
+        if act != activation.act_id(activation.tanh) or gact != activation.act_id(activation.sigmoid):
+            raise NotImplementedError("training: Gru layers with fun=tanh, gatefun=sigmoid only")
+        dev = h.device
+        iW, sW, sW2, b = layer.iW.dev(), layer.sW.dev(), layer.sW2.dev(), layer.b.dev()
+        xh = torch.empty((M, K), dtype=torch.float32, device=dev)
+        _lib.check(L.slk_train_pack_xh_f32(xin.data_ptr(), layers._row_stride(xin), h.data_ptr(), layers._row_stride(h),
+                                           xh.data_ptr(), T, B, i_sz, n, int(rev), st()), "pack_xh")
+        zr = torch.empty((M, 2 * n), dtype=torch.float32, device=dev)
+        self._gemm(xh.data_ptr(), K, torch.cat([iW[:2 * n], sW], 1).contiguous(), b[:2 * n].data_ptr(), zr.data_ptr(), 2 * n,
+                   M, K, 2 * n, gact)
+        xrh = torch.empty((M, K), dtype=torch.float32, device=dev)
+        _lib.check(L.slk_train_pack_xrh_f32(xh.data_ptr(), zr.data_ptr(), xrh.data_ptr(), M, i_sz, n, st()), "pack_xrh")
+        c = torch.empty((M, n), dtype=torch.float32, device=dev)
+        self._gemm(xrh.data_ptr(), K, torch.cat([iW[2 * n:], sW2], 1).contiguous(), b[2 * n:].data_ptr(), c.data_ptr(), n, M,
+                   K, n, act)
+        da = torch.empty((M, 3 * n), dtype=torch.float32, device=dev)
+        rc = L.slk_gru_backward_f32(dy.data_ptr(), layers._row_stride(dy), xh.data_ptr(), i_sz, zr.data_ptr(), c.data_ptr(),
+                                    sW.data_ptr(), sW2.data_ptr(), da.data_ptr(), T, B, n, int(rev), act, gact, st())
+        if rc == _lib.SLK_ERR_UNSUPPORTED:
+            raise NotImplementedError("training: no reverse-scan kernel for a Gru of size %d" % n)
+        _lib.check(rc, "gru_backward")
+        f4 = 4                                                                       # bytes per float, for column offsets
+        self._tn(da.data_ptr(), 3 * n, xh.data_ptr(), K, self._grad_of(layer.iW).data_ptr(), i_sz, M, 3 * n, i_sz)
+        self._tn(da.data_ptr(), 3 * n, xh.data_ptr() + f4 * i_sz, K, self._grad_of(layer.sW).data_ptr(), n, M, 2 * n, n)
+        self._tn(da.data_ptr() + f4 * 2 * n, 3 * n, xrh.data_ptr() + f4 * i_sz, K, self._grad_of(layer.sW2).data_ptr(), n, M,
+                 n, n)
+        if layer.has_bias:
+            self._colsum(da.data_ptr(), 3 * n, self._grad_of(layer.b).data_ptr(), M, 3 * n)
+        if not need_dx:
+            return None
+        dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
+        _lib.check(L.slk_gemm_bias_act_f32(da.data_ptr(), 3 * n, iW.t().contiguous().data_ptr(), None, dx.data_ptr(), i_sz, M,
+                                           3 * n, i_sz, 0, st()), "gru dx")
+        return dx
+
+    def _conv_backward(self, layer, xin, y, dy):
+        import torch
+        L = _lib.lib()
+        st = layers._stream
+        T, B = int(xin.shape[0]), int(xin.shape[1])
+        To, n = int(y.shape[0]), layer.size
+        M = To * B
+        dpre = torch.empty_like(y)
+        rc = L.slk_act_backward_f32(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), y.numel(), activation.act_id(layer.fun), st())
+        if rc == _lib.SLK_ERR_UNSUPPORTED:
+            raise NotImplementedError("training: Convolution activation %s has no derivative kernel" % layer.fun.__name__)
+        _lib.check(rc, "act_backward")
+        cols = torch.empty((M, layer.winlen), dtype=torch.float32, device=y.device)
+        xc = xin.contiguous()
+        _lib.check(L.slk_train_im2col_cin1_f32(xc.data_ptr(), B, 1, T, B, layer.winlen, layer.stride, layer.padding[0],
+                                               layer.padding[1], cols.data_ptr(), st()), "im2col")
+        self._tn(dpre.data_ptr(), n, cols.data_ptr(), layer.winlen, self._grad_of(layer.W).data_ptr(), layer.winlen, M, n,
+                 layer.winlen)
+        if layer.has_bias:
+            self._colsum(dpre.data_ptr(), n, self._grad_of(layer.b).data_ptr(), M, n)
+
+    def update(self, rate):
+        """One optimiser step on the gradient left by forward_backward (updates.py:36-89, or :9-33 for sgd)."""
+        L = _lib.lib()
+        n = self.flat.numel()
+        gscale = getattr(self, "gscale", 1.0)
+        if self.optimiser == "adam":
+            lr_t, mdecay, self.t = adamski_scalars(self.t, rate, self.decay, self.mrate)
+            rc = L.slk_adamski_update_f32(self.flat.data_ptr(), self.grad.data_ptr(), self.momentum.data_ptr(),
+                                          self.variance.data_ptr(), n, lr_t, mdecay, self.decay[0], self.decay[1], self.epsilon,
+                                          self.clip, self.l2, gscale, layers._stream())
+        else:
+            rc = L.slk_sgd_update_f32(self.flat.data_ptr(), self.grad.data_ptr(), self.momentum.data_ptr(), n, float(rate),
+                                      self.sgd_momentum, self.clip, self.l2, gscale, layers._stream())
+        _lib.check(rc, "update")
+        self._drop_caches()
+
+    def gradients(self):
+        """d loss / d params of the last forward_backward as numpy arrays in network.params() order (updates.py:66),
+        including the l2 term and the rank average -- what the optimiser sees before clipping."""
+        g = (self.grad * getattr(self, "gscale", 1.0) + 2.0 * self.l2 * self.flat).cpu().numpy()
+        return [g[a:b].reshape(p.shape) for p, a, b in zip(self.shared, self.offsets[:-1], self.offsets[1:])]
+
+
+def wrap_network(network, min_prob=0.0, l2=0.0, drop=0, adam=(0.9, 0.999)):
+    """train_network.py:124-142.  `adam` = (decay1, decay2), the reference's `args.adam.decay1/2`."""
+    return TrainingStep(network, min_prob=min_prob, l2=l2, drop=drop, decay=tuple(adam))
+
+
+def save_model(network, output, index=None, step=None):
+    """train_network.py:145-152 (pickle of the network object, loadable by helpers.load_model)."""
+    import os
+    import pickle
+    if step is not None:
+        step.sync_host()
+    model_file = 'model_final.pkl' if index is None else 'model_checkpoint_{:05d}.pkl'.format(index)
+    with open(os.path.join(output, model_file), 'wb') as fh:
+        pickle.dump(network, fh, protocol=pickle.HIGHEST_PROTOCOL)
+    return os.path.join(output, model_file)

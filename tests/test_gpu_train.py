@@ -1,0 +1,185 @@
+"""Parity of the training step (sloika_amd/train.py + csrc/train.hip through the C ABI)
+with the float64 oracle of bin/train_network.py:124-142 and sloika/updates.py:36-89 (oracle/oracle_train.py, itself
+checked against finite differences in tests/test_oracle_train.py)."""
+import numpy as np
+import pytest
+
+from tests.gpu_util import need_gpu, dev, stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(rs, n=32, nstate=17, winlen=5, stride=2, nlayer=3, conv=True, bias=True, scale=0.5):
+    from sloika_amd import activation, layers
+    init = lambda shape: (rs.normal(size=shape) * scale).astype(np.float32)
+    subs = []
+    if conv:
+        subs.append(layers.Convolution(1, n, winlen, stride, init=init, has_bias=bias, fun=activation.elu))
+    for l in range(nlayer):
+        g = layers.Gru(n, n, init=init, has_bias=bias, fun=activation.tanh)
+        subs.append(layers.Reverse(g) if l % 2 == 0 else g)
+    subs.append(layers.Softmax(n, nstate, init=init, has_bias=bias))
+    return layers.Serial(subs)
+
+
+def _batch(rs, net, T, B, nfeat=1):
+    x = rs.normal(size=(T, B, nfeat)).astype(np.float32)
+    first = net.layers[0]
+    To = first.out_len(T) if hasattr(first, "out_len") else T
+    labels = rs.randint(0, net.size, size=(To, B)).astype(np.int32)
+    weights = rs.uniform(0.5, 1.5, size=(To, B)).astype(np.float32)
+    return x, labels, weights
+
+
+def _assert_grads_close(got, want, tol=2e-4):
+    """Relative to the largest entry of each tensor: float32 sums over T*B rows against float64."""
+    assert len(got) == len(want)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape, k
+        scale = max(float(np.abs(w).max()), 1e-6)
+        np.testing.assert_allclose(g / scale, w / scale, atol=tol, err_msg="parameter %d" % k)
+
+
+@pytest.mark.parametrize("n,nstate,T,B,min_prob,l2,drop,bias", [
+    (32, 17, 61, 5, 0.0, 0.0, 0, True),
+    (32, 17, 40, 3, 1e-3, 0.01, 3, True),
+    (16, 5, 24, 2, 1e-30, 0.0, 1, False),
+    (96, 1025, 75, 4, 1e-30, 0.0, 2, True),        # the shapes of models/raw_0.98_rgrgr.py
+    (64, 260, 2100, 2, 1e-5, 0.0, 20, True),       # more rows than one slice of the A^T B contraction
+])
+def test_loss_and_gradients_vs_oracle(n, nstate, T, B, min_prob, l2, drop, bias):
+    need_gpu()
+    from oracle import oracle_train as ot
+    from sloika_amd import train
+    rs = np.random.RandomState(n + T)
+    net = _build(rs, n=n, nstate=nstate, stride=5 if n == 96 else 2, winlen=11 if n == 96 else 5, nlayer=5 if n == 96 else 3,
+                 bias=bias, scale=0.5 if T < 1000 else 0.3)
+    x, labels, weights = _batch(rs, net, T, B)
+    spec = net.spec()
+    for sub in [spec] + spec["sublayers"] + [s.get("sublayer", {}) for s in spec["sublayers"]]:
+        if not bias and "b" in sub:
+            sub["b"] = None                          # the oracle returns gradients for the parameters that exist
+    want_loss, want_acc, want = ot.loss_and_grads(spec, x, labels, weights, min_prob, l2, drop)
+    step = train.TrainingStep(net, min_prob=min_prob, l2=l2, drop=drop)
+    loss, acc = step.forward_backward(x, labels, weights)
+    assert loss == pytest.approx(want_loss, rel=2e-5)
+    assert acc == pytest.approx(want_acc, abs=1e-6)
+    _assert_grads_close(step.gradients(), want)
+
+
+def test_gru_only_network_and_device_inputs():
+    """No convolution in front (the first Gru needs no dL/dx), inputs already on the device."""
+    torch = need_gpu()
+    from oracle import oracle_train as ot
+    from sloika_amd import train
+    rs = np.random.RandomState(3)
+    net = _build(rs, n=16, nstate=9, nlayer=2, conv=False)
+    x, labels, weights = _batch(rs, net, 30, 4, nfeat=16)
+    want_loss, want_acc, want = ot.loss_and_grads(net.spec(), x, labels, weights, 0.0, 0.0, 0)
+    step = train.TrainingStep(net)
+    loss, acc = step.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(labels).cuda(),
+                                      torch.from_numpy(weights).cuda())
+    assert loss == pytest.approx(want_loss, rel=2e-5) and acc == pytest.approx(want_acc, abs=1e-6)
+    _assert_grads_close(step.gradients(), want)
+
+
+@pytest.mark.parametrize("M,N1,N2", [(1, 1, 1), (37, 5, 3), (2049, 96, 11), (5000, 1025, 96), (4111, 288, 100), (300, 33, 1)])
+def test_gemm_tn_vs_numpy(M, N1, N2):
+    """C = A^T B with operands inside wider rows (lda, ldb > N) and a padded result."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(M)
+    lda, ldb, ldc = N1 + 3, N2 + 5, N2 + 2
+    A = rs.normal(size=(M, lda)).astype(np.float32)
+    Bm = rs.normal(size=(M, ldb)).astype(np.float32)
+    dA, dB = dev(A), dev(Bm)
+    C = torch.full((N1, ldc), -7.0, dtype=torch.float32, device="cuda")
+    nbytes = L.slk_gemm_tn_workspace_bytes(M, N1, N2)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    assert L.slk_gemm_tn_f32(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, ws.data_ptr(), nbytes,
+                             stream()) == 0
+    want = A[:, :N1].astype(np.float64).T @ Bm[:, :N2].astype(np.float64)
+    got = C.cpu().numpy()
+    np.testing.assert_allclose(got[:, :N2], want, rtol=1e-5, atol=1e-5 * np.sqrt(M))
+    assert (got[:, N2:] == -7.0).all()
+    assert L.slk_gemm_tn_f32(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, ws.data_ptr(), nbytes - 1,
+                             stream()) == _lib.SLK_ERR_WORKSPACE
+
+
+@pytest.mark.parametrize("optimiser", ["adam", "sgd"])
+def test_optimiser_kernel_vs_oracle(optimiser):
+    """The same gradients through the update kernel and through the float32 restatement of updates.py:36-89 (adam) /
+    :9-33 (sgd), five steps with a decaying rate; clip and l2 active."""
+    torch = need_gpu()
+    from oracle import oracle_train as ot
+    from sloika_amd import train
+    rs = np.random.RandomState(11)
+    net = _build(rs, n=16, nstate=9, nlayer=1)
+    l2 = 0.02
+    step = train.TrainingStep(net, l2=l2, optimiser=optimiser, momentum=0.8)
+    params = [p.get_value() for p in net.params()]
+    opt = ot.Adamski(params)
+    vel = [np.zeros_like(p) for p in params]
+    for it in range(5):
+        grads = [(rs.normal(size=p.shape) * (10.0 if it == 2 else 1.0)).astype(np.float32) for p in params]
+        rate = 1e-2 / (1.0 + it)
+        step.grad.copy_(torch.from_numpy(np.concatenate([g.reshape(-1) for g in grads])))
+        step.update(rate)
+        full = [g + np.float32(2 * l2) * p for g, p in zip(grads, params)]          # th.grad of loss incl. the penalty
+        if optimiser == "adam":
+            params = opt.step(params, full, rate)
+        else:
+            for k in range(len(params)):
+                vel[k] = np.float32(0.8) * vel[k] - np.float32(rate) * np.clip(full[k], -5, 5)
+                params[k] = params[k] + vel[k]
+        step.sync_host()
+        for p, want in zip(net.params(), params):
+            np.testing.assert_allclose(p.get_value(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_training_reduces_loss_and_model_pickles(tmp_path):
+    """fg(x, labels, weights, rate) as the reference's loop calls it (train_network.py:308): a learnable toy task (the
+    label is a function of the local signal level) gets better, the inference path sees the updated weights, and the
+    pickled checkpoint reloads to the same posteriors."""
+    torch = need_gpu()
+    from sloika_amd import helpers, train
+    rs = np.random.RandomState(2)
+    net = _build(rs, n=32, nstate=5, winlen=5, stride=2, nlayer=2, scale=0.3)
+    fg = train.wrap_network(net, min_prob=1e-30, drop=2)
+    T, B = 80, 16
+
+    def batch():
+        level = rs.randint(0, 5, size=(T // 2, B))
+        x = np.repeat(level, 2, axis=0).astype(np.float32)[:, :, None] - 2.0 + 0.1 * rs.normal(size=(T, B, 1)).astype(np.float32)
+        return x, level.astype(np.int32), np.ones((T // 2, B), dtype=np.float32)
+
+    first = last = None
+    for it in range(150):
+        loss, acc = fg(*batch(), 3e-3)
+        assert np.isfinite(loss)
+        first = loss if first is None else first
+        last = (loss, acc)
+    assert last[0] < 0.5 * first and last[1] > 0.8, (first, last)
+    x, labels, _ = batch()
+    post = net.run(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert (post.argmax(2) == labels)[2:-2].mean() > 0.8
+    path = train.save_model(net, str(tmp_path), index=1, step=fg)
+    assert path.endswith("model_checkpoint_00001.pkl")
+    again = helpers.load_model(path)
+    np.testing.assert_allclose(again.run(torch.from_numpy(x).cuda()).cpu().numpy(), post, atol=1e-6)
+
+
+def test_argument_validation():
+    need_gpu()
+    from sloika_amd import train
+    rs = np.random.RandomState(1)
+    net = _build(rs, n=16, nstate=5, nlayer=1)
+    step = train.TrainingStep(net, drop=2)
+    x, labels, weights = _batch(rs, net, 20, 2)
+    with pytest.raises(ValueError):
+        step.forward_backward(x, labels[:-1], weights[:-1])
+    with pytest.raises(ValueError):
+        step.forward_backward(x, labels + 5, weights)
+    with pytest.raises(ValueError):
+        train.TrainingStep(net, drop=5).forward_backward(x, labels, weights)
