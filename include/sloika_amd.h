@@ -292,13 +292,14 @@ int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *e
  * slk_gru_backward_f32: the reverse scan.  dy:[T][B] rows lddy apart = dL/dh from the layer above; writes
  *   da:[M][3n] = dL/dvI = [daz | dar | dac].  n in {16,32,48,64,96,112,128,144}, tanh / sigmoid, else SLK_ERR_UNSUPPORTED.
  *   Weight gradients follow as contractions over m (slk_gemm_tn_f32): diW = da^T x, dsW = da[:, :2n]^T h_prev,
- *   dsW2 = da[:, 2n:]^T (r*h_prev), db = da^T 1; and dL/dx = da . iW (slk_gemm_bias_act_f32 with iW^T).
+ *   dsW2 = da[:, 2n:]^T (r*h_prev), db = da^T 1 (its colsum output); and dL/dx = da . iW (slk_gemm_bias_act_f32 with iW^T).
  * slk_softmax_xent_grad_f32: loss terms and dL/dlogits of train_network.py:128-136, in place over the logits written by
  *   slk_linear_rowstats_* (stats:[M][2] = max, 1/sum).  loss_rows[m] and correct_rows[m] are already divided by the
  *   number of counted positions (T - 2 drop) * B, so their sums are the data term of the loss and the accuracy.
  *   Columns nstate..ld-1 of every row are set to zero.  labels must lie in [0, nstate).
  * slk_reduce_sum_f32: out[0] = sum x (square = 0) or sum x^2 (square = 1: updates.param_sqr), float64, fixed order.
- * slk_gemm_tn_f32: C[N1][N2] (rows ldc apart) = A^T B, A:[M][N1] rows lda apart, B:[M][N2] rows ldb apart.
+ * slk_gemm_tn_f32: C[N1][N2] (rows ldc apart) = A^T B, A:[M][N1] rows lda apart, B:[M][N2] rows ldb apart; when colsum is
+ *   given it also receives the column sums of A (A^T 1: the bias gradient) from the same pass.
  * slk_act_backward_f32: out = dy * fun'(pre-activation) written through the OUTPUT y; linear/tanh/sigmoid/relu/elu.
  * slk_train_im2col_cin1_f32: window rows of a one-feature Convolution, cols:[Tout*B][winlen] (dW = dpre^T cols).
  * slk_adamski_update_f32: updates.py:77-87 over flat buffers with this step's lr_t / momentum_decay (updates.py:73-76);
@@ -316,7 +317,7 @@ int slk_softmax_xent_grad_f32(float *logits, long ld, const float *stats, const 
 int slk_reduce_sum_f32(const float *x, size_t n, int square, double *out, slk_stream_t stream);
 size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2);
 int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
-                    void *workspace, size_t workspace_bytes, slk_stream_t stream);
+                    float *colsum /* [N1] or NULL */, void *workspace, size_t workspace_bytes, slk_stream_t stream);
 int slk_act_backward_f32(const float *dy, const float *y, float *out, size_t n, int act, slk_stream_t stream);
 int slk_train_im2col_cin1_f32(const float *x, long x_t_stride, long x_b_stride, int T, int B, int winlen, int stride,
                               int pad_lo, int pad_hi, float *cols, slk_stream_t stream);

@@ -20,44 +20,50 @@
 //   * ADAMski (updates.py:36-89) is one element-wise kernel over the flat parameter / gradient / moment buffers; the
 //     data-parallel all-reduce of the flat gradient (RCCL) happens on the host side between the two.
 #include "common.h"
+#include "mfma4.h"
 
 // ---------------------------------------------------------------------------------------------------------------
 // Packed rows for the gate recompute: xh[m] = [x[m] | h_prev[m]], h_prev(t, b) = h at the previous SCAN step (zero at
 // the scan start: layers.py:85-88), the scan running backwards in time when `reverse` (layers.py:1449-1450).
 // ---------------------------------------------------------------------------------------------------------------
+// V = 4: float4 per thread (sizes, strides and pointers multiples of 4 floats), V = 1: any
+template <int V>
 __global__ void __launch_bounds__(256) pack_xh_kernel(const float *__restrict__ x, long ldx, const float *__restrict__ h,
                                                       long ldh, float *__restrict__ xh, int T, int B, int I, int N,
                                                       int reverse)
 {
-    const int W = I + N;
+    typedef float vec __attribute__((ext_vector_type(V)));
+    const int W = (I + N) / V;
     const size_t total = (size_t)T * B * W;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const size_t m = e / W;
-        const int j = (int)(e - m * W);
-        float v;
+        const int j = (int)(e - m * W) * V;
+        vec v = 0.0f;
         if (j < I) {
-            v = x[m * ldx + j];
+            v = *reinterpret_cast<const vec *>(x + m * ldx + j);
         } else {
             const int t = (int)(m / B), b = (int)(m - (size_t)t * B);
             const int tp = reverse ? t + 1 : t - 1;
-            v = (tp >= 0 && tp < T) ? h[((size_t)tp * B + b) * ldh + (j - I)] : 0.0f;
+            if (tp >= 0 && tp < T) v = *reinterpret_cast<const vec *>(h + ((size_t)tp * B + b) * ldh + (j - I));
         }
-        xh[e] = v;
+        *reinterpret_cast<vec *>(xh + e * V) = v;
     }
 }
 
 // xrh[m] = [x[m] | r[m] * h_prev[m]] from xh and the gates zr[m] = [z | r]
+template <int V>
 __global__ void __launch_bounds__(256) pack_xrh_kernel(const float *__restrict__ xh, const float *__restrict__ zr,
                                                        float *__restrict__ xrh, size_t M, int I, int N)
 {
-    const int W = I + N;
+    typedef float vec __attribute__((ext_vector_type(V)));
+    const int W = (I + N) / V;
     const size_t total = M * W;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const size_t m = e / W;
-        const int j = (int)(e - m * W);
-        float v = xh[e];
-        if (j >= I) v *= zr[m * (2 * (size_t)N) + N + (j - I)];
-        xrh[e] = v;
+        const int j = (int)(e - m * W) * V;
+        vec v = *reinterpret_cast<const vec *>(xh + e * V);
+        if (j >= I) v *= *reinterpret_cast<const vec *>(zr + m * (2 * (size_t)N) + N + (j - I));
+        *reinterpret_cast<vec *>(xrh + e * V) = v;
     }
 }
 
@@ -71,8 +77,14 @@ extern "C" int slk_train_pack_xh_f32(const float *x, long ldx, const float *h, l
                                      int N, int reverse, slk_stream_t stream)
 {
     if (!x || !h || !xh || T < 1 || B < 1 || I < 1 || N < 1 || ldx < I || ldh < N) return SLK_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(pack_xh_kernel, dim3(elementwise_grid((size_t)T * B * (I + N))), dim3(256), 0, slk_stream(stream), x,
-                       ldx, h, ldh, xh, T, B, I, N, reverse);
+    const bool v4 = I % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldh % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(xh)) & 15) == 0;
+    if (v4)
+        hipLaunchKernelGGL(pack_xh_kernel<4>, dim3(elementwise_grid((size_t)T * B * (I + N) / 4)), dim3(256), 0,
+                           slk_stream(stream), x, ldx, h, ldh, xh, T, B, I, N, reverse);
+    else
+        hipLaunchKernelGGL(pack_xh_kernel<1>, dim3(elementwise_grid((size_t)T * B * (I + N))), dim3(256), 0, slk_stream(stream),
+                           x, ldx, h, ldh, xh, T, B, I, N, reverse);
     return slk_launch_status();
 }
 
@@ -80,8 +92,14 @@ extern "C" int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *x
                                       slk_stream_t stream)
 {
     if (!xh || !zr || !xrh || M < 1 || I < 1 || N < 1) return SLK_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(pack_xrh_kernel, dim3(elementwise_grid((size_t)M * (I + N))), dim3(256), 0, slk_stream(stream), xh,
-                       zr, xrh, (size_t)M, I, N);
+    const bool v4 = I % 4 == 0 && N % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(xh) | reinterpret_cast<uintptr_t>(zr) | reinterpret_cast<uintptr_t>(xrh)) & 15) == 0;
+    if (v4)
+        hipLaunchKernelGGL(pack_xrh_kernel<4>, dim3(elementwise_grid((size_t)M * (I + N) / 4)), dim3(256), 0, slk_stream(stream),
+                           xh, zr, xrh, (size_t)M, I, N);
+    else
+        hipLaunchKernelGGL(pack_xrh_kernel<1>, dim3(elementwise_grid((size_t)M * (I + N))), dim3(256), 0, slk_stream(stream), xh,
+                           zr, xrh, (size_t)M, I, N);
     return slk_launch_status();
 }
 
@@ -167,12 +185,116 @@ __global__ void __launch_bounds__(4 * N) gru_backward_kernel(const float *__rest
     }
 }
 
+// Same scan, restructured for latency (the step is a chain of dependent LDS round trips and barriers, not arithmetic):
+//   * operands of every step arrive through a dedicated loader wave and LDS-DMA (global_load_lds, no register staging)
+//     D steps ahead of their use.  In the kernel above the owner threads' own loads and stores share one vmcnt counter,
+//     so "wait for this step's operands" also waits for everything younger and every step pays a memory round trip;
+//     here the compute waves never wait on memory (their da stores just drain), the loader issues loads only, so
+//     s_waitcnt vmcnt(5*(D-1)) means exactly "the step needed next has landed", and barriers are LDS-only;
+//   * the four K-quarters of an output live in ONE wave (lane = 16*quarter + output), so the partial sums meet through
+//     two row-swap instructions instead of an LDS write, a barrier and an LDS read: two barriers per step, not four;
+//   * the vectors the next step overwrites are double-buffered by step parity instead of fenced by a third barrier.
+// Needs 16-byte aligned operand rows.
+template <int N>
+__global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const float *__restrict__ dy, long lddy,
+                                                                      const float *__restrict__ xh, int I,
+                                                                      const float *__restrict__ zr,
+                                                                      const float *__restrict__ c,
+                                                                      const float *__restrict__ sW,
+                                                                      const float *__restrict__ sW2, float *__restrict__ da,
+                                                                      int T, int B, int reverse)
+{
+    constexpr int Q2 = N / 4, Q1 = 2 * N / 4, D = 8;
+    __shared__ __attribute__((aligned(16))) float ring[D][5][N];
+    __shared__ __attribute__((aligned(16))) float v_dac[2][N], v_dzr[2][2 * N];
+    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63;
+    const bool loader = tid >= 4 * N;
+    const int i = loader ? 0 : 16 * (tid >> 6) + (lane & 15), q = lane >> 4;
+    const bool owner = !loader && q == 0;
+    const long ldxh = I + N;
+    auto row = [&](int s) { return (size_t)(reverse ? T - 1 - s : s) * B + b; };
+    auto issue = [&](int sp) {                                    // loader wave: the five operand rows of scan step sp
+        if (lane < N / 4) {
+            const size_t m = row(sp);
+            float *dst = &ring[sp % D][0][0];
+            const float *src[5] = {dy + m * lddy, zr + m * (2 * N), zr + m * (2 * N) + N, c + m * N, xh + m * ldxh + I};
+#pragma unroll
+            for (int a = 0; a < 5; a++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[a] + 4 * lane),
+                                                 (__attribute__((address_space(3))) void *)(dst + a * N), 16, 0, 0);
+        }
+    };
+    float w2[Q2], w1[Q1];
+    if (!loader) {
+#pragma unroll
+        for (int j = 0; j < Q2; j++) w2[j] = sW2[(size_t)(q * Q2 + j) * N + i];      // drh[i] = sum_k dac[k] sW2[k][i]
+#pragma unroll
+        for (int j = 0; j < Q1; j++) w1[j] = sW[(size_t)(q * Q1 + j) * N + i];       // carry[i] += sum_k dzr[k] sW[k][i]
+    } else {
+        for (int sp = T - 1; sp >= 0 && sp > T - 1 - D; sp--) issue(sp);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    float carry = 0.0f;
+    for (int s = T - 1; s >= 0; s--) {
+        const int par = s & 1;
+        float g = 0.f, z = 0.f, r = 0.f, h = 0.f;
+        if (owner) {
+            const float *op = &ring[s % D][0][0];
+            g = op[i] + carry; z = op[N + i]; r = op[2 * N + i]; h = op[4 * N + i];
+            const float cc = op[3 * N + i];
+            const float dac = g * (1.0f - z) * (1.0f - cc * cc);
+            const float daz = g * (h - cc) * z * (1.0f - z);
+            v_dac[par][i] = dac;
+            v_dzr[par][i] = daz;
+            da[row(s) * (3 * N) + 2 * N + i] = dac;
+            da[row(s) * (3 * N) + i] = daz;
+        }
+        lds_barrier();                                            // 1: dac visible; ring slot s % D is free again
+        float keep = 0.0f;
+        if (loader) {
+            // step s-1 is read after barrier 2; the D-1 younger steps (5 loads each) may stay in flight -- unless fewer
+            // than that were issued (the last D steps), where everything is awaited
+            if (s - D >= 0) {
+                issue(s - D);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (D - 1)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < Q2; j++) acc = fmaf(v_dac[par][q * Q2 + j], w2[j], acc);
+            const float drh = xor32_sum(xor16_sum(acc));
+            if (owner) {
+                const float dar = drh * h * r * (1.0f - r);
+                v_dzr[par][N + i] = dar;
+                da[row(s) * (3 * N) + N + i] = dar;
+                keep = g * z + drh * r;
+            }
+        }
+        lds_barrier();                                            // 2: [daz dar] visible; ring slot (s-1) % D has landed
+        if (!loader) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < Q1; j++) acc = fmaf(v_dzr[par][q * Q1 + j], w1[j], acc);
+            carry = keep + xor32_sum(xor16_sum(acc));
+        }
+    }
+}
+
 template <int N>
 static int launch_gru_backward(const float *dy, long lddy, const float *xh, int I, const float *zr, const float *c,
                                const float *sW, const float *sW2, float *da, int T, int B, int reverse, hipStream_t s)
 {
-    hipLaunchKernelGGL((gru_backward_kernel<N>), dim3(B), dim3(4 * N), 0, s, dy, lddy, xh, I, zr, c, sW, sW2, da, T, B,
-                       reverse);
+    const bool aligned = lddy % 4 == 0 && I % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(xh) |
+                                                           reinterpret_cast<uintptr_t>(zr) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+    if (aligned)
+        hipLaunchKernelGGL((gru_backward_dma_kernel<N>), dim3(B), dim3(4 * N + 64), 0, s, dy, lddy, xh, I, zr, c, sW, sW2, da,
+                           T, B, reverse);
+    else
+        hipLaunchKernelGGL((gru_backward_kernel<N>), dim3(B), dim3(4 * N), 0, s, dy, lddy, xh, I, zr, c, sW, sW2, da, T, B,
+                           reverse);
     return slk_launch_status();
 }
 
@@ -259,7 +381,15 @@ __global__ void __launch_bounds__(1024) reduce_sum_kernel(const float *__restric
 {
     __shared__ double part[1024];
     double acc = 0.0;
-    for (size_t e = threadIdx.x; e < n; e += 1024) {
+    size_t e = threadIdx.x;
+    for (; e + 7 * 1024 < n; e += 8 * 1024) {            // eight loads in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = x[e + (size_t)k * 1024];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc += square ? (double)v[k] * v[k] : (double)v[k];
+    }
+    for (; e < n; e += 1024) {
         const double v = x[e];
         acc += square ? v * v : v;
     }
@@ -283,25 +413,31 @@ extern "C" int slk_reduce_sum_f32(const float *x, size_t n, int square, double *
 // C[N1][N2] = A^T B over M rows (A:[M][N1], B:[M][N2], row-major): every weight gradient of the reverse pass.
 // v_mfma_f32_32x32x2_f32 contracts over k = the ROW index m, and both operands want "32 consecutive columns of one row
 // per half-wave": exactly what row-major A and B give, so operands go from global memory to the MFMA without LDS or
-// transposes.  One wave per workgroup owns a 96 x 96 block of C (3 x 3 accumulators) for one slice of TN_ROWS rows and
-// writes a partial block; tn_reduce_kernel adds the slices in a fixed order (deterministic, unlike atomics).
+// transposes.  One wave per workgroup owns a 96 x 96 block of C (3 x 3 accumulators) for one slice of rows and writes a
+// partial block; tn_reduce_kernel adds the slices in a fixed order (deterministic, unlike atomics).  The slice height
+// is chosen per call so that a small C still gives every SIMD of the chip a wave or two (tn_slice_rows).
 // ---------------------------------------------------------------------------------------------------------------
-#define TN_ROWS 2048
+#define TN_ROWS 2048           /* tallest slice */
+#define TN_MIN_ROWS 256
+#define TN_WAVES 2048          /* waves wanted per launch: 256 CUs x 4 SIMDs x 2 */
 #define TN_BLK 96
 #define TN_UNROLL 8
 
+// CS: also produce the column sums of A (the bias gradient, da^T 1) from the operands already in registers
+template <bool CS>
 __global__ void __launch_bounds__(64) gemm_tn_kernel(const float *__restrict__ A, long lda, const float *__restrict__ Bm,
-                                                     long ldb, float *__restrict__ partial, long M, int N1, int N2)
+                                                     long ldb, float *__restrict__ partial, long M, int N1, int N2,
+                                                     float *__restrict__ cs_partial, int slice_rows)
 {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     const int n1_0 = blockIdx.y * TN_BLK, n2_0 = blockIdx.z * TN_BLK;
-    const long m_lo = (long)blockIdx.x * TN_ROWS, m_hi = min(m_lo + TN_ROWS, M);
+    const long m_lo = (long)blockIdx.x * slice_rows, m_hi = min(m_lo + slice_rows, M);
     const int ta = min(3, (N1 - n1_0 + 31) / 32), tb = min(3, (N2 - n2_0 + 31) / 32);    // live 32-wide tiles (uniform)
-    int ca[3], cb[3];
+    const float *pa[3], *pb[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        ca[i] = min(n1_0 + 32 * i + r, N1 - 1);
-        cb[i] = min(n2_0 + 32 * i + r, N2 - 1);
+        pa[i] = A + min(n1_0 + 32 * i + r, N1 - 1);
+        pb[i] = Bm + min(n2_0 + 32 * i + r, N2 - 1);
     }
     f32x16 acc[3][3];
 #pragma unroll
@@ -310,27 +446,48 @@ __global__ void __launch_bounds__(64) gemm_tn_kernel(const float *__restrict__ A
         for (int j = 0; j < 3; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+    float cs[3] = {0.0f, 0.0f, 0.0f};
 
-    for (long m0 = m_lo; m0 < m_hi; m0 += 2 * TN_UNROLL) {
-        float av[TN_UNROLL][3], bv[TN_UNROLL][3];
+    // two register buffers of 2*TN_UNROLL rows each: the loads of the next block are in flight while the matrix pipe
+    // works through the current one (one wave per SIMD at this register footprint, so the overlap has to be in-wave).
+    // Rows past the slice are read from a clamped (valid) address and zeroed when consumed -- masking at load time
+    // would make the wave wait for the load immediately.
+    float a0[TN_UNROLL][3], b0[TN_UNROLL][3], a1[TN_UNROLL][3], b1[TN_UNROLL][3];
+    auto load = [&](float (&av)[TN_UNROLL][3], float (&bv)[TN_UNROLL][3], long m0) {
 #pragma unroll
         for (int u = 0; u < TN_UNROLL; u++) {
-            const long m = m0 + 2 * u + h, mc = min(m, M - 1);
-            const float live = m < m_hi ? 1.0f : 0.0f;
+            const long mc = min(m0 + 2 * u + h, M - 1);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                av[u][i] = i < ta ? A[mc * lda + ca[i]] * live : 0.0f;
-                bv[u][i] = i < tb ? Bm[mc * ldb + cb[i]] : 0.0f;
+                av[u][i] = i < ta ? pa[i][mc * lda] : 0.0f;
+                bv[u][i] = i < tb ? pb[i][mc * ldb] : 0.0f;
             }
         }
+    };
+    auto mma = [&](float (&av)[TN_UNROLL][3], float (&bv)[TN_UNROLL][3], long m0) {
 #pragma unroll
-        for (int u = 0; u < TN_UNROLL; u++)
+        for (int u = 0; u < TN_UNROLL; u++) {
+            const float live = (m0 + 2 * u + h) < m_hi ? 1.0f : 0.0f;
+            float a[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                a[i] = av[u][i] * live;
+                if (CS) cs[i] += a[i];
+            }
 #pragma unroll
             for (int i = 0; i < 3; i++)
 #pragma unroll
                 for (int j = 0; j < 3; j++)
-                    if (i < ta && j < tb)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
+                    if (i < ta && j < tb) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[u][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    constexpr int STEP = 2 * TN_UNROLL;
+    load(a0, b0, m_lo);
+    for (long m0 = m_lo; m0 < m_hi; m0 += 2 * STEP) {
+        load(a1, b1, m0 + STEP);
+        mma(a0, b0, m0);
+        load(a0, b0, m0 + 2 * STEP);
+        mma(a1, b1, m0 + STEP);
     }
     // partial[slice][N1][N2]; D[row = (e&3) + 8*(e>>2) + 4*h][col = r]; columns clamped above are dropped here
     float *out = partial + (size_t)blockIdx.x * N1 * N2;
@@ -347,6 +504,14 @@ __global__ void __launch_bounds__(64) gemm_tn_kernel(const float *__restrict__ A
                 }
             }
         }
+    if (CS && blockIdx.z == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float tot = cs[i] + __shfl_xor(cs[i], 32);
+            const int colc = n1_0 + 32 * i + r;
+            if (h == 0 && i < ta && colc < N1) cs_partial[(size_t)blockIdx.x * N1 + colc] = tot;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) tn_reduce_kernel(const float *__restrict__ partial, int nslice, int N1, int N2,
@@ -355,30 +520,56 @@ __global__ void __launch_bounds__(256) tn_reduce_kernel(const float *__restrict_
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)N1 * N2;
     if (e >= total) return;
     double acc = 0.0;
-    for (int s = 0; s < nslice; s++) acc += partial[(size_t)s * total + e];
+    int s = 0;
+    for (; s + 8 <= nslice; s += 8) {                    // eight loads in flight, added in slice order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = partial[(size_t)(s + k) * total + e];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc += v[k];
+    }
+    for (; s < nslice; s++) acc += partial[(size_t)s * total + e];
     C[(e / N2) * ldc + (e % N2)] = (float)acc;
+}
+
+static int tn_slice_rows(long M, int N1, int N2)
+{
+    const long blocks = (long)((N1 + TN_BLK - 1) / TN_BLK) * ((N2 + TN_BLK - 1) / TN_BLK);
+    long rows = M * blocks / TN_WAVES;
+    rows = (rows + 31) / 32 * 32;                              // the kernel walks 32 rows per double-buffered iteration
+    return (int)(rows < TN_MIN_ROWS ? TN_MIN_ROWS : (rows > TN_ROWS ? TN_ROWS : rows));
 }
 
 extern "C" size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2)
 {
     if (M < 1 || N1 < 1 || N2 < 1) return 0;
-    return (size_t)((M + TN_ROWS - 1) / TN_ROWS) * N1 * N2 * sizeof(float);
+    const int rows = tn_slice_rows(M, N1, N2);
+    return (size_t)((M + rows - 1) / rows) * N1 * ((size_t)N2 + 1) * sizeof(float);
 }
 
 extern "C" int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
-                               void *workspace, size_t workspace_bytes, slk_stream_t stream)
+                               float *colsum, void *workspace, size_t workspace_bytes, slk_stream_t stream)
 {
     if (!A || !B || !C || M < 1 || N1 < 1 || N2 < 1 || lda < N1 || ldb < N2 || ldc < N2) return SLK_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < slk_gemm_tn_workspace_bytes(M, N1, N2)) return SLK_ERR_WORKSPACE;
-    const long nslice = (M + TN_ROWS - 1) / TN_ROWS;
+    const int rows = tn_slice_rows(M, N1, N2);
+    const long nslice = (M + rows - 1) / rows;
     const int g1 = (N1 + TN_BLK - 1) / TN_BLK, g2 = (N2 + TN_BLK - 1) / TN_BLK;
     if (nslice > 0x7fffffffL || g1 > 65535 || g2 > 65535) return SLK_ERR_UNSUPPORTED;
     hipStream_t s = slk_stream(stream);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)nslice, g1, g2), dim3(64), 0, s, A, lda, B, ldb, (float *)workspace, M,
-                       N1, N2);
+    float *partial = (float *)workspace, *cs_partial = partial + (size_t)nslice * N1 * N2;
+    if (colsum)
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)nslice, g1, g2), dim3(64), 0, s, A, lda, B, ldb, partial, M, N1,
+                           N2, cs_partial, rows);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3((unsigned)nslice, g1, g2), dim3(64), 0, s, A, lda, B, ldb, partial, M,
+                           N1, N2, cs_partial, rows);
     const size_t total = (size_t)N1 * N2;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)workspace,
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)partial,
                        (int)nslice, N1, N2, C, ldc);
+    if (colsum)
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((N1 + 255) / 256)), dim3(256), 0, s, (const float *)cs_partial,
+                           (int)nslice, N1, 1, colsum, 1L);
     return slk_launch_status();
 }
 

@@ -140,7 +140,6 @@ class TrainingStep(object):
         self.variance = torch.zeros(total, dtype=torch.float32, device=dev) if optimiser == "adam" else None
         self._index = {id(p): i for i, p in enumerate(self.shared)}
         self._ws = None
-        self._ones = None
         self._scalars = torch.zeros(3, dtype=torch.float64, device=dev)
         self._drop_caches()
 
@@ -169,18 +168,13 @@ class TrainingStep(object):
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.flat.device)
         return self._ws
 
-    def _tn(self, A, lda, Bm, ldb, C, ldc, M, n1, n2):
-        """C[n1][n2] = A^T B over M rows."""
+    def _tn(self, A, lda, Bm, ldb, C, ldc, M, n1, n2, colsum=None):
+        """C[n1][n2] = A^T B over M rows; colsum (optional) = A^T 1."""
         L = _lib.lib()
         nbytes = L.slk_gemm_tn_workspace_bytes(M, n1, n2)
         ws = self._workspace(nbytes)
-        _lib.check(L.slk_gemm_tn_f32(A, lda, Bm, ldb, C, ldc, M, n1, n2, ws.data_ptr(), nbytes, layers._stream()), "gemm_tn")
-
-    def _colsum(self, A, lda, C, M, n1):
-        import torch
-        if self._ones is None or self._ones.numel() < M:
-            self._ones = torch.ones(M, dtype=torch.float32, device=self.flat.device)
-        self._tn(A, lda, self._ones.data_ptr(), 1, C, 1, M, n1, 1)
+        _lib.check(L.slk_gemm_tn_f32(A, lda, Bm, ldb, C, ldc, M, n1, n2, colsum, ws.data_ptr(), nbytes, layers._stream()),
+                   "gemm_tn")
 
     def _gemm(self, x, ldx, W, bias, y, ldy, M, K, N, act):
         """y = act(x . W^T + b), W:[N][K] -- fp16 3-term split where it applies, else float32 MFMA."""
@@ -243,9 +237,7 @@ class TrainingStep(object):
         # ---- softmax layer ---------------------------------------------------------------------------------------------
         n_in = sm.insize
         self._tn(logits.data_ptr(), ld, h_top.data_ptr(), layers._row_stride(h_top), self._grad_of(sm.W).data_ptr(), n_in, M,
-                 sm.size, n_in)
-        if sm.has_bias:
-            self._colsum(logits.data_ptr(), ld, self._grad_of(sm.b).data_ptr(), M, sm.size)
+                 sm.size, n_in, colsum=self._grad_of(sm.b).data_ptr() if sm.has_bias else None)
         dy = None
         if len(self.plan) > 1:
             wt = torch.zeros((n_in, ld), dtype=torch.float32, device=x.device)          # W^T, rows padded like the logits
@@ -301,12 +293,11 @@ class TrainingStep(object):
             raise NotImplementedError("training: no reverse-scan kernel for a Gru of size %d" % n)
         _lib.check(rc, "gru_backward")
         f4 = 4                                                                       # bytes per float, for column offsets
-        self._tn(da.data_ptr(), 3 * n, xh.data_ptr(), K, self._grad_of(layer.iW).data_ptr(), i_sz, M, 3 * n, i_sz)
+        self._tn(da.data_ptr(), 3 * n, xh.data_ptr(), K, self._grad_of(layer.iW).data_ptr(), i_sz, M, 3 * n, i_sz,
+                 colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
         self._tn(da.data_ptr(), 3 * n, xh.data_ptr() + f4 * i_sz, K, self._grad_of(layer.sW).data_ptr(), n, M, 2 * n, n)
         self._tn(da.data_ptr() + f4 * 2 * n, 3 * n, xrh.data_ptr() + f4 * i_sz, K, self._grad_of(layer.sW2).data_ptr(), n, M,
                  n, n)
-        if layer.has_bias:
-            self._colsum(da.data_ptr(), 3 * n, self._grad_of(layer.b).data_ptr(), M, 3 * n)
         if not need_dx:
             return None
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
@@ -331,9 +322,7 @@ class TrainingStep(object):
         _lib.check(L.slk_train_im2col_cin1_f32(xc.data_ptr(), B, 1, T, B, layer.winlen, layer.stride, layer.padding[0],
                                                layer.padding[1], cols.data_ptr(), st()), "im2col")
         self._tn(dpre.data_ptr(), n, cols.data_ptr(), layer.winlen, self._grad_of(layer.W).data_ptr(), layer.winlen, M, n,
-                 layer.winlen)
-        if layer.has_bias:
-            self._colsum(dpre.data_ptr(), n, self._grad_of(layer.b).data_ptr(), M, n)
+                 layer.winlen, colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
 
     def update(self, rate):
         """One optimiser step on the gradient left by forward_backward (updates.py:36-89, or :9-33 for sgd)."""

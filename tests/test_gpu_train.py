@@ -97,14 +97,21 @@ def test_gemm_tn_vs_numpy(M, N1, N2):
     C = torch.full((N1, ldc), -7.0, dtype=torch.float32, device="cuda")
     nbytes = L.slk_gemm_tn_workspace_bytes(M, N1, N2)
     ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-    assert L.slk_gemm_tn_f32(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, ws.data_ptr(), nbytes,
-                             stream()) == 0
+    cs = torch.full((N1 + 1,), -7.0, dtype=torch.float32, device="cuda")
+    assert L.slk_gemm_tn_f32(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, cs.data_ptr(), ws.data_ptr(),
+                             nbytes, stream()) == 0
     want = A[:, :N1].astype(np.float64).T @ Bm[:, :N2].astype(np.float64)
     got = C.cpu().numpy()
     np.testing.assert_allclose(got[:, :N2], want, rtol=1e-5, atol=1e-5 * np.sqrt(M))
     assert (got[:, N2:] == -7.0).all()
-    assert L.slk_gemm_tn_f32(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, ws.data_ptr(), nbytes - 1,
-                             stream()) == _lib.SLK_ERR_WORKSPACE
+    np.testing.assert_allclose(cs.cpu().numpy()[:N1], A[:, :N1].astype(np.float64).sum(0), rtol=1e-5, atol=1e-5 * np.sqrt(M))
+    assert float(cs[N1]) == -7.0
+    C.fill_(-7.0)
+    assert L.slk_gemm_tn_f32(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, None, ws.data_ptr(), nbytes,
+                             stream()) == 0
+    np.testing.assert_allclose(C.cpu().numpy()[:, :N2], want, rtol=1e-5, atol=1e-5 * np.sqrt(M))
+    assert L.slk_gemm_tn_f32(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, None, ws.data_ptr(),
+                             nbytes - 1, stream()) == _lib.SLK_ERR_WORKSPACE
 
 
 @pytest.mark.parametrize("optimiser", ["adam", "sgd"])
@@ -183,3 +190,51 @@ def test_argument_validation():
         step.forward_backward(x, labels + 5, weights)
     with pytest.raises(ValueError):
         train.TrainingStep(net, drop=5).forward_backward(x, labels, weights)
+
+
+@pytest.mark.parametrize("n,reverse", [(96, 0), (32, 1), (144, 1)])
+def test_gru_backward_kernels_agree(n, reverse):
+    """The reverse scan has two kernels: operands through an LDS-DMA loader wave (16-byte aligned rows) and a plain one
+    (any alignment).  Same inputs, dy once aligned and once shifted by one float: identical pre-activation gradients, and
+    both equal the float64 recursion of oracle_train._backward's GRU step."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(n)
+    T, B, I = 37, 5, 16
+    M = T * B
+    dy = rs.normal(size=(M, n)).astype(np.float32)
+    xh = rs.normal(size=(M, I + n)).astype(np.float32)
+    zr = rs.uniform(0.05, 0.95, size=(M, 2 * n)).astype(np.float32)
+    c = rs.uniform(-0.95, 0.95, size=(M, n)).astype(np.float32)
+    sW = (rs.normal(size=(2 * n, n)) / np.sqrt(n)).astype(np.float32)
+    sW2 = (rs.normal(size=(n, n)) / np.sqrt(n)).astype(np.float32)
+    # float64 recursion
+    want = np.zeros((M, 3 * n))
+    carry = np.zeros((B, n))
+    for s in range(T - 1, -1, -1):
+        t = T - 1 - s if reverse else s
+        rows = slice(t * B, (t + 1) * B)
+        g = dy[rows] + carry
+        z, r, h, cc = zr[rows, :n].astype(np.float64), zr[rows, n:].astype(np.float64), xh[rows, I:].astype(np.float64), c[rows].astype(np.float64)
+        dac = g * (1 - z) * (1 - cc * cc)
+        daz = g * (h - cc) * z * (1 - z)
+        drh = dac @ sW2
+        dar = drh * h * r * (1 - r)
+        carry = g * z + drh * r + np.concatenate([daz, dar], 1) @ sW
+        want[rows] = np.concatenate([daz, dar, dac], 1)
+    d = {k: dev(v) for k, v in dict(xh=xh, zr=zr, c=c, sW=sW, sW2=sW2).items()}
+    outs = []
+    for shift in (0, 1):
+        buf = torch.zeros(M * n + 4, dtype=torch.float32, device="cuda")
+        buf[shift:shift + M * n] = dev(dy).reshape(-1)
+        da = torch.empty((M, 3 * n), dtype=torch.float32, device="cuda")
+        rc = L.slk_gru_backward_f32(buf.data_ptr() + 4 * shift, n, d["xh"].data_ptr(), I, d["zr"].data_ptr(), d["c"].data_ptr(),
+                                    d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), T, B, n, reverse, 1, 2, stream())
+        assert rc == 0
+        outs.append(da.cpu().numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0], want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+    assert L.slk_gru_backward_f32(d["xh"].data_ptr(), 160, d["xh"].data_ptr(), I, d["zr"].data_ptr(), d["c"].data_ptr(),
+                                  d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), T, B, 40, reverse, 1, 2,
+                                  stream()) == _lib.SLK_ERR_UNSUPPORTED

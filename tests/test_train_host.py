@@ -1,0 +1,107 @@
+"""Host logic of the training step (sloika_amd/train.py) that needs no GPU: which networks the step accepts, the ADAMski
+step-size schedule (updates.py:54-76), and the data-parallel reduction on two gloo ranks -- each rank differentiates its
+own half of the batch (here with the float64 oracle, allowed in tests only), one all-reduce + the returned scale must
+reproduce the gradient of the whole batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+
+def test_supported_architectures():
+    from sloika_amd import activation, layers, models, train
+    plan = train._plan(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=1))
+    assert [k for k, _, _ in plan] == ["conv"] + ["gru"] * 5 + ["softmax"]
+    assert [r for _, _, r in plan] == [False, True, False, True, False, True, False]
+    g = layers.Gru(4, 8)
+    assert [k for k, _, _ in train._plan(layers.Serial([layers.Reverse(layers.Reverse(g)), layers.Softmax(8, 5)]))] == ["gru", "softmax"]
+    for bad in (layers.Serial([g]),                                                      # no softmax
+                layers.Serial([layers.Lstm(4, 8), layers.Softmax(8, 5)]),
+                layers.Serial([layers.Convolution(4, 8, 3), layers.Softmax(8, 5)]),    # multi-feature convolution
+                models.build_model("baseline_raw_gru", klen=5, sd=0.5, seed=1)):       # Parallel / FeedForward inside
+        with pytest.raises(NotImplementedError):
+            train._plan(bad)
+
+
+@pytest.mark.parametrize("mrate", [0.0005, 0.01, None])
+def test_adamski_schedule_matches_oracle(mrate):
+    from oracle import oracle_train as ot
+    from sloika_amd import train
+    opt = ot.Adamski([np.zeros(1)], decay=(0.9, 0.999), mrate=mrate)
+    t = 0.0
+    for it in range(12):
+        rate = 1e-3 / (1.0 + it / 5.0)
+        lr, md, t = train.adamski_scalars(t, rate, (0.9, 0.999), mrate)
+        want_lr, want_md = opt.scalars(rate)
+        assert lr == float(want_lr) and md == float(want_md) and t == float(opt.t)
+
+
+def test_helpers_mirror_reference():
+    from sloika_amd import train
+    labels = np.array([[3, 0, 0, 2, 0], [0, 0, 1, 0, 4]])
+    assert train.remove_blanks(labels.copy()).tolist() == [[3, 3, 3, 2, 2], [0, 0, 1, 1, 4]]      # train_network.py:116-121
+    sm = train.ExponentialSmoother(0.5)
+    sm.update(2.0)
+    sm.update(4.0)
+    assert sm.value == pytest.approx((0.5 * 1.0 + 0.5 * 4.0) / (0.5 * 0.5 + 0.5), rel=1e-9)       # :100-113
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem():
+    rs = np.random.RandomState(4)
+    n, nstate, T, B = 5, 7, 12, 6
+    r = lambda *shape: rs.normal(size=shape) * 0.5
+    spec = {"type": "serial", "sublayers": [
+        {"type": "convolution", "W": r(n, 1, 3), "b": r(n), "stride": 1, "padding": (1, 1), "activation": "elu"},
+        {"type": "reverse", "sublayer": {"type": "GRU", "iW": r(3 * n, n), "sW": r(2 * n, n), "sW2": r(n, n), "b": r(3 * n),
+                                         "activation": "tanh", "gate": "sigmoid"}},
+        {"type": "softmax", "W": r(nstate, n), "b": r(nstate)}]}
+    x = rs.normal(size=(T, B, 1))
+    labels = rs.randint(0, nstate, size=(T, B))
+    weights = rs.uniform(0.5, 1.5, size=(T, B))
+    return spec, x, labels, weights
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle_train as ot
+    from sloika_amd import train
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec, x, labels, weights = _problem()
+    mine = slice(rank, None, world)                                   # chunks rank::world, as the inference sharding
+    loss, acc, grads = ot.loss_and_grads(spec, x[:, mine], labels[:, mine], weights[:, mine], 1e-3, 0.0, 1)
+    flat = torch.from_numpy(np.concatenate([g.reshape(-1) for g in grads] + [[loss, acc]]))
+    scale = train.allreduce_mean_(flat)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "mean.npy"), flat.numpy() * scale)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_equals_whole_batch(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    from oracle import oracle_train as ot
+    from sloika_amd import train
+    assert train.allreduce_mean_(torch.ones(3)) == 1.0                 # not initialised: a no-op
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "mean.npy"))
+    spec, x, labels, weights = _problem()
+    loss, acc, grads = ot.loss_and_grads(spec, x, labels, weights, 1e-3, 0.0, 1)
+    want = np.concatenate([g.reshape(-1) for g in grads] + [[loss, acc]])
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
