@@ -22,6 +22,11 @@
 #include "common.h"
 #include "mfma4.h"
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef GBWD_DIAG
+#define GBWD_DIAG 0
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // Packed rows for the gate recompute: xh[m] = [x[m] | h_prev[m]], h_prev(t, b) = h at the previous SCAN step (zero at
 // the scan start: layers.py:85-88), the scan running backwards in time when `reverse` (layers.py:1449-1450).
@@ -185,16 +190,46 @@ __global__ void __launch_bounds__(4 * N) gru_backward_kernel(const float *__rest
     }
 }
 
-// Same scan, restructured for latency (the step is a chain of dependent LDS round trips and barriers, not arithmetic):
-//   * operands of every step arrive through a dedicated loader wave and LDS-DMA (global_load_lds, no register staging)
-//     D steps ahead of their use.  In the kernel above the owner threads' own loads and stores share one vmcnt counter,
-//     so "wait for this step's operands" also waits for everything younger and every step pays a memory round trip;
-//     here the compute waves never wait on memory (their da stores just drain), the loader issues loads only, so
-//     s_waitcnt vmcnt(5*(D-1)) means exactly "the step needed next has landed", and barriers are LDS-only;
-//   * the four K-quarters of an output live in ONE wave (lane = 16*quarter + output), so the partial sums meet through
-//     two row-swap instructions instead of an LDS write, a barrier and an LDS read: two barriers per step, not four;
-//   * the vectors the next step overwrites are double-buffered by step parity instead of fenced by a third barrier.
+// Same scan, restructured (the step is a chain of dependent LDS round trips and barriers, and with one output per lane
+// every FMA needs its own LDS operand -- the vector broadcast alone costs 72 floats per lane and step, 110 KB per chunk,
+// i.e. ~860 cycles of LDS bandwidth):
+//   * lane (row g, slice sl) of wave w accumulates FOUR outputs (16w + 4g + 0..3) over ONE SIXTEENTH of k, so a vector
+//     element read from LDS feeds four FMAs (two v_pk_fma_f32) and the LDS traffic drops fourfold;
+//   * the 16 partial sums of an output meet inside a DPP row: two reduce-scatter steps inside the quad (each lane keeps
+//     half of what it holds, which halves the adds; the accumulator order is pre-permuted per lane through the weight
+//     layout, so no selects are needed) and two rotations across the quads: 5 instructions for 4 outputs, no LDS, no
+//     barrier.  Afterwards lane sl holds output 4g + m(sl), m = bit-swap of sl & 3, replicated in the four quads;
+//   * two chunks per workgroup share the weights in registers (quad q of every row finishes chunk q), so a batch of
+//     1024 is resident at once instead of in two rounds;
+//   * operands of every step arrive through a dedicated loader wave and LDS-DMA (global_load_lds) D steps ahead.  In
+//     the plain kernel the owner threads' loads and stores share one vmcnt counter, so "wait for this step's operands"
+//     also waits for everything younger; here the compute waves never wait on memory (their da stores just drain), the
+//     loader issues loads only, so s_waitcnt vmcnt(10*(D-1)) means exactly "the step needed next has landed";
+//   * two LDS-only barriers per step; the vectors the next step overwrites are double-buffered by step parity.
 // Needs 16-byte aligned operand rows.
+__device__ __forceinline__ float dpp_add_xor1(float keep, float send)
+{
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1 /* quad_perm 1,0,3,2 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_add_xor2(float keep, float send)
+{
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E /* quad_perm 2,3,0,1 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_add_ror(float v, int /*4 or 8*/ n)
+{
+    return n == 4 ? v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124 /* row_ror:4 */, 0xf, 0xf, false))
+                  : v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+}
+// acc01/acc23: this lane's partial sums of its four outputs in permuted order (position p <-> output p ^ m).  Returns the
+// complete sum of output m, the same in all four quads of the row.
+__device__ __forceinline__ float row_reduce4(f32x2 acc01, f32x2 acc23)
+{
+    const float a = dpp_add_xor1(acc01.x, acc23.x);
+    const float b = dpp_add_xor1(acc01.y, acc23.y);
+    const float c = dpp_add_xor2(a, b);
+    return dpp_add_ror(dpp_add_ror(c, 4), 8);
+}
+
 template <int N>
 __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const float *__restrict__ dy, long lddy,
                                                                       const float *__restrict__ xh, int I,
@@ -204,32 +239,47 @@ __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const floa
                                                                       const float *__restrict__ sW2, float *__restrict__ da,
                                                                       int T, int B, int reverse)
 {
-    constexpr int Q2 = N / 4, Q1 = 2 * N / 4, D = 8;
-    __shared__ __attribute__((aligned(16))) float ring[D][5][N];
-    __shared__ __attribute__((aligned(16))) float v_dac[2][N], v_dzr[2][2 * N];
-    const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63;
+    constexpr int CH = 2, KA = N / 16, KB = 2 * N / 16, D = 6;
+    static_assert(5 * CH * (D - 1) <= 63, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) float ring[D][CH][5][N];
+    __shared__ __attribute__((aligned(16))) float v_dac[2][CH][N], v_dzr[2][CH][2 * N];
+    const int tid = threadIdx.x, b0 = blockIdx.x * CH, lane = tid & 63;
     const bool loader = tid >= 4 * N;
-    const int i = loader ? 0 : 16 * (tid >> 6) + (lane & 15), q = lane >> 4;
-    const bool owner = !loader && q == 0;
+    const int sl = lane & 15, quad = sl >> 2, m = ((sl & 1) << 1) | ((sl >> 1) & 1);
+    const int ibase = loader ? 0 : 16 * (tid >> 6) + 4 * (lane >> 4);       // first of this lane's four outputs
+    const int i = ibase + m;                                                 // the output this lane finishes
+    const bool owner = !loader && quad < CH && b0 + quad < B;
+    const int bq = min(b0 + (quad < CH ? quad : 0), B - 1);                  // the chunk this lane finishes
     const long ldxh = I + N;
-    auto row = [&](int s) { return (size_t)(reverse ? T - 1 - s : s) * B + b; };
-    auto issue = [&](int sp) {                                    // loader wave: the five operand rows of scan step sp
+    auto row = [&](int s, int bb) { return (size_t)(reverse ? T - 1 - s : s) * B + bb; };
+    auto issue = [&](int sp) {                                    // loader wave: the operand rows of scan step sp
         if (lane < N / 4) {
-            const size_t m = row(sp);
-            float *dst = &ring[sp % D][0][0];
-            const float *src[5] = {dy + m * lddy, zr + m * (2 * N), zr + m * (2 * N) + N, c + m * N, xh + m * ldxh + I};
 #pragma unroll
-            for (int a = 0; a < 5; a++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[a] + 4 * lane),
-                                                 (__attribute__((address_space(3))) void *)(dst + a * N), 16, 0, 0);
+            for (int ch = 0; ch < CH; ch++) {
+                const size_t mm = row(sp, min(b0 + ch, B - 1));
+                float *dst = &ring[sp % D][ch][0][0];
+                const float *src[5] = {dy + mm * lddy, zr + mm * (2 * N), zr + mm * (2 * N) + N, c + mm * N,
+                                       xh + mm * ldxh + I};
+#pragma unroll
+                for (int a = 0; a < 5; a++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[a] + 4 * lane),
+                                                     (__attribute__((address_space(3))) void *)(dst + a * N), 16, 0, 0);
+            }
         }
     };
-    float w2[Q2], w1[Q1];
+    // weights of positions (0,1) and (2,3), position p <-> output ibase + (p ^ m)
+    f32x2 wa01[KA], wa23[KA], wb01[KB], wb23[KB];
     if (!loader) {
 #pragma unroll
-        for (int j = 0; j < Q2; j++) w2[j] = sW2[(size_t)(q * Q2 + j) * N + i];      // drh[i] = sum_k dac[k] sW2[k][i]
+        for (int k = 0; k < KA; k++) {                                                 // drh[i] = sum_k dac[k] sW2[k][i]
+            const float *w = sW2 + (size_t)(sl * KA + k) * N + ibase;
+            wa01[k].x = w[0 ^ m]; wa01[k].y = w[1 ^ m]; wa23[k].x = w[2 ^ m]; wa23[k].y = w[3 ^ m];
+        }
 #pragma unroll
-        for (int j = 0; j < Q1; j++) w1[j] = sW[(size_t)(q * Q1 + j) * N + i];       // carry[i] += sum_k dzr[k] sW[k][i]
+        for (int k = 0; k < KB; k++) {                                                 // carry[i] += sum_k dzr[k] sW[k][i]
+            const float *w = sW + (size_t)(sl * KB + k) * N + ibase;
+            wb01[k].x = w[0 ^ m]; wb01[k].y = w[1 ^ m]; wb23[k].x = w[2 ^ m]; wb23[k].y = w[3 ^ m];
+        }
     } else {
         for (int sp = T - 1; sp >= 0 && sp > T - 1 - D; sp--) issue(sp);
     }
@@ -240,45 +290,68 @@ __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const floa
         const int par = s & 1;
         float g = 0.f, z = 0.f, r = 0.f, h = 0.f;
         if (owner) {
-            const float *op = &ring[s % D][0][0];
+            const float *op = &ring[s % D][quad][0][0];
             g = op[i] + carry; z = op[N + i]; r = op[2 * N + i]; h = op[4 * N + i];
             const float cc = op[3 * N + i];
             const float dac = g * (1.0f - z) * (1.0f - cc * cc);
             const float daz = g * (h - cc) * z * (1.0f - z);
-            v_dac[par][i] = dac;
-            v_dzr[par][i] = daz;
-            da[row(s) * (3 * N) + 2 * N + i] = dac;
-            da[row(s) * (3 * N) + i] = daz;
+            v_dac[par][quad][i] = dac;
+            v_dzr[par][quad][i] = daz;
+            if (GBWD_DIAG != 1) {
+            da[row(s, bq) * (3 * N) + 2 * N + i] = dac;
+            da[row(s, bq) * (3 * N) + i] = daz;
+            }
         }
         lds_barrier();                                            // 1: dac visible; ring slot s % D is free again
         float keep = 0.0f;
         if (loader) {
-            // step s-1 is read after barrier 2; the D-1 younger steps (5 loads each) may stay in flight -- unless fewer
-            // than that were issued (the last D steps), where everything is awaited
-            if (s - D >= 0) {
+            // step s-1 is read after barrier 2; the D-1 younger steps (5*CH loads each) may stay in flight -- unless
+            // fewer than that were issued (the last D steps), where everything is awaited
+            if (GBWD_DIAG == 2) {
+            } else if (s - D >= 0) {
                 issue(s - D);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (D - 1)) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * CH * (D - 1)) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         } else {
-            float acc = 0.0f;
+            float drh[CH];
 #pragma unroll
-            for (int j = 0; j < Q2; j++) acc = fmaf(v_dac[par][q * Q2 + j], w2[j], acc);
-            const float drh = xor32_sum(xor16_sum(acc));
+            for (int ch = 0; ch < CH; ch++) {
+                const float *vp = &v_dac[par][ch][sl * KA];
+                f32x2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < (GBWD_DIAG == 3 ? 1 : KA); k++) {
+                    const f32x2 vv = {vp[k], vp[k]};
+                    a01 = __builtin_elementwise_fma(vv, wa01[k], a01);
+                    a23 = __builtin_elementwise_fma(vv, wa23[k], a23);
+                }
+                drh[ch] = row_reduce4(a01, a23);
+            }
             if (owner) {
-                const float dar = drh * h * r * (1.0f - r);
-                v_dzr[par][N + i] = dar;
-                da[row(s) * (3 * N) + N + i] = dar;
-                keep = g * z + drh * r;
+                const float mine = quad == 0 ? drh[0] : drh[CH - 1];
+                const float dar = mine * h * r * (1.0f - r);
+                v_dzr[par][quad][N + i] = dar;
+                if (GBWD_DIAG != 1) da[row(s, bq) * (3 * N) + N + i] = dar;
+                keep = g * z + mine * r;
             }
         }
         lds_barrier();                                            // 2: [daz dar] visible; ring slot (s-1) % D has landed
         if (!loader) {
-            float acc = 0.0f;
+            float tot[CH];
 #pragma unroll
-            for (int j = 0; j < Q1; j++) acc = fmaf(v_dzr[par][q * Q1 + j], w1[j], acc);
-            carry = keep + xor32_sum(xor16_sum(acc));
+            for (int ch = 0; ch < CH; ch++) {
+                const float *vp = &v_dzr[par][ch][sl * KB];
+                f32x2 a01 = {0.0f, 0.0f}, a23 = {0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < (GBWD_DIAG == 3 ? 1 : KB); k++) {
+                    const f32x2 vv = {vp[k], vp[k]};
+                    a01 = __builtin_elementwise_fma(vv, wb01[k], a01);
+                    a23 = __builtin_elementwise_fma(vv, wb23[k], a23);
+                }
+                tot[ch] = row_reduce4(a01, a23);
+            }
+            carry = keep + (quad == 0 ? tot[0] : tot[CH - 1]);
         }
     }
 }
@@ -290,8 +363,8 @@ static int launch_gru_backward(const float *dy, long lddy, const float *xh, int 
     const bool aligned = lddy % 4 == 0 && I % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(xh) |
                                                            reinterpret_cast<uintptr_t>(zr) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
     if (aligned)
-        hipLaunchKernelGGL((gru_backward_dma_kernel<N>), dim3(B), dim3(4 * N + 64), 0, s, dy, lddy, xh, I, zr, c, sW, sW2, da,
-                           T, B, reverse);
+        hipLaunchKernelGGL((gru_backward_dma_kernel<N>), dim3((B + 1) / 2), dim3(4 * N + 64), 0, s, dy, lddy, xh, I, zr, c, sW,
+                           sW2, da, T, B, reverse);
     else
         hipLaunchKernelGGL((gru_backward_kernel<N>), dim3(B), dim3(4 * N), 0, s, dy, lddy, xh, I, zr, c, sW, sW2, da, T, B,
                            reverse);
@@ -417,21 +490,23 @@ extern "C" int slk_reduce_sum_f32(const float *x, size_t n, int square, double *
 // partial block; tn_reduce_kernel adds the slices in a fixed order (deterministic, unlike atomics).  The slice height
 // is chosen per call so that a small C still gives every SIMD of the chip a wave or two (tn_slice_rows).
 // ---------------------------------------------------------------------------------------------------------------
-#define TN_ROWS 2048           /* tallest slice */
+#define TN_ROWS 8192           /* tallest slice */
 #define TN_MIN_ROWS 256
 #define TN_WAVES 2048          /* waves wanted per launch: 256 CUs x 4 SIMDs x 2 */
 #define TN_BLK 96
-#define TN_UNROLL 8
+#define TN_UNROLL 4
 
 // CS: also produce the column sums of A (the bias gradient, da^T 1) from the operands already in registers
 template <bool CS>
-__global__ void __launch_bounds__(64) gemm_tn_kernel(const float *__restrict__ A, long lda, const float *__restrict__ Bm,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_tn_kernel(const float *__restrict__ A, long lda, const float *__restrict__ Bm,
                                                      long ldb, float *__restrict__ partial, long M, int N1, int N2,
                                                      float *__restrict__ cs_partial, int slice_rows)
 {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-    const int n1_0 = blockIdx.y * TN_BLK, n2_0 = blockIdx.z * TN_BLK;
-    const long m_lo = (long)blockIdx.x * slice_rows, m_hi = min(m_lo + slice_rows, M);
+    // the column blocks of one slice are neighbours in launch order, so the operand rows they share are read from HBM once
+    // and from L2 by the others
+    const int n1_0 = blockIdx.x * TN_BLK, n2_0 = blockIdx.z * TN_BLK;
+    const long m_lo = (long)blockIdx.y * slice_rows, m_hi = min(m_lo + slice_rows, M);
     const int ta = min(3, (N1 - n1_0 + 31) / 32), tb = min(3, (N2 - n2_0 + 31) / 32);    // live 32-wide tiles (uniform)
     const float *pa[3], *pb[3];
 #pragma unroll
@@ -490,7 +565,7 @@ __global__ void __launch_bounds__(64) gemm_tn_kernel(const float *__restrict__ A
         mma(a1, b1, m0 + STEP);
     }
     // partial[slice][N1][N2]; D[row = (e&3) + 8*(e>>2) + 4*h][col = r]; columns clamped above are dropped here
-    float *out = partial + (size_t)blockIdx.x * N1 * N2;
+    float *out = partial + (size_t)blockIdx.y * N1 * N2;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -509,27 +584,39 @@ __global__ void __launch_bounds__(64) gemm_tn_kernel(const float *__restrict__ A
         for (int i = 0; i < 3; i++) {
             const float tot = cs[i] + __shfl_xor(cs[i], 32);
             const int colc = n1_0 + 32 * i + r;
-            if (h == 0 && i < ta && colc < N1) cs_partial[(size_t)blockIdx.x * N1 + colc] = tot;
+            if (h == 0 && i < ta && colc < N1) cs_partial[(size_t)blockIdx.y * N1 + colc] = tot;
         }
     }
 }
 
-__global__ void __launch_bounds__(256) tn_reduce_kernel(const float *__restrict__ partial, int nslice, int N1, int N2,
-                                                        float *__restrict__ C, long ldc)
+// C = sum over slices of partial, in a fixed order: 64 outputs x 16 slice groups per workgroup; group sg adds slices
+// sg, sg+16, ... (eight loads in flight), then the 16 group sums are added in group order.
+__global__ void __launch_bounds__(1024) tn_reduce_kernel(const float *__restrict__ partial, int nslice, int N1, int N2,
+                                                         float *__restrict__ C, long ldc)
 {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)N1 * N2;
-    if (e >= total) return;
+    __shared__ double part[16][64];
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const size_t e = (size_t)blockIdx.x * 64 + o, total = (size_t)N1 * N2;
     double acc = 0.0;
-    int s = 0;
-    for (; s + 8 <= nslice; s += 8) {                    // eight loads in flight, added in slice order
-        float v[8];
+    if (e < total) {
+        int s = sg;
+        for (; s + 7 * 16 < nslice; s += 8 * 16) {
+            float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = partial[(size_t)(s + k) * total + e];
+            for (int k = 0; k < 8; k++) v[k] = partial[(size_t)(s + 16 * k) * total + e];
 #pragma unroll
-        for (int k = 0; k < 8; k++) acc += v[k];
+            for (int k = 0; k < 8; k++) acc += v[k];
+        }
+        for (; s < nslice; s += 16) acc += partial[(size_t)s * total + e];
     }
-    for (; s < nslice; s++) acc += partial[(size_t)s * total + e];
-    C[(e / N2) * ldc + (e % N2)] = (float)acc;
+    part[sg][o] = acc;
+    __syncthreads();
+    if (sg == 0 && e < total) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) tot += part[k][o];
+        C[(e / N2) * ldc + (e % N2)] = (float)tot;
+    }
 }
 
 static int tn_slice_rows(long M, int N1, int N2)
@@ -555,20 +642,20 @@ extern "C" int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ld
     const int rows = tn_slice_rows(M, N1, N2);
     const long nslice = (M + rows - 1) / rows;
     const int g1 = (N1 + TN_BLK - 1) / TN_BLK, g2 = (N2 + TN_BLK - 1) / TN_BLK;
-    if (nslice > 0x7fffffffL || g1 > 65535 || g2 > 65535) return SLK_ERR_UNSUPPORTED;
+    if (nslice > 65535 || g2 > 65535) return SLK_ERR_UNSUPPORTED;
     hipStream_t s = slk_stream(stream);
     float *partial = (float *)workspace, *cs_partial = partial + (size_t)nslice * N1 * N2;
     if (colsum)
-        hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3((unsigned)nslice, g1, g2), dim3(64), 0, s, A, lda, B, ldb, partial, M, N1,
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(g1, (unsigned)nslice, g2), dim3(64), 0, s, A, lda, B, ldb, partial, M, N1,
                            N2, cs_partial, rows);
     else
-        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3((unsigned)nslice, g1, g2), dim3(64), 0, s, A, lda, B, ldb, partial, M,
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(g1, (unsigned)nslice, g2), dim3(64), 0, s, A, lda, B, ldb, partial, M,
                            N1, N2, cs_partial, rows);
     const size_t total = (size_t)N1 * N2;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float *)partial,
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, s, (const float *)partial,
                        (int)nslice, N1, N2, C, ldc);
     if (colsum)
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((N1 + 255) / 256)), dim3(256), 0, s, (const float *)cs_partial,
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((N1 + 63) / 64)), dim3(1024), 0, s, (const float *)cs_partial,
                            (int)nslice, N1, 1, colsum, 1L);
     return slk_launch_status();
 }

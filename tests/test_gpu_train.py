@@ -233,7 +233,7 @@ def test_gru_backward_kernels_agree(n, reverse):
                                     d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), T, B, n, reverse, 1, 2, stream())
         assert rc == 0
         outs.append(da.cpu().numpy())
-    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-4, atol=1e-5 * np.abs(want).max())     # different summation orders
     np.testing.assert_allclose(outs[0], want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
     assert L.slk_gru_backward_f32(d["xh"].data_ptr(), 160, d["xh"].data_ptr(), I, d["zr"].data_ptr(), d["c"].data_ptr(),
                                   d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), T, B, 40, reverse, 1, 2,
