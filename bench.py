@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams per GPU; with 2, consecutive batches overlap (batch i decodes while batch i+1 "
                          "runs its recurrent layers)")
+    ap.add_argument("--train", action="store_true",
+                    help="time the TRAINING step instead (BASELINE.json configs[4]: forward + backward + ADAMski, "
+                         "gradient all-reduce over RCCL when --gpus > 1); prints the same kind of JSON line")
     return ap.parse_args()
 
 
@@ -91,8 +94,76 @@ def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
     return out
 
 
+def main_train(args):
+    """One step = wrap_network's fg(x, labels, weights, rate) on one batch per GPU (bin/train_network.py:308)."""
+    import torch
+    from sloika_amd import _lib, models, profiler, shard, train
+    rank, world, local_rank = shard.dist_info()
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    net = models.randomise_zero_layers(models.build_model(args.model, klen=5, sd=0.5, seed=11))     # same weights on every rank
+    fg = train.wrap_network(net, min_prob=1e-30, l2=0.0, drop=20)                                  # train_network.py defaults
+    B, L = args.batch, args.chunk_len
+    rs = np.random.RandomState(1234 + rank)
+    To = net.layers[0].out_len(L)
+    x = torch.from_numpy(rs.normal(size=(L, B, 1)).astype(np.float32)).cuda()
+    labels = torch.from_numpy(rs.randint(0, net.size, size=(To, B)).astype(np.int32)).cuda()
+    weights = torch.ones((To, B), dtype=torch.float32, device="cuda")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        fg(x, labels, weights, 1e-3)
+    barrier()
+    rec = None if args.no_stage_timing else profiler.start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, acc = fg(x, labels, weights, 1e-3 / (1.0 + i / 5000.0))
+    barrier()
+    dt = time.perf_counter() - t0
+    if rec is not None:
+        profiler.stop()
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stages = rec.summary() if rec is not None else {}
+    roofline = None
+    if stages:
+        dom = max(stages, key=lambda k: stages[k]["ms_total"])
+        d = stages[dom]
+        flops = d["flops"] / d["calls"]
+        f16 = d.get("f16x3_flops", 0.0) / d["calls"]
+        t_min = (flops - f16) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + 3.0 * f16 / (F16_MFMA_PEAK_TFLOPS * 1e12)
+        ach = flops / (d["ms_avg"] * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": flops / t_min / 1e12, "unit": "TFLOP/s",
+                    "frac": ach / (flops / t_min / 1e12), "traffic": None, "ms_per_launch": d["ms_avg"], "launches": d["calls"]}
+    if rank == 0:
+        print(json.dumps({
+            "metric": "raw-signal samples/sec trained", "value": world * B * L * args.steps / dt, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s training step (forward, backward, ADAMski), %d-sample chunks, batch %d per GPU, "
+                                   "klen 5 (1025 states), drop 20" % (args.model, L, B),
+                       "model": args.model, "chunk_len": L, "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": "data parallel over %d GPU(s), one all-reduce of the flat gradient per step" % world},
+            "roofline": roofline, "cpu_baseline": None, "final_loss": loss,
+            "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.train:
+        return main_train(args)
     import torch
     from sloika_amd import _lib, models, pipeline, profiler, shard
     rank, world, local_rank = shard.dist_info()

@@ -17,7 +17,7 @@ losses because every rank counts the same number of positions.
 """
 import numpy as np
 
-from . import _lib, activation, layers
+from . import _lib, activation, layers, profiler
 from .config import sloika_dtype
 
 
@@ -227,24 +227,28 @@ class TrainingStep(object):
             raise ValueError("labels must lie in [0, %d)" % sm.size)
         # ---- loss, accuracy, d loss / d logits (in place) -------------------------------------------------------------
         rows = torch.empty((2, M), dtype=torch.float32, device=x.device)
-        _lib.check(L.slk_softmax_xent_grad_f32(logits.data_ptr(), ld, stats.data_ptr(), labels.data_ptr(),
-                                               weights.data_ptr(), To, B, sm.size, self.drop, self.min_prob,
-                                               rows[0].data_ptr(), rows[1].data_ptr(), st()), "softmax_xent")
         sc = self._scalars
-        _lib.check(L.slk_reduce_sum_f32(rows[0].data_ptr(), M, 0, sc[0:].data_ptr(), st()), "reduce")
-        _lib.check(L.slk_reduce_sum_f32(rows[1].data_ptr(), M, 0, sc[1:].data_ptr(), st()), "reduce")
-        _lib.check(L.slk_reduce_sum_f32(self.flat.data_ptr(), self.flat.numel(), 1, sc[2:].data_ptr(), st()), "reduce")
+        with profiler.region("train_xent", 0.0, 8.0 * M * ld):
+            _lib.check(L.slk_softmax_xent_grad_f32(logits.data_ptr(), ld, stats.data_ptr(), labels.data_ptr(),
+                                                   weights.data_ptr(), To, B, sm.size, self.drop, self.min_prob,
+                                                   rows[0].data_ptr(), rows[1].data_ptr(), st()), "softmax_xent")
+            _lib.check(L.slk_reduce_sum_f32(rows[0].data_ptr(), M, 0, sc[0:].data_ptr(), st()), "reduce")
+            _lib.check(L.slk_reduce_sum_f32(rows[1].data_ptr(), M, 0, sc[1:].data_ptr(), st()), "reduce")
+            if self.l2 != 0.0:
+                _lib.check(L.slk_reduce_sum_f32(self.flat.data_ptr(), self.flat.numel(), 1, sc[2:].data_ptr(), st()), "reduce")
         # ---- softmax layer ---------------------------------------------------------------------------------------------
         n_in = sm.insize
-        self._tn(logits.data_ptr(), ld, h_top.data_ptr(), layers._row_stride(h_top), self._grad_of(sm.W).data_ptr(), n_in, M,
-                 sm.size, n_in, colsum=self._grad_of(sm.b).data_ptr() if sm.has_bias else None)
+        with profiler.region("train_wgrad", 2.0 * M * sm.size * n_in, 4.0 * M * (ld + n_in)):
+            self._tn(logits.data_ptr(), ld, h_top.data_ptr(), layers._row_stride(h_top), self._grad_of(sm.W).data_ptr(), n_in,
+                     M, sm.size, n_in, colsum=self._grad_of(sm.b).data_ptr() if sm.has_bias else None)
         dy = None
         if len(self.plan) > 1:
             wt = torch.zeros((n_in, ld), dtype=torch.float32, device=x.device)          # W^T, rows padded like the logits
             wt[:, :sm.size] = sm.W.dev().t()
             dy = torch.empty((To, B, n_in), dtype=torch.float32, device=x.device)
-            _lib.check(L.slk_gemm_bias_act_f32(logits.data_ptr(), ld, wt.data_ptr(), None, dy.data_ptr(), n_in, M, ld, n_in,
-                                               0, st()), "softmax dx")
+            with profiler.region("train_dx", 2.0 * M * sm.size * n_in, 4.0 * M * (ld + n_in)):
+                _lib.check(L.slk_gemm_bias_act_f32(logits.data_ptr(), ld, wt.data_ptr(), None, dy.data_ptr(), n_in, M, ld,
+                                                   n_in, 0, st()), "softmax dx")
         del logits
         # ---- recurrent layers, top down -------------------------------------------------------------------------------
         for pos in range(len(self.plan) - 2, -1, -1):
@@ -261,7 +265,7 @@ class TrainingStep(object):
         if self.gscale != 1.0:
             allreduce_mean_(sc[:2])
         s = sc.cpu().numpy()
-        loss = float(s[0]) * self.gscale + self.l2 * float(s[2])
+        loss = float(s[0]) * self.gscale + (self.l2 * float(s[2]) if self.l2 != 0.0 else 0.0)
         return loss, float(s[1]) * self.gscale
 
     def _gru_backward(self, layer, rev, xin, h, dy, need_dx):
@@ -275,34 +279,39 @@ class TrainingStep(object):
             raise NotImplementedError("training: Gru layers with fun=tanh, gatefun=sigmoid only")
         dev = h.device
         iW, sW, sW2, b = layer.iW.dev(), layer.sW.dev(), layer.sW2.dev(), layer.b.dev()
-        xh = torch.empty((M, K), dtype=torch.float32, device=dev)
-        _lib.check(L.slk_train_pack_xh_f32(xin.data_ptr(), layers._row_stride(xin), h.data_ptr(), layers._row_stride(h),
-                                           xh.data_ptr(), T, B, i_sz, n, int(rev), st()), "pack_xh")
-        zr = torch.empty((M, 2 * n), dtype=torch.float32, device=dev)
-        self._gemm(xh.data_ptr(), K, torch.cat([iW[:2 * n], sW], 1).contiguous(), b[:2 * n].data_ptr(), zr.data_ptr(), 2 * n,
-                   M, K, 2 * n, gact)
-        xrh = torch.empty((M, K), dtype=torch.float32, device=dev)
-        _lib.check(L.slk_train_pack_xrh_f32(xh.data_ptr(), zr.data_ptr(), xrh.data_ptr(), M, i_sz, n, st()), "pack_xrh")
-        c = torch.empty((M, n), dtype=torch.float32, device=dev)
-        self._gemm(xrh.data_ptr(), K, torch.cat([iW[2 * n:], sW2], 1).contiguous(), b[2 * n:].data_ptr(), c.data_ptr(), n, M,
-                   K, n, act)
+        with profiler.region("train_gates", 6.0 * M * n * K, 4.0 * M * (3 * K + 3 * n), f16x3_flops=6.0 * M * n * K):
+            xh = torch.empty((M, K), dtype=torch.float32, device=dev)
+            _lib.check(L.slk_train_pack_xh_f32(xin.data_ptr(), layers._row_stride(xin), h.data_ptr(), layers._row_stride(h),
+                                               xh.data_ptr(), T, B, i_sz, n, int(rev), st()), "pack_xh")
+            zr = torch.empty((M, 2 * n), dtype=torch.float32, device=dev)
+            self._gemm(xh.data_ptr(), K, torch.cat([iW[:2 * n], sW], 1).contiguous(), b[:2 * n].data_ptr(), zr.data_ptr(),
+                       2 * n, M, K, 2 * n, gact)
+            xrh = torch.empty((M, K), dtype=torch.float32, device=dev)
+            _lib.check(L.slk_train_pack_xrh_f32(xh.data_ptr(), zr.data_ptr(), xrh.data_ptr(), M, i_sz, n, st()), "pack_xrh")
+            c = torch.empty((M, n), dtype=torch.float32, device=dev)
+            self._gemm(xrh.data_ptr(), K, torch.cat([iW[2 * n:], sW2], 1).contiguous(), b[2 * n:].data_ptr(), c.data_ptr(), n,
+                       M, K, n, act)
         da = torch.empty((M, 3 * n), dtype=torch.float32, device=dev)
-        rc = L.slk_gru_backward_f32(dy.data_ptr(), layers._row_stride(dy), xh.data_ptr(), i_sz, zr.data_ptr(), c.data_ptr(),
-                                    sW.data_ptr(), sW2.data_ptr(), da.data_ptr(), T, B, n, int(rev), act, gact, st())
+        with profiler.region("train_gru_scan", 6.0 * M * n * n, 4.0 * M * 8 * n):
+            rc = L.slk_gru_backward_f32(dy.data_ptr(), layers._row_stride(dy), xh.data_ptr(), i_sz, zr.data_ptr(),
+                                        c.data_ptr(), sW.data_ptr(), sW2.data_ptr(), da.data_ptr(), T, B, n, int(rev), act,
+                                        gact, st())
         if rc == _lib.SLK_ERR_UNSUPPORTED:
             raise NotImplementedError("training: no reverse-scan kernel for a Gru of size %d" % n)
         _lib.check(rc, "gru_backward")
         f4 = 4                                                                       # bytes per float, for column offsets
-        self._tn(da.data_ptr(), 3 * n, xh.data_ptr(), K, self._grad_of(layer.iW).data_ptr(), i_sz, M, 3 * n, i_sz,
-                 colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
-        self._tn(da.data_ptr(), 3 * n, xh.data_ptr() + f4 * i_sz, K, self._grad_of(layer.sW).data_ptr(), n, M, 2 * n, n)
-        self._tn(da.data_ptr() + f4 * 2 * n, 3 * n, xrh.data_ptr() + f4 * i_sz, K, self._grad_of(layer.sW2).data_ptr(), n, M,
-                 n, n)
+        with profiler.region("train_wgrad", 2.0 * M * (3 * n * i_sz + 3 * n * n), 4.0 * M * (3 * n + 2 * K)):
+            self._tn(da.data_ptr(), 3 * n, xh.data_ptr(), K, self._grad_of(layer.iW).data_ptr(), i_sz, M, 3 * n, i_sz,
+                     colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
+            self._tn(da.data_ptr(), 3 * n, xh.data_ptr() + f4 * i_sz, K, self._grad_of(layer.sW).data_ptr(), n, M, 2 * n, n)
+            self._tn(da.data_ptr() + f4 * 2 * n, 3 * n, xrh.data_ptr() + f4 * i_sz, K, self._grad_of(layer.sW2).data_ptr(), n,
+                     M, n, n)
         if not need_dx:
             return None
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
-        _lib.check(L.slk_gemm_bias_act_f32(da.data_ptr(), 3 * n, iW.t().contiguous().data_ptr(), None, dx.data_ptr(), i_sz, M,
-                                           3 * n, i_sz, 0, st()), "gru dx")
+        with profiler.region("train_dx", 6.0 * M * n * i_sz, 4.0 * M * (3 * n + i_sz)):
+            _lib.check(L.slk_gemm_bias_act_f32(da.data_ptr(), 3 * n, iW.t().contiguous().data_ptr(), None, dx.data_ptr(), i_sz,
+                                               M, 3 * n, i_sz, 0, st()), "gru dx")
         return dx
 
     def _conv_backward(self, layer, xin, y, dy):
