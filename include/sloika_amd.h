@@ -319,6 +319,7 @@ size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2);
 int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
                     float *colsum /* [N1] or NULL */, void *workspace, size_t workspace_bytes, slk_stream_t stream);
 int slk_act_backward_f32(const float *dy, const float *y, float *out, size_t n, int act, slk_stream_t stream);
+int slk_add_inplace_f32(float *y, const float *x, size_t n, slk_stream_t stream);   /* y += x: dL/dx of Parallel branches */
 int slk_train_im2col_cin1_f32(const float *x, long x_t_stride, long x_b_stride, int T, int B, int winlen, int stride,
                               int pad_lo, int pad_hi, float *cols, slk_stream_t stream);
 int slk_adamski_update_f32(float *param, const float *grad, float *momentum, float *variance, size_t n, float lr_t,

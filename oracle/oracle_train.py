@@ -10,7 +10,7 @@ What is restated, and from where:
   * the gradient th.grad(loss, network.params()) (sloika/updates.py:66) -- the reference gets it from Theano's
     automatic differentiation; here it is the hand-derived reverse pass of the layer formulas restated in
     oracle/oracle_np.py (Convolution layers.py:417-419, Gru.step layers.py:1010-1021, Softmax layers.py:309-314,
-    FeedForward layers.py:157-158, Reverse layers.py:1449-1450, Serial layers.py:1500-1504);
+    FeedForward layers.py:157-158, Reverse layers.py:1449-1450, Parallel layers.py:1486-1487, Serial layers.py:1500-1504);
   * the "ADAMski" update sloika/updates.py:36-89 (float32 arithmetic like the reference's shared variables), `sgd`
     updates.py:9-33 and `param_sqr` updates.py:92-103.
 
@@ -47,6 +47,8 @@ def params_of(spec):
         return [p for sub in spec["sublayers"] for p in params_of(sub)]
     if t == "reverse":
         return params_of(spec["sublayer"])
+    if t == "parallel":
+        return [p for sub in spec["sublayers"] for p in params_of(sub)]
     if t == "GRU":
         return [spec[k] for k in ("iW", "sW", "sW2", "b") if spec.get(k) is not None]
     if t in ("convolution", "softmax", "feed-forward"):
@@ -67,6 +69,9 @@ def _forward(spec, x):
     if t == "reverse":
         y, tp = _forward(spec["sublayer"], x[::-1])
         return y[::-1], tp
+    if t == "parallel":                                            # layers.py:1486-1487
+        outs = [_forward(sub, x) for sub in spec["sublayers"]]
+        return np.concatenate([o for o, _ in outs], axis=2), ([tp for _, tp in outs], [o.shape[2] for o, _ in outs])
     if t == "convolution":
         W = np.asarray(spec["W"], f64)
         pad, stride = tuple(spec["padding"]), spec["stride"]
@@ -125,6 +130,13 @@ def _backward(spec, tape, dy):
     if t == "reverse":
         dx, g = _backward(spec["sublayer"], tape, dy[::-1])
         return dx[::-1], g
+    if t == "parallel":
+        tapes, sizes = tape
+        dx, grads, off = 0.0, [], 0
+        for sub, tp, size in zip(spec["sublayers"], tapes, sizes):
+            d, g = _backward(sub, tp, dy[:, :, off:off + size])
+            dx, grads, off = dx + d, grads + g, off + size
+        return dx, grads
     if t == "convolution":
         xp, a, y, Tout = tape
         W = np.asarray(spec["W"], f64)

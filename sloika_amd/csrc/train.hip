@@ -691,6 +691,20 @@ extern "C" int slk_act_backward_f32(const float *dy, const float *y, float *out,
     return slk_launch_status();
 }
 
+// y += x (the contributions of the branches of a Parallel layer to dL/d(input): layers.py:1486-1487 concatenates forward)
+__global__ void __launch_bounds__(256) add_inplace_kernel(float *__restrict__ y, const float *__restrict__ x, size_t n)
+{
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) y[e] += x[e];
+}
+
+extern "C" int slk_add_inplace_f32(float *y, const float *x, size_t n, slk_stream_t stream)
+{
+    if (!y || !x) return SLK_ERR_INVALID_ARG;
+    if (n == 0) return SLK_OK;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(elementwise_grid(n)), dim3(256), 0, slk_stream(stream), y, x, n);
+    return slk_launch_status();
+}
+
 // Window rows of a one-feature convolution (conv.py:66-111 with insize 1): cols[(t*B + b)][k] = x(b, t*stride + k - pad_lo),
 // zero outside the signal; x addressed as x[t*x_t_stride + b*x_b_stride] like slk_conv1d_f32.  dL/dW = dpre^T cols.
 __global__ void __launch_bounds__(256) im2col_cin1_kernel(const float *__restrict__ x, long xts, long xbs, int T, int B,

@@ -6,9 +6,11 @@ like the Theano function the reference compiles.  Device side: csrc/train.hip (r
 contractions for the weight gradients, softmax cross-entropy, the optimiser) on top of the inference kernels, which
 ARE the forward pass.  There is no CPU fallback.
 
-Supported networks: Serial([Convolution(insize=1, ...)] + [Gru | Reverse(Gru)]* + [Softmax]) -- the raw-signal models
-models/raw_0.98_rgrgr.py and relatives; anything else raises NotImplementedError (the reference differentiates any
-layer through Theano; only the recurrent raw-signal path is accelerated here).
+Supported networks: a Serial that ends in Softmax and is built from Convolution(insize=1) as the first layer, Gru,
+FeedForward, Reverse, Parallel (so `birnn`) and nested Serial -- the raw-signal models models/raw_0.98_rgrgr.py,
+baseline_raw_gru.py, bigger_raw_gru.py; anything else (Lstm, Window, multi-feature Convolution, Gru sizes without a
+reverse-scan kernel) raises NotImplementedError: the reference differentiates any layer through Theano, only the
+raw-signal GRU path is accelerated here.
 
 Data parallel (BASELINE.json configs[4]): with torch.distributed initialised (backend "nccl" = RCCL over xGMI) every
 rank runs the same step on its own chunks, the flat float32 gradient is summed with ONE all-reduce and divided by the
@@ -78,28 +80,60 @@ def allreduce_mean_(tensor):
     return 1.0 / dist.get_world_size()
 
 
+def _unwrap(layer, rev=False):
+    while isinstance(layer, layers.Reverse):
+        layer, rev = layer.layer, not rev
+    return layer, rev
+
+
+_FF_ACTS = ("linear", "tanh", "sigmoid", "relu", "elu")     # activations whose derivative is a function of the output
+
+
+def _validate(layer, first, rev=False, where="network"):
+    """Raise NotImplementedError unless `layer` (a sub-tree in front of the Softmax) can be differentiated here."""
+    layer, rev = _unwrap(layer, rev)
+    name = type(layer).__name__
+    if isinstance(layer, layers.Serial):
+        for k, sub in enumerate(layer.layers):
+            _validate(sub, first and k == 0, rev, where)
+    elif isinstance(layer, layers.Parallel):
+        for sub in layer.layers:
+            _validate(sub, False, rev, where)
+    elif isinstance(layer, layers.Convolution):
+        if not first or layer.insize != 1 or rev:
+            raise NotImplementedError("training: Convolution only as the first layer, on one-feature (raw) input, not reversed")
+        if activation.act_name(layer.fun) not in _FF_ACTS:
+            raise NotImplementedError("training: Convolution activation %s has no derivative kernel" % layer.fun.__name__)
+    elif isinstance(layer, layers.Gru):
+        if activation.act_name(layer.fun) != "tanh" or activation.act_name(layer.gatefun) != "sigmoid":
+            raise NotImplementedError("training: Gru layers with fun=tanh, gatefun=sigmoid only")
+        if layer.size not in (16, 32, 48, 64, 96, 112, 128, 144):
+            raise NotImplementedError("training: no reverse-scan kernel for a Gru of size %d" % layer.size)
+    elif isinstance(layer, layers.FeedForward):
+        if activation.act_name(layer.fun) not in _FF_ACTS:
+            raise NotImplementedError("training: FeedForward activation %s has no derivative kernel" % layer.fun.__name__)
+    else:
+        raise NotImplementedError(
+            "training on the GPU path covers Convolution(insize=1) first, Gru, FeedForward, Reverse, Parallel, Serial and a "
+            "final Softmax; %s (%s) is outside it" % (name, where))
+
+
 def _plan(network):
-    """[(kind, layer, reverse)] for the supported architecture, or NotImplementedError."""
-    subs = network.layers if isinstance(network, layers.Serial) else [network]
-    plan = []
-    for pos, layer in enumerate(subs):
-        rev = False
-        while isinstance(layer, layers.Reverse):
-            layer, rev = layer.layer, not rev
-        if isinstance(layer, layers.Convolution) and pos == 0 and layer.insize == 1 and not rev:
-            kind = "conv"
-        elif isinstance(layer, layers.Gru):
-            kind = "gru"
-        elif isinstance(layer, layers.Softmax) and pos == len(subs) - 1:
-            kind = "softmax"
-        else:
-            raise NotImplementedError(
-                "training on the GPU path covers Serial([Convolution(insize=1)] + Gru/Reverse(Gru)... + Softmax); "
-                "layer %d (%s) is outside it" % (pos, type(layer).__name__))
-        plan.append((kind, layer, rev))
-    if not plan or plan[-1][0] != "softmax":
+    """(body, softmax): the layers in front of the output layer as a Serial-like list, and the Softmax; raises
+    NotImplementedError for anything the reverse pass does not cover."""
+    subs = list(network.layers) if isinstance(network, layers.Serial) else [network]
+    if not subs or not isinstance(subs[-1], layers.Softmax):
         raise NotImplementedError("the training loss needs a Softmax output layer (train_network.py:128-133)")
-    return plan
+    for k, sub in enumerate(subs[:-1]):
+        _validate(sub, k == 0, where="layer %d" % k)
+    return subs[:-1], subs[-1]
+
+
+def _leaves(layer):
+    layer, _ = _unwrap(layer)
+    if isinstance(layer, (layers.Serial, layers.Parallel)):
+        return [leaf for sub in layer.layers for leaf in _leaves(sub)]
+    return [layer]
 
 
 class TrainingStep(object):
@@ -118,7 +152,8 @@ class TrainingStep(object):
         assert 0.0 < decay[0] < 1.0 and 0.0 < decay[1] < 1.0, "Decay must lie strictly between zero and one"   # updates.py:51-52
         assert mrate is None or mrate > 0.0, "Rate of momentum increase must be positive"                      # updates.py:53
         assert optimiser in ("adam", "sgd")
-        self.network, self.plan = network, _plan(network)
+        self.network = network
+        self.body, self.softmax = _plan(network)
         self.min_prob, self.l2, self.drop = float(min_prob), float(l2), int(drop)
         self.decay, self.epsilon, self.clip, self.mrate = tuple(decay), float(epsilon), float(clip), mrate
         self.optimiser, self.sgd_momentum = optimiser, float(momentum)
@@ -151,7 +186,7 @@ class TrainingStep(object):
     def _drop_caches(self):
         """Device copies derived from the parameters (fp16 splits, padded twins) are keyed on the identity of the
         parameter's device tensor, which no longer changes when the optimiser writes in place: forget them."""
-        for _, layer, _ in self.plan:
+        for layer in [leaf for sub in self.body for leaf in _leaves(sub)] + [self.softmax]:
             for attr in ("_w16", "_iw16", "_pad_cache"):
                 layer.__dict__.pop(attr, None)
 
@@ -209,11 +244,11 @@ class TrainingStep(object):
             raise ValueError("x must be [T, B, %d]" % self.network.insize)
         T, B = int(x.shape[0]), int(x.shape[1])
         # ---- forward: the inference kernels, keeping every layer's output -------------------------------------------
-        acts = [x]
-        for kind, layer, rev in self.plan[:-1]:
-            acts.append(layer._forward(acts[-1], None, rev))
-        sm = self.plan[-1][1]
-        h_top = acts[-1]
+        h_top, tapes = x, []
+        for sub in self.body:
+            h_top, tp = self._forward(sub, h_top, False)
+            tapes.append(tp)
+        sm = self.softmax
         To = int(h_top.shape[0])
         M = To * B
         logits, stats, ld = sm.logits_and_stats(h_top)
@@ -242,7 +277,7 @@ class TrainingStep(object):
             self._tn(logits.data_ptr(), ld, h_top.data_ptr(), layers._row_stride(h_top), self._grad_of(sm.W).data_ptr(), n_in,
                      M, sm.size, n_in, colsum=self._grad_of(sm.b).data_ptr() if sm.has_bias else None)
         dy = None
-        if len(self.plan) > 1:
+        if self.body:
             wt = torch.zeros((n_in, ld), dtype=torch.float32, device=x.device)          # W^T, rows padded like the logits
             wt[:, :sm.size] = sm.W.dev().t()
             dy = torch.empty((To, B, n_in), dtype=torch.float32, device=x.device)
@@ -250,16 +285,10 @@ class TrainingStep(object):
                 _lib.check(L.slk_gemm_bias_act_f32(logits.data_ptr(), ld, wt.data_ptr(), None, dy.data_ptr(), n_in, M, ld,
                                                    n_in, 0, st()), "softmax dx")
         del logits
-        # ---- recurrent layers, top down -------------------------------------------------------------------------------
-        for pos in range(len(self.plan) - 2, -1, -1):
-            kind, layer, rev = self.plan[pos]
-            xin, yout = acts[pos], acts[pos + 1]
-            if kind == "gru":
-                dy = self._gru_backward(layer, rev, xin, yout, dy, need_dx=pos > 0)
-            else:
-                self._conv_backward(layer, xin, yout, dy)
-                dy = None
-            acts[pos + 1] = None
+        # ---- the layers in front of it, top down ----------------------------------------------------------------------
+        for k in range(len(tapes) - 1, -1, -1):
+            dy = self._backward(tapes[k], dy, need_dx=k > 0)
+            tapes[k] = None
         # ---- data-parallel average --------------------------------------------------------------------------------------
         self.gscale = allreduce_mean_(self.grad)
         if self.gscale != 1.0:
@@ -267,6 +296,90 @@ class TrainingStep(object):
         s = sc.cpu().numpy()
         loss = float(s[0]) * self.gscale + (self.l2 * float(s[2]) if self.l2 != 0.0 else 0.0)
         return loss, float(s[1]) * self.gscale
+
+    def _forward(self, layer, x, rev):
+        """(output, tape): run `layer` on the inference kernels and keep what its reverse pass needs."""
+        import torch
+        layer, rev = _unwrap(layer, rev)
+        if isinstance(layer, layers.Serial):
+            tapes = []
+            for sub in layer.layers:
+                x, tp = self._forward(sub, x, rev)
+                tapes.append(tp)
+            return x, ("serial", tapes)
+        if isinstance(layer, layers.Parallel):
+            subs = [_unwrap(sub, rev) for sub in layer.layers]
+            if all(isinstance(sub, (layers.Gru, layers.FeedForward)) for sub, _ in subs):
+                # the sub-layers write their slices of the concatenated output directly (and run side by side on their
+                # own streams at small batches): their outputs are strided views of it
+                y = layer._forward(x, None, rev)
+                tapes, off = [], 0
+                for sub, srev in subs:
+                    kind = "gru" if isinstance(sub, layers.Gru) else "ff"
+                    tapes.append((kind, sub, srev, x, y[:, :, off:off + sub.size]))
+                    off += sub.size
+                return y, ("parallel", tapes, [sub.size for sub, _ in subs])
+            outs, tapes = [], []
+            for sub in layer.layers:
+                ysub, tp = self._forward(sub, x, rev)
+                outs.append(ysub)
+                tapes.append(tp)
+            return torch.cat(outs, dim=2), ("parallel", tapes, [int(o.shape[2]) for o in outs])
+        kind = "conv" if isinstance(layer, layers.Convolution) else "gru" if isinstance(layer, layers.Gru) else "ff"
+        x = layers._check_input(x, layer.insize)
+        y = layer._forward(x, None, rev)
+        return y, (kind, layer, rev, x, y)
+
+    def _backward(self, tape, dy, need_dx):
+        """dL/d(input) of the sub-tree `tape` describes (None when not needed); parameter gradients go to self.grad."""
+        kind = tape[0]
+        if kind == "serial":
+            tapes = tape[1]
+            for k in range(len(tapes) - 1, -1, -1):
+                dy = self._backward(tapes[k], dy, need_dx or k > 0)
+            return dy
+        if kind == "parallel":
+            _, tapes, sizes = tape
+            dx, off = None, 0
+            for tp, size in zip(tapes, sizes):
+                d = self._backward(tp, dy[:, :, off:off + size], need_dx)
+                off += size
+                if need_dx:
+                    if dx is None:
+                        dx = d
+                    else:
+                        _lib.check(_lib.lib().slk_add_inplace_f32(dx.data_ptr(), d.data_ptr(), dx.numel(), layers._stream()),
+                                   "add")
+            return dx
+        _, layer, rev, xin, y = tape
+        if kind == "gru":
+            return self._gru_backward(layer, rev, xin, y, dy, need_dx)
+        if kind == "ff":
+            return self._ff_backward(layer, xin, y, dy, need_dx)
+        self._conv_backward(layer, xin, y, dy)
+        return None
+
+    def _ff_backward(self, layer, xin, y, dy, need_dx):
+        """FeedForward (layers.py:157-158): dpre = dy * fun'(.), dW = dpre^T x, db = dpre^T 1, dx = dpre . W"""
+        import torch
+        L = _lib.lib()
+        st = layers._stream
+        T, B, n = int(dy.shape[0]), int(dy.shape[1]), layer.size
+        M, i_sz = T * B, layer.insize
+        y, dy = y.contiguous(), dy.contiguous()
+        dpre = torch.empty((M, n), dtype=torch.float32, device=dy.device)
+        _lib.check(L.slk_act_backward_f32(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), dpre.numel(),
+                                          activation.act_id(layer.fun), st()), "act_backward")
+        with profiler.region("train_wgrad", 2.0 * M * n * i_sz, 4.0 * M * (n + i_sz)):
+            self._tn(dpre.data_ptr(), n, xin.data_ptr(), layers._row_stride(xin), self._grad_of(layer.W).data_ptr(), i_sz, M, n,
+                     i_sz, colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
+        if not need_dx:
+            return None
+        dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dy.device)
+        with profiler.region("train_dx", 2.0 * M * n * i_sz, 4.0 * M * (n + i_sz)):
+            _lib.check(L.slk_gemm_bias_act_f32(dpre.data_ptr(), n, layer.W.dev().t().contiguous().data_ptr(), None,
+                                               dx.data_ptr(), i_sz, M, n, i_sz, 0, st()), "ff dx")
+        return dx
 
     def _gru_backward(self, layer, rev, xin, h, dy, need_dx):
         import torch

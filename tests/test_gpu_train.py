@@ -67,6 +67,47 @@ def test_loss_and_gradients_vs_oracle(n, nstate, T, B, min_prob, l2, drop, bias)
     _assert_grads_close(step.gradients(), want)
 
 
+@pytest.mark.parametrize("model,T,B", [("baseline_raw_gru", 120, 3), ("bigger_raw_gru", 90, 2)])
+def test_birnn_feedforward_models_vs_oracle(model, T, B):
+    """models/baseline_raw_gru.py and bigger_raw_gru.py: convolution, then birnn (Parallel of a Gru and a reversed Gru,
+    their outputs strided slices of one tensor) and FeedForward layers alternating; gradients of every parameter."""
+    need_gpu()
+    from oracle import oracle_train as ot
+    from sloika_amd import models, train
+    net = models.randomise_zero_layers(models.build_model(model, klen=3, sd=0.5, seed=5))
+    rs = np.random.RandomState(T)
+    x, labels, weights = _batch(rs, net, T, B)
+    want_loss, want_acc, want = ot.loss_and_grads(net.spec(), x, labels, weights, 1e-5, 0.001, 2)
+    step = train.TrainingStep(net, min_prob=1e-5, l2=0.001, drop=2)
+    loss, acc = step.forward_backward(x, labels, weights)
+    assert loss == pytest.approx(want_loss, rel=2e-5) and acc == pytest.approx(want_acc, abs=1e-6)
+    _assert_grads_close(step.gradients(), want)
+
+
+def test_nested_serial_in_parallel_vs_oracle():
+    """A Parallel whose branches are Serials (not plain layers): the generic path (per-branch forward, concatenate)."""
+    need_gpu()
+    from oracle import oracle_train as ot
+    from sloika_amd import activation, layers, train
+    rs = np.random.RandomState(8)
+    init = lambda shape: (rs.normal(size=shape) * 0.5).astype(np.float32)
+    n = 16
+    branch = lambda: layers.Serial([layers.FeedForward(n, n, init=init, has_bias=True, fun=activation.relu),
+                                    layers.Reverse(layers.Gru(n, n, init=init, has_bias=True))])
+    net = layers.Serial([layers.Convolution(1, n, 5, 2, init=init, has_bias=True, fun=activation.tanh),
+                         layers.Parallel([branch(), layers.Gru(n, 32, init=init, has_bias=True)]),
+                         layers.FeedForward(n + 32, n, init=init, has_bias=False, fun=activation.sigmoid),
+                         layers.Softmax(n, 7, init=init, has_bias=True)])
+    x, labels, weights = _batch(rs, net, 50, 3)
+    spec = net.spec()
+    spec["sublayers"][2]["b"] = None
+    want_loss, want_acc, want = ot.loss_and_grads(spec, x, labels, weights, 0.0, 0.0, 0)
+    step = train.TrainingStep(net)
+    loss, acc = step.forward_backward(x, labels, weights)
+    assert loss == pytest.approx(want_loss, rel=2e-5) and acc == pytest.approx(want_acc, abs=1e-6)
+    _assert_grads_close(step.gradients(), want)
+
+
 def test_gru_only_network_and_device_inputs():
     """No convolution in front (the first Gru needs no dL/dx), inputs already on the device."""
     torch = need_gpu()

@@ -18,6 +18,8 @@ def _net(rs, nfeat=1, n=6, nstate=9, conv_act="elu", stride=2, winlen=5, bias=Tr
         {"type": "reverse", "sublayer": gru(n)},
         gru(n),
         {"type": "feed-forward", "W": r(n, n), "b": r(n) if bias else None, "activation": "tanh"},
+        {"type": "parallel", "sublayers": [gru(n), {"type": "reverse", "sublayer": gru(n)}]},           # a birnn
+        {"type": "feed-forward", "W": r(n, 2 * n), "b": r(n) if bias else None, "activation": "tanh"},
         {"type": "reverse", "sublayer": gru(n)},
         {"type": "softmax", "W": r(nstate, n), "b": r(nstate) if bias else None}]}
 

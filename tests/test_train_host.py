@@ -13,16 +13,24 @@ from tests.conftest import ROOT
 
 
 def test_supported_architectures():
-    from sloika_amd import activation, layers, models, train
-    plan = train._plan(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=1))
-    assert [k for k, _, _ in plan] == ["conv"] + ["gru"] * 5 + ["softmax"]
-    assert [r for _, _, r in plan] == [False, True, False, True, False, True, False]
-    g = layers.Gru(4, 8)
-    assert [k for k, _, _ in train._plan(layers.Serial([layers.Reverse(layers.Reverse(g)), layers.Softmax(8, 5)]))] == ["gru", "softmax"]
+    from sloika_amd import layers, models, train
+    body, sm = train._plan(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=1))
+    assert [type(train._unwrap(l)[0]).__name__ for l in body] == ["Convolution"] + ["Gru"] * 5
+    assert [train._unwrap(l)[1] for l in body] == [False, True, False, True, False, True] and isinstance(sm, layers.Softmax)
+    for name in ("baseline_raw_gru", "bigger_raw_gru"):                        # birnn (Parallel) + FeedForward stacks
+        body, sm = train._plan(models.build_model(name, klen=5, sd=0.5, seed=1))
+        kinds = set(type(l).__name__ for sub in body for l in train._leaves(sub))
+        assert kinds == {"Convolution", "Gru", "FeedForward"}, kinds
+    g = layers.Gru(4, 16)
+    body, _ = train._plan(layers.Serial([layers.Reverse(layers.Reverse(g)), layers.Softmax(16, 5)]))
+    assert train._unwrap(body[0]) == (g, False)
     for bad in (layers.Serial([g]),                                                      # no softmax
                 layers.Serial([layers.Lstm(4, 8), layers.Softmax(8, 5)]),
                 layers.Serial([layers.Convolution(4, 8, 3), layers.Softmax(8, 5)]),    # multi-feature convolution
-                models.build_model("baseline_raw_gru", klen=5, sd=0.5, seed=1)):       # Parallel / FeedForward inside
+                layers.Serial([layers.FeedForward(4, 1), layers.Convolution(1, 8, 3), layers.Softmax(8, 5)]),   # conv not first
+                layers.Serial([layers.Gru(4, 20), layers.Softmax(20, 5)]),            # no reverse-scan kernel for 20
+                models.build_model("raw_1.00_rGr", klen=5, sd=0.5, seed=1),            # 110/142-wide layers
+                models.build_model("baseline_lstm", klen=5, sd=0.5, seed=1)):
         with pytest.raises(NotImplementedError):
             train._plan(bad)
 
