@@ -484,3 +484,139 @@ def save_model(network, output, index=None, step=None):
     with open(os.path.join(output, model_file), 'wb') as fh:
         pickle.dump(network, fh, protocol=pickle.HIGHEST_PROTOCOL)
     return os.path.join(output, model_file)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The loop around the step: bin/train_network.py:180-330 as callable functions (the reference has it inline in a script).
+# ---------------------------------------------------------------------------------------------------------------------
+class Logger(object):
+    """train_network.py:153-170"""
+
+    def __init__(self, log_file_name, quiet=False):
+        self.fh = open(log_file_name, 'wb', 0)
+        self.quiet = quiet
+
+    def write(self, message):
+        import sys
+        if not self.quiet:
+            sys.stdout.write(message)
+            sys.stdout.flush()
+        try:
+            self.fh.write(message.encode('utf-8'))
+        except IOError as e:
+            print("Failed to write to log\n Message: {}\n Error: {}".format(message, repr(e)))
+
+
+def load_chunk_file(path, reweight='weights'):
+    """The training data of train_network.py:199-210 from a `.npz` with the datasets `chunkify` writes to HDF5
+    (sloika/util.py:60-91: `chunks` [n, chunk_len, nfeature] f4, `labels` [n, label_len] i4, `bad` [n, label_len] i1,
+    `weights` [n] f4) and the attributes `kmer` / `alphabet` as 0-d arrays.  h5py is not available on the GPU boxes; a
+    chunk file converts with `np.savez(out, **{k: h5[k][:] for k in h5}, **dict(h5.attrs))`."""
+    with np.load(path, allow_pickle=False) as z:
+        data = {k: z[k] for k in z.files}
+    alphabet = data["alphabet"].item() if "alphabet" in data else b"ACGT"       # variables.DEFAULT_ALPHABET, :259-264
+    if isinstance(alphabet, str):
+        alphabet = alphabet.encode("ascii")
+    out = {"chunks": data["chunks"].astype(sloika_dtype), "labels": data["labels"].astype(np.int32), "bad": data["bad"],
+           "kmer": int(data["kmer"]) if "kmer" in data else None, "alphabet": alphabet}
+    if reweight is not None and reweight in data:                                   # :203-206
+        out["weights"] = data[reweight].astype('float64')
+    else:
+        out["weights"] = np.ones(len(out["chunks"]), dtype='float64')
+    return out
+
+
+def prepare_training_data(data, transducer=True, bad=True, ilf=False):
+    """train_network.py:207-252: normalised sampling weights, blank removal, bad positions, per-label weights.
+
+    One deliberate difference: `all_labels[all_bad] = 0` (:240) indexes with the int8 array HDF5 returns, i.e. it
+    fancy-indexes ROWS 0 and 1 of the labels instead of masking the flagged positions; here `bad` is used as the boolean
+    mask the line was written for."""
+    all_labels = np.array(data["labels"], dtype=np.int32)
+    all_weights = np.asarray(data["weights"], dtype='float64')
+    all_weights = all_weights / np.sum(all_weights)                                 # :207-208
+    if not transducer:
+        remove_blanks(all_labels)                                                   # :236-237
+    if bad:
+        all_labels[np.asarray(data["bad"]).astype(bool)] = 0                        # :239-240 (see above)
+    if ilf:                                                                         # :242-249
+        label_weights = np.zeros(np.max(all_labels) + 1, dtype='f4')
+        for i, lbls in enumerate(all_labels):
+            label_weights += all_weights[i] * np.bincount(lbls, minlength=len(label_weights))
+        label_weights = np.reciprocal(label_weights)
+        label_weights /= np.mean(label_weights)
+    else:
+        label_weights = np.ones(np.max(all_labels) + 1, dtype='f4')                 # :250-252
+    return all_labels, all_weights, label_weights
+
+
+def training_batches(all_chunks, all_labels, all_weights, label_weights, niteration, batch_size=100,
+                     chunk_len_range=(0.5, 1.0), drop=20, rate=1e-3, lrdecay=5000.0):
+    """The sampler of train_network.py:213-230,288-306, drawing from numpy's global generator in the reference's order
+    (seed it with np.random.seed like :180).  Yields (indata [chunk_len, batch, nfeature], labels [label_len, batch],
+    weights, learning_rate) per iteration."""
+    data_chunk = all_chunks.shape[1]
+    training_stride = int(np.ceil(float(all_chunks.shape[1]) / all_labels.shape[1]))            # :213
+    min_chunk = 2 * drop + 1 if chunk_len_range[0] is None else int(np.around(chunk_len_range[0] * data_chunk))
+    max_chunk = data_chunk if chunk_len_range[1] is None else int(np.around(chunk_len_range[1] * data_chunk))
+    assert max_chunk >= min_chunk, "Min chunk size (got {}) must be <= chunk size (got {})".format(min_chunk, max_chunk)
+    assert data_chunk >= max_chunk, "Max chunk size (got {}) must be <= data chunk size (got {})".format(max_chunk, data_chunk)
+    assert data_chunk >= (2 * drop + 1), "Data chunk size (got {}) must be > 2 * drop (got {})".format(data_chunk, drop)
+    assert min_chunk >= (2 * drop + 1), "Min chunk size (got {}) must be > 2 * drop (got {})".format(min_chunk, drop)
+    max_batch_size = (all_weights > 0).sum()                                                    # :209
+    for i in range(niteration):
+        learning_rate = rate / (1.0 + i / lrdecay)                                              # :289
+        chunk_len = np.random.randint(min_chunk, max_chunk + 1)                                 # :291-292
+        chunk_len = chunk_len - (chunk_len % training_stride)
+        this_batch = int(batch_size * float(max_chunk) / chunk_len)                             # :294
+        start = np.random.randint(data_chunk - chunk_len + 1)                                   # :296-297
+        start = start - (start % training_stride)
+        label_lb = start // training_stride                                                     # :299-300
+        label_ub = (start + chunk_len) // training_stride
+        idx = np.sort(np.random.choice(len(all_chunks), size=min(this_batch, max_batch_size), replace=False,
+                                       p=all_weights))                                          # :302-303
+        indata = np.ascontiguousarray(all_chunks[idx, start: start + chunk_len].transpose((1, 0, 2)))      # :304
+        labels = np.ascontiguousarray(all_labels[idx, label_lb: label_ub].transpose())          # :305
+        yield indata, labels, label_weights[labels], learning_rate                              # :306
+
+
+def train_loop(network, data, output, niteration=50000, batch_size=100, chunk_len_range=(0.5, 1.0), drop=20,
+               adam=(1e-3, 0.9, 0.999), lrdecay=5000.0, min_prob=1e-30, l2=0.0, save_every=5000, smooth=0.45, seed=None,
+               transducer=True, bad=True, ilf=False, quiet=False):
+    """train_network.py:180-330 for an already built network and loaded data (`load_chunk_file`): writes model.log,
+    model_checkpoint_NNNNN.pkl every `save_every` iterations and model_final.pkl into `output`; returns the step."""
+    import os
+    import time
+    np.random.seed(seed)                                                            # :180
+    if not os.path.exists(output):
+        os.mkdir(output)
+    log = Logger(os.path.join(output, 'model.log'), quiet)
+    all_labels, all_weights, label_weights = prepare_training_data(data, transducer, bad, ilf)
+    fg = wrap_network(network, min_prob=min_prob, l2=l2, drop=drop, adam=adam[1:])
+    total_ev = 0
+    score_smoothed, acc_smoothed = ExponentialSmoother(smooth), ExponentialSmoother(smooth)
+    log.write('* Dumping initial model\n')
+    save_model(network, output, 0, step=fg)                                         # :282
+    t0 = time.time()
+    log.write('* Training\n')
+    batches = training_batches(data["chunks"], all_labels, all_weights, label_weights, niteration, batch_size,
+                               chunk_len_range, drop, adam[0], lrdecay)
+    for i, (indata, labels, weights, learning_rate) in enumerate(batches):
+        fval, batch_acc = fg(indata, labels, weights, learning_rate)                # :308
+        total_ev += np.size(labels)
+        score_smoothed.update(float(fval))
+        acc_smoothed.update(batch_acc)
+        if (i + 1) % save_every == 0:                                               # :315-319
+            save_model(network, output, (i + 1) // save_every, step=fg)
+            log.write('C')
+        else:
+            log.write('.')
+        if (i + 1) % 50 == 0:                                                       # :321-328
+            tn = time.time()
+            dt = tn - t0
+            log.write(' {:5d} {:5.3f}  {:5.2f}%  {:5.2f}s ({:.2f} kev/s)\n'.format(
+                (i + 1) // 50, score_smoothed.value, 100.0 * acc_smoothed.value, dt, total_ev / 1000.0 / dt))
+            total_ev = 0
+            t0 = tn
+    save_model(network, output, step=fg)                                            # :330
+    return fg

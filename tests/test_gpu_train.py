@@ -1,6 +1,8 @@
 """Parity of the training step (sloika_amd/train.py + csrc/train.hip through the C ABI)
 with the float64 oracle of bin/train_network.py:124-142 and sloika/updates.py:36-89 (oracle/oracle_train.py, itself
 checked against finite differences in tests/test_oracle_train.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -279,3 +281,40 @@ def test_gru_backward_kernels_agree(n, reverse):
     assert L.slk_gru_backward_f32(d["xh"].data_ptr(), 160, d["xh"].data_ptr(), I, d["zr"].data_ptr(), d["c"].data_ptr(),
                                   d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), T, B, 40, reverse, 1, 2,
                                   stream()) == _lib.SLK_ERR_UNSUPPORTED
+
+
+def test_train_loop_end_to_end(tmp_path):
+    """train_network.py:180-330 as a function: chunk file -> sampler -> fg -> log, checkpoints, final model.  The toy task
+    (label = quantised local signal level, half of the positions blank) must be learnt."""
+    torch = need_gpu()
+    from sloika_amd import helpers, train
+    rs = np.random.RandomState(3)
+    n, clen, stride = 64, 200, 2
+    level = rs.randint(1, 5, size=(n, clen // stride))
+    chunks = (np.repeat(level, stride, axis=1).astype(np.float32) - 2.5 + 0.1 * rs.normal(size=(n, clen)))[:, :, None]
+    labels = level.astype(np.int32)
+    labels[:, 1::2] = 0                                                   # blanks
+    chunks[:, 2::4, 0] += 3.0                                             # ... which the signal marks
+    chunks[:, 3::4, 0] += 3.0
+    path = os.path.join(str(tmp_path), "chunks.npz")
+    np.savez(path, chunks=chunks.astype(np.float32), labels=labels, bad=np.zeros_like(labels, dtype='i1'),
+             weights=np.ones(n, dtype=np.float32), kmer=np.int64(1), alphabet=np.bytes_(b"ACGT"))
+    net = _build(np.random.RandomState(4), n=32, nstate=5, winlen=5, stride=stride, nlayer=2, scale=0.3)
+    out = os.path.join(str(tmp_path), "run")
+    fg = train.train_loop(net, train.load_chunk_file(path), out, niteration=200, batch_size=32, drop=4, adam=(4e-3, 0.9, 0.999),
+                          save_every=100, seed=9, quiet=True)
+    files = sorted(os.listdir(out))
+    assert files == ["model.log", "model_checkpoint_00000.pkl", "model_checkpoint_00001.pkl", "model_checkpoint_00002.pkl",
+                     "model_final.pkl"]
+    log = open(os.path.join(out, "model.log")).read()
+    assert log.count("C") >= 2 and log.count(".") >= 198 and "kev/s" in log
+    lines = [l for l in log.splitlines() if "kev/s" in l]
+    pct = lambda line: float([tok for tok in line.split() if tok.endswith("%")][0].rstrip("%"))
+    first_acc, last_acc = pct(lines[0]), pct(lines[-1])
+    assert last_acc > 90.0 and last_acc > first_acc, (first_acc, last_acc)
+    final = helpers.load_model(os.path.join(out, "model_final.pkl"))
+    x = torch.from_numpy(np.ascontiguousarray(chunks[:8].transpose(1, 0, 2)).astype(np.float32)).cuda()
+    post = final.run(x).cpu().numpy()
+    assert (post.argmax(2) == labels[:8].T)[4:-4].mean() > 0.9
+    initial = helpers.load_model(os.path.join(out, "model_checkpoint_00000.pkl"))
+    assert (initial.run(x).cpu().numpy().argmax(2) == labels[:8].T)[4:-4].mean() < 0.6

@@ -113,3 +113,53 @@ def test_two_rank_gradient_average_equals_whole_batch(tmp_path):
     loss, acc, grads = ot.loss_and_grads(spec, x, labels, weights, 1e-3, 0.0, 1)
     want = np.concatenate([g.reshape(-1) for g in grads] + [[loss, acc]])
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
+
+
+def _toy_data(rs, n=40, chunk_len=120, stride=2, nstate=6):
+    labels = rs.randint(0, nstate, size=(n, chunk_len // stride)).astype(np.int32)
+    labels[rs.uniform(size=labels.shape) < 0.5] = 0
+    bad = (rs.uniform(size=labels.shape) < 0.05).astype('i1')
+    chunks = rs.normal(size=(n, chunk_len, 1)).astype(np.float32)
+    weights = rs.uniform(size=n).astype(np.float32)
+    weights[:3] = 0.0
+    return chunks, labels, bad, weights
+
+
+def test_chunk_file_preparation_and_sampler(tmp_path):
+    """train_network.py:199-252 (data preparation) and :288-306 (the sampler), on a `.npz` chunk file."""
+    from sloika_amd import train
+    rs = np.random.RandomState(0)
+    chunks, labels, bad, weights = _toy_data(rs)
+    path = os.path.join(str(tmp_path), "chunks.npz")
+    np.savez(path, chunks=chunks, labels=labels, bad=bad, weights=weights, kmer=np.int64(2), alphabet=np.bytes_(b"ACGT"))
+    data = train.load_chunk_file(path)
+    assert data["kmer"] == 2 and data["alphabet"] == b"ACGT" and data["weights"].dtype == np.float64
+    all_labels, all_weights, label_weights = train.prepare_training_data(data, transducer=True, bad=True, ilf=False)
+    assert all_weights.sum() == pytest.approx(1.0) and (all_labels[bad.astype(bool)] == 0).all()
+    assert (all_labels[~bad.astype(bool)] == labels[~bad.astype(bool)]).all() and (label_weights == 1).all()
+    lab2, _, lw = train.prepare_training_data(data, transducer=False, bad=False, ilf=True)
+    assert (lab2[:, 1:] != 0).sum() >= (labels[:, 1:] != 0).sum() and lw.mean() == pytest.approx(1.0, rel=1e-6)
+    for row, src in zip(lab2, labels):                       # remove_blanks: a blank repeats the label before it
+        for j in range(1, len(row)):
+            assert row[j] == (src[j] if src[j] != 0 else row[j - 1])
+    # sampler: lengths multiple of the stride inside [min, max], label window aligned with the signal window, zero-weight
+    # chunks never drawn, batch scaled inversely with the chunk length, learning rate decays, reproducible from the seed
+    def draw(seed):
+        np.random.seed(seed)
+        return list(train.training_batches(data["chunks"], all_labels, all_weights, label_weights, niteration=25,
+                                           batch_size=8, chunk_len_range=(0.5, 1.0), drop=5, rate=1e-3, lrdecay=10.0))
+    a, b = draw(7), draw(7)
+    assert all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+    zero = set(np.flatnonzero(weights == 0))
+    for i, (indata, lab, w, lr) in enumerate(a):
+        clen, nb, _ = indata.shape
+        assert 60 <= clen <= 120 and clen % 2 == 0 and lab.shape == (clen // 2, nb) and w.shape == lab.shape
+        assert nb == min(int(8 * 120.0 / clen), 37)
+        assert lr == pytest.approx(1e-3 / (1.0 + i / 10.0))
+        # every drawn chunk is a window of one of the positive-weight chunks, with the matching label window
+        for k in range(nb):
+            hits = [(c, s) for c in range(40) if c not in zero for s in range(0, 120 - clen + 1, 2)
+                    if np.array_equal(chunks[c, s:s + clen, 0], indata[:, k, 0])]
+            assert len(hits) == 1
+            c, s = hits[0]
+            assert np.array_equal(all_labels[c, s // 2:(s + clen) // 2], lab[:, k])
