@@ -8,8 +8,8 @@ ARE the forward pass.  There is no CPU fallback.
 
 Supported networks: a Serial that ends in Softmax and is built from Convolution(insize=1) as the first layer, Gru,
 FeedForward, Reverse, Parallel (so `birnn`) and nested Serial -- the raw-signal models models/raw_0.98_rgrgr.py,
-baseline_raw_gru.py, bigger_raw_gru.py; anything else (Lstm, Window, multi-feature Convolution, Gru sizes without a
-reverse-scan kernel) raises NotImplementedError: the reference differentiates any layer through Theano, only the
+baseline_raw_gru.py, bigger_raw_gru.py, raw_1.00_rGr.py (its 110/142-wide layers run zero-padded); anything else (Lstm,
+Window, multi-feature Convolution, Gru wider than 144) raises NotImplementedError: the reference differentiates any layer through Theano, only the
 raw-signal GRU path is accelerated here.
 
 Data parallel (BASELINE.json configs[4]): with torch.distributed initialised (backend "nccl" = RCCL over xGMI) every
@@ -107,7 +107,7 @@ def _validate(layer, first, rev=False, where="network"):
     elif isinstance(layer, layers.Gru):
         if activation.act_name(layer.fun) != "tanh" or activation.act_name(layer.gatefun) != "sigmoid":
             raise NotImplementedError("training: Gru layers with fun=tanh, gatefun=sigmoid only")
-        if layer.size not in (16, 32, 48, 64, 96, 112, 128, 144):
+        if (layer.size + 15) // 16 * 16 not in (16, 32, 48, 64, 96, 112, 128, 144):
             raise NotImplementedError("training: no reverse-scan kernel for a Gru of size %d" % layer.size)
     elif isinstance(layer, layers.FeedForward):
         if activation.act_name(layer.fun) not in _FF_ACTS:
@@ -189,6 +189,10 @@ class TrainingStep(object):
         for layer in [leaf for sub in self.body for leaf in _leaves(sub)] + [self.softmax]:
             for attr in ("_w16", "_iw16", "_pad_cache"):
                 layer.__dict__.pop(attr, None)
+            if isinstance(layer, layers.Gru) and (layer.size % 16 or layer.insize % 16):
+                # its forward pass builds a zero-padded twin from the HOST copy of the weights (layers.Gru._padded)
+                for p in layer.params():
+                    p._value = np.ascontiguousarray(p._dev.cpu().numpy(), dtype=sloika_dtype)
 
     def sync_host(self):
         """Copy the trained parameters back into the layers' numpy storage (what pickling a network saves:
@@ -382,16 +386,50 @@ class TrainingStep(object):
         return dx
 
     def _gru_backward(self, layer, rev, xin, h, dy, need_dx):
+        """Reverse pass of one Gru layer.  Sizes that are not multiples of 16 (models/raw_1.00_rGr.py: 110, 142) run
+        zero-padded, like the forward pass (layers.Gru._padded): padding neurons have zero weights, zero state and receive
+        zero gradient, so the leading blocks of every gradient are those of the unpadded layer."""
+        import torch
+        n, i_sz = layer.size, layer.insize
+        n16, i16 = (n + 15) // 16 * 16, (i_sz + 15) // 16 * 16
+        iW, sW, sW2, b = layer.iW.dev(), layer.sW.dev(), layer.sW2.dev(), layer.b.dev()
+        gb = self._grad_of(layer.b) if layer.has_bias else None
+        if n16 == n and i16 == i_sz:
+            return self._gru_backward_core(xin, h, dy, rev, n, i_sz, iW, sW, sW2, b, self._grad_of(layer.iW),
+                                           self._grad_of(layer.sW), self._grad_of(layer.sW2), gb, need_dx)
+        T, B, dev = int(h.shape[0]), int(h.shape[1]), h.device
+
+        def widen(t, width):
+            out = torch.zeros((T, B, width), dtype=torch.float32, device=dev)
+            out[:, :, :t.shape[2]] = t
+            return out
+
+        def pad(t, blocks, rows, cols, prow, pcol):
+            out = torch.zeros((blocks, prow, pcol), dtype=torch.float32, device=dev)
+            out[:, :rows, :cols] = t.reshape(blocks, rows, cols)
+            return out.reshape(blocks * prow, pcol)
+
+        iW_p, sW_p, sW2_p = pad(iW, 3, n, i_sz, n16, i16), pad(sW, 2, n, n, n16, n16), pad(sW2, 1, n, n, n16, n16)
+        b_p = pad(b, 3, n, 1, n16, 1).reshape(-1)
+        giW, gsW, gsW2 = torch.empty_like(iW_p), torch.empty_like(sW_p), torch.empty_like(sW2_p)
+        gb_p = torch.empty_like(b_p) if gb is not None else None
+        dx = self._gru_backward_core(widen(xin, i16), widen(h, n16), widen(dy, n16), rev, n16, i16, iW_p, sW_p, sW2_p, b_p,
+                                     giW.reshape(-1), gsW.reshape(-1), gsW2.reshape(-1), gb_p, need_dx)
+        self._grad_of(layer.iW).view(3, n, i_sz).copy_(giW.view(3, n16, i16)[:, :n, :i_sz])
+        self._grad_of(layer.sW).view(2, n, n).copy_(gsW.view(2, n16, n16)[:, :n, :n])
+        self._grad_of(layer.sW2).view(n, n).copy_(gsW2.view(n16, n16)[:n, :n])
+        if gb is not None:
+            gb.view(3, n).copy_(gb_p.view(3, n16)[:, :n])
+        return dx[:, :, :i_sz].contiguous() if need_dx else None
+
+    def _gru_backward_core(self, xin, h, dy, rev, n, i_sz, iW, sW, sW2, b, giW, gsW, gsW2, gb, need_dx):
         import torch
         L = _lib.lib()
         st = layers._stream
-        T, B, n = int(h.shape[0]), int(h.shape[1]), layer.size
-        i_sz, M, K = layer.insize, int(h.shape[0]) * int(h.shape[1]), layer.insize + layer.size
-        act, gact = activation.act_id(layer.fun), activation.act_id(layer.gatefun)
-        if act != activation.act_id(activation.tanh) or gact != activation.act_id(activation.sigmoid):
-            raise NotImplementedError("training: Gru layers with fun=tanh, gatefun=sigmoid only")
+        T, B = int(h.shape[0]), int(h.shape[1])
+        M, K = T * B, i_sz + n
+        act, gact = activation.act_id(activation.tanh), activation.act_id(activation.sigmoid)
         dev = h.device
-        iW, sW, sW2, b = layer.iW.dev(), layer.sW.dev(), layer.sW2.dev(), layer.b.dev()
         with profiler.region("train_gates", 6.0 * M * n * K, 4.0 * M * (3 * K + 3 * n), f16x3_flops=6.0 * M * n * K):
             xh = torch.empty((M, K), dtype=torch.float32, device=dev)
             _lib.check(L.slk_train_pack_xh_f32(xin.data_ptr(), layers._row_stride(xin), h.data_ptr(), layers._row_stride(h),
@@ -414,11 +452,10 @@ class TrainingStep(object):
         _lib.check(rc, "gru_backward")
         f4 = 4                                                                       # bytes per float, for column offsets
         with profiler.region("train_wgrad", 2.0 * M * (3 * n * i_sz + 3 * n * n), 4.0 * M * (3 * n + 2 * K)):
-            self._tn(da.data_ptr(), 3 * n, xh.data_ptr(), K, self._grad_of(layer.iW).data_ptr(), i_sz, M, 3 * n, i_sz,
-                     colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
-            self._tn(da.data_ptr(), 3 * n, xh.data_ptr() + f4 * i_sz, K, self._grad_of(layer.sW).data_ptr(), n, M, 2 * n, n)
-            self._tn(da.data_ptr() + f4 * 2 * n, 3 * n, xrh.data_ptr() + f4 * i_sz, K, self._grad_of(layer.sW2).data_ptr(), n,
-                     M, n, n)
+            self._tn(da.data_ptr(), 3 * n, xh.data_ptr(), K, giW.data_ptr(), i_sz, M, 3 * n, i_sz,
+                     colsum=gb.data_ptr() if gb is not None else None)
+            self._tn(da.data_ptr(), 3 * n, xh.data_ptr() + f4 * i_sz, K, gsW.data_ptr(), n, M, 2 * n, n)
+            self._tn(da.data_ptr() + f4 * 2 * n, 3 * n, xrh.data_ptr() + f4 * i_sz, K, gsW2.data_ptr(), n, M, n, n)
         if not need_dx:
             return None
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)

@@ -69,10 +69,11 @@ def test_loss_and_gradients_vs_oracle(n, nstate, T, B, min_prob, l2, drop, bias)
     _assert_grads_close(step.gradients(), want)
 
 
-@pytest.mark.parametrize("model,T,B", [("baseline_raw_gru", 120, 3), ("bigger_raw_gru", 90, 2)])
+@pytest.mark.parametrize("model,T,B", [("baseline_raw_gru", 120, 3), ("bigger_raw_gru", 90, 2), ("raw_1.00_rGr", 80, 3)])
 def test_birnn_feedforward_models_vs_oracle(model, T, B):
     """models/baseline_raw_gru.py and bigger_raw_gru.py: convolution, then birnn (Parallel of a Gru and a reversed Gru,
-    their outputs strided slices of one tensor) and FeedForward layers alternating; gradients of every parameter."""
+    their outputs strided slices of one tensor) and FeedForward layers alternating; raw_1.00_rGr.py: 110- and 142-wide Gru
+    layers, run zero-padded to 112 / 144.  Gradients of every parameter."""
     need_gpu()
     from oracle import oracle_train as ot
     from sloika_amd import models, train

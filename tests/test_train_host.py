@@ -17,6 +17,7 @@ def test_supported_architectures():
     body, sm = train._plan(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=1))
     assert [type(train._unwrap(l)[0]).__name__ for l in body] == ["Convolution"] + ["Gru"] * 5
     assert [train._unwrap(l)[1] for l in body] == [False, True, False, True, False, True] and isinstance(sm, layers.Softmax)
+    train._plan(models.build_model("raw_1.00_rGr", klen=5, sd=0.5, seed=1))    # 110/142-wide layers: zero-padded
     for name in ("baseline_raw_gru", "bigger_raw_gru"):                        # birnn (Parallel) + FeedForward stacks
         body, sm = train._plan(models.build_model(name, klen=5, sd=0.5, seed=1))
         kinds = set(type(l).__name__ for sub in body for l in train._leaves(sub))
@@ -28,8 +29,7 @@ def test_supported_architectures():
                 layers.Serial([layers.Lstm(4, 8), layers.Softmax(8, 5)]),
                 layers.Serial([layers.Convolution(4, 8, 3), layers.Softmax(8, 5)]),    # multi-feature convolution
                 layers.Serial([layers.FeedForward(4, 1), layers.Convolution(1, 8, 3), layers.Softmax(8, 5)]),   # conv not first
-                layers.Serial([layers.Gru(4, 20), layers.Softmax(20, 5)]),            # no reverse-scan kernel for 20
-                models.build_model("raw_1.00_rGr", klen=5, sd=0.5, seed=1),            # 110/142-wide layers
+                layers.Serial([layers.Gru(4, 150), layers.Softmax(150, 5)]),          # wider than the widest kernel
                 models.build_model("baseline_lstm", klen=5, sd=0.5, seed=1)):
         with pytest.raises(NotImplementedError):
             train._plan(bad)
