@@ -10,7 +10,7 @@ What is restated, and from where:
   * the gradient th.grad(loss, network.params()) (sloika/updates.py:66) -- the reference gets it from Theano's
     automatic differentiation; here it is the hand-derived reverse pass of the layer formulas restated in
     oracle/oracle_np.py (Convolution layers.py:417-419, Gru.step layers.py:1010-1021, Softmax layers.py:309-314,
-    FeedForward layers.py:157-158, Reverse layers.py:1449-1450, Parallel layers.py:1486-1487, Serial layers.py:1500-1504);
+    FeedForward layers.py:157-158, Window layers.py:346-351, Reverse layers.py:1449-1450, Parallel layers.py:1486-1487, Serial layers.py:1500-1504);
   * the "ADAMski" update sloika/updates.py:36-89 (float32 arithmetic like the reference's shared variables), `sgd`
     updates.py:9-33 and `param_sqr` updates.py:92-103.
 
@@ -53,6 +53,8 @@ def params_of(spec):
         return [spec[k] for k in ("iW", "sW", "sW2", "b") if spec.get(k) is not None]
     if t in ("convolution", "softmax", "feed-forward"):
         return [spec[k] for k in ("W", "b") if spec.get(k) is not None]
+    if t == "window":
+        return []
     raise ValueError("oracle_train: unsupported layer type %r" % t)
 
 
@@ -72,6 +74,8 @@ def _forward(spec, x):
     if t == "parallel":                                            # layers.py:1486-1487
         outs = [_forward(sub, x) for sub in spec["sublayers"]]
         return np.concatenate([o for o, _ in outs], axis=2), ([tp for _, tp in outs], [o.shape[2] for o, _ in outs])
+    if t == "window":                                              # layers.py:346-351
+        return onp.window(x, spec["w"]), (x.shape, spec["w"])
     if t == "convolution":
         W = np.asarray(spec["W"], f64)
         pad, stride = tuple(spec["padding"]), spec["stride"]
@@ -137,6 +141,12 @@ def _backward(spec, tape, dy):
             d, g = _backward(sub, tp, dy[:, :, off:off + size])
             dx, grads, off = dx + d, grads + g, off + size
         return dx, grads
+    if t == "window":
+        (T, B, F), w = tape                                        # out[t, :, j*F:(j+1)*F] = xpad[t + j], xpad = w//2 zeros each side
+        dxp = np.zeros((T + 2 * (w // 2), B, F))
+        for j in range(w):
+            dxp[j:j + T] += dy[:, :, j * F:(j + 1) * F]
+        return dxp[w // 2: w // 2 + T], []
     if t == "convolution":
         xp, a, y, Tout = tape
         W = np.asarray(spec["W"], f64)

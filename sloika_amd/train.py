@@ -6,10 +6,10 @@ like the Theano function the reference compiles.  Device side: csrc/train.hip (r
 contractions for the weight gradients, softmax cross-entropy, the optimiser) on top of the inference kernels, which
 ARE the forward pass.  There is no CPU fallback.
 
-Supported networks: a Serial that ends in Softmax and is built from Convolution(insize=1) as the first layer, Gru,
+Supported networks: a Serial that ends in Softmax and is built from Convolution(insize=1) or Window as the first layer, Gru,
 FeedForward, Reverse, Parallel (so `birnn`) and nested Serial -- the raw-signal models models/raw_0.98_rgrgr.py,
-baseline_raw_gru.py, bigger_raw_gru.py, raw_1.00_rGr.py (its 110/142-wide layers run zero-padded); anything else (Lstm,
-Window, multi-feature Convolution, Gru wider than 144) raises NotImplementedError: the reference differentiates any layer through Theano, only the
+baseline_raw_gru.py, bigger_raw_gru.py, raw_1.00_rGr.py (its 110/142-wide layers run zero-padded) and the event-feature
+models baseline_gru.py / tiny_gru.py; anything else (Lstm, multi-feature Convolution, Gru wider than 144) raises NotImplementedError: the reference differentiates any layer through Theano, only the
 raw-signal GRU path is accelerated here.
 
 Data parallel (BASELINE.json configs[4]): with torch.distributed initialised (backend "nccl" = RCCL over xGMI) every
@@ -104,6 +104,10 @@ def _validate(layer, first, rev=False, where="network"):
             raise NotImplementedError("training: Convolution only as the first layer, on one-feature (raw) input, not reversed")
         if activation.act_name(layer.fun) not in _FF_ACTS:
             raise NotImplementedError("training: Convolution activation %s has no derivative kernel" % layer.fun.__name__)
+    elif isinstance(layer, layers.Window):
+        if not first:
+            raise NotImplementedError("training: Window only as the first layer (the event-feature front end), where it needs "
+                                      "no reverse pass")
     elif isinstance(layer, layers.Gru):
         if activation.act_name(layer.fun) != "tanh" or activation.act_name(layer.gatefun) != "sigmoid":
             raise NotImplementedError("training: Gru layers with fun=tanh, gatefun=sigmoid only")
@@ -114,8 +118,8 @@ def _validate(layer, first, rev=False, where="network"):
             raise NotImplementedError("training: FeedForward activation %s has no derivative kernel" % layer.fun.__name__)
     else:
         raise NotImplementedError(
-            "training on the GPU path covers Convolution(insize=1) first, Gru, FeedForward, Reverse, Parallel, Serial and a "
-            "final Softmax; %s (%s) is outside it" % (name, where))
+            "training on the GPU path covers Convolution(insize=1) or Window first, Gru, FeedForward, Reverse, Parallel, Serial "
+            "and a final Softmax; %s (%s) is outside it" % (name, where))
 
 
 def _plan(network):
@@ -329,7 +333,8 @@ class TrainingStep(object):
                 outs.append(ysub)
                 tapes.append(tp)
             return torch.cat(outs, dim=2), ("parallel", tapes, [int(o.shape[2]) for o in outs])
-        kind = "conv" if isinstance(layer, layers.Convolution) else "gru" if isinstance(layer, layers.Gru) else "ff"
+        kind = ("conv" if isinstance(layer, layers.Convolution) else "gru" if isinstance(layer, layers.Gru) else
+                "window" if isinstance(layer, layers.Window) else "ff")
         x = layers._check_input(x, layer.insize)
         y = layer._forward(x, None, rev)
         return y, (kind, layer, rev, x, y)
@@ -360,6 +365,9 @@ class TrainingStep(object):
             return self._gru_backward(layer, rev, xin, y, dy, need_dx)
         if kind == "ff":
             return self._ff_backward(layer, xin, y, dy, need_dx)
+        if kind == "window":                            # first layer, no parameters: nothing to do
+            assert not need_dx
+            return None
         self._conv_backward(layer, xin, y, dy)
         return None
 

@@ -69,17 +69,19 @@ def test_loss_and_gradients_vs_oracle(n, nstate, T, B, min_prob, l2, drop, bias)
     _assert_grads_close(step.gradients(), want)
 
 
-@pytest.mark.parametrize("model,T,B", [("baseline_raw_gru", 120, 3), ("bigger_raw_gru", 90, 2), ("raw_1.00_rGr", 80, 3)])
+@pytest.mark.parametrize("model,T,B", [("baseline_raw_gru", 120, 3), ("bigger_raw_gru", 90, 2), ("raw_1.00_rGr", 80, 3),
+                                       ("baseline_gru", 45, 3), ("tiny_gru", 30, 5)])
 def test_birnn_feedforward_models_vs_oracle(model, T, B):
     """models/baseline_raw_gru.py and bigger_raw_gru.py: convolution, then birnn (Parallel of a Gru and a reversed Gru,
     their outputs strided slices of one tensor) and FeedForward layers alternating; raw_1.00_rGr.py: 110- and 142-wide Gru
-    layers, run zero-padded to 112 / 144.  Gradients of every parameter."""
+    layers, run zero-padded to 112 / 144; baseline_gru.py / tiny_gru.py: event features through a Window, Gru layers with 12
+    inputs and (tiny) 4 neurons, zero-padded.  Gradients of every parameter."""
     need_gpu()
     from oracle import oracle_train as ot
     from sloika_amd import models, train
     net = models.randomise_zero_layers(models.build_model(model, klen=3, sd=0.5, seed=5))
     rs = np.random.RandomState(T)
-    x, labels, weights = _batch(rs, net, T, B)
+    x, labels, weights = _batch(rs, net, T, B, nfeat=net.insize)
     want_loss, want_acc, want = ot.loss_and_grads(net.spec(), x, labels, weights, 1e-5, 0.001, 2)
     step = train.TrainingStep(net, min_prob=1e-5, l2=0.001, drop=2)
     loss, acc = step.forward_backward(x, labels, weights)

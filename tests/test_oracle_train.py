@@ -52,6 +52,33 @@ def test_gradients_match_finite_differences(min_prob, l2, drop, conv_act, bias):
             assert g.reshape(-1)[idx] == pytest.approx((up - dn) / (2 * eps), rel=2e-5, abs=1e-8)
 
 
+def test_window_network_gradients():
+    """Event-feature front end (models/baseline_gru.py): Window, then layers; Window in the middle exercises its reverse pass."""
+    rs = np.random.RandomState(9)
+    r = lambda *shape: rs.normal(size=shape) * 0.5
+    n = 5
+    gru = lambda i: {"type": "GRU", "iW": r(3 * n, i), "sW": r(2 * n, n), "sW2": r(n, n), "b": r(3 * n), "activation": "tanh",
+                     "gate": "sigmoid"}
+    spec = {"type": "serial", "sublayers": [{"type": "window", "w": 3}, gru(12), {"type": "window", "w": 5},
+                                            {"type": "feed-forward", "W": r(n, 5 * n), "b": r(n), "activation": "tanh"},
+                                            {"type": "softmax", "W": r(7, n), "b": r(7)}]}
+    x = rs.normal(size=(15, 2, 4))
+    labels = rs.randint(0, 7, size=(15, 2))
+    weights = rs.uniform(0.5, 1.5, size=(15, 2))
+    loss, acc, grads = ot.loss_and_grads(spec, x, labels, weights, 1e-4, 0.0, 1)
+    eps = 1e-6
+    for p, g in zip(ot.params_of(spec), grads):
+        flat = p.reshape(-1)
+        for idx in rs.choice(flat.size, size=min(5, flat.size), replace=False):
+            keep = flat[idx]
+            flat[idx] = keep + eps
+            up, _ = ot.loss_only(spec, x, labels, weights, 1e-4, 0.0, 1)
+            flat[idx] = keep - eps
+            dn, _ = ot.loss_only(spec, x, labels, weights, 1e-4, 0.0, 1)
+            flat[idx] = keep
+            assert g.reshape(-1)[idx] == pytest.approx((up - dn) / (2 * eps), rel=2e-5, abs=1e-8)
+
+
 def test_adamski_first_steps_closed_form():
     """updates.py:36-89: with momentum/variance starting at zero, step 1 moves every parameter by
     lr_1 * (1-d1) g / (sqrt((1-d2) g^2) + eps) with lr_1 = rate sqrt(1-d2) / momentum_factor_1."""

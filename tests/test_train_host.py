@@ -18,6 +18,8 @@ def test_supported_architectures():
     assert [type(train._unwrap(l)[0]).__name__ for l in body] == ["Convolution"] + ["Gru"] * 5
     assert [train._unwrap(l)[1] for l in body] == [False, True, False, True, False, True] and isinstance(sm, layers.Softmax)
     train._plan(models.build_model("raw_1.00_rGr", klen=5, sd=0.5, seed=1))    # 110/142-wide layers: zero-padded
+    train._plan(models.build_model("baseline_gru", klen=5, sd=0.5, seed=1))    # Window front end
+    train._plan(models.build_model("tiny_gru", klen=5, sd=0.5, seed=1))
     for name in ("baseline_raw_gru", "bigger_raw_gru"):                        # birnn (Parallel) + FeedForward stacks
         body, sm = train._plan(models.build_model(name, klen=5, sd=0.5, seed=1))
         kinds = set(type(l).__name__ for sub in body for l in train._leaves(sub))
