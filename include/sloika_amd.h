@@ -286,13 +286,15 @@ int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *e
  *
  * Gate recompute (forward values the reverse scan needs, recomputed time-parallel from the finished forward pass):
  *   slk_train_pack_xh_f32:  xh[m] = [x[m] (I) | h_prev[m] (N)], h_prev = h at the previous scan step, 0 at the scan start
- *   slk_train_pack_xrh_f32: xrh[m] = [x[m] | r[m] * h_prev[m]] with zr[m] = [z | r] ([M][2N])
- *   then zr = sigmoid(xh . [iW[:2n] | sW]^T + b[:2n]) and c = tanh(xrh . [iW[2n:] | sW2]^T + b[2n:]) are plain
- *   slk_gemm_bias_act_f16x3 / slk_gemm_bias_act_f32 calls.
- * slk_gru_backward_f32: the reverse scan.  dy:[T][B] rows lddy apart = dL/dh from the layer above; writes
- *   da:[M][3n] = dL/dvI = [daz | dar | dac].  n in {16,32,48,64,96,112,128,144}, tanh / sigmoid, else SLK_ERR_UNSUPPORTED.
+ *   slk_train_pack_xrh_f32: xrh[m] = [x[m] | r[m] * h_prev[m]] with zr[m] = [z | r] ([M][2N]) (kept for callers that
+ *     want the candidate as a GEMM too: c = tanh(xrh . [iW[2n:] | sW2]^T + b[2n:]))
+ *   then zr = sigmoid(xh . [iW[:2n] | sW]^T + b[:2n]) is a plain slk_gemm_bias_act_f16x3 / slk_gemm_bias_act_f32 call.
+ * slk_gru_backward_f32: the reverse scan.  dy:[T][B] rows lddy apart = dL/dh from the layer above; h: the layer's own
+ *   forward output (rows ldh apart), from which the candidate of every step is recovered as (h_t - z h_prev) / (1 - z);
+ *   writes da:[M][3n] = dL/dvI = [daz | dar | dac] and rh:[M][n] = r * h_prev.  n in {16,32,48,64,96,112,128,144},
+ *   tanh / sigmoid, else SLK_ERR_UNSUPPORTED.
  *   Weight gradients follow as contractions over m (slk_gemm_tn_f32): diW = da^T x, dsW = da[:, :2n]^T h_prev,
- *   dsW2 = da[:, 2n:]^T (r*h_prev), db = da^T 1 (its colsum output); and dL/dx = da . iW (slk_gemm_bias_act_f32 with iW^T).
+ *   dsW2 = da[:, 2n:]^T rh, db = da^T 1 (its colsum output); and dL/dx = da . iW (slk_gemm_bias_act_f32 with iW^T).
  * slk_softmax_xent_grad_f32: loss terms and dL/dlogits of train_network.py:128-136, in place over the logits written by
  *   slk_linear_rowstats_* (stats:[M][2] = max, 1/sum).  loss_rows[m] and correct_rows[m] are already divided by the
  *   number of counted positions (T - 2 drop) * B, so their sums are the data term of the loss and the accuracy.
@@ -308,9 +310,9 @@ int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *e
 int slk_train_pack_xh_f32(const float *x, long ldx, const float *h, long ldh, float *xh, int T, int B, int insize, int n,
                           int reverse, slk_stream_t stream);
 int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *xrh, long M, int insize, int n, slk_stream_t stream);
-int slk_gru_backward_f32(const float *dy, long lddy, const float *xh, int insize, const float *zr, const float *c,
-                         const float *sW, const float *sW2, float *da, int T, int B, int n, int reverse, int act,
-                         int gate_act, slk_stream_t stream);
+int slk_gru_backward_f32(const float *dy, long lddy, const float *xh, int insize, const float *zr, const float *h, long ldh,
+                         const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n, int reverse,
+                         int act, int gate_act, slk_stream_t stream);
 int slk_softmax_xent_grad_f32(float *logits, long ld, const float *stats, const int32_t *labels, const float *weights, int T,
                               int B, int nstate, int drop, float min_prob, float *loss_rows, float *correct_rows,
                               slk_stream_t stream);

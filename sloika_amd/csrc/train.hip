@@ -7,8 +7,8 @@
 //   * the forward pass IS the inference path (conv kernel, gru_fused.hip, gemm_rows_f16x3.hip) -- nothing is saved
 //     inside the recurrent kernel.  What the reverse scan needs (gates z, r and candidate c of every step) is a
 //     function of (x_t, h_{t-1}) only, and every h_{t-1} is known once the forward scan has finished, so the gates of
-//     ALL steps are recomputed as two time-parallel GEMMs over packed rows [x_t | h_{t-1}] and [x_t | r*h_{t-1}]
-//     (slk_train_pack_xh_f32 / slk_train_pack_xrh_f32 + slk_gemm_bias_act_f16x3);
+//     ALL steps are recomputed time-parallel: [z r] as one GEMM over packed rows [x_t | h_{t-1}] (slk_train_pack_xh_f32 +
+//     slk_gemm_bias_act_f16x3), the candidate inside the reverse scan as c = (h_t - z h_{t-1}) / (1 - z);
 //   * the only sequential part is gru_backward_kernel: per step two dependent matrix-vector products with sW2^T and
 //     sW^T (float32 FMA, weights held in registers, one workgroup per chunk) producing the pre-activation gradients
 //     da = dL/d(vI) for every step;
@@ -118,12 +118,22 @@ extern "C" int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *x
 // (N/4 + 2N/4 floats) and produces a partial sum; the N "owner" threads (q = 0) do the element-wise part.  Operands of
 // the next step are loaded while the current one computes (their addresses do not depend on the recursion).
 // ---------------------------------------------------------------------------------------------------------------
+// The candidate c is not an operand: h_t = z h + (1-z) c gives c = (h_t - z h) / (1 - z) from the layer's own output.
+// Where z -> 1 the quotient is ill-conditioned, but c only enters through g (1-z) (1-c^2) and g (h-c) z (1-z), both
+// carrying the factor (1-z): with c clamped to tanh's range the error stays below g (1-z), i.e. negligible exactly there.
+__device__ __forceinline__ float gru_candidate(float h_t, float z, float h)
+{
+    const float omz = 1.0f - z;
+    return omz > 0.0f ? slk_clip((h_t - z * h) / omz, -1.0f, 1.0f) : 0.0f;
+}
+
 template <int N>
 __global__ void __launch_bounds__(4 * N) gru_backward_kernel(const float *__restrict__ dy, long lddy,
                                                              const float *__restrict__ xh, int I,
-                                                             const float *__restrict__ zr, const float *__restrict__ c,
-                                                             const float *__restrict__ sW, const float *__restrict__ sW2,
-                                                             float *__restrict__ da, int T, int B, int reverse)
+                                                             const float *__restrict__ zr, const float *__restrict__ hout,
+                                                             long ldh, const float *__restrict__ sW,
+                                                             const float *__restrict__ sW2, float *__restrict__ da,
+                                                             float *__restrict__ rh, int T, int B, int reverse)
 {
     constexpr int Q2 = N / 4, Q1 = 2 * N / 4;
     __shared__ float v_dac[N], v_dzr[2 * N], part[4][N];
@@ -144,14 +154,14 @@ __global__ void __launch_bounds__(4 * N) gru_backward_kernel(const float *__rest
         n_g = dy[m * lddy + i];
         n_z = zr[m * (2 * N) + i];
         n_r = zr[m * (2 * N) + N + i];
-        n_c = c[m * N + i];
+        n_c = hout[m * ldh + i];
         n_h = xh[m * ldxh + I + i];
     };
     if (owner) fetch(T - 1);
     for (int s = T - 1; s >= 0; s--) {
         float g = 0.f, z = 0.f, r = 0.f, cc = 0.f, h = 0.f, daz = 0.f;
         if (owner) {
-            g = n_g + carry; z = n_z; r = n_r; cc = n_c; h = n_h;
+            g = n_g + carry; z = n_z; r = n_r; h = n_h; cc = gru_candidate(n_c, z, h);
             if (s > 0) fetch(s - 1);
             const float dac = g * (1.0f - z) * (1.0f - cc * cc);
             daz = g * (h - cc) * z * (1.0f - z);
@@ -174,6 +184,7 @@ __global__ void __launch_bounds__(4 * N) gru_backward_kernel(const float *__rest
             const float dar = drh * h * r * (1.0f - r);
             v_dzr[N + i] = dar;
             da[row(s) * (3 * N) + N + i] = dar;
+            rh[row(s) * N + i] = r * h;
             keep = g * z + drh * r;
         }
         __syncthreads();
@@ -234,10 +245,10 @@ template <int N>
 __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const float *__restrict__ dy, long lddy,
                                                                       const float *__restrict__ xh, int I,
                                                                       const float *__restrict__ zr,
-                                                                      const float *__restrict__ c,
+                                                                      const float *__restrict__ hout, long ldh,
                                                                       const float *__restrict__ sW,
                                                                       const float *__restrict__ sW2, float *__restrict__ da,
-                                                                      int T, int B, int reverse)
+                                                                      float *__restrict__ rh, int T, int B, int reverse)
 {
     constexpr int CH = 2, KA = N / 16, KB = 2 * N / 16, D = 6;
     static_assert(5 * CH * (D - 1) <= 63, "vmcnt is a 6-bit counter");
@@ -258,7 +269,7 @@ __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const floa
             for (int ch = 0; ch < CH; ch++) {
                 const size_t mm = row(sp, min(b0 + ch, B - 1));
                 float *dst = &ring[sp % D][ch][0][0];
-                const float *src[5] = {dy + mm * lddy, zr + mm * (2 * N), zr + mm * (2 * N) + N, c + mm * N,
+                const float *src[5] = {dy + mm * lddy, zr + mm * (2 * N), zr + mm * (2 * N) + N, hout + mm * ldh,
                                        xh + mm * ldxh + I};
 #pragma unroll
                 for (int a = 0; a < 5; a++)
@@ -292,7 +303,7 @@ __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const floa
         if (owner) {
             const float *op = &ring[s % D][quad][0][0];
             g = op[i] + carry; z = op[N + i]; r = op[2 * N + i]; h = op[4 * N + i];
-            const float cc = op[3 * N + i];
+            const float cc = gru_candidate(op[3 * N + i], z, h);
             const float dac = g * (1.0f - z) * (1.0f - cc * cc);
             const float daz = g * (h - cc) * z * (1.0f - z);
             v_dac[par][quad][i] = dac;
@@ -332,7 +343,10 @@ __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const floa
                 const float mine = quad == 0 ? drh[0] : drh[CH - 1];
                 const float dar = mine * h * r * (1.0f - r);
                 v_dzr[par][quad][N + i] = dar;
-                if (GBWD_DIAG != 1) da[row(s, bq) * (3 * N) + N + i] = dar;
+                if (GBWD_DIAG != 1) {
+                    da[row(s, bq) * (3 * N) + N + i] = dar;
+                    rh[row(s, bq) * N + i] = r * h;
+                }
                 keep = g * z + mine * r;
             }
         }
@@ -357,30 +371,33 @@ __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const floa
 }
 
 template <int N>
-static int launch_gru_backward(const float *dy, long lddy, const float *xh, int I, const float *zr, const float *c,
-                               const float *sW, const float *sW2, float *da, int T, int B, int reverse, hipStream_t s)
+static int launch_gru_backward(const float *dy, long lddy, const float *xh, int I, const float *zr, const float *h, long ldh,
+                               const float *sW, const float *sW2, float *da, float *rh, int T, int B, int reverse,
+                               hipStream_t s)
 {
-    const bool aligned = lddy % 4 == 0 && I % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(xh) |
-                                                           reinterpret_cast<uintptr_t>(zr) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+    const bool aligned = lddy % 4 == 0 && I % 4 == 0 && ldh % 4 == 0 &&
+                         ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(xh) | reinterpret_cast<uintptr_t>(zr) |
+                           reinterpret_cast<uintptr_t>(h)) & 15) == 0;
     if (aligned)
-        hipLaunchKernelGGL((gru_backward_dma_kernel<N>), dim3((B + 1) / 2), dim3(4 * N + 64), 0, s, dy, lddy, xh, I, zr, c, sW,
-                           sW2, da, T, B, reverse);
+        hipLaunchKernelGGL((gru_backward_dma_kernel<N>), dim3((B + 1) / 2), dim3(4 * N + 64), 0, s, dy, lddy, xh, I, zr, h, ldh,
+                           sW, sW2, da, rh, T, B, reverse);
     else
-        hipLaunchKernelGGL((gru_backward_kernel<N>), dim3(B), dim3(4 * N), 0, s, dy, lddy, xh, I, zr, c, sW, sW2, da, T, B,
-                           reverse);
+        hipLaunchKernelGGL((gru_backward_kernel<N>), dim3(B), dim3(4 * N), 0, s, dy, lddy, xh, I, zr, h, ldh, sW, sW2, da, rh,
+                           T, B, reverse);
     return slk_launch_status();
 }
 
-extern "C" int slk_gru_backward_f32(const float *dy, long lddy, const float *xh, int insize, const float *zr, const float *c,
-                                    const float *sW, const float *sW2, float *da, int T, int B, int n, int reverse, int act,
-                                    int gate_act, slk_stream_t stream)
+extern "C" int slk_gru_backward_f32(const float *dy, long lddy, const float *xh, int insize, const float *zr, const float *h,
+                                    long ldh, const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n,
+                                    int reverse, int act, int gate_act, slk_stream_t stream)
 {
-    if (!dy || !xh || !zr || !c || !sW || !sW2 || !da || T < 1 || B < 1 || n < 1 || insize < 1 || lddy < n)
+    if (!dy || !xh || !zr || !h || !sW || !sW2 || !da || !rh || T < 1 || B < 1 || n < 1 || insize < 1 || lddy < n || ldh < n)
         return SLK_ERR_INVALID_ARG;
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
     hipStream_t s = slk_stream(stream);
     switch (n) {
-#define GRU_BWD_CASE(NN) case NN: return launch_gru_backward<NN>(dy, lddy, xh, insize, zr, c, sW, sW2, da, T, B, reverse, s)
+#define GRU_BWD_CASE(NN) \
+    case NN: return launch_gru_backward<NN>(dy, lddy, xh, insize, zr, h, ldh, sW, sW2, da, rh, T, B, reverse, s)
         GRU_BWD_CASE(16); GRU_BWD_CASE(32); GRU_BWD_CASE(48); GRU_BWD_CASE(64); GRU_BWD_CASE(96); GRU_BWD_CASE(112);
         GRU_BWD_CASE(128); GRU_BWD_CASE(144);
 #undef GRU_BWD_CASE

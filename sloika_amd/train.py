@@ -438,23 +438,20 @@ class TrainingStep(object):
         M, K = T * B, i_sz + n
         act, gact = activation.act_id(activation.tanh), activation.act_id(activation.sigmoid)
         dev = h.device
-        with profiler.region("train_gates", 6.0 * M * n * K, 4.0 * M * (3 * K + 3 * n), f16x3_flops=6.0 * M * n * K):
+        with profiler.region("train_gates", 4.0 * M * n * K, 4.0 * M * (2 * K + 2 * n), f16x3_flops=4.0 * M * n * K):
             xh = torch.empty((M, K), dtype=torch.float32, device=dev)
             _lib.check(L.slk_train_pack_xh_f32(xin.data_ptr(), layers._row_stride(xin), h.data_ptr(), layers._row_stride(h),
                                                xh.data_ptr(), T, B, i_sz, n, int(rev), st()), "pack_xh")
             zr = torch.empty((M, 2 * n), dtype=torch.float32, device=dev)
             self._gemm(xh.data_ptr(), K, torch.cat([iW[:2 * n], sW], 1).contiguous(), b[:2 * n].data_ptr(), zr.data_ptr(),
                        2 * n, M, K, 2 * n, gact)
-            xrh = torch.empty((M, K), dtype=torch.float32, device=dev)
-            _lib.check(L.slk_train_pack_xrh_f32(xh.data_ptr(), zr.data_ptr(), xrh.data_ptr(), M, i_sz, n, st()), "pack_xrh")
-            c = torch.empty((M, n), dtype=torch.float32, device=dev)
-            self._gemm(xrh.data_ptr(), K, torch.cat([iW[2 * n:], sW2], 1).contiguous(), b[2 * n:].data_ptr(), c.data_ptr(), n,
-                       M, K, n, act)
+        # the candidate is not recomputed by a GEMM: the scan recovers it from the layer's own output (csrc/train.hip)
         da = torch.empty((M, 3 * n), dtype=torch.float32, device=dev)
-        with profiler.region("train_gru_scan", 6.0 * M * n * n, 4.0 * M * 8 * n):
+        rh = torch.empty((M, n), dtype=torch.float32, device=dev)
+        with profiler.region("train_gru_scan", 6.0 * M * n * n, 4.0 * M * 9 * n):
             rc = L.slk_gru_backward_f32(dy.data_ptr(), layers._row_stride(dy), xh.data_ptr(), i_sz, zr.data_ptr(),
-                                        c.data_ptr(), sW.data_ptr(), sW2.data_ptr(), da.data_ptr(), T, B, n, int(rev), act,
-                                        gact, st())
+                                        h.data_ptr(), layers._row_stride(h), sW.data_ptr(), sW2.data_ptr(), da.data_ptr(),
+                                        rh.data_ptr(), T, B, n, int(rev), act, gact, st())
         if rc == _lib.SLK_ERR_UNSUPPORTED:
             raise NotImplementedError("training: no reverse-scan kernel for a Gru of size %d" % n)
         _lib.check(rc, "gru_backward")
@@ -463,7 +460,7 @@ class TrainingStep(object):
             self._tn(da.data_ptr(), 3 * n, xh.data_ptr(), K, giW.data_ptr(), i_sz, M, 3 * n, i_sz,
                      colsum=gb.data_ptr() if gb is not None else None)
             self._tn(da.data_ptr(), 3 * n, xh.data_ptr() + f4 * i_sz, K, gsW.data_ptr(), n, M, 2 * n, n)
-            self._tn(da.data_ptr() + f4 * 2 * n, 3 * n, xrh.data_ptr() + f4 * i_sz, K, gsW2.data_ptr(), n, M, n, n)
+            self._tn(da.data_ptr() + f4 * 2 * n, 3 * n, rh.data_ptr(), n, gsW2.data_ptr(), n, M, n, n)
         if not need_dx:
             return None
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)

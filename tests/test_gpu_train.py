@@ -241,8 +241,9 @@ def test_argument_validation():
 @pytest.mark.parametrize("n,reverse", [(96, 0), (32, 1), (144, 1)])
 def test_gru_backward_kernels_agree(n, reverse):
     """The reverse scan has two kernels: operands through an LDS-DMA loader wave (16-byte aligned rows) and a plain one
-    (any alignment).  Same inputs, dy once aligned and once shifted by one float: identical pre-activation gradients, and
-    both equal the float64 recursion of oracle_train._backward's GRU step."""
+    (any alignment).  Same inputs, dy once aligned and once shifted by one float: the same pre-activation gradients, and
+    both equal the float64 recursion of oracle_train._backward's GRU step (the candidate c is handed over implicitly,
+    through the layer output h_t = z h + (1-z) c)."""
     torch = need_gpu()
     from sloika_amd import _lib
     L = _lib.lib()
@@ -269,21 +270,26 @@ def test_gru_backward_kernels_agree(n, reverse):
         dar = drh * h * r * (1 - r)
         carry = g * z + drh * r + np.concatenate([daz, dar], 1) @ sW
         want[rows] = np.concatenate([daz, dar, dac], 1)
-    d = {k: dev(v) for k, v in dict(xh=xh, zr=zr, c=c, sW=sW, sW2=sW2).items()}
+    # the kernels take the layer's forward output h_t = z h + (1-z) c and recover the candidate from it
+    hout = (zr[:, :n] * xh[:, I:] + (1.0 - zr[:, :n]) * c).astype(np.float32)
+    d = {k: dev(v) for k, v in dict(xh=xh, zr=zr, hout=hout, sW=sW, sW2=sW2).items()}
     outs = []
     for shift in (0, 1):
         buf = torch.zeros(M * n + 4, dtype=torch.float32, device="cuda")
         buf[shift:shift + M * n] = dev(dy).reshape(-1)
         da = torch.empty((M, 3 * n), dtype=torch.float32, device="cuda")
-        rc = L.slk_gru_backward_f32(buf.data_ptr() + 4 * shift, n, d["xh"].data_ptr(), I, d["zr"].data_ptr(), d["c"].data_ptr(),
-                                    d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), T, B, n, reverse, 1, 2, stream())
+        rh = torch.empty((M, n), dtype=torch.float32, device="cuda")
+        rc = L.slk_gru_backward_f32(buf.data_ptr() + 4 * shift, n, d["xh"].data_ptr(), I, d["zr"].data_ptr(), d["hout"].data_ptr(),
+                                    n, d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), rh.data_ptr(), T, B, n, reverse,
+                                    1, 2, stream())
         assert rc == 0
         outs.append(da.cpu().numpy())
+        np.testing.assert_array_equal(rh.cpu().numpy(), zr[:, n:] * xh[:, I:])
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-4, atol=1e-5 * np.abs(want).max())     # different summation orders
     np.testing.assert_allclose(outs[0], want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
-    assert L.slk_gru_backward_f32(d["xh"].data_ptr(), 160, d["xh"].data_ptr(), I, d["zr"].data_ptr(), d["c"].data_ptr(),
-                                  d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), T, B, 40, reverse, 1, 2,
-                                  stream()) == _lib.SLK_ERR_UNSUPPORTED
+    assert L.slk_gru_backward_f32(d["xh"].data_ptr(), 160, d["xh"].data_ptr(), I, d["zr"].data_ptr(), d["hout"].data_ptr(), 160,
+                                  d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), rh.data_ptr(), T, B, 40, reverse, 1,
+                                  2, stream()) == _lib.SLK_ERR_UNSUPPORTED
 
 
 def test_train_loop_end_to_end(tmp_path):
