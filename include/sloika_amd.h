@@ -313,6 +313,17 @@ int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *xrh, long M,
 int slk_gru_backward_f32(const float *dy, long lddy, const float *xh, int insize, const float *zr, const float *h, long ldh,
                          const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n, int reverse,
                          int act, int gate_act, slk_stream_t stream);
+/* Lstm (layers.py:677-697) in the reverse pass.  sum:[M][4n] = [x_t | out_{t-1}] . [iW | sW]^T + b (a GEMM over
+ * slk_train_pack_xh_f32 rows), gate rows interleaved j*4 + gate as the reference stores them.
+ *   slk_lstm_gates_f32: the element-wise cell recursion -> gates:[M][4n] = (candidate, input, forget, output) activated,
+ *     cell:[M][n] = c_t.   peep:[3][n] or NULL.
+ *   slk_lstm_backward_f32: the reverse scan -> dsum:[M][4n] = dL/dsum, dpeep:[B][3][n] per-chunk peephole gradients.
+ *     n in {16,32,48,64,96,128}, tanh / sigmoid.  Then diW = dsum^T x, dsW = dsum^T out_prev, db = dsum^T 1, dx = dsum . iW. */
+int slk_lstm_gates_f32(const float *sum, const float *peep, float *gates, float *cell, int T, int B, int n, int reverse,
+                       slk_stream_t stream);
+int slk_lstm_backward_f32(const float *dy, long lddy, const float *gates, const float *cell, const float *sW, const float *peep,
+                          float *dsum, float *dpeep, int T, int B, int n, int reverse, int act, int gate_act,
+                          slk_stream_t stream);
 int slk_softmax_xent_grad_f32(float *logits, long ld, const float *stats, const int32_t *labels, const float *weights, int T,
                               int B, int nstate, int drop, float min_prob, float *loss_rows, float *correct_rows,
                               slk_stream_t stream);

@@ -9,7 +9,8 @@ What is restated, and from where:
         acc   = mean((argmax(post, axis=2) == labels)[drop : -drop])
   * the gradient th.grad(loss, network.params()) (sloika/updates.py:66) -- the reference gets it from Theano's
     automatic differentiation; here it is the hand-derived reverse pass of the layer formulas restated in
-    oracle/oracle_np.py (Convolution layers.py:417-419, Gru.step layers.py:1010-1021, Softmax layers.py:309-314,
+    oracle/oracle_np.py (Convolution layers.py:417-419, Gru.step layers.py:1010-1021, Lstm.step layers.py:677-697,
+    Softmax layers.py:309-314,
     FeedForward layers.py:157-158, Window layers.py:346-351, Reverse layers.py:1449-1450, Parallel layers.py:1486-1487, Serial layers.py:1500-1504);
   * the "ADAMski" update sloika/updates.py:36-89 (float32 arithmetic like the reference's shared variables), `sgd`
     updates.py:9-33 and `param_sqr` updates.py:92-103.
@@ -51,6 +52,8 @@ def params_of(spec):
         return [p for sub in spec["sublayers"] for p in params_of(sub)]
     if t == "GRU":
         return [spec[k] for k in ("iW", "sW", "sW2", "b") if spec.get(k) is not None]
+    if t == "LSTM":                                                # layers.py Lstm.params(): iW, sW, b, p
+        return [spec[k] for k in ("iW", "sW", "b", "p") if spec.get(k) is not None]
     if t in ("convolution", "softmax", "feed-forward"):
         return [spec[k] for k in ("W", "b") if spec.get(k) is not None]
     if t == "window":
@@ -118,6 +121,28 @@ def _forward(spec, x):
             h = z * h + (1 - z) * c
             out[s] = h
         return out, (x, tape)
+    if t == "LSTM":                                                # layers.py:677-697 (gate rows interleaved: j*4 + gate)
+        iW, sW = np.asarray(spec["iW"], f64), np.asarray(spec["sW"], f64)
+        n = sW.shape[1]
+        b = np.zeros(4 * n) if spec.get("b") is None else np.asarray(spec["b"], f64)
+        pp = np.zeros((3, n)) if spec.get("p") is None else np.asarray(spec["p"], f64)
+        T, B, _ = x.shape
+        out, cell = np.zeros((B, n)), np.zeros((B, n))
+        outs = np.empty((T, B, n))
+        tape = []
+        for s in range(T):
+            sm = (x[s] @ iW.T + out @ sW.T + b).reshape((-1, n, 4))
+            g = onp.ACT[spec["activation"]](sm[:, :, 0])
+            a_i, a_f = sm[:, :, 1] + cell * pp[0], sm[:, :, 2] + cell * pp[1]
+            i, f = onp.ACT[spec["gate"]](a_i), onp.ACT[spec["gate"]](a_f)
+            cn = cell * f + g * i
+            a_o = sm[:, :, 3] + cn * pp[2]
+            o = onp.ACT[spec["gate"]](a_o)
+            tc = onp.ACT[spec["activation"]](cn)
+            tape.append((out, cell, cn, g, i, f, o, tc, sm[:, :, 0], a_i, a_f, a_o))
+            out, cell = tc * o, cn
+            outs[s] = out
+        return outs, (x, tape)
     raise ValueError("oracle_train: unsupported layer type %r" % t)
 
 
@@ -194,6 +219,33 @@ def _backward(spec, tape, dy):
             dx[s] = da @ iW
         g = [diW, dsW, dsW2] + ([db] if spec.get("b") is not None else [])
         return dx, g
+    if t == "LSTM":
+        x, steps = tape
+        iW, sW = np.asarray(spec["iW"], f64), np.asarray(spec["sW"], f64)
+        n = sW.shape[1]
+        pp = np.zeros((3, n)) if spec.get("p") is None else np.asarray(spec["p"], f64)
+        T, B, _ = x.shape
+        diW, dsW, db, dp = np.zeros_like(iW), np.zeros_like(sW), np.zeros(4 * n), np.zeros((3, n))
+        dx = np.empty_like(x)
+        d_out, d_cell = np.zeros((B, n)), np.zeros((B, n))
+        for s in range(T - 1, -1, -1):
+            out_prev, c_prev, cn, g, i, f, o, tc, a_g, a_i, a_f, a_o = steps[s]
+            go = dy[s] + d_out
+            do_pre = go * tc * _dact(spec["gate"], o, a_o)
+            dc = go * o * _dact(spec["activation"], tc, cn) + do_pre * pp[2] + d_cell
+            di_pre = dc * g * _dact(spec["gate"], i, a_i)
+            df_pre = dc * c_prev * _dact(spec["gate"], f, a_f)
+            dg_pre = dc * i * _dact(spec["activation"], g, a_g)
+            d_cell = dc * f + di_pre * pp[0] + df_pre * pp[1]
+            dsum = np.stack([dg_pre, di_pre, df_pre, do_pre], axis=2).reshape(B, 4 * n)      # rows j*4 + gate
+            d_out = dsum @ sW
+            diW += dsum.T @ x[s]
+            dsW += dsum.T @ out_prev
+            db += dsum.sum(axis=0)
+            dp += np.stack([(di_pre * c_prev).sum(0), (df_pre * c_prev).sum(0), (do_pre * cn).sum(0)])
+            dx[s] = dsum @ iW
+        g_list = [diW, dsW] + ([db] if spec.get("b") is not None else []) + ([dp] if spec.get("p") is not None else [])
+        return dx, g_list
     raise ValueError("oracle_train: unsupported layer type %r" % t)
 
 

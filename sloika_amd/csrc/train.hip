@@ -406,6 +406,134 @@ extern "C" int slk_gru_backward_f32(const float *dy, long lddy, const float *xh,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Lstm (layers.py:677-697; gate rows interleaved, row j*4 + gate: 0 candidate, 1 input, 2 forget, 3 output; peepholes p).
+// The forward kernels keep only the layer output.  Every out_{t-1} is known after the forward pass, so the summed gate
+// inputs of ALL steps are one time-parallel GEMM over [x_t | out_{t-1}]; what remains sequential is the cell recursion
+// c_t = c_{t-1} f + g i through the peepholes, which is element-wise: lstm_gates_kernel scans it with one thread per
+// (chunk, neuron) and leaves the activated gates and the cell states for the reverse scan.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) lstm_gates_kernel(const float *__restrict__ sum, const float *__restrict__ peep,
+                                                         float *__restrict__ gates, float *__restrict__ cell, int T, int B,
+                                                         int n, int reverse)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * n) return;
+    const int b = idx / n, j = idx - b * n;
+    const float p0 = peep ? peep[j] : 0.0f, p1 = peep ? peep[n + j] : 0.0f, p2 = peep ? peep[2 * n + j] : 0.0f;
+    float c = 0.0f;
+#pragma unroll 4
+    for (int s = 0; s < T; s++) {
+        const size_t m = (size_t)(reverse ? T - 1 - s : s) * B + b;
+        const float4 v = *reinterpret_cast<const float4 *>(sum + m * (4 * (size_t)n) + 4 * j);
+        const float g = slk_tanh(v.x);
+        const float i = slk_sigmoid(v.y + c * p0);                                   // layers.py:688
+        const float f = slk_sigmoid(v.z + c * p1);                                   // layers.py:686
+        const float cn = c * f + g * i;
+        const float o = slk_sigmoid(v.w + cn * p2);                                  // layers.py:690
+        *reinterpret_cast<float4 *>(gates + m * (4 * (size_t)n) + 4 * j) = make_float4(g, i, f, o);
+        cell[m * n + j] = cn;
+        c = cn;
+    }
+}
+
+extern "C" int slk_lstm_gates_f32(const float *sum, const float *peep, float *gates, float *cell, int T, int B, int n,
+                                  int reverse, slk_stream_t stream)
+{
+    if (!sum || !gates || !cell || T < 1 || B < 1 || n < 1) return SLK_ERR_INVALID_ARG;
+    if (((reinterpret_cast<uintptr_t>(sum) | reinterpret_cast<uintptr_t>(gates)) & 15) != 0) return SLK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(lstm_gates_kernel, dim3((unsigned)(((size_t)B * n + 255) / 256)), dim3(256), 0, slk_stream(stream), sum,
+                       peep, gates, cell, T, B, n, reverse);
+    return slk_launch_status();
+}
+
+// Reverse scan of one Lstm layer.  With go = dL/dout_t + carry_out, tc = tanh(c_t):
+//     do' = go tc o(1-o) ; dc = go o (1-tc^2) + do' p2 + carry_c ; di' = dc g i(1-i) ; df' = dc c_{t-1} f(1-f)
+//     dg' = dc i (1-g^2) ; carry_c = dc f + di' p0 + df' p1 ; carry_out = [dg' di' df' do'] . sW   (one 4n -> n product)
+// dsum:[M][4n] (interleaved like the gates) is dL/d(summed gate inputs); dpeep:[B][3][n] the per-chunk peephole
+// gradients (summed over chunks by the caller).  One workgroup per chunk, 4n threads, thread (k, quarter) holds column k
+// of one quarter of sW's rows in registers; the n owner threads (quarter 0) do the element-wise part.
+template <int N>
+__global__ void __launch_bounds__(4 * N) lstm_backward_kernel(const float *__restrict__ dy, long lddy,
+                                                              const float *__restrict__ gates, const float *__restrict__ cell,
+                                                              const float *__restrict__ sW, const float *__restrict__ peep,
+                                                              float *__restrict__ dsum, float *__restrict__ dpeep, int T, int B,
+                                                              int reverse)
+{
+    __shared__ __attribute__((aligned(16))) float v[4 * N];
+    __shared__ float part[4][N];
+    const int tid = threadIdx.x, i = tid % N, q = tid / N, b = blockIdx.x;
+    const bool owner = q == 0;
+    float w[N];
+#pragma unroll
+    for (int r = 0; r < N; r++) w[r] = sW[(size_t)(q * N + r) * N + i];              // carry_out[i] = sum_r dsum[r] sW[r][i]
+    const float p0 = peep ? peep[i] : 0.0f, p1 = peep ? peep[N + i] : 0.0f, p2 = peep ? peep[2 * N + i] : 0.0f;
+    auto row = [&](int s) { return (size_t)(reverse ? T - 1 - s : s) * B + b; };
+    float carry_out = 0.0f, carry_c = 0.0f, ap0 = 0.0f, ap1 = 0.0f, ap2 = 0.0f;
+    float n_go = 0.f, n_cn = 0.f, n_cp = 0.f;
+    float4 n_gt = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](int s) {
+        const size_t m = row(s);
+        n_go = dy[m * lddy + i];
+        n_gt = *reinterpret_cast<const float4 *>(gates + m * (4 * N) + 4 * i);
+        n_cn = cell[m * N + i];
+        n_cp = s > 0 ? cell[row(s - 1) * N + i] : 0.0f;
+    };
+    if (owner) fetch(T - 1);
+    for (int s = T - 1; s >= 0; s--) {
+        if (owner) {
+            const float go = n_go + carry_out, g = n_gt.x, ig = n_gt.y, f = n_gt.z, o = n_gt.w, cn = n_cn, cp = n_cp;
+            const size_t m = row(s);
+            if (s > 0) fetch(s - 1);
+            const float tc = slk_tanh(cn);
+            const float do_pre = go * tc * o * (1.0f - o);
+            const float dc = go * o * (1.0f - tc * tc) + do_pre * p2 + carry_c;
+            const float di_pre = dc * g * ig * (1.0f - ig);
+            const float df_pre = dc * cp * f * (1.0f - f);
+            const float dg_pre = dc * ig * (1.0f - g * g);
+            carry_c = dc * f + di_pre * p0 + df_pre * p1;
+            ap0 += di_pre * cp; ap1 += df_pre * cp; ap2 += do_pre * cn;
+            const float4 d4 = make_float4(dg_pre, di_pre, df_pre, do_pre);
+            *reinterpret_cast<float4 *>(&v[4 * i]) = d4;
+            *reinterpret_cast<float4 *>(dsum + m * (4 * N) + 4 * i) = d4;
+        }
+        __syncthreads();
+        {
+            float acc = 0.0f;
+#pragma unroll
+            for (int r = 0; r < N; r++) acc = fmaf(v[q * N + r], w[r], acc);
+            part[q][i] = acc;
+        }
+        __syncthreads();
+        if (owner) carry_out = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+    }
+    if (owner) {
+        dpeep[((size_t)b * 3 + 0) * N + i] = ap0;
+        dpeep[((size_t)b * 3 + 1) * N + i] = ap1;
+        dpeep[((size_t)b * 3 + 2) * N + i] = ap2;
+    }
+}
+
+extern "C" int slk_lstm_backward_f32(const float *dy, long lddy, const float *gates, const float *cell, const float *sW,
+                                     const float *peep, float *dsum, float *dpeep, int T, int B, int n, int reverse, int act,
+                                     int gate_act, slk_stream_t stream)
+{
+    if (!dy || !gates || !cell || !sW || !dsum || !dpeep || T < 1 || B < 1 || n < 1 || lddy < n) return SLK_ERR_INVALID_ARG;
+    if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
+    if (((reinterpret_cast<uintptr_t>(gates) | reinterpret_cast<uintptr_t>(dsum)) & 15) != 0) return SLK_ERR_INVALID_ARG;
+    hipStream_t s = slk_stream(stream);
+    switch (n) {
+#define LSTM_BWD_CASE(NN)                                                                                                  \
+    case NN:                                                                                                               \
+        hipLaunchKernelGGL((lstm_backward_kernel<NN>), dim3(B), dim3(4 * NN), 0, s, dy, lddy, gates, cell, sW, peep, dsum,   \
+                           dpeep, T, B, reverse);                                                                          \
+        return slk_launch_status()
+        LSTM_BWD_CASE(16); LSTM_BWD_CASE(32); LSTM_BWD_CASE(48); LSTM_BWD_CASE(64); LSTM_BWD_CASE(96); LSTM_BWD_CASE(128);
+#undef LSTM_BWD_CASE
+    default: return SLK_ERR_UNSUPPORTED;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Loss of train_network.py:128-136 and its gradient with respect to the logits, in place.  One wave per row (t, b):
 //     p = exp(l - max) * inv_sum ; post = min_prob + (1 - min_prob) p ; row loss = -w log(post[label]) / count
 //     dl_j = (w / count) (1 - min_prob) p[label] / post[label] * (p_j - [j == label])

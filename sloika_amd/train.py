@@ -6,10 +6,10 @@ like the Theano function the reference compiles.  Device side: csrc/train.hip (r
 contractions for the weight gradients, softmax cross-entropy, the optimiser) on top of the inference kernels, which
 ARE the forward pass.  There is no CPU fallback.
 
-Supported networks: a Serial that ends in Softmax and is built from Convolution(insize=1) or Window as the first layer, Gru,
+Supported networks: a Serial that ends in Softmax and is built from Convolution(insize=1) or Window as the first layer, Gru, Lstm,
 FeedForward, Reverse, Parallel (so `birnn`) and nested Serial -- the raw-signal models models/raw_0.98_rgrgr.py,
 baseline_raw_gru.py, bigger_raw_gru.py, raw_1.00_rGr.py (its 110/142-wide layers run zero-padded) and the event-feature
-models baseline_gru.py / tiny_gru.py; anything else (Lstm, multi-feature Convolution, Gru wider than 144) raises NotImplementedError: the reference differentiates any layer through Theano, only the
+models baseline_gru.py / tiny_gru.py / baseline_lstm.py; anything else (multi-feature Convolution, Gru wider than 144) raises NotImplementedError: the reference differentiates any layer through Theano, only the
 raw-signal GRU path is accelerated here.
 
 Data parallel (BASELINE.json configs[4]): with torch.distributed initialised (backend "nccl" = RCCL over xGMI) every
@@ -113,13 +113,18 @@ def _validate(layer, first, rev=False, where="network"):
             raise NotImplementedError("training: Gru layers with fun=tanh, gatefun=sigmoid only")
         if (layer.size + 15) // 16 * 16 not in (16, 32, 48, 64, 96, 112, 128, 144):
             raise NotImplementedError("training: no reverse-scan kernel for a Gru of size %d" % layer.size)
+    elif isinstance(layer, layers.Lstm):
+        if activation.act_name(layer.fun) != "tanh" or activation.act_name(layer.gatefun) != "sigmoid":
+            raise NotImplementedError("training: Lstm layers with fun=tanh, gatefun=sigmoid only")
+        if layer.size not in (16, 32, 48, 64, 96, 128):
+            raise NotImplementedError("training: no reverse-scan kernel for an Lstm of size %d" % layer.size)
     elif isinstance(layer, layers.FeedForward):
         if activation.act_name(layer.fun) not in _FF_ACTS:
             raise NotImplementedError("training: FeedForward activation %s has no derivative kernel" % layer.fun.__name__)
     else:
         raise NotImplementedError(
-            "training on the GPU path covers Convolution(insize=1) or Window first, Gru, FeedForward, Reverse, Parallel, Serial "
-            "and a final Softmax; %s (%s) is outside it" % (name, where))
+            "training on the GPU path covers Convolution(insize=1) or Window first, Gru, Lstm, FeedForward, Reverse, Parallel, "
+            "Serial and a final Softmax; %s (%s) is outside it" % (name, where))
 
 
 def _plan(network):
@@ -317,13 +322,13 @@ class TrainingStep(object):
             return x, ("serial", tapes)
         if isinstance(layer, layers.Parallel):
             subs = [_unwrap(sub, rev) for sub in layer.layers]
-            if all(isinstance(sub, (layers.Gru, layers.FeedForward)) for sub, _ in subs):
+            if all(isinstance(sub, (layers.Gru, layers.Lstm, layers.FeedForward)) for sub, _ in subs):
                 # the sub-layers write their slices of the concatenated output directly (and run side by side on their
                 # own streams at small batches): their outputs are strided views of it
                 y = layer._forward(x, None, rev)
                 tapes, off = [], 0
                 for sub, srev in subs:
-                    kind = "gru" if isinstance(sub, layers.Gru) else "ff"
+                    kind = "gru" if isinstance(sub, layers.Gru) else "lstm" if isinstance(sub, layers.Lstm) else "ff"
                     tapes.append((kind, sub, srev, x, y[:, :, off:off + sub.size]))
                     off += sub.size
                 return y, ("parallel", tapes, [sub.size for sub, _ in subs])
@@ -334,7 +339,7 @@ class TrainingStep(object):
                 tapes.append(tp)
             return torch.cat(outs, dim=2), ("parallel", tapes, [int(o.shape[2]) for o in outs])
         kind = ("conv" if isinstance(layer, layers.Convolution) else "gru" if isinstance(layer, layers.Gru) else
-                "window" if isinstance(layer, layers.Window) else "ff")
+                "lstm" if isinstance(layer, layers.Lstm) else "window" if isinstance(layer, layers.Window) else "ff")
         x = layers._check_input(x, layer.insize)
         y = layer._forward(x, None, rev)
         return y, (kind, layer, rev, x, y)
@@ -363,6 +368,8 @@ class TrainingStep(object):
         _, layer, rev, xin, y = tape
         if kind == "gru":
             return self._gru_backward(layer, rev, xin, y, dy, need_dx)
+        if kind == "lstm":
+            return self._lstm_backward(layer, rev, xin, y, dy, need_dx)
         if kind == "ff":
             return self._ff_backward(layer, xin, y, dy, need_dx)
         if kind == "window":                            # first layer, no parameters: nothing to do
@@ -467,6 +474,53 @@ class TrainingStep(object):
         with profiler.region("train_dx", 6.0 * M * n * i_sz, 4.0 * M * (3 * n + i_sz)):
             _lib.check(L.slk_gemm_bias_act_f32(da.data_ptr(), 3 * n, iW.t().contiguous().data_ptr(), None, dx.data_ptr(), i_sz,
                                                M, 3 * n, i_sz, 0, st()), "gru dx")
+        return dx
+
+    def _lstm_backward(self, layer, rev, xin, out, dy, need_dx):
+        """Reverse pass of one Lstm layer (layers.py:677-697): gate inputs of all steps as one GEMM over [x_t | out_{t-1}],
+        the element-wise cell recursion, the reverse scan, then the weight gradients as contractions over all rows."""
+        import torch
+        L = _lib.lib()
+        st = layers._stream
+        T, B, n, i_sz = int(out.shape[0]), int(out.shape[1]), layer.size, layer.insize
+        M, K = T * B, layer.insize + layer.size
+        act, gact = activation.act_id(layer.fun), activation.act_id(layer.gatefun)
+        dev = out.device
+        iW, sW, b = layer.iW.dev(), layer.sW.dev(), layer.b.dev()
+        peep = layer.p.dev().data_ptr() if layer.has_peep else None
+        with profiler.region("train_gates", 8.0 * M * n * K, 4.0 * M * (K + 8 * n)):
+            xh = torch.empty((M, K), dtype=torch.float32, device=dev)
+            _lib.check(L.slk_train_pack_xh_f32(xin.data_ptr(), layers._row_stride(xin), out.data_ptr(), layers._row_stride(out),
+                                               xh.data_ptr(), T, B, i_sz, n, int(rev), st()), "pack_xh")
+            summed = torch.empty((M, 4 * n), dtype=torch.float32, device=dev)
+            self._gemm(xh.data_ptr(), K, torch.cat([iW, sW], 1).contiguous(), b.data_ptr(), summed.data_ptr(), 4 * n, M, K,
+                       4 * n, 0)
+            gates = torch.empty((M, 4 * n), dtype=torch.float32, device=dev)
+            cell = torch.empty((M, n), dtype=torch.float32, device=dev)
+            _lib.check(L.slk_lstm_gates_f32(summed.data_ptr(), peep, gates.data_ptr(), cell.data_ptr(), T, B, n, int(rev),
+                                            st()), "lstm_gates")
+        dsum = summed                                                            # reuse: the sums are not needed again
+        dpeep = torch.empty((B, 3 * n), dtype=torch.float32, device=dev)
+        with profiler.region("train_lstm_scan", 8.0 * M * n * n, 4.0 * M * 10 * n):
+            rc = L.slk_lstm_backward_f32(dy.data_ptr(), layers._row_stride(dy), gates.data_ptr(), cell.data_ptr(), sW.data_ptr(),
+                                         peep, dsum.data_ptr(), dpeep.data_ptr(), T, B, n, int(rev), act, gact, st())
+        if rc == _lib.SLK_ERR_UNSUPPORTED:
+            raise NotImplementedError("training: no reverse-scan kernel for an Lstm of size %d" % n)
+        _lib.check(rc, "lstm_backward")
+        with profiler.region("train_wgrad", 8.0 * M * n * K, 4.0 * M * (4 * n + K)):
+            self._tn(dsum.data_ptr(), 4 * n, xh.data_ptr(), K, self._grad_of(layer.iW).data_ptr(), i_sz, M, 4 * n, i_sz,
+                     colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
+            self._tn(dsum.data_ptr(), 4 * n, xh.data_ptr() + 4 * i_sz, K, self._grad_of(layer.sW).data_ptr(), n, M, 4 * n, n)
+            if layer.has_peep:                        # sum of the per-chunk peephole gradients: the column sums of dpeep
+                scratch = torch.empty(3 * n, dtype=torch.float32, device=dev)
+                self._tn(dpeep.data_ptr(), 3 * n, dpeep.data_ptr(), 3 * n, scratch.data_ptr(), 1, B, 3 * n, 1,
+                         colsum=self._grad_of(layer.p).data_ptr())
+        if not need_dx:
+            return None
+        dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
+        with profiler.region("train_dx", 8.0 * M * n * i_sz, 4.0 * M * (4 * n + i_sz)):
+            _lib.check(L.slk_gemm_bias_act_f32(dsum.data_ptr(), 4 * n, iW.t().contiguous().data_ptr(), None, dx.data_ptr(), i_sz,
+                                               M, 4 * n, i_sz, 0, st()), "lstm dx")
         return dx
 
     def _conv_backward(self, layer, xin, y, dy):

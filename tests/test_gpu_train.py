@@ -70,12 +70,12 @@ def test_loss_and_gradients_vs_oracle(n, nstate, T, B, min_prob, l2, drop, bias)
 
 
 @pytest.mark.parametrize("model,T,B", [("baseline_raw_gru", 120, 3), ("bigger_raw_gru", 90, 2), ("raw_1.00_rGr", 80, 3),
-                                       ("baseline_gru", 45, 3), ("tiny_gru", 30, 5)])
+                                       ("baseline_gru", 45, 3), ("tiny_gru", 30, 5), ("baseline_lstm", 40, 3)])
 def test_birnn_feedforward_models_vs_oracle(model, T, B):
     """models/baseline_raw_gru.py and bigger_raw_gru.py: convolution, then birnn (Parallel of a Gru and a reversed Gru,
     their outputs strided slices of one tensor) and FeedForward layers alternating; raw_1.00_rGr.py: 110- and 142-wide Gru
     layers, run zero-padded to 112 / 144; baseline_gru.py / tiny_gru.py: event features through a Window, Gru layers with 12
-    inputs and (tiny) 4 neurons, zero-padded.  Gradients of every parameter."""
+    inputs and (tiny) 4 neurons, zero-padded; baseline_lstm.py: birnn of peephole Lstm cells.  Gradients of every parameter."""
     need_gpu()
     from oracle import oracle_train as ot
     from sloika_amd import models, train
@@ -108,6 +108,31 @@ def test_nested_serial_in_parallel_vs_oracle():
     spec["sublayers"][2]["b"] = None
     want_loss, want_acc, want = ot.loss_and_grads(spec, x, labels, weights, 0.0, 0.0, 0)
     step = train.TrainingStep(net)
+    loss, acc = step.forward_backward(x, labels, weights)
+    assert loss == pytest.approx(want_loss, rel=2e-5) and acc == pytest.approx(want_acc, abs=1e-6)
+    _assert_grads_close(step.gradients(), want)
+
+
+@pytest.mark.parametrize("n,bias,peep,T,B", [(32, True, True, 33, 4), (16, False, False, 20, 2), (96, True, True, 25, 3)])
+def test_lstm_stack_vs_oracle(n, bias, peep, T, B):
+    """Lstm layers in both directions, with and without biases / peepholes, outside a Parallel (dense outputs)."""
+    need_gpu()
+    from oracle import oracle_train as ot
+    from sloika_amd import layers, train
+    rs = np.random.RandomState(n + T)
+    init = lambda shape: (rs.normal(size=shape) * 0.5).astype(np.float32)
+    net = layers.Serial([layers.Lstm(8, n, init=init, has_bias=bias, has_peep=peep),
+                         layers.Reverse(layers.Lstm(n, n, init=init, has_bias=bias, has_peep=peep)),
+                         layers.Softmax(n, 11, init=init, has_bias=True)])
+    x, labels, weights = _batch(rs, net, T, B, nfeat=8)
+    spec = net.spec()
+    for sub in (spec["sublayers"][0], spec["sublayers"][1]["sublayer"]):
+        if not bias:
+            sub["b"] = None
+        if not peep:
+            sub["p"] = None
+    want_loss, want_acc, want = ot.loss_and_grads(spec, x, labels, weights, 1e-6, 0.0, 1)
+    step = train.TrainingStep(net, min_prob=1e-6, drop=1)
     loss, acc = step.forward_backward(x, labels, weights)
     assert loss == pytest.approx(want_loss, rel=2e-5) and acc == pytest.approx(want_acc, abs=1e-6)
     _assert_grads_close(step.gradients(), want)

@@ -79,6 +79,41 @@ def test_window_network_gradients():
             assert g.reshape(-1)[idx] == pytest.approx((up - dn) / (2 * eps), rel=2e-5, abs=1e-8)
 
 
+@pytest.mark.parametrize("bias,peep", [(True, True), (False, False)])
+def test_lstm_network_gradients(bias, peep):
+    """models/baseline_lstm.py's structure in small: Window, birnn of peephole Lstm cells, FeedForward, Softmax."""
+    rs = np.random.RandomState(21)
+    r = lambda *shape: rs.normal(size=shape) * 0.5
+    n = 4
+    lstm = lambda i: {"type": "LSTM", "iW": r(4 * n, i), "sW": r(4 * n, n), "b": r(4 * n) if bias else None,
+                      "p": r(3, n) if peep else None, "activation": "tanh", "gate": "sigmoid"}
+    spec = {"type": "serial", "sublayers": [
+        {"type": "window", "w": 3},
+        {"type": "parallel", "sublayers": [lstm(6), {"type": "reverse", "sublayer": lstm(6)}]},
+        {"type": "feed-forward", "W": r(n, 2 * n), "b": r(n), "activation": "tanh"},
+        {"type": "reverse", "sublayer": lstm(n)},
+        {"type": "softmax", "W": r(5, n), "b": r(5)}]}
+    x = rs.normal(size=(14, 3, 2))
+    labels = rs.randint(0, 5, size=(14, 3))
+    weights = rs.uniform(0.5, 1.5, size=(14, 3))
+    loss, acc, grads = ot.loss_and_grads(spec, x, labels, weights, 1e-4, 0.0, 1)
+    assert loss == pytest.approx(ot.loss_only(spec, x, labels, weights, 1e-4, 0.0, 1)[0], rel=1e-12)
+    params = ot.params_of(spec)
+    assert len(params) == len(grads)
+    eps = 1e-6
+    for p, g in zip(params, grads):
+        assert np.shape(p) == g.shape
+        flat = p.reshape(-1)
+        for idx in rs.choice(flat.size, size=min(6, flat.size), replace=False):
+            keep = flat[idx]
+            flat[idx] = keep + eps
+            up, _ = ot.loss_only(spec, x, labels, weights, 1e-4, 0.0, 1)
+            flat[idx] = keep - eps
+            dn, _ = ot.loss_only(spec, x, labels, weights, 1e-4, 0.0, 1)
+            flat[idx] = keep
+            assert g.reshape(-1)[idx] == pytest.approx((up - dn) / (2 * eps), rel=2e-5, abs=1e-8)
+
+
 def test_adamski_first_steps_closed_form():
     """updates.py:36-89: with momentum/variance starting at zero, step 1 moves every parameter by
     lr_1 * (1-d1) g / (sqrt((1-d2) g^2) + eps) with lr_1 = rate sqrt(1-d2) / momentum_factor_1."""

@@ -20,6 +20,7 @@ def test_supported_architectures():
     train._plan(models.build_model("raw_1.00_rGr", klen=5, sd=0.5, seed=1))    # 110/142-wide layers: zero-padded
     train._plan(models.build_model("baseline_gru", klen=5, sd=0.5, seed=1))    # Window front end
     train._plan(models.build_model("tiny_gru", klen=5, sd=0.5, seed=1))
+    train._plan(models.build_model("baseline_lstm", klen=5, sd=0.5, seed=1))   # peephole Lstm cells
     for name in ("baseline_raw_gru", "bigger_raw_gru"):                        # birnn (Parallel) + FeedForward stacks
         body, sm = train._plan(models.build_model(name, klen=5, sd=0.5, seed=1))
         kinds = set(type(l).__name__ for sub in body for l in train._leaves(sub))
@@ -28,11 +29,11 @@ def test_supported_architectures():
     body, _ = train._plan(layers.Serial([layers.Reverse(layers.Reverse(g)), layers.Softmax(16, 5)]))
     assert train._unwrap(body[0]) == (g, False)
     for bad in (layers.Serial([g]),                                                      # no softmax
-                layers.Serial([layers.Lstm(4, 8), layers.Softmax(8, 5)]),
+                layers.Serial([layers.Lstm(4, 8), layers.Softmax(8, 5)]),             # no Lstm reverse-scan kernel for 8
                 layers.Serial([layers.Convolution(4, 8, 3), layers.Softmax(8, 5)]),    # multi-feature convolution
                 layers.Serial([layers.FeedForward(4, 1), layers.Convolution(1, 8, 3), layers.Softmax(8, 5)]),   # conv not first
                 layers.Serial([layers.Gru(4, 150), layers.Softmax(150, 5)]),          # wider than the widest kernel
-                models.build_model("baseline_lstm", klen=5, sd=0.5, seed=1)):
+                layers.Serial([layers.Convolution(1, 8, 3), layers.Window(8, 3), layers.Softmax(24, 5)])):   # Window not first
         with pytest.raises(NotImplementedError):
             train._plan(bad)
 
