@@ -33,17 +33,31 @@ def zeros(size):
 
 
 class Shared(object):
-    """Stand-in for a Theano shared variable: numpy storage, lazily mirrored to HBM."""
+    """Stand-in for a Theano shared variable: numpy storage, lazily mirrored to HBM.  While a training step owns the
+    parameter (sloika_amd.train.TrainingStep) the device copy is the master and the numpy side is refreshed from it on
+    demand, so `get_value()` and pickling see what the optimiser wrote, as with Theano's updates."""
 
     def __init__(self, value):
         self._value = np.ascontiguousarray(value, dtype=sloika_dtype)
         self._dev = None
+        self._device_is_master = False
+
+    def _pull(self):
+        if getattr(self, "_device_is_master", False) and self._dev is not None:
+            self._value = np.ascontiguousarray(self._dev.detach().cpu().numpy(), dtype=sloika_dtype)
 
     def get_value(self, borrow=False):
+        self._pull()
         return self._value if borrow else self._value.copy()
 
     def set_value(self, value, borrow=False):
-        self._value = np.ascontiguousarray(value, dtype=sloika_dtype)
+        value = np.ascontiguousarray(value, dtype=sloika_dtype)
+        if getattr(self, "_device_is_master", False) and self._dev is not None and value.shape == tuple(self._dev.shape):
+            import torch
+            self._dev.copy_(torch.from_numpy(value))         # keep the optimiser's flat buffer as the storage
+            self._value = value
+            return
+        self._value = value
         self._dev = None
 
     def dev(self):
@@ -57,11 +71,13 @@ class Shared(object):
         return self._value.shape
 
     def __getstate__(self):
+        self._pull()
         return {"_value": self._value}
 
     def __setstate__(self, state):
         self._value = np.ascontiguousarray(state["_value"], dtype=sloika_dtype)
         self._dev = None
+        self._device_is_master = False
 
 
 def shared(value):

@@ -179,6 +179,7 @@ class TrainingStep(object):
         for p, off, n in zip(self.shared, self.offsets, sizes):
             self.flat[off:off + n].copy_(torch.from_numpy(p.get_value(borrow=True).reshape(-1)))
             p._dev = self.flat[off:off + n].view(p.shape)
+            p._device_is_master = True                 # get_value() / pickling now read the optimiser's buffer
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.momentum = torch.zeros(total, dtype=torch.float32, device=dev)
         self.variance = torch.zeros(total, dtype=torch.float32, device=dev) if optimiser == "adam" else None
@@ -198,10 +199,7 @@ class TrainingStep(object):
         for layer in [leaf for sub in self.body for leaf in _leaves(sub)] + [self.softmax]:
             for attr in ("_w16", "_iw16", "_pad_cache"):
                 layer.__dict__.pop(attr, None)
-            if isinstance(layer, layers.Gru) and (layer.size % 16 or layer.insize % 16):
-                # its forward pass builds a zero-padded twin from the HOST copy of the weights (layers.Gru._padded)
-                for p in layer.params():
-                    p._value = np.ascontiguousarray(p._dev.cpu().numpy(), dtype=sloika_dtype)
+            # (a Gru whose forward pass runs a zero-padded twin rebuilds it from get_value(), which reads the device copy)
 
     def sync_host(self):
         """Copy the trained parameters back into the layers' numpy storage (what pickling a network saves:

@@ -242,6 +242,18 @@ def test_training_reduces_loss_and_model_pickles(tmp_path):
     x, labels, _ = batch()
     post = net.run(torch.from_numpy(x).cuda()).cpu().numpy()
     assert (post.argmax(2) == labels)[2:-2].mean() > 0.8
+    # like a Theano shared variable under `updates`, a parameter shows what the optimiser wrote: get_value(), plain
+    # pickling and set_value() all go through the step's device buffer
+    import pickle
+    w = net.layers[-1].W
+    assert np.array_equal(w.get_value(), w.dev().cpu().numpy()) and np.abs(w.get_value()).max() > 0
+    clone = pickle.loads(pickle.dumps(net))
+    np.testing.assert_allclose(clone.run(torch.from_numpy(x).cuda()).cpu().numpy(), post, atol=1e-6)
+    keep = w.get_value()
+    w.set_value(np.zeros_like(keep))
+    assert float(fg.flat[fg.offsets[-3]:fg.offsets[-2]].abs().max()) == 0.0 or float(w.dev().abs().max()) == 0.0
+    w.set_value(keep)
+    np.testing.assert_allclose(net.run(torch.from_numpy(x).cuda()).cpu().numpy(), post, atol=1e-6)
     path = train.save_model(net, str(tmp_path), index=1, step=fg)
     assert path.endswith("model_checkpoint_00001.pkl")
     again = helpers.load_model(path)
