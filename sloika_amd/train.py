@@ -24,30 +24,33 @@ from .config import sloika_dtype
 
 
 def remove_blanks(labels):
-    """train_network.py:116-121"""
-    for lbl_ch in labels:
-        for i in range(1, len(lbl_ch)):
-            if lbl_ch[i] == 0:
-                lbl_ch[i] = lbl_ch[i - 1]
+    """Non-transducer labels (train_network.py:116-121): every blank (0) after the first position takes the label that
+    precedes it, in place, row by row.  Vectorised: carry the index of the last non-blank position forward."""
+    labels = np.asarray(labels)
+    for row in labels:
+        pos = np.where(row != 0, np.arange(len(row)), 0)
+        pos[0] = 0                                            # position 0 keeps whatever it holds, blank included
+        row[:] = row[np.maximum.accumulate(pos)]
     return labels
 
 
 class ExponentialSmoother(object):
-    """train_network.py:100-113"""
+    """Exponentially weighted running mean with bias correction, as used for the progress lines
+    (train_network.py:100-113): value = sum_k f^(n-k) (1-f) v_k / sum_k f^(n-k) (1-f) w_k."""
 
     def __init__(self, factor, val=0.0, weight=1e-30):
-        assert 0.0 <= factor <= 1.0, "Smoothing factor was {}, should be between 0.0 and 1.0.\n".format(factor)
-        self.factor = factor
-        self.val = val
-        self.weight = weight
+        if not 0.0 <= factor <= 1.0:
+            raise AssertionError("Smoothing factor was {}, should be between 0.0 and 1.0.\n".format(factor))
+        self.factor, self.val, self.weight = factor, val, weight
 
     @property
     def value(self):
         return self.val / self.weight
 
     def update(self, val, weight=1.0):
-        self.val = self.factor * self.val + (1.0 - self.factor) * val
-        self.weight = self.factor * self.weight + (1.0 - self.factor) * weight
+        keep, take = self.factor, 1.0 - self.factor
+        self.val = keep * self.val + take * val
+        self.weight = keep * self.weight + take * weight
 
 
 def adamski_scalars(t, rate, decay, mrate=0.0005):
@@ -584,11 +587,11 @@ def save_model(network, output, index=None, step=None):
 # The loop around the step: bin/train_network.py:180-330 as callable functions (the reference has it inline in a script).
 # ---------------------------------------------------------------------------------------------------------------------
 class Logger(object):
-    """train_network.py:153-170"""
+    """Progress text to stdout (unless quiet) and, unbuffered, to the log file (train_network.py:153-170)."""
 
     def __init__(self, log_file_name, quiet=False):
-        self.fh = open(log_file_name, 'wb', 0)
         self.quiet = quiet
+        self.fh = open(log_file_name, 'wb', buffering=0)
 
     def write(self, message):
         import sys
@@ -597,8 +600,8 @@ class Logger(object):
             sys.stdout.flush()
         try:
             self.fh.write(message.encode('utf-8'))
-        except IOError as e:
-            print("Failed to write to log\n Message: {}\n Error: {}".format(message, repr(e)))
+        except IOError as err:
+            print("Failed to write to log\n Message: {}\n Error: {}".format(message, repr(err)))
 
 
 def load_chunk_file(path, reweight='weights'):
