@@ -364,3 +364,32 @@ def test_train_loop_end_to_end(tmp_path):
     assert (post.argmax(2) == labels[:8].T)[4:-4].mean() > 0.9
     initial = helpers.load_model(os.path.join(out, "model_checkpoint_00000.pkl"))
     assert (initial.run(x).cpu().numpy().argmax(2) == labels[:8].T)[4:-4].mean() < 0.6
+
+
+def test_full_size_gradient_is_mean_over_batch_halves():
+    """BASELINE.json's shape (raw_0.98_rgrgr, 4000-sample chunks) is too large for the float64 oracle; the size-independent
+    property: the loss is a mean over chunks, so the gradient of a batch equals the mean of the gradients of its halves
+    (this is also exactly what the data-parallel all-reduce relies on).  512 chunks = 409600 rows per contraction."""
+    torch = need_gpu()
+    from sloika_amd import models, train
+    net = models.randomise_zero_layers(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=3))
+    step = train.TrainingStep(net, min_prob=1e-30, drop=20)
+    rs = np.random.RandomState(0)
+    B, T = 512, 4000
+    x = torch.from_numpy(rs.normal(size=(T, B, 1)).astype(np.float32)).cuda()
+    To = net.layers[0].out_len(T)
+    labels = torch.from_numpy(rs.randint(0, net.size, size=(To, B)).astype(np.int32)).cuda()
+    weights = torch.from_numpy(rs.uniform(0.5, 1.5, size=(To, B)).astype(np.float32)).cuda()
+    loss, acc = step.forward_backward(x, labels, weights)
+    whole = step.gradients()
+    halves, losses = [], []
+    for sl in (slice(0, B // 2), slice(B // 2, B)):
+        l, _ = step.forward_backward(x[:, sl].contiguous(), labels[:, sl].contiguous(), weights[:, sl].contiguous())
+        halves.append(step.gradients())
+        losses.append(l)
+    assert loss == pytest.approx(0.5 * (losses[0] + losses[1]), rel=1e-5)
+    assert abs(loss - np.log(1025.0)) < 0.5 and np.isfinite(loss)                 # random weights: near the uniform posterior
+    for w, a, b in zip(whole, halves[0], halves[1]):
+        scale = max(float(np.abs(w).max()), 1e-12)
+        np.testing.assert_allclose(w / scale, 0.5 * (a + b) / scale, atol=2e-4)
+        assert np.isfinite(w).all() and np.abs(w).max() > 0
