@@ -109,8 +109,8 @@ def main_train(args):
     fg = train.wrap_network(net, min_prob=1e-30, l2=0.0, drop=20)                                  # train_network.py defaults
     B, L = args.batch, args.chunk_len
     rs = np.random.RandomState(1234 + rank)
-    To = net.layers[0].out_len(L)
-    x = torch.from_numpy(rs.normal(size=(L, B, 1)).astype(np.float32)).cuda()
+    To = net.layers[0].out_len(L) if hasattr(net.layers[0], "out_len") else L        # event-feature models keep the length
+    x = torch.from_numpy(rs.normal(size=(L, B, net.insize)).astype(np.float32)).cuda()
     labels = torch.from_numpy(rs.randint(0, net.size, size=(To, B)).astype(np.int32)).cuda()
     weights = torch.ones((To, B), dtype=torch.float32, device="cuda")
 
