@@ -289,8 +289,10 @@ int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *e
  *   slk_train_pack_xrh_f32: xrh[m] = [x[m] | r[m] * h_prev[m]] with zr[m] = [z | r] ([M][2N]) (kept for callers that
  *     want the candidate as a GEMM too: c = tanh(xrh . [iW[2n:] | sW2]^T + b[2n:]))
  *   then zr = sigmoid(xh . [iW[:2n] | sW]^T + b[:2n]) is a plain slk_gemm_bias_act_f16x3 / slk_gemm_bias_act_f32 call.
- * slk_gru_backward_f32: the reverse scan.  dy:[T][B] rows lddy apart = dL/dh from the layer above; h: the layer's own
- *   forward output (rows ldh apart), from which the candidate of every step is recovered as (h_t - z h_prev) / (1 - z);
+ * slk_gru_backward_f32: the reverse scan.  dy:[T][B] rows lddy apart = dL/dh from the layer above; hprev: h at the
+ *   previous scan step per row (rows ldhp apart: the h half of the packed xh rows, or a view of the layer output shifted
+ *   by one step over a zero row); zr:[M][2n] the activated gates (recomputed as above, or saved by
+ *   slk_gru_fused_train_f32); h: the layer's own forward output (rows ldh apart), from which the candidate of every step is recovered as (h_t - z h_prev) / (1 - z);
  *   writes da:[M][3n] = dL/dvI = [daz | dar | dac] and rh:[M][n] = r * h_prev.  n in {16,32,48,64,96,112,128,144},
  *   tanh / sigmoid, else SLK_ERR_UNSUPPORTED.
  *   Weight gradients follow as contractions over m (slk_gemm_tn_f32): diW = da^T x, dsW = da[:, :2n]^T h_prev,
@@ -307,10 +309,14 @@ int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *e
  * slk_adamski_update_f32: updates.py:77-87 over flat buffers with this step's lr_t / momentum_decay (updates.py:73-76);
  *   g = clip(grad * gscale + 2 l2 param).   slk_sgd_update_f32: updates.py:9-33.
  * ------------------------------------------------------------------------------------------------------- */
+/* Forward pass that also saves the gates: slk_gru_fused_f32 + zr_out:[T*B][2n] = [z | r] of every step. */
+int slk_gru_fused_train_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+                            float *y, long ldy, float *zr_out, int T, int B, int insize, int n, int reverse, int act,
+                            int gate_act, slk_stream_t stream);
 int slk_train_pack_xh_f32(const float *x, long ldx, const float *h, long ldh, float *xh, int T, int B, int insize, int n,
                           int reverse, slk_stream_t stream);
 int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *xrh, long M, int insize, int n, slk_stream_t stream);
-int slk_gru_backward_f32(const float *dy, long lddy, const float *xh, int insize, const float *zr, const float *h, long ldh,
+int slk_gru_backward_f32(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h, long ldh,
                          const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n, int reverse,
                          int act, int gate_act, slk_stream_t stream);
 /* Lstm (layers.py:677-697) in the reverse pass.  sum:[M][4n] = [x_t | out_{t-1}] . [iW | sW]^T + b (a GEMM over

@@ -82,12 +82,16 @@ __device__ __forceinline__ void keep(float &v) { asm volatile("" : "+v"(v)); }
 
 // DIAG: diagnostic instantiation (per-phase s_memtime stamps, optional skipping of the projection MFMAs); the production
 // instantiation carries none of those branches -- a taken branch costs a lone wave an instruction refetch.
-template <int I, int N, int ACT, int GACT, bool DIAG>
+// SAVE (training, sloika_amd/train.py): the activated gates z | r of every step are also written to zr_out[(t*B + b)][2N]
+// straight from the recurrent waves' registers (they have no loads, so the stores never make them wait); the reverse pass
+// then needs no gate recompute at all.
+template <int I, int N, int ACT, int GACT, bool DIAG, bool SAVE = false>
 __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restrict__ x, long ldx,
                                                            const float *__restrict__ iW, const float *__restrict__ bias,
                                                            const float *__restrict__ sW, const float *__restrict__ sW2,
                                                            float *__restrict__ h_out, long ldh, int T, int B, int reverse,
-                                                           int act, int gate_act, int diag, const int *__restrict__ lens)
+                                                           int act, int gate_act, int diag, const int *__restrict__ lens,
+                                                           float *__restrict__ zr_out)
 {
     static_assert(I % 16 == 0 && N % 16 == 0 && N <= 128, "unsupported size for the fused GRU kernel");
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -260,6 +264,14 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
             STAMP(2)
 #pragma unroll
             for (int i = 0; i < 4; i++) g[i] = act_sel<GACT>(gate_act, g[i]);
+            if constexpr (SAVE) {
+                if (validA && ga == 0) {                     // one lane per gate row; its four values are the four chunks
+                    const size_t trow = (size_t)(reverse ? T - 1 - s : s) * B + b0;
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; c4++)
+                        if (b0 + c4 < B) zr_out[(trow + c4) * (2 * N) + rowA] = g[c4];
+                }
+            }
             if (rlane) *reinterpret_cast<f32x4 *>(&rhbuf[4 * neuronA]) = g * hown;
             publish(flags, wave, s + 1, lane);
             STAMP(3)
@@ -502,13 +514,26 @@ static int launch_fused(const float *x, long ldx, const float *iW, const float *
     if constexpr (I == 96 && N == 96) {
         if (diag) {
             hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, true>), dim3((B + 3) / 4), dim3(512), 0, s,
-                               x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, diag, lens);
+                               x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, diag, lens,
+                               (float *)nullptr);
             return slk_launch_status();
         }
     }
     static const size_t dyn_lds = exclusive_cu_lds(gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>);
     hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>), dim3((B + 3) / 4), dim3(512), dyn_lds, s,
-                       x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, 0, lens);
+                       x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, 0, lens,
+                       (float *)nullptr);
+    return slk_launch_status();
+}
+
+template <int I, int N>
+static int launch_fused_train(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
+                              float *y, long ldy, float *zr_out, int T, int B, int reverse, hipStream_t s)
+{
+    static const size_t dyn_lds = exclusive_cu_lds(gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false, true>);
+    hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false, true>), dim3((B + 3) / 4), dim3(512),
+                       dyn_lds, s, x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, 0,
+                       (const int *)nullptr, zr_out);
     return slk_launch_status();
 }
 
@@ -549,4 +574,22 @@ extern "C" int slk_gru_fused_ragged_f32(const float *x, long ldx, const float *i
 {
     if (!lens) return SLK_ERR_INVALID_ARG;
     return gru_fused_entry(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse & 1, act, gate_act, lens, stream);
+}
+
+// Forward pass of a training step: slk_gru_fused_f32 that also leaves the activated gates of every step in
+// zr_out[(t*B + b)][2n] = [z | r] (what the reverse scan slk_gru_backward_f32 consumes).  Same shapes as slk_gru_fused_f32.
+extern "C" int slk_gru_fused_train_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
+                                       const float *bias, float *y, long ldy, float *zr_out, int T, int B, int insize, int n,
+                                       int reverse, int act, int gate_act, slk_stream_t stream)
+{
+    if (!x || !iW || !sW || !sW2 || !y || !zr_out || T < 1 || B < 1 || insize < 1 || n < 1 || ldx < insize || ldy < n)
+        return SLK_ERR_INVALID_ARG;
+    if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
+    if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;
+    hipStream_t s = slk_stream(stream);
+#define FUSED(II, NN) \
+    if (insize == II && n == NN) return launch_fused_train<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, zr_out, T, B, reverse, s);
+    FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(128, 96) FUSED(16, 16) FUSED(48, 32) FUSED(64, 96) FUSED(16, 64)
+#undef FUSED
+    return SLK_ERR_UNSUPPORTED;
 }

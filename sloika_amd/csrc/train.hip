@@ -129,7 +129,7 @@ __device__ __forceinline__ float gru_candidate(float h_t, float z, float h)
 
 template <int N>
 __global__ void __launch_bounds__(4 * N) gru_backward_kernel(const float *__restrict__ dy, long lddy,
-                                                             const float *__restrict__ xh, int I,
+                                                             const float *__restrict__ hprev, long ldhp,
                                                              const float *__restrict__ zr, const float *__restrict__ hout,
                                                              long ldh, const float *__restrict__ sW,
                                                              const float *__restrict__ sW2, float *__restrict__ da,
@@ -144,7 +144,6 @@ __global__ void __launch_bounds__(4 * N) gru_backward_kernel(const float *__rest
     for (int j = 0; j < Q2; j++) w2[j] = sW2[(size_t)(q * Q2 + j) * N + i];      // drh[i] = sum_k dac[k] sW2[k][i]
 #pragma unroll
     for (int j = 0; j < Q1; j++) w1[j] = sW[(size_t)(q * Q1 + j) * N + i];       // carry[i] += sum_k dzr[k] sW[k][i]
-    const long ldxh = I + N;
     float carry = 0.0f;
     // operands of scan step s (owner threads only)
     auto row = [&](int s) { return (size_t)(reverse ? T - 1 - s : s) * B + b; };
@@ -155,7 +154,7 @@ __global__ void __launch_bounds__(4 * N) gru_backward_kernel(const float *__rest
         n_z = zr[m * (2 * N) + i];
         n_r = zr[m * (2 * N) + N + i];
         n_c = hout[m * ldh + i];
-        n_h = xh[m * ldxh + I + i];
+        n_h = hprev[m * ldhp + i];
     };
     if (owner) fetch(T - 1);
     for (int s = T - 1; s >= 0; s--) {
@@ -243,7 +242,7 @@ __device__ __forceinline__ float row_reduce4(f32x2 acc01, f32x2 acc23)
 
 template <int N>
 __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const float *__restrict__ dy, long lddy,
-                                                                      const float *__restrict__ xh, int I,
+                                                                      const float *__restrict__ hprev, long ldhp,
                                                                       const float *__restrict__ zr,
                                                                       const float *__restrict__ hout, long ldh,
                                                                       const float *__restrict__ sW,
@@ -261,7 +260,6 @@ __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const floa
     const int i = ibase + m;                                                 // the output this lane finishes
     const bool owner = !loader && quad < CH && b0 + quad < B;
     const int bq = min(b0 + (quad < CH ? quad : 0), B - 1);                  // the chunk this lane finishes
-    const long ldxh = I + N;
     auto row = [&](int s, int bb) { return (size_t)(reverse ? T - 1 - s : s) * B + bb; };
     auto issue = [&](int sp) {                                    // loader wave: the operand rows of scan step sp
         if (lane < N / 4) {
@@ -270,7 +268,7 @@ __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const floa
                 const size_t mm = row(sp, min(b0 + ch, B - 1));
                 float *dst = &ring[sp % D][ch][0][0];
                 const float *src[5] = {dy + mm * lddy, zr + mm * (2 * N), zr + mm * (2 * N) + N, hout + mm * ldh,
-                                       xh + mm * ldxh + I};
+                                       hprev + mm * ldhp};
 #pragma unroll
                 for (int a = 0; a < 5; a++)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[a] + 4 * lane),
@@ -371,33 +369,33 @@ __global__ void __launch_bounds__(4 * N + 64) gru_backward_dma_kernel(const floa
 }
 
 template <int N>
-static int launch_gru_backward(const float *dy, long lddy, const float *xh, int I, const float *zr, const float *h, long ldh,
-                               const float *sW, const float *sW2, float *da, float *rh, int T, int B, int reverse,
+static int launch_gru_backward(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h,
+                               long ldh, const float *sW, const float *sW2, float *da, float *rh, int T, int B, int reverse,
                                hipStream_t s)
 {
-    const bool aligned = lddy % 4 == 0 && I % 4 == 0 && ldh % 4 == 0 &&
-                         ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(xh) | reinterpret_cast<uintptr_t>(zr) |
-                           reinterpret_cast<uintptr_t>(h)) & 15) == 0;
+    const bool aligned = lddy % 4 == 0 && ldhp % 4 == 0 && ldh % 4 == 0 &&
+                         ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(hprev) |
+                           reinterpret_cast<uintptr_t>(zr) | reinterpret_cast<uintptr_t>(h)) & 15) == 0;
     if (aligned)
-        hipLaunchKernelGGL((gru_backward_dma_kernel<N>), dim3((B + 1) / 2), dim3(4 * N + 64), 0, s, dy, lddy, xh, I, zr, h, ldh,
-                           sW, sW2, da, rh, T, B, reverse);
+        hipLaunchKernelGGL((gru_backward_dma_kernel<N>), dim3((B + 1) / 2), dim3(4 * N + 64), 0, s, dy, lddy, hprev, ldhp, zr, h,
+                           ldh, sW, sW2, da, rh, T, B, reverse);
     else
-        hipLaunchKernelGGL((gru_backward_kernel<N>), dim3(B), dim3(4 * N), 0, s, dy, lddy, xh, I, zr, h, ldh, sW, sW2, da, rh,
-                           T, B, reverse);
+        hipLaunchKernelGGL((gru_backward_kernel<N>), dim3(B), dim3(4 * N), 0, s, dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da,
+                           rh, T, B, reverse);
     return slk_launch_status();
 }
 
-extern "C" int slk_gru_backward_f32(const float *dy, long lddy, const float *xh, int insize, const float *zr, const float *h,
+extern "C" int slk_gru_backward_f32(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h,
                                     long ldh, const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n,
                                     int reverse, int act, int gate_act, slk_stream_t stream)
 {
-    if (!dy || !xh || !zr || !h || !sW || !sW2 || !da || !rh || T < 1 || B < 1 || n < 1 || insize < 1 || lddy < n || ldh < n)
+    if (!dy || !hprev || !zr || !h || !sW || !sW2 || !da || !rh || T < 1 || B < 1 || n < 1 || lddy < n || ldh < n || ldhp < n)
         return SLK_ERR_INVALID_ARG;
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
     hipStream_t s = slk_stream(stream);
     switch (n) {
 #define GRU_BWD_CASE(NN) \
-    case NN: return launch_gru_backward<NN>(dy, lddy, xh, insize, zr, h, ldh, sW, sW2, da, rh, T, B, reverse, s)
+    case NN: return launch_gru_backward<NN>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, reverse, s)
         GRU_BWD_CASE(16); GRU_BWD_CASE(32); GRU_BWD_CASE(48); GRU_BWD_CASE(64); GRU_BWD_CASE(96); GRU_BWD_CASE(112);
         GRU_BWD_CASE(128); GRU_BWD_CASE(144);
 #undef GRU_BWD_CASE

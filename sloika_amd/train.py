@@ -342,6 +342,10 @@ class TrainingStep(object):
         kind = ("conv" if isinstance(layer, layers.Convolution) else "gru" if isinstance(layer, layers.Gru) else
                 "lstm" if isinstance(layer, layers.Lstm) else "window" if isinstance(layer, layers.Window) else "ff")
         x = layers._check_input(x, layer.insize)
+        if kind == "gru":
+            saved = self._gru_forward_saving(layer, x, rev)
+            if saved is not None:
+                return saved[0], (kind, layer, rev, x, saved[0], saved[1])
         y = layer._forward(x, None, rev)
         return y, (kind, layer, rev, x, y)
 
@@ -366,9 +370,9 @@ class TrainingStep(object):
                         _lib.check(_lib.lib().slk_add_inplace_f32(dx.data_ptr(), d.data_ptr(), dx.numel(), layers._stream()),
                                    "add")
             return dx
-        _, layer, rev, xin, y = tape
+        layer, rev, xin, y = tape[1:5]
         if kind == "gru":
-            return self._gru_backward(layer, rev, xin, y, dy, need_dx)
+            return self._gru_backward(layer, rev, xin, y, dy, need_dx, saved=tape[5] if len(tape) > 5 else None)
         if kind == "lstm":
             return self._lstm_backward(layer, rev, xin, y, dy, need_dx)
         if kind == "ff":
@@ -401,7 +405,38 @@ class TrainingStep(object):
                                                dx.data_ptr(), i_sz, M, n, i_sz, 0, st()), "ff dx")
         return dx
 
-    def _gru_backward(self, layer, rev, xin, h, dy, need_dx):
+    def _gru_forward_saving(self, layer, x, rev):
+        """Forward pass of a Gru layer through the fused kernel's training instantiation, which also writes the gates
+        [z | r] of every step.  The output lives inside a buffer with one zero time step on either side, so "h at the
+        previous scan step" is just a shifted view of it (no packing pass).  None when no such instantiation exists
+        (sizes, activations, SLOIKA_AMD_EXACT_F32): the caller then runs the plain forward pass and the reverse pass
+        recomputes the gates."""
+        import torch
+        if not layers.SPLIT_F16:
+            return None
+        T, B, n = int(x.shape[0]), int(x.shape[1]), layer.size
+        hbuf = torch.empty((T + 2, B, n), dtype=torch.float32, device=x.device)
+        hbuf[0].zero_()
+        hbuf[T + 1].zero_()
+        y = hbuf[1:T + 1]
+        zr = torch.empty((T * B, 2 * n), dtype=torch.float32, device=x.device)
+        M = T * B
+        with profiler.region("gru_fused", 6.0 * M * n * (n + layer.insize), 4.0 * M * (layer.insize + 3 * n),
+                             f16x3_flops=6.0 * M * n * layer.insize) as reg:
+            rc = _lib.lib().slk_gru_fused_train_f32(x.data_ptr(), layers._row_stride(x), layer.iW.dev().data_ptr(),
+                                                    layer.sW.dev().data_ptr(), layer.sW2.dev().data_ptr(),
+                                                    layer.b.dev().data_ptr(), y.data_ptr(), n, zr.data_ptr(), T, B,
+                                                    layer.insize, n, int(rev), activation.act_id(layer.fun),
+                                                    activation.act_id(layer.gatefun), layers._stream())
+            if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
+                reg.cancel()
+        if rc == _lib.SLK_ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc, "gru_fused_train")
+        hprev = hbuf[2:T + 2] if rev else hbuf[0:T]
+        return y, (zr, hprev)
+
+    def _gru_backward(self, layer, rev, xin, h, dy, need_dx, saved=None):
         """Reverse pass of one Gru layer.  Sizes that are not multiples of 16 (models/raw_1.00_rGr.py: 110, 142) run
         zero-padded, like the forward pass (layers.Gru._padded): padding neurons have zero weights, zero state and receive
         zero gradient, so the leading blocks of every gradient are those of the unpadded layer."""
@@ -412,7 +447,7 @@ class TrainingStep(object):
         gb = self._grad_of(layer.b) if layer.has_bias else None
         if n16 == n and i16 == i_sz:
             return self._gru_backward_core(xin, h, dy, rev, n, i_sz, iW, sW, sW2, b, self._grad_of(layer.iW),
-                                           self._grad_of(layer.sW), self._grad_of(layer.sW2), gb, need_dx)
+                                           self._grad_of(layer.sW), self._grad_of(layer.sW2), gb, need_dx, saved=saved)
         T, B, dev = int(h.shape[0]), int(h.shape[1]), h.device
 
         def widen(t, width):
@@ -438,7 +473,7 @@ class TrainingStep(object):
             gb.view(3, n).copy_(gb_p.view(3, n16)[:, :n])
         return dx[:, :, :i_sz].contiguous() if need_dx else None
 
-    def _gru_backward_core(self, xin, h, dy, rev, n, i_sz, iW, sW, sW2, b, giW, gsW, gsW2, gb, need_dx):
+    def _gru_backward_core(self, xin, h, dy, rev, n, i_sz, iW, sW, sW2, b, giW, gsW, gsW2, gb, need_dx, saved=None):
         import torch
         L = _lib.lib()
         st = layers._stream
@@ -446,18 +481,26 @@ class TrainingStep(object):
         M, K = T * B, i_sz + n
         act, gact = activation.act_id(activation.tanh), activation.act_id(activation.sigmoid)
         dev = h.device
-        with profiler.region("train_gates", 4.0 * M * n * K, 4.0 * M * (2 * K + 2 * n), f16x3_flops=4.0 * M * n * K):
-            xh = torch.empty((M, K), dtype=torch.float32, device=dev)
-            _lib.check(L.slk_train_pack_xh_f32(xin.data_ptr(), layers._row_stride(xin), h.data_ptr(), layers._row_stride(h),
-                                               xh.data_ptr(), T, B, i_sz, n, int(rev), st()), "pack_xh")
-            zr = torch.empty((M, 2 * n), dtype=torch.float32, device=dev)
-            self._gemm(xh.data_ptr(), K, torch.cat([iW[:2 * n], sW], 1).contiguous(), b[:2 * n].data_ptr(), zr.data_ptr(),
-                       2 * n, M, K, 2 * n, gact)
+        if saved is not None:
+            # the forward pass left the gates and a shifted view of its output (see _gru_forward_saving)
+            zr, hprev = saved
+            x_ptr, ldx, hp_ptr, ldhp = xin.data_ptr(), layers._row_stride(xin), hprev.data_ptr(), layers._row_stride(hprev)
+        else:
+            # recompute [z r] of all steps at once: one GEMM over packed rows [x_t | h_{t-1}]
+            with profiler.region("train_gates", 4.0 * M * n * K, 4.0 * M * (2 * K + 2 * n), f16x3_flops=4.0 * M * n * K):
+                xh = torch.empty((M, K), dtype=torch.float32, device=dev)
+                _lib.check(L.slk_train_pack_xh_f32(xin.data_ptr(), layers._row_stride(xin), h.data_ptr(),
+                                                   layers._row_stride(h), xh.data_ptr(), T, B, i_sz, n, int(rev), st()),
+                           "pack_xh")
+                zr = torch.empty((M, 2 * n), dtype=torch.float32, device=dev)
+                self._gemm(xh.data_ptr(), K, torch.cat([iW[:2 * n], sW], 1).contiguous(), b[:2 * n].data_ptr(), zr.data_ptr(),
+                           2 * n, M, K, 2 * n, gact)
+            x_ptr, ldx, hp_ptr, ldhp = xh.data_ptr(), K, xh.data_ptr() + 4 * i_sz, K
         # the candidate is not recomputed by a GEMM: the scan recovers it from the layer's own output (csrc/train.hip)
         da = torch.empty((M, 3 * n), dtype=torch.float32, device=dev)
         rh = torch.empty((M, n), dtype=torch.float32, device=dev)
         with profiler.region("train_gru_scan", 6.0 * M * n * n, 4.0 * M * 9 * n):
-            rc = L.slk_gru_backward_f32(dy.data_ptr(), layers._row_stride(dy), xh.data_ptr(), i_sz, zr.data_ptr(),
+            rc = L.slk_gru_backward_f32(dy.data_ptr(), layers._row_stride(dy), hp_ptr, ldhp, zr.data_ptr(),
                                         h.data_ptr(), layers._row_stride(h), sW.data_ptr(), sW2.data_ptr(), da.data_ptr(),
                                         rh.data_ptr(), T, B, n, int(rev), act, gact, st())
         if rc == _lib.SLK_ERR_UNSUPPORTED:
@@ -465,9 +508,9 @@ class TrainingStep(object):
         _lib.check(rc, "gru_backward")
         f4 = 4                                                                       # bytes per float, for column offsets
         with profiler.region("train_wgrad", 2.0 * M * (3 * n * i_sz + 3 * n * n), 4.0 * M * (3 * n + 2 * K)):
-            self._tn(da.data_ptr(), 3 * n, xh.data_ptr(), K, giW.data_ptr(), i_sz, M, 3 * n, i_sz,
+            self._tn(da.data_ptr(), 3 * n, x_ptr, ldx, giW.data_ptr(), i_sz, M, 3 * n, i_sz,
                      colsum=gb.data_ptr() if gb is not None else None)
-            self._tn(da.data_ptr(), 3 * n, xh.data_ptr() + f4 * i_sz, K, gsW.data_ptr(), n, M, 2 * n, n)
+            self._tn(da.data_ptr(), 3 * n, hp_ptr, ldhp, gsW.data_ptr(), n, M, 2 * n, n)
             self._tn(da.data_ptr() + f4 * 2 * n, 3 * n, rh.data_ptr(), n, gsW2.data_ptr(), n, M, n, n)
         if not need_dx:
             return None

@@ -316,15 +316,15 @@ def test_gru_backward_kernels_agree(n, reverse):
         buf[shift:shift + M * n] = dev(dy).reshape(-1)
         da = torch.empty((M, 3 * n), dtype=torch.float32, device="cuda")
         rh = torch.empty((M, n), dtype=torch.float32, device="cuda")
-        rc = L.slk_gru_backward_f32(buf.data_ptr() + 4 * shift, n, d["xh"].data_ptr(), I, d["zr"].data_ptr(), d["hout"].data_ptr(),
-                                    n, d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), rh.data_ptr(), T, B, n, reverse,
-                                    1, 2, stream())
+        rc = L.slk_gru_backward_f32(buf.data_ptr() + 4 * shift, n, d["xh"].data_ptr() + 4 * I, I + n, d["zr"].data_ptr(),
+                                    d["hout"].data_ptr(), n, d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(),
+                                    rh.data_ptr(), T, B, n, reverse, 1, 2, stream())
         assert rc == 0
         outs.append(da.cpu().numpy())
         np.testing.assert_array_equal(rh.cpu().numpy(), zr[:, n:] * xh[:, I:])
     np.testing.assert_allclose(outs[0], outs[1], rtol=1e-4, atol=1e-5 * np.abs(want).max())     # different summation orders
     np.testing.assert_allclose(outs[0], want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
-    assert L.slk_gru_backward_f32(d["xh"].data_ptr(), 160, d["xh"].data_ptr(), I, d["zr"].data_ptr(), d["hout"].data_ptr(), 160,
+    assert L.slk_gru_backward_f32(d["xh"].data_ptr(), 160, d["xh"].data_ptr(), 160, d["zr"].data_ptr(), d["hout"].data_ptr(), 160,
                                   d["sW"].data_ptr(), d["sW2"].data_ptr(), da.data_ptr(), rh.data_ptr(), T, B, 40, reverse, 1,
                                   2, stream()) == _lib.SLK_ERR_UNSUPPORTED
 

@@ -10,9 +10,9 @@ da = torch.empty(M, 3 * n, device="cuda")
 rh = torch.empty(M, n, device="cuda")
 vp = ctypes.c_void_p
 f = lib.slk_gru_backward_f32
-f.argtypes = [vp, ctypes.c_long, vp, ctypes.c_int, vp, vp, ctypes.c_long, vp, vp, vp, vp] + [ctypes.c_int] * 6 + [vp]
+f.argtypes = [vp, ctypes.c_long, vp, ctypes.c_long, vp, vp, ctypes.c_long, vp, vp, vp, vp] + [ctypes.c_int] * 6 + [vp]
 def run():
-    return f(dy.data_ptr(), n, xh.data_ptr(), I, zr.data_ptr(), h.data_ptr(), n, sW.data_ptr(), sW2.data_ptr(), da.data_ptr(), rh.data_ptr(), T, B, n, 0, 1, 2, None)
+    return f(dy.data_ptr(), n, xh.data_ptr() + 4 * I, I + n, zr.data_ptr(), h.data_ptr(), n, sW.data_ptr(), sW2.data_ptr(), da.data_ptr(), rh.data_ptr(), T, B, n, 0, 1, 2, None)
 assert run() == 0
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(10): run()
