@@ -560,14 +560,35 @@ __global__ void __launch_bounds__(256) softmax_xent_grad_kernel(float *__restric
     const float w = counted ? weights[m] / count : 0.0f;
     const float coef = w * (1.0f - min_prob) * p_lab / post_lab;
     int first = 0x7fffffff;
-    for (int j = lane; j < (int)ld; j += 64) {
+    auto grad = [&](float l, int j) {
         float d = 0.0f;
         if (j < nstate) {
-            const float l = row[j];
             if (l == mx && j < first) first = j;
             d = coef * (__expf(l - mx) * inv - (j == label ? 1.0f : 0.0f));
         }
-        row[j] = d;
+        return d;
+    };
+    if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+        // 16-byte accesses, all loads of the row in flight before the first store
+        float4 *row4 = reinterpret_cast<float4 *>(row);
+        const int n4 = (int)(ld >> 2);
+        for (int j0 = 0; j0 < n4; j0 += 64 * 5) {
+            float4 v[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int j4 = j0 + 64 * k + lane;
+                v[k] = row4[min(j4, n4 - 1)];                      // clamped, not conditional: the loads stay back to back
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int j4 = j0 + 64 * k + lane;
+                if (j4 < n4)
+                    row4[j4] = make_float4(grad(v[k].x, 4 * j4), grad(v[k].y, 4 * j4 + 1), grad(v[k].z, 4 * j4 + 2),
+                                           grad(v[k].w, 4 * j4 + 3));
+            }
+        }
+    } else {
+        for (int j = lane; j < (int)ld; j += 64) row[j] = grad(row[j], j);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
