@@ -385,6 +385,10 @@ static int launch_gru_backward(const float *dy, long lddy, const float *hprev, l
     return slk_launch_status();
 }
 
+int slk_gru_backward_mfma_dispatch(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h,
+                                   long ldh, const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n,
+                                   int reverse, hipStream_t s);                                  // gru_backward_mfma.hip
+
 extern "C" int slk_gru_backward_f32(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h,
                                     long ldh, const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n,
                                     int reverse, int act, int gate_act, slk_stream_t stream)
@@ -393,6 +397,10 @@ extern "C" int slk_gru_backward_f32(const float *dy, long lddy, const float *hpr
         return SLK_ERR_INVALID_ARG;
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
     hipStream_t s = slk_stream(stream);
+    {
+        const int rc = slk_gru_backward_mfma_dispatch(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, s);
+        if (rc != SLK_ERR_UNSUPPORTED) return rc;              // gru_backward_mfma.hip: aligned rows, n <= 128
+    }
     switch (n) {
 #define GRU_BWD_CASE(NN) \
     case NN: return launch_gru_backward<NN>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, reverse, s)
