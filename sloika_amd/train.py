@@ -83,6 +83,14 @@ def allreduce_mean_(tensor):
     return 1.0 / dist.get_world_size()
 
 
+def broadcast_from_rank0_(tensor):
+    """Every rank takes rank 0's values (in place).  A no-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(tensor, src=0)
+    return tensor
+
+
 def _unwrap(layer, rev=False):
     while isinstance(layer, layers.Reverse):
         layer, rev = layer.layer, not rev
@@ -183,6 +191,7 @@ class TrainingStep(object):
             self.flat[off:off + n].copy_(torch.from_numpy(p.get_value(borrow=True).reshape(-1)))
             p._dev = self.flat[off:off + n].view(p.shape)
             p._device_is_master = True                 # get_value() / pickling now read the optimiser's buffer
+        broadcast_from_rank0_(self.flat)                # data-parallel replicas start from rank 0's parameters
         self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.momentum = torch.zeros(total, dtype=torch.float32, device=dev)
         self.variance = torch.zeros(total, dtype=torch.float32, device=dev) if optimiser == "adam" else None
@@ -247,8 +256,8 @@ class TrainingStep(object):
         return loss, acc
 
     def forward_backward(self, x, labels, weights):
-        """Loss and accuracy of the batch; leaves d loss / d params (without the l2 term, which the update adds) in
-        self.grad, already averaged over the ranks."""
+        """Loss and accuracy of the (global) batch; leaves d loss / d params (without the l2 term, which the update adds) in
+        self.grad, summed over the ranks, and the factor that turns the sum into the mean in self.gscale."""
         import torch
         from . import device as D
         L = _lib.lib()

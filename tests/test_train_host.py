@@ -96,6 +96,8 @@ def _worker(rank, world, port, out_dir):
     mine = slice(rank, None, world)                                   # chunks rank::world, as the inference sharding
     loss, acc, grads = ot.loss_and_grads(spec, x[:, mine], labels[:, mine], weights[:, mine], 1e-3, 0.0, 1)
     flat = torch.from_numpy(np.concatenate([g.reshape(-1) for g in grads] + [[loss, acc]]))
+    start = torch.full((4,), float(rank + 1))
+    assert train.broadcast_from_rank0_(start).tolist() == [1.0] * 4      # replicas start from rank 0's parameters
     scale = train.allreduce_mean_(flat)
     if rank == 0:
         np.save(os.path.join(out_dir, "mean.npy"), flat.numpy() * scale)
