@@ -393,3 +393,37 @@ def test_full_size_gradient_is_mean_over_batch_halves():
         scale = max(float(np.abs(w).max()), 1e-12)
         np.testing.assert_allclose(w / scale, 0.5 * (a + b) / scale, atol=2e-4)
         assert np.isfinite(w).all() and np.abs(w).max() > 0
+
+
+def test_training_edge_cases():
+    """Smallest shapes (one chunk, three output steps), zero label weights (only the l2 term is left: gradient = 2 l2 theta,
+    loss = l2 |theta|^2), plain ADAM (mrate=None) and SGD taking a step without producing NaNs."""
+    need_gpu()
+    from oracle import oracle_train as ot
+    from sloika_amd import train
+    rs = np.random.RandomState(12)
+    net = _build(rs, n=16, nstate=5, winlen=3, stride=2, nlayer=2)
+    x, labels, weights = _batch(rs, net, 6, 1)                       # T' = 3, B = 1
+    want_loss, want_acc, want = ot.loss_and_grads(net.spec(), x, labels, weights, 1e-4, 0.0, 1)
+    step = train.TrainingStep(net, min_prob=1e-4, drop=1)
+    loss, acc = step.forward_backward(x, labels, weights)
+    assert loss == pytest.approx(want_loss, rel=2e-5) and acc == pytest.approx(want_acc, abs=1e-6)
+    _assert_grads_close(step.gradients(), want)
+    # zero weights: the data term vanishes
+    l2 = 0.05
+    step = train.TrainingStep(net, l2=l2, drop=1)
+    loss, _ = step.forward_backward(x, labels, np.zeros_like(weights))
+    params = [p.get_value() for p in net.params()]
+    assert loss == pytest.approx(l2 * sum(float(np.sum(np.square(p.astype(np.float64)))) for p in params), rel=1e-5)
+    for g, p in zip(step.gradients(), params):
+        np.testing.assert_allclose(g, 2 * l2 * p, rtol=1e-5, atol=1e-7)
+    # optimiser variants take finite steps
+    for kw in (dict(mrate=None), dict(optimiser="sgd", momentum=0.5)):
+        fg = train.TrainingStep(net, min_prob=1e-4, drop=1, **kw)
+        before = [p.get_value() for p in net.params()]
+        first, _ = fg(x, labels, weights, 1e-2)
+        for _ in range(20):
+            last, _ = fg(x, labels, weights, 1e-2)
+        after = [p.get_value() for p in net.params()]
+        assert np.isfinite(last) and last < first
+        assert all(np.isfinite(a).all() for a in after) and any(np.abs(a - b).max() > 0 for a, b in zip(after, before))
