@@ -102,9 +102,9 @@ def main_train(args):
     _lib.require_gpu()
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:          # under a launcher (also with one rank: the RCCL path is the path that runs)
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
     net = models.randomise_zero_layers(models.build_model(args.model, klen=5, sd=0.5, seed=11))     # same weights on every rank
     fg = train.wrap_network(net, min_prob=1e-30, l2=0.0, drop=20)                                  # train_network.py defaults
     B, L = args.batch, args.chunk_len
@@ -160,8 +160,31 @@ def main_train(args):
         dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this script under torch.distributed.run (one process
+    per GPU, rendezvous on 127.0.0.1) as a CHILD process and exit with its return code.  Nothing here has touched the GPU
+    (no torch.cuda call, no library load), and the parent never replaces itself with another program."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if world_env is not None and int(world_env) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n" % (args.gpus, world_env))
+        sys.exit(2)
+    sys.stderr.write("bench.py: rank %s of %s starting\n" % (os.environ.get("RANK", "0"), world_env or "1"))
+    sys.stderr.flush()
     if args.train:
         return main_train(args)
     import torch
@@ -170,9 +193,9 @@ def main():
     _lib.require_gpu()
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
     dist = None
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:          # under a launcher (also with one rank: the RCCL path is the path that runs)
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
     net = models.randomise_zero_layers(models.build_model(args.model, klen=5, sd=0.5, seed=11))
     nstream = max(1, args.streams)
     bcs = [pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0) for _ in range(nstream)]

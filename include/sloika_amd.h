@@ -169,6 +169,16 @@ int slk_gru_f32(const float *x, long ldx, const float *iW, const float *sW, cons
 int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                       float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                       slk_stream_t stream);
+/* The same layer with the RECURRENCE on the fp16 matrix pipe as well (csrc/gru_fused16.hip): every float32 operand of
+ * h.sW^T and (r*h).sW2^T is split v = hi + lo into two fp16 halves and each product evaluated as hi.lo + lo.hi + hi.hi in
+ * float32 accumulators (v_mfma_f32_16x16x32_f16) -- 22 significand bits per operand, |h| <= 1 and trained |w| << 65504 by
+ * construction; x is scaled per row by a power of two before its split, so any finite float32 input is safe.  Callers
+ * must not pass weights with |w| >= 32768 (sloika_amd/layers.py checks once per weight update and takes slk_gru_fused_f32
+ * otherwise).  lens: NULL, or ragged lengths as slk_gru_fused_ragged_f32; zr_out: NULL, or [T*B][2n] = [z | r] of every
+ * step as slk_gru_fused_train_f32.  n in {32, 64, 96}; SLK_ERR_UNSUPPORTED for shapes without an instantiation.     */
+int slk_gru_fused16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+                        float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
+                        const int32_t *lens, float *zr_out, slk_stream_t stream);
 /* Ragged batches (whole reads of different lengths, zero-padded to T steps; the reference calls reads one at a time,
  * sloika/basecall.py:88-121): lens[b] in [1, T] (int32, device) is the number of valid steps of chunk b.  Steps
  * t >= lens[b] of y / h_out are left untouched, and with reverse = 1 the scan of chunk b starts at ITS last step,

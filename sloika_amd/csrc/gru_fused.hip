@@ -19,6 +19,7 @@
 // MFMA A-operand reads without conflicts.  Exact fp32 (v_mfma_f32_4x4x1_16b_f32).
 #include <limits.h>
 
+#include "lds_flags.h"
 #include "mfma4.h"
 
 // Diagnostic: shader-clock cycles and 100 MHz wall ticks spent by workgroup 0 in the last fused launch
@@ -46,39 +47,6 @@ extern "C" int slk_debug_read_clock(unsigned long long *host_out)
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_clock), sizeof(unsigned long long) * 2) == hipSuccess ? SLK_OK
                                                                                                                : SLK_ERR_LAUNCH;
 }
-
-typedef __attribute__((address_space(3))) int lds_int_t;
-
-__device__ __forceinline__ void publish(int *flags, int idx, int value, int lane)
-{
-    asm volatile("" ::: "memory");          // the data writes stay ahead of the counter write in program order
-    if (lane == 0) *(volatile lds_int_t *)(lds_int_t *)&flags[idx] = value;
-    asm volatile("" ::: "memory");
-}
-// Polling is split in two so that the consumer's data reads travel with the counter read (one LDS round trip):
-//   poll_issue  -- ds_read of the watched counter (lane l watches flags[l & 15]), NOT waited for
-//   ... the caller issues its data reads ...
-//   poll_result -- waits for everything and tells whether every watched counter had reached the lane's `need`
-// (LDS executes a wave's operations in order, so data read after a counter that had arrived is valid data).
-__device__ __forceinline__ int poll_issue(const int *flags, int lane)
-{
-    int v;
-    const unsigned addr = (unsigned)(uintptr_t)(lds_int_t *)&flags[lane & 15];
-    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ bool poll_result(int v, int need)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v)::"memory");
-    return __builtin_amdgcn_ballot_w64(v < need) == 0;
-}
-__device__ __forceinline__ bool reached(const int *flags, int lane, int need)
-{
-    return poll_result(poll_issue(flags, lane), need);
-}
-// keeps values loaded inside a retry loop from being sunk out of it
-__device__ __forceinline__ void keep(f32x4 &v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void keep(float &v) { asm volatile("" : "+v"(v)); }
 
 // DIAG: diagnostic instantiation (per-phase s_memtime stamps, optional skipping of the projection MFMAs); the production
 // instantiation carries none of those branches -- a taken branch costs a lone wave an instruction refetch.

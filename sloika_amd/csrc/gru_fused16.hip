@@ -1,0 +1,547 @@
+// gru_fused16.hip -- a whole Gru layer (sloika/layers.py:1010-1021) in ONE persistent kernel, with BOTH halves -- the
+// time-parallel input projection and the recurrence -- on the fp16 matrix pipe at float32-grade accuracy.
+//
+// gru_fused.hip keeps the recurrent products in exact fp32 (v_mfma_f32_4x4x1, 8 cycles per 64 outputs x 4 chunks x 1 k):
+// 144 MFMAs = 1150 pipe cycles per step on a chain that is strictly serial, plus K-slice sums and 4-wide gate maths on
+// 48 of 64 lanes.  Here every float32 operand of the recurrence is split  v = hi + lo  (two fp16 halves, 22 significand
+// bits) and a product is  w_hi.h_lo + w_lo.h_hi + w_hi.h_hi  in float32 accumulators (v_mfma_f32_16x16x32_f16, 16 cycles
+// per 16 neurons x 16 columns x 32 k): a tile of 16 neurons over all of K = 96 costs 9 MFMAs instead of 96 x 4x4x1.
+//
+// Layout that makes the 16x16 tile dense although a workgroup only has 4 chunks (B = 1024 chunks over 256 CUs):
+//   * A = weights (row i = neuron 16*tile + i), B = state, and the state of chunk c is supplied in ALL FOUR column groups
+//     (column 4q + c, q = 0..3).  Lane (q, c, g = lane>>4) then receives D[4g + r][4q + c], r = 0..3 -- the same four neurons
+//     four times over -- and keeps r = q: every lane owns ONE (neuron 16*tile + 4g + q, chunk c) pair, 64 lanes = 16 neurons x
+//     4 chunks, so gate arithmetic is one value per lane and tile, on all 64 lanes.
+//   * chain wave w owns neurons 32w .. 32w+31 (tiles 2w, 2w+1) for z, r AND the candidate: h, z, r of a (neuron, chunk) pair
+//     live in one lane's registers; only the MFMA operands travel.
+//   * the order of k inside a 32-wide K block is free (A and B only have to agree): k-block w is exactly what wave w
+//     produces, laid out so that a lane's two values (tiles 2w, 2w+1) are adjacent halves -> ONE ds_write_b32 for the hi
+//     image and one for the lo image per exchange; readers fetch their B operand as one ds_read_b128 per K block and image.
+//
+// Waves: 0 .. N/32-1 chain (raised priority), 4-7 projection / x DMA / h_out copies exactly as in gru_fused.hip, coupled by
+// LDS progress counters (lds_flags.h), no s_barrier after start-up.
+// Accuracy: |h| <= 1, |r.h| <= 1 and trained |w| <= ~6 are far inside fp16 range; hi + lo carries 22 bits, the dropped
+// lo.lo term is < 2^-22 relative.  x (unbounded: the first layer reads an elu convolution) is scaled per row by a power of two
+// before its split (XSCALE below).  Callers that need plain fp32 arithmetic use gru_fused.hip / the two-kernel path.
+#include <limits.h>
+
+#include "lds_flags.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void keep(half8 &v) { asm volatile("" : "+v"(v)); }
+
+__device__ __forceinline__ float sel4(const f32x4 &a, int q)
+{
+    const float lo = (q & 1) ? a[1] : a[0];
+    const float hi = (q & 1) ? a[3] : a[2];
+    return (q & 2) ? hi : lo;
+}
+
+// two float32 -> one dword of fp16 "hi" parts and one of fp16 "lo" parts (v = hi + lo)
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
+{
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+    half2_t h = {ha, hb}, l = {la, lb};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// acc += W . h as a 3-term split; small terms first so that they are not absorbed by the large one
+__device__ __forceinline__ f32x4 mfma3(const half8 &w_hi, const half8 &w_lo, const half8 &h_hi, const half8 &h_lo, f32x4 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi, h_lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo, h_hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi, h_hi, acc, 0, 0, 0);
+    return acc;
+}
+
+// SAVE (training, sloika_amd/train.py): the activated gates z | r of every step are also written to zr_out[(t*B + b)][2N].
+template <int I, int N, bool SAVE>
+__global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__restrict__ x, long ldx,
+                                                             const float *__restrict__ iW, const float *__restrict__ bias,
+                                                             const float *__restrict__ sW, const float *__restrict__ sW2,
+                                                             float *__restrict__ h_out, long ldh, int T, int B, int reverse,
+                                                             const int *__restrict__ lens, float *__restrict__ zr_out)
+{
+    static_assert(I % 16 == 0 && N % 32 == 0 && N <= 96, "unsupported size for the fp16-split fused GRU kernel");
+    constexpr int NCW = N / 32;                          // chain waves = 32-wide K blocks of the recurrent products
+    constexpr int KBS = N / 32;
+    // ---------------- projection role constants (as gru_fused.hip) ----------------
+    constexpr int NT16 = 3 * N / 16;                     // tiles of vI rows
+    constexpr int NTW = (NT16 + 3) / 4;                  // tiles per proj wave (tile pw + 4*i; the last may be absent)
+    constexpr int KBLK = (I + 31) / 32;
+    constexpr int GS = 4;                                // time steps per projection group
+    // ---------------- LDS ----------------
+    constexpr int KB = 8;                                // steps per x block / per h_out block
+    constexpr int R = 2 * GS;                            // vI ring: the projection works one group of steps ahead
+    constexpr int XIMG = 4 * I;                          // floats of one step's x image: [k/4][chunk][k%4]
+    constexpr int XPIECES = KB * I;                      // 16-byte pieces per x block
+    constexpr int NDMA = (XPIECES / 64 + 3) / 4;
+    constexpr int HSLOTS = 3 * KB, HIMG = 4 * N;         // float32 state history [slot][neuron][chunk] = h_out staging
+    __shared__ __attribute__((aligned(16))) float xbuf[2 * KB * XIMG];
+    __shared__ __attribute__((aligned(16))) float vbuf[R * 3 * N * 4];      // vI[slot][row][chunk]
+    __shared__ __attribute__((aligned(16))) float hring[HSLOTS * HIMG];
+    // MFMA B-operand images of h and r*h: [k block][k group 4][chunk 4][8 halves], hi and lo parts
+    __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * N], h_lo[2 * N], rh_hi[2 * N], rh_lo[2 * N];
+    __shared__ float bias_lds[3 * N];
+    __shared__ __attribute__((aligned(64))) int flags[16];
+    __shared__ __attribute__((aligned(64))) int xflags[16];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b0 = blockIdx.x * 4;
+    const int cls = (lane & 15) >> 2;                    // which counter group this lane watches when polling
+
+    for (int i = tid; i < 2 * N; i += 512) { h_hi[i] = 0u; h_lo[i] = 0u; }             // h(-1) = 0
+    for (int i = tid; i < 3 * N; i += 512) bias_lds[i] = bias ? bias[i] : 0.0f;
+    if (tid < 16) {
+        // counters: 0-3 fA (r*h of step s published -> s+1), 4-7 fB (h of step s -> s+1), 8-11 vready, 12-15 flushed;
+        // chain waves that do not exist never hold anyone up
+        const int idx = tid & 3, grp = tid >> 2;
+        flags[tid] = (grp < 2 && idx >= NCW) ? INT_MAX : 0;
+        xflags[tid] = 0;
+    }
+    __syncthreads();                                     // the only hardware barrier
+
+    if (wave < 4) {
+        if (wave >= NCW) return;
+        // =================================================================================================
+        // chain waves
+        // =================================================================================================
+        const int w = wave;
+        const int c = lane & 3, q = (lane >> 2) & 3, g = lane >> 4;
+        // A operands: lane supplies row i = lane & 15 of a tile and, for k group g, elements j = 0..7 of a K block, where
+        // element (g, j) of block kb is neuron 32*kb + 16*(j&1) + 4*g + (j>>1) -- the order the owners' packed writes create.
+        // K blocks are visited in the rotated order w, w+1, ...: the wave's own block first (no handshake needed).
+        half8 wz_hi[2][KBS], wz_lo[2][KBS], wr_hi[2][KBS], wr_lo[2][KBS], wc_hi[2][KBS], wc_lo[2][KBS];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int row = 32 * w + 16 * p + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < KBS; i++) {
+                const int kb = (w + i) % KBS;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = 32 * kb + 16 * (j & 1) + 4 * g + (j >> 1);
+                    const float vz = sW[(size_t)row * N + k], vr = sW[(size_t)(N + row) * N + k], vc = sW2[(size_t)row * N + k];
+                    const _Float16 hz = (_Float16)vz, hr = (_Float16)vr, hc = (_Float16)vc;
+                    wz_hi[p][i][j] = hz; wz_lo[p][i][j] = (_Float16)(vz - (float)hz);
+                    wr_hi[p][i][j] = hr; wr_lo[p][i][j] = (_Float16)(vr - (float)hr);
+                    wc_hi[p][i][j] = hc; wc_lo[p][i][j] = (_Float16)(vc - (float)hc);
+                }
+            }
+        }
+        // B operand of K block kb: 16-byte piece (kb*4 + g)*4 + c of an image (the same piece for every q)
+        int boff[KBS];
+#pragma unroll
+        for (int i = 0; i < KBS; i++) boff[i] = ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
+        const int wd = ((w * 4 + g) * 4 + c) * 4 + q;                                           // my packed pair, in dwords
+        const int n0 = 32 * w + 4 * g + q;                                                      // my neuron of tile 2w (+16: 2w+1)
+        auto ldB = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
+
+        __builtin_amdgcn_s_setprio(3);      // the serial chain goes first; projection MFMAs fill its gaps
+        constexpr int NOWATCH = INT_MIN / 2;
+        const int offH = cls == 1 ? 0 : NOWATCH;             // h(s-1) complete:   fB >= s
+        const int offRH = cls == 0 ? 1 : NOWATCH;            // r*h of step s:     fA >= s+1
+        const bool watch_flush = cls == 3;
+        const int offV = cls == 2 ? 2 : NOWATCH;             // vI(s+1) written:   vready >= s+2
+
+        float hold[2] = {0.0f, 0.0f};
+        float vz[2], vr[2], vc[2];                           // vI rows of my two neurons, read one step ahead
+        for (;;) {                                           // vI(0)
+            const int f = poll_issue(flags, lane);
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                vz[p] = vbuf[4 * (n0 + 16 * p) + c];
+                vr[p] = vbuf[4 * (N + n0 + 16 * p) + c];
+                vc[p] = vbuf[4 * (2 * N + n0 + 16 * p) + c];
+            }
+            const bool ok = poll_result(f, cls == 2 ? 1 : NOWATCH);
+#pragma unroll
+            for (int p = 0; p < 2; p++) { keep(vz[p]); keep(vr[p]); keep(vc[p]); }
+            if (ok) break;
+        }
+
+        for (int s = 0; s < T; s++) {
+            const int needH = s + offH, needRH = s + offRH;
+            const int needV = watch_flush ? (s + 1) / KB - 2 : s + offV;
+            half8 bh[KBS], bl[KBS];
+            f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+            // ---------------- r | z: products with h(s-1) ----------------
+            // own K block: my own (ordered) writes; the others' blocks are requested at the same time and checked after the
+            // own block's twelve MFMAs, which hide the round trip
+            bh[0] = ldB(h_hi, boff[0]);
+            bl[0] = ldB(h_lo, boff[0]);
+            int f = poll_issue(flags, lane);
+#pragma unroll
+            for (int i = 1; i < KBS; i++) { bh[i] = ldB(h_hi, boff[i]); bl[i] = ldB(h_lo, boff[i]); }
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (KBS - 1) + 1) : "memory");          // own block has landed
+            keep(bh[0]); keep(bl[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 2; p++) accR[p] = mfma3(wr_hi[p][0], wr_lo[p][0], bh[0], bl[0], accR[p]);
+#pragma unroll
+            for (int p = 0; p < 2; p++) accZ[p] = mfma3(wz_hi[p][0], wz_lo[p][0], bh[0], bl[0], accZ[p]);
+            if constexpr (KBS > 1) {
+                bool ok = poll_result(f, needH);
+#pragma unroll
+                for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
+                while (!ok) {
+                    f = poll_issue(flags, lane);
+#pragma unroll
+                    for (int i = 1; i < KBS; i++) { bh[i] = ldB(h_hi, boff[i]); bl[i] = ldB(h_lo, boff[i]); }
+                    ok = poll_result(f, needH);
+#pragma unroll
+                    for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 1; i < KBS; i++)
+#pragma unroll
+                    for (int p = 0; p < 2; p++) accR[p] = mfma3(wr_hi[p][i], wr_lo[p][i], bh[i], bl[i], accR[p]);
+#pragma unroll
+                for (int i = 1; i < KBS; i++)
+#pragma unroll
+                    for (int p = 0; p < 2; p++) accZ[p] = mfma3(wz_hi[p][i], wz_lo[p][i], bh[i], bl[i], accZ[p]);
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f)::"memory");
+            }
+            // r, r*h -> operand images of the candidate product (the z MFMAs above execute underneath this arithmetic)
+            float rr[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) rr[p] = slk_sigmoid(sel4(accR[p], q) + vr[p]);
+            {
+                unsigned hi, lo;
+                split2(rr[0] * hold[0], rr[1] * hold[1], hi, lo);
+                rh_hi[wd] = hi;
+                rh_lo[wd] = lo;
+            }
+            publish(flags, w, s + 1, lane);
+            if constexpr (SAVE) {
+                const size_t trow = (size_t)(reverse ? T - 1 - s : s) * B + b0 + c;
+                if (b0 + c < B) {
+                    zr_out[trow * (2 * N) + N + n0] = rr[0];
+                    zr_out[trow * (2 * N) + N + n0 + 16] = rr[1];
+                }
+            }
+
+            // ---------------- candidate: products with r*h ----------------
+            f32x4 accC[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            half8 ch[KBS], cl[KBS];
+            ch[0] = ldB(rh_hi, boff[0]);
+            cl[0] = ldB(rh_lo, boff[0]);
+            f = poll_issue(flags, lane);
+#pragma unroll
+            for (int i = 1; i < KBS; i++) { ch[i] = ldB(rh_hi, boff[i]); cl[i] = ldB(rh_lo, boff[i]); }
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (KBS - 1) + 1) : "memory");
+            keep(ch[0]); keep(cl[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 2; p++) accC[p] = mfma3(wc_hi[p][0], wc_lo[p][0], ch[0], cl[0], accC[p]);
+            // the update gate, needed only at the end of the step
+            float zz[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) zz[p] = slk_sigmoid(sel4(accZ[p], q) + vz[p]);
+            if constexpr (KBS > 1) {
+                bool ok = poll_result(f, needRH);
+#pragma unroll
+                for (int i = 1; i < KBS; i++) { keep(ch[i]); keep(cl[i]); }
+                while (!ok) {
+                    f = poll_issue(flags, lane);
+#pragma unroll
+                    for (int i = 1; i < KBS; i++) { ch[i] = ldB(rh_hi, boff[i]); cl[i] = ldB(rh_lo, boff[i]); }
+                    ok = poll_result(f, needRH);
+#pragma unroll
+                    for (int i = 1; i < KBS; i++) { keep(ch[i]); keep(cl[i]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 1; i < KBS; i++)
+#pragma unroll
+                    for (int p = 0; p < 2; p++) accC[p] = mfma3(wc_hi[p][i], wc_lo[p][i], ch[i], cl[i], accC[p]);
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f)::"memory");
+            }
+            // vI(s+1), one step ahead (its latency disappears behind the candidate chain)
+            const float *vnext = vbuf + ((s + 1) % R) * (3 * N * 4);
+            const bool more = s + 1 < T;
+            int fv = 0;
+            float vzn[2] = {vz[0], vz[1]}, vrn[2] = {vr[0], vr[1]}, vcn[2] = {vc[0], vc[1]};
+            auto read_vnext = [&] {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    vzn[p] = vnext[4 * (n0 + 16 * p) + c];
+                    vrn[p] = vnext[4 * (N + n0 + 16 * p) + c];
+                    vcn[p] = vnext[4 * (2 * N + n0 + 16 * p) + c];
+                }
+            };
+            if (more) {
+                fv = poll_issue(flags, lane);
+                read_vnext();
+            }
+            if constexpr (SAVE) {
+                const size_t trow = (size_t)(reverse ? T - 1 - s : s) * B + b0 + c;
+                if (b0 + c < B) {
+                    zr_out[trow * (2 * N) + n0] = zz[0];
+                    zr_out[trow * (2 * N) + n0 + 16] = zz[1];
+                }
+            }
+            float hn[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const float hbar = slk_tanh(sel4(accC[p], q) + vc[p]);
+                hn[p] = zz[p] * hold[p] + (1.0f - zz[p]) * hbar;              // layers.py:1020
+            }
+            if (more) {                                      // long since answered; checked before the writes below queue up
+                bool ok = poll_result(fv, needV);
+#pragma unroll
+                for (int p = 0; p < 2; p++) { keep(vzn[p]); keep(vrn[p]); keep(vcn[p]); }
+                while (!ok) {
+                    const int f2 = poll_issue(flags, lane);
+                    read_vnext();
+                    ok = poll_result(f2, needV);
+#pragma unroll
+                    for (int p = 0; p < 2; p++) { keep(vzn[p]); keep(vrn[p]); keep(vcn[p]); }
+                }
+            }
+            {
+                unsigned hi, lo;
+                split2(hn[0], hn[1], hi, lo);
+                h_hi[wd] = hi;
+                h_lo[wd] = lo;
+                float *hcur = hring + (s % HSLOTS) * HIMG;
+                hcur[4 * n0 + c] = hn[0];
+                hcur[4 * (n0 + 16) + c] = hn[1];
+            }
+            publish(flags, 4 + w, s + 1, lane);
+#pragma unroll
+            for (int p = 0; p < 2; p++) { hold[p] = hn[p]; vz[p] = vzn[p]; vr[p] = vrn[p]; vc[p] = vcn[p]; }
+        }
+    } else {
+        // =================================================================================================
+        // projection waves (vI = x.iW^T + b four steps at a time, x DMA, h_out copies)
+        // =================================================================================================
+        const int pw = wave - 4;
+        const int col = lane & 15, kq = lane >> 4;
+        constexpr bool LAST_MAYBE = (NT16 % 4) != 0;        // the last tile slot exists only for some waves
+        const bool last_ok = pw + 4 * (NTW - 1) < NT16;
+        // B operands: lane holds vI row 16*t + col, k = 32*kb + 8*kq + 0..7, as fp16 hi and lo parts
+        half8 whi[NTW][KBLK], wlo[NTW][KBLK];
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const bool ok = (i < NTW - 1) || !LAST_MAYBE || last_ok;
+            const int row = ok ? 16 * (pw + 4 * i) + col : 0;
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+                const int k0 = 32 * kb + 8 * kq;
+                const bool kok = ok && (I % 32 == 0 || k0 < I);
+                const float *src = iW + (size_t)row * I + (kok ? k0 : 0);
+                const float4 u0 = *reinterpret_cast<const float4 *>(src), u1 = *reinterpret_cast<const float4 *>(src + 4);
+                const float u[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float v = kok ? u[j] : 0.0f;
+                    const _Float16 h = (_Float16)v;
+                    whi[i][kb][j] = h;
+                    wlo[i][kb][j] = (_Float16)(v - (float)h);
+                }
+            }
+        }
+        // A operands: lane supplies row m = lane & 15 = (step in group, chunk) and k = 32*kb + 8*kq + 0..7 from the
+        // step's x image, where element x[chunk][k] sits at 16*(k>>2) + 4*chunk + (k&3)
+        const int a_step = col >> 2, a_chunk = col & 3;
+        auto dma_block = [&](int s0, int slot) {
+#pragma unroll
+            for (int j = 0; j < NDMA; j++) {
+                const int piece0 = (j * 4 + pw) * 64;
+                if (piece0 < XPIECES) {
+                    const int p = piece0 + lane;
+                    const int kk = p / I, pp = p % I, qq = pp >> 2, cc = pp & 3;
+                    const int bc = min(b0 + cc, B - 1);
+                    // ragged batch: chunk bc is Tc <= T steps long; a reversed scan starts at ITS last step, and the
+                    // steps past the end re-read the last valid row (their results are never stored)
+                    const int Tc = lens ? min(max(lens[bc], 1), T) : T;
+                    const int ss = min(s0 + kk, Tc - 1);
+                    const int tt = reverse ? Tc - 1 - ss : ss;
+                    const float *src = x + ((size_t)tt * B + bc) * ldx + 4 * qq;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)&xbuf[slot * (KB * XIMG) + piece0 * 4],
+                                                     16, 0, 0);
+                }
+            }
+        };
+        const bool vec_store = (ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
+        constexpr int OF4 = KB * N;                         // float4s per block
+        constexpr int NFL = (OF4 + 255) / 256;              // parts per block
+        auto flush_part = [&](int kb, int j) {
+            const int idx = (tid - 256) + 256 * j;
+            const int cc = idx & 3, rest = idx >> 2, f4 = rest % (N / 4), kk = rest / (N / 4);
+            const int ss = kb * KB + kk;
+            const int Tc = (lens && b0 + cc < B) ? min(max(lens[b0 + cc], 1), T) : T;
+            if (idx < OF4 && ss < Tc && b0 + cc < B) {
+                const float *src = hring + (ss % HSLOTS) * HIMG + 16 * f4 + cc;
+                const float v0 = src[0], v1 = src[4], v2 = src[8], v3 = src[12];
+                const int tt = reverse ? Tc - 1 - ss : ss;
+                float *dst = h_out + ((size_t)tt * B + b0 + cc) * ldh + 4 * f4;
+                if (vec_store) *reinterpret_cast<float4 *>(dst) = make_float4(v0, v1, v2, v3);
+                else { dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3; }
+            }
+        };
+        auto wait_flags = [&](int group, int value) {       // every counter of `group` (0 fA, 1 fB) >= value
+            const int need = cls == group ? value : INT_MIN;
+            while (!reached(flags, lane, need)) __builtin_amdgcn_s_sleep(1);
+        };
+        auto wait_xflags = [&](int group, int value) {      // group 0 xready, 1 xdone (lanes watch xflags[l & 15], 8..15 stay 0)
+            const int need = cls == group ? value : INT_MIN;
+            while (!reached(xflags, lane, need)) __builtin_amdgcn_s_sleep(1);
+        };
+
+        dma_block(0, 0);
+        const int NG = (T + GS - 1) / GS;
+        for (int qg = 0; qg < NG; qg++) {
+            if ((qg & 1) == 0) {                                        // KB = 2 groups: a new x block starts here
+                const int xb = qg / 2;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my share of block xb (issued a block ago) landed
+                publish(xflags, pw, xb + 1, lane);
+                publish(xflags, 4 + pw, xb, lane);                      // and I am done reading block xb-1
+                if ((xb + 1) * KB < T) {
+                    wait_xflags(1, xb);                                 // slot (xb+1)&1 held block xb-1: everyone past it
+                    dma_block((xb + 1) * KB, (xb + 1) & 1);
+                }
+                wait_xflags(0, xb + 1);
+            } else if (qg >= 3) {
+                // copy a finished block of states out (vI is published through step 4qg-1, block fkb ends at step 4qg-5)
+                const int fkb = (qg - 3) / 2;
+                wait_flags(1, (fkb + 1) * KB);
+                for (int j = 0; j < NFL; j++) flush_part(fkb, j);
+                publish(flags, 12 + pw, fkb + 1, lane);
+            }
+            // ---- the group's A operands (x split into halves on the fly; XSCALE: each row scaled by a power of two so that
+            //      its largest |x| lies in [1, 2) -- exact, undone on the accumulators), then every tile's three MFMAs ----
+            const float *img = xbuf + ((qg >> 1) & 1) * (KB * XIMG) + (GS * (qg & 1) + a_step) * XIMG + 4 * a_chunk;
+            f32x4 xu[KBLK][2];
+            float amax = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+                const int k0 = 32 * kb + 8 * kq;
+                const bool kok = (I % 32 == 0) || k0 < I;
+                const float *src = img + 4 * (kok ? k0 : 0);           // 16 * (k0 / 4)
+                xu[kb][0] = *reinterpret_cast<const f32x4 *>(src);
+                xu[kb][1] = *reinterpret_cast<const f32x4 *>(src + 16);
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (!kok) xu[kb][j >> 2][j & 3] = 0.0f;
+                    amax = fmaxf(amax, fabsf(xu[kb][j >> 2][j & 3]));
+                }
+            }
+            // row maximum: the row's K is spread over the four k groups (lanes m, m+16, m+32, m+48)
+            amax = fmaxf(amax, __shfl_xor(amax, 16));
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            // scale = 2^(127 - e), inverse 2^(e - 127), e = biased exponent of the row maximum, kept inside [27, 227] so that
+            // both are normal numbers (rows that small or that large are beyond any network's activations)
+            const int e = min(max((int)((__float_as_uint(amax) >> 23) & 0xff), 27), 227);
+            const float xs = __uint_as_float((unsigned)(254 - e) << 23), xinv = __uint_as_float((unsigned)e << 23);
+            // the accumulator rows of this lane are (step kq, chunk 0..3): their inverse scales sit in lanes 4*kq + (0..3)
+            f32x4 inv;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) inv[r4] = __shfl(xinv, 4 * kq + r4);
+            f32x4 acc[NTW];
+#pragma unroll
+            for (int i = 0; i < NTW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+                half8 ahi, alo;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float v = xu[kb][j >> 2][j & 3] * xs;
+                    const _Float16 h = (_Float16)v;
+                    ahi[j] = h;
+                    alo[j] = (_Float16)(v - (float)h);
+                }
+#pragma unroll
+                for (int i = 0; i < NTW; i++) {
+                    if (i < NTW - 1 || !LAST_MAYBE || last_ok) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wlo[i][kb], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, whi[i][kb], acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, whi[i][kb], acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            // the group's ring slots were last read during steps GS*qg - R ... GS*qg + GS-1 - R
+            if (GS * qg + GS > R) wait_flags(0, GS * qg + GS - R);
+            // D: lane holds the four chunks of (step GS*qg + kq, vI row 16*t + col) = one 16-byte entry of vbuf
+            const int st = GS * qg + kq;
+            if (st < T) {
+                float *vdst = vbuf + (st % R) * (3 * N * 4) + 4 * col;
+#pragma unroll
+                for (int i = 0; i < NTW; i++)
+                    if (i < NTW - 1 || !LAST_MAYBE || last_ok) {
+                        const float tb = bias_lds[16 * (pw + 4 * i) + col];
+                        f32x4 o;
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; r4++) o[r4] = fmaf(acc[i][r4], inv[r4], tb);
+                        *reinterpret_cast<f32x4 *>(&vdst[64 * (pw + 4 * i)]) = o;
+                    }
+            }
+            publish(flags, 8 + pw, GS * qg + GS, lane);
+        }
+        // blocks of states the loop did not copy out
+        wait_flags(1, T);
+        const int kbl = (T - 1) / KB;
+        for (int kb = 0; kb <= kbl; kb++)
+            if (2 * kb + 3 >= NG)
+                for (int j = 0; j < NFL; j++) flush_part(kb, j);
+    }
+}
+
+// One workgroup per CU (see gru_fused.hip): ask for enough dynamic LDS that two cannot share a CU.
+template <typename K>
+static size_t exclusive_cu_lds16(K kernel)
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) != hipSuccess) return 0;
+    const size_t half_cu = 80 * 1024 + 512;                         // 160 KB of LDS per CU
+    const size_t dyn = attr.sharedSizeBytes >= half_cu ? 0 : half_cu - attr.sharedSizeBytes;
+    if (dyn && hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)dyn) != hipSuccess)
+        return 0;
+    return dyn;
+}
+
+template <int I, int N>
+static int launch_fused16(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
+                          float *y, long ldy, int T, int B, int reverse, const int *lens, float *zr_out, hipStream_t s)
+{
+    if (zr_out) {
+        static const size_t dyn = exclusive_cu_lds16(gru_fused16_kernel<I, N, true>);
+        hipLaunchKernelGGL((gru_fused16_kernel<I, N, true>), dim3((B + 3) / 4), dim3(512), dyn, s, x, ldx, iW, bias, sW, sW2, y,
+                           ldy, T, B, reverse & 1, lens, zr_out);
+    } else {
+        static const size_t dyn = exclusive_cu_lds16(gru_fused16_kernel<I, N, false>);
+        hipLaunchKernelGGL((gru_fused16_kernel<I, N, false>), dim3((B + 3) / 4), dim3(512), dyn, s, x, ldx, iW, bias, sW, sW2, y,
+                           ldy, T, B, reverse & 1, lens, zr_out);
+    }
+    return slk_launch_status();
+}
+
+// Whole Gru layer with projection AND recurrence as 3-term fp16 splits (float32 accumulation).  lens: NULL or the ragged
+// lengths (see slk_gru_fused_ragged_f32); zr_out: NULL or [T*B][2n] for the activated gates (training forward pass).
+// SLK_ERR_UNSUPPORTED when no instantiation covers the request: the caller falls back to slk_gru_fused_f32 (fp32 recurrence).
+extern "C" int slk_gru_fused16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
+                                   const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse,
+                                   int act, int gate_act, const int32_t *lens, float *zr_out, slk_stream_t stream)
+{
+    if (!x || !iW || !sW || !sW2 || !y || T < 1 || B < 1 || insize < 1 || n < 1 || ldx < insize || ldy < n)
+        return SLK_ERR_INVALID_ARG;
+    if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
+    if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;   // 16-byte DMA pieces
+    hipStream_t s = slk_stream(stream);
+#define FUSED16(II, NN) \
+    if (insize == II && n == NN) return launch_fused16<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s);
+    FUSED16(96, 96) FUSED16(64, 64) FUSED16(32, 96) FUSED16(128, 96) FUSED16(64, 96) FUSED16(48, 32) FUSED16(16, 64)
+#undef FUSED16
+    return SLK_ERR_UNSUPPORTED;
+}

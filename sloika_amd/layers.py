@@ -41,6 +41,7 @@ class Shared(object):
         self._value = np.ascontiguousarray(value, dtype=sloika_dtype)
         self._dev = None
         self._device_is_master = False
+        self._version = 0                    # bumped by every set_value: caches derived from the value key on it
 
     def _pull(self):
         if getattr(self, "_device_is_master", False) and self._dev is not None:
@@ -52,6 +53,7 @@ class Shared(object):
 
     def set_value(self, value, borrow=False):
         value = np.ascontiguousarray(value, dtype=sloika_dtype)
+        self._version = getattr(self, "_version", 0) + 1
         if getattr(self, "_device_is_master", False) and self._dev is not None and value.shape == tuple(self._dev.shape):
             import torch
             self._dev.copy_(torch.from_numpy(value))         # keep the optimiser's flat buffer as the storage
@@ -78,6 +80,7 @@ class Shared(object):
         self._value = np.ascontiguousarray(state["_value"], dtype=sloika_dtype)
         self._dev = None
         self._device_is_master = False
+        self._version = 0
 
 
 def shared(value):
@@ -100,6 +103,30 @@ def _stream():
 #: FP16 matrix pipe as a 3-term split of every float32 operand (csrc/gemm_rows_f16x3.hip: float32 accumulation, error a few
 #: float32 ulps, ~5x the fp32-MFMA rate).  SLOIKA_AMD_EXACT_F32=1 selects plain fp32 MFMA everywhere.
 SPLIT_F16 = os.environ.get("SLOIKA_AMD_EXACT_F32", "0") != "1"
+
+
+#: The recurrent products of a fused Gru layer also run as 3-term fp16 splits (csrc/gru_fused16.hip) unless
+#: SLOIKA_AMD_RECURRENT_F32=1 asks for the exact-fp32 recurrence of csrc/gru_fused.hip (SLOIKA_AMD_EXACT_F32=1 implies it).
+RECURRENT_F16 = os.environ.get("SLOIKA_AMD_RECURRENT_F32", "0") != "1"
+
+#: fp16 halves overflow at 65504: weights whose magnitude reaches 2^15 (or are not finite) never take a split path.
+F16_SPLIT_LIMIT = 32768.0
+
+
+def _f16_safe(owner, params):
+    """True when every weight of `params` is finite and below F16_SPLIT_LIMIT in magnitude, i.e. its fp16 hi/lo split is
+    exact to 22 bits.  One device reduction + host read per weight UPDATE (cached on the identity of the device tensors and
+    on the optimiser's step counter), never per call."""
+    import torch
+    devs = tuple(p.dev() for p in params)
+    stamp = tuple(getattr(p, "_version", 0) for p in params)
+    cache = owner.__dict__.get("_f16_ok")
+    if cache is not None and len(cache[0]) == len(devs) and all(a is b for a, b in zip(cache[0], devs)) and cache[1] == stamp:
+        return cache[2]
+    worst = max(float(torch.nan_to_num(d.abs().max(), nan=float("inf")).item()) for d in devs)
+    ok = worst < F16_SPLIT_LIMIT
+    owner.__dict__["_f16_ok"] = (devs, stamp, ok)
+    return ok
 
 
 def _split_f16_cached(owner, attr, param, rows, k):
@@ -751,9 +778,10 @@ class Gru(RNN):
         kernels are instantiated for).  Padding neurons see zero weights and zero bias, so their state stays exactly 0
         (h0 = 0, candidate = fun(0) = 0 for tanh-like fun) and padded input columns multiply zero weights: the first
         `size` outputs are those of the unpadded layer.  Cached until a parameter changes."""
-        key = tuple(id(p.dev()) for p in (self.iW, self.sW, self.sW2, self.b))
+        # the cache holds the device tensors themselves (an id() of a freed tensor can be reused by its successor)
+        key = tuple(p.dev() for p in (self.iW, self.sW, self.sW2, self.b))
         cache = getattr(self, "_pad_cache", None)
-        if cache is not None and cache[0] == key:
+        if cache is not None and all(a is b for a, b in zip(cache[0], key)):
             return cache[1]
         n, i = self.size, self.insize
         n16, i16 = (n + 15) // 16 * 16, (i + 15) // 16 * 16
@@ -774,6 +802,7 @@ class Gru(RNN):
         d = dict(self.__dict__)
         d.pop("_pad_cache", None)
         d.pop("_iw16", None)         # device caches: never pickled
+        d.pop("_f16_ok", None)
         return d
 
     def _forward(self, x, out, reverse):
@@ -803,22 +832,36 @@ class Gru(RNN):
             raise ValueError("ragged lengths do not match the batch")
         # one persistent kernel (projection waves + recurrent waves) where an instantiation exists (its projection half
         # runs as an fp16 3-term split, so SLOIKA_AMD_EXACT_F32=1 takes the two-kernel all-fp32 path instead) ...
-        if SPLIT_F16:
-            with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
-                                 f16x3_flops=6.0 * rows * n * self.insize) as reg:
-                if lens is None:
-                    rc = L.slk_gru_fused_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
-                                             self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
-                                             y.data_ptr(), _row_stride(y), T, B, self.insize, n, int(reverse),
-                                             activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
-                else:
-                    rc = L.slk_gru_fused_ragged_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
-                                                    self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
-                                                    self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), T, B,
-                                                    self.insize, n, int(reverse), activation.act_id(self.fun),
-                                                    activation.act_id(self.gatefun), lens.data_ptr(), _stream())
-                if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
-                    reg.cancel()
+        if SPLIT_F16 and _f16_safe(self, (self.iW, self.sW, self.sW2)):
+            rc = _lib.SLK_ERR_UNSUPPORTED
+            if RECURRENT_F16:
+                # projection AND recurrence as 3-term fp16 splits (csrc/gru_fused16.hip)
+                with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
+                                     f16x3_flops=6.0 * rows * n * (n + self.insize)) as reg:
+                    rc = L.slk_gru_fused16_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
+                                               self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
+                                               y.data_ptr(), _row_stride(y), T, B, self.insize, n, int(reverse),
+                                               activation.act_id(self.fun), activation.act_id(self.gatefun),
+                                               None if lens is None else lens.data_ptr(), None, _stream())
+                    if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
+                        reg.cancel()
+            if rc == _lib.SLK_ERR_UNSUPPORTED:
+                # fp32 recurrence (v_mfma_f32_4x4x1), projection as a 3-term fp16 split (csrc/gru_fused.hip)
+                with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
+                                     f16x3_flops=6.0 * rows * n * self.insize) as reg:
+                    if lens is None:
+                        rc = L.slk_gru_fused_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
+                                                 self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
+                                                 y.data_ptr(), _row_stride(y), T, B, self.insize, n, int(reverse),
+                                                 activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
+                    else:
+                        rc = L.slk_gru_fused_ragged_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
+                                                        self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
+                                                        self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), T, B,
+                                                        self.insize, n, int(reverse), activation.act_id(self.fun),
+                                                        activation.act_id(self.gatefun), lens.data_ptr(), _stream())
+                    if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
+                        reg.cancel()
             if rc != _lib.SLK_ERR_UNSUPPORTED:
                 _lib.check(rc, "Gru")
                 return y

@@ -209,7 +209,7 @@ class TrainingStep(object):
         """Device copies derived from the parameters (fp16 splits, padded twins) are keyed on the identity of the
         parameter's device tensor, which no longer changes when the optimiser writes in place: forget them."""
         for layer in [leaf for sub in self.body for leaf in _leaves(sub)] + [self.softmax]:
-            for attr in ("_w16", "_iw16", "_pad_cache"):
+            for attr in ("_w16", "_iw16", "_pad_cache", "_f16_ok"):
                 layer.__dict__.pop(attr, None)
             # (a Gru whose forward pass runs a zero-padded twin rebuilds it from get_value(), which reads the device copy)
 

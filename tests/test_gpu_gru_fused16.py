@@ -1,0 +1,191 @@
+"""csrc/gru_fused16.hip -- whole Gru layer with projection AND recurrence as 3-term fp16 splits -- through the C ABI, against
+the oracle (float32 C port, itself pinned to the reference's layers.py by tests/test_oracle_reference_layers.py)."""
+import numpy as np
+import pytest
+
+from tests.gpu_util import need_gpu, dev, stream
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+SHAPES = [(96, 96), (64, 64), (32, 96), (128, 96), (64, 96), (48, 32), (16, 64)]
+
+
+def _params(rs, I, n, bias=True, scale=1.0):
+    iW = (rs.normal(size=(3 * n, I)) / np.sqrt(I + n)).astype(np.float32)
+    sW = (scale * rs.normal(size=(2 * n, n)) / np.sqrt(2 * n)).astype(np.float32)
+    sW2 = (scale * rs.normal(size=(n, n)) / np.sqrt(2 * n)).astype(np.float32)
+    b = rs.normal(size=3 * n).astype(np.float32) if bias else None
+    return iW, sW, sW2, b
+
+
+def _call(L, x, ldx, iW, sW, sW2, b, y, ldy, T, B, I, n, reverse, lens=None, zr=None):
+    return L.slk_gru_fused16_f32(x, ldx, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), None if b is None else b.data_ptr(),
+                                 y, ldy, T, B, I, n, int(reverse), 1, 2, None if lens is None else lens.data_ptr(),
+                                 None if zr is None else zr.data_ptr(), stream())
+
+
+@pytest.mark.parametrize("I,n", SHAPES)
+@pytest.mark.parametrize("T,B,reverse", [(23, 9, False), (8, 4, True), (3, 2, False), (1, 1, True), (41, 5, True)])
+def test_fused16_vs_oracle(oracle, I, n, T, B, reverse):
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(I + n + T)
+    iW, sW, sW2, b = _params(rs, I, n, scale=2.0)
+    x = rs.normal(size=(T, B, I)).astype(np.float32)
+    ref = oracle.gru(x, iW, sW, sW2, b, reverse=reverse)
+    xd, iWd, sWd, sW2d, bd = dev(x), dev(iW), dev(sW), dev(sW2), dev(b)
+    y = torch.full((T, B, n), np.nan, dtype=torch.float32, device="cuda")
+    assert _call(L, xd.data_ptr(), I, iWd, sWd, sW2d, bd, y.data_ptr(), n, T, B, I, n, reverse) == 0
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err < 2e-5, err                          # float32-grade: the exact-fp32 kernels measure ~2e-6 here
+    # no bias + strided input/output rows (slices of wider tensors, as birnn produces them)
+    xw = torch.zeros((T, B, I + 16), device="cuda")
+    xw[:, :, 8:8 + I] = xd
+    yw = torch.full((T, B, n + 8), -5.0, device="cuda")
+    assert _call(L, xw.data_ptr() + 8 * 4, I + 16, iWd, sWd, sW2d, None, yw.data_ptr() + 4 * 4, n + 8, T, B, I, n, reverse) == 0
+    out = yw.cpu().numpy()
+    np.testing.assert_allclose(out[:, :, 4:4 + n], oracle.gru(x, iW, sW, sW2, None, reverse=reverse), atol=2e-5)
+    assert (out[:, :, :4] == -5.0).all() and (out[:, :, 4 + n:] == -5.0).all()
+
+
+@pytest.mark.parametrize("xmag", [1e-7, 1e-3, 1e3, 1e5, 3e7])
+def test_fused16_input_magnitudes(oracle, xmag):
+    """The fp16 halves of the projection's x are taken AFTER a per-row power-of-two scaling: inputs far outside fp16's
+    range (65504) or below its normal range (6e-5) keep float32-grade accuracy.  Weights scaled inversely so that the
+    gates are exercised, not saturated."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    I, n, T, B = 96, 96, 17, 6
+    rs = np.random.RandomState(5)
+    iW, sW, sW2, b = _params(rs, I, n, scale=2.0)
+    x = (rs.normal(size=(T, B, I)) * xmag).astype(np.float32)
+    x[3, 2, :] *= 1e-3                                       # rows of very different size inside one 16-row MFMA tile
+    x[4, 1, 7] *= 50.0                                       # an outlier inside a row
+    iW = (iW / xmag).astype(np.float32)
+    ref = oracle.gru(x, iW, sW, sW2, b)
+    y = torch.full((T, B, n), np.nan, dtype=torch.float32, device="cuda")
+    xd, iWd, sWd, sW2d, bd = dev(x), dev(iW), dev(sW), dev(sW2), dev(b)
+    assert _call(_lib.lib(), xd.data_ptr(), I, iWd, sWd, sW2d, bd, y.data_ptr(), n, T, B, I, n, False) == 0
+    out = y.cpu().numpy()
+    assert np.isfinite(out).all()
+    assert np.abs(out - ref).max() < 5e-5, np.abs(out - ref).max()
+
+
+def test_fused16_trained_weight_magnitudes(oracle):
+    """|w| up to 6 with saturating gates, as in models/pretrained.pkl."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    I, n, T, B = 96, 96, 60, 7
+    rs = np.random.RandomState(11)
+    iW, sW, sW2, b = _params(rs, I, n, scale=12.0)
+    iW *= 4.0
+    assert np.abs(sW2).max() > 4.0
+    x = rs.normal(size=(T, B, I)).astype(np.float32)
+    for reverse in (False, True):
+        ref = oracle.gru(x, iW, sW, sW2, b, reverse=reverse)
+        y = torch.full((T, B, n), np.nan, dtype=torch.float32, device="cuda")
+        xd, iWd, sWd, sW2d, bd = dev(x), dev(iW), dev(sW), dev(sW2), dev(b)
+        assert _call(_lib.lib(), xd.data_ptr(), I, iWd, sWd, sW2d, bd, y.data_ptr(), n, T, B, I, n, reverse) == 0
+        assert np.abs(y.cpu().numpy() - ref).max() < TOL
+
+
+@pytest.mark.parametrize("I,n", [(96, 96), (64, 64)])
+def test_fused16_ragged_and_saved_gates(oracle, I, n):
+    """Ragged batch (each chunk must equal the call on the chunk alone at its own length, reversed scans included) and the
+    training variant that also stores the activated gates z | r."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(n)
+    T = 29
+    lens = [29, 1, 20, 8, 28, 9, 2]
+    B = len(lens)
+    iW, sW, sW2, b = _params(rs, I, n, scale=2.0)
+    x = np.zeros((T, B, I), dtype=np.float32)
+    for bb, tb in enumerate(lens):
+        x[:tb, bb] = rs.normal(size=(tb, I))
+    xd, iWd, sWd, sW2d, bd = dev(x), dev(iW), dev(sW), dev(sW2), dev(b)
+    ld = dev(np.asarray(lens, dtype=np.int32))
+    for reverse in (False, True):
+        y = torch.full((T, B, n), np.nan, dtype=torch.float32, device="cuda")
+        assert _call(L, xd.data_ptr(), I, iWd, sWd, sW2d, bd, y.data_ptr(), n, T, B, I, n, reverse, lens=ld) == 0
+        out = y.cpu().numpy()
+        for bb, tb in enumerate(lens):
+            want = oracle.gru(x[:tb, bb:bb + 1], iW, sW, sW2, b, reverse=reverse)
+            np.testing.assert_allclose(out[:tb, bb:bb + 1], want, atol=2e-5, err_msg="chunk %d" % bb)
+            assert np.isnan(out[tb:, bb]).all()                     # rows past a read's end are left untouched
+        # saved gates: z | r of every step, checked through the identity h_t = z h_{t-1} + (1-z) c with the oracle's h
+        zr = torch.full((T, B, 2 * n), np.nan, dtype=torch.float32, device="cuda")
+        y2 = torch.empty((T, B, n), dtype=torch.float32, device="cuda")
+        assert _call(L, xd.data_ptr(), I, iWd, sWd, sW2d, bd, y2.data_ptr(), n, T, B, I, n, reverse, zr=zr) == 0
+        h = oracle.gru(x, iW, sW, sW2, b, reverse=reverse).astype(np.float64)
+        np.testing.assert_allclose(y2.cpu().numpy(), h, atol=2e-5)
+        hs = h[::-1] if reverse else h
+        xs = x[::-1] if reverse else x
+        hprev = np.concatenate([np.zeros((1, B, n)), hs[:-1]], axis=0)
+        vI = xs.astype(np.float64) @ iW.astype(np.float64).T + b
+        vS = hprev @ sW.astype(np.float64).T
+        zz = 1.0 / (1.0 + np.exp(-(vI[..., :n] + vS[..., :n])))
+        rr = 1.0 / (1.0 + np.exp(-(vI[..., n:2 * n] + vS[..., n:])))
+        want = np.concatenate([zz, rr], axis=2)
+        got = zr.cpu().numpy()
+        got = got[::-1] if reverse else got
+        np.testing.assert_allclose(got, want, atol=2e-5)
+
+
+@pytest.mark.parametrize("I,n", [(96, 96), (128, 96), (64, 64)])
+def test_fused16_agrees_with_exact_kernels_under_load(I, n):
+    """Race screen: every CU busy, hundreds of steps (dozens of LDS ring turnovers), repeated: any operand image or ring
+    slot reused too early shows up as a large error in some chunk."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    T, B = 333, 1021
+    g = torch.Generator(device="cuda").manual_seed(I * n)
+    x = torch.randn((T, B, I), device="cuda", generator=g)
+    iW = torch.randn((3 * n, I), device="cuda", generator=g) / np.sqrt(I + n)
+    sW = 2.0 * torch.randn((2 * n, n), device="cuda", generator=g) / np.sqrt(2 * n)
+    sW2 = 2.0 * torch.randn((n, n), device="cuda", generator=g) / np.sqrt(2 * n)
+    b = torch.randn(3 * n, device="cuda", generator=g)
+    vI = torch.empty((T, B, 3 * n), device="cuda")
+    assert L.slk_gemm_bias_act_f32(x.data_ptr(), I, iW.data_ptr(), b.data_ptr(), vI.data_ptr(), 3 * n, T * B, I, 3 * n, 0,
+                                   stream()) == 0
+    for reverse in (0, 1):
+        ref = torch.empty((T, B, n), device="cuda")
+        assert L.slk_gru_recurrent_f32_ex(vI.data_ptr(), sW.data_ptr(), sW2.data_ptr(), ref.data_ptr(), n, T, B, n, reverse,
+                                          1, 2, 1, stream()) == 0
+        for rep in range(3):
+            y = torch.full((T, B, n), float("nan"), device="cuda")
+            assert _call(L, x.data_ptr(), I, iW, sW, sW2, b, y.data_ptr(), n, T, B, I, n, reverse) == 0
+            err = (y - ref).abs().max().item()
+            assert err < 5e-5, "reverse=%d rep=%d: %g" % (reverse, rep, err)
+
+
+def test_fused16_unsupported_shapes():
+    need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    z = dev(np.zeros((4, 4), dtype=np.float32))
+    for I, n, act in ((7, 5, 1), (96, 128, 1), (96, 96, 3), (96, 112, 1)):
+        assert L.slk_gru_fused16_f32(z.data_ptr(), I, z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), n, 1, 1,
+                                     I, n, 0, act, 2, None, None, stream()) == _lib.SLK_ERR_UNSUPPORTED
+
+
+def test_layer_takes_the_exact_path_for_weights_out_of_fp16_range(oracle, monkeypatch):
+    """layers.Gru checks the weights once per update: |w| >= 32768 (fp16 halves would overflow) -> fp32 kernels."""
+    need_gpu()
+    from sloika_amd import layers
+    rs = np.random.RandomState(3)
+    I = n = 96
+    iW, sW, sW2, b = _params(rs, I, n)
+    x = (rs.normal(size=(11, 3, I)) * 1e-5).astype(np.float32)
+    iW[5, 7] = 1e5                                           # times x ~ 1e-5: an ordinary pre-activation
+    g = layers.Gru(I, n, has_bias=True)
+    g.set_params({"iW": iW.reshape(3, n, I), "sW": sW.reshape(2, n, n), "sW2": sW2, "b": b.reshape(3, n)})
+    assert not layers._f16_safe(g, (g.iW, g.sW, g.sW2))
+    y = g.compile()(x)
+    assert np.isfinite(y).all()
+    np.testing.assert_allclose(y, oracle.run_network(g.spec(), x), atol=TOL)
+    g.iW.set_value(np.clip(iW, -10, 10))
+    assert layers._f16_safe(g, (g.iW, g.sW, g.sW2))          # re-checked after the update
