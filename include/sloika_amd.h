@@ -127,14 +127,18 @@ int slk_softmax_from_stats_f32(const float *logits, long ld_in, const float *sta
 /* Same contraction on the FP16 matrix pipe with float32-grade accuracy (csrc/gemm_rows_f16x3.hip): operands split
  * v = hi + lo in fp16, x.w ~= x_hi.w_hi + x_hi.w_lo + x_lo.w_hi accumulated in float32 -- ~5x the fp32-MFMA
  * throughput, error a few float32 ulps.  Weights are split once with slk_split_f16x2_f32 into two fp16 matrices
- * [N][KP], KP = K rounded up to 16 (2*N*KP bytes each).                                                            */
-int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, void *lo, slk_stream_t stream);
-int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias, float *y,
-                              long ldy, long M, int K, int N, float *stats /* [M][2] or NULL */, slk_stream_t stream);
+ * [N][KP], KP = K rounded up to 16 (2*N*KP bytes each), every row scaled by a power of two that brings its largest
+ * magnitude into [1, 2) (inv_scale[N] receives the inverse scales); the kernels scale every row of x the same way and undo
+ * both on the float32 accumulators, so operands of ANY finite float32 magnitude are handled (fp16 alone overflows at 65504
+ * and loses its lo half below 6e-5).                                                                                 */
+int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, void *lo, float *inv_scale, slk_stream_t stream);
+int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
+                              const float *bias, float *y, long ldy, long M, int K, int N,
+                              float *stats /* [M][2] or NULL */, slk_stream_t stream);
 /* FeedForward.run (sloika/layers.py:157-158) on the same kernel: y = act(x.W^T + b); act one of linear / tanh / sigmoid /
  * relu / elu, otherwise SLK_ERR_UNSUPPORTED (use slk_gemm_bias_act_f32).  Both: K <= 192, N <= 2048.                  */
-int slk_gemm_bias_act_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias, float *y,
-                            long ldy, long M, int K, int N, int act, slk_stream_t stream);
+int slk_gemm_bias_act_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
+                            const float *bias, float *y, long ldy, long M, int K, int N, int act, slk_stream_t stream);
 /* In-place row softmax of y:[M][N] (the second half of the above, exposed for testing).                     */
 int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream);
 /* Row statistics only: stats[r] = (max_j logits[r][j], 1 / sum_j exp(logits[r][j] - max)); the posterior
@@ -171,10 +175,9 @@ int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW
                       slk_stream_t stream);
 /* The same layer with the RECURRENCE on the fp16 matrix pipe as well (csrc/gru_fused16.hip): every float32 operand of
  * h.sW^T and (r*h).sW2^T is split v = hi + lo into two fp16 halves and each product evaluated as hi.lo + lo.hi + hi.hi in
- * float32 accumulators (v_mfma_f32_16x16x32_f16) -- 22 significand bits per operand, |h| <= 1 and trained |w| << 65504 by
- * construction; x is scaled per row by a power of two before its split, so any finite float32 input is safe.  Callers
- * must not pass weights with |w| >= 32768 (sloika_amd/layers.py checks once per weight update and takes slk_gru_fused_f32
- * otherwise).  lens: NULL, or ragged lengths as slk_gru_fused_ragged_f32; zr_out: NULL, or [T*B][2n] = [z | r] of every
+ * float32 accumulators (v_mfma_f32_16x16x32_f16) -- 22 significand bits per operand.  |h| <= 1 by construction; every
+ * row of x and of the three weight matrices is scaled by a power of two to a maximum in [1, 2) before its split and the
+ * accumulators are scaled back, so inputs and weights of any finite float32 magnitude are safe.  lens: NULL, or ragged lengths as slk_gru_fused_ragged_f32; zr_out: NULL, or [T*B][2n] = [z | r] of every
  * step as slk_gru_fused_train_f32.  n in {32, 64, 96}; SLK_ERR_UNSUPPORTED for shapes without an instantiation.     */
 int slk_gru_fused16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                         float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,

@@ -32,9 +32,9 @@ PROTOTYPES = {
     "slk_gemm_bias_act_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
     "slk_linear_softmax_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "slk_linear_rowstats_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _l, _i, _i, _vp, _vp]),
-    "slk_split_f16x2_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
-    "slk_linear_rowstats_f16x3": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _vp, _vp]),
-    "slk_gemm_bias_act_f16x3": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
+    "slk_split_f16x2_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "slk_linear_rowstats_f16x3": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _vp, _vp]),
+    "slk_gemm_bias_act_f16x3": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
     "slk_softmax_from_stats_f32": (_i, [_vp, _l, _vp, _vp, _l, _l, _i, _vp]),
     "slk_softmax_rows_f32": (_i, [_vp, _l, _i, _vp]),
     "slk_softmax_rowstats_f32": (_i, [_vp, _l, _i, _vp, _vp]),

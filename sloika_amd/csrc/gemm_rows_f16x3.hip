@@ -8,6 +8,12 @@
 //
 // x-stationary like gemm_rows.hip (128 rows x all N columns per workgroup, row statistics accumulated online); the weights
 // arrive pre-split (slk_split_f16x2_f32).
+//
+// Range: fp16 overflows at 65504 and loses its lo half below 6e-5, so every row of x (in the kernel) and every row of W (in
+// slk_split_f16x2_f32) is first scaled by a power of two that brings its largest magnitude into [1, 2); the scaling is
+// exact and is undone on the float32 accumulators (one multiply by the product row's inverse scale, one fused
+// multiply-add with the weight row's inverse scale and the bias).  Any finite float32 operand is therefore handled with
+// 22 significand bits relative to its row maximum -- float32-grade.
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -15,29 +21,46 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define GH_BM 128
 #define GH_BN 64
 
-__global__ void split_f16x2_kernel(const float *__restrict__ w, int rows, int K, int KP, _Float16 *__restrict__ hi,
-                                   _Float16 *__restrict__ lo)
+// power-of-two scale that brings a row whose largest magnitude is amax into [1, 2) (exponent kept inside [27, 227])
+__device__ __forceinline__ float gh_pow2_scale(float amax, float &inv)
 {
-    const size_t total = (size_t)rows * KP;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i % KP);
-        const size_t r = i / KP;
-        const float v = k < K ? w[r * K + k] : 0.0f;
-        const _Float16 h = (_Float16)v;
-        hi[i] = h;
-        lo[i] = (_Float16)(v - (float)h);
+    const int e = min(max((int)((__float_as_uint(amax) >> 23) & 0xff), 27), 227);
+    inv = __uint_as_float((unsigned)e << 23);
+    return __uint_as_float((unsigned)(254 - e) << 23);
+}
+
+// one wave per weight row: row maximum, power-of-two scale, hi/lo halves of the scaled row
+__global__ void split_f16x2_kernel(const float *__restrict__ w, int rows, int K, int KP, _Float16 *__restrict__ hi,
+                                   _Float16 *__restrict__ lo, float *__restrict__ inv_scale)
+{
+    const int lane = threadIdx.x & 63;
+    for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < rows; r += gridDim.x * (blockDim.x >> 6)) {
+        float m = 0.0f;
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(w[(size_t)r * K + k]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        float inv;
+        const float sc = gh_pow2_scale(m, inv);
+        if (lane == 0) inv_scale[r] = inv;
+        for (int k = lane; k < KP; k += 64) {
+            const float v = k < K ? w[(size_t)r * K + k] * sc : 0.0f;
+            const _Float16 h = (_Float16)v;
+            hi[(size_t)r * KP + k] = h;
+            lo[(size_t)r * KP + k] = (_Float16)(v - (float)h);
+        }
     }
 }
 
-// Split a float32 matrix [rows][K] into fp16 hi/lo parts [rows][KP], KP = K rounded up to a multiple of 16 (zero padded).
-extern "C" int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, void *lo, slk_stream_t stream)
+// Split a float32 matrix [rows][K] into fp16 hi/lo parts [rows][KP], KP = K rounded up to a multiple of 16 (zero padded),
+// each row scaled by a power of two to a maximum in [1, 2); inv_scale[rows] receives the inverse scales.
+extern "C" int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, void *lo, float *inv_scale, slk_stream_t stream)
 {
-    if (!w || !hi || !lo || rows < 1 || K < 1) return SLK_ERR_INVALID_ARG;
+    if (!w || !hi || !lo || !inv_scale || rows < 1 || K < 1) return SLK_ERR_INVALID_ARG;
     const int KP = (K + 15) / 16 * 16;
-    size_t total = (size_t)rows * KP, blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(split_f16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, slk_stream(stream), w, rows, K, KP,
-                       static_cast<_Float16 *>(hi), static_cast<_Float16 *>(lo));
+                       static_cast<_Float16 *>(hi), static_cast<_Float16 *>(lo), inv_scale);
     return slk_launch_status();
 }
 
@@ -58,6 +81,7 @@ template <int KS, bool STATS, int ACT>
 __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__restrict__ x, long ldx,
                                                               const _Float16 *__restrict__ Whi,
                                                               const _Float16 *__restrict__ Wlo,
+                                                              const float *__restrict__ winv,
                                                               const float *__restrict__ bias, float *__restrict__ y,
                                                               long ldy, long M, int K, int N,
                                                               float2 *__restrict__ stats)
@@ -71,13 +95,17 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
     __shared__ __attribute__((aligned(16))) _Float16 wsl[RING][GH_BN * LD];
     __shared__ float2 red[2][GH_BM];
     __shared__ __attribute__((aligned(16))) float bias_lds[BIAS_MAX];   // zero padded to whole tiles
+    __shared__ __attribute__((aligned(16))) float winv_lds[BIAS_MAX];   // inverse scales of the weight rows (= columns here)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long m0 = (long)blockIdx.x * GH_BM;
     const int ntiles = (N + GH_BN - 1) / GH_BN;
     auto tile_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    for (int i = tid; i < ntiles * GH_BN; i += 576) bias_lds[i] = (bias && i < N) ? bias[i] : 0.0f;
+    for (int i = tid; i < ntiles * GH_BN; i += 576) {
+        bias_lds[i] = (bias && i < N) ? bias[i] : 0.0f;
+        winv_lds[i] = i < N ? winv[i] : 0.0f;
+    }
 
     if (wave == 8) {
         // =============================== loader wave ===============================
@@ -120,6 +148,7 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
     const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
     // ---- x fragments: x[row][16s + 8h + j], split into hi/lo halves ----
     half8 ahi[KS], alo[KS];
+    float xinv;                                    // inverse of this lane's row scale
     const long row = m0 + 32 * wm + r;
     const bool rowok = row < M;
     {
@@ -148,13 +177,22 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
                 }
             }
         }
+        // row scale: the row's K is split between lanes l and l ^ 32
+        float amax = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) amax = fmaxf(amax, fabsf(xv[s][j]));
+        amax = fmaxf(amax, __shfl_xor(amax, 32));
+        const float xs = gh_pow2_scale(amax, xinv);
 #pragma unroll
         for (int s = 0; s < KS; s++) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const _Float16 hv = (_Float16)xv[s][j];
+                const float v = xv[s][j] * xs;
+                const _Float16 hv = (_Float16)v;
                 ahi[s][j] = hv;
-                alo[s][j] = (_Float16)(xv[s][j] - (float)hv);
+                alo[s][j] = (_Float16)(v - (float)hv);
             }
         }
     }
@@ -171,12 +209,10 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
         const _Float16 *th = &wsh[nt % RING][(32 * wn + r) * LD + 8 * h];
         const _Float16 *tl = &wsl[nt % RING][(32 * wn + r) * LD + 8 * h];
         const int cbase = nt * GH_BN + 32 * wn + 4 * h;            // column of acc[0]; acc[4q+i] is column cbase + 8q + i
-        f32x16 acc;                                                // accumulators start from the bias
+        f32x16 acc;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float4 b4 = *reinterpret_cast<const float4 *>(&bias_lds[cbase + 8 * q]);
-            acc[4 * q] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
-        }
+        for (int reg = 0; reg < 16; reg++) acc[reg] = 0.0f;
+        (void)cbase;
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             const half8 bh = *reinterpret_cast<const half8 *>(th + 16 * s);
@@ -188,8 +224,24 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
         }
         return acc;
     };
+    // scaled accumulators -> logits: (acc * row inverse scale) * column inverse scale + bias
+    auto finish = [&](int nt, const f32x16 &raw) {
+        const int cbase = nt * GH_BN + 32 * wn + 4 * h;
+        f32x16 v;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(&bias_lds[cbase + 8 * q]);
+            const float4 w4 = *reinterpret_cast<const float4 *>(&winv_lds[cbase + 8 * q]);
+            v[4 * q] = fmaf(raw[4 * q] * xinv, w4.x, b4.x);
+            v[4 * q + 1] = fmaf(raw[4 * q + 1] * xinv, w4.y, b4.y);
+            v[4 * q + 2] = fmaf(raw[4 * q + 2] * xinv, w4.z, b4.z);
+            v[4 * q + 3] = fmaf(raw[4 * q + 3] * xinv, w4.w, b4.w);
+        }
+        return v;
+    };
     // acc[reg] = logit(row, column cbase + 8*(reg>>2) + (reg&3))
-    auto epilogue = [&](int nt, const f32x16 &acc) {
+    auto epilogue = [&](int nt, const f32x16 &raw) {
+        const f32x16 acc = finish(nt, raw);
         const int cbase = nt * GH_BN + 32 * wn + 4 * h;
         const bool tile_full = (nt + 1) * GH_BN <= N;              // workgroup-uniform: every column of the tile exists
         const bool full = tile_full || cbase + 27 < N;             // all 16 columns of this lane exist
@@ -237,7 +289,8 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
     };
     // Straight-line epilogue for the common case (whole workgroup inside M, aligned rows, every column of the tile
     // exists): no branch, so that it shares a scheduling region with the next tile's MFMA chain.
-    auto epilogue_fast = [&](int nt, const f32x16 &acc) {
+    auto epilogue_fast = [&](int nt, const f32x16 &raw) {
+        const f32x16 acc = finish(nt, raw);
         f32x16 o = acc;
         if constexpr (ACT != SLK_ACT_LINEAR) {
 #pragma unroll
@@ -325,12 +378,12 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
 }
 
 template <int KS>
-static int launch_f16x3(const float *x, long ldx, const _Float16 *hi, const _Float16 *lo, const float *bias, float *y,
+static int launch_f16x3(const float *x, long ldx, const _Float16 *hi, const _Float16 *lo, const float *winv, const float *bias, float *y,
                         long ldy, long M, int K, int N, float2 *stats, int act, hipStream_t s)
 {
     dim3 grid((unsigned)((M + GH_BM - 1) / GH_BM)), block(576);
 #define F16X3_LAUNCH(ST, A) \
-    hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, ST, A>), grid, block, 0, s, x, ldx, hi, lo, bias, y, ldy, M, K, N, stats)
+    hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, ST, A>), grid, block, 0, s, x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, stats)
     if (stats) F16X3_LAUNCH(true, SLK_ACT_LINEAR);
     else if (act == SLK_ACT_LINEAR) F16X3_LAUNCH(false, SLK_ACT_LINEAR);
     else if (act == SLK_ACT_TANH) F16X3_LAUNCH(false, SLK_ACT_TANH);
@@ -342,10 +395,10 @@ static int launch_f16x3(const float *x, long ldx, const _Float16 *hi, const _Flo
     return slk_launch_status();
 }
 
-static int dispatch_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias, float *y, long ldy,
+static int dispatch_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *winv, const float *bias, float *y, long ldy,
                           long M, int K, int N, float *stats, int act, slk_stream_t stream)
 {
-    if (!x || !W_hi || !W_lo || !y || M < 0 || K < 1 || N < 1 || ldx < K || ldy < N || !slk_act_valid(act))
+    if (!x || !W_hi || !W_lo || !winv || !y || M < 0 || K < 1 || N < 1 || ldx < K || ldy < N || !slk_act_valid(act))
         return SLK_ERR_INVALID_ARG;
     if (stats && act != SLK_ACT_LINEAR) return SLK_ERR_INVALID_ARG;
     if (M == 0) return SLK_OK;
@@ -354,33 +407,35 @@ static int dispatch_f16x3(const float *x, long ldx, const void *W_hi, const void
     float2 *st = reinterpret_cast<float2 *>(stats);
     hipStream_t s = slk_stream(stream);
     switch ((K + 15) / 16) {
-    case 1: return launch_f16x3<1>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 2: return launch_f16x3<2>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 3: return launch_f16x3<3>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 4: return launch_f16x3<4>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 5: return launch_f16x3<5>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 6: return launch_f16x3<6>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 7: return launch_f16x3<7>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 8: return launch_f16x3<8>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 9: return launch_f16x3<9>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 10: return launch_f16x3<10>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 11: return launch_f16x3<11>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
-    case 12: return launch_f16x3<12>(x, ldx, hi, lo, bias, y, ldy, M, K, N, st, act, s);
+    case 1: return launch_f16x3<1>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 2: return launch_f16x3<2>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 3: return launch_f16x3<3>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 4: return launch_f16x3<4>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 5: return launch_f16x3<5>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 6: return launch_f16x3<6>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 7: return launch_f16x3<7>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 8: return launch_f16x3<8>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 9: return launch_f16x3<9>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 10: return launch_f16x3<10>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 11: return launch_f16x3<11>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
+    case 12: return launch_f16x3<12>(x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, st, act, s);
     default: return SLK_ERR_UNSUPPORTED;
     }
 }
 
-// logits = x.W^T + b from pre-split weights (slk_split_f16x2_f32), optional softmax row statistics.  K <= 192, N <= 2048.
-extern "C" int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias,
-                                         float *y, long ldy, long M, int K, int N, float *stats, slk_stream_t stream)
+// logits = x.W^T + b from pre-split weights (slk_split_f16x2_f32: halves + inverse row scales), optional softmax row
+// statistics.  K <= 192, N <= 2048.
+extern "C" int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
+                                         const float *bias, float *y, long ldy, long M, int K, int N, float *stats,
+                                         slk_stream_t stream)
 {
-    return dispatch_f16x3(x, ldx, W_hi, W_lo, bias, y, ldy, M, K, N, stats, SLK_ACT_LINEAR, stream);
+    return dispatch_f16x3(x, ldx, W_hi, W_lo, W_inv_scale, bias, y, ldy, M, K, N, stats, SLK_ACT_LINEAR, stream);
 }
 
 // y = act(x.W^T + b) from pre-split weights: FeedForward.run (sloika/layers.py:157-158) on the fp16 pipe.
 // act: linear, tanh, sigmoid, relu or elu (others: SLK_ERR_UNSUPPORTED -> use slk_gemm_bias_act_f32).
-extern "C" int slk_gemm_bias_act_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *bias,
-                                       float *y, long ldy, long M, int K, int N, int act, slk_stream_t stream)
+extern "C" int slk_gemm_bias_act_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
+                                       const float *bias, float *y, long ldy, long M, int K, int N, int act, slk_stream_t stream)
 {
-    return dispatch_f16x3(x, ldx, W_hi, W_lo, bias, y, ldy, M, K, N, nullptr, act, stream);
+    return dispatch_f16x3(x, ldx, W_hi, W_lo, W_inv_scale, bias, y, ldy, M, K, N, nullptr, act, stream);
 }

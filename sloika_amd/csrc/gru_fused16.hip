@@ -20,9 +20,11 @@
 //
 // Waves: 0 .. N/32-1 chain (raised priority), 4-7 projection / x DMA / h_out copies exactly as in gru_fused.hip, coupled by
 // LDS progress counters (lds_flags.h), no s_barrier after start-up.
-// Accuracy: |h| <= 1, |r.h| <= 1 and trained |w| <= ~6 are far inside fp16 range; hi + lo carries 22 bits, the dropped
-// lo.lo term is < 2^-22 relative.  x (unbounded: the first layer reads an elu convolution) is scaled per row by a power of two
-// before its split (XSCALE below).  Callers that need plain fp32 arithmetic use gru_fused.hip / the two-kernel path.
+// Accuracy: hi + lo carries 22 bits, the dropped lo.lo term is < 2^-22 relative.  |h| <= 1 and |r.h| <= 1 are inside fp16
+// range by construction; every row of x (unbounded: the first layer reads an elu convolution) and every row of the three
+// weight matrices is scaled by a power of two to a maximum in [1, 2) before its split and the accumulators are scaled
+// back (exact), so any finite float32 input or weight is handled at float32-grade accuracy relative to its row maximum.
+// Callers that need plain fp32 arithmetic use gru_fused.hip / the two-kernel path.
 #include <limits.h>
 
 #include "lds_flags.h"
@@ -40,13 +42,33 @@ __device__ __forceinline__ float sel4(const f32x4 &a, int q)
 }
 
 // two float32 -> one dword of fp16 "hi" parts and one of fp16 "lo" parts (v = hi + lo)
+// (the inputs are made opaque first: hipcc otherwise folds the multiply or add that produced them into the conversion --
+// v_fma_mixlo_f16, ONE rounding -- for the value it subtracts, while the stored hi part is the conversion of the rounded
+// float32: the two disagree whenever the float32 value is an exact fp16 tie, 1 in 8192, and hi + lo is then off by an
+// fp16 ulp.  Found by tools/f16_error_probe4.py.)
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
 {
+    asm volatile("" : "+v"(a), "+v"(b));
     const _Float16 ha = (_Float16)a, hb = (_Float16)b;
     const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
     half2_t h = {ha, hb}, l = {la, lb};
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
+}
+
+// Power-of-two scale that brings a row whose largest magnitude is `amax` into [1, 2): scale = 2^(127 - e), inv = 2^(e - 127),
+// e = biased exponent of amax kept inside [27, 227] so that both are normal numbers.  Multiplying by either is exact.
+__device__ __forceinline__ float pow2_scale(float amax, float &inv)
+{
+    const int e = min(max((int)((__float_as_uint(amax) >> 23) & 0xff), 27), 227);
+    inv = __uint_as_float((unsigned)e << 23);
+    return __uint_as_float((unsigned)(254 - e) << 23);
+}
+// maximum over the four k groups of an MFMA operand row (lanes m, m+16, m+32, m+48)
+__device__ __forceinline__ float kgroup_max(float v)
+{
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
 }
 
 // acc += W . h as a 3-term split; small terms first so that they are not absorbed by the large one
@@ -115,21 +137,41 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
         // A operands: lane supplies row i = lane & 15 of a tile and, for k group g, elements j = 0..7 of a K block, where
         // element (g, j) of block kb is neuron 32*kb + 16*(j&1) + 4*g + (j>>1) -- the order the owners' packed writes create.
         // K blocks are visited in the rotated order w, w+1, ...: the wave's own block first (no handshake needed).
+        // Every weight row is scaled by a power of two so that its largest magnitude lies in [1, 2) before the split (any
+        // finite float32 weight is then inside fp16 range with 22 bits relative to the row maximum); the inverse scale is
+        // applied to the accumulator of the lane that owns the row's neuron.
         half8 wz_hi[2][KBS], wz_lo[2][KBS], wr_hi[2][KBS], wr_lo[2][KBS], wc_hi[2][KBS], wc_lo[2][KBS];
+        float inv_z[2], inv_r[2], inv_c[2];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
             const int row = 32 * w + 16 * p + (lane & 15);
+            float vz[KBS][8], vr[KBS][8], vc[KBS][8];
+            float mz = 0.0f, mr = 0.0f, mc = 0.0f;
 #pragma unroll
             for (int i = 0; i < KBS; i++) {
                 const int kb = (w + i) % KBS;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const int k = 32 * kb + 16 * (j & 1) + 4 * g + (j >> 1);
-                    const float vz = sW[(size_t)row * N + k], vr = sW[(size_t)(N + row) * N + k], vc = sW2[(size_t)row * N + k];
-                    const _Float16 hz = (_Float16)vz, hr = (_Float16)vr, hc = (_Float16)vc;
-                    wz_hi[p][i][j] = hz; wz_lo[p][i][j] = (_Float16)(vz - (float)hz);
-                    wr_hi[p][i][j] = hr; wr_lo[p][i][j] = (_Float16)(vr - (float)hr);
-                    wc_hi[p][i][j] = hc; wc_lo[p][i][j] = (_Float16)(vc - (float)hc);
+                    vz[i][j] = sW[(size_t)row * N + k];
+                    vr[i][j] = sW[(size_t)(N + row) * N + k];
+                    vc[i][j] = sW2[(size_t)row * N + k];
+                    mz = fmaxf(mz, fabsf(vz[i][j])); mr = fmaxf(mr, fabsf(vr[i][j])); mc = fmaxf(mc, fabsf(vc[i][j]));
+                }
+            }
+            float iz, ir, ic;
+            const float sz = pow2_scale(kgroup_max(mz), iz), sr = pow2_scale(kgroup_max(mr), ir), sc = pow2_scale(kgroup_max(mc), ic);
+            // the lane that consumes row 4g + q of this tile (lane index = row index in k group 0 holds its inverse scale)
+            inv_z[p] = __shfl(iz, 4 * g + q); inv_r[p] = __shfl(ir, 4 * g + q); inv_c[p] = __shfl(ic, 4 * g + q);
+#pragma unroll
+            for (int i = 0; i < KBS; i++) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float az = vz[i][j] * sz, ar = vr[i][j] * sr, ac = vc[i][j] * sc;
+                    const _Float16 hz = (_Float16)az, hr = (_Float16)ar, hc = (_Float16)ac;
+                    wz_hi[p][i][j] = hz; wz_lo[p][i][j] = (_Float16)(az - (float)hz);
+                    wr_hi[p][i][j] = hr; wr_lo[p][i][j] = (_Float16)(ar - (float)hr);
+                    wc_hi[p][i][j] = hc; wc_lo[p][i][j] = (_Float16)(ac - (float)hc);
                 }
             }
         }
@@ -212,7 +254,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
             // r, r*h -> operand images of the candidate product (the z MFMAs above execute underneath this arithmetic)
             float rr[2];
 #pragma unroll
-            for (int p = 0; p < 2; p++) rr[p] = slk_sigmoid(sel4(accR[p], q) + vr[p]);
+            for (int p = 0; p < 2; p++) rr[p] = slk_sigmoid(fmaf(sel4(accR[p], q), inv_r[p], vr[p]));
             {
                 unsigned hi, lo;
                 split2(rr[0] * hold[0], rr[1] * hold[1], hi, lo);
@@ -244,7 +286,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
             // the update gate, needed only at the end of the step
             float zz[2];
 #pragma unroll
-            for (int p = 0; p < 2; p++) zz[p] = slk_sigmoid(sel4(accZ[p], q) + vz[p]);
+            for (int p = 0; p < 2; p++) zz[p] = slk_sigmoid(fmaf(sel4(accZ[p], q), inv_z[p], vz[p]));
             if constexpr (KBS > 1) {
                 bool ok = poll_result(f, needRH);
 #pragma unroll
@@ -292,7 +334,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
             float hn[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                const float hbar = slk_tanh(sel4(accC[p], q) + vc[p]);
+                const float hbar = slk_tanh(fmaf(sel4(accC[p], q), inv_c[p], vc[p]));
                 hn[p] = zz[p] * hold[p] + (1.0f - zz[p]) * hbar;              // layers.py:1020
             }
             if (more) {                                      // long since answered; checked before the writes below queue up
@@ -329,21 +371,34 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
         constexpr bool LAST_MAYBE = (NT16 % 4) != 0;        // the last tile slot exists only for some waves
         const bool last_ok = pw + 4 * (NTW - 1) < NT16;
         // B operands: lane holds vI row 16*t + col, k = 32*kb + 8*kq + 0..7, as fp16 hi and lo parts
+        // (rows scaled by a power of two like the recurrent weights; the lane that holds a row is the lane that stores it)
         half8 whi[NTW][KBLK], wlo[NTW][KBLK];
+        float inv_w[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
             const bool ok = (i < NTW - 1) || !LAST_MAYBE || last_ok;
             const int row = ok ? 16 * (pw + 4 * i) + col : 0;
+            float u[KBLK][8];
+            float m = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < KBLK; kb++) {
                 const int k0 = 32 * kb + 8 * kq;
                 const bool kok = ok && (I % 32 == 0 || k0 < I);
                 const float *src = iW + (size_t)row * I + (kok ? k0 : 0);
                 const float4 u0 = *reinterpret_cast<const float4 *>(src), u1 = *reinterpret_cast<const float4 *>(src + 4);
-                const float u[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+                const float t[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float v = kok ? u[j] : 0.0f;
+                    u[kb][j] = kok ? t[j] : 0.0f;
+                    m = fmaxf(m, fabsf(u[kb][j]));
+                }
+            }
+            const float ws = pow2_scale(kgroup_max(m), inv_w[i]);
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float v = u[kb][j] * ws;
                     const _Float16 h = (_Float16)v;
                     whi[i][kb][j] = h;
                     wlo[i][kb][j] = (_Float16)(v - (float)h);
@@ -438,12 +493,9 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
                 }
             }
             // row maximum: the row's K is spread over the four k groups (lanes m, m+16, m+32, m+48)
-            amax = fmaxf(amax, __shfl_xor(amax, 16));
-            amax = fmaxf(amax, __shfl_xor(amax, 32));
-            // scale = 2^(127 - e), inverse 2^(e - 127), e = biased exponent of the row maximum, kept inside [27, 227] so that
-            // both are normal numbers (rows that small or that large are beyond any network's activations)
-            const int e = min(max((int)((__float_as_uint(amax) >> 23) & 0xff), 27), 227);
-            const float xs = __uint_as_float((unsigned)(254 - e) << 23), xinv = __uint_as_float((unsigned)e << 23);
+            amax = kgroup_max(amax);
+            float xinv;
+            const float xs = pow2_scale(amax, xinv);
             // the accumulator rows of this lane are (step kq, chunk 0..3): their inverse scales sit in lanes 4*kq + (0..3)
             f32x4 inv;
 #pragma unroll
@@ -482,7 +534,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
                         const float tb = bias_lds[16 * (pw + 4 * i) + col];
                         f32x4 o;
 #pragma unroll
-                        for (int r4 = 0; r4 < 4; r4++) o[r4] = fmaf(acc[i][r4], inv[r4], tb);
+                        for (int r4 = 0; r4 < 4; r4++) o[r4] = fmaf(acc[i][r4] * inv[r4], inv_w[i], tb);
                         *reinterpret_cast<f32x4 *>(&vdst[64 * (pw + 4 * i)]) = o;
                     }
             }

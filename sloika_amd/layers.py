@@ -109,28 +109,9 @@ SPLIT_F16 = os.environ.get("SLOIKA_AMD_EXACT_F32", "0") != "1"
 #: SLOIKA_AMD_RECURRENT_F32=1 asks for the exact-fp32 recurrence of csrc/gru_fused.hip (SLOIKA_AMD_EXACT_F32=1 implies it).
 RECURRENT_F16 = os.environ.get("SLOIKA_AMD_RECURRENT_F32", "0") != "1"
 
-#: fp16 halves overflow at 65504: weights whose magnitude reaches 2^15 (or are not finite) never take a split path.
-F16_SPLIT_LIMIT = 32768.0
-
-
-def _f16_safe(owner, params):
-    """True when every weight of `params` is finite and below F16_SPLIT_LIMIT in magnitude, i.e. its fp16 hi/lo split is
-    exact to 22 bits.  One device reduction + host read per weight UPDATE (cached on the identity of the device tensors and
-    on the optimiser's step counter), never per call."""
-    import torch
-    devs = tuple(p.dev() for p in params)
-    stamp = tuple(getattr(p, "_version", 0) for p in params)
-    cache = owner.__dict__.get("_f16_ok")
-    if cache is not None and len(cache[0]) == len(devs) and all(a is b for a, b in zip(cache[0], devs)) and cache[1] == stamp:
-        return cache[2]
-    worst = max(float(torch.nan_to_num(d.abs().max(), nan=float("inf")).item()) for d in devs)
-    ok = worst < F16_SPLIT_LIMIT
-    owner.__dict__["_f16_ok"] = (devs, stamp, ok)
-    return ok
-
-
 def _split_f16_cached(owner, attr, param, rows, k):
-    """fp16 hi/lo parts of the [rows][k] weight `param` on the device, re-made whenever the parameter changes."""
+    """fp16 hi/lo parts of the [rows][k] weight `param` (rows scaled by powers of two) and the inverse row scales, on the
+    device, re-made whenever the parameter changes."""
     import torch
     wd = param.dev()
     cache = owner.__dict__.get(attr)
@@ -138,10 +119,11 @@ def _split_f16_cached(owner, attr, param, rows, k):
         kp = (k + 15) // 16 * 16
         hi = torch.empty((rows, kp), dtype=torch.float16, device=wd.device)
         lo = torch.empty((rows, kp), dtype=torch.float16, device=wd.device)
-        _lib.check(_lib.lib().slk_split_f16x2_f32(wd.data_ptr(), rows, k, hi.data_ptr(), lo.data_ptr(), _stream()),
-                   "split_f16")
-        owner.__dict__[attr] = cache = (wd, hi, lo)
-    return cache[1], cache[2]
+        inv = torch.empty((rows,), dtype=torch.float32, device=wd.device)
+        _lib.check(_lib.lib().slk_split_f16x2_f32(wd.data_ptr(), rows, k, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(),
+                                                  _stream()), "split_f16")
+        owner.__dict__[attr] = cache = (wd, hi, lo, inv)
+    return cache[1], cache[2], cache[3]
 
 
 def _projection(owner, x, W, b, ws_ptr, rows, k, n_out, stage, name):
@@ -153,9 +135,9 @@ def _projection(owner, x, W, b, ws_ptr, rows, k, n_out, stage, name):
                          f16x3_flops=2.0 * rows * k * n_out if use_f16 else 0.0):
         rc = _lib.SLK_ERR_UNSUPPORTED
         if use_f16:
-            hi, lo = _split_f16_cached(owner, "_iw16", W, n_out, k)
-            rc = L.slk_linear_rowstats_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(), b.dev().data_ptr(),
-                                             ws_ptr, n_out, rows, k, n_out, None, _stream())
+            hi, lo, inv = _split_f16_cached(owner, "_iw16", W, n_out, k)
+            rc = L.slk_linear_rowstats_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(), inv.data_ptr(),
+                                             b.dev().data_ptr(), ws_ptr, n_out, rows, k, n_out, None, _stream())
         if rc == _lib.SLK_ERR_UNSUPPORTED:
             rc = L.slk_gemm_bias_act_f32(x.data_ptr(), _row_stride(x), W.dev().data_ptr(), b.dev().data_ptr(), ws_ptr,
                                          n_out, rows, k, n_out, 0, _stream())
@@ -386,8 +368,8 @@ class FeedForward(Layer):
                              f16x3_flops=2.0 * rows * self.insize * self.size if use_f16 else 0.0) as reg:
             rc = _lib.SLK_ERR_UNSUPPORTED
             if use_f16:
-                hi, lo = _split_f16_cached(self, "_w16", self.W, self.size, self.insize)
-                rc = L.slk_gemm_bias_act_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(),
+                hi, lo, inv = _split_f16_cached(self, "_w16", self.W, self.size, self.insize)
+                rc = L.slk_gemm_bias_act_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(), inv.data_ptr(),
                                                self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), rows, self.insize,
                                                self.size, act, _stream())
             if rc == _lib.SLK_ERR_UNSUPPORTED:           # activation or size the fp16x3 kernel does not cover
@@ -432,18 +414,8 @@ class Softmax(Layer):
     split_f16 = os.environ.get("SLOIKA_AMD_EXACT_F32", "0") != "1"
 
     def _split_weights(self):
-        """fp16 hi/lo parts of W on the device, re-made whenever W changes."""
-        import torch
-        wd = self.W.dev()
-        cache = getattr(self, "_w16", None)
-        if cache is None or cache[0] is not wd:
-            kp = (self.insize + 15) // 16 * 16
-            hi = torch.empty((self.size, kp), dtype=torch.float16, device=wd.device)
-            lo = torch.empty((self.size, kp), dtype=torch.float16, device=wd.device)
-            _lib.check(_lib.lib().slk_split_f16x2_f32(wd.data_ptr(), self.size, self.insize, hi.data_ptr(),
-                                                      lo.data_ptr(), _stream()), "Softmax.split")
-            self._w16 = cache = (wd, hi, lo)
-        return cache[1], cache[2]
+        """fp16 hi/lo parts of W and the inverse row scales on the device, re-made whenever W changes."""
+        return _split_f16_cached(self, "_w16", self.W, self.size, self.insize)
 
     def __getstate__(self):
         d = dict(self.__dict__)
@@ -462,8 +434,8 @@ class Softmax(Layer):
                              4.0 * rows * (self.insize + self.size),
                              f16x3_flops=2.0 * rows * self.insize * self.size if use_f16 else 0.0):
             if use_f16:
-                hi, lo = self._split_weights()
-                rc = L.slk_linear_rowstats_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(),
+                hi, lo, inv = self._split_weights()
+                rc = L.slk_linear_rowstats_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(), inv.data_ptr(),
                                                  self.b.dev().data_ptr(), y.data_ptr(), ld, rows, self.insize,
                                                  self.size, stats.data_ptr(), _stream())
             else:
@@ -802,7 +774,6 @@ class Gru(RNN):
         d = dict(self.__dict__)
         d.pop("_pad_cache", None)
         d.pop("_iw16", None)         # device caches: never pickled
-        d.pop("_f16_ok", None)
         return d
 
     def _forward(self, x, out, reverse):
@@ -832,7 +803,7 @@ class Gru(RNN):
             raise ValueError("ragged lengths do not match the batch")
         # one persistent kernel (projection waves + recurrent waves) where an instantiation exists (its projection half
         # runs as an fp16 3-term split, so SLOIKA_AMD_EXACT_F32=1 takes the two-kernel all-fp32 path instead) ...
-        if SPLIT_F16 and _f16_safe(self, (self.iW, self.sW, self.sW2)):
+        if SPLIT_F16:
             rc = _lib.SLK_ERR_UNSUPPORTED
             if RECURRENT_F16:
                 # projection AND recurrence as 3-term fp16 splits (csrc/gru_fused16.hip)

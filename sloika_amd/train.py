@@ -209,7 +209,7 @@ class TrainingStep(object):
         """Device copies derived from the parameters (fp16 splits, padded twins) are keyed on the identity of the
         parameter's device tensor, which no longer changes when the optimiser writes in place: forget them."""
         for layer in [leaf for sub in self.body for leaf in _leaves(sub)] + [self.softmax]:
-            for attr in ("_w16", "_iw16", "_pad_cache", "_f16_ok"):
+            for attr in ("_w16", "_iw16", "_pad_cache"):
                 layer.__dict__.pop(attr, None)
             # (a Gru whose forward pass runs a zero-padded twin rebuilds it from get_value(), which reads the device copy)
 
@@ -243,8 +243,11 @@ class TrainingStep(object):
             kp = (K + 15) // 16 * 16
             hi = torch.empty((N, kp), dtype=torch.float16, device=W.device)
             lo = torch.empty((N, kp), dtype=torch.float16, device=W.device)
-            _lib.check(L.slk_split_f16x2_f32(W.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), layers._stream()), "split")
-            rc = L.slk_gemm_bias_act_f16x3(x, ldx, hi.data_ptr(), lo.data_ptr(), bias, y, ldy, M, K, N, act, layers._stream())
+            inv = torch.empty((N,), dtype=torch.float32, device=W.device)
+            _lib.check(L.slk_split_f16x2_f32(W.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), layers._stream()),
+                       "split")
+            rc = L.slk_gemm_bias_act_f16x3(x, ldx, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), bias, y, ldy, M, K, N, act,
+                                           layers._stream())
         if rc == _lib.SLK_ERR_UNSUPPORTED:
             rc = L.slk_gemm_bias_act_f32(x, ldx, W.data_ptr(), bias, y, ldy, M, K, N, act, layers._stream())
         _lib.check(rc, "gemm")

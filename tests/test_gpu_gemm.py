@@ -135,12 +135,14 @@ def test_linear_rowstats_kernels_vs_float64(M, K, N, ld, kernel):
         KP = (K + 15) // 16 * 16
         hi = torch.empty((N, KP), dtype=torch.float16, device="cuda")
         lo = torch.empty((N, KP), dtype=torch.float16, device="cuda")
-        assert L.slk_split_f16x2_f32(Wd.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), stream()) == 0
-        # the two halves reproduce W to ~2^-22 relative
-        back = hi[:, :K].float() + lo[:, :K].float()
-        assert ((back - Wd).abs() <= 3e-7 * Wd.abs() + 1e-7).all()
-        rc = L.slk_linear_rowstats_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), bd.data_ptr(), y.data_ptr(), ld, M,
-                                         K, N, stats.data_ptr(), stream())
+        inv = torch.empty((N,), dtype=torch.float32, device="cuda")
+        assert L.slk_split_f16x2_f32(Wd.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), stream()) == 0
+        # the two halves times the inverse row scale reproduce W to ~2^-22 of each row's largest weight
+        back = (hi[:, :K].float() + lo[:, :K].float()) * inv[:, None]
+        assert ((back - Wd).abs() <= 3e-7 * Wd.abs().amax(dim=1, keepdim=True)).all()
+        assert (hi.float().abs().amax(dim=1) < 2.001).all() and (hi.float().abs().amax(dim=1) >= 1.0).all()
+        rc = L.slk_linear_rowstats_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), bd.data_ptr(),
+                                         y.data_ptr(), ld, M, K, N, stats.data_ptr(), stream())
     assert rc == 0
     out = y.cpu().numpy()
     ref = x.astype(np.float64) @ W.astype(np.float64).T + b
@@ -157,8 +159,8 @@ def test_linear_rowstats_kernels_vs_float64(M, K, N, ld, kernel):
     if kernel == "f32":
         rc = L.slk_linear_rowstats_f32(xd.data_ptr(), K, Wd.data_ptr(), bd.data_ptr(), y2.data_ptr(), ld, M, K, N, None, stream())
     else:
-        rc = L.slk_linear_rowstats_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), bd.data_ptr(), y2.data_ptr(), ld, M, K,
-                                         N, None, stream())
+        rc = L.slk_linear_rowstats_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), bd.data_ptr(),
+                                         y2.data_ptr(), ld, M, K, N, None, stream())
     assert rc == 0
     assert torch.equal(y2[:, :N], y[:, :N])
 
@@ -191,15 +193,49 @@ def test_gemm_bias_act_f16x3_vs_float64(K, N, act):
     kp = (K + 15) // 16 * 16
     hi = torch.empty((N, kp), dtype=torch.float16, device="cuda")
     lo = torch.empty((N, kp), dtype=torch.float16, device="cuda")
-    assert L.slk_split_f16x2_f32(Wd.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), stream()) == 0
+    inv = torch.empty((N,), dtype=torch.float32, device="cuda")
+    assert L.slk_split_f16x2_f32(Wd.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), stream()) == 0
     ld = N + 5
     y = torch.full((M, ld), -7.0, dtype=torch.float32, device="cuda")
-    rc = L.slk_gemm_bias_act_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), bd.data_ptr(), y.data_ptr(), ld, M, K, N,
-                                   aid, stream())
+    rc = L.slk_gemm_bias_act_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), bd.data_ptr(), y.data_ptr(),
+                                   ld, M, K, N, aid, stream())
     assert rc == 0
     out = y.cpu().numpy()
     np.testing.assert_allclose(out[:, :N], ref, atol=2e-5)
     assert (out[:, N:] == -7.0).all()
     # unsupported activation -> caller falls back to the fp32 kernel
-    assert L.slk_gemm_bias_act_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), bd.data_ptr(), y.data_ptr(), ld, M, K, N,
-                                     7, stream()) == _lib.SLK_ERR_UNSUPPORTED
+    assert L.slk_gemm_bias_act_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), bd.data_ptr(), y.data_ptr(),
+                                     ld, M, K, N, 7, stream()) == _lib.SLK_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("xmag,wmag", [(1e-7, 1.0), (1e-3, 1e3), (1e3, 1e-3), (1e5, 1e-5), (1e5, 1.0), (3e7, 1e-6), (1.0, 1e6)])
+def test_f16x3_operands_of_any_magnitude(xmag, wmag):
+    """fp16 alone overflows at 65504 and has no lo half below 6e-5.  Rows of x and of W are scaled by powers of two before
+    their split, so the 3-term product stays float32-grade for any finite magnitudes -- also when rows of very different
+    size share a tile and when one row holds an outlier.  Checked against float64, relative to sum |x||w|."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    M, K, N = 300, 96, 1025
+    rs = np.random.RandomState(17)
+    x = (rs.normal(size=(M, K)) * xmag).astype(np.float32)
+    x[5] *= 1e-4; x[6] *= 1e3; x[7, 11] *= 300.0; x[8] = 0.0
+    W = (rs.normal(size=(N, K)) * wmag).astype(np.float32)
+    W[3] *= 1e-5; W[4] *= 1e4; W[9, 2] *= 100.0; W[10] = 0.0
+    b = (rs.normal(size=N) * xmag * wmag).astype(np.float32)
+    xd, Wd, bd = dev(x), dev(W), dev(b)
+    hi = torch.empty((N, K), dtype=torch.float16, device="cuda")
+    lo = torch.empty((N, K), dtype=torch.float16, device="cuda")
+    inv = torch.empty((N,), dtype=torch.float32, device="cuda")
+    assert L.slk_split_f16x2_f32(Wd.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), stream()) == 0
+    y = torch.full((M, N), np.nan, dtype=torch.float32, device="cuda")
+    stats = torch.empty((M, 2), dtype=torch.float32, device="cuda")
+    assert L.slk_linear_rowstats_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), bd.data_ptr(),
+                                       y.data_ptr(), N, M, K, N, stats.data_ptr(), stream()) == 0
+    out = y.cpu().numpy().astype(np.float64)
+    assert np.isfinite(out).all()
+    ref = x.astype(np.float64) @ W.astype(np.float64).T + b
+    # error bound of a float32-grade product: a few 2^-24 of (row max |x|) * (row max |w|) * K, plus the terms' own sum
+    bound = 1e-6 * (np.abs(x).max(axis=1, keepdims=True).astype(np.float64) * np.abs(W).max(axis=1)[None, :] * np.sqrt(K)
+                    + np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b))
+    assert (np.abs(out - ref) <= bound + 1e-30).all(), float((np.abs(out - ref) / (bound + 1e-300)).max())

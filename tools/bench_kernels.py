@@ -114,15 +114,16 @@ def main():
         KP = (K + 15) // 16 * 16
         hi = torch.empty(N, KP, dtype=torch.float16, device="cuda")
         lo = torch.empty(N, KP, dtype=torch.float16, device="cuda")
-        assert L.slk_split_f16x2_f32(W.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), st) == 0
+        inv = torch.empty((N,), dtype=torch.float32, device="cuda")
+        assert L.slk_split_f16x2_f32(W.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), st) == 0
         ld = 1056
         y = torch.empty(M, ld, device="cuda")
         y2 = torch.empty(M, ld, device="cuda")
         stats = torch.empty(M, 2, device="cuda")
         stats2 = torch.empty(M, 2, device="cuda")
         for rnd in range(2):
-            ms0 = timeit(lambda: L.slk_linear_rowstats_f16x3(x.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), b.data_ptr(), y.data_ptr(), ld, M, K, N, None, st), reps=5)
-            ms1 = timeit(lambda: L.slk_linear_rowstats_f16x3(x.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), b.data_ptr(), y.data_ptr(), ld, M, K, N, stats.data_ptr(), st), reps=5)
+            ms0 = timeit(lambda: L.slk_linear_rowstats_f16x3(x.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), b.data_ptr(), y.data_ptr(), ld, M, K, N, None, st), reps=5)
+            ms1 = timeit(lambda: L.slk_linear_rowstats_f16x3(x.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), b.data_ptr(), y.data_ptr(), ld, M, K, N, stats.data_ptr(), st), reps=5)
             print("gemm_rows_f16x3 M=%d K=%d N=%d: no-stats %.3f ms (%.1f TF-equiv)  with-stats %.3f ms (%.1f TF-equiv, %.0f GB/s written)" % (M, K, N, ms0, 2.0 * M * K * N / ms0 / 1e9, ms1, 2.0 * M * K * N / ms1 / 1e9, 4.0 * M * N / ms1 / 1e6))
         L.slk_linear_rowstats_f32(x.data_ptr(), K, W.data_ptr(), b.data_ptr(), y2.data_ptr(), ld, M, K, N, stats2.data_ptr(), st)
         torch.cuda.synchronize()
