@@ -72,16 +72,42 @@ __device__ __forceinline__ float kgroup_max(float v)
 }
 
 // acc += W . h as a 3-term split; small terms first so that they are not absorbed by the large one
+template <int ABL = 0>
 __device__ __forceinline__ f32x4 mfma3(const half8 &w_hi, const half8 &w_lo, const half8 &h_hi, const half8 &h_lo, f32x4 acc)
 {
+    if constexpr (ABL & 1) {
+        half8 a = w_hi, b = h_hi;
+        asm volatile("" : "+v"(a), "+v"(b), "+v"(acc));
+        return acc;
+    }
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi, h_lo, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo, h_hi, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi, h_hi, acc, 0, 0, 0);
     return acc;
 }
 
+// Diagnostic instantiation: shader-clock cycles workgroup 0's chain wave 0 spends between the marks of one step, summed over
+// the scan (tools/bench_kernels.py --what gruf16 reads them).  The production instantiation carries none of this.
+__device__ unsigned long long slk_dbg_stamp16[16];
+extern "C" int slk_debug_read_stamps16(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_stamp16), sizeof(unsigned long long) * 16) == hipSuccess ? SLK_OK
+                                                                                                                  : SLK_ERR_LAUNCH;
+}
+#define STAMP16(i)                                                                    \
+    if constexpr (DIAG) {                                                             \
+        unsigned long long tnow;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");   \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        stamp_acc[i] += tnow - tprev;                                                 \
+        tprev = tnow;                                                                 \
+    }
+
 // SAVE (training, sloika_amd/train.py): the activated gates z | r of every step are also written to zr_out[(t*B + b)][2N].
-template <int I, int N, bool SAVE>
+// ABL (diagnostic builds only): 1 = no MFMAs in the chain waves, 2 = chain polls never wait, 4 = cheap activations,
+// 8 = projection waves idle (vI ring holds whatever was there) -- timing experiments, results are garbage.
+template <int I, int N, bool SAVE, bool DIAG = false, int ABL = 0>
 __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__restrict__ x, long ldx,
                                                              const float *__restrict__ iW, const float *__restrict__ bias,
                                                              const float *__restrict__ sW, const float *__restrict__ sW2,
@@ -93,7 +119,6 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
     constexpr int KBS = N / 32;
     // ---------------- projection role constants (as gru_fused.hip) ----------------
     constexpr int NT16 = 3 * N / 16;                     // tiles of vI rows
-    constexpr int NTW = (NT16 + 3) / 4;                  // tiles per proj wave (tile pw + 4*i; the last may be absent)
     constexpr int KBLK = (I + 31) / 32;
     constexpr int GS = 4;                                // time steps per projection group
     // ---------------- LDS ----------------
@@ -109,26 +134,41 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
     // MFMA B-operand images of h and r*h: [k block][k group 4][chunk 4][8 halves], hi and lo parts
     __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * N], h_lo[2 * N], rh_hi[2 * N], rh_lo[2 * N];
     __shared__ float bias_lds[3 * N];
-    __shared__ __attribute__((aligned(64))) int flags[16];
-    __shared__ __attribute__((aligned(64))) int xflags[16];
+    // progress counters, in groups of four (lane l polls counter l & 31; its group is `cls`):
+    //   flags : 0 fA (r*h of step s published -> s+1)   1 fB (h of step s -> s+1)   2 vready of the service waves 4-7
+    //           3 flushed (h_out blocks copied)          4 vready of the extra projection waves NCW..3
+    //   xflags: 0 xready   1 xdone of the service waves   2 xdone of the extra projection waves
+    // counters of waves that do not exist are preset to INT_MAX and never hold anyone up
+    __shared__ __attribute__((aligned(128))) int flags[32];
+    __shared__ __attribute__((aligned(128))) int xflags[32];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
-    const int cls = (lane & 15) >> 2;                    // which counter group this lane watches when polling
+    const int cls = (lane & 31) >> 2;                    // which counter group this lane watches when polling
+    // ---------------- who computes which tiles of vI ----------------
+    // Chain waves 0..NCW-1 sit on NCW of the four SIMDs (a workgroup's waves go round the SIMDs, so wave i and wave i+4
+    // share one).  The projection's MFMAs go mostly to the waves on the REMAINING SIMDs ("free": waves NCW..3 and
+    // 4+NCW..7); the waves that share a SIMD with a chain wave take what is left.  Measured with the projection spread
+    // evenly over waves 4-7, the chain spent a sixth of every step waiting for vI.
+    constexpr int NFREE = 2 * (4 - NCW);
+    constexpr int TILE_CAP = (N == 96) ? (KBLK <= 3 ? 5 : 4) : (N == 64 ? 3 : 1);      // register budget of one wave
+    constexpr int FREE_EACH = (NT16 + NFREE - 1) / NFREE < TILE_CAP ? (NT16 + NFREE - 1) / NFREE : TILE_CAP;
+    constexpr int REM = NT16 - NFREE * FREE_EACH > 0 ? NT16 - NFREE * FREE_EACH : 0;
+    constexpr int SH_BASE = REM / NCW, SH_EXTRA = REM % NCW;
+    constexpr int MAXT = FREE_EACH > SH_BASE + (SH_EXTRA ? 1 : 0) ? FREE_EACH : SH_BASE + (SH_EXTRA ? 1 : 0);
+    static_assert(NFREE * FREE_EACH + REM >= NT16, "tile assignment");
 
     for (int i = tid; i < 2 * N; i += 512) { h_hi[i] = 0u; h_lo[i] = 0u; }             // h(-1) = 0
     for (int i = tid; i < 3 * N; i += 512) bias_lds[i] = bias ? bias[i] : 0.0f;
-    if (tid < 16) {
-        // counters: 0-3 fA (r*h of step s published -> s+1), 4-7 fB (h of step s -> s+1), 8-11 vready, 12-15 flushed;
-        // chain waves that do not exist never hold anyone up
+    if (tid < 32) {
         const int idx = tid & 3, grp = tid >> 2;
-        flags[tid] = (grp < 2 && idx >= NCW) ? INT_MAX : 0;
-        xflags[tid] = 0;
+        const bool extra_missing = idx >= 4 - NCW;          // extra projection wave idx = wave NCW + idx
+        flags[tid] = ((grp < 2 && idx >= NCW) || (grp == 4 && extra_missing)) ? INT_MAX : 0;
+        xflags[tid] = (grp == 2 && extra_missing) ? INT_MAX : 0;
     }
     __syncthreads();                                     // the only hardware barrier
 
-    if (wave < 4) {
-        if (wave >= NCW) return;
+    if (wave < NCW) {
         // =================================================================================================
         // chain waves
         // =================================================================================================
@@ -188,19 +228,21 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
         const int offH = cls == 1 ? 0 : NOWATCH;             // h(s-1) complete:   fB >= s
         const int offRH = cls == 0 ? 1 : NOWATCH;            // r*h of step s:     fA >= s+1
         const bool watch_flush = cls == 3;
-        const int offV = cls == 2 ? 2 : NOWATCH;             // vI(s+1) written:   vready >= s+2
+        const int offV = (cls == 2 || cls == 4) ? 2 : NOWATCH;   // vI(s+1) written: every projection wave's vready >= s+2
 
+        unsigned long long stamp_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+        if constexpr (DIAG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
         float hold[2] = {0.0f, 0.0f};
         float vz[2], vr[2], vc[2];                           // vI rows of my two neurons, read one step ahead
         for (;;) {                                           // vI(0)
-            const int f = poll_issue(flags, lane);
+            const int f = poll_issue<32>(flags, lane);
 #pragma unroll
             for (int p = 0; p < 2; p++) {
                 vz[p] = vbuf[4 * (n0 + 16 * p) + c];
                 vr[p] = vbuf[4 * (N + n0 + 16 * p) + c];
                 vc[p] = vbuf[4 * (2 * N + n0 + 16 * p) + c];
             }
-            const bool ok = poll_result(f, cls == 2 ? 1 : NOWATCH);
+            const bool ok = poll_result(f, (cls == 2 || cls == 4) ? 1 : NOWATCH) || (ABL & 2);
 #pragma unroll
             for (int p = 0; p < 2; p++) { keep(vz[p]); keep(vr[p]); keep(vc[p]); }
             if (ok) break;
@@ -212,56 +254,68 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
             half8 bh[KBS], bl[KBS];
             f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
-            // ---------------- r | z: products with h(s-1) ----------------
-            // own K block: my own (ordered) writes; the others' blocks are requested at the same time and checked after the
-            // own block's twelve MFMAs, which hide the round trip
+            STAMP16(0)
+            // Schedule of one step (MFMA = 16 pipe cycles, of which the issuing wave is busy for 8: the other 8 take VALU):
+            //   r  own block (6 MFMAs) while the other waves' h(s-1) arrives, then r others (12)      -- the critical path
+            //   z  all blocks (18)      || sigmoid(r), r*h, split, write, publish; own r*h read back
+            //   c  own block (6) while the others' r*h arrives, c others (12)   || sigmoid(z), vI(s+1) reads
+            //   tanh, blend, split, write, publish
+            // ---------------- r: products with h(s-1) ----------------
             bh[0] = ldB(h_hi, boff[0]);
             bl[0] = ldB(h_lo, boff[0]);
-            int f = poll_issue(flags, lane);
+            int f = poll_issue<32>(flags, lane);
 #pragma unroll
             for (int i = 1; i < KBS; i++) { bh[i] = ldB(h_hi, boff[i]); bl[i] = ldB(h_lo, boff[i]); }
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (KBS - 1) + 1) : "memory");          // own block has landed
             keep(bh[0]); keep(bl[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 0; p < 2; p++) accR[p] = mfma3(wr_hi[p][0], wr_lo[p][0], bh[0], bl[0], accR[p]);
-#pragma unroll
-            for (int p = 0; p < 2; p++) accZ[p] = mfma3(wz_hi[p][0], wz_lo[p][0], bh[0], bl[0], accZ[p]);
+            for (int p = 0; p < 2; p++) accR[p] = mfma3<ABL>(wr_hi[p][0], wr_lo[p][0], bh[0], bl[0], accR[p]);
             if constexpr (KBS > 1) {
-                bool ok = poll_result(f, needH);
+                bool ok = poll_result(f, needH) || (ABL & 2);
 #pragma unroll
                 for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
                 while (!ok) {
-                    f = poll_issue(flags, lane);
+                    if constexpr (DIAG) stamp_acc[8]++;
+                    f = poll_issue<32>(flags, lane);
 #pragma unroll
                     for (int i = 1; i < KBS; i++) { bh[i] = ldB(h_hi, boff[i]); bl[i] = ldB(h_lo, boff[i]); }
                     ok = poll_result(f, needH);
 #pragma unroll
                     for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
                 }
+                STAMP16(1)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 1; i < KBS; i++)
 #pragma unroll
-                    for (int p = 0; p < 2; p++) accR[p] = mfma3(wr_hi[p][i], wr_lo[p][i], bh[i], bl[i], accR[p]);
-#pragma unroll
-                for (int i = 1; i < KBS; i++)
-#pragma unroll
-                    for (int p = 0; p < 2; p++) accZ[p] = mfma3(wz_hi[p][i], wz_lo[p][i], bh[i], bl[i], accZ[p]);
+                    for (int p = 0; p < 2; p++) accR[p] = mfma3<ABL>(wr_hi[p][i], wr_lo[p][i], bh[i], bl[i], accR[p]);
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f)::"memory");
             }
-            // r, r*h -> operand images of the candidate product (the z MFMAs above execute underneath this arithmetic)
+            __builtin_amdgcn_sched_barrier(0);
+            // ---------------- z MFMAs, with the r epilogue in their issue gaps ----------------
+#pragma unroll
+            for (int i = 0; i < KBS; i++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) accZ[p] = mfma3<ABL>(wz_hi[p][i], wz_lo[p][i], bh[i], bl[i], accZ[p]);
             float rr[2];
 #pragma unroll
-            for (int p = 0; p < 2; p++) rr[p] = slk_sigmoid(fmaf(sel4(accR[p], q), inv_r[p], vr[p]));
+            for (int p = 0; p < 2; p++) rr[p] = (ABL & 4) ? fmaf(sel4(accR[p], q), inv_r[p], vr[p]) * 0.01f : slk_sigmoid(fmaf(sel4(accR[p], q), inv_r[p], vr[p]));
             {
                 unsigned hi, lo;
                 split2(rr[0] * hold[0], rr[1] * hold[1], hi, lo);
                 rh_hi[wd] = hi;
                 rh_lo[wd] = lo;
             }
+            // one MFMA, then up to three VALU instructions, for as long as both last
+#pragma unroll
+            for (int i = 0; i < 6 * KBS; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
             publish(flags, w, s + 1, lane);
+            STAMP16(2)
             if constexpr (SAVE) {
                 const size_t trow = (size_t)(reverse ? T - 1 - s : s) * B + b0 + c;
                 if (b0 + c < B) {
@@ -275,38 +329,33 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
             half8 ch[KBS], cl[KBS];
             ch[0] = ldB(rh_hi, boff[0]);
             cl[0] = ldB(rh_lo, boff[0]);
-            f = poll_issue(flags, lane);
+            f = poll_issue<32>(flags, lane);
 #pragma unroll
             for (int i = 1; i < KBS; i++) { ch[i] = ldB(rh_hi, boff[i]); cl[i] = ldB(rh_lo, boff[i]); }
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (KBS - 1) + 1) : "memory");
             keep(ch[0]); keep(cl[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 0; p < 2; p++) accC[p] = mfma3(wc_hi[p][0], wc_lo[p][0], ch[0], cl[0], accC[p]);
-            // the update gate, needed only at the end of the step
-            float zz[2];
-#pragma unroll
-            for (int p = 0; p < 2; p++) zz[p] = slk_sigmoid(fmaf(sel4(accZ[p], q), inv_z[p], vz[p]));
+            for (int p = 0; p < 2; p++) accC[p] = mfma3<ABL>(wc_hi[p][0], wc_lo[p][0], ch[0], cl[0], accC[p]);
             if constexpr (KBS > 1) {
-                bool ok = poll_result(f, needRH);
+                bool ok = poll_result(f, needRH) || (ABL & 2);
 #pragma unroll
                 for (int i = 1; i < KBS; i++) { keep(ch[i]); keep(cl[i]); }
                 while (!ok) {
-                    f = poll_issue(flags, lane);
+                    if constexpr (DIAG) stamp_acc[9]++;
+                    f = poll_issue<32>(flags, lane);
 #pragma unroll
                     for (int i = 1; i < KBS; i++) { ch[i] = ldB(rh_hi, boff[i]); cl[i] = ldB(rh_lo, boff[i]); }
                     ok = poll_result(f, needRH);
 #pragma unroll
                     for (int i = 1; i < KBS; i++) { keep(ch[i]); keep(cl[i]); }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 1; i < KBS; i++)
-#pragma unroll
-                    for (int p = 0; p < 2; p++) accC[p] = mfma3(wc_hi[p][i], wc_lo[p][i], ch[i], cl[i], accC[p]);
+                STAMP16(3)
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f)::"memory");
             }
+            __builtin_amdgcn_sched_barrier(0);
+            // c others, with the update gate and the requests for vI(s+1) in their issue gaps
             // vI(s+1), one step ahead (its latency disappears behind the candidate chain)
             const float *vnext = vbuf + ((s + 1) % R) * (3 * N * 4);
             const bool more = s + 1 < T;
@@ -321,9 +370,28 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
                 }
             };
             if (more) {
-                fv = poll_issue(flags, lane);
+                fv = poll_issue<32>(flags, lane);
                 read_vnext();
             }
+#pragma unroll
+            for (int i = 1; i < KBS; i++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) accC[p] = mfma3<ABL>(wc_hi[p][i], wc_lo[p][i], ch[i], cl[i], accC[p]);
+            float zz[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) zz[p] = (ABL & 4) ? fmaf(sel4(accZ[p], q), inv_z[p], vz[p]) * 0.01f : slk_sigmoid(fmaf(sel4(accZ[p], q), inv_z[p], vz[p]));
+            float omz[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                omz[p] = 1.0f - zz[p];
+                asm volatile("" : "+v"(zz[p]), "+v"(omz[p]));                 // pinned here: not sunk to the blend below
+            }
+#pragma unroll
+            for (int i = 0; i < 6 * (KBS - 1); i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (SAVE) {
                 const size_t trow = (size_t)(reverse ? T - 1 - s : s) * B + b0 + c;
                 if (b0 + c < B) {
@@ -331,24 +399,28 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
                     zr_out[trow * (2 * N) + n0 + 16] = zz[1];
                 }
             }
+            STAMP16(4)
             float hn[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                const float hbar = slk_tanh(fmaf(sel4(accC[p], q), inv_c[p], vc[p]));
-                hn[p] = zz[p] * hold[p] + (1.0f - zz[p]) * hbar;              // layers.py:1020
+                const float hbar = (ABL & 4) ? fmaf(sel4(accC[p], q), inv_c[p], vc[p]) * 0.01f : slk_tanh(fmaf(sel4(accC[p], q), inv_c[p], vc[p]));
+                hn[p] = zz[p] * hold[p] + omz[p] * hbar;                      // layers.py:1020
             }
+            STAMP16(7)
             if (more) {                                      // long since answered; checked before the writes below queue up
-                bool ok = poll_result(fv, needV);
+                bool ok = poll_result(fv, needV) || (ABL & 2);
 #pragma unroll
                 for (int p = 0; p < 2; p++) { keep(vzn[p]); keep(vrn[p]); keep(vcn[p]); }
                 while (!ok) {
-                    const int f2 = poll_issue(flags, lane);
+                    if constexpr (DIAG) stamp_acc[10]++;
+                    const int f2 = poll_issue<32>(flags, lane);
                     read_vnext();
                     ok = poll_result(f2, needV);
 #pragma unroll
                     for (int p = 0; p < 2; p++) { keep(vzn[p]); keep(vrn[p]); keep(vcn[p]); }
                 }
             }
+            STAMP16(6)
             {
                 unsigned hi, lo;
                 split2(hn[0], hn[1], hi, lo);
@@ -361,23 +433,35 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
             publish(flags, 4 + w, s + 1, lane);
 #pragma unroll
             for (int p = 0; p < 2; p++) { hold[p] = hn[p]; vz[p] = vzn[p]; vr[p] = vrn[p]; vc[p] = vcn[p]; }
+            STAMP16(5)
+        }
+        if constexpr (DIAG) {
+            if (blockIdx.x == 0 && tid == 0)
+                for (int i = 0; i < 12; i++) slk_dbg_stamp16[i] = stamp_acc[i];
         }
     } else {
         // =================================================================================================
-        // projection waves (vI = x.iW^T + b four steps at a time, x DMA, h_out copies)
+        // projection waves (vI = x.iW^T + b four steps at a time); the service waves 4-7 also run the x DMA and copy
+        // finished blocks of states to h_out
         // =================================================================================================
-        const int pw = wave - 4;
+        const bool service = wave >= 4;
+        const int pw = wave - 4;                            // service index 0..3
+        const int ew = wave - NCW;                          // extra index 0..3-NCW (waves NCW..3)
+        const bool on_free_simd = (wave & 3) >= NCW;
+        const int free_idx = wave < 4 ? wave - NCW : (4 - NCW) + (wave - 4 - NCW);
+        const int ntile = on_free_simd ? FREE_EACH : SH_BASE + ((wave - 4) < SH_EXTRA ? 1 : 0);
+        const int tile0 = on_free_simd ? free_idx * FREE_EACH
+                                       : NFREE * FREE_EACH + (wave - 4) * SH_BASE + min(wave - 4, SH_EXTRA);
+        const int my_tiles = max(0, min(ntile, NT16 - tile0));
         const int col = lane & 15, kq = lane >> 4;
-        constexpr bool LAST_MAYBE = (NT16 % 4) != 0;        // the last tile slot exists only for some waves
-        const bool last_ok = pw + 4 * (NTW - 1) < NT16;
         // B operands: lane holds vI row 16*t + col, k = 32*kb + 8*kq + 0..7, as fp16 hi and lo parts
         // (rows scaled by a power of two like the recurrent weights; the lane that holds a row is the lane that stores it)
-        half8 whi[NTW][KBLK], wlo[NTW][KBLK];
-        float inv_w[NTW];
+        half8 whi[MAXT][KBLK], wlo[MAXT][KBLK];
+        float inv_w[MAXT];
 #pragma unroll
-        for (int i = 0; i < NTW; i++) {
-            const bool ok = (i < NTW - 1) || !LAST_MAYBE || last_ok;
-            const int row = ok ? 16 * (pw + 4 * i) + col : 0;
+        for (int i = 0; i < MAXT; i++) {
+            const bool ok = i < my_tiles;
+            const int row = ok ? 16 * (tile0 + i) + col : 0;
             float u[KBLK][8];
             float m = 0.0f;
 #pragma unroll
@@ -447,105 +531,116 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
         };
         auto wait_flags = [&](int group, int value) {       // every counter of `group` (0 fA, 1 fB) >= value
             const int need = cls == group ? value : INT_MIN;
-            while (!reached(flags, lane, need)) __builtin_amdgcn_s_sleep(1);
+            while (!reached<32>(flags, lane, need)) __builtin_amdgcn_s_sleep(1);
         };
-        auto wait_xflags = [&](int group, int value) {      // group 0 xready, 1 xdone (lanes watch xflags[l & 15], 8..15 stay 0)
-            const int need = cls == group ? value : INT_MIN;
-            while (!reached(xflags, lane, need)) __builtin_amdgcn_s_sleep(1);
+        auto wait_xready = [&](int value) {
+            const int need = cls == 0 ? value : INT_MIN;
+            while (!reached<32>(xflags, lane, need)) __builtin_amdgcn_s_sleep(1);
+        };
+        auto wait_xdone = [&](int value) {                  // service and extra waves past block value-1
+            const int need = (cls == 1 || cls == 2) ? value : INT_MIN;
+            while (!reached<32>(xflags, lane, need)) __builtin_amdgcn_s_sleep(1);
         };
 
-        dma_block(0, 0);
+        if (service) dma_block(0, 0);
         const int NG = (T + GS - 1) / GS;
         for (int qg = 0; qg < NG; qg++) {
             if ((qg & 1) == 0) {                                        // KB = 2 groups: a new x block starts here
                 const int xb = qg / 2;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my share of block xb (issued a block ago) landed
-                publish(xflags, pw, xb + 1, lane);
-                publish(xflags, 4 + pw, xb, lane);                      // and I am done reading block xb-1
-                if ((xb + 1) * KB < T) {
-                    wait_xflags(1, xb);                                 // slot (xb+1)&1 held block xb-1: everyone past it
-                    dma_block((xb + 1) * KB, (xb + 1) & 1);
+                if (service) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of block xb (issued a block ago) landed
+                    publish(xflags, pw, xb + 1, lane);
+                    publish(xflags, 4 + pw, xb, lane);                  // and I am done reading block xb-1
+                    if ((xb + 1) * KB < T) {
+                        wait_xdone(xb);                                 // slot (xb+1)&1 held block xb-1: everyone past it
+                        dma_block((xb + 1) * KB, (xb + 1) & 1);
+                    }
+                } else {
+                    publish(xflags, 8 + ew, xb, lane);
                 }
-                wait_xflags(0, xb + 1);
-            } else if (qg >= 3) {
+                wait_xready(xb + 1);
+            } else if (service && qg >= 3) {
                 // copy a finished block of states out (vI is published through step 4qg-1, block fkb ends at step 4qg-5)
                 const int fkb = (qg - 3) / 2;
                 wait_flags(1, (fkb + 1) * KB);
                 for (int j = 0; j < NFL; j++) flush_part(fkb, j);
                 publish(flags, 12 + pw, fkb + 1, lane);
             }
-            // ---- the group's A operands (x split into halves on the fly; XSCALE: each row scaled by a power of two so that
-            //      its largest |x| lies in [1, 2) -- exact, undone on the accumulators), then every tile's three MFMAs ----
-            const float *img = xbuf + ((qg >> 1) & 1) * (KB * XIMG) + (GS * (qg & 1) + a_step) * XIMG + 4 * a_chunk;
-            f32x4 xu[KBLK][2];
-            float amax = 0.0f;
+            if (my_tiles > 0 && !(ABL & 8)) {
+                // ---- the group's A operands (x split into halves on the fly; each row scaled by a power of two so that its
+                //      largest |x| lies in [1, 2) -- exact, undone on the accumulators), then every tile's three MFMAs ----
+                const float *img = xbuf + ((qg >> 1) & 1) * (KB * XIMG) + (GS * (qg & 1) + a_step) * XIMG + 4 * a_chunk;
+                f32x4 xu[KBLK][2];
+                float amax = 0.0f;
 #pragma unroll
-            for (int kb = 0; kb < KBLK; kb++) {
-                const int k0 = 32 * kb + 8 * kq;
-                const bool kok = (I % 32 == 0) || k0 < I;
-                const float *src = img + 4 * (kok ? k0 : 0);           // 16 * (k0 / 4)
-                xu[kb][0] = *reinterpret_cast<const f32x4 *>(src);
-                xu[kb][1] = *reinterpret_cast<const f32x4 *>(src + 16);
+                for (int kb = 0; kb < KBLK; kb++) {
+                    const int k0 = 32 * kb + 8 * kq;
+                    const bool kok = (I % 32 == 0) || k0 < I;
+                    const float *src = img + 4 * (kok ? k0 : 0);           // 16 * (k0 / 4)
+                    xu[kb][0] = *reinterpret_cast<const f32x4 *>(src);
+                    xu[kb][1] = *reinterpret_cast<const f32x4 *>(src + 16);
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    if (!kok) xu[kb][j >> 2][j & 3] = 0.0f;
-                    amax = fmaxf(amax, fabsf(xu[kb][j >> 2][j & 3]));
-                }
-            }
-            // row maximum: the row's K is spread over the four k groups (lanes m, m+16, m+32, m+48)
-            amax = kgroup_max(amax);
-            float xinv;
-            const float xs = pow2_scale(amax, xinv);
-            // the accumulator rows of this lane are (step kq, chunk 0..3): their inverse scales sit in lanes 4*kq + (0..3)
-            f32x4 inv;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; r4++) inv[r4] = __shfl(xinv, 4 * kq + r4);
-            f32x4 acc[NTW];
-#pragma unroll
-            for (int i = 0; i < NTW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < KBLK; kb++) {
-                half8 ahi, alo;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float v = xu[kb][j >> 2][j & 3] * xs;
-                    const _Float16 h = (_Float16)v;
-                    ahi[j] = h;
-                    alo[j] = (_Float16)(v - (float)h);
-                }
-#pragma unroll
-                for (int i = 0; i < NTW; i++) {
-                    if (i < NTW - 1 || !LAST_MAYBE || last_ok) {
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wlo[i][kb], acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, whi[i][kb], acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, whi[i][kb], acc[i], 0, 0, 0);
+                    for (int j = 0; j < 8; j++) {
+                        if (!kok) xu[kb][j >> 2][j & 3] = 0.0f;
+                        amax = fmaxf(amax, fabsf(xu[kb][j >> 2][j & 3]));
                     }
                 }
-            }
-            // the group's ring slots were last read during steps GS*qg - R ... GS*qg + GS-1 - R
-            if (GS * qg + GS > R) wait_flags(0, GS * qg + GS - R);
-            // D: lane holds the four chunks of (step GS*qg + kq, vI row 16*t + col) = one 16-byte entry of vbuf
-            const int st = GS * qg + kq;
-            if (st < T) {
-                float *vdst = vbuf + (st % R) * (3 * N * 4) + 4 * col;
+                amax = kgroup_max(amax);
+                float xinv;
+                const float xs = pow2_scale(amax, xinv);
+                // the accumulator rows of this lane are (step kq, chunk 0..3): their inverse scales sit in lanes 4*kq + (0..3)
+                f32x4 inv;
 #pragma unroll
-                for (int i = 0; i < NTW; i++)
-                    if (i < NTW - 1 || !LAST_MAYBE || last_ok) {
-                        const float tb = bias_lds[16 * (pw + 4 * i) + col];
-                        f32x4 o;
+                for (int r4 = 0; r4 < 4; r4++) inv[r4] = __shfl(xinv, 4 * kq + r4);
+                f32x4 acc[MAXT];
 #pragma unroll
-                        for (int r4 = 0; r4 < 4; r4++) o[r4] = fmaf(acc[i][r4] * inv[r4], inv_w[i], tb);
-                        *reinterpret_cast<f32x4 *>(&vdst[64 * (pw + 4 * i)]) = o;
+                for (int i = 0; i < MAXT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kb = 0; kb < KBLK; kb++) {
+                    half8 ahi, alo;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float v = xu[kb][j >> 2][j & 3] * xs;
+                        const _Float16 h = (_Float16)v;
+                        ahi[j] = h;
+                        alo[j] = (_Float16)(v - (float)h);
                     }
+#pragma unroll
+                    for (int i = 0; i < MAXT; i++) {
+                        if (i < my_tiles) {
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wlo[i][kb], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, whi[i][kb], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, whi[i][kb], acc[i], 0, 0, 0);
+                        }
+                    }
+                }
+                // the group's ring slots were last read during steps GS*qg - R ... GS*qg + GS-1 - R
+                if (GS * qg + GS > R) wait_flags(0, GS * qg + GS - R);
+                // D: lane holds the four chunks of (step GS*qg + kq, vI row 16*t + col) = one 16-byte entry of vbuf
+                const int st = GS * qg + kq;
+                if (st < T) {
+                    float *vdst = vbuf + (st % R) * (3 * N * 4) + 4 * col;
+#pragma unroll
+                    for (int i = 0; i < MAXT; i++)
+                        if (i < my_tiles) {
+                            const float tb = bias_lds[16 * (tile0 + i) + col];
+                            f32x4 o;
+#pragma unroll
+                            for (int r4 = 0; r4 < 4; r4++) o[r4] = fmaf(acc[i][r4] * inv[r4], inv_w[i], tb);
+                            *reinterpret_cast<f32x4 *>(&vdst[64 * (tile0 + i)]) = o;
+                        }
+                }
             }
-            publish(flags, 8 + pw, GS * qg + GS, lane);
+            publish(flags, service ? 8 + pw : 16 + ew, GS * qg + GS, lane);
         }
-        // blocks of states the loop did not copy out
-        wait_flags(1, T);
-        const int kbl = (T - 1) / KB;
-        for (int kb = 0; kb <= kbl; kb++)
-            if (2 * kb + 3 >= NG)
-                for (int j = 0; j < NFL; j++) flush_part(kb, j);
+        if (service) {
+            // blocks of states the loop did not copy out
+            wait_flags(1, T);
+            const int kbl = (T - 1) / KB;
+            for (int kb = 0; kb <= kbl; kb++)
+                if (2 * kb + 3 >= NG)
+                    for (int j = 0; j < NFL; j++) flush_part(kb, j);
+        }
     }
 }
 
@@ -567,6 +662,19 @@ template <int I, int N>
 static int launch_fused16(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
                           float *y, long ldy, int T, int B, int reverse, const int *lens, float *zr_out, hipStream_t s)
 {
+    if constexpr (I == 96 && N == 96) {
+        const int dv = reverse >> 1;                    // diagnostic launches (undocumented bits, tools/bench_kernels.py)
+#define DIAG_LAUNCH(CODE, STAMPS, ABLV)                                                                                   \
+        if (dv == CODE) {                                                                                                 \
+            static const size_t dyn = exclusive_cu_lds16(gru_fused16_kernel<I, N, false, STAMPS, ABLV>);                  \
+            hipLaunchKernelGGL((gru_fused16_kernel<I, N, false, STAMPS, ABLV>), dim3((B + 3) / 4), dim3(512), dyn, s, x, ldx, \
+                               iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, lens, zr_out);                                \
+            return slk_launch_status();                                                                                    \
+        }
+        DIAG_LAUNCH(1, true, 0) DIAG_LAUNCH(2, false, 1) DIAG_LAUNCH(3, false, 2) DIAG_LAUNCH(4, false, 4) DIAG_LAUNCH(5, false, 8)
+        DIAG_LAUNCH(6, false, 3) DIAG_LAUNCH(7, false, 7) DIAG_LAUNCH(8, false, 15) DIAG_LAUNCH(9, false, 10)
+#undef DIAG_LAUNCH
+    }
     if (zr_out) {
         static const size_t dyn = exclusive_cu_lds16(gru_fused16_kernel<I, N, true>);
         hipLaunchKernelGGL((gru_fused16_kernel<I, N, true>), dim3((B + 3) / 4), dim3(512), dyn, s, x, ldx, iW, bias, sW, sW2, y,

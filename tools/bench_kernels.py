@@ -44,6 +44,40 @@ def main():
                                                            n, 0, 1, 2, generic, st))
             fl = 6.0 * T * B * n * n
             print("gru_recurrent n=%d B=%d T=%d generic=%d: %.3f ms  %.1f TF  %.0f ns/step" % (n, B, T, generic, ms, fl / ms / 1e9, ms * 1e6 / T))
+    if "gruf16" in what:
+        import ctypes
+        I = n
+        x = torch.randn(T, B, I, device="cuda")
+        iW = torch.randn(3 * n, I, device="cuda") / np.sqrt(I + n)
+        bb = torch.randn(3 * n, device="cuda")
+        sW = torch.randn(2 * n, n, device="cuda") / np.sqrt(2 * n)
+        sW2 = torch.randn(n, n, device="cuda") / np.sqrt(2 * n)
+        y = torch.empty(T, B, n, device="cuda")
+        call = lambda rev: L.slk_gru_fused16_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(),
+                                                 y.data_ptr(), n, T, B, I, n, rev, 1, 2, None, None, st)
+        assert call(0) == 0
+        for rnd in range(2):
+            ms = timeit(lambda: call(0))
+            print("gru_fused16 n=%d B=%d T=%d: %.3f ms  %.0f ns/step = %.0f cycles at 2.39 GHz" % (n, B, T, ms, ms * 1e6 / T, ms * 1e6 / T * 2.39))
+        for code, nm in ((2, "no chain MFMAs"), (3, "polls never wait"), (4, "cheap activations"), (5, "projection idle"),
+                         (6, "no MFMAs + no waits"), (7, "no MFMAs, no waits, cheap act"), (8, "all four"), (9, "no waits + projection idle")):
+            ms = timeit(lambda: call(2 * code))
+            print("   ablation %-32s %.3f ms  %.0f cycles/step" % (nm, ms, ms * 1e6 / T * 2.39))
+        ms = timeit(lambda: call(2))
+        torch.cuda.synchronize()
+        stp = (ctypes.c_ulonglong * 16)()
+        L.slk_debug_read_stamps16.argtypes = [ctypes.c_void_p]
+        L.slk_debug_read_stamps16(stp)
+        names = ["loop top -> (vI prefetch wait etc.)", "own-block r|z MFMAs + wait for h", "r|z others + r epilogue + publish",
+                 "own c MFMAs + z epilogue + wait for r*h", "c others + vI prefetch issue", "c epilogue + writes + publish"]
+        names = ["loop top", "own-block r|z MFMAs + wait for h", "r|z others + r epilogue + publish",
+                 "own c MFMAs + z epilogue + wait for r*h", "c others + vI prefetch issue", "split/writes/publish",
+                 "wait for vI(s+1)", "tanh + blend (waits for the c MFMAs)"]
+        tot = sum(stp[i] for i in range(8))
+        print("diag launch %.3f ms; cycles per step (wave 0 of workgroup 0): total %.0f" % (ms, tot / T))
+        for i, nm in enumerate(names):
+            print("   %-44s %7.0f" % (nm, stp[i] / T))
+        print("   poll retries per step: h %.2f  r*h %.2f  vI/flush %.2f" % (stp[8] / T, stp[9] / T, stp[10] / T))
     if "gruf" in what:
         I = n
         x = torch.randn(T, B, I, device="cuda")
