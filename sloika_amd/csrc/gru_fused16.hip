@@ -89,6 +89,21 @@ __device__ __forceinline__ f32x4 mfma3(const half8 &w_hi, const half8 &w_lo, con
 // Diagnostic instantiation: shader-clock cycles workgroup 0's chain wave 0 spends between the marks of one step, summed over
 // the scan (tools/bench_kernels.py --what gruf16 reads them).  The production instantiation carries none of this.
 __device__ unsigned long long slk_dbg_stamp16[16];
+__device__ unsigned long long slk_dbg_pstamp16[8][8];          // projection waves of workgroup 0: cycles per section
+extern "C" int slk_debug_read_pstamps16(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_pstamp16), sizeof(unsigned long long) * 64) == hipSuccess ? SLK_OK
+                                                                                                                   : SLK_ERR_LAUNCH;
+}
+#define PSTAMP(i)                                                                     \
+    if constexpr (DIAG) {                                                             \
+        unsigned long long tnow;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");   \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        pacc[i] += tnow - ptprev;                                                     \
+        ptprev = tnow;                                                                \
+    }
 extern "C" int slk_debug_read_stamps16(unsigned long long *host_out)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_stamp16), sizeof(unsigned long long) * 16) == hipSuccess ? SLK_OK
@@ -126,9 +141,10 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
     constexpr int R = 2 * GS;                            // vI ring: the projection works one group of steps ahead
     constexpr int XIMG = 4 * I;                          // floats of one step's x image: [k/4][chunk][k%4]
     constexpr int XPIECES = KB * I;                      // 16-byte pieces per x block
-    constexpr int NDMA = (XPIECES / 64 + 3) / 4;
+    constexpr int XSLOTS = 4;                            // x ring: blocks are requested XSLOTS-1 blocks (24 steps) ahead
+    constexpr int NPER = (XPIECES / 64 + 1) / 2;         // 1 KiB DMA requests per block and DMA wave (service waves 0, 1)
     constexpr int HSLOTS = 3 * KB, HIMG = 4 * N;         // float32 state history [slot][neuron][chunk] = h_out staging
-    __shared__ __attribute__((aligned(16))) float xbuf[2 * KB * XIMG];
+    __shared__ __attribute__((aligned(16))) float xbuf[XSLOTS * KB * XIMG];
     __shared__ __attribute__((aligned(16))) float vbuf[R * 3 * N * 4];      // vI[slot][row][chunk]
     __shared__ __attribute__((aligned(16))) float hring[HSLOTS * HIMG];
     // MFMA B-operand images of h and r*h: [k block][k group 4][chunk 4][8 halves], hi and lo parts
@@ -151,7 +167,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
     // 4+NCW..7); the waves that share a SIMD with a chain wave take what is left.  Measured with the projection spread
     // evenly over waves 4-7, the chain spent a sixth of every step waiting for vI.
     constexpr int NFREE = 2 * (4 - NCW);
-    constexpr int TILE_CAP = (N == 96) ? (KBLK <= 3 ? 5 : 4) : (N == 64 ? 3 : 1);      // register budget of one wave
+    constexpr int TILE_CAP = (N == 96) ? 4 : (N == 64 ? 3 : 1);      // register budget of one wave
     constexpr int FREE_EACH = (NT16 + NFREE - 1) / NFREE < TILE_CAP ? (NT16 + NFREE - 1) / NFREE : TILE_CAP;
     constexpr int REM = NT16 - NFREE * FREE_EACH > 0 ? NT16 - NFREE * FREE_EACH : 0;
     constexpr int SH_BASE = REM / NCW, SH_EXTRA = REM % NCW;
@@ -163,8 +179,9 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
     if (tid < 32) {
         const int idx = tid & 3, grp = tid >> 2;
         const bool extra_missing = idx >= 4 - NCW;          // extra projection wave idx = wave NCW + idx
-        flags[tid] = ((grp < 2 && idx >= NCW) || (grp == 4 && extra_missing)) ? INT_MAX : 0;
-        xflags[tid] = (grp == 2 && extra_missing) ? INT_MAX : 0;
+        // service waves 0, 1 run the x DMA (xready), 2, 3 copy states out (flushed)
+        flags[tid] = ((grp < 2 && idx >= NCW) || (grp == 4 && extra_missing) || (grp == 3 && idx < 2)) ? INT_MAX : 0;
+        xflags[tid] = ((grp == 2 && extra_missing) || (grp == 0 && idx >= 2)) ? INT_MAX : 0;
     }
     __syncthreads();                                     // the only hardware barrier
 
@@ -294,11 +311,9 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f)::"memory");
             }
             __builtin_amdgcn_sched_barrier(0);
-            // ---------------- z MFMAs, with the r epilogue in their issue gaps ----------------
+            // ---------------- z MFMAs, first part, with the r epilogue in their issue gaps ----------------
 #pragma unroll
-            for (int i = 0; i < KBS; i++)
-#pragma unroll
-                for (int p = 0; p < 2; p++) accZ[p] = mfma3<ABL>(wz_hi[p][i], wz_lo[p][i], bh[i], bl[i], accZ[p]);
+            for (int p = 0; p < 2; p++) accZ[p] = mfma3<ABL>(wz_hi[p][0], wz_lo[p][0], bh[0], bl[0], accZ[p]);
             float rr[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) rr[p] = (ABL & 4) ? fmaf(sel4(accR[p], q), inv_r[p], vr[p]) * 0.01f : slk_sigmoid(fmaf(sel4(accR[p], q), inv_r[p], vr[p]));
@@ -308,11 +323,11 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
                 rh_hi[wd] = hi;
                 rh_lo[wd] = lo;
             }
-            // one MFMA, then up to three VALU instructions, for as long as both last
+            // one MFMA, then up to four VALU instructions, for as long as both last
 #pragma unroll
-            for (int i = 0; i < 6 * KBS; i++) {
+            for (int i = 0; i < 6; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             }
             publish(flags, w, s + 1, lane);
             STAMP16(2)
@@ -332,6 +347,13 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
             f = poll_issue<32>(flags, lane);
 #pragma unroll
             for (int i = 1; i < KBS; i++) { ch[i] = ldB(rh_hi, boff[i]); cl[i] = ldB(rh_lo, boff[i]); }
+            // the rest of the z MFMAs execute while the other waves' r*h is on its way
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 1; i < KBS; i++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) accZ[p] = mfma3<ABL>(wz_hi[p][i], wz_lo[p][i], bh[i], bl[i], accZ[p]);
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (KBS - 1) + 1) : "memory");
             keep(ch[0]); keep(cl[0]);
             __builtin_amdgcn_sched_barrier(0);
@@ -492,10 +514,10 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
         // A operands: lane supplies row m = lane & 15 = (step in group, chunk) and k = 32*kb + 8*kq + 0..7 from the
         // step's x image, where element x[chunk][k] sits at 16*(k>>2) + 4*chunk + (k&3)
         const int a_step = col >> 2, a_chunk = col & 3;
-        auto dma_block = [&](int s0, int slot) {
+        auto dma_block = [&](int s0, int slot) {             // service waves 0, 1: NPER requests each
 #pragma unroll
-            for (int j = 0; j < NDMA; j++) {
-                const int piece0 = (j * 4 + pw) * 64;
+            for (int j = 0; j < NPER; j++) {
+                const int piece0 = (j * 2 + pw) * 64;
                 if (piece0 < XPIECES) {
                     const int p = piece0 + lane;
                     const int kk = p / I, pp = p % I, qq = pp >> 2, cc = pp & 3;
@@ -509,14 +531,19 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                      (__attribute__((address_space(3))) void *)&xbuf[slot * (KB * XIMG) + piece0 * 4],
                                                      16, 0, 0);
+                } else {
+                    // keep the number of requests per block fixed (the waits below count them): repeat the first piece
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + 4 * (lane % (I / 4))),
+                                                     (__attribute__((address_space(3))) void *)&xbuf[slot * (KB * XIMG) + XPIECES * 4 - 256],
+                                                     16, 0, 0);
                 }
             }
         };
         const bool vec_store = (ldh % 4 == 0) && ((reinterpret_cast<uintptr_t>(h_out) & 15) == 0);
         constexpr int OF4 = KB * N;                         // float4s per block
-        constexpr int NFL = (OF4 + 255) / 256;              // parts per block
+        constexpr int NFL = (OF4 + 127) / 128;              // parts per block (service waves 2, 3: 128 threads)
         auto flush_part = [&](int kb, int j) {
-            const int idx = (tid - 256) + 256 * j;
+            const int idx = (tid - 384) + 128 * j;
             const int cc = idx & 3, rest = idx >> 2, f4 = rest % (N / 4), kk = rest / (N / 4);
             const int ss = kb * KB + kk;
             const int Tc = (lens && b0 + cc < B) ? min(max(lens[b0 + cc], 1), T) : T;
@@ -542,48 +569,55 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
             while (!reached<32>(xflags, lane, need)) __builtin_amdgcn_s_sleep(1);
         };
 
-        if (service) dma_block(0, 0);
+        const bool dma_wave = service && pw < 2, flush_wave = service && pw >= 2;
+        unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ptprev = 0;
+        if constexpr (DIAG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ptprev)::"memory"); }
+        const int NBLK = (T + KB - 1) / KB;
+        if (dma_wave)
+            for (int xb = 0; xb < XSLOTS - 1 && xb < NBLK; xb++) dma_block(xb * KB, xb);
         const int NG = (T + GS - 1) / GS;
         for (int qg = 0; qg < NG; qg++) {
+            PSTAMP(0)
             if ((qg & 1) == 0) {                                        // KB = 2 groups: a new x block starts here
                 const int xb = qg / 2;
-                if (service) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my share of block xb (issued a block ago) landed
+                if (dma_wave) {
+                    // my share of block xb has landed once at most the requests of the younger blocks are outstanding
+                    // (these waves issue no other vector memory operation; requests complete in order)
+                    const int younger = min(XSLOTS - 2, NBLK - 1 - xb);
+                    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPER) : "memory");
+                    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPER) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     publish(xflags, pw, xb + 1, lane);
-                    publish(xflags, 4 + pw, xb, lane);                  // and I am done reading block xb-1
-                    if ((xb + 1) * KB < T) {
-                        wait_xdone(xb);                                 // slot (xb+1)&1 held block xb-1: everyone past it
-                        dma_block((xb + 1) * KB, (xb + 1) & 1);
-                    }
-                } else {
-                    publish(xflags, 8 + ew, xb, lane);
+                }
+                if (service) publish(xflags, 4 + pw, xb, lane);         // I am done reading block xb-1
+                else publish(xflags, 8 + ew, xb, lane);
+                if (dma_wave && xb + XSLOTS - 1 < NBLK) {
+                    wait_xdone(xb);                                     // the slot held block xb-1: everyone past it
+                    dma_block((xb + XSLOTS - 1) * KB, (xb + XSLOTS - 1) % XSLOTS);
                 }
                 wait_xready(xb + 1);
-            } else if (service && qg >= 3) {
+            } else if (flush_wave && qg >= 3) {
                 // copy a finished block of states out (vI is published through step 4qg-1, block fkb ends at step 4qg-5)
                 const int fkb = (qg - 3) / 2;
                 wait_flags(1, (fkb + 1) * KB);
                 for (int j = 0; j < NFL; j++) flush_part(fkb, j);
                 publish(flags, 12 + pw, fkb + 1, lane);
             }
+            PSTAMP(1)
             if (my_tiles > 0 && !(ABL & 8)) {
                 // ---- the group's A operands (x split into halves on the fly; each row scaled by a power of two so that its
                 //      largest |x| lies in [1, 2) -- exact, undone on the accumulators), then every tile's three MFMAs ----
-                const float *img = xbuf + ((qg >> 1) & 1) * (KB * XIMG) + (GS * (qg & 1) + a_step) * XIMG + 4 * a_chunk;
-                f32x4 xu[KBLK][2];
+                const float *img = xbuf + ((qg >> 1) % XSLOTS) * (KB * XIMG) + (GS * (qg & 1) + a_step) * XIMG + 4 * a_chunk;
+                // (two passes over the image instead of holding it: the weights leave few registers)
                 float amax = 0.0f;
 #pragma unroll
                 for (int kb = 0; kb < KBLK; kb++) {
                     const int k0 = 32 * kb + 8 * kq;
                     const bool kok = (I % 32 == 0) || k0 < I;
                     const float *src = img + 4 * (kok ? k0 : 0);           // 16 * (k0 / 4)
-                    xu[kb][0] = *reinterpret_cast<const f32x4 *>(src);
-                    xu[kb][1] = *reinterpret_cast<const f32x4 *>(src + 16);
+                    const f32x4 u0 = *reinterpret_cast<const f32x4 *>(src), u1 = *reinterpret_cast<const f32x4 *>(src + 16);
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        if (!kok) xu[kb][j >> 2][j & 3] = 0.0f;
-                        amax = fmaxf(amax, fabsf(xu[kb][j >> 2][j & 3]));
-                    }
+                    for (int j = 0; j < 4; j++) amax = fmaxf(amax, kok ? fmaxf(fabsf(u0[j]), fabsf(u1[j])) : 0.0f);
                 }
                 amax = kgroup_max(amax);
                 float xinv;
@@ -597,10 +631,14 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
                 for (int i = 0; i < MAXT; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kb = 0; kb < KBLK; kb++) {
+                    const int k0 = 32 * kb + 8 * kq;
+                    const bool kok = (I % 32 == 0) || k0 < I;
+                    const float *src = img + 4 * (kok ? k0 : 0);
+                    const f32x4 u0 = *reinterpret_cast<const f32x4 *>(src), u1 = *reinterpret_cast<const f32x4 *>(src + 16);
                     half8 ahi, alo;
 #pragma unroll
                     for (int j = 0; j < 8; j++) {
-                        const float v = xu[kb][j >> 2][j & 3] * xs;
+                        const float v = kok ? (j < 4 ? u0[j & 3] : u1[j & 3]) * xs : 0.0f;
                         const _Float16 h = (_Float16)v;
                         ahi[j] = h;
                         alo[j] = (_Float16)(v - (float)h);
@@ -614,8 +652,10 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
                         }
                     }
                 }
+                PSTAMP(2)
                 // the group's ring slots were last read during steps GS*qg - R ... GS*qg + GS-1 - R
                 if (GS * qg + GS > R) wait_flags(0, GS * qg + GS - R);
+                PSTAMP(3)
                 // D: lane holds the four chunks of (step GS*qg + kq, vI row 16*t + col) = one 16-byte entry of vbuf
                 const int st = GS * qg + kq;
                 if (st < T) {
@@ -632,8 +672,13 @@ __global__ void __launch_bounds__(512, 2) gru_fused16_kernel(const float *__rest
                 }
             }
             publish(flags, service ? 8 + pw : 16 + ew, GS * qg + GS, lane);
+            PSTAMP(4)
         }
-        if (service) {
+        if constexpr (DIAG) {
+            if (blockIdx.x == 0 && lane == 0)
+                for (int i = 0; i < 8; i++) slk_dbg_pstamp16[wave][i] = pacc[i];
+        }
+        if (flush_wave) {
             // blocks of states the loop did not copy out
             wait_flags(1, T);
             const int kbl = (T - 1) / KB;
@@ -672,7 +717,7 @@ static int launch_fused16(const float *x, long ldx, const float *iW, const float
             return slk_launch_status();                                                                                    \
         }
         DIAG_LAUNCH(1, true, 0) DIAG_LAUNCH(2, false, 1) DIAG_LAUNCH(3, false, 2) DIAG_LAUNCH(4, false, 4) DIAG_LAUNCH(5, false, 8)
-        DIAG_LAUNCH(6, false, 3) DIAG_LAUNCH(7, false, 7) DIAG_LAUNCH(8, false, 15) DIAG_LAUNCH(9, false, 10)
+        DIAG_LAUNCH(6, false, 3) DIAG_LAUNCH(7, false, 7) DIAG_LAUNCH(8, false, 15) DIAG_LAUNCH(9, false, 10) DIAG_LAUNCH(10, true, 3)
 #undef DIAG_LAUNCH
     }
     if (zr_out) {

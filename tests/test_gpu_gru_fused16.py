@@ -98,9 +98,14 @@ def test_fused16_trained_weight_magnitudes(oracle):
     from sloika_amd import _lib
     I, n, T, B = 96, 96, 60, 7
     rs = np.random.RandomState(11)
-    iW, sW, sW2, b = _params(rs, I, n, scale=12.0)
-    iW *= 4.0
-    assert np.abs(sW2).max() > 3.0
+    iW, sW, sW2, b = _params(rs, I, n, scale=3.0)
+    # a few weights of the size the trained model holds (pretrained.pkl: sW2 up to 6), the bulk moderate: with EVERY weight
+    # that large the recurrence is chaotic and float32 evaluations in different orders diverge from each other
+    for m in (sW, sW2):
+        idx = rs.randint(0, m.size, size=60)
+        m.reshape(-1)[idx] = rs.choice([-6.0, 5.0, 4.5], size=60)
+    iW *= 2.0
+    assert np.abs(sW2).max() > 4.0
     x = rs.normal(size=(T, B, I)).astype(np.float32)
     for reverse in (False, True):
         ref = oracle.gru(x, iW, sW, sW2, b, reverse=reverse)

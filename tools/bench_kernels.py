@@ -78,6 +78,17 @@ def main():
         for i, nm in enumerate(names):
             print("   %-44s %7.0f" % (nm, stp[i] / T))
         print("   poll retries per step: h %.2f  r*h %.2f  vI/flush %.2f" % (stp[8] / T, stp[9] / T, stp[10] / T))
+        L.slk_debug_read_pstamps16.argtypes = [ctypes.c_void_p]
+        for code, nm in ((1, "normal run"), (10, "chain neither computes nor waits")):
+            timeit(lambda: call(2 * code), reps=2, warm=1)
+            torch.cuda.synchronize()
+            pst = (ctypes.c_ulonglong * 64)()
+            L.slk_debug_read_pstamps16(pst)
+            print("   projection waves, %s: cycles per GROUP of 4 steps [x-block/flush | x split + MFMAs | wait ring slot | store+publish | loop]" % nm)
+            for wv in range(8):
+                v = [pst[wv * 8 + i] / (T / 4) for i in range(5)]
+                if sum(v) > 0:
+                    print("      wave %d: %7.0f %7.0f %7.0f %7.0f %7.0f   total %7.0f" % (wv, v[1], v[2], v[3], v[4], v[0], sum(v)))
     if "gruf" in what:
         I = n
         x = torch.randn(T, B, I, device="cuda")
