@@ -264,6 +264,17 @@ int slk_argmax_decode_f32(const float *post, int T, int B, int nstate, int zero_
                           int32_t *len_out, slk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * f1. States -> bases (sloika/bio.py:160-179 max_overlap, :206-225 reduce_kmers, :228-237 kmers_to_sequence; what
+ *   basecall.SeqPrinter.write does with a call, basecall.py:157-163), for a whole batch of decoded paths on the device.
+ *   A state is the base-`nbase` number of its k-mer (first letter most significant, bio.py:12-24), so the overlap test
+ *   k1[i:] == k2[:-i] is  s1 mod nbase^(k-i) == s2 div nbase^i; the smallest such i is the move (k if none, 0 for a
+ *   repeated state unless always_move).  paths:[B][ld] int32, lens:[B]; alphabet: the letters packed little-endian in 8
+ *   bytes; out:[B][cap] bytes with cap >= klen * max(lens); nbases[b] = letters written for read b.
+ * ------------------------------------------------------------------------------------------------------- */
+int slk_paths_to_bases(const int32_t *paths, long ld, const int32_t *lens, int B, int klen, int nbase, int always_move,
+                       unsigned long long alphabet, uint8_t *out, long cap, int32_t *nbases, slk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * a9. The reference's only true FFI: viterbi_helpers.slip_update (sloika/viterbi_helpers.pyx:12-35), and
  * its caller transducer.map_to_sequence (sloika/transducer.py:14-73).
  *   slk_slip_update_f32: x:[n] -> from_score:[n] float32, from_pos:[n] int64; n >= 3.

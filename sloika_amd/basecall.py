@@ -114,7 +114,7 @@ class SeqPrinter(object):
     def __init__(self, kmer_len, datatype="events", transducer=False, fname=None, alphabet=DEFAULT_ALPHABET):
         if isinstance(alphabet, bytes):
             alphabet = alphabet.decode('utf-8')
-        self.kmers = bio.all_kmers(kmer_len, alphabet=alphabet)
+        self.kmer_len, self.alphabet = kmer_len, alphabet
         self.transducer = transducer
         self.datatype = datatype
         if fname is None:
@@ -129,8 +129,7 @@ class SeqPrinter(object):
             self.fh.close()
 
     def write(self, read_name, score, call, nev):
-        kmer_path = [self.kmers[i] for i in call]
-        seq = bio.kmers_to_sequence(kmer_path, always_move=self.transducer)
+        seq = bio.states_to_sequence(call, self.kmer_len, self.alphabet, always_move=self.transducer)
         self.fh.write(">{} score {:.0f}, {} {} to {} bases\n".format(read_name, score, nev, self.datatype, len(seq)))
         self.fh.write(seq + '\n')
         return len(seq)

@@ -141,3 +141,21 @@ def test_shard_bounds_cover_everything():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard.shard_bounds(4, 2, 2)
+
+
+def test_states_to_sequence_equals_string_route(golden_bio, golden_decode):
+    """The integer route (state numbers, no strings) gives what the reference's string route gave on the decode goldens."""
+    from sloika_amd import bio
+    for case in golden_bio["cases"]:
+        path = golden_decode["path_" + case["name"]]
+        assert bio.states_to_sequence(path, 5, "ACGT", always_move=True) == case["seq_always_move"]
+        assert bio.states_to_sequence(path, 5, b"ACGT", always_move=False) == case["seq_allow_stay"]
+    assert bio.states_to_sequence([], 5) == ""
+    assert bio.states_to_sequence([7], 3, "ACGT") == "ACT"
+    # reference known answers, test/unit/test_bio.py:137-148
+    assert bio.kmers_to_sequence(["AAC", "ACT", "CTG"]) == "AACTG"
+    assert bio.max_overlap(["AAC", "ACT", "ACT", "CTG", "GGA"]) == [1, 0, 1, 2]
+    assert bio.max_overlap(["AAC", "TTT"]) == [3]
+    assert bio.max_overlap(["AAA", "AAA"], allow_identical=False) == [1]
+    assert bio.moves_compatible(["AAC", "ACT", "GGA"], [1, 3]) == [True, True]
+    assert bio.moves_compatible(["AAC", "ACT"], [2]) == [False]
