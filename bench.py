@@ -45,6 +45,12 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams per GPU; with 2, consecutive batches overlap (batch i decodes while batch i+1 "
                          "runs its recurrent layers)")
+    ap.add_argument("--with-bases", action="store_true",
+                    help="also turn the decoded paths into base sequences on the device (slk_paths_to_bases) and copy those "
+                         "to the host, inside the timed step")
+    ap.add_argument("--exact-steps", type=int, default=5,
+                    help="steps of the all-fp32 arithmetic (SLOIKA_AMD_EXACT_F32=1) timed after the main region for the "
+                         "`exact_f32` entry of the line (0 = skip)")
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (BASELINE.json configs[4]: forward + backward + ADAMski, "
                          "gradient all-reduce over RCCL when --gpus > 1); prints the same kind of JSON line")
@@ -92,6 +98,33 @@ def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
     finally:
         orc.set_num_threads(cores)
     return out
+
+
+def cpu_baseline_train(model_name, chunk_len, nchunk=2):
+    """The training oracle (oracle/oracle_train.py: numpy float64 forward + hand-derived reverse pass + ADAMski) on a bounded
+    sample of the same workload, on the host: the CPU restatement of one fg(x, labels, weights, rate) call."""
+    from oracle import oracle_train as ot
+    from sloika_amd import models
+    net = models.randomise_zero_layers(models.build_model(model_name, klen=5, sd=0.5, seed=11))
+    spec = net.spec()
+    rs = np.random.RandomState(99)
+    To = net.layers[0].out_len(chunk_len) if hasattr(net.layers[0], "out_len") else chunk_len
+    x = rs.normal(size=(chunk_len, nchunk, net.insize)).astype(np.float32)
+    labels = rs.randint(0, net.size, size=(To, nchunk)).astype(np.int32)
+    weights = np.ones((To, nchunk), dtype=np.float32)
+    t0 = time.perf_counter()
+    loss, acc, grads = ot.loss_and_grads(spec, x, labels, weights, 1e-30, 0.0, 20)
+    params = ot.params_of(spec)
+    ot.Adamski(params).step(params, grads, 1e-3)
+    dt = time.perf_counter() - t0
+    try:
+        import threadpoolctl
+        cores = max(int(i.get("num_threads", 1)) for i in threadpoolctl.threadpool_info()) if threadpoolctl.threadpool_info() else 1
+    except Exception:
+        cores = 1
+    return {"value": nchunk * chunk_len / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d chunks x %d samples, one forward + backward + ADAMski step of the numpy float64 training oracle "
+                      "(BLAS threads: %d), %.1f s" % (nchunk, chunk_len, cores, dt)}
 
 
 def main_train(args):
@@ -149,12 +182,16 @@ def main_train(args):
         print(json.dumps({
             "metric": "raw-signal samples/sec trained", "value": world * B * L * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (forward products and the weight-gradient-free GEMMs as 3-term fp16 splits, f32 accumulation)",
+            "data": "synthetic",
             "config": {"workload": "%s training step (forward, backward, ADAMski), %d-sample chunks, batch %d per GPU, "
                                    "klen 5 (1025 states), drop 20" % (args.model, L, B),
                        "model": args.model, "chunk_len": L, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "data parallel over %d GPU(s), one all-reduce of the flat gradient per step" % world},
-            "roofline": roofline, "cpu_baseline": None, "final_loss": loss,
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline_train(args.model, L) if (world == 1 and args.cpu_chunks > 0) else None,
+            "final_loss": loss,
             "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())}}))
     if dist is not None:
         dist.destroy_process_group()
@@ -209,12 +246,26 @@ def main():
     dev = [torch.from_numpy(h).cuda() for h in host]
     tout = bc.network.layers[0].out_len(L) if hasattr(bc.network.layers[0], "out_len") else L
     out_host = [torch.empty((B, tout), dtype=torch.int32).pin_memory() for _ in range(nstream)]
+    klen = 5
+    if args.with_bases:
+        bases_dev = [torch.empty((B, klen * tout), dtype=torch.uint8, device="cuda") for _ in range(nstream)]
+        nbases_dev = [torch.empty((B,), dtype=torch.int32, device="cuda") for _ in range(nstream)]
+        bases_host = [torch.empty((B, klen * tout), dtype=torch.uint8).pin_memory() for _ in range(nstream)]
+        nbases_host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(nstream)]
+        acgt = int.from_bytes(b"ACGT".ljust(8, b"\0"), "little")
 
     def step(i):
         k = i % nstream
         with torch.cuda.stream(streams[k]):
             scores, paths, lens = bcs[k].call_chunks(dev[i % nbuf])
             out_host[k][:, : paths.shape[1]].copy_(paths, non_blocking=True)     # paths end up on the host
+            if args.with_bases:                                                 # ... and so do the base sequences
+                with profiler.region("bases", 0.0, 5.0 * paths.numel()):
+                    _lib.check(_lib.lib().slk_paths_to_bases(paths.data_ptr(), paths.stride(0), lens.data_ptr(), B, klen, 4, 1,
+                                                             acgt, bases_dev[k].data_ptr(), klen * tout, nbases_dev[k].data_ptr(),
+                                                             streams[k].cuda_stream), "paths_to_bases")
+                bases_host[k].copy_(bases_dev[k], non_blocking=True)
+                nbases_host[k].copy_(nbases_dev[k], non_blocking=True)
         return scores, lens
 
     def barrier():
@@ -239,6 +290,30 @@ def main():
         dt = float(tmax.item())
     samples = world * B * L * args.steps
     value = samples / dt
+
+    # the same workload with every product in plain float32 MFMA (no fp16 splits anywhere): a few steps, same run
+    exact = None
+    if args.exact_steps > 0 and nstream == 1:
+        from sloika_amd import layers as _layers
+        keep = (_layers.SPLIT_F16, _layers.Softmax.split_f16)
+        _layers.SPLIT_F16, _layers.Softmax.split_f16 = False, False
+        try:
+            step(0)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(args.exact_steps):
+                step(i)
+            barrier()
+            dte = time.perf_counter() - t1
+            if dist is not None:
+                tm = torch.tensor([dte], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dte = float(tm.item())
+            exact = {"ms_per_step": dte / args.exact_steps * 1e3, "value": world * B * L * args.exact_steps / dte,
+                     "unit": "samples/s", "steps": args.exact_steps,
+                     "arithmetic": "float32 MFMA for every product (SLOIKA_AMD_EXACT_F32=1): two-kernel Gru, fp32 softmax projection"}
+        finally:
+            _layers.SPLIT_F16, _layers.Softmax.split_f16 = keep
 
     stages = rec.summary() if rec is not None else {}
     roofline = None
@@ -268,7 +343,11 @@ def main():
                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic_by_stage.get(dom),
                         "ms_per_launch": d["ms_avg"], "launches": d["calls"],
                         "mix": {"fp32_mfma_flops": flops - f16, "f16x3_flops": f16,
-                                "fp32_peak": FP32_MFMA_PEAK_TFLOPS, "f16_peak": F16_MFMA_PEAK_TFLOPS}}
+                                "fp32_peak": FP32_MFMA_PEAK_TFLOPS, "f16_peak": F16_MFMA_PEAK_TFLOPS},
+                        # SURVEY 8(d)'s yardstick for the NN stage (all flops at the fp32 MFMA peak), for comparison only
+                        "frac_vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
+                        # B = 1024 over 256 CUs leaves 4 chunks per workgroup: 4 of the 16 columns of a 16x16x32 MFMA tile
+                        "note": "latency-bound serial scan; 4 chunks per CU fill 4 of 16 MFMA columns"}
         else:
             ach = d["bytes"] / d["calls"] / (d["ms_avg"] * 1e-3) / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -282,13 +361,18 @@ def main():
         line = {
             "metric": "raw-signal samples/sec basecalled", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (products as 3-term fp16 splits with f32 accumulation, 22-bit operands; elementwise and DP in f32)",
+            "data": "synthetic",
             "config": {"workload": "%s inference, %d-sample chunks, batch %d per GPU, klen 5 (1025 states), "
-                                   "normalise->conv->GRU->softmax->Viterbi->paths on host" % (args.model, L, B),
+                                   "normalise->conv->GRU->softmax->Viterbi->paths%s on host; matrix products as fp16x3 splits "
+                                   "(f32-grade, see exact_f32 for plain fp32 MFMA)"
+                                   % (args.model, L, B, " + base sequences" if args.with_bases else ""),
                        "model": args.model, "chunk_len": L, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "chunks sharded over %d GPU(s), no collective" % world, "streams_per_gpu": nstream},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "exact_f32": exact,
             "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())},
             "e2e_algorithmic_tflops": (gemm_flops / (dt / args.steps) / 1e12) if stages else None,
         }

@@ -1,39 +1,26 @@
-"""Padding arithmetic of sloika/conv.py:10-63 (host-side; the convolution itself is csrc/frontend.hip)."""
+"""Padding arithmetic of the Convolution layer (reference: sloika/conv.py:10-63; the convolution itself is
+csrc/frontend.hip).  A mode names how many zero steps go in front of and behind the time axis."""
 
-PADDING_MODES = frozenset(['same', 'half', 'valid', 'full', 'same_left'])
+#: mode -> (front, back) as functions of the window length w
+_PADDING = {
+    'same': lambda w: ((w - 1) // 2, w // 2),            # output length = ceil(T / stride) (tensorflow 'SAME')
+    'half': lambda w: (w // 2, w // 2),                  # Theano 'half'
+    'valid': lambda w: (0, 0),
+    'full': lambda w: (w - 1, w - 1),
+    'same_left': lambda w: (w // 2, (w - 1) // 2),
+}
+PADDING_MODES = frozenset(_PADDING)
 
 
 def calculate_padding(mode, winlen):
-    """Calculate padding amount for given convolution mode and window length (conv.py:10-63)
+    """(padding to start, padding to end) for a mode name, a single int (both ends) or an (int, int) pair.
 
-        'same'        [(winlen - 1) // 2, winlen // 2]      tensorflow 'SAME'
-        'half'        [winlen // 2, winlen // 2]            Theano 'half'
-        'valid'       [0, 0]
-        'full'        [winlen - 1, winlen - 1]
-        'same_left'   [winlen // 2, (winlen - 1) // 2]
-        int           [int, int]
-        (int1, int2)  [int1, int2]
-
-    :returns: (padding to start, padding to end)
-    """
+    The pair form is what conv.py:47-49 intends; there the py2-era test `map(type, mode) == [int, int]` never holds on
+    python 3, so the reference itself cannot reach it."""
     assert winlen > 0, "winlen must be positive"
     if isinstance(mode, int):
         return (mode, mode)
-    if isinstance(mode, (tuple, list)):
-        # conv.py:47-49 intends this; its py2-era `map(type, mode) == [int, int]` never matches on python 3
-        if len(mode) == 2 and all(isinstance(m, int) for m in mode):
-            return tuple(mode)
-
+    if isinstance(mode, (tuple, list)) and len(mode) == 2 and all(isinstance(m, int) for m in mode):
+        return tuple(mode)
     assert mode in PADDING_MODES, 'Padding mode "{}" not supported'.format(mode)
-    if mode == "same":
-        return ((winlen - 1) // 2, winlen // 2)
-    if mode == "half":
-        return (winlen // 2, winlen // 2)
-    if mode == "valid":
-        return (0, 0)
-    if mode == "full":
-        return (winlen - 1, winlen - 1)
-    if mode == "same_left":
-        return (winlen // 2, (winlen - 1) // 2)
-
-    raise NotImplementedError("Padding mode case {} not dealt with".format(mode))
+    return _PADDING[mode](winlen)

@@ -67,6 +67,13 @@ class Basecaller(object):
         return decode.viterbi_batch(post, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
                                     min_prob=self.min_prob, workspace=self._ws)
 
+    def call_bases(self, chunks, alphabet='ACGT'):
+        """call_chunks + states -> bases on the device (what basecall.SeqPrinter.write does per read, basecall.py:157-163,
+        with always_move as for a transducer model): -> (scores device [B], list of B base strings)."""
+        from . import bio
+        scores, paths, lens = self.call_chunks(chunks)
+        return scores, bio.paths_to_bases(paths, lens, self.kmer_len, alphabet, always_move=True)
+
     def call_reads(self, signals, trim=(0, 0), open_pore_fraction=0.0):
         """Whole reads of different lengths in ONE batch (the reference calls them one at a time, basecall.py:88-121):
         `signals` is a list of 1-D float arrays (already scaled, e.g. fast5.Fast5.get_read()); each is trimmed as raw_worker does, median/MAD
