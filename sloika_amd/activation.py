@@ -26,8 +26,8 @@ class Activation(object):
         return "<sloika_amd.activation.%s>" % self.__name__
 
     def __reduce__(self):
-        # pickles by qualified name, exactly like a module-level function (so model files stay
-        # loadable by either implementation)
+        # pickles by qualified name, exactly like a module-level function of the reference's activation.py (the
+        # reference's pickles name sloika.activation.<name> and load here; files written here load here)
         return (_lookup, (self.__name__,))
 
 

@@ -5,6 +5,10 @@
     compile_model(path)     sloika/helpers.py:54-79 boundary: model file -> callable posterior function
                             (no child process / temp file: that machinery exists only to keep Theano fork-safe)
 
+Direction of compatibility: the reference's pickles (models/pretrained.pkl, train_network.py checkpoints) load here;
+checkpoints written by sloika_amd.train.save_model name this package's classes and load here only -- the reference
+could not read them anyway without rebuilding Theano shared variables.
+
 Reference pickles hold Theano shared variables at their leaves.  Theano is not needed to read them: the
 unpickler maps `theano.*` classes to inert holders, then every holder whose state carries a numpy array in
 `.container.storage[0]` is replaced by a `layers.Shared`.
@@ -42,6 +46,19 @@ def _shared_value(obj):
     raise TypeError("object does not look like a Theano shared variable")
 
 
+#: Globals a model pickle may name besides theano.* (inert holders) and sloika.* / sloika_amd.* (this package's classes):
+#: what numpy needs to rebuild arrays, and the two containers layer objects hold.  Anything else -- os.system, builtins.eval
+#: ... -- is refused: a model file is data, loading one must not run code (the reference's plain pickle.load would).
+_ALLOWED_GLOBALS = {
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),      # protocol-5 array pickles
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("collections", "OrderedDict"), ("functools", "partial"),
+    ("copyreg", "_reconstructor"), ("copy_reg", "_reconstructor"), ("builtins", "object"), ("__builtin__", "object"),
+}
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module == "theano" or module.startswith("theano."):
@@ -52,7 +69,13 @@ class _Unpickler(pickle.Unpickler):
             return type(name, (_Holder,), {"__module__": module})
         if module == "sloika" or module.startswith("sloika."):
             compat.install()
-        return super().find_class(module, name)
+            return super().find_class(module, name)
+        if module == "sloika_amd" or module.startswith("sloika_amd."):
+            return super().find_class(module, name)
+        if (module, name) in _ALLOWED_GLOBALS:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("model file names the global %s.%s, which a sloika model does not need; refusing to "
+                                     "load it" % (module, name))
 
 
 def _convert_leaves(obj, seen=None):

@@ -83,6 +83,14 @@ def allreduce_mean_(tensor):
     return 1.0 / dist.get_world_size()
 
 
+def rank_and_world():
+    """(rank, world size) of the initialised process group, (0, 1) without one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def broadcast_from_rank0_(tensor):
     """Every rank takes rank 0's values (in place).  A no-op without an initialised process group."""
     import torch.distributed as dist
@@ -433,15 +441,27 @@ class TrainingStep(object):
         y = hbuf[1:T + 1]
         zr = torch.empty((T * B, 2 * n), dtype=torch.float32, device=x.device)
         M = T * B
-        with profiler.region("gru_fused", 6.0 * M * n * (n + layer.insize), 4.0 * M * (layer.insize + 3 * n),
-                             f16x3_flops=6.0 * M * n * layer.insize) as reg:
-            rc = _lib.lib().slk_gru_fused_train_f32(x.data_ptr(), layers._row_stride(x), layer.iW.dev().data_ptr(),
+        rc = _lib.SLK_ERR_UNSUPPORTED
+        if layers.RECURRENT_F16:            # projection and recurrence as fp16 splits (csrc/gru_fused16.hip)
+            with profiler.region("gru_fused", 6.0 * M * n * (n + layer.insize), 4.0 * M * (layer.insize + 3 * n),
+                                 f16x3_flops=6.0 * M * n * (n + layer.insize)) as reg:
+                rc = _lib.lib().slk_gru_fused16_f32(x.data_ptr(), layers._row_stride(x), layer.iW.dev().data_ptr(),
                                                     layer.sW.dev().data_ptr(), layer.sW2.dev().data_ptr(),
-                                                    layer.b.dev().data_ptr(), y.data_ptr(), n, zr.data_ptr(), T, B,
-                                                    layer.insize, n, int(rev), activation.act_id(layer.fun),
-                                                    activation.act_id(layer.gatefun), layers._stream())
-            if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
-                reg.cancel()
+                                                    layer.b.dev().data_ptr(), y.data_ptr(), n, T, B, layer.insize, n, int(rev),
+                                                    activation.act_id(layer.fun), activation.act_id(layer.gatefun), None,
+                                                    zr.data_ptr(), layers._stream())
+                if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
+                    reg.cancel()
+        if rc == _lib.SLK_ERR_UNSUPPORTED:
+            with profiler.region("gru_fused", 6.0 * M * n * (n + layer.insize), 4.0 * M * (layer.insize + 3 * n),
+                                 f16x3_flops=6.0 * M * n * layer.insize) as reg:
+                rc = _lib.lib().slk_gru_fused_train_f32(x.data_ptr(), layers._row_stride(x), layer.iW.dev().data_ptr(),
+                                                        layer.sW.dev().data_ptr(), layer.sW2.dev().data_ptr(),
+                                                        layer.b.dev().data_ptr(), y.data_ptr(), n, zr.data_ptr(), T, B,
+                                                        layer.insize, n, int(rev), activation.act_id(layer.fun),
+                                                        activation.act_id(layer.gatefun), layers._stream())
+                if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
+                    reg.cancel()
         if rc == _lib.SLK_ERR_UNSUPPORTED:
             return None
         _lib.check(rc, "gru_fused_train")
@@ -703,10 +723,14 @@ def prepare_training_data(data, transducer=True, bad=True, ilf=False):
 
 
 def training_batches(all_chunks, all_labels, all_weights, label_weights, niteration, batch_size=100,
-                     chunk_len_range=(0.5, 1.0), drop=20, rate=1e-3, lrdecay=5000.0):
+                     chunk_len_range=(0.5, 1.0), drop=20, rate=1e-3, lrdecay=5000.0, rank=0, world=1):
     """The sampler of train_network.py:213-230,288-306, drawing from numpy's global generator in the reference's order
     (seed it with np.random.seed like :180).  Yields (indata [chunk_len, batch, nfeature], labels [label_len, batch],
-    weights, learning_rate) per iteration."""
+    weights, learning_rate) per iteration.
+
+    Data parallel (`world` ranks seeded IDENTICALLY): every rank draws the same global batch -- same chunk length, same
+    window, same chunk ids -- and keeps ids rank, rank + world, ...; the global batch is cut to a multiple of `world`, so all
+    ranks hold the same number of positions (what TrainingStep's gradient average assumes) and no chunk is used twice."""
     data_chunk = all_chunks.shape[1]
     training_stride = int(np.ceil(float(all_chunks.shape[1]) / all_labels.shape[1]))            # :213
     min_chunk = 2 * drop + 1 if chunk_len_range[0] is None else int(np.around(chunk_len_range[0] * data_chunk))
@@ -727,6 +751,10 @@ def training_batches(all_chunks, all_labels, all_weights, label_weights, niterat
         label_ub = (start + chunk_len) // training_stride
         idx = np.sort(np.random.choice(len(all_chunks), size=min(this_batch, max_batch_size), replace=False,
                                        p=all_weights))                                          # :302-303
+        if world > 1:
+            if len(idx) < world:
+                raise ValueError("a batch of %d chunks cannot be shared by %d ranks" % (len(idx), world))
+            idx = idx[:len(idx) - len(idx) % world][rank::world]
         indata = np.ascontiguousarray(all_chunks[idx, start: start + chunk_len].transpose((1, 0, 2)))      # :304
         labels = np.ascontiguousarray(all_labels[idx, label_lb: label_ub].transpose())          # :305
         yield indata, labels, label_weights[labels], learning_rate                              # :306
@@ -739,27 +767,43 @@ def train_loop(network, data, output, niteration=50000, batch_size=100, chunk_le
     model_checkpoint_NNNNN.pkl every `save_every` iterations and model_final.pkl into `output`; returns the step."""
     import os
     import time
+    rank, world = rank_and_world()
+    if world > 1:
+        # every rank must draw the same batches: one seed for all (rank 0's when none was given)
+        import torch.distributed as dist
+        box = [seed if seed is not None else int(np.random.SeedSequence().entropy % (2 ** 32))]
+        dist.broadcast_object_list(box, src=0)
+        seed = box[0]
     np.random.seed(seed)                                                            # :180
-    if not os.path.exists(output):
+    if rank == 0 and not os.path.exists(output):
         os.mkdir(output)
-    log = Logger(os.path.join(output, 'model.log'), quiet)
+    if world > 1:
+        dist.barrier()
+    # one writer: rank 0 owns model.log and the checkpoints; the other ranks log nowhere
+    log = Logger(os.path.join(output, 'model.log'), quiet) if rank == 0 else Logger(os.devnull, True)
     all_labels, all_weights, label_weights = prepare_training_data(data, transducer, bad, ilf)
+    # checked here, identically on every rank, so that no rank can fail alone inside a step and leave the others waiting
+    # in the gradient all-reduce
+    if all_labels.min() < 0 or all_labels.max() >= network.size:
+        raise ValueError("labels must lie in [0, %d)" % network.size)
     fg = wrap_network(network, min_prob=min_prob, l2=l2, drop=drop, adam=adam[1:])
     total_ev = 0
     score_smoothed, acc_smoothed = ExponentialSmoother(smooth), ExponentialSmoother(smooth)
     log.write('* Dumping initial model\n')
-    save_model(network, output, 0, step=fg)                                         # :282
+    if rank == 0:
+        save_model(network, output, 0, step=fg)                                     # :282
     t0 = time.time()
     log.write('* Training\n')
     batches = training_batches(data["chunks"], all_labels, all_weights, label_weights, niteration, batch_size,
-                               chunk_len_range, drop, adam[0], lrdecay)
+                               chunk_len_range, drop, adam[0], lrdecay, rank=rank, world=world)
     for i, (indata, labels, weights, learning_rate) in enumerate(batches):
         fval, batch_acc = fg(indata, labels, weights, learning_rate)                # :308
         total_ev += np.size(labels)
         score_smoothed.update(float(fval))
         acc_smoothed.update(batch_acc)
         if (i + 1) % save_every == 0:                                               # :315-319
-            save_model(network, output, (i + 1) // save_every, step=fg)
+            if rank == 0:
+                save_model(network, output, (i + 1) // save_every, step=fg)
             log.write('C')
         else:
             log.write('.')
@@ -770,5 +814,8 @@ def train_loop(network, data, output, niteration=50000, batch_size=100, chunk_le
                 (i + 1) // 50, score_smoothed.value, 100.0 * acc_smoothed.value, dt, total_ev / 1000.0 / dt))
             total_ev = 0
             t0 = tn
-    save_model(network, output, step=fg)                                            # :330
+    if rank == 0:
+        save_model(network, output, step=fg)                                        # :330
+    if world > 1:
+        dist.barrier()
     return fg

@@ -159,3 +159,20 @@ def test_states_to_sequence_equals_string_route(golden_bio, golden_decode):
     assert bio.max_overlap(["AAA", "AAA"], allow_identical=False) == [1]
     assert bio.moves_compatible(["AAC", "ACT", "GGA"], [1, 3]) == [True, True]
     assert bio.moves_compatible(["AAC", "ACT"], [2]) == [False]
+
+
+def test_model_unpickler_refuses_code_execution(tmp_path):
+    """A model file is data: globals outside theano.* / sloika.* / numpy's array rebuilders are refused."""
+    import pickle
+    from sloika_amd import helpers
+
+    class Evil(object):
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+    p = tmp_path / "evil.pkl"
+    with open(p, "wb") as fh:
+        pickle.dump(Evil(), fh)
+    with pytest.raises(pickle.UnpicklingError):
+        helpers.load_pickle(str(p))
+    assert not (tmp_path / "pwned").exists()

@@ -168,3 +168,34 @@ def test_chunk_file_preparation_and_sampler(tmp_path):
             assert len(hits) == 1
             c, s = hits[0]
             assert np.array_equal(all_labels[c, s // 2:(s + clen) // 2], lab[:, k])
+
+
+def test_sampler_shares_a_batch_between_ranks():
+    """Data-parallel sampling (train.training_batches with rank/world): identically seeded ranks draw the SAME global
+    batch (window, length, chunk ids) and keep disjoint, equally sized shares of it."""
+    from sloika_amd import train
+    rs = np.random.RandomState(5)
+    chunks, labels, bad, weights = _toy_data(rs)
+    data = {"chunks": chunks, "labels": labels.copy(), "bad": bad, "weights": weights}
+    all_labels, all_weights, label_weights = train.prepare_training_data(data)
+
+    def batches(rank, world):
+        np.random.seed(11)
+        return list(train.training_batches(chunks, all_labels, all_weights, label_weights, 6, batch_size=9, drop=2,
+                                           rank=rank, world=world))
+    whole = batches(0, 1)
+    for world in (2, 3):
+        shares = [batches(r, world) for r in range(world)]
+        for it in range(6):
+            x_all, l_all, w_all, rate = whole[it]
+            n = x_all.shape[1] - x_all.shape[1] % world
+            parts = [shares[r][it] for r in range(world)]
+            assert all(p[0].shape[0] == x_all.shape[0] and p[0].shape[1] == n // world for p in parts)   # same T, same B
+            assert all(p[3] == rate for p in parts)
+            for r, p in enumerate(parts):                   # rank r holds chunks r, r + world, ... of the global batch
+                np.testing.assert_array_equal(p[0], x_all[:, :n][:, r::world])
+                np.testing.assert_array_equal(p[1], l_all[:, :n][:, r::world])
+    with pytest.raises(ValueError):
+        np.random.seed(1)
+        next(train.training_batches(chunks[:4], all_labels[:4], np.full(4, 0.25), label_weights, 1, batch_size=2, drop=2,
+                                    rank=0, world=5))
