@@ -15,6 +15,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+def _logits_reference(oracle, net, x):
+    """(hidden state after the last recurrent layer, logits) of the oracle: the float32 C port for the layer stack, the
+    final projection in float64."""
+    spec = net.spec()
+    body = {"type": "serial", "sublayers": spec["sublayers"][:-1]}
+    hid = oracle.run_network(body, x)
+    last = spec["sublayers"][-1]
+    logits = hid.astype(np.float64) @ last["W"].astype(np.float64).T + last["b"].astype(np.float64)
+    return hid, logits
+
+
 def _check_end_to_end(oracle, net, chunks, klen=5, skip=0.0, tol=TOL):
     torch = need_gpu()
     from sloika_amd import _lib, pipeline, decode
@@ -22,10 +33,21 @@ def _check_end_to_end(oracle, net, chunks, klen=5, skip=0.0, tol=TOL):
     cd = dev(chunks)
     post = bc.posteriors(cd)
     x = oracle.med_mad_normalise(chunks)
-    ref = oracle.run_network(net.spec(), np.ascontiguousarray(x.T)[:, :, None])
+    xin = np.ascontiguousarray(x.T)[:, :, None]
+    ref = oracle.run_network(net.spec(), xin)
     assert post.shape == ref.shape
-    err = np.abs(post.cpu().numpy() - ref).max()
+    got = post.cpu().numpy()
+    err = np.abs(got - ref).max()
     assert err < tol, "posterior max abs err %g" % err
+    # 1025-way posteriors average 1e-3: the absolute bound alone would let a 10 % error through.  Relative to each row's
+    # largest posterior, and on the quantities BEFORE the softmax squashes them: hidden state and logits.
+    assert (np.abs(got - ref) / ref.max(axis=2, keepdims=True)).max() < 2e-4
+    hid_ref, logits_ref = _logits_reference(oracle, net, xin)
+    hid = bc._hidden(cd, len(net.layers) - 1)
+    assert np.abs(hid.cpu().numpy() - hid_ref).max() < 2e-5
+    logits, stats, ld = net.layers[-1].logits_and_stats(hid)
+    lg = logits.view(hid.shape[0], hid.shape[1], ld)[:, :, :net.size].cpu().numpy()
+    assert np.abs(lg - logits_ref).max() <= 1e-4 * np.abs(logits_ref).max()
     scores, paths, lens = bc.call_chunks(cd)                       # logits path: posterior never materialised
     s2, p2, l2 = decode.viterbi_batch(post, klen, skip_pen=skip, min_prob=1e-5)   # posterior path
     assert torch.equal(paths, p2) and torch.equal(lens, l2) and torch.equal(scores, s2)
@@ -97,6 +119,35 @@ def test_raw_chunk_worker_and_seqprinter(oracle, golden_bio, golden_decode):
     g = golden_bio["seqprinter"]
     nb = sp.write(g["read_name"], g["score"], [int(v) for v in golden_decode[g["path_key"]]], g["nev"])
     assert sp.fh.getvalue() == g["text"] and nb == g["nbases"]
+
+
+@pytest.mark.parametrize("name,B", [("raw_0.98_rgrgr", 1024), ("baseline_raw_gru", 256)])
+def test_full_size_batch_sampled_chunks_vs_oracle(oracle, name, B):
+    """BASELINE.json configs[2] / configs[1] at FULL size (4000-sample chunks, batch 1024 / 256): eight chunks picked at
+    random out of the batch are compared with the oracle run on those chunks alone -- posteriors relative to each row's
+    maximum, and the decoded paths against the oracle's decoder on the device's own log-posteriors."""
+    torch = need_gpu()
+    from sloika_amd import _lib, models, pipeline
+    net = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=13))
+    bc = pipeline.Basecaller(net)
+    chunks = pipeline.synthetic_chunks(B, chunk_len=4000, seed=77)
+    cd = dev(chunks)
+    post = bc.posteriors(cd)
+    scores, paths, lens = bc.call_chunks(cd)
+    pick = np.sort(np.random.RandomState(B).choice(B, size=8, replace=False))
+    sub = post[:, torch.from_numpy(pick).cuda(), :].contiguous()
+    got = sub.cpu().numpy()
+    x = oracle.med_mad_normalise(chunks[pick])
+    ref = oracle.run_network(net.spec(), np.ascontiguousarray(x.T)[:, :, None])
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-5
+    assert (np.abs(got - ref) / ref.max(axis=2, keepdims=True)).max() < 3e-4
+    lp = torch.empty_like(sub)
+    _lib.check(_lib.lib().slk_log_post_f32(sub.data_ptr(), lp.data_ptr(), sub.numel(), _lib.POST_RAW, 1e-5, stream()))
+    o_scores, o_paths, o_lens = oracle.viterbi_batch(lp.cpu().numpy(), 5, skip_pen=0.0)
+    assert np.array_equal(lens.cpu().numpy()[pick], o_lens)
+    assert np.array_equal(paths.cpu().numpy()[pick], o_paths)
+    assert np.array_equal(scores.cpu().numpy()[pick], o_scores)
 
 
 def test_full_size_batch_properties():
