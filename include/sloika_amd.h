@@ -88,6 +88,9 @@ int slk_activation_f32(const float *x, float *y, size_t count, int act, slk_stre
 int slk_med_mad_normalise_f32(const float *signal, int nchunk, int chunk_len, float *out,
                               long out_chunk_stride, long out_sample_stride, float *med_out, float *mad_out,
                               slk_stream_t stream);
+/* Standard deviation of each of nwin consecutive windows of `win` samples (population form, numpy's .std()):
+ * batch.trim_open_pore(var_method='std'), sloika/batch.py:210-211.  out:[nwin].                                    */
+int slk_window_std_f32(const float *signal, int nwin, int win, float *out, slk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * a3. Convolution.run  (sloika/layers.py:417-419 -> sloika/conv.py:66-77,90-111)

@@ -26,6 +26,7 @@ PROTOTYPES = {
     "slk_error_string": (C.c_char_p, [_i]),
     "slk_device_count": (_i, []),
     "slk_med_mad_normalise_f32": (_i, [_vp, _i, _i, _vp, _l, _l, _vp, _vp, _vp]),
+    "slk_window_std_f32": (_i, [_vp, _i, _i, _vp, _vp]),
     "slk_conv1d_out_len": (_i, [_i, _i, _i, _i, _i]),
     "slk_conv1d_f32": (_i, [_vp, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_window_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

@@ -78,27 +78,28 @@ def trim_open_pore(signal, max_op_fraction=0.3, var_method='mad', window_size=10
 
     :param signal: raw data containing a read (1D float32, numpy or device tensor)
     :param max_op_fraction: maximum expected fraction of signal that consists of open pore
-    :param var_method: only 'mad' (the default of the reference) is implemented
+    :param var_method: 'mad' (median absolute deviation, the default) or 'std' (standard deviation) of each window
     :param window_size: size of patches used to estimate local variance
     """
     import torch
     from . import device as D
     assert var_method in TRIM_OPEN_PORE_LOCAL_VAR_METHODS, "var_method not understood: {}".format(var_method)
-    if var_method != 'mad':
-        raise NotImplementedError("trim_open_pore: only var_method='mad' (the reference default) is implemented")
-    ml = len(signal) // window_size
-    ub = ml * window_size
+    nwin = len(signal) // window_size
     sd = D.to_dev(signal)
     if sd.dim() != 1:
         raise ValueError("trim_open_pore expects a 1D signal")
-    windows = sd[:ub].reshape(ml, window_size)
-    _, _, local_var = normalise_chunks(windows, 'per-chunk', return_stats=True)
-    local_var = local_var.cpu().numpy() if isinstance(local_var, torch.Tensor) else np.asarray(local_var)
-    probably_read = (local_var > np.percentile(local_var, 100 * max_op_fraction))
-    ix = np.arange(local_var.shape[0])[probably_read]
-    start = ix.min() * window_size
-    end = (ix.max() + 1) * window_size
-    return signal[start:end]
+    windows = sd[:nwin * window_size].reshape(nwin, window_size)
+    if var_method == 'mad':
+        _, _, spread = normalise_chunks(windows, 'per-chunk', return_stats=True)
+    else:
+        spread = torch.empty((nwin,), dtype=torch.float32, device=sd.device)
+        _lib.check(_lib.lib().slk_window_std_f32(windows.contiguous().data_ptr(), nwin, window_size, spread.data_ptr(),
+                                                 D.stream_ptr()), "window_std")
+    spread = spread.cpu().numpy() if isinstance(spread, torch.Tensor) else np.asarray(spread)
+    # windows livelier than the max_op_fraction quantile are read; keep everything from the first to the last of them
+    lively = np.flatnonzero(spread > np.percentile(spread, 100 * max_op_fraction))
+    first_win, last_win = int(lively[0]), int(lively[-1])
+    return signal[first_win * window_size: (last_win + 1) * window_size]
 
 
 def chunks_to_network_input(chunks):

@@ -183,6 +183,35 @@ extern "C" int slk_med_mad_normalise_f32(const float *signal, int nchunk, int ch
     return slk_launch_status();
 }
 
+// Per-window standard deviation (population form, numpy's ndarray.std): the local-variance measure of
+// batch.trim_open_pore(var_method='std'), sloika/batch.py:210-211.  One wave per window, sums in double.
+__global__ void __launch_bounds__(256) window_std_kernel(const float *__restrict__ signal, int nwin, int win,
+                                                          float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= nwin) return;
+    const float *p = signal + (size_t)w * win;
+    double s = 0.0;
+    for (int i = lane; i < win; i += 64) s += (double)p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const double mean = s / win;
+    double q = 0.0;
+    for (int i = lane; i < win; i += 64) { const double d = (double)p[i] - mean; q += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) out[w] = (float)sqrt(q / win);
+}
+
+extern "C" int slk_window_std_f32(const float *signal, int nwin, int win, float *out, slk_stream_t stream)
+{
+    if (!signal || !out || nwin < 0 || win < 1) return SLK_ERR_INVALID_ARG;
+    if (nwin == 0) return SLK_OK;
+    hipLaunchKernelGGL(window_std_kernel, dim3((nwin + 3) / 4), dim3(256), 0, slk_stream(stream), signal, nwin, win, out);
+    return slk_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------------
 // conv1d.  threadIdx.x <-> output feature (so stores are fully coalesced), threadIdx.y <-> one of PPB (to, b)
 // positions handled per block iteration; the filter is staged transposed in LDS (Wt[c][k][o]) so lanes read

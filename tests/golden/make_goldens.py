@@ -223,6 +223,9 @@ def main():
         # locate the slice exactly (trim_open_pore returns a view)
         start = (trimmed.__array_interface__["data"][0] - signal.__array_interface__["data"][0]) // 4
         sig["trim_open_pore_%g" % frac] = np.asarray([start, start + len(trimmed)], dtype=np.int64)
+        trimmed = batch.trim_open_pore(signal, frac, var_method='std')
+        start = (trimmed.__array_interface__["data"][0] - signal.__array_interface__["data"][0]) // 4
+        sig["trim_open_pore_std_%g" % frac] = np.asarray([start, start + len(trimmed)], dtype=np.int64)
     med, mad = maths.med_mad(signal)
     sig["med_mad_read"] = np.asarray([med, mad], dtype=np.float32)
     # basecall.py:117-118 maths on the whole read

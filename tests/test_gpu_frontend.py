@@ -122,8 +122,22 @@ def test_trim_open_pore_matches_reference(golden_signal):
         out = batch.trim_open_pore(sig, frac)
         assert out.base is sig or out.base is sig.base or np.shares_memory(out, sig)
         assert len(out) == hi - lo and np.array_equal(out, sig[lo:hi])
-    with pytest.raises(NotImplementedError):
-        batch.trim_open_pore(sig, 0.3, var_method='std')
+        lo, hi = g["trim_open_pore_std_%g" % frac]                    # var_method='std' (batch.py:210-211)
+        out = batch.trim_open_pore(sig, frac, var_method='std')
+        assert len(out) == hi - lo and np.array_equal(out, sig[lo:hi])
+    with pytest.raises(AssertionError):
+        batch.trim_open_pore(sig, 0.3, var_method='variance')
+
+
+def test_window_std_kernel_vs_numpy():
+    torch = need_gpu()
+    from sloika_amd import _lib
+    rs = np.random.RandomState(3)
+    for nwin, win in ((1, 1), (7, 100), (513, 100), (40, 333)):
+        x = (rs.normal(size=(nwin, win)) * rs.uniform(0.1, 30, size=(nwin, 1)) + 90).astype(np.float32)
+        out = torch.empty(nwin, dtype=torch.float32, device="cuda")
+        assert _lib.lib().slk_window_std_f32(dev(x).data_ptr(), nwin, win, out.data_ptr(), stream()) == 0
+        np.testing.assert_allclose(out.cpu().numpy(), x.astype(np.float64).std(axis=1), rtol=2e-7)
 
 
 @pytest.mark.parametrize("n", [32769, 70001, 114400])
