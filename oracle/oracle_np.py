@@ -4,8 +4,10 @@ TEST INFRASTRUCTURE ONLY (see oracle/sloika_oracle.c header).  Written as a lite
 the Theano expressions in sloika/layers.py so that the C oracle and the HIP kernels can both be
 checked against "the formula as the reference wrote it", evaluated in float64.
 
-PARITY UNPINNED against Theano itself for Convolution / Gru / Lstm (the reference holds no numeric
-expectation for them and Theano is not installable here); FeedForward / Softmax / Window restate
+Pinned (tests/test_oracle_reference_layers.py, <= 1e-10) to what the reference's own sloika/layers.py, conv.py,
+activation.py and models/*.py compute when executed unmodified under the eager Theano stand-in of
+tests/golden/theano_standin (fixtures tests/golden/layers.npz): the formulas here ARE the reference's, not merely close.
+Theano's own float32 kernels were never run (not installable); FeedForward / Softmax / Window additionally restate
 the numpy known-answer tests of test/unit/test_layers.py:58-69, 118-125, 246-266.
 """
 import numpy as np

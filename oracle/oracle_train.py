@@ -15,11 +15,14 @@ What is restated, and from where:
   * the "ADAMski" update sloika/updates.py:36-89 (float32 arithmetic like the reference's shared variables), `sgd`
     updates.py:9-33 and `param_sqr` updates.py:92-103.
 
-PARITY UNPINNED against the reference itself: Theano is not installable here and the reference's tests hold no expected
-value for a training step, a gradient of Gru/Convolution, or updates.adam.  What pins this file
-instead: (1) its forward pass is oracle_np.run_network, already pinned; (2) tests/test_oracle_train.py checks every
-gradient against central finite differences of that forward pass in float64; (3) the update rule is a line-by-line
-restatement, checked against the closed form of its first steps.
+Pinned (tests/test_oracle_reference_layers.py::test_training_step_vs_reference_code) to the reference's own
+bin/train_network.py:wrap_network + sloika/updates.py:adam, imported unmodified and executed under the eager Theano
+stand-in of tests/golden/theano_standin, whose `theano.grad` is automatic differentiation of the reference's own graph:
+loss and accuracy to 1e-9, every gradient to 1e-9 of its largest entry, the parameters after two or three ADAMski steps to
+2e-6 (float32 optimiser arithmetic), on three small networks covering Convolution, Gru, birnn, FeedForward, Window, Lstm.
+Not pinned: Theano's own kernels (never run).  Independently of that: (1) the forward pass is oracle_np.run_network;
+(2) tests/test_oracle_train.py checks every gradient against central finite differences in float64; (3) the update rule is
+checked against the closed form of its first steps.
 """
 import numpy as np
 

@@ -17,10 +17,15 @@
  *     (tests/golden/make_goldens.py).
  *   - orc_feedforward/softmax/window: pinned by restating the reference's numpy known-answer tests
  *     (test/unit/test_layers.py:58-69, 118-125, 246-266).
- *   - orc_conv1d, orc_gru, orc_lstm: PARITY UNPINNED against Theano -- the reference's tests hold no
- *     numerical expectation for these layers (test_layers.py:291-471 run-only) and Theano 0.8.2 is
- *     not installable here.  They follow the formulas at the cited lines and are cross-checked
- *     against an independent float64 numpy restatement (oracle/oracle_np.py).
+ *   - orc_conv1d, orc_gru, orc_lstm (and the layer graph as a whole): pinned to the outputs of the
+ *     reference's OWN layer code -- sloika/layers.py, conv.py, activation.py, models/*.py and
+ *     models/pretrained.pkl imported unmodified and executed, in the build container, under an eager
+ *     stand-in for the ~40 Theano primitives they call (tests/golden/theano_standin, validated by the
+ *     reference's own test/unit/test_layers.py) -- fixtures tests/golden/layers.npz, checked in
+ *     tests/test_oracle_reference_layers.py (this C port <= 2e-5, the float64 numpy restatement
+ *     <= 1e-10).  That pins gate order, reshapes, padding, scan order and initial state.  NOT pinned:
+ *     Theano's own float32 kernels (BLAS summation order, its clipped C sigmoid, <= 3.1e-7), which
+ *     were never run: Theano 0.8.2 is not installable here.
  *
  * Build: see oracle/Makefile (gcc -O2 -fopenmp, no -ffast-math: IEEE semantics are part of the
  * contract for the integer/float DP code).

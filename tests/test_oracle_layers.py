@@ -1,7 +1,7 @@
 """Oracle layer maths: restates the reference's numpy known-answer tests (test/unit/test_layers.py) and
 cross-checks the C oracle (float32) against the independent float64 numpy restatement.
 
-Gru / Lstm / Convolution are PARITY UNPINNED against Theano (see oracle/sloika_oracle.c header).
+Gru / Lstm / Convolution are pinned to the reference's own layer code in tests/test_oracle_reference_layers.py.
 """
 import numpy as np
 import pytest

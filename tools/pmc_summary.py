@@ -20,7 +20,30 @@ def load(d):
     return out
 
 
+STAGES = {            # bench.py stage -> substrings of the kernels it launches (summed)
+    "gru_fused": ("gru_fused16_kernel", "gru_fused_kernel"),
+    "softmax_gemm": ("gemm_rows_f16x3_kernel", "gemm_rows_kernel"),
+    "viterbi": ("viterbi_forward", "viterbi_backtrace"),
+    "conv1d": ("conv1d_",),
+    "normalise": ("med_mad_",),
+}
+
+
+def stage_file(summary_path, workload):
+    """profiles/pmc_traffic.json (what bench.py quotes as roofline.traffic) from a per-kernel summary."""
+    d = json.load(open(summary_path))
+    out = {}
+    for stage, keys in STAGES.items():
+        tot = sum(v["hbm_bytes_per_launch"] for k, v in d["kernels"].items() if any(s in k for s in keys))
+        if tot:
+            out[stage] = tot
+    json.dump({"workload": workload, "source": summary_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+               "tools/collect_pmc.sh; FETCH doubled per the gfx950 correction)", "stage_bytes_per_launch": out}, sys.stdout, indent=1)
+
+
 def main():
+    if sys.argv[1] == "--stages":
+        return stage_file(sys.argv[2], ["raw_0.98_rgrgr", 1024, 4000])
     fetch, write = load(sys.argv[1]), load(sys.argv[2])
     res = {}
     for k in sorted(set(fetch) | set(write)):
