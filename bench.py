@@ -100,7 +100,7 @@ def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
     return out
 
 
-def cpu_baseline_train(model_name, chunk_len, nchunk=2):
+def cpu_baseline_train(model_name, chunk_len, nchunk=48):
     """The training oracle (oracle/oracle_train.py: numpy float64 forward + hand-derived reverse pass + ADAMski) on a bounded
     sample of the same workload, on the host: the CPU restatement of one fg(x, labels, weights, rate) call."""
     from oracle import oracle_train as ot

@@ -10,14 +10,33 @@
 
 __device__ __forceinline__ void slip_update_seq(const float *x, int n, float slip, float *from_score, int *from_pos)
 {
-    // viterbi_helpers.pyx:22-33
+    // viterbi_helpers.pyx:22-33.  The recurrence itself is sequential (its float32 roundings depend on the order), but its
+    // inputs are not: eight x values are fetched together ahead of the eight dependent compare / select / subtract steps
+    // that consume them, so the loop pays LDS latency once per eight positions instead of once per position.
     from_score[0] = from_score[1] = -1e38f;
     from_pos[0] = from_pos[1] = 0;
     float fs = x[0] - slip;
     int fp = 0;
     from_score[2] = fs;
     from_pos[2] = 0;
-    for (int j = 3; j < n; j++) {
+    int j = 3;
+    for (; j + 8 <= n; j += 8) {
+        float xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) xv[u] = x[j - 2 + u];
+        float fo[8];
+        int po[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (!(fs >= xv[u])) { fp = j - 2 + u; fs = xv[u]; }
+            fs = fs - slip;
+            fo[u] = fs;
+            po[u] = fp;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { from_score[j + u] = fo[u]; from_pos[j + u] = po[u]; }
+    }
+    for (; j < n; j++) {
         float xv = x[j - 2];
         if (!(fs >= xv)) { fp = j - 2; fs = xv; }
         fs = fs - slip;
