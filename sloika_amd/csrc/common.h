@@ -27,10 +27,12 @@ __device__ __forceinline__ float slk_rcp(float x) { return __builtin_amdgcn_rcpf
 __device__ __forceinline__ float slk_sigmoid(float x) { return slk_rcp(1.0f + __expf(-x)); }
 
 // tanh through one exp: tanh(x) = 1 - 2/(exp(2x)+1); abs error < 3e-7 over the whole range.
+// Five instructions (mul, exp, add, rcp, fma).  The values are those of  1 - 2 * rcp(__expf(2x) + 1)  bit for bit: doubling is
+// exact, so x * (2 log2 e) rounds like (2x) * log2 e and fma(-2, r, 1) like 1 - 2r.
 __device__ __forceinline__ float slk_tanh(float x)
 {
-    float e = __expf(2.0f * x);
-    return 1.0f - 2.0f * slk_rcp(e + 1.0f);
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390043258667f);       // 2 * 0x3fb8aa3b
+    return fmaf(-2.0f, slk_rcp(e + 1.0f), 1.0f);
 }
 
 template <int ACT>

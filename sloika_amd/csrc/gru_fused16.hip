@@ -27,64 +27,8 @@
 // Callers that need plain fp32 arithmetic use gru_fused.hip / the two-kernel path.
 #include <limits.h>
 
+#include "f16split.h"
 #include "lds_flags.h"
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void keep(half8 &v) { asm volatile("" : "+v"(v)); }
-
-__device__ __forceinline__ float sel4(const f32x4 &a, int q)
-{
-    const float lo = (q & 1) ? a[1] : a[0];
-    const float hi = (q & 1) ? a[3] : a[2];
-    return (q & 2) ? hi : lo;
-}
-
-// two float32 -> one dword of fp16 "hi" parts and one of fp16 "lo" parts (v = hi + lo)
-// (the inputs are made opaque first: hipcc otherwise folds the multiply or add that produced them into the conversion --
-// v_fma_mixlo_f16, ONE rounding -- for the value it subtracts, while the stored hi part is the conversion of the rounded
-// float32: the two disagree whenever the float32 value is an exact fp16 tie, 1 in 8192, and hi + lo is then off by an
-// fp16 ulp.  Found by tools/f16_error_probe4.py.)
-__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
-{
-    asm volatile("" : "+v"(a), "+v"(b));
-    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-    const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
-    half2_t h = {ha, hb}, l = {la, lb};
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
-}
-
-// Power-of-two scale that brings a row whose largest magnitude is `amax` into [1, 2): scale = 2^(127 - e), inv = 2^(e - 127),
-// e = biased exponent of amax kept inside [27, 227] so that both are normal numbers.  Multiplying by either is exact.
-__device__ __forceinline__ float pow2_scale(float amax, float &inv)
-{
-    const int e = min(max((int)((__float_as_uint(amax) >> 23) & 0xff), 27), 227);
-    inv = __uint_as_float((unsigned)e << 23);
-    return __uint_as_float((unsigned)(254 - e) << 23);
-}
-// maximum over the four k groups of an MFMA operand row (lanes m, m+16, m+32, m+48)
-__device__ __forceinline__ float kgroup_max(float v)
-{
-    v = fmaxf(v, __shfl_xor(v, 16));
-    return fmaxf(v, __shfl_xor(v, 32));
-}
-
-// acc += W . h as a 3-term split; small terms first so that they are not absorbed by the large one
-template <int ABL = 0>
-__device__ __forceinline__ f32x4 mfma3(const half8 &w_hi, const half8 &w_lo, const half8 &h_hi, const half8 &h_lo, f32x4 acc)
-{
-    if constexpr (ABL & 1) {
-        half8 a = w_hi, b = h_hi;
-        asm volatile("" : "+v"(a), "+v"(b), "+v"(acc));
-        return acc;
-    }
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi, h_lo, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo, h_hi, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi, h_hi, acc, 0, 0, 0);
-    return acc;
-}
 
 // Diagnostic instantiation: shader-clock cycles workgroup 0's chain wave 0 spends between the marks of one step, summed over
 // the scan (tools/bench_kernels.py --what gruf16 reads them).  The production instantiation carries none of this.

@@ -1,0 +1,685 @@
+// EXPERIMENT, not part of libsloika_amd.so (build + run: tools/bar16_check.py --build, then the same script on the GPU box).
+// Outcome on MI355X (T=800, B=1024, 96->96): 0.727 ms against 0.71-0.74 ms for the production kernel gru_fused16.hip in the same
+// process -- no gain; DESIGN.md 3.1 has the measurements that explain why (a wave alone on its SIMD is bound by its own
+// instruction issue and by LDS round trips taken by four waves at once right after each barrier).
+//
+// gru_bar16.hip -- a whole Gru layer (sloika/layers.py:1010-1021) in one persistent kernel of FOUR waves per workgroup,
+// one per SIMD, in lock step: the same arithmetic as gru_fused16.hip (3-term fp16 split products, float32 accumulation,
+// rows scaled by powers of two) on a different execution plan.
+//
+// gru_fused16.hip runs eight waves coupled by progress counters in LDS; a step of its chain costs two counter round trips
+// (poll, ballot, retry), shares its SIMDs with the projection waves, and lives in 256 registers.  Measured there: of
+// ~2200 cycles per step only ~860 are the chain's MFMAs.  Here:
+//   * one wave per SIMD (256 threads, 512 registers each): nobody competes with the chain for issue slots;
+//   * the two exchanges of a step (r*h, then h) are two s_barrier -- LDS data written before the barrier is simply there
+//     after it, no counters, no retries;
+//   * the time-parallel projection vI = x.iW^T + b (four steps at a time) is cut into pieces that the waves execute at
+//     fixed places of the step: a chain wave issues its share (CT tiles, one K block per step) right after a barrier,
+//     while its LDS reads of the state are in flight; the service waves (the SIMDs without a chain wave) take the rest,
+//     split x into fp16 halves ONCE per group for everybody (operand images in LDS), and run the x DMA one request at a
+//     time so that they always reach the next barrier before the chain does;
+//   * every chain lane owns (neuron, chunk) pairs and stores its new state straight to h_out (a lane quartet writes 16
+//     consecutive bytes, a wave a whole 128-byte line per chunk and step): no staging ring, no copy-out pass.
+// Layout of the 16x16x32 tiles (weights = A, state of the 4 chunks in all four column groups = B, lane (c, q, g) keeps
+// neuron 4g+q of its tile) and the packed operand images are those of gru_fused16.hip.
+#include <limits.h>
+
+#include <type_traits>
+
+#include "../../sloika_amd/csrc/f16split.h"
+
+template <bool REAL = true>
+__device__ __forceinline__ void lds_bar()
+{
+    if constexpr (REAL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// barrier for a wave whose two youngest LDS operations are reads of its OWN data: LDS executes a wave's operations in
+// order, so everything older -- the writes the other waves are waiting for -- has been performed once at most two remain
+template <bool REAL = true>
+__device__ __forceinline__ void lds_bar_2reads()
+{
+    if constexpr (REAL) asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+}
+__device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }
+// tanh through one exp, 1 - 2/(exp(2x)+1), written so that it is five instructions (the same values as slk_tanh: 2x and
+// 2r are exact)
+__device__ __forceinline__ float tanh5(float x)
+{
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+}
+__device__ __forceinline__ float sigmoid4(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
+template <int V>
+using ic = std::integral_constant<int, V>;
+template <int B_, int E_, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B_ < E_) {
+        f(ic<B_>{});
+        static_for<B_ + 1, E_>(f);
+    }
+}
+
+// acc0 += W0.h, acc1 += W1.h as 3-term splits with the two accumulation chains interleaved: consecutive MFMAs never depend on
+// each other (per accumulator the order of the terms is that of mfma3)
+__device__ __forceinline__ void mfma3x2(const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi, const half8 &w1_lo,
+                                        const half8 &h_hi, const half8 &h_lo, f32x4 &acc0, f32x4 &acc1)
+{
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0_hi, h_lo, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1_hi, h_lo, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0_lo, h_hi, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1_lo, h_hi, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0_hi, h_hi, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1_hi, h_hi, acc1, 0, 0, 0);
+}
+// the same for NT tiles of the projection and K block kb of their weights
+template <int NT, int KBLK_>
+__device__ __forceinline__ void mfma3xn(const half8 (*w_hi)[KBLK_], const half8 (*w_lo)[KBLK_], int kb, const half8 &x_hi,
+                                        const half8 &x_lo, f32x4 *acc)
+{
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[t][kb], x_lo, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo[t][kb], x_hi, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[t][kb], x_hi, acc[t], 0, 0, 0);
+}
+
+// Diagnostic instantiation: shader-clock cycles the waves of workgroup 0 spend in each section of a step, summed over the scan
+// (tools/bar16_check.py reads them).  The production instantiation carries none of this.
+__device__ unsigned long long slk_dbg_bar16[4][16];
+extern "C" int slk_debug_read_bar16(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_bar16), sizeof(unsigned long long) * 64) == hipSuccess ? SLK_OK
+                                                                                                                : SLK_ERR_LAUNCH;
+}
+#define BSTAMP(i)                                                                     \
+    if constexpr (DIAG) {                                                             \
+        unsigned long long tnow;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");   \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        sacc[i] += tnow - tprev;                                                      \
+        tprev = tnow;                                                                 \
+    }
+
+// ABL (timing experiments of tools/bar16_check.py only; results are garbage): 1 = no s_barrier, 2 = chain waves issue no MFMAs,
+// 4 = cheap activations, 8 = service waves only keep the barriers, 16 = no stores to h_out
+template <int I, int N, bool SAVE, bool DIAG = false, int ABL = 0>
+__global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restrict__ x, long ldx, const float *__restrict__ iW,
+                                                           const float *__restrict__ bias, const float *__restrict__ sW,
+                                                           const float *__restrict__ sW2, float *__restrict__ h_out, long ldh,
+                                                           int T, int B, int reverse, const int *__restrict__ lens,
+                                                           float *__restrict__ zr_out)
+{
+    static_assert(I % 16 == 0 && N % 32 == 0 && N <= 96, "unsupported size for the barrier-stepped GRU kernel");
+    constexpr int NCW = N / 32;                          // chain waves = 32-wide K blocks of the recurrent products
+    constexpr int KBS = N / 32;
+    constexpr int NSW = 4 - NCW;                         // service waves
+    constexpr int NT = N / 16;                           // tiles per gate
+    constexpr int NT16 = 3 * NT;                         // tiles of vI rows (z | r | c)
+    constexpr int KBLK = (I + 31) / 32;
+    constexpr int GS = 4;                                // steps per projection group (16 MFMA columns = 4 steps x 4 chunks)
+    constexpr int KB = 8;                                // steps per x block
+    constexpr int R = 2 * GS;                            // vI ring: group G+1 is written while group G is consumed
+    constexpr int CT = NCW == 3 ? 3 : (NCW == 2 ? 2 : 0);               // projection tiles of a chain wave
+    constexpr int ST = (NT16 - NCW * CT) / NSW;                         // ... of a service wave
+    static_assert(NCW * CT + NSW * ST == NT16, "tile assignment");
+    static_assert(KBLK <= 4 && ST <= 16, "interval plan");
+    constexpr int XIMG = 4 * I;                          // floats of one step's x image: [k/4][chunk][k%4]
+    constexpr int XPIECES = KB * I;                      // 16-byte pieces per x block
+    constexpr int XSLOTS = 4;
+    constexpr int NREQ = XPIECES / 64;                   // 1 KiB DMA requests per block, one per interval
+    static_assert(XPIECES % 64 == 0 && NREQ <= 16, "x block requests");
+    constexpr int OPIMG = GS * KBLK * 64;                // dwords of one operand image: [step][k block][k group][chunk][8 halves]
+    constexpr int VSTEP = NT16 * 64;                     // floats of one step's vI: [tile][g][chunk][r], row = 16 tile + 4g + r
+
+    __shared__ __attribute__((aligned(16))) float xraw[XSLOTS * KB * XIMG];
+    __shared__ __attribute__((aligned(16))) unsigned xop_hi[2 * OPIMG], xop_lo[2 * OPIMG];
+    __shared__ __attribute__((aligned(16))) float xinv_lds[2 * 16];
+    __shared__ __attribute__((aligned(16))) float vbuf[R * VSTEP];
+    __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * N], h_lo[2 * N], rh_hi[2 * N], rh_lo[2 * N];
+    __shared__ __attribute__((aligned(16))) float bias_lds[3 * N], invw_lds[3 * N];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b0 = blockIdx.x * 4;
+
+    for (int i = tid; i < 2 * N; i += 256) { h_hi[i] = 0u; h_lo[i] = 0u; }             // h(-1) = 0
+    for (int i = tid; i < 3 * N; i += 256) bias_lds[i] = bias ? bias[i] : 0.0f;
+
+    // ---------------- projection pieces shared by both kinds of wave ----------------
+    const int pcol = lane & 15, kg = lane >> 4;          // operand row / column and k group of this lane
+    const int pstep = pcol >> 2, pc = pcol & 3;          // as a B column: (step in group, chunk)
+    const int poff = pstep * (KBLK * 64) + kg * 16 + pc * 4;            // + 64 kb: my 16 bytes of an operand image, in dwords
+    auto ldH = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
+    // iW tile -> A operands (lane: row pcol of the tile, k = 32 kb + 8 kg + 0..7), row scale remembered in invw_lds
+    auto load_tile = [&](int tile, half8 *hi, half8 *lo) {
+        const int row = 16 * tile + pcol;
+        float u[KBLK][8];
+        float m = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < KBLK; kb++) {
+            const int k0 = 32 * kb + 8 * kg;
+            const bool kok = (I % 32 == 0) || k0 < I;
+            const float *src = iW + (size_t)row * I + (kok ? k0 : 0);
+            const float4 u0 = *reinterpret_cast<const float4 *>(src), u1 = *reinterpret_cast<const float4 *>(src + 4);
+            const float t[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                u[kb][j] = kok ? t[j] : 0.0f;
+                m = fmaxf(m, fabsf(u[kb][j]));
+            }
+        }
+        float inv;
+        const float ws = pow2_scale(kgroup_max(m), inv);
+        if (kg == 0) invw_lds[row] = inv;
+#pragma unroll
+        for (int kb = 0; kb < KBLK; kb++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float v = u[kb][j] * ws;
+                const _Float16 h = (_Float16)v;
+                hi[kb][j] = h;
+                lo[kb][j] = (_Float16)(v - (float)h);
+            }
+        }
+    };
+    // accumulator of a tile for group G1 -> vI ring: lane holds rows 4 kg + r of column (pstep, pc)
+    auto proj_out = [&](int tile, const f32x4 &acc, int G1) {
+        const float xin = xinv_lds[(G1 & 1) * 16 + pcol];
+        const f32x4 iw = *reinterpret_cast<const f32x4 *>(&invw_lds[16 * tile + 4 * kg]);
+        const f32x4 bs = *reinterpret_cast<const f32x4 *>(&bias_lds[16 * tile + 4 * kg]);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = fmaf(acc[r] * xin, iw[r], bs[r]);
+        const int st = GS * G1 + pstep;
+        *reinterpret_cast<f32x4 *>(&vbuf[(st % R) * VSTEP + ((tile * 4 + kg) * 4 + pc) * 4]) = o;
+    };
+    const int NG = (T + GS - 1) / GS;
+    const int NBLK = (T + KB - 1) / KB;
+
+    if (wave < NCW) {
+        // =================================================================================================
+        // chain waves
+        // =================================================================================================
+        const int w = wave;
+        const int c = lane & 3, q = (lane >> 2) & 3, g = lane >> 4;
+        // recurrent weights: A operands, K blocks in the rotated order w, w+1, ... (element (g, j) of block kb is neuron
+        // 32 kb + 16 (j&1) + 4 g + (j>>1), the order the owners' packed writes create), rows scaled to [1, 2)
+        half8 wz_hi[2][KBS], wz_lo[2][KBS], wr_hi[2][KBS], wr_lo[2][KBS], wc_hi[2][KBS], wc_lo[2][KBS];
+        float inv_z[2], inv_r[2], inv_c[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const int row = 32 * w + 16 * p + (lane & 15);
+            float vz[KBS][8], vr[KBS][8], vc[KBS][8];
+            float mz = 0.0f, mr = 0.0f, mc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < KBS; i++) {
+                const int kb = (w + i) % KBS;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int k = 32 * kb + 16 * (j & 1) + 4 * g + (j >> 1);
+                    vz[i][j] = sW[(size_t)row * N + k];
+                    vr[i][j] = sW[(size_t)(N + row) * N + k];
+                    vc[i][j] = sW2[(size_t)row * N + k];
+                    mz = fmaxf(mz, fabsf(vz[i][j])); mr = fmaxf(mr, fabsf(vr[i][j])); mc = fmaxf(mc, fabsf(vc[i][j]));
+                }
+            }
+            float iz, ir, ic_;
+            const float sz = pow2_scale(kgroup_max(mz), iz), sr = pow2_scale(kgroup_max(mr), ir), sc = pow2_scale(kgroup_max(mc), ic_);
+            inv_z[p] = __shfl(iz, 4 * g + q); inv_r[p] = __shfl(ir, 4 * g + q); inv_c[p] = __shfl(ic_, 4 * g + q);
+#pragma unroll
+            for (int i = 0; i < KBS; i++) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float az = vz[i][j] * sz, ar = vr[i][j] * sr, ac = vc[i][j] * sc;
+                    const _Float16 hz = (_Float16)az, hr = (_Float16)ar, hc = (_Float16)ac;
+                    wz_hi[p][i][j] = hz; wz_lo[p][i][j] = (_Float16)(az - (float)hz);
+                    wr_hi[p][i][j] = hr; wr_lo[p][i][j] = (_Float16)(ar - (float)hr);
+                    wc_hi[p][i][j] = hc; wc_lo[p][i][j] = (_Float16)(ac - (float)hc);
+                }
+            }
+        }
+        constexpr int CTA = CT > 0 ? CT : 1;
+        half8 pw_hi[CTA][KBLK], pw_lo[CTA][KBLK];
+        f32x4 pacc[CTA];
+        if constexpr (CT > 0) {
+#pragma unroll
+            for (int t = 0; t < CT; t++) load_tile(w * CT + t, pw_hi[t], pw_lo[t]);
+        }
+        int boff[KBS];
+#pragma unroll
+        for (int i = 0; i < KBS; i++) boff[i] = ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
+        const int wd = ((w * 4 + g) * 4 + c) * 4 + q;                                           // my packed pair, in dwords
+        const int n0 = 32 * w + 4 * g + q;                                                      // my neuron of tile 2w (+16: 2w+1)
+        const int voff = (g * 4 + c) * 4 + q;                                                   // my element of a vI tile
+        // my chunk's rows of h_out (ragged batch: chunk bc is Tc <= T steps long; a reversed scan starts at ITS last step)
+        const int bc = b0 + c;
+        const bool live = bc < B;
+        const int Tc = (lens && live) ? min(max(lens[bc], 1), T) : T;
+        const long hstep = (reverse ? -1L : 1L) * (long)B * ldh;
+        float *hp = h_out + ((size_t)(reverse ? Tc - 1 : 0) * B + (live ? bc : 0)) * ldh + n0;
+        const long zstep = (reverse ? -1L : 1L) * (long)B * 2 * N;
+        float *zp = SAVE ? zr_out + ((size_t)(reverse ? Tc - 1 : 0) * B + (live ? bc : 0)) * (2 * N) + n0 : nullptr;
+
+        __syncthreads();                                 // LDS initialised, every wave's invw_lds rows written
+        lds_bar();                                       // x operand images of groups 0 and 1 (service leader)
+        if constexpr (CT > 0) {                          // vI of group 0
+#pragma unroll
+            for (int t = 0; t < CT; t++) pacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+                const half8 xh = ldH(xop_hi, poff + 64 * kb), xl = ldH(xop_lo, poff + 64 * kb);
+#pragma unroll
+                for (int t = 0; t < CT; t++) pacc[t] = mfma3(pw_hi[t][kb], pw_lo[t][kb], xh, xl, pacc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < CT; t++) proj_out(w * CT + t, pacc[t], 0);
+        }
+        lds_bar();                                       // vI of group 0 complete
+
+        unsigned long long sacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+        if constexpr (DIAG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
+        float hold[2] = {0.0f, 0.0f};
+        // carried from step to step: my own K block of h(s-1) as B operand (read back right after I wrote it) and vI(s)
+        half8 oh = {0, 0, 0, 0, 0, 0, 0, 0}, ol = {0, 0, 0, 0, 0, 0, 0, 0};
+        float vz[2], vr[2], vc[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            vr[p] = vbuf[voff + 64 * (NT + 2 * w + p)];
+            vz[p] = vbuf[voff + 64 * (2 * w + p)];
+            vc[p] = vbuf[voff + 64 * (2 * NT + 2 * w + p)];
+        }
+        // One step = two intervals, each opened by a barrier; MFMAs are issued in an order that keeps the matrix pipe busy
+        // through every LDS round trip and every stretch of gate arithmetic (an MFMA occupies the pipe for 16 cycles and
+        // the issuing wave for 4):
+        //   A  [others' h(s-1) visible]  request the other K blocks; r products with my own block (already in registers);
+        //      r products with the others; z products (all but the last block) with sigmoid(r), r*h, split, write, own
+        //      block read back in their shadow
+        //   B  [others' r*h visible]     request the other K blocks, vI(s+1) and the x operands of this step's share of the
+        //      projection; last z block and candidate products with my own block while they fly; candidate products with
+        //      the others, sigmoid(z) in their shadow; projection MFMAs (vI of the NEXT group of four steps, K block `ph`)
+        //      under tanh, blend, split, write, own block read back, store to h_out
+        auto mfma3x2 = [](const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi, const half8 &w1_lo, const half8 &h_hi_, const half8 &h_lo_,
+                          f32x4 &acc0, f32x4 &acc1) {
+            if constexpr (ABL & 2) {
+                half8 a = w0_hi, b = h_hi_;
+                asm volatile("" : "+v"(a), "+v"(b), "+v"(acc0), "+v"(acc1));
+            } else {
+                ::mfma3x2(w0_hi, w0_lo, w1_hi, w1_lo, h_hi_, h_lo_, acc0, acc1);
+            }
+        };
+        auto step = [&](auto PHC, const int s, const int G) {
+            constexpr int ph = decltype(PHC)::value;
+            constexpr bool PROJ = CT > 0 && ph < KBLK;
+            // ------------------------------ interval A ------------------------------
+            if constexpr (DIAG) lds_bar(); else lds_bar_2reads<!(ABL & 1)>();
+            BSTAMP(0)
+            half8 bh[KBS], bl[KBS];
+            bh[0] = oh;
+            bl[0] = ol;
+#pragma unroll
+            for (int i = 1; i < KBS; i++) { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
+            if constexpr (CT > 0 && ph == 3) {           // last step of the group: vI of group G+1 (MFMAs issued in steps 0..2)
+#pragma unroll
+                for (int t = 0; t < CT; t++) proj_out(w * CT + t, pacc[t], G + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (KBS > 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
+                __builtin_amdgcn_sched_barrier(0);
+                BSTAMP(1)
+#pragma unroll
+                for (int i = 1; i < KBS; i++)
+                    mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            BSTAMP(2)
+#pragma unroll
+            for (int i = 0; i < KBS - 1; i++)
+                mfma3x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i], accZ[0], accZ[1]);
+            float rr[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) rr[p] = (ABL & 4) ? fmaf(sel4(accR[p], q), inv_r[p], vr[p]) * 0.01f : sigmoid4(fmaf(sel4(accR[p], q), inv_r[p], vr[p]));
+            {
+                unsigned hi, lo;
+                split2(rr[0] * hold[0], rr[1] * hold[1], hi, lo);
+                lds_fence();
+                rh_hi[wd] = hi;
+                rh_lo[wd] = lo;
+            }
+            half8 ch[KBS], cl[KBS];
+            ch[0] = ldH(rh_hi, boff[0]);                 // my own block, straight back (LDS executes a wave's operations in order)
+            cl[0] = ldH(rh_lo, boff[0]);
+            lds_fence();
+            // one MFMA, then up to three VALU instructions, for as long as both last
+#pragma unroll
+            for (int i = 0; i < 6 * (KBS - 1); i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+            const bool store = live && s < Tc && !(ABL & 16);
+            if constexpr (SAVE) {
+                if (store) { zp[N] = rr[0]; zp[N + 16] = rr[1]; }
+            }
+            // ------------------------------ interval B ------------------------------
+            if constexpr (DIAG) { BSTAMP(3) lds_bar(); } else lds_bar_2reads<!(ABL & 1)>();
+            BSTAMP(4)
+#pragma unroll
+            for (int i = 1; i < KBS; i++) { ch[i] = ldH(rh_hi, boff[i]); cl[i] = ldH(rh_lo, boff[i]); }
+            const float *vnext = vbuf + ((s + 1) % R) * VSTEP + voff;
+            float vzn[2], vrn[2], vcn[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                vrn[p] = vnext[64 * (NT + 2 * w + p)];
+                vzn[p] = vnext[64 * (2 * w + p)];
+                vcn[p] = vnext[64 * (2 * NT + 2 * w + p)];
+            }
+            half8 xh, xl;
+            if constexpr (PROJ) {
+                const int ob = ((G + 1) & 1) * OPIMG + poff + 64 * ph;
+                xh = ldH(xop_hi, ob);
+                xl = ldH(xop_lo, ob);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma3x2(wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1], bl[KBS - 1], accZ[0],
+                    accZ[1]);
+            f32x4 accC[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            mfma3x2(wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0], accC[0], accC[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 1; i < KBS; i++) { keep(ch[i]); keep(cl[i]); }
+#pragma unroll
+            for (int p = 0; p < 2; p++) { keepf(vzn[p]); keepf(vrn[p]); keepf(vcn[p]); }
+            if constexpr (PROJ) { keep(xh); keep(xl); }
+            __builtin_amdgcn_sched_barrier(0);
+            BSTAMP(5)
+#pragma unroll
+            for (int i = 1; i < KBS; i++)
+                mfma3x2(wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i], accC[0], accC[1]);
+            float zz[2], omz[2], zh[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                zz[p] = (ABL & 4) ? fmaf(sel4(accZ[p], q), inv_z[p], vz[p]) * 0.01f : sigmoid4(fmaf(sel4(accZ[p], q), inv_z[p], vz[p]));
+                omz[p] = 1.0f - zz[p];
+                zh[p] = zz[p] * hold[p];
+                asm volatile("" : "+v"(zh[p]), "+v"(omz[p]));                 // pinned here: not sunk to the blend below
+            }
+#pragma unroll
+            for (int i = 0; i < 6 * (KBS - 1); i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            BSTAMP(6)
+            if constexpr (PROJ) {
+                if constexpr (ph == 0) {
+#pragma unroll
+                    for (int t = 0; t < CT; t++) pacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if constexpr (!(ABL & 2)) mfma3xn<CTA, KBLK>(pw_hi, pw_lo, ph, xh, xl, pacc);
+            }
+            float hn[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const float hbar = (ABL & 4) ? fmaf(sel4(accC[p], q), inv_c[p], vc[p]) * 0.01f : tanh5(fmaf(sel4(accC[p], q), inv_c[p], vc[p]));
+                hn[p] = fmaf(omz[p], hbar, zh[p]);                            // layers.py:1020
+            }
+            {
+                unsigned hi, lo;
+                split2(hn[0], hn[1], hi, lo);
+                lds_fence();
+                h_hi[wd] = hi;
+                h_lo[wd] = lo;
+            }
+            oh = ldH(h_hi, boff[0]);
+            ol = ldH(h_lo, boff[0]);
+            lds_fence();
+            if constexpr (PROJ) {
+#pragma unroll
+                for (int i = 0; i < 3 * CT; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+            }
+            if (store) {
+                hp[0] = hn[0];
+                hp[16] = hn[1];
+                if constexpr (SAVE) { zp[0] = zz[0]; zp[16] = zz[1]; }
+            }
+            hp += hstep;
+            if constexpr (SAVE) zp += zstep;
+#pragma unroll
+            for (int p = 0; p < 2; p++) { hold[p] = hn[p]; vz[p] = vzn[p]; vr[p] = vrn[p]; vc[p] = vcn[p]; }
+            BSTAMP(7)
+        };
+        for (int G = 0; G < NG; G++) {
+            const int s = GS * G;
+            step(ic<0>{}, s, G);
+            if (s + 1 < T) step(ic<1>{}, s + 1, G);
+            if (s + 2 < T) step(ic<2>{}, s + 2, G);
+            if (s + 3 < T) step(ic<3>{}, s + 3, G);
+        }
+        if constexpr (DIAG) {
+            if (blockIdx.x == 0 && lane == 0)
+                for (int i = 0; i < 16; i++) slk_dbg_bar16[wave][i] = sacc[i];
+        }
+    } else {
+        // =================================================================================================
+        // service waves: the rest of the projection; the leader (first of them) also runs the x DMA and splits x
+        // =================================================================================================
+        const int sw = wave - NCW;
+        const bool leader = sw == 0;
+        const int tile0 = NCW * CT + sw * ST;
+        half8 pw_hi[ST][KBLK], pw_lo[ST][KBLK];
+#pragma unroll
+        for (int t = 0; t < ST; t++) load_tile(tile0 + t, pw_hi[t], pw_lo[t]);
+
+        // x DMA: request j of a block moves pieces 64 j .. 64 j + 63; piece p = (step kk, 16-byte column qq, chunk cc)
+        // (p % I) & 3 = lane & 3: a lane always serves the same chunk
+        const int dcc = lane & 3;
+        const int dbc = min(b0 + dcc, B - 1);
+        const int dTc = lens ? min(max(lens[dbc], 1), T) : T;
+        auto dma_request = [&](int blk, int j) {
+            const int p = 64 * j + lane;
+            const int kk = p / I, qq = (p % I) >> 2;
+            // steps past the chunk's end re-read its last valid row (their results are never stored)
+            const int ss = min(blk * KB + kk, dTc - 1);
+            const int tt = reverse ? dTc - 1 - ss : ss;
+            const float *src = x + ((size_t)tt * B + dbc) * ldx + 4 * qq;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)&xraw[(blk % XSLOTS) * (KB * XIMG) + 256 * j],
+                                             16, 0, 0);
+        };
+        // split of group G2's x rows: lane = (row pcol = (step, chunk), k group kg); element x[chunk][k] of a step's image
+        // sits at 16 (k>>2) + 4 chunk + (k&3)
+        float xs = 1.0f;
+        auto split_img = [&](int G2) {
+            return xraw + ((G2 >> 1) % XSLOTS) * (KB * XIMG) + (GS * (G2 & 1) + pstep) * XIMG + 4 * pc;
+        };
+        auto split_scale = [&](int G2) {                 // pass 1: the row's power-of-two scale
+            const float *img = split_img(G2);
+            float amax = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+                const int k0 = 32 * kb + 8 * kg;
+                const bool kok = (I % 32 == 0) || k0 < I;
+                const float *src = img + 4 * (kok ? k0 : 0);
+                const f32x4 u0 = *reinterpret_cast<const f32x4 *>(src), u1 = *reinterpret_cast<const f32x4 *>(src + 16);
+#pragma unroll
+                for (int j = 0; j < 4; j++) amax = fmaxf(amax, kok ? fmaxf(fabsf(u0[j]), fabsf(u1[j])) : 0.0f);
+            }
+            float xinv;
+            xs = pow2_scale(kgroup_max(amax), xinv);
+            if (kg == 0) xinv_lds[(G2 & 1) * 16 + pcol] = xinv;
+        };
+        auto split_block = [&](int G2, int kb) {         // pass 2: K block kb -> operand images
+            const float *img = split_img(G2);
+            const int k0 = 32 * kb + 8 * kg;
+            const bool kok = (I % 32 == 0) || k0 < I;
+            const float *src = img + 4 * (kok ? k0 : 0);
+            const f32x4 u0 = *reinterpret_cast<const f32x4 *>(src), u1 = *reinterpret_cast<const f32x4 *>(src + 16);
+            half8 ahi, alo;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float v = kok ? (j < 4 ? u0[j & 3] : u1[j & 3]) * xs : 0.0f;
+                const _Float16 h = (_Float16)v;
+                ahi[j] = h;
+                alo[j] = (_Float16)(v - (float)h);
+            }
+            const int ob = (G2 & 1) * OPIMG + poff + 64 * kb;
+            *reinterpret_cast<half8 *>(xop_hi + ob) = ahi;
+            *reinterpret_cast<half8 *>(xop_lo + ob) = alo;
+        };
+
+        __syncthreads();
+        if (leader) {
+            const int nb0 = min(XSLOTS - 1, NBLK);
+            for (int blk = 0; blk < nb0; blk++)
+                for (int j = 0; j < NREQ; j++) dma_request(blk, j);
+            if (nb0 >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NREQ) : "memory");
+            else if (nb0 == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NREQ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int G2 = 0; G2 < 2; G2++) {
+                split_scale(G2);
+#pragma unroll
+                for (int kb = 0; kb < KBLK; kb++) split_block(G2, kb);
+            }
+        }
+        lds_bar();
+        half8 xh[KBLK], xl[KBLK];
+        auto load_operands = [&](int G1) {
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+                const int ob = (G1 & 1) * OPIMG + poff + 64 * kb;
+                xh[kb] = ldH(xop_hi, ob);
+                xl[kb] = ldH(xop_lo, ob);
+            }
+        };
+        auto project_tile = [&](auto TC, int G1) {
+            constexpr int t = decltype(TC)::value;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) acc = mfma3(pw_hi[t][kb], pw_lo[t][kb], xh[kb], xl[kb], acc);
+            proj_out(tile0 + t, acc, G1);
+        };
+        load_operands(0);
+        static_for<0, ST>([&](auto TC) { project_tile(TC, 0); });
+        lds_bar();                                       // vI of group 0 complete
+
+        // interval k = 0..7 of group G (two per step, each opened by the barrier the chain waves open theirs with)
+        unsigned long long sacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+        if constexpr (DIAG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
+        auto interval = [&](auto KC, const int G) {
+            constexpr int k = decltype(KC)::value;
+            lds_bar<!(ABL & 1)>();
+            BSTAMP(8 + k)
+            if constexpr (ABL & 8) return;
+            if (leader) {
+                const int blk = G >> 1;                  // block the chain is in; j counts its 16 intervals
+                const int j = (G & 1) * 8 + k;
+                if constexpr (k == 0) {
+                    if ((G & 1) == 0 && blk + 1 < NBLK) {
+                        // block blk+1 (split from here on) has landed once only block blk+2's requests are outstanding
+                        if (blk + 2 < NBLK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NREQ) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                }
+                if (j < NREQ && blk + XSLOTS - 1 < NBLK) dma_request(blk + XSLOTS - 1, j);
+            }
+            if constexpr (k == 0) load_operands(G + 1);
+            // (nothing in the last interval: the chain reads vI of the group's first step right after its barrier)
+            if constexpr (k < 7 && k < ST) project_tile(ic<k>{}, G + 1);
+            if constexpr (k < 7 && k + 7 < ST) project_tile(ic<k + 7>{}, G + 1);
+            if constexpr (k < 7 && k + 14 < ST) project_tile(ic<k + 14>{}, G + 1);
+            if (leader) {
+                if constexpr (k == 1) split_scale(G + 2);
+                if constexpr (k >= 2 && k < 2 + KBLK) split_block(G + 2, k - 2);
+            }
+            BSTAMP(k)
+        };
+        for (int G = 0; G < NG; G++) {
+            const int s = GS * G;
+            interval(ic<0>{}, G); interval(ic<1>{}, G);
+            if (s + 1 < T) { interval(ic<2>{}, G); interval(ic<3>{}, G); }
+            if (s + 2 < T) { interval(ic<4>{}, G); interval(ic<5>{}, G); }
+            if (s + 3 < T) { interval(ic<6>{}, G); interval(ic<7>{}, G); }
+        }
+        if constexpr (DIAG) {
+            if (blockIdx.x == 0 && lane == 0)
+                for (int i = 0; i < 16; i++) slk_dbg_bar16[wave][i] = sacc[i];
+        }
+    }
+}
+
+// One workgroup per CU: ask for enough dynamic LDS that two cannot share a CU.
+template <typename K>
+static size_t exclusive_cu_lds_bar(K kernel)
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) != hipSuccess) return 0;
+    const size_t half_cu = 80 * 1024 + 512;                         // 160 KB of LDS per CU
+    const size_t dyn = attr.sharedSizeBytes >= half_cu ? 0 : half_cu - attr.sharedSizeBytes;
+    if (dyn && hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)dyn) != hipSuccess)
+        return 0;
+    return dyn;
+}
+
+template <int I, int N>
+static int launch_bar16(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
+                        float *y, long ldy, int T, int B, int reverse, const int *lens, float *zr_out, hipStream_t s)
+{
+    if constexpr (I == 96 && N == 96) {
+        const int dv = reverse >> 1;                    // diagnostic launches (undocumented bits, tools/bar16_check.py)
+#define DIAG_LAUNCH(CODE, STAMPS, ABLV)                                                                                   \
+        if (dv == CODE) {                                                                                                 \
+            static const size_t dyn = exclusive_cu_lds_bar(gru_bar16_kernel<I, N, false, STAMPS, ABLV>);                  \
+            hipLaunchKernelGGL((gru_bar16_kernel<I, N, false, STAMPS, ABLV>), dim3((B + 3) / 4), dim3(256), dyn, s, x, ldx, \
+                               iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, lens, zr_out);                                \
+            return slk_launch_status();                                                                                    \
+        }
+        DIAG_LAUNCH(1, true, 0) DIAG_LAUNCH(2, false, 1) DIAG_LAUNCH(3, false, 2) DIAG_LAUNCH(4, false, 4) DIAG_LAUNCH(5, false, 8)
+        DIAG_LAUNCH(6, false, 16) DIAG_LAUNCH(7, false, 9) DIAG_LAUNCH(8, false, 3) DIAG_LAUNCH(9, false, 11) DIAG_LAUNCH(10, false, 31)
+#undef DIAG_LAUNCH
+    }
+    if (zr_out) {
+        static const size_t dyn = exclusive_cu_lds_bar(gru_bar16_kernel<I, N, true>);
+        hipLaunchKernelGGL((gru_bar16_kernel<I, N, true>), dim3((B + 3) / 4), dim3(256), dyn, s, x, ldx, iW, bias, sW, sW2, y,
+                           ldy, T, B, reverse & 1, lens, zr_out);
+    } else {
+        static const size_t dyn = exclusive_cu_lds_bar(gru_bar16_kernel<I, N, false>);
+        hipLaunchKernelGGL((gru_bar16_kernel<I, N, false>), dim3((B + 3) / 4), dim3(256), dyn, s, x, ldx, iW, bias, sW, sW2, y,
+                           ldy, T, B, reverse & 1, lens, zr_out);
+    }
+    return slk_launch_status();
+}
+
+// Same contract as slk_gru_fused16_f32 (include/sloika_amd.h); SLK_ERR_UNSUPPORTED when no instantiation covers the request.
+extern "C" int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
+                                 const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse, int act,
+                                 int gate_act, const int32_t *lens, float *zr_out, slk_stream_t stream)
+{
+    if (!x || !iW || !sW || !sW2 || !y || T < 1 || B < 1 || insize < 1 || n < 1 || ldx < insize || ldy < n)
+        return SLK_ERR_INVALID_ARG;
+    if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
+    if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;   // 16-byte DMA pieces
+    hipStream_t s = slk_stream(stream);
+#define BAR16(II, NN) \
+    if (insize == II && n == NN) return launch_bar16<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s);
+    BAR16(96, 96)
+#undef BAR16
+    return SLK_ERR_UNSUPPORTED;
+}
