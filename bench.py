@@ -254,18 +254,34 @@ def main():
         nbases_host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(nstream)]
         acgt = int.from_bytes(b"ACGT".ljust(8, b"\0"), "little")
 
+    # The results leave for the host on a copy stream of their own: the next step's kernels do not queue behind a PCIe
+    # transfer.  `paths` is a fresh tensor every step (record_stream keeps the allocator from reusing it before the copy
+    # has run); the persistent base buffers are protected by the copy's event.
+    copy_stream = torch.cuda.Stream()
+    copied = [None] * nstream
+
     def step(i):
         k = i % nstream
         with torch.cuda.stream(streams[k]):
             scores, paths, lens = bcs[k].call_chunks(dev[i % nbuf])
-            out_host[k][:, : paths.shape[1]].copy_(paths, non_blocking=True)     # paths end up on the host
-            if args.with_bases:                                                 # ... and so do the base sequences
+            paths.record_stream(copy_stream)
+            if args.with_bases:                                                 # base sequences, still on the device
+                if copied[k] is not None:
+                    streams[k].wait_event(copied[k])
                 with profiler.region("bases", 0.0, 5.0 * paths.numel()):
                     _lib.check(_lib.lib().slk_paths_to_bases(paths.data_ptr(), paths.stride(0), lens.data_ptr(), B, klen, 4, 1,
                                                              acgt, bases_dev[k].data_ptr(), klen * tout, nbases_dev[k].data_ptr(),
                                                              streams[k].cuda_stream), "paths_to_bases")
+            done = torch.cuda.Event()
+            done.record(streams[k])
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(done)
+            out_host[k][:, : paths.shape[1]].copy_(paths, non_blocking=True)     # paths end up on the host
+            if args.with_bases:                                                 # ... and so do the base sequences
                 bases_host[k].copy_(bases_dev[k], non_blocking=True)
                 nbases_host[k].copy_(nbases_dev[k], non_blocking=True)
+            copied[k] = torch.cuda.Event()
+            copied[k].record(copy_stream)
         return scores, lens
 
     def barrier():

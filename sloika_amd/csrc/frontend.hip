@@ -160,6 +160,124 @@ __global__ void __launch_bounds__(1024) med_mad_radix_kernel(const float *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Chunks of up to 4096 samples (the basecaller's 4000-sample chunks): no sort at all.  Each of 256 threads keeps 16 samples
+// in registers as order-preserving integer keys; the wanted order statistic is built from its most significant bit down,
+// two bits per round: count the keys below three candidate prefixes (register compares, a wave reduction, one exchange
+// through LDS) and keep the largest prefix that at most `rank` keys lie below.  16 rounds give the exact key of rank n/2-1;
+// its upper neighbour (rank n/2) is either the same key (duplicates) or the smallest larger key -- one more count and a
+// minimum.  The MAD repeats this on the keys of |x - med|.  ~10 us for 1024 chunks against 140 us for the LDS bitonic
+// sort (which moves 32 KB through LDS in each of its 78 stages).
+// ------------------------------------------------------------------------------------------------------
+template <int EPT>
+struct KeySet {
+    unsigned k[EPT];
+};
+
+// number of keys < each of the three candidates, summed over the workgroup (every thread gets the totals)
+template <int EPT>
+__device__ __forceinline__ void count_below3(const KeySet<EPT> &ks, unsigned c1, unsigned c2, unsigned c3, unsigned *xch, int round,
+                                             unsigned &n1, unsigned &n2, unsigned &n3)
+{
+    // wave totals straight from the compare masks (v_cmp writes a 64-bit lane mask, s_bcnt1 counts it): no cross-lane traffic
+    unsigned a = 0, b = 0;                       // a = n1 | n2 << 16 (each <= 4096), b = n3
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        a += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ks.k[i] < c1)) +
+             ((unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ks.k[i] < c2)) << 16);
+        b += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ks.k[i] < c3));
+    }
+    // four waves exchange through a slot pair that alternates between rounds: one barrier per round is enough
+    unsigned *slot = xch + (round & 1) * 8;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { slot[2 * wave] = a; slot[2 * wave + 1] = b; }
+    __syncthreads();
+    a = slot[0] + slot[2] + slot[4] + slot[6];
+    b = slot[1] + slot[3] + slot[5] + slot[7];
+    n1 = a & 0xffffu;
+    n2 = a >> 16;
+    n3 = b;
+}
+
+// keys of rank r and r+1 (0-based) of the workgroup's keys; r + 1 < number of real keys when `need_next`
+template <int EPT>
+__device__ void select_pair(const KeySet<EPT> &ks, unsigned r, bool need_next, unsigned *xch, unsigned &key_r, unsigned &key_next)
+{
+    unsigned prefix = 0;
+#pragma unroll 1
+    for (int round = 0; round < 16; round++) {
+        const int sh = 30 - 2 * round;
+        unsigned n1, n2, n3;
+        count_below3<EPT>(ks, prefix | (1u << sh), prefix | (2u << sh), prefix | (3u << sh), xch, round, n1, n2, n3);
+        const unsigned d = n3 <= r ? 3u : (n2 <= r ? 2u : (n1 <= r ? 1u : 0u));
+        prefix |= d << sh;
+    }
+    key_r = prefix;
+    key_next = prefix;
+    if (need_next) {
+        // how many keys are <= key_r, and the smallest key above it
+        unsigned le = 0, mn = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            le += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ks.k[i] <= prefix));
+            mn = min(mn, ks.k[i] > prefix ? ks.k[i] : 0xffffffffu);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor(mn, o));
+        unsigned *slot = xch + 16;
+        const int wave = threadIdx.x >> 6;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { slot[2 * wave] = le; slot[2 * wave + 1] = mn; }
+        __syncthreads();
+        le = slot[0] + slot[2] + slot[4] + slot[6];
+        mn = min(min(slot[1], slot[3]), min(slot[5], slot[7]));
+        if (le < r + 2) key_next = mn;            // rank r+1 lies beyond the run of keys equal to key_r
+    }
+    __syncthreads();                              // the exchange slots are reused by the next selection
+}
+
+template <int EPT>
+__global__ void __launch_bounds__(256) med_mad_select_kernel(const float *__restrict__ signal, int chunk_len,
+                                                             float *__restrict__ out, long out_chunk_stride,
+                                                             long out_sample_stride, float *__restrict__ med_out,
+                                                             float *__restrict__ mad_out)
+{
+    __shared__ unsigned xch[24];
+    const int c = blockIdx.x, tid = threadIdx.x, n = chunk_len;
+    const float *sig = signal + (size_t)c * chunk_len;
+    float x[EPT];
+    KeySet<EPT> ks;
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int idx = tid + 256 * i;
+        x[i] = idx < n ? sig[idx] : 0.0f;
+        ks.k[i] = idx < n ? f2key(x[i]) : 0xffffffffu;            // padding sorts after every sample
+    }
+    const bool even = (n & 1) == 0;
+    const unsigned r = even ? (unsigned)(n >> 1) - 1 : (unsigned)(n >> 1);
+    unsigned ka, kb;
+    select_pair<EPT>(ks, r, even, xch, ka, kb);
+    const float med = even ? (key2f(ka) + key2f(kb)) / 2.0f : key2f(ka);   // numpy: mean of the two middle samples in float32
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int idx = tid + 256 * i;
+        ks.k[i] = idx < n ? f2key(fabsf(x[i] - med)) : 0xffffffffu;
+    }
+    select_pair<EPT>(ks, r, even, xch, ka, kb);
+    const float dm = even ? (key2f(ka) + key2f(kb)) / 2.0f : key2f(ka);
+    const float mad = 1.4826f * dm;
+    float *o = out + (size_t)c * out_chunk_stride;
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int idx = tid + 256 * i;
+        if (idx < n) o[(size_t)idx * out_sample_stride] = (x[i] - med) / mad;
+    }
+    if (tid == 0) {
+        if (med_out) med_out[c] = med;
+        if (mad_out) mad_out[c] = mad;
+    }
+}
+
 extern "C" int slk_med_mad_normalise_f32(const float *signal, int nchunk, int chunk_len, float *out,
                                          long out_chunk_stride, long out_sample_stride, float *med_out,
                                          float *mad_out, slk_stream_t stream)
@@ -169,6 +287,15 @@ extern "C" int slk_med_mad_normalise_f32(const float *signal, int nchunk, int ch
     if (chunk_len > 32768) {      // whole reads: radix selection, any length
         hipLaunchKernelGGL(med_mad_radix_kernel, dim3(nchunk), dim3(1024), 0, slk_stream(stream), signal, chunk_len, out,
                            out_chunk_stride, out_sample_stride, med_out, mad_out);
+        return slk_launch_status();
+    }
+    if (chunk_len >= 1024 && chunk_len <= 4096) { // the basecaller's chunks: selection on keys held in registers
+        if (chunk_len <= 2048)
+            hipLaunchKernelGGL(med_mad_select_kernel<8>, dim3(nchunk), dim3(256), 0, slk_stream(stream), signal, chunk_len, out,
+                               out_chunk_stride, out_sample_stride, med_out, mad_out);
+        else
+            hipLaunchKernelGGL(med_mad_select_kernel<16>, dim3(nchunk), dim3(256), 0, slk_stream(stream), signal, chunk_len, out,
+                               out_chunk_stride, out_sample_stride, med_out, mad_out);
         return slk_launch_status();
     }
     int npow2 = 1;
