@@ -185,6 +185,14 @@ int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW
 int slk_gru_fused16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                         float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                         const int32_t *lens, float *zr_out, slk_stream_t stream);
+/* The same arithmetic and contract as slk_gru_fused16_f32 on a different execution plan (csrc/gru_bar16.hip): four waves
+ * per workgroup, one per SIMD with 512 registers each, stepping in lock step through two s_barrier per time step instead of
+ * LDS progress counters; projection weights live in accumulation registers.  Results agree with slk_gru_fused16_f32 to a
+ * few 1e-7 (the three split terms are summed in a different order).  This is the plan sloika_amd.layers.Gru runs;
+ * SLK_ERR_UNSUPPORTED for shapes without an instantiation (the same list as slk_gru_fused16_f32).                      */
+int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+                      float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
+                      const int32_t *lens, float *zr_out, slk_stream_t stream);
 /* Ragged batches (whole reads of different lengths, zero-padded to T steps; the reference calls reads one at a time,
  * sloika/basecall.py:88-121): lens[b] in [1, T] (int32, device) is the number of valid steps of chunk b.  Steps
  * t >= lens[b] of y / h_out are left untouched, and with reverse = 1 the scan of chunk b starts at ITS last step,

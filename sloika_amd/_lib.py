@@ -50,6 +50,7 @@ PROTOTYPES = {
     "slk_gru_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slk_paths_to_bases": (_i, [_vp, _l, _vp, _i, _i, _i, _i, C.c_ulonglong, _vp, _l, _vp, _vp]),
     "slk_gru_fused16_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "slk_gru_bar16_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "slk_gru_fused_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_lstm_recurrent_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_lstm_recurrent_ragged_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -1,8 +1,3 @@
-// EXPERIMENT, not part of libsloika_amd.so (build + run: tools/bar16_check.py --build, then the same script on the GPU box).
-// Outcome on MI355X (T=800, B=1024, 96->96): 0.727 ms against 0.71-0.74 ms for the production kernel gru_fused16.hip in the same
-// process -- no gain; DESIGN.md 3.1 has the measurements that explain why (a wave alone on its SIMD is bound by its own
-// instruction issue and by LDS round trips taken by four waves at once right after each barrier).
-//
 // gru_bar16.hip -- a whole Gru layer (sloika/layers.py:1010-1021) in one persistent kernel of FOUR waves per workgroup,
 // one per SIMD, in lock step: the same arithmetic as gru_fused16.hip (3-term fp16 split products, float32 accumulation,
 // rows scaled by powers of two) on a different execution plan.
@@ -26,7 +21,7 @@
 
 #include <type_traits>
 
-#include "../../sloika_amd/csrc/f16split.h"
+#include "f16split.h"
 
 template <bool REAL = true>
 __device__ __forceinline__ void lds_bar()
@@ -91,6 +86,44 @@ __device__ __forceinline__ void mfma3xn(const half8 (*w_hi)[KBLK_], const half8 
     for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[t][kb], x_hi, acc[t], 0, 0, 0);
 }
 
+// Projection weights in ACCUMULATION registers (a wave alone on its SIMD has 256 of them next to its 256 ordinary ones), named
+// directly as the MFMA's A operand.  hipcc treats those registers as spill space and copies every operand back (four
+// v_accvgpr_read per operand and use); operands only ever used through an "a" constraint stay where they are.
+__device__ __forceinline__ half8 to_acc_regs(half8 v)
+{
+    half8 a;
+    asm volatile("" : "=a"(a) : "0"(v));
+    return a;
+}
+// a whole tile: acc = sum over K blocks of the 3-term split, first MFMA with a zero C operand (no VALU write of the accumulator
+// in front of an instruction the compiler does not know to be an MFMA), then let the matrix pipe drain before ordinary
+// instructions read the result (the compiler's hazard bookkeeping does not see asm)
+template <int KBLK_>
+__device__ __forceinline__ f32x4 tile_mfma_acc(const half8 *w_hi, const half8 *w_lo, const half8 *x_hi, const half8 *x_lo)
+{
+    f32x4 acc;
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w_hi[0]), "v"(x_lo[0]));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_lo[0]), "v"(x_hi[0]));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi[0]), "v"(x_hi[0]));
+#pragma unroll
+    for (int kb = 1; kb < KBLK_; kb++) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi[kb]), "v"(x_lo[kb]));
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_lo[kb]), "v"(x_hi[kb]));
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi[kb]), "v"(x_hi[kb]));
+    }
+    return acc;
+}
+__device__ __forceinline__ void mfma_drain(f32x4 &a) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a)); }
+// one K block of one tile, accumulator kept across steps (chain waves); FIRST: start from zero
+template <bool FIRST>
+__device__ __forceinline__ void block_mfma_acc(f32x4 &acc, const half8 &w_hi, const half8 &w_lo, const half8 &x_hi, const half8 &x_lo)
+{
+    if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w_hi), "v"(x_lo));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi), "v"(x_lo));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_lo), "v"(x_hi));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi), "v"(x_hi));
+}
+
 // Diagnostic instantiation: shader-clock cycles the waves of workgroup 0 spend in each section of a step, summed over the scan
 // (tools/bar16_check.py reads them).  The production instantiation carries none of this.
 __device__ unsigned long long slk_dbg_bar16[4][16];
@@ -111,6 +144,17 @@ extern "C" int slk_debug_read_bar16(unsigned long long *host_out)
 
 // ABL (timing experiments of tools/bar16_check.py only; results are garbage): 1 = no s_barrier, 2 = chain waves issue no MFMAs,
 // 4 = cheap activations, 8 = service waves only keep the barriers, 16 = no stores to h_out
+// first tile of interval k when a service wave has st tiles per group (k = 8: st)
+__host__ __device__ constexpr int tile_first(int st, int k)
+{
+    // share per interval in sixteenths: light where the leader also splits x (intervals 1..4) and fetches operands (0)
+    constexpr int w[8] = {1, 0, 1, 1, 2, 2, 2, 3};
+    int tot = 0, acc = 0;
+    for (int i = 0; i < 8; i++) tot += w[i];
+    for (int i = 0; i < k && i < 8; i++) acc += w[i];
+    return k >= 8 ? st : (acc * st + tot / 2) / tot < st ? (acc * st + tot / 2) / tot : st;
+}
+
 template <int I, int N, bool SAVE, bool DIAG = false, int ABL = 0>
 __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restrict__ x, long ldx, const float *__restrict__ iW,
                                                            const float *__restrict__ bias, const float *__restrict__ sW,
@@ -128,10 +172,12 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
     constexpr int GS = 4;                                // steps per projection group (16 MFMA columns = 4 steps x 4 chunks)
     constexpr int KB = 8;                                // steps per x block
     constexpr int R = 2 * GS;                            // vI ring: group G+1 is written while group G is consumed
-    constexpr int CT = NCW == 3 ? 3 : (NCW == 2 ? 2 : 0);               // projection tiles of a chain wave
+    constexpr int CT = NCW == 3 ? 2 : 0;                                // projection tiles of a chain wave (weights in accumulation registers)
     constexpr int ST = (NT16 - NCW * CT) / NSW;                         // ... of a service wave
+    constexpr int NACAP = 240 / (8 * KBLK);                              // 256 accumulation registers, 2 * KBLK * 4 per tile
+    constexpr int NA = ST < NACAP ? ST : NACAP;                               // of which this many keep their weights in accumulation registers
     static_assert(NCW * CT + NSW * ST == NT16, "tile assignment");
-    static_assert(KBLK <= 4 && ST <= 16, "interval plan");
+    static_assert(KBLK <= 4 && ST <= 21, "interval plan");
     constexpr int XIMG = 4 * I;                          // floats of one step's x image: [k/4][chunk][k%4]
     constexpr int XPIECES = KB * I;                      // 16-byte pieces per x block
     constexpr int XSLOTS = 4;
@@ -251,7 +297,11 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         f32x4 pacc[CTA];
         if constexpr (CT > 0) {
 #pragma unroll
-            for (int t = 0; t < CT; t++) load_tile(w * CT + t, pw_hi[t], pw_lo[t]);
+            for (int t = 0; t < CT; t++) {
+                load_tile(w * CT + t, pw_hi[t], pw_lo[t]);
+#pragma unroll
+                for (int kb = 0; kb < KBLK; kb++) { pw_hi[t][kb] = to_acc_regs(pw_hi[t][kb]); pw_lo[t][kb] = to_acc_regs(pw_lo[t][kb]); }
+            }
         }
         int boff[KBS];
 #pragma unroll
@@ -270,17 +320,19 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
 
         __syncthreads();                                 // LDS initialised, every wave's invw_lds rows written
         lds_bar();                                       // x operand images of groups 0 and 1 (service leader)
+        half8 pxh = {0, 0, 0, 0, 0, 0, 0, 0}, pxl = pxh;    // x operands of the coming step's share of the projection
         if constexpr (CT > 0) {                          // vI of group 0
+            half8 xh0[KBLK], xl0[KBLK];
 #pragma unroll
-            for (int t = 0; t < CT; t++) pacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kb = 0; kb < KBLK; kb++) { xh0[kb] = ldH(xop_hi, poff + 64 * kb); xl0[kb] = ldH(xop_lo, poff + 64 * kb); }
 #pragma unroll
-            for (int kb = 0; kb < KBLK; kb++) {
-                const half8 xh = ldH(xop_hi, poff + 64 * kb), xl = ldH(xop_lo, poff + 64 * kb);
-#pragma unroll
-                for (int t = 0; t < CT; t++) pacc[t] = mfma3(pw_hi[t][kb], pw_lo[t][kb], xh, xl, pacc[t]);
+            for (int t = 0; t < CT; t++) {
+                pacc[t] = tile_mfma_acc<KBLK>(pw_hi[t], pw_lo[t], xh0, xl0);
+                mfma_drain(pacc[t]);
+                proj_out(w * CT + t, pacc[t], 0);
             }
-#pragma unroll
-            for (int t = 0; t < CT; t++) proj_out(w * CT + t, pacc[t], 0);
+            pxh = ldH(xop_hi, OPIMG + poff);             // step 0 projects K block 0 of group 1
+            pxl = ldH(xop_lo, OPIMG + poff);
         }
         lds_bar();                                       // vI of group 0 complete
 
@@ -289,13 +341,6 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         float hold[2] = {0.0f, 0.0f};
         // carried from step to step: my own K block of h(s-1) as B operand (read back right after I wrote it) and vI(s)
         half8 oh = {0, 0, 0, 0, 0, 0, 0, 0}, ol = {0, 0, 0, 0, 0, 0, 0, 0};
-        float vz[2], vr[2], vc[2];
-#pragma unroll
-        for (int p = 0; p < 2; p++) {
-            vr[p] = vbuf[voff + 64 * (NT + 2 * w + p)];
-            vz[p] = vbuf[voff + 64 * (2 * w + p)];
-            vc[p] = vbuf[voff + 64 * (2 * NT + 2 * w + p)];
-        }
         // One step = two intervals, each opened by a barrier; MFMAs are issued in an order that keeps the matrix pipe busy
         // through every LDS round trip and every stretch of gate arithmetic (an MFMA occupies the pipe for 16 cycles and
         // the issuing wave for 4):
@@ -326,16 +371,34 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             bl[0] = ol;
 #pragma unroll
             for (int i = 1; i < KBS; i++) { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+            // vI(s): complete since the previous barrier at the latest (the service waves use every interval)
+            const float *vcur = vbuf + (s % R) * VSTEP + voff;
+            float vz[2], vr[2], vc[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                vr[p] = vcur[64 * (NT + 2 * w + p)];
+                vz[p] = vcur[64 * (2 * w + p)];
+                vc[p] = vcur[64 * (2 * NT + 2 * w + p)];
+            }
             __builtin_amdgcn_sched_barrier(0);
             f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
-            if constexpr (CT > 0 && ph == 3) {           // last step of the group: vI of group G+1 (MFMAs issued in steps 0..2)
+            if constexpr (PROJ) {                        // my tile of the projection, K block ph: inside the LDS round trip
+                if constexpr (!(ABL & 2)) {
 #pragma unroll
-                for (int t = 0; t < CT; t++) proj_out(w * CT + t, pacc[t], G + 1);
+                    for (int t = 0; t < CT; t++) block_mfma_acc<ph == 0>(pacc[t], pw_hi[t][ph], pw_lo[t][ph], pxh, pxl);
+                }
+            }
+            if constexpr (CT > 0 && ph == 3) {           // vI of group G+1 (its last MFMAs were issued a step ago unless KBLK = 4)
+#pragma unroll
+                for (int t = 0; t < CT; t++) {
+                    if constexpr (KBLK == 4) mfma_drain(pacc[t]);
+                    proj_out(w * CT + t, pacc[t], G + 1);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (KBS > 1) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");       // the six vI words may still be on their way
 #pragma unroll
                 for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
                 __builtin_amdgcn_sched_barrier(0);
@@ -378,17 +441,11 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             BSTAMP(4)
 #pragma unroll
             for (int i = 1; i < KBS; i++) { ch[i] = ldH(rh_hi, boff[i]); cl[i] = ldH(rh_lo, boff[i]); }
-            const float *vnext = vbuf + ((s + 1) % R) * VSTEP + voff;
-            float vzn[2], vrn[2], vcn[2];
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                vrn[p] = vnext[64 * (NT + 2 * w + p)];
-                vzn[p] = vnext[64 * (2 * w + p)];
-                vcn[p] = vnext[64 * (2 * NT + 2 * w + p)];
-            }
+            constexpr int nph = (ph + 1) & 3;            // the next step projects K block nph of the group after ITS group
+            constexpr bool NPROJ = CT > 0 && nph < KBLK;
             half8 xh, xl;
-            if constexpr (PROJ) {
-                const int ob = ((G + 1) & 1) * OPIMG + poff + 64 * ph;
+            if constexpr (NPROJ) {
+                const int ob = ((G + (ph == 3 ? 2 : 1)) & 1) * OPIMG + poff + 64 * nph;
                 xh = ldH(xop_hi, ob);
                 xl = ldH(xop_lo, ob);
             }
@@ -401,9 +458,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 1; i < KBS; i++) { keep(ch[i]); keep(cl[i]); }
-#pragma unroll
-            for (int p = 0; p < 2; p++) { keepf(vzn[p]); keepf(vrn[p]); keepf(vcn[p]); }
-            if constexpr (PROJ) { keep(xh); keep(xl); }
+            if constexpr (NPROJ) { keep(xh); keep(xl); pxh = xh; pxl = xl; }
             __builtin_amdgcn_sched_barrier(0);
             BSTAMP(5)
 #pragma unroll
@@ -424,13 +479,6 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             }
             __builtin_amdgcn_sched_barrier(0);
             BSTAMP(6)
-            if constexpr (PROJ) {
-                if constexpr (ph == 0) {
-#pragma unroll
-                    for (int t = 0; t < CT; t++) pacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                if constexpr (!(ABL & 2)) mfma3xn<CTA, KBLK>(pw_hi, pw_lo, ph, xh, xl, pacc);
-            }
             float hn[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
@@ -447,13 +495,6 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             oh = ldH(h_hi, boff[0]);
             ol = ldH(h_lo, boff[0]);
             lds_fence();
-            if constexpr (PROJ) {
-#pragma unroll
-                for (int i = 0; i < 3 * CT; i++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                }
-            }
             if (store) {
                 hp[0] = hn[0];
                 hp[16] = hn[1];
@@ -462,7 +503,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             hp += hstep;
             if constexpr (SAVE) zp += zstep;
 #pragma unroll
-            for (int p = 0; p < 2; p++) { hold[p] = hn[p]; vz[p] = vzn[p]; vr[p] = vrn[p]; vc[p] = vcn[p]; }
+            for (int p = 0; p < 2; p++) hold[p] = hn[p];
             BSTAMP(7)
         };
         for (int G = 0; G < NG; G++) {
@@ -483,9 +524,17 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         const int sw = wave - NCW;
         const bool leader = sw == 0;
         const int tile0 = NCW * CT + sw * ST;
-        half8 pw_hi[ST][KBLK], pw_lo[ST][KBLK];
+        constexpr int NV = ST - NA > 0 ? ST - NA : 1;
+        half8 pa_hi[NA][KBLK], pa_lo[NA][KBLK];          // tiles 0..NA-1: accumulation registers
+        half8 pw_hi[NV][KBLK], pw_lo[NV][KBLK];          // the rest: ordinary registers
 #pragma unroll
-        for (int t = 0; t < ST; t++) load_tile(tile0 + t, pw_hi[t], pw_lo[t]);
+        for (int t = 0; t < NA; t++) {
+            load_tile(tile0 + t, pa_hi[t], pa_lo[t]);
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) { pa_hi[t][kb] = to_acc_regs(pa_hi[t][kb]); pa_lo[t][kb] = to_acc_regs(pa_lo[t][kb]); }
+        }
+#pragma unroll
+        for (int t = NA; t < ST; t++) load_tile(tile0 + t, pw_hi[t - NA], pw_lo[t - NA]);
 
         // x DMA: request j of a block moves pieces 64 j .. 64 j + 63; piece p = (step kk, 16-byte column qq, chunk cc)
         // (p % I) & 3 = lane & 3: a lane always serves the same chunk
@@ -509,6 +558,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         auto split_img = [&](int G2) {
             return xraw + ((G2 >> 1) % XSLOTS) * (KB * XIMG) + (GS * (G2 & 1) + pstep) * XIMG + 4 * pc;
         };
+        float raw[KBLK][8];                              // the group's rows as read for the scale, kept for the split
         auto split_scale = [&](int G2) {                 // pass 1: the row's power-of-two scale
             const float *img = split_img(G2);
             float amax = 0.0f;
@@ -519,22 +569,21 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 const float *src = img + 4 * (kok ? k0 : 0);
                 const f32x4 u0 = *reinterpret_cast<const f32x4 *>(src), u1 = *reinterpret_cast<const f32x4 *>(src + 16);
 #pragma unroll
-                for (int j = 0; j < 4; j++) amax = fmaxf(amax, kok ? fmaxf(fabsf(u0[j]), fabsf(u1[j])) : 0.0f);
+                for (int j = 0; j < 4; j++) {
+                    raw[kb][j] = kok ? u0[j] : 0.0f;
+                    raw[kb][4 + j] = kok ? u1[j] : 0.0f;
+                    amax = fmaxf(amax, fmaxf(fabsf(raw[kb][j]), fabsf(raw[kb][4 + j])));
+                }
             }
             float xinv;
             xs = pow2_scale(kgroup_max(amax), xinv);
             if (kg == 0) xinv_lds[(G2 & 1) * 16 + pcol] = xinv;
         };
         auto split_block = [&](int G2, int kb) {         // pass 2: K block kb -> operand images
-            const float *img = split_img(G2);
-            const int k0 = 32 * kb + 8 * kg;
-            const bool kok = (I % 32 == 0) || k0 < I;
-            const float *src = img + 4 * (kok ? k0 : 0);
-            const f32x4 u0 = *reinterpret_cast<const f32x4 *>(src), u1 = *reinterpret_cast<const f32x4 *>(src + 16);
             half8 ahi, alo;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float v = kok ? (j < 4 ? u0[j & 3] : u1[j & 3]) * xs : 0.0f;
+                const float v = raw[kb][j] * xs;
                 const _Float16 h = (_Float16)v;
                 ahi[j] = h;
                 alo[j] = (_Float16)(v - (float)h);
@@ -568,15 +617,56 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 xl[kb] = ldH(xop_lo, ob);
             }
         };
-        auto project_tile = [&](auto TC, int G1) {
+        // accumulator of one tile (no drain): accumulation-register weights through asm, the rest through the builtin
+        auto tile_acc = [&](auto TC) {
             constexpr int t = decltype(TC)::value;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (t < NA) {
+                return tile_mfma_acc<KBLK>(pa_hi[t], pa_lo[t], xh, xl);
+            } else {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kb = 0; kb < KBLK; kb++) acc = mfma3(pw_hi[t][kb], pw_lo[t][kb], xh[kb], xl[kb], acc);
-            proj_out(tile0 + t, acc, G1);
+                for (int kb = 0; kb < KBLK; kb++) acc = mfma3(pw_hi[t - NA][kb], pw_lo[t - NA][kb], xh[kb], xl[kb], acc);
+                return acc;
+            }
+        };
+        // two tiles: their output constants are requested first, then all MFMAs (the matrix pipe stays busy through the LDS
+        // round trip), one drain, then the outputs
+        auto project_tiles = [&](auto T0, auto T1, int G1) {
+            constexpr int t0 = decltype(T0)::value, t1 = decltype(T1)::value;
+            const float xin = xinv_lds[(G1 & 1) * 16 + pcol];
+            f32x4 iw0, bs0, iw1, bs1;
+            iw0 = *reinterpret_cast<const f32x4 *>(&invw_lds[16 * (tile0 + t0) + 4 * kg]);
+            bs0 = *reinterpret_cast<const f32x4 *>(&bias_lds[16 * (tile0 + t0) + 4 * kg]);
+            if constexpr (t1 < ST) {
+                iw1 = *reinterpret_cast<const f32x4 *>(&invw_lds[16 * (tile0 + t1) + 4 * kg]);
+                bs1 = *reinterpret_cast<const f32x4 *>(&bias_lds[16 * (tile0 + t1) + 4 * kg]);
+            }
+            f32x4 a0 = tile_acc(T0), a1 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (t1 < ST) a1 = tile_acc(ic<t1 < ST ? t1 : 0>{});
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a0), "+v"(a1));
+            const int st = GS * G1 + pstep;
+            float *dst = &vbuf[(st % R) * VSTEP + (kg * 4 + pc) * 4];
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = fmaf(a0[r] * xin, iw0[r], bs0[r]);
+            *reinterpret_cast<f32x4 *>(dst + 64 * (tile0 + t0)) = o;
+            if constexpr (t1 < ST) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[r] = fmaf(a1[r] * xin, iw1[r], bs1[r]);
+                *reinterpret_cast<f32x4 *>(dst + 64 * (tile0 + t1)) = o;
+            }
+        };
+        // which tiles an interval computes: the leader's intervals 1-3 carry the x split, so they get fewer
+        auto project_interval = [&](auto KC, int G1) {
+            constexpr int k = decltype(KC)::value;
+            constexpr int lo = tile_first(ST, k), hi = tile_first(ST, k + 1);
+            static_assert(hi - lo <= 3, "at most three tiles per interval");
+            if constexpr (hi - lo == 1) project_tiles(ic<lo>{}, ic<ST>{}, G1);
+            if constexpr (hi - lo == 2) project_tiles(ic<lo>{}, ic<lo + 1>{}, G1);
+            if constexpr (hi - lo == 3) { project_tiles(ic<lo>{}, ic<lo + 1>{}, G1); project_tiles(ic<lo + 2>{}, ic<ST>{}, G1); }
         };
         load_operands(0);
-        static_for<0, ST>([&](auto TC) { project_tile(TC, 0); });
+        static_for<0, 8>([&](auto KC) { project_interval(KC, 0); });
         lds_bar();                                       // vI of group 0 complete
 
         // interval k = 0..7 of group G (two per step, each opened by the barrier the chain waves open theirs with)
@@ -600,10 +690,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 if (j < NREQ && blk + XSLOTS - 1 < NBLK) dma_request(blk + XSLOTS - 1, j);
             }
             if constexpr (k == 0) load_operands(G + 1);
-            // (nothing in the last interval: the chain reads vI of the group's first step right after its barrier)
-            if constexpr (k < 7 && k < ST) project_tile(ic<k>{}, G + 1);
-            if constexpr (k < 7 && k + 7 < ST) project_tile(ic<k + 7>{}, G + 1);
-            if constexpr (k < 7 && k + 14 < ST) project_tile(ic<k + 14>{}, G + 1);
+            project_interval(KC, G + 1);
             if (leader) {
                 if constexpr (k == 1) split_scale(G + 2);
                 if constexpr (k >= 2 && k < 2 + KBLK) split_block(G + 2, k - 2);
@@ -679,7 +766,7 @@ extern "C" int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, cons
     hipStream_t s = slk_stream(stream);
 #define BAR16(II, NN) \
     if (insize == II && n == NN) return launch_bar16<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s);
-    BAR16(96, 96)
+    BAR16(96, 96) BAR16(64, 64) BAR16(32, 96) BAR16(128, 96) BAR16(64, 96) BAR16(48, 32) BAR16(16, 64)
 #undef BAR16
     return SLK_ERR_UNSUPPORTED;
 }

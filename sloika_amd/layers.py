@@ -105,9 +105,20 @@ def _stream():
 SPLIT_F16 = os.environ.get("SLOIKA_AMD_EXACT_F32", "0") != "1"
 
 
-#: The recurrent products of a fused Gru layer also run as 3-term fp16 splits (csrc/gru_fused16.hip) unless
-#: SLOIKA_AMD_RECURRENT_F32=1 asks for the exact-fp32 recurrence of csrc/gru_fused.hip (SLOIKA_AMD_EXACT_F32=1 implies it).
+#: The recurrent products of a fused Gru layer also run as 3-term fp16 splits unless SLOIKA_AMD_RECURRENT_F32=1 asks for the
+#: exact-fp32 recurrence of csrc/gru_fused.hip (SLOIKA_AMD_EXACT_F32=1 implies it).
 RECURRENT_F16 = os.environ.get("SLOIKA_AMD_RECURRENT_F32", "0") != "1"
+#: Execution plan of that kernel: "bar" = four waves stepping through barriers (csrc/gru_bar16.hip, the faster one),
+#: "flags" = eight waves coupled by LDS progress counters (csrc/gru_fused16.hip).  Same arithmetic, same contract.
+GRU_PLAN = os.environ.get("SLOIKA_AMD_GRU_PLAN", "bar")
+
+
+def gru_f16_entry():
+    """The C-ABI entry of the fp16-split fused Gru kernel selected by GRU_PLAN."""
+    if GRU_PLAN not in ("bar", "flags"):
+        raise ValueError("SLOIKA_AMD_GRU_PLAN must be 'bar' or 'flags'")
+    L = _lib.lib()
+    return L.slk_gru_bar16_f32 if GRU_PLAN == "bar" else L.slk_gru_fused16_f32
 
 def _split_f16_cached(owner, attr, param, rows, k):
     """fp16 hi/lo parts of the [rows][k] weight `param` (rows scaled by powers of two) and the inverse row scales, on the
@@ -806,14 +817,14 @@ class Gru(RNN):
         if SPLIT_F16:
             rc = _lib.SLK_ERR_UNSUPPORTED
             if RECURRENT_F16:
-                # projection AND recurrence as 3-term fp16 splits (csrc/gru_fused16.hip)
+                # projection AND recurrence as 3-term fp16 splits (csrc/gru_bar16.hip / gru_fused16.hip)
                 with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
                                      f16x3_flops=6.0 * rows * n * (n + self.insize)) as reg:
-                    rc = L.slk_gru_fused16_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
-                                               self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
-                                               y.data_ptr(), _row_stride(y), T, B, self.insize, n, int(reverse),
-                                               activation.act_id(self.fun), activation.act_id(self.gatefun),
-                                               None if lens is None else lens.data_ptr(), None, _stream())
+                    rc = gru_f16_entry()(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
+                                         self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
+                                         y.data_ptr(), _row_stride(y), T, B, self.insize, n, int(reverse),
+                                         activation.act_id(self.fun), activation.act_id(self.gatefun),
+                                         None if lens is None else lens.data_ptr(), None, _stream())
                     if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
                         reg.cancel()
             if rc == _lib.SLK_ERR_UNSUPPORTED:

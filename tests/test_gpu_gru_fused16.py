@@ -18,8 +18,19 @@ def _params(rs, I, n, bias=True, scale=1.0):
     return iW, sW, sW2, b
 
 
+#: the two execution plans of the same arithmetic: LDS progress counters (gru_fused16.hip) and barrier-stepped (gru_bar16.hip)
+ENTRY = "slk_gru_bar16_f32"
+
+
+@pytest.fixture(autouse=True, params=["slk_gru_bar16_f32", "slk_gru_fused16_f32"])
+def _entry(request):
+    global ENTRY
+    ENTRY = request.param
+    yield
+
+
 def _call(L, x, ldx, iW, sW, sW2, b, y, ldy, T, B, I, n, reverse, lens=None, zr=None):
-    return L.slk_gru_fused16_f32(x, ldx, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), None if b is None else b.data_ptr(),
+    return getattr(L, ENTRY)(x, ldx, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), None if b is None else b.data_ptr(),
                                  y, ldy, T, B, I, n, int(reverse), 1, 2, None if lens is None else lens.data_ptr(),
                                  None if zr is None else zr.data_ptr(), stream())
 
@@ -195,7 +206,7 @@ def test_fused16_unsupported_shapes():
     L = _lib.lib()
     z = dev(np.zeros((4, 4), dtype=np.float32))
     for I, n, act in ((7, 5, 1), (96, 128, 1), (96, 96, 3), (96, 112, 1)):
-        assert L.slk_gru_fused16_f32(z.data_ptr(), I, z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), n, 1, 1,
+        assert getattr(L, ENTRY)(z.data_ptr(), I, z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), n, 1, 1,
                                      I, n, 0, act, 2, None, None, stream()) == _lib.SLK_ERR_UNSUPPORTED
 
 

@@ -1,23 +1,10 @@
-"""tools/experiments/gru_bar16.hip against gru_fused16 (same arithmetic, differences of a few 1e-7 from the order of the split terms) and in-process timing of both, plus the experiment's ablations and section stamps."""
+"""csrc/gru_bar16.hip against gru_fused16 (same arithmetic, differences of a few 1e-7 from the order of the split terms) and in-process timing of both, plus the experiment's ablations and section stamps."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import ctypes, subprocess
-HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "_build", "libbar16.so")
-if "--build" in sys.argv:                 # on the CPU box, before gpurun ships the tree
-    os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=off",
-                           "-shared", "-o", SO, os.path.join(HERE, "experiments", "gru_bar16.hip")])
-    sys.exit(0)
+import ctypes
 import numpy as np, torch
 from sloika_amd import _lib
 L = _lib.lib()
-X = ctypes.CDLL(SO)
-_vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
-X.slk_gru_bar16_f32.argtypes = [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]
-X.slk_gru_bar16_f32.restype = _i
-L.slk_gru_bar16_f32 = X.slk_gru_bar16_f32
-L.slk_debug_read_bar16 = X.slk_debug_read_bar16
 st = torch.cuda.current_stream().cuda_stream
 
 def run(entry, x, iW, sW, sW2, b, T, B, I, n, rev, lens=None, zr=None):

@@ -21,7 +21,7 @@ def load(d):
 
 
 STAGES = {            # bench.py stage -> substrings of the kernels it launches (summed)
-    "gru_fused": ("gru_fused16_kernel", "gru_fused_kernel"),
+    "gru_fused": ("gru_bar16_kernel", "gru_fused16_kernel", "gru_fused_kernel"),
     "softmax_gemm": ("gemm_rows_f16x3_kernel", "gemm_rows_kernel"),
     "viterbi": ("viterbi_forward", "viterbi_backtrace"),
     "conv1d": ("conv1d_",),
