@@ -372,6 +372,11 @@ int slk_reduce_sum_f32(const float *x, size_t n, int square, double *out, slk_st
 size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2);
 int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
                     float *colsum /* [N1] or NULL */, void *workspace, size_t workspace_bytes, slk_stream_t stream);
+/* The same contraction with every float32 operand cut into three bf16 pieces and each product evaluated as six bf16 MFMA terms
+ * in float32 accumulators (v_mfma_f32_32x32x16_bf16): float32-grade results (terms below 2^-24 of a product are dropped), no
+ * scaling needed (bf16 has float32's exponent range), ~2x the speed of the fp32 MFMA form.  Same workspace.               */
+int slk_gemm_tn_bf16x6_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
+                           float *colsum, void *workspace, size_t workspace_bytes, slk_stream_t stream);
 int slk_act_backward_f32(const float *dy, const float *y, float *out, size_t n, int act, slk_stream_t stream);
 int slk_add_inplace_f32(float *y, const float *x, size_t n, slk_stream_t stream);   /* y += x: dL/dx of Parallel branches */
 int slk_train_im2col_cin1_f32(const float *x, long x_t_stride, long x_b_stride, int T, int B, int winlen, int stride,

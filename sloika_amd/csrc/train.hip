@@ -761,6 +761,133 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     }
 }
 
+// The same contraction on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate): every float32 operand is
+// cut into three bf16 pieces v = b1 + b2 + b3 (8 significand bits each: the top 16 bits of v, of v - b1, of v - b1 - b2 --
+// exact, and bf16 has float32's exponent range, so no scaling is needed and gradients of 1e-30 are as safe as 1e+3) and a
+// product is the six terms b1c1 + (b1c2 + b2c1) + (b1c3 + b2c2 + b3c1) in float32 accumulators; what is dropped is below
+// 2^-24 of the product.  A lane supplies 8 consecutive ROWS m of one column per operand tile -- again straight from global
+// memory (a half-wave reads 32 consecutive columns of one row per load).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8 &p1, bf16x8 &p2, bf16x8 &p3)
+{
+    union { bf16x8 v; unsigned u[4]; } o1, o2, o3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        unsigned t1[2], t2[2], t3[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float x = v[2 * j + e];
+            t1[e] = __float_as_uint(x) & 0xffff0000u;
+            const float r1 = x - __uint_as_float(t1[e]);
+            t2[e] = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(t2[e]);
+            t3[e] = __float_as_uint(r2) & 0xffff0000u;
+        }
+        o1.u[j] = (t1[0] >> 16) | t1[1];
+        o2.u[j] = (t2[0] >> 16) | t2[1];
+        o3.u[j] = (t3[0] >> 16) | t3[1];
+    }
+    p1 = o1.v; p2 = o2.v; p3 = o3.v;
+}
+
+template <bool CS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm_tn_bf16_kernel(const float *__restrict__ A, long lda, const float *__restrict__ Bm,
+                                                          long ldb, float *__restrict__ partial, long M, int N1, int N2,
+                                                          float *__restrict__ cs_partial, int slice_rows)
+{
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const int n1_0 = blockIdx.x * TN_BLK, n2_0 = blockIdx.z * TN_BLK;
+    const long m_lo = (long)blockIdx.y * slice_rows, m_hi = min(m_lo + slice_rows, M);
+    const int ta = min(3, (N1 - n1_0 + 31) / 32), tb = min(3, (N2 - n2_0 + 31) / 32);    // live 32-wide tiles (uniform)
+    const float *pa[3], *pb[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        pa[i] = A + min(n1_0 + 32 * i + r, N1 - 1);
+        pb[i] = Bm + min(n2_0 + 32 * i + r, N2 - 1);
+    }
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+    float cs[3] = {0.0f, 0.0f, 0.0f};
+    // one K block = 16 rows: this lane holds rows m0 + 8h + (0..7) of its column in each of the six operand tiles.  Two
+    // register buffers: the loads of the next block are in flight while the matrix pipe works through the current one.
+    float a0[3][8], b0[3][8], a1[3][8], b1[3][8];
+    auto load = [&](float (&av)[3][8], float (&bv)[3][8], long m0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const long mc = min(m0 + 8 * h + j, M - 1);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                av[i][j] = i < ta ? pa[i][mc * lda] : 0.0f;
+                bv[i][j] = i < tb ? pb[i][mc * ldb] : 0.0f;
+            }
+        }
+    };
+    auto mma = [&](float (&av)[3][8], float (&bv)[3][8], long m0) {
+        bf16x8 pa1[3], pa2[3], pa3[3], pb1[3], pb2[3], pb3[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                av[i][j] = (m0 + 8 * h + j) < m_hi ? av[i][j] : 0.0f;       // rows past the slice (read from a clamped address)
+                if (CS) cs[i] += av[i][j];
+            }
+            split_bf16x3(av[i], pa1[i], pa2[i], pa3[i]);
+            split_bf16x3(bv[i], pb1[i], pb2[i], pb3[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if (i < ta && j < tb) {
+                    // small terms first so that they are not absorbed by the large one
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1[i], pb3[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa2[i], pb2[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa3[i], pb1[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1[i], pb2[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa2[i], pb1[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1[i], pb1[j], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+    };
+    constexpr int STEP = 16;
+    load(a0, b0, m_lo);
+    for (long m0 = m_lo; m0 < m_hi; m0 += 2 * STEP) {
+        load(a1, b1, m0 + STEP);
+        mma(a0, b0, m0);
+        load(a0, b0, m0 + 2 * STEP);
+        mma(a1, b1, m0 + STEP);
+    }
+    float *out = partial + (size_t)blockIdx.y * N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int col = n2_0 + 32 * j + r;
+            if (i < ta && j < tb && col < N2) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int rowc = n1_0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (rowc < N1) out[(size_t)rowc * N2 + col] = acc[i][j][e];
+                }
+            }
+        }
+    if (CS && blockIdx.z == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float tot = cs[i] + __shfl_xor(cs[i], 32);
+            const int colc = n1_0 + 32 * i + r;
+            if (h == 0 && i < ta && colc < N1) cs_partial[(size_t)blockIdx.y * N1 + colc] = tot;
+        }
+    }
+}
+
 // C = sum over slices of partial, in a fixed order: 64 outputs x 16 slice groups per workgroup; group sg adds slices
 // sg, sg+16, ... (eight loads in flight), then the 16 group sums are added in group order.
 __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float *__restrict__ partial, int nslice, int N1, int N2,
@@ -806,8 +933,8 @@ extern "C" size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2)
     return (size_t)((M + rows - 1) / rows) * N1 * ((size_t)N2 + 1) * sizeof(float);
 }
 
-extern "C" int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
-                               float *colsum, void *workspace, size_t workspace_bytes, slk_stream_t stream)
+static int gemm_tn_launch(bool bf16, const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
+                          float *colsum, void *workspace, size_t workspace_bytes, slk_stream_t stream)
 {
     if (!A || !B || !C || M < 1 || N1 < 1 || N2 < 1 || lda < N1 || ldb < N2 || ldc < N2) return SLK_ERR_INVALID_ARG;
     if (!workspace || workspace_bytes < slk_gemm_tn_workspace_bytes(M, N1, N2)) return SLK_ERR_WORKSPACE;
@@ -817,12 +944,16 @@ extern "C" int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ld
     if (nslice > 65535 || g2 > 65535) return SLK_ERR_UNSUPPORTED;
     hipStream_t s = slk_stream(stream);
     float *partial = (float *)workspace, *cs_partial = partial + (size_t)nslice * N1 * N2;
-    if (colsum)
-        hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(g1, (unsigned)nslice, g2), dim3(64), 0, s, A, lda, B, ldb, partial, M, N1,
-                           N2, cs_partial, rows);
-    else
-        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(g1, (unsigned)nslice, g2), dim3(64), 0, s, A, lda, B, ldb, partial, M,
-                           N1, N2, cs_partial, rows);
+    const dim3 grid(g1, (unsigned)nslice, g2);
+#define TN_LAUNCH(K) hipLaunchKernelGGL(K, grid, dim3(64), 0, s, A, lda, B, ldb, partial, M, N1, N2, cs_partial, rows)
+    if (bf16) {
+        if (colsum) TN_LAUNCH(gemm_tn_bf16_kernel<true>);
+        else TN_LAUNCH(gemm_tn_bf16_kernel<false>);
+    } else {
+        if (colsum) TN_LAUNCH(gemm_tn_kernel<true>);
+        else TN_LAUNCH(gemm_tn_kernel<false>);
+    }
+#undef TN_LAUNCH
     const size_t total = (size_t)N1 * N2;
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, s, (const float *)partial,
                        (int)nslice, N1, N2, C, ldc);
@@ -830,6 +961,19 @@ extern "C" int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ld
         hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((N1 + 63) / 64)), dim3(1024), 0, s, (const float *)cs_partial,
                            (int)nslice, N1, 1, colsum, 1L);
     return slk_launch_status();
+}
+
+extern "C" int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
+                               float *colsum, void *workspace, size_t workspace_bytes, slk_stream_t stream)
+{
+    return gemm_tn_launch(false, A, lda, B, ldb, C, ldc, M, N1, N2, colsum, workspace, workspace_bytes, stream);
+}
+
+// the same with every product as six bf16 terms (float32-grade, see gemm_tn_bf16_kernel); same workspace
+extern "C" int slk_gemm_tn_bf16x6_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1,
+                                      int N2, float *colsum, void *workspace, size_t workspace_bytes, slk_stream_t stream)
+{
+    return gemm_tn_launch(true, A, lda, B, ldb, C, ldc, M, N1, N2, colsum, workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

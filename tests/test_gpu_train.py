@@ -154,12 +154,14 @@ def test_gru_only_network_and_device_inputs():
     _assert_grads_close(step.gradients(), want)
 
 
+@pytest.mark.parametrize("entry", ["slk_gemm_tn_bf16x6_f32", "slk_gemm_tn_f32"])
 @pytest.mark.parametrize("M,N1,N2", [(1, 1, 1), (37, 5, 3), (2049, 96, 11), (5000, 1025, 96), (4111, 288, 100), (300, 33, 1)])
-def test_gemm_tn_vs_numpy(M, N1, N2):
-    """C = A^T B with operands inside wider rows (lda, ldb > N) and a padded result."""
+def test_gemm_tn_vs_numpy(M, N1, N2, entry):
+    """C = A^T B with operands inside wider rows (lda, ldb > N) and a padded result; the fp32-MFMA form and the six-term bf16 form."""
     torch = need_gpu()
     from sloika_amd import _lib
     L = _lib.lib()
+    tn = getattr(L, entry)
     rs = np.random.RandomState(M)
     lda, ldb, ldc = N1 + 3, N2 + 5, N2 + 2
     A = rs.normal(size=(M, lda)).astype(np.float32)
@@ -169,7 +171,7 @@ def test_gemm_tn_vs_numpy(M, N1, N2):
     nbytes = L.slk_gemm_tn_workspace_bytes(M, N1, N2)
     ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     cs = torch.full((N1 + 1,), -7.0, dtype=torch.float32, device="cuda")
-    assert L.slk_gemm_tn_f32(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, cs.data_ptr(), ws.data_ptr(),
+    assert tn(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, cs.data_ptr(), ws.data_ptr(),
                              nbytes, stream()) == 0
     want = A[:, :N1].astype(np.float64).T @ Bm[:, :N2].astype(np.float64)
     got = C.cpu().numpy()
@@ -178,12 +180,34 @@ def test_gemm_tn_vs_numpy(M, N1, N2):
     np.testing.assert_allclose(cs.cpu().numpy()[:N1], A[:, :N1].astype(np.float64).sum(0), rtol=1e-5, atol=1e-5 * np.sqrt(M))
     assert float(cs[N1]) == -7.0
     C.fill_(-7.0)
-    assert L.slk_gemm_tn_f32(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, None, ws.data_ptr(), nbytes,
+    assert tn(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, None, ws.data_ptr(), nbytes,
                              stream()) == 0
     np.testing.assert_allclose(C.cpu().numpy()[:, :N2], want, rtol=1e-5, atol=1e-5 * np.sqrt(M))
-    assert L.slk_gemm_tn_f32(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, None, ws.data_ptr(),
+    assert tn(dA.data_ptr(), lda, dB.data_ptr(), ldb, C.data_ptr(), ldc, M, N1, N2, None, ws.data_ptr(),
                              nbytes - 1, stream()) == _lib.SLK_ERR_WORKSPACE
 
+
+
+@pytest.mark.parametrize("amag,bmag", [(1e-30, 1e3), (1e-12, 1e-12), (1e20, 1e-25), (3e4, 7e4)])
+def test_gemm_tn_bf16x6_any_magnitude(amag, bmag):
+    """bf16 has float32's exponent range: gradients of 1e-30 and activations of 1e+4 need no scaling, and the six-term
+    product keeps float32-grade accuracy relative to the size of the sum's terms."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(11)
+    M, N1, N2 = 3000, 96, 40
+    A = (rs.normal(size=(M, N1)) * amag * np.exp(rs.normal(size=(1, N1)) * 3)).astype(np.float32)     # columns of different sizes
+    Bm = (rs.normal(size=(M, N2)) * bmag).astype(np.float32)
+    C = torch.empty((N1, N2), dtype=torch.float32, device="cuda")
+    nbytes = L.slk_gemm_tn_workspace_bytes(M, N1, N2)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    assert L.slk_gemm_tn_bf16x6_f32(dev(A).data_ptr(), N1, dev(Bm).data_ptr(), N2, C.data_ptr(), N2, M, N1, N2, None, ws.data_ptr(),
+                                    nbytes, stream()) == 0
+    want = A.astype(np.float64).T @ Bm.astype(np.float64)
+    scale = np.sqrt((A.astype(np.float64) ** 2).sum(0))[:, None] * np.sqrt((Bm.astype(np.float64) ** 2).sum(0))[None, :]
+    err = np.abs(C.cpu().numpy() - want) / scale
+    assert err.max() < 2e-6, err.max()
 
 @pytest.mark.parametrize("optimiser", ["adam", "sgd"])
 def test_optimiser_kernel_vs_oracle(optimiser):
