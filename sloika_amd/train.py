@@ -135,7 +135,7 @@ def _validate(layer, first, rev=False, where="network"):
     elif isinstance(layer, layers.Lstm):
         if activation.act_name(layer.fun) != "tanh" or activation.act_name(layer.gatefun) != "sigmoid":
             raise NotImplementedError("training: Lstm layers with fun=tanh, gatefun=sigmoid only")
-        if layer.size not in (16, 32, 48, 64, 96, 128):
+        if layer.size > 128:
             raise NotImplementedError("training: no reverse-scan kernel for an Lstm of size %d" % layer.size)
     elif isinstance(layer, layers.FeedForward):
         if activation.act_name(layer.fun) not in _FF_ACTS:
@@ -554,25 +554,75 @@ class TrainingStep(object):
                                                M, 3 * n, i_sz, 0, st()), "gru dx")
         return dx
 
+    #: Lstm widths the reverse-scan kernels are instantiated for (csrc/train.hip); others run zero-padded to the next one
+    _LSTM_SCAN_SIZES = (16, 32, 48, 64, 96, 128)
+
     def _lstm_backward(self, layer, rev, xin, out, dy, need_dx):
-        """Reverse pass of one Lstm layer (layers.py:677-697): gate inputs of all steps as one GEMM over [x_t | out_{t-1}],
-        the element-wise cell recursion, the reverse scan, then the weight gradients as contractions over all rows."""
+        """Reverse pass of one Lstm layer.  Widths without a reverse-scan instantiation run zero-padded to the next one that
+        has: a padding neuron has zero weights, bias and peepholes, so its gates are gatefun(0), its cell and output stay 0
+        and it receives and passes on zero gradient -- the leading blocks of every gradient are those of the unpadded layer
+        (rows of iW / sW / b are interleaved neuron-major, j*4 + gate, so padding appends rows)."""
+        import torch
+        n, i_sz = layer.size, layer.insize
+        iW, sW, b = layer.iW.dev(), layer.sW.dev(), layer.b.dev()
+        peep = layer.p.dev() if layer.has_peep else None
+        gb = self._grad_of(layer.b) if layer.has_bias else None
+        gp = self._grad_of(layer.p) if layer.has_peep else None
+        act, gact = activation.act_id(layer.fun), activation.act_id(layer.gatefun)
+        if n in self._LSTM_SCAN_SIZES:
+            return self._lstm_backward_core(xin, out, dy, rev, n, i_sz, iW, sW, b, peep, self._grad_of(layer.iW),
+                                            self._grad_of(layer.sW), gb, gp, need_dx, act, gact)
+        bigger = [m for m in self._LSTM_SCAN_SIZES if m >= n]
+        if not bigger:
+            raise NotImplementedError("training: no reverse-scan kernel for an Lstm of size %d" % n)
+        npad = bigger[0]
+        T, B, dev = int(out.shape[0]), int(out.shape[1]), out.device
+
+        def widen(t):
+            w = torch.zeros((T, B, npad), dtype=torch.float32, device=dev)
+            w[:, :, :n] = t
+            return w
+
+        iW_p = torch.zeros((4 * npad, i_sz), dtype=torch.float32, device=dev)
+        iW_p[:4 * n] = iW.reshape(4 * n, i_sz)
+        sW_p = torch.zeros((4 * npad, npad), dtype=torch.float32, device=dev)
+        sW_p[:4 * n, :n] = sW.reshape(4 * n, n)
+        b_p = torch.zeros(4 * npad, dtype=torch.float32, device=dev)
+        b_p[:4 * n] = b.reshape(-1)
+        peep_p = None
+        if peep is not None:
+            peep_p = torch.zeros((3, npad), dtype=torch.float32, device=dev)
+            peep_p[:, :n] = peep.reshape(3, n)
+        giW, gsW = torch.empty_like(iW_p), torch.empty_like(sW_p)
+        gb_p = torch.empty_like(b_p) if gb is not None else None
+        gp_p = torch.empty((3, npad), dtype=torch.float32, device=dev) if gp is not None else None
+        dx = self._lstm_backward_core(xin, widen(out), widen(dy), rev, npad, i_sz, iW_p, sW_p, b_p, peep_p, giW.reshape(-1),
+                                      gsW.reshape(-1), gb_p, None if gp_p is None else gp_p.reshape(-1), need_dx, act, gact)
+        self._grad_of(layer.iW).view(4 * n, i_sz).copy_(giW[:4 * n])
+        self._grad_of(layer.sW).view(4 * n, n).copy_(gsW[:4 * n, :n])
+        if gb is not None:
+            gb.view(-1).copy_(gb_p[:4 * n])
+        if gp is not None:
+            gp.view(3, n).copy_(gp_p[:, :n])
+        return dx
+
+    def _lstm_backward_core(self, xin, out, dy, rev, n, i_sz, iW, sW, b, peep_t, giW, gsW, gb, gp, need_dx, act, gact):
+        """layers.py:677-697 differentiated: gate inputs of all steps as one GEMM over [x_t | out_{t-1}], the element-wise cell
+        recursion, the reverse scan, then the weight gradients as contractions over all rows."""
         import torch
         L = _lib.lib()
         st = layers._stream
-        T, B, n, i_sz = int(out.shape[0]), int(out.shape[1]), layer.size, layer.insize
-        M, K = T * B, layer.insize + layer.size
-        act, gact = activation.act_id(layer.fun), activation.act_id(layer.gatefun)
+        T, B = int(out.shape[0]), int(out.shape[1])
+        M, K = T * B, i_sz + n
         dev = out.device
-        iW, sW, b = layer.iW.dev(), layer.sW.dev(), layer.b.dev()
-        peep = layer.p.dev().data_ptr() if layer.has_peep else None
+        peep = peep_t.data_ptr() if peep_t is not None else None
         with profiler.region("train_gates", 8.0 * M * n * K, 4.0 * M * (K + 8 * n)):
             xh = torch.empty((M, K), dtype=torch.float32, device=dev)
             _lib.check(L.slk_train_pack_xh_f32(xin.data_ptr(), layers._row_stride(xin), out.data_ptr(), layers._row_stride(out),
                                                xh.data_ptr(), T, B, i_sz, n, int(rev), st()), "pack_xh")
             summed = torch.empty((M, 4 * n), dtype=torch.float32, device=dev)
-            self._gemm(xh.data_ptr(), K, torch.cat([iW, sW], 1).contiguous(), b.data_ptr(), summed.data_ptr(), 4 * n, M, K,
-                       4 * n, 0)
+            self._gemm(xh.data_ptr(), K, torch.cat([iW.reshape(4 * n, i_sz), sW.reshape(4 * n, n)], 1).contiguous(), b.data_ptr(),
+                       summed.data_ptr(), 4 * n, M, K, 4 * n, 0)
             gates = torch.empty((M, 4 * n), dtype=torch.float32, device=dev)
             cell = torch.empty((M, n), dtype=torch.float32, device=dev)
             _lib.check(L.slk_lstm_gates_f32(summed.data_ptr(), peep, gates.data_ptr(), cell.data_ptr(), T, B, n, int(rev),
@@ -586,19 +636,19 @@ class TrainingStep(object):
             raise NotImplementedError("training: no reverse-scan kernel for an Lstm of size %d" % n)
         _lib.check(rc, "lstm_backward")
         with profiler.region("train_wgrad", 8.0 * M * n * K, 4.0 * M * (4 * n + K)):
-            self._tn(dsum.data_ptr(), 4 * n, xh.data_ptr(), K, self._grad_of(layer.iW).data_ptr(), i_sz, M, 4 * n, i_sz,
-                     colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
-            self._tn(dsum.data_ptr(), 4 * n, xh.data_ptr() + 4 * i_sz, K, self._grad_of(layer.sW).data_ptr(), n, M, 4 * n, n)
-            if layer.has_peep:                        # sum of the per-chunk peephole gradients: the column sums of dpeep
+            self._tn(dsum.data_ptr(), 4 * n, xh.data_ptr(), K, giW.data_ptr(), i_sz, M, 4 * n, i_sz,
+                     colsum=gb.data_ptr() if gb is not None else None)
+            self._tn(dsum.data_ptr(), 4 * n, xh.data_ptr() + 4 * i_sz, K, gsW.data_ptr(), n, M, 4 * n, n)
+            if gp is not None:                        # sum of the per-chunk peephole gradients: the column sums of dpeep
                 scratch = torch.empty(3 * n, dtype=torch.float32, device=dev)
                 self._tn(dpeep.data_ptr(), 3 * n, dpeep.data_ptr(), 3 * n, scratch.data_ptr(), 1, B, 3 * n, 1,
-                         colsum=self._grad_of(layer.p).data_ptr())
+                         colsum=gp.data_ptr())
         if not need_dx:
             return None
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
         with profiler.region("train_dx", 8.0 * M * n * i_sz, 4.0 * M * (4 * n + i_sz)):
-            _lib.check(L.slk_gemm_bias_act_f32(dsum.data_ptr(), 4 * n, iW.t().contiguous().data_ptr(), None, dx.data_ptr(), i_sz,
-                                               M, 4 * n, i_sz, 0, st()), "lstm dx")
+            _lib.check(L.slk_gemm_bias_act_f32(dsum.data_ptr(), 4 * n, iW.reshape(4 * n, i_sz).t().contiguous().data_ptr(), None,
+                                               dx.data_ptr(), i_sz, M, 4 * n, i_sz, 0, st()), "lstm dx")
         return dx
 
     def _conv_backward(self, layer, xin, y, dy):

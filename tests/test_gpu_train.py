@@ -113,9 +113,11 @@ def test_nested_serial_in_parallel_vs_oracle():
     _assert_grads_close(step.gradients(), want)
 
 
-@pytest.mark.parametrize("n,bias,peep,T,B", [(32, True, True, 33, 4), (16, False, False, 20, 2), (96, True, True, 25, 3)])
+@pytest.mark.parametrize("n,bias,peep,T,B", [(32, True, True, 33, 4), (16, False, False, 20, 2), (96, True, True, 25, 3),
+                                            (24, True, True, 21, 3), (7, False, True, 12, 2), (80, True, False, 17, 2), (100, True, True, 9, 2)])
 def test_lstm_stack_vs_oracle(n, bias, peep, T, B):
-    """Lstm layers in both directions, with and without biases / peepholes, outside a Parallel (dense outputs)."""
+    """Lstm layers in both directions, with and without biases / peepholes, outside a Parallel (dense outputs); widths
+    without a reverse-scan instantiation (24, 7, 80, 100) run zero-padded to the next one that has (32, 16, 96, 128)."""
     need_gpu()
     from oracle import oracle_train as ot
     from sloika_amd import layers, train
