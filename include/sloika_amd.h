@@ -381,6 +381,14 @@ int slk_act_backward_f32(const float *dy, const float *y, float *out, size_t n, 
 int slk_add_inplace_f32(float *y, const float *x, size_t n, slk_stream_t stream);   /* y += x: dL/dx of Parallel branches */
 int slk_train_im2col_cin1_f32(const float *x, long x_t_stride, long x_b_stride, int T, int B, int winlen, int stride,
                               int pad_lo, int pad_hi, float *cols, slk_stream_t stream);
+/* Any number of input features (a Convolution that is not the first layer, or multi-feature input): x:[T][B][Cin], rows ldx
+ * floats apart; cols[(t*B + b)][c*winlen + k] = x(t*stride + k - pad_lo, b, c), zero outside the signal (the flattened column
+ * order of Convolution.W:[Cout][Cin][winlen], conv.py:66-111), so dL/dW = dpre^T cols and dL/dcols = dpre . W; col2im is the
+ * adjoint (dx(t', b, c) = sum of the dcols entries whose window covers t'), a gather in a fixed order.                     */
+int slk_train_im2col_f32(const float *x, long ldx, int T, int B, int Cin, int winlen, int stride, int pad_lo, int pad_hi,
+                         float *cols, slk_stream_t stream);
+int slk_train_col2im_f32(const float *dcols, int T, int B, int Cin, int winlen, int stride, int pad_lo, int pad_hi, float *dx,
+                         long lddx, slk_stream_t stream);
 int slk_adamski_update_f32(float *param, const float *grad, float *momentum, float *variance, size_t n, float lr_t,
                            float momentum_decay, float decay1, float decay2, float epsilon, float clip, float l2,
                            float gscale, slk_stream_t stream);

@@ -80,6 +80,8 @@ PROTOTYPES = {
     "slk_act_backward_f32": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "slk_add_inplace_f32": (_i, [_vp, _vp, _sz, _vp]),
     "slk_train_im2col_cin1_f32": (_i, [_vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "slk_train_im2col_f32": (_i, [_vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "slk_train_col2im_f32": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _vp]),
     "slk_adamski_update_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "slk_sgd_update_f32": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp]),
 }

@@ -1047,6 +1047,70 @@ extern "C" int slk_train_im2col_cin1_f32(const float *x, long x_t_stride, long x
     return slk_launch_status();
 }
 
+// The same for any number of input features: x:[T][B][Cin] (rows of Cin floats, ldx apart); cols[(t*B + b)][c*winlen + k] =
+// x(t*stride + k - pad_lo, b, c), zero outside the signal -- the column order of Convolution.W:[Cout][Cin][winlen] flattened, so
+// dL/dW = dpre^T cols and dL/dcols = dpre . W.
+__global__ void __launch_bounds__(256) im2col_kernel(const float *__restrict__ x, long ldx, int T, int B, int Cin, int Tout,
+                                                     int winlen, int stride, int pad_lo, float *__restrict__ cols)
+{
+    const int K = Cin * winlen;
+    const size_t total = (size_t)Tout * B * K;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t m = e / K;
+        const int ck = (int)(e - m * K), c = ck / winlen, k = ck - c * winlen;
+        const int t = (int)(m / B), b = (int)(m - (size_t)t * B);
+        const int src = t * stride + k - pad_lo;
+        cols[e] = (src >= 0 && src < T) ? x[((size_t)src * B + b) * ldx + c] : 0.0f;
+    }
+}
+
+// ... and its adjoint: dx(t', b, c) = sum over the windows (t, k) that cover sample t' of dcols[(t*B + b)][c*winlen + k], as a
+// gather in a fixed order (deterministic; at most ceil(winlen / stride) terms)
+__global__ void __launch_bounds__(256) col2im_kernel(const float *__restrict__ dcols, int T, int B, int Cin, int Tout, int winlen,
+                                                     int stride, int pad_lo, float *__restrict__ dx, long lddx)
+{
+    const int K = Cin * winlen;
+    const size_t total = (size_t)T * B * Cin;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e % Cin);
+        const size_t tb = e / Cin;
+        const int b = (int)(tb % B), tp = (int)(tb / B);
+        float acc = 0.0f;
+        for (int k = 0; k < winlen; k++) {
+            const int num = tp + pad_lo - k;
+            if (num < 0) break;                               // larger k only makes it smaller
+            if (num % stride) continue;
+            const int t = num / stride;
+            if (t < Tout) acc += dcols[((size_t)t * B + b) * K + c * winlen + k];
+        }
+        dx[((size_t)tp * B + b) * lddx + c] = acc;
+    }
+}
+
+extern "C" int slk_train_im2col_f32(const float *x, long ldx, int T, int B, int Cin, int winlen, int stride, int pad_lo,
+                                    int pad_hi, float *cols, slk_stream_t stream)
+{
+    if (!x || !cols || T < 1 || B < 1 || Cin < 1 || ldx < Cin || winlen < 1 || stride < 1 || pad_lo < 0 || pad_hi < 0)
+        return SLK_ERR_INVALID_ARG;
+    const int Tout = slk_conv1d_out_len(T, winlen, stride, pad_lo, pad_hi);
+    if (Tout < 1) return SLK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(im2col_kernel, dim3(elementwise_grid((size_t)Tout * B * Cin * winlen)), dim3(256), 0, slk_stream(stream), x,
+                       ldx, T, B, Cin, Tout, winlen, stride, pad_lo, cols);
+    return slk_launch_status();
+}
+
+extern "C" int slk_train_col2im_f32(const float *dcols, int T, int B, int Cin, int winlen, int stride, int pad_lo, int pad_hi,
+                                    float *dx, long lddx, slk_stream_t stream)
+{
+    if (!dcols || !dx || T < 1 || B < 1 || Cin < 1 || lddx < Cin || winlen < 1 || stride < 1 || pad_lo < 0 || pad_hi < 0)
+        return SLK_ERR_INVALID_ARG;
+    const int Tout = slk_conv1d_out_len(T, winlen, stride, pad_lo, pad_hi);
+    if (Tout < 1) return SLK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(col2im_kernel, dim3(elementwise_grid((size_t)T * B * Cin)), dim3(256), 0, slk_stream(stream), dcols, T, B,
+                       Cin, Tout, winlen, stride, pad_lo, dx, lddx);
+    return slk_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // updates.adam ("ADAMski", updates.py:77-87) over flat buffers; lr_t and momentum_decay are this step's scalars
 // (updates.py:73-76, computed on the host in float32 like the reference's shared variables).  `l2` adds the gradient of

@@ -6,11 +6,12 @@ like the Theano function the reference compiles.  Device side: csrc/train.hip (r
 contractions for the weight gradients, softmax cross-entropy, the optimiser) on top of the inference kernels, which
 ARE the forward pass.  There is no CPU fallback.
 
-Supported networks: a Serial that ends in Softmax and is built from Convolution(insize=1) or Window as the first layer, Gru, Lstm,
+Supported networks: a Serial that ends in Softmax and is built from Convolution (any number of input features, anywhere but
+inside a Reverse), Window as the first layer, Gru (up to 144 wide), Lstm (up to 128 wide; odd widths run zero-padded),
 FeedForward, Reverse, Parallel (so `birnn`) and nested Serial -- the raw-signal models models/raw_0.98_rgrgr.py,
 baseline_raw_gru.py, bigger_raw_gru.py, raw_1.00_rGr.py (its 110/142-wide layers run zero-padded) and the event-feature
-models baseline_gru.py / tiny_gru.py / baseline_lstm.py; anything else (multi-feature Convolution, Gru wider than 144) raises NotImplementedError: the reference differentiates any layer through Theano, only the
-raw-signal GRU path is accelerated here.
+models baseline_gru.py / tiny_gru.py / baseline_lstm.py; anything else (wider recurrent layers, other activations) raises
+NotImplementedError: the reference differentiates any layer through Theano, only the raw-signal GRU path is accelerated here.
 
 Data parallel (BASELINE.json configs[4]): with torch.distributed initialised (backend "nccl" = RCCL over xGMI) every
 rank runs the same step on its own chunks, the flat float32 gradient is summed with ONE all-reduce and divided by the
@@ -119,8 +120,8 @@ def _validate(layer, first, rev=False, where="network"):
         for sub in layer.layers:
             _validate(sub, False, rev, where)
     elif isinstance(layer, layers.Convolution):
-        if not first or layer.insize != 1 or rev:
-            raise NotImplementedError("training: Convolution only as the first layer, on one-feature (raw) input, not reversed")
+        if rev:
+            raise NotImplementedError("training: Convolution inside a Reverse is not covered")
         if activation.act_name(layer.fun) not in _FF_ACTS:
             raise NotImplementedError("training: Convolution activation %s has no derivative kernel" % layer.fun.__name__)
     elif isinstance(layer, layers.Window):
@@ -142,7 +143,7 @@ def _validate(layer, first, rev=False, where="network"):
             raise NotImplementedError("training: FeedForward activation %s has no derivative kernel" % layer.fun.__name__)
     else:
         raise NotImplementedError(
-            "training on the GPU path covers Convolution(insize=1) or Window first, Gru, Lstm, FeedForward, Reverse, Parallel, "
+            "training on the GPU path covers Convolution, Window first, Gru, Lstm, FeedForward, Reverse, Parallel, "
             "Serial and a final Softmax; %s (%s) is outside it" % (name, where))
 
 
@@ -402,8 +403,7 @@ class TrainingStep(object):
         if kind == "window":                            # first layer, no parameters: nothing to do
             assert not need_dx
             return None
-        self._conv_backward(layer, xin, y, dy)
-        return None
+        return self._conv_backward(layer, xin, y, dy, need_dx)
 
     def _ff_backward(self, layer, xin, y, dy, need_dx):
         """FeedForward (layers.py:157-158): dpre = dy * fun'(.), dW = dpre^T x, db = dpre^T 1, dx = dpre . W"""
@@ -651,24 +651,43 @@ class TrainingStep(object):
                                                dx.data_ptr(), i_sz, M, 4 * n, i_sz, 0, st()), "lstm dx")
         return dx
 
-    def _conv_backward(self, layer, xin, y, dy):
+    def _conv_backward(self, layer, xin, y, dy, need_dx=False):
+        """Convolution (layers.py:417-419, conv.py:66-111) as window rows times the flattened filter bank: dpre = dy * fun'(.),
+        dW = dpre^T cols, db = dpre^T 1, and for a convolution that is not the first layer dcols = dpre . W folded back onto
+        the input (col2im)."""
         import torch
         L = _lib.lib()
         st = layers._stream
         T, B = int(xin.shape[0]), int(xin.shape[1])
-        To, n = int(y.shape[0]), layer.size
-        M = To * B
+        To, n, cin, w = int(y.shape[0]), layer.size, layer.insize, layer.winlen
+        M, K = To * B, layer.insize * layer.winlen
+        y, dy = y.contiguous(), dy.contiguous()
         dpre = torch.empty_like(y)
         rc = L.slk_act_backward_f32(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), y.numel(), activation.act_id(layer.fun), st())
         if rc == _lib.SLK_ERR_UNSUPPORTED:
             raise NotImplementedError("training: Convolution activation %s has no derivative kernel" % layer.fun.__name__)
         _lib.check(rc, "act_backward")
-        cols = torch.empty((M, layer.winlen), dtype=torch.float32, device=y.device)
+        cols = torch.empty((M, K), dtype=torch.float32, device=y.device)
         xc = xin.contiguous()
-        _lib.check(L.slk_train_im2col_cin1_f32(xc.data_ptr(), B, 1, T, B, layer.winlen, layer.stride, layer.padding[0],
-                                               layer.padding[1], cols.data_ptr(), st()), "im2col")
-        self._tn(dpre.data_ptr(), n, cols.data_ptr(), layer.winlen, self._grad_of(layer.W).data_ptr(), layer.winlen, M, n,
-                 layer.winlen, colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
+        if cin == 1:
+            _lib.check(L.slk_train_im2col_cin1_f32(xc.data_ptr(), B, 1, T, B, w, layer.stride, layer.padding[0], layer.padding[1],
+                                                   cols.data_ptr(), st()), "im2col")
+        else:
+            _lib.check(L.slk_train_im2col_f32(xc.data_ptr(), cin, T, B, cin, w, layer.stride, layer.padding[0], layer.padding[1],
+                                              cols.data_ptr(), st()), "im2col")
+        with profiler.region("train_wgrad", 2.0 * M * n * K, 4.0 * M * (n + K)):
+            self._tn(dpre.data_ptr(), n, cols.data_ptr(), K, self._grad_of(layer.W).data_ptr(), K, M, n, K,
+                     colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
+        if not need_dx:
+            return None
+        dcols = cols                                                        # reuse: the window rows are not needed again
+        dx = torch.empty((T, B, cin), dtype=torch.float32, device=y.device)
+        with profiler.region("train_dx", 2.0 * M * n * K, 4.0 * M * (n + K)):
+            _lib.check(L.slk_gemm_bias_act_f32(dpre.data_ptr(), n, layer.W.dev().reshape(n, K).t().contiguous().data_ptr(), None,
+                                               dcols.data_ptr(), K, M, n, K, 0, st()), "conv dcols")
+            _lib.check(L.slk_train_col2im_f32(dcols.data_ptr(), T, B, cin, w, layer.stride, layer.padding[0], layer.padding[1],
+                                              dx.data_ptr(), cin, st()), "col2im")
+        return dx
 
     def update(self, rate):
         """One optimiser step on the gradient left by forward_backward (updates.py:36-89, or :9-33 for sgd)."""
