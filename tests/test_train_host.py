@@ -28,10 +28,13 @@ def test_supported_architectures():
     g = layers.Gru(4, 16)
     body, _ = train._plan(layers.Serial([layers.Reverse(layers.Reverse(g)), layers.Softmax(16, 5)]))
     assert train._unwrap(body[0]) == (g, False)
+    for good in (layers.Serial([layers.Lstm(4, 8), layers.Softmax(8, 5)]),            # Lstm of 8: zero-padded to 16
+                 layers.Serial([layers.Convolution(4, 8, 3), layers.Softmax(8, 5)]),   # multi-feature convolution
+                 layers.Serial([layers.FeedForward(4, 1), layers.Convolution(1, 8, 3), layers.Softmax(8, 5)])):   # conv not first
+        train._plan(good)
     for bad in (layers.Serial([g]),                                                      # no softmax
-                layers.Serial([layers.Lstm(4, 8), layers.Softmax(8, 5)]),             # no Lstm reverse-scan kernel for 8
-                layers.Serial([layers.Convolution(4, 8, 3), layers.Softmax(8, 5)]),    # multi-feature convolution
-                layers.Serial([layers.FeedForward(4, 1), layers.Convolution(1, 8, 3), layers.Softmax(8, 5)]),   # conv not first
+                layers.Serial([layers.Lstm(4, 130), layers.Softmax(130, 5)]),         # wider than the widest Lstm reverse scan
+                layers.Serial([layers.Reverse(layers.Convolution(1, 8, 3)), layers.Softmax(8, 5)]),    # reversed convolution
                 layers.Serial([layers.Gru(4, 150), layers.Softmax(150, 5)]),          # wider than the widest kernel
                 layers.Serial([layers.Convolution(1, 8, 3), layers.Window(8, 3), layers.Softmax(24, 5)])):   # Window not first
         with pytest.raises(NotImplementedError):
