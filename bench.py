@@ -169,6 +169,15 @@ def main_train(args):
         dt = float(tmax.item())
     stages = rec.summary() if rec is not None else {}
     roofline = None
+    # HBM bytes per step of every stage from the committed PMC passes of this same workload (tools/collect_pmc.sh --train)
+    stage_traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_train.json")) as fh:
+            pmc = json.load(fh)
+        if pmc.get("workload") == [args.model, args.batch, args.chunk_len]:
+            stage_traffic = pmc.get("stage_bytes_per_step", {})
+    except (OSError, ValueError):
+        pass
     if stages:
         dom = max(stages, key=lambda k: stages[k]["ms_total"])
         d = stages[dom]
@@ -176,8 +185,10 @@ def main_train(args):
         f16 = d.get("f16x3_flops", 0.0) / d["calls"]
         t_min = (flops - f16) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + 3.0 * f16 / (F16_MFMA_PEAK_TFLOPS * 1e12)
         ach = flops / (d["ms_avg"] * 1e-3) / 1e12
+        per_launch = stage_traffic[dom] * args.steps / d["calls"] if dom in stage_traffic else None
         roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": flops / t_min / 1e12, "unit": "TFLOP/s",
-                    "frac": ach / (flops / t_min / 1e12), "traffic": None, "ms_per_launch": d["ms_avg"], "launches": d["calls"]}
+                    "frac": ach / (flops / t_min / 1e12), "traffic": per_launch, "ms_per_launch": d["ms_avg"],
+                    "launches": d["calls"]}
     if rank == 0:
         print(json.dumps({
             "metric": "raw-signal samples/sec trained", "value": world * B * L * args.steps / dt, "unit": "samples/s",
@@ -192,7 +203,8 @@ def main_train(args):
             "roofline": roofline,
             "cpu_baseline": cpu_baseline_train(args.model, L) if (world == 1 and args.cpu_chunks > 0) else None,
             "final_loss": loss,
-            "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())}}))
+            "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())},
+            "stages_hbm_bytes_per_step": {k: stage_traffic[k] for k in sorted(stages) if k in stage_traffic} or None}))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -41,9 +41,37 @@ def stage_file(summary_path, workload):
                "tools/collect_pmc.sh; FETCH doubled per the gfx950 correction)", "stage_bytes_per_launch": out}, sys.stdout, indent=1)
 
 
+TRAIN_STAGES = {      # bench.py --train stage -> substrings of the kernels it launches
+    "gru_fused": ("gru_bar16_kernel", "gru_fused16_kernel", "gru_fused_kernel"),
+    "softmax_gemm": ("gemm_rows_f16x3_kernel", "gemm_rows_kernel"),
+    "conv1d": ("conv1d_",),
+    "train_xent": ("softmax_xent_grad_kernel", "reduce_sum_kernel"),
+    "train_gru_scan": ("gru_backward_",),
+    "train_wgrad": ("gemm_tn_", "tn_reduce_kernel", "im2col_"),
+    "train_dx": ("gemm_bias_act_kernel", "act_backward_kernel"),
+}
+
+
+def train_stage_file(summary_path, workload, steps_sampled=3):
+    """profiles/pmc_traffic_train.json: HBM bytes per STEP of every training stage (launches per step x bytes per launch,
+    summed over the stage's kernels; tools/collect_pmc.sh --train samples `steps_sampled` steps)."""
+    d = json.load(open(summary_path))
+    out, launches = {}, {}
+    for stage, keys in TRAIN_STAGES.items():
+        ks = [v for k, v in d["kernels"].items() if any(s in k for s in keys)]
+        if ks:
+            out[stage] = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] / steps_sampled for v in ks)
+            launches[stage] = sum(v["launches_sampled"] / steps_sampled for v in ks)
+    json.dump({"workload": workload, "source": summary_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+               "tools/collect_pmc.sh --train; FETCH doubled per the gfx950 correction)", "stage_bytes_per_step": out,
+               "kernel_launches_per_step": launches}, sys.stdout, indent=1)
+
+
 def main():
     if sys.argv[1] == "--stages":
         return stage_file(sys.argv[2], ["raw_0.98_rgrgr", 1024, 4000])
+    if sys.argv[1] == "--train-stages":
+        return train_stage_file(sys.argv[2], ["raw_0.98_rgrgr", 1024, 4000])
     fetch, write = load(sys.argv[1]), load(sys.argv[2])
     res = {}
     for k in sorted(set(fetch) | set(write)):
