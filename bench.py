@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--exact-steps", type=int, default=5,
                     help="steps of the all-fp32 arithmetic (SLOIKA_AMD_EXACT_F32=1) timed after the main region for the "
                          "`exact_f32` entry of the line (0 = skip)")
+    ap.add_argument("--overlap-steps", type=int, default=10,
+                    help="steps timed after the main region with TWO batches in flight on two streams, for the `two_in_flight` "
+                         "entry of the line (0 = skip); the main region and `value` always use --streams (default 1)")
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (BASELINE.json configs[4]: forward + backward + ADAMski, "
                          "gradient all-reduce over RCCL when --gpus > 1); prints the same kind of JSON line")
@@ -247,9 +250,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
     net = models.randomise_zero_layers(models.build_model(args.model, klen=5, sd=0.5, seed=11))
     nstream = max(1, args.streams)
-    bcs = [pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0) for _ in range(nstream)]
+    nslot = max(nstream, 2 if (args.overlap_steps > 0 and nstream == 1) else 1)     # the two_in_flight leg needs a second slot
+    bcs = [pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0) for _ in range(nslot)]
     bc = bcs[0]
-    streams = [torch.cuda.Stream() for _ in range(nstream)] if nstream > 1 else [torch.cuda.current_stream()]
+    streams = ([torch.cuda.Stream() for _ in range(nslot)] if nstream > 1
+               else [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nslot - 1)])
     B, L = args.batch, args.chunk_len
     # a few distinct batches so that steps do not all hit the same cache lines
     nbuf = 2
@@ -257,23 +262,23 @@ def main():
             for i in range(nbuf)]
     dev = [torch.from_numpy(h).cuda() for h in host]
     tout = bc.network.layers[0].out_len(L) if hasattr(bc.network.layers[0], "out_len") else L
-    out_host = [torch.empty((B, tout), dtype=torch.int32).pin_memory() for _ in range(nstream)]
+    out_host = [torch.empty((B, tout), dtype=torch.int32).pin_memory() for _ in range(nslot)]
     klen = 5
     if args.with_bases:
-        bases_dev = [torch.empty((B, klen * tout), dtype=torch.uint8, device="cuda") for _ in range(nstream)]
-        nbases_dev = [torch.empty((B,), dtype=torch.int32, device="cuda") for _ in range(nstream)]
-        bases_host = [torch.empty((B, klen * tout), dtype=torch.uint8).pin_memory() for _ in range(nstream)]
-        nbases_host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(nstream)]
+        bases_dev = [torch.empty((B, klen * tout), dtype=torch.uint8, device="cuda") for _ in range(nslot)]
+        nbases_dev = [torch.empty((B,), dtype=torch.int32, device="cuda") for _ in range(nslot)]
+        bases_host = [torch.empty((B, klen * tout), dtype=torch.uint8).pin_memory() for _ in range(nslot)]
+        nbases_host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(nslot)]
         acgt = int.from_bytes(b"ACGT".ljust(8, b"\0"), "little")
 
     # The results leave for the host on a copy stream of their own: the next step's kernels do not queue behind a PCIe
     # transfer.  `paths` is a fresh tensor every step (record_stream keeps the allocator from reusing it before the copy
     # has run); the persistent base buffers are protected by the copy's event.
     copy_stream = torch.cuda.Stream()
-    copied = [None] * nstream
+    copied = [None] * nslot
 
-    def step(i):
-        k = i % nstream
+    def step(i, nact=nstream):
+        k = i % nact
         with torch.cuda.stream(streams[k]):
             scores, paths, lens = bcs[k].call_chunks(dev[i % nbuf])
             paths.record_stream(copy_stream)
@@ -343,6 +348,24 @@ def main():
         finally:
             _layers.SPLIT_F16, _layers.Softmax.split_f16 = keep
 
+    # the same workload with two batches in flight (two streams): batch i decodes while batch i+1 runs its recurrent layers
+    overlap = None
+    if args.overlap_steps > 0 and nstream == 1:
+        for i in range(4):                    # the second slot allocates its buffers on first use
+            step(i, 2)
+        barrier()
+        t2 = time.perf_counter()
+        for i in range(args.overlap_steps):
+            step(i, 2)
+        barrier()
+        dto = time.perf_counter() - t2
+        if dist is not None:
+            tm = torch.tensor([dto], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dto = float(tm.item())
+        overlap = {"ms_per_step": dto / args.overlap_steps * 1e3, "value": world * B * L * args.overlap_steps / dto,
+                   "unit": "samples/s", "steps": args.overlap_steps, "streams_per_gpu": 2}
+
     stages = rec.summary() if rec is not None else {}
     roofline = None
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/collect_pmc.sh);
@@ -401,6 +424,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "exact_f32": exact,
+            "two_in_flight": overlap,
             "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())},
             "e2e_algorithmic_tflops": (gemm_flops / (dt / args.steps) / 1e12) if stages else None,
         }
