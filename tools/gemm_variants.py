@@ -10,17 +10,18 @@ hi = torch.empty(N, K, dtype=torch.float16, device="cuda"); lo = torch.empty_lik
 y = torch.empty(M, ld, device="cuda"); stats = torch.empty(M, 2, device="cuda")
 vp, i_, l_ = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 res = {}
-for v in (0, 1):
+NV = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+for v in range(NV):
     sp = getattr(lib, "slk_sp_v%d" % v); sp.argtypes = [vp, i_, i_, vp, vp, vp, vp]; sp.restype = i_
     assert sp(W.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), st) == 0
     f = getattr(lib, "slk_lr_v%d" % v); f.argtypes = [vp, l_, vp, vp, vp, vp, vp, l_, l_, i_, i_, vp, vp]; f.restype = i_
     res[v] = (f, [])
 def run(f): assert f(x.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), b.data_ptr(), y.data_ptr(), ld, M, K, N, stats.data_ptr(), st) == 0
-for v in (0, 1): run(res[v][0])
+for v in range(NV): run(res[v][0])
 torch.cuda.synchronize()
 for rnd in range(6):
-    for v in (0, 1):
+    for v in range(NV):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); [run(res[v][0]) for _ in range(5)]; e1.record(); torch.cuda.synchronize(); res[v][1].append(e0.elapsed_time(e1) / 5)
-for v in (0, 1):
-    print("v%d (%s): median %.3f ms  min %.3f ms" % (v, "through LDS" if v else "direct", float(np.median(res[v][1])), min(res[v][1])))
+for v in range(NV):
+    print("v%d: median %.3f ms  min %.3f ms" % (v, float(np.median(res[v][1])), min(res[v][1])))
