@@ -19,6 +19,7 @@
 // MFMA A-operand reads without conflicts.  Exact fp32 (v_mfma_f32_4x4x1_16b_f32).
 #include <limits.h>
 
+#include "f16split.h"
 #include "lds_flags.h"
 #include "mfma4.h"
 
@@ -62,7 +63,6 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                                                            float *__restrict__ zr_out)
 {
     static_assert(I % 16 == 0 && N % 16 == 0 && N <= 128, "unsupported size for the fused GRU kernel");
-    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     // ---------------- recurrent role constants (as in gru_mfma_kernel) ----------------
     constexpr int NW = N / 4;
     constexpr int SA = (2 * NW <= 16) ? 4 : ((2 * NW <= 32) ? 2 : 1);
@@ -306,21 +306,35 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
         constexpr bool LAST_MAYBE = (NT16 % 4) != 0;        // the last tile slot exists only for some waves
         const bool last_ok = pw + 4 * (NTW - 1) < NT16;
         // B operands: lane holds vI row 16*t + col, k = 32*kb + 8*kq + 0..7, as fp16 hi and lo parts
+        // (every row scaled by a power of two to a maximum in [1, 2) before the split, as in gru_fused16.hip: any finite float32
+        // weight is then inside fp16 range; the lane that holds a row is the lane that stores it and undoes the scale)
         half8 whi[NTW][KBLK], wlo[NTW][KBLK];
+        float inv_w[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
             const bool ok = (i < NTW - 1) || !LAST_MAYBE || last_ok;
             const int row = ok ? 16 * (pw + 4 * i) + col : 0;
+            float u[KBLK][8];
+            float m = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < KBLK; kb++) {
                 const int k0 = 32 * kb + 8 * kq;
                 const bool kok = ok && (I % 32 == 0 || k0 < I);
                 const float *src = iW + (size_t)row * I + (kok ? k0 : 0);
                 const float4 u0 = *reinterpret_cast<const float4 *>(src), u1 = *reinterpret_cast<const float4 *>(src + 4);
-                const float u[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+                const float t[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float v = kok ? u[j] : 0.0f;
+                    u[kb][j] = kok ? t[j] : 0.0f;
+                    m = fmaxf(m, fabsf(u[kb][j]));
+                }
+            }
+            const float ws = pow2_scale(kgroup_max(m), inv_w[i]);
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float v = u[kb][j] * ws;
                     const _Float16 h = (_Float16)v;
                     whi[i][kb][j] = h;
                     wlo[i][kb][j] = (_Float16)(v - (float)h);
@@ -403,11 +417,26 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
             // ---- per K block: the group's A operands (x split into halves on the fly), then every tile's three MFMAs ----
             f32x4 acc[NTW];
 #pragma unroll
-            for (int i = 0; i < NTW; i++) {
-                const float tb = bias_lds[(i < NTW - 1 || !LAST_MAYBE || last_ok) ? 16 * (pw + 4 * i) + col : 0];
-                acc[i] = f32x4{tb, tb, tb, tb};
-            }
+            for (int i = 0; i < NTW; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             const float *img = xbuf + ((q >> 1) & 1) * (KB * XIMG) + (GS * (q & 1) + a_step) * XIMG + 4 * a_chunk;
+            // each row of x is scaled by a power of two so that its largest |x| lies in [1, 2) (exact, undone on the
+            // accumulators): the first layer's input is an unbounded elu convolution output
+            float amax = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+                const int k0 = 32 * kb + 8 * kq;
+                const bool kok = (I % 32 == 0) || k0 < I;
+                const float *src = img + 4 * (kok ? k0 : 0);
+                const f32x4 u0 = *reinterpret_cast<const f32x4 *>(src), u1 = *reinterpret_cast<const f32x4 *>(src + 16);
+#pragma unroll
+                for (int j = 0; j < 4; j++) amax = fmaxf(amax, kok ? fmaxf(fabsf(u0[j]), fabsf(u1[j])) : 0.0f);
+            }
+            float xinv;
+            const float xs = pow2_scale(kgroup_max(amax), xinv);
+            // the accumulator rows of this lane are (step kq, chunk 0..3): their inverse scales sit in lanes 4*kq + (0..3)
+            f32x4 inv;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) inv[r4] = __shfl(xinv, 4 * kq + r4);
 #pragma unroll
             for (int kb = 0; kb < KBLK; kb++) {
                 const int k0 = 32 * kb + 8 * kq;
@@ -417,7 +446,7 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
                 half8 ahi, alo;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float v = kok ? (j < 4 ? u0[j & 3] : u1[j & 3]) : 0.0f;
+                    const float v = kok ? (j < 4 ? u0[j & 3] : u1[j & 3]) * xs : 0.0f;
                     const _Float16 h = (_Float16)v;
                     ahi[j] = h;
                     alo[j] = (_Float16)(v - (float)h);
@@ -426,12 +455,18 @@ __global__ void __launch_bounds__(512, 2) gru_fused_kernel(const float *__restri
 #pragma unroll
                     for (int i = 0; i < NTW; i++) {
                         if (i < NTW - 1 || !LAST_MAYBE || last_ok) {
-                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, whi[i][kb], acc[i], 0, 0, 0);
                             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wlo[i][kb], acc[i], 0, 0, 0);
                             acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, whi[i][kb], acc[i], 0, 0, 0);
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, whi[i][kb], acc[i], 0, 0, 0);
                         }
                     }
                 }
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; i++) {
+                const float tb = bias_lds[(i < NTW - 1 || !LAST_MAYBE || last_ok) ? 16 * (pw + 4 * i) + col : 0];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; r4++) acc[i][r4] = fmaf(acc[i][r4] * inv[r4], inv_w[i], tb);
             }
             // the group's ring slots were last read by phase A of steps GS*q - R ... GS*q + GS-1 - R
             if (GS * q + GS > R) wait_flags(0, GS * q + GS - R);
@@ -522,7 +557,9 @@ static int gru_fused_entry(const float *x, long ldx, const float *iW, const floa
     if (insize == II && n == NN) return launch_fused<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, s);
     // only shapes whose two roles fit 256 VGPRs without spilling are instantiated (e.g. 128->112 / 144->112 spill
     // > 1 KB per lane and run far slower than the two-kernel path)
-    FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(128, 96) FUSED(16, 16) FUSED(48, 32) FUSED(64, 96) FUSED(16, 64)
+    // (128 -> 96 left this list when the projection gained its row scaling: four K blocks no longer fit 256 registers without
+    // spills; that shape takes the projection GEMM + recurrence kernel in this arithmetic, and gru_bar16 by default)
+    FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(16, 16) FUSED(48, 32) FUSED(64, 96) FUSED(16, 64)
 #undef FUSED
     return SLK_ERR_UNSUPPORTED;
 }
@@ -557,7 +594,9 @@ extern "C" int slk_gru_fused_train_f32(const float *x, long ldx, const float *iW
     hipStream_t s = slk_stream(stream);
 #define FUSED(II, NN) \
     if (insize == II && n == NN) return launch_fused_train<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, zr_out, T, B, reverse, s);
-    FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(128, 96) FUSED(16, 16) FUSED(48, 32) FUSED(64, 96) FUSED(16, 64)
+    // (128 -> 96 left this list when the projection gained its row scaling: four K blocks no longer fit 256 registers without
+    // spills; that shape takes the projection GEMM + recurrence kernel in this arithmetic, and gru_bar16 by default)
+    FUSED(96, 96) FUSED(64, 64) FUSED(32, 96) FUSED(16, 16) FUSED(48, 32) FUSED(64, 96) FUSED(16, 64)
 #undef FUSED
     return SLK_ERR_UNSUPPORTED;
 }

@@ -147,7 +147,7 @@ def test_layer_input_validation():
         g.run(torch.zeros((5, 2, 4)))                          # not on the device
 
 
-@pytest.mark.parametrize("I,n", [(96, 96), (64, 64), (32, 96), (128, 96), (64, 96), (16, 16), (48, 32), (16, 64)])
+@pytest.mark.parametrize("I,n", [(96, 96), (64, 64), (32, 96), (64, 96), (16, 16), (48, 32), (16, 64)])
 @pytest.mark.parametrize("T,B,reverse", [(23, 9, False), (8, 4, True), (3, 2, False), (1, 1, True), (41, 5, True)])
 def test_gru_fused_layer_kernel(oracle, I, n, T, B, reverse):
     """Projection + recurrence in one persistent kernel (csrc/gru_fused.hip) vs the oracle."""
