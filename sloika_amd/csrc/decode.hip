@@ -44,6 +44,32 @@ __device__ __forceinline__ float log_logit_val(float l, float2 st, float min_pro
     return fast_logf(__fadd_rn(prepare_post_val(p, min_prob, one_m), VIT_ETA));
 }
 
+// The same transforms on TWO values at a time: element-wise vector arithmetic compiles to v_pk_mul_f32 / v_pk_add_f32 (one
+// instruction for both lanes of the pair, each component rounded exactly like the scalar instruction; no contraction:
+// -ffp-contract=off), only exp and log stay scalar.  Bit-identical to log_post_val / log_logit_val by construction; the
+// decoder's vector work per state drops by a fifth.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fast_logf2(f32x2 x)
+{
+    const f32x2 l = {__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
+    return l * 0.6931471805599453f;
+}
+__device__ __forceinline__ f32x2 prepare_post_val2(f32x2 p, float min_prob, float one_m) { return min_prob + one_m * p; }
+__device__ __forceinline__ f32x2 log_post_val2(f32x2 p, int mode, float min_prob, float one_m)
+{
+    if (mode == SLK_POST_LOG) return p;
+    if (mode == SLK_POST_LN) return fast_logf2(p);
+    if (mode == SLK_POST_RAW) p = prepare_post_val2(p, min_prob, one_m);
+    return fast_logf2(p + VIT_ETA);
+}
+__device__ __forceinline__ f32x2 log_logit_val2(f32x2 l, float2 st, float min_prob, float one_m)
+{
+    const f32x2 a = (l - st.x) * 1.4426950408889634f;              // __expf(y) = v_exp_f32(y * log2 e)
+    const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f32x2 p = e * st.y;
+    return fast_logf2(prepare_post_val2(p, min_prob, one_m) + VIT_ETA);
+}
+
 __global__ void log_post_kernel(const float *__restrict__ post, float *__restrict__ lpost, size_t count, int mode,
                                 float min_prob, float one_m)
 {
@@ -290,6 +316,9 @@ __global__ void __launch_bounds__(1024) viterbi_forward4_kernel(const float *__r
     auto xform = [&](float val, float2 st) {
         return LOGITS ? log_logit_val(val, st, min_prob, one_m) : log_post_val(val, mode, min_prob, one_m);
     };
+    auto xform2 = [&](f32x2 val, float2 st) {
+        return LOGITS ? log_logit_val2(val, st, min_prob, one_m) : log_post_val2(val, mode, min_prob, one_m);
+    };
     auto load_row = [&](int t) { return *reinterpret_cast<const unaligned_f4 *>(pb + (size_t)t * tstride + 1 + 4 * jj); };
     auto row_stats = [&](int t) { return LOGITS ? stats[(size_t)t * B + b] : make_float2(0.f, 1.f); };
     // blank column of step t0 + j (one step per thread)
@@ -311,6 +340,8 @@ __global__ void __launch_bounds__(1024) viterbi_forward4_kernel(const float *__r
     if (T > nt) load_blank(nt, blank_raw, blank_st);           // next block, converted when it starts
     // Two row buffers that swap roles statically (time loop unrolled by two): copying a just-requested row into the
     // "current" registers would make every step wait for that request.  During step t `use` holds row t, `fill` gets t+1.
+    // (requesting rows two steps ahead with a third buffer was measured: 1.064 against 1.041 ms -- memory latency is not what
+    // the step waits for)
     unaligned_f4 rowA = raw, rowB = raw;
     float2 stA = rst, stB = rst;
     if (T > 1) { rowA = load_row(1); stA = row_stats(1); }
@@ -346,7 +377,7 @@ __global__ void __launch_bounds__(1024) viterbi_forward4_kernel(const float *__r
         }
         const float4 own = *reinterpret_cast<const float4 *>(&vold[4 * jj]);
         const float lp0 = lp0buf[tl];
-        const float lp[4] = {xform(raw.x, rst), xform(raw.y, rst), xform(raw.z, rst), xform(raw.w, rst)};
+        const f32x2 lp01 = xform2(f32x2{raw.x, raw.y}, rst), lp23 = xform2(f32x2{raw.z, raw.w}, rst);
         // quad exchange: lane ^ 1, then lane ^ 2 (first maximum in ab order wins, decode.py:72-73)
 #pragma unroll
         for (int r = 0; r < 2; r++) {
@@ -364,16 +395,16 @@ __global__ void __launch_bounds__(1024) viterbi_forward4_kernel(const float *__r
         const float mx = fmaxf(sstep, sskip);
         const int code = sstep > sskip ? sarg : NB + karg;          // decode.py:76 (tie -> skip)
         if (active) {
-            const float ownv[4] = {own.x, own.y, own.z, own.w};
+            const f32x2 nv01 = lp01 + mx, nv23 = lp23 + mx;         // decode.py:75
+            const f32x2 st01 = f32x2{own.x, own.y} + lp0, st23 = f32x2{own.z, own.w} + lp0;     // decode.py:80
+            const float nvv[4] = {nv01.x, nv01.y, nv23.x, nv23.y}, stv[4] = {st01.x, st01.y, st23.x, st23.y};
             float nw[4];
             uint32_t packed = 0;
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
-                const float nv = lp[cc] + mx;                       // decode.py:75
-                const float stay = ownv[cc] + lp0;                  // decode.py:80
-                const bool move = nv > stay;                        // decode.py:81 (tie -> stay)
+                const bool move = nvv[cc] > stv[cc];                // decode.py:81 (tie -> stay)
                 packed |= (uint32_t)(move ? code : VIT_STAY) << (8 * cc);
-                nw[cc] = move ? nv : stay;
+                nw[cc] = move ? nvv[cc] : stv[cc];
             }
             *reinterpret_cast<float4 *>(&vnew[4 * jj]) = make_float4(nw[0], nw[1], nw[2], nw[3]);
             tbs[(t % VIT_TBS) * nrem1 + jj] = packed;
