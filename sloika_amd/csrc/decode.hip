@@ -10,9 +10,11 @@
 // in two levels (step maxima first), which preserves numpy's first-maximum tie-breaking because the combined
 // key (value desc, a*nbase+b asc) is what np.argmax over the reshaped (nbase^2, nkmer/nbase^2) view selects.
 // Float arithmetic is max / add / sub in float32 only (no contraction possible), so scores are bit-identical
-// to numpy's given the same log-posteriors.  The traceback is stored as ONE BYTE per (t, state):
-//   0..nbase-1 = step from a, nbase..nbase+nbase^2-1 = skip from ab, 255 = stay    (reference: int32 from-state)
-// and walked by a second kernel that stages 64 KB time-blocks of it in LDS.
+// to numpy's given the same log-posteriors.  The traceback (reference: an int32 from-state per (t, state)) is stored as ONE BYTE
+// per (t, state) by the generic and the one-wave kernels:
+//   0..nbase-1 = step from a, nbase..nbase+nbase^2-1 = skip from ab, 255 = stay
+// and as ONE 16-BIT WORD per (t, four states) by viterbi_forward4_kernel (see there), and walked by a second kernel that stages
+// time-blocks of it in LDS.
 #include "common.h"
 
 #define VIT_ETA 1e-10f
@@ -304,14 +306,17 @@ __global__ void __launch_bounds__(1024) viterbi_forward4_kernel(const float *__r
     float *lp0buf = sm + 2 * nkmer;                            // [nt] blank log-posteriors of the current block of steps
     float *redv = lp0buf + nt;                                 // [16]
     int *redi = reinterpret_cast<int *>(redv + 16);            // [16]
-    // traceback codes of VIT_TBS steps are staged in LDS as an image of the global layout and copied out with 16-byte
-    // stores: a store every step would make the loop-top wait for the prefetched row (vmcnt) also wait for that store
-    uint32_t *tbs = reinterpret_cast<uint32_t *>(redi + 16);   // [VIT_TBS][nrem1] words
+    // Traceback, PACKED: the four to-states of a thread share their step predecessor a and the sixteen of a quad their skip
+    // predecessor (a, b), so a thread's step is 14 bits -- 2 bits per state (0 stay, 1 step, 2 skip), a in bits 8-9, a*4+b in
+    // bits 10-13 -- one 16-bit word instead of four bytes: half the traceback traffic of a kernel that is HBM bound.
+    // VIT_TBS steps are staged in LDS as an image of the global layout and copied out with 16-byte stores: a store every step
+    // would make the loop-top wait for the prefetched row (vmcnt) also wait for that store
+    uint16_t *tbs = reinterpret_cast<uint16_t *>(redi + 16);   // [VIT_TBS][nrem1] half words
     const bool active = j < nrem1;
     const int jj = active ? j : 0, q = jj >> 2, c = jj & 3;
     const float *pb = post + (size_t)b * ld;                   // rows (t, b) are `ld` floats apart (ld >= nkmer + 1)
     const size_t tstride = (size_t)B * ld;
-    uint8_t *tbb = tb + (size_t)b * Tpad * nkmer;
+    uint8_t *tbb = tb + (size_t)b * Tpad * (nkmer / 2);         // 2 bytes per thread (4 states) and step
 
     auto xform = [&](float val, float2 st) {
         return LOGITS ? log_logit_val(val, st, min_prob, one_m) : log_post_val(val, mode, min_prob, one_m);
@@ -393,31 +398,31 @@ __global__ void __launch_bounds__(1024) viterbi_forward4_kernel(const float *__r
         }
         const float sskip = kbest - skip_pen;                       // decode.py:72
         const float mx = fmaxf(sstep, sskip);
-        const int code = sstep > sskip ? sarg : NB + karg;          // decode.py:76 (tie -> skip)
+        const uint32_t how = sstep > sskip ? 1u : 2u;               // decode.py:76 (tie -> skip)
         if (active) {
             const f32x2 nv01 = lp01 + mx, nv23 = lp23 + mx;         // decode.py:75
             const f32x2 st01 = f32x2{own.x, own.y} + lp0, st23 = f32x2{own.z, own.w} + lp0;     // decode.py:80
             const float nvv[4] = {nv01.x, nv01.y, nv23.x, nv23.y}, stv[4] = {st01.x, st01.y, st23.x, st23.y};
             float nw[4];
-            uint32_t packed = 0;
+            uint32_t packed = ((uint32_t)sarg << 8) | ((uint32_t)karg << 10);
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
                 const bool move = nvv[cc] > stv[cc];                // decode.py:81 (tie -> stay)
-                packed |= (uint32_t)(move ? code : VIT_STAY) << (8 * cc);
+                packed |= (move ? how : 0u) << (2 * cc);
                 nw[cc] = move ? nvv[cc] : stv[cc];
             }
             *reinterpret_cast<float4 *>(&vnew[4 * jj]) = make_float4(nw[0], nw[1], nw[2], nw[3]);
-            tbs[(t % VIT_TBS) * nrem1 + jj] = packed;
+            tbs[(t % VIT_TBS) * nrem1 + jj] = (uint16_t)packed;
         }
         __syncthreads();
         if ((t % VIT_TBS) == VIT_TBS - 1 || t == T - 1) {
             // rows t0..t of the traceback are complete in LDS (t0 = first step of this block, >= 1)
             const int t0 = t - (t % VIT_TBS);
             const int first = t0 < 1 ? 1 : t0;
-            const int nwords = (t - first + 1) * nrem1;
-            const uint32_t *src = tbs + (first - t0) * nrem1;
-            uint32_t *dst = reinterpret_cast<uint32_t *>(tbb + (size_t)first * nkmer);
-            if ((nrem1 & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+            const int nwords = (t - first + 1) * (nrem1 / 2);         // 32-bit words (nrem1 is a multiple of 16 here)
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(tbs + (first - t0) * nrem1);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(tbb + (size_t)first * (nkmer / 2));
+            if ((nrem1 & 7) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
                 for (int k = j; k < nwords / 4; k += nt)
                     reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
             } else {
@@ -655,12 +660,14 @@ __global__ void __launch_bounds__(256) viterbi_forward4_wave_kernel(const float 
 // ------------------------------------------------------------------------------------------------------
 #define VBT_RING 3
 #define VBT_BLOCK 12288            /* bytes; a multiple of 3 KiB (three stager waves) and of every 4^k k-mer count <= 4096 */
-template <int NB>
+// PACKED: the traceback of viterbi_forward4_kernel (one 16-bit word per four states and step) instead of a byte per state
+template <int NB, bool PACKED>
 __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *__restrict__ tb,
                                                                 const int32_t *__restrict__ best, int T, int nkmer,
                                                                 int tblk, int dma, int32_t *__restrict__ path_out,
                                                                 int32_t *__restrict__ len_out, const int *__restrict__ lens)
 {
+    const int rowbytes = PACKED ? nkmer / 2 : nkmer;
     constexpr int NB2 = NB * NB;
     constexpr int PER_WAVE = VBT_BLOCK / 1024 / 3;
     const int Tpad = T;                                        // row strides of tb / path_out; T = this chunk's own length
@@ -670,7 +677,7 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nrem1 = nkmer / NB, nrem2 = nkmer / NB2;
-    const uint8_t *tbb = tb + (size_t)b * Tpad * nkmer;
+    const uint8_t *tbb = tb + (size_t)b * Tpad * rowbytes;
     int32_t *path = path_out + (size_t)b * Tpad;
     if (tid == 0) {
         sh_cur = best[b];
@@ -689,10 +696,20 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
         // dependent chain to the scalar unit
         int cur = __builtin_amdgcn_readfirstlane(sh_cur), pos = __builtin_amdgcn_readfirstlane(sh_pos);
         for (int t = t1 - 1; t >= t0; t--) {
-            const int code = __builtin_amdgcn_readfirstlane((int)rows[(t - t0) * nkmer + cur]);
-            if (code != VIT_STAY) {
-                cur = code < NB ? code * nrem1 + cur / NB : (code - NB) * nrem2 + cur / NB2;
-                path[--pos] = cur;                             // decode.py:88-90
+            if constexpr (PACKED) {
+                const int w = __builtin_amdgcn_readfirstlane(
+                    (int)reinterpret_cast<const uint16_t *>(rows)[(t - t0) * (nkmer / 4) + (cur >> 2)]);
+                const int how = (w >> (2 * (cur & 3))) & 3;        // 0 stay, 1 step, 2 skip
+                if (how) {
+                    cur = how == 1 ? ((w >> 8) & 3) * nrem1 + cur / NB : ((w >> 10) & 15) * nrem2 + cur / NB2;
+                    path[--pos] = cur;                         // decode.py:88-90
+                }
+            } else {
+                const int code = __builtin_amdgcn_readfirstlane((int)rows[(t - t0) * nkmer + cur]);
+                if (code != VIT_STAY) {
+                    cur = code < NB ? code * nrem1 + cur / NB : (code - NB) * nrem2 + cur / NB2;
+                    path[--pos] = cur;                         // decode.py:88-90
+                }
             }
         }
         sh_cur = cur;
@@ -705,8 +722,8 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
         auto request = [&](int i) {
             int t0, t1;
             bounds(i, t0, t1);
-            const int nbytes = (t1 - t0) * nkmer;
-            const uint8_t *src = tbb + (size_t)t0 * nkmer;
+            const int nbytes = (t1 - t0) * rowbytes;
+            const uint8_t *src = tbb + (size_t)t0 * rowbytes;
             uint8_t *dst = blk + (i % VBT_RING) * VBT_BLOCK;
 #pragma unroll
             for (int k = 0; k < PER_WAVE; k++) {
@@ -740,8 +757,8 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
             int t0, t1;
             bounds(i, t0, t1);
             __syncthreads();
-            const int nbytes = (t1 - t0) * nkmer;
-            for (int k = tid; k < nbytes; k += nt) blk[k] = tbb[(size_t)t0 * nkmer + k];
+            const int nbytes = (t1 - t0) * rowbytes;
+            for (int k = tid; k < nbytes; k += nt) blk[k] = tbb[(size_t)t0 * rowbytes + k];
             __syncthreads();
             if (tid == 0) walk(i, blk);
         }
@@ -791,6 +808,7 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
     if (nrem1 > 1024) return SLK_ERR_UNSUPPORTED;
     size_t lds = sizeof(float) * ((size_t)nkmer + nrem1 + 16) + sizeof(int) * ((size_t)nrem1 + 16);
     float one_m = (float)(1.0 - (double)min_prob);
+    bool packed_tb = false;                                  // which traceback format the forward kernel writes
     if (NB == 4 && nkmer <= 1024 && nkmer >= 64 && B >= 1536) {
         // one wave per chunk, four chunks per workgroup: fewer instructions per (chunk, step), but a lone wave per SIMD
         // cannot hide its own dependent-issue and memory latency -- it wins once there are ~2 chunks per SIMD (1024 SIMDs)
@@ -804,6 +822,7 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
             hipLaunchKernelGGL((viterbi_forward4_wave_kernel<false>), grid, block, ldsw, s, post, nullptr, ld, T, B, nkmer,
                                skip_pen, mode, min_prob, one_m, tb, best, score_out, lens);
     } else if constexpr (NB == 4) {
+        packed_tb = true;
         const size_t lds4 = sizeof(float) * (2 * (size_t)nkmer + threads + 32 + (size_t)VIT_TBS * nrem1);
         if (stats)
             hipLaunchKernelGGL((viterbi_forward4_kernel<true>), dim3(B), dim3(threads), lds4, s, post,
@@ -821,12 +840,17 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
                            skip_pen, mode, min_prob, one_m, tb, best, score_out, lens);
     int rc = slk_launch_status();
     if (rc != SLK_OK) return rc;
-    int tblk = VBT_BLOCK / nkmer;                            // rows per staged block
+    const int rowbytes = packed_tb ? nkmer / 2 : nkmer;
+    int tblk = VBT_BLOCK / rowbytes;                         // rows per staged block
     if (tblk < 1) return SLK_ERR_UNSUPPORTED;
-    const int dma = (VBT_BLOCK % nkmer == 0) && (nkmer % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
+    const int dma = (VBT_BLOCK % rowbytes == 0) && (rowbytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
     if (tblk > T) tblk = T;
-    hipLaunchKernelGGL((viterbi_backtrace_kernel<NB>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
-                       len_out, lens);
+    if (packed_tb)
+        hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, true>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+                           len_out, lens);
+    else
+        hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, false>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+                           len_out, lens);
     return slk_launch_status();
 }
 
