@@ -39,6 +39,30 @@ def test_normalise_ragged_sizes_vs_oracle(oracle, n, clen):
     assert np.array_equal(out, ref, equal_nan=True)
 
 
+@pytest.mark.parametrize("clen", [1024, 1025, 2047, 2048, 2049, 3000, 3999, 4000, 4001, 4095, 4096])
+@pytest.mark.parametrize("kind", ["normal", "rounded", "two-valued", "negative"])
+def test_normalise_by_selection_vs_oracle(oracle, clen, kind):
+    """Chunks of 1024..4096 samples take med_mad_select_kernel (order statistics by bitwise selection on register-resident
+    keys): odd and even lengths, both register footprints, heavy duplication (the upper median neighbour is then the same
+    key), signals of both signs -- median, MAD and the normalised samples bit for bit."""
+    need_gpu()
+    from sloika_amd import batch
+    rs = np.random.RandomState(clen)
+    x = (rs.normal(size=(37, clen)) * 12 + 90).astype(np.float32)
+    if kind == "rounded":
+        x = np.round(x)
+    elif kind == "two-valued":
+        x = np.where(rs.uniform(size=x.shape) < 0.5, 1.0, 2.0).astype(np.float32)
+        x[:, 0] = 5.0
+    elif kind == "negative":
+        x = (x - 90.0).astype(np.float32)
+    with np.errstate(all="ignore"):
+        ref, rmed, rmad = oracle.med_mad_normalise(x, return_stats=True)
+    out, med, mad = batch.normalise_chunks(x, 'per-chunk', return_stats=True)
+    assert np.array_equal(med, rmed) and np.array_equal(mad, rmad)
+    assert np.array_equal(out, ref, equal_nan=True)
+
+
 def test_normalise_rejects_bad_shapes():
     need_gpu()
     from sloika_amd import batch
