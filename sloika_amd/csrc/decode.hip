@@ -11,10 +11,10 @@
 // key (value desc, a*nbase+b asc) is what np.argmax over the reshaped (nbase^2, nkmer/nbase^2) view selects.
 // Float arithmetic is max / add / sub in float32 only (no contraction possible), so scores are bit-identical
 // to numpy's given the same log-posteriors.  The traceback (reference: an int32 from-state per (t, state)) is stored as ONE BYTE
-// per (t, state) by the generic and the one-wave kernels:
+// per (t, state) by the generic kernel:
 //   0..nbase-1 = step from a, nbase..nbase+nbase^2-1 = skip from ab, 255 = stay
-// and as ONE 16-BIT WORD per (t, four states) by viterbi_forward4_kernel (see there), and walked by a second kernel that stages
-// time-blocks of it in LDS.
+// and as ONE 16-BIT WORD per (t, four states) by the two nbase-4 kernels (see viterbi_forward4_kernel), and walked by a second
+// kernel that stages time-blocks of it in LDS.
 #include "common.h"
 
 #define VIT_ETA 1e-10f
@@ -480,7 +480,6 @@ __global__ void __launch_bounds__(256) viterbi_forward4_wave_kernel(const float 
                                                                     int32_t *__restrict__ best_out,
                                                                     float *__restrict__ score_out, const int *__restrict__ lens)
 {
-    constexpr int NB = 4;
     extern __shared__ float sm[];
     const int Tpad = T;                                        // row stride of the traceback
     // the chunk index is wave-uniform: keeping it in a scalar register makes the row statistics scalar loads
@@ -495,7 +494,7 @@ __global__ void __launch_bounds__(256) viterbi_forward4_wave_kernel(const float 
     const int q = active ? lane : 0;
     const float *pb = post + (size_t)b * ld;
     const size_t tstride = (size_t)B * ld;
-    uint8_t *tbb = tb + (size_t)b * Tpad * nkmer;
+    uint8_t *tbb = tb + (size_t)b * Tpad * (nkmer / 2);         // packed traceback, as viterbi_forward4_kernel writes it
 
     auto xform = [&](float val, float2 st) {
         return LOGITS ? log_logit_val(val, st, min_prob, one_m) : log_post_val(val, mode, min_prob, one_m);
@@ -600,26 +599,27 @@ __global__ void __launch_bounds__(256) viterbi_forward4_wave_kernel(const float 
                 sarg = take ? a : sarg;
             }
             const float mx = fmaxf(sstep, sskip);
-            const int code = sstep > sskip ? sarg : NB + karg;      // decode.py:76 (tie -> skip)
+            const uint32_t how = sstep > sskip ? 1u : 2u;           // decode.py:76 (tie -> skip)
             const float ownv[4] = {own[c].x, own[c].y, own[c].z, own[c].w};
             float nw[4];
-            uint32_t packed = 0;
+            uint32_t packed = ((uint32_t)sarg << 8) | ((uint32_t)karg << 10);
 #pragma unroll
             for (int cc = 0; cc < 4; cc++) {
                 const float nv = lp[4 * c + cc] + mx;               // decode.py:75
                 const float stay = ownv[cc] + lp0;                  // decode.py:80
                 const bool move = nv > stay;                        // decode.py:81 (tie -> stay)
-                packed |= (uint32_t)(move ? code : VIT_STAY) << (8 * cc);
+                packed |= (move ? how : 0u) << (2 * cc);
                 nw[cc] = move ? nv : stay;
             }
             out[c] = make_float4(nw[0], nw[1], nw[2], nw[3]);
-            codes[c] = packed;
+            codes[c] = packed;                                       // 16 bits: step group 4q + c
         }
         if (active) {
             // every read of the old scores above precedes these writes in program order (one wave, in-order LDS)
 #pragma unroll
             for (int c = 0; c < 4; c++) *reinterpret_cast<float4 *>(&v[16 * q + 4 * c]) = out[c];
-            *reinterpret_cast<uint4 *>(tbb + (size_t)t * nkmer + 16 * (size_t)q) = make_uint4(codes[0], codes[1], codes[2], codes[3]);
+            *reinterpret_cast<uint2 *>(tbb + (size_t)t * (nkmer / 2) + 8 * (size_t)q) =
+                make_uint2(codes[0] | (codes[1] << 16), codes[2] | (codes[3] << 16));
         }
         xform_row(use, st_use, lp);                                  // log-posteriors of step t+1
     };
@@ -810,6 +810,7 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
     float one_m = (float)(1.0 - (double)min_prob);
     bool packed_tb = false;                                  // which traceback format the forward kernel writes
     if (NB == 4 && nkmer <= 1024 && nkmer >= 64 && B >= 1536) {
+        packed_tb = true;
         // one wave per chunk, four chunks per workgroup: fewer instructions per (chunk, step), but a lone wave per SIMD
         // cannot hide its own dependent-issue and memory latency -- it wins once there are ~2 chunks per SIMD (1024 SIMDs)
         const size_t ldsw = sizeof(float) * 4 * ((size_t)nkmer + 64);
