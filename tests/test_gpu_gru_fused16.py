@@ -225,3 +225,33 @@ def test_layer_with_weights_outside_fp16_range(oracle):
         y = g.compile()(x)
         assert np.isfinite(y).all()
         np.testing.assert_allclose(y, oracle.run_network(g.spec(), x), atol=TOL)
+
+
+@pytest.mark.parametrize("I,n", [(96, 96), (128, 96), (16, 64)])
+def test_fused16_launches_are_deterministic(I, n):
+    """Race screen of a different kind: a kernel whose waves exchange data through LDS without enough ordering gives different
+    bits from launch to launch.  Every launch of the same inputs -- full-size batch, ragged lengths, both directions, with the
+    saved gates -- must reproduce the first one exactly."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(I + n)
+    T, B = 400, 1024
+    iW = torch.randn(3 * n, I, device="cuda", generator=g) / np.sqrt(I + n)
+    bb = torch.randn(3 * n, device="cuda", generator=g)
+    sW = 2 * torch.randn(2 * n, n, device="cuda", generator=g) / np.sqrt(2 * n)
+    sW2 = 2 * torch.randn(n, n, device="cuda", generator=g) / np.sqrt(2 * n)
+    x = torch.randn(T, B, I, device="cuda", generator=g)
+    lens = torch.randint(1, T + 1, (B,), device="cuda", dtype=torch.int32, generator=g)
+    for reverse in (False, True):
+        for lp in (None, lens):
+            first = None
+            for rep in range(5):
+                y = torch.full((T, B, n), float("nan"), device="cuda")
+                zr = torch.full((T * B, 2 * n), float("nan"), device="cuda")
+                assert _call(L, x.data_ptr(), I, iW, sW, sW2, bb, y.data_ptr(), n, T, B, I, n, reverse, lens=lp, zr=zr) == 0
+                got = (torch.nan_to_num(y, nan=9.0), torch.nan_to_num(zr, nan=9.0))
+                if first is None:
+                    first = got
+                else:
+                    assert torch.equal(first[0], got[0]) and torch.equal(first[1], got[1]), (reverse, lp is not None, rep)
