@@ -6,7 +6,7 @@
 // (the fp32-input MFMA runs at 1/16 of the fp16 rate on gfx950 and there is no TF32 path), i.e. ~5x the fp32 MFMA
 // throughput at an error of a few float32 ulps -- far inside the 1e-4 layer tolerance (tests/test_gpu_gemm.py).
 //
-// x-stationary like gemm_rows.hip (128 rows x all N columns per workgroup, row statistics accumulated online); the weights
+// x-stationary like gemm_rows.hip (128 rows (GH_NWM = 4 groups of 32) x all N columns per workgroup, row statistics accumulated online); the weights
 // arrive pre-split (slk_split_f16x2_f32).
 //
 // Range: fp16 overflows at 65504 and loses its lo half below 6e-5, so every row of x (in the kernel) and every row of W (in
@@ -18,7 +18,22 @@
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-#define GH_BM 128
+// Row groups of 32 per workgroup.  Every workgroup streams the whole of W through LDS once, so W traffic per row falls with
+// the workgroup height.  Back-to-back launches in one process (tools/build_gemm_variants.sh): 2 groups 1.35 ms, 4 groups 1.03,
+// 5 groups 0.97, 6 groups 0.99 (13 waves need <= 128 registers: spills) -- but inside the pipeline, between the last GRU and
+// the decoder, 4 and 5 groups both take 0.91-0.92 ms (alternating runs on one device), so the default stays at 4, which keeps
+// the patch stores for K up to 128 and fits 168 registers without scratch.
+#ifndef GH_NWM
+#define GH_NWM 4
+#endif
+#define GH_BM (32 * GH_NWM)
+#define GH_THREADS (64 * (2 * GH_NWM + 1))
+#ifndef GH_RINGMAX
+#define GH_RINGMAX 3
+#endif
+#ifndef GH_BIASMAX
+#define GH_BIASMAX 2048
+#endif
 #define GH_BN 64
 
 // power-of-two scale that brings a row whose largest magnitude is amax into [1, 2) (exponent kept inside [27, 227])
@@ -65,7 +80,7 @@ extern "C" int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, vo
 }
 
 // Kernel structure
-//   * 128 rows x all N columns per workgroup; the MFMA computes the TRANSPOSED 64-column tile D[W column][x row]
+//   * GH_BM = 128 rows x all N columns per workgroup; the MFMA computes the TRANSPOSED 64-column tile D[W column][x row]
 //     (A = weights from LDS, B = x held in registers for the whole row block): a lane then owns 16 columns of ONE output
 //     row, four of them consecutive per accumulator quad, so the logits leave as 16-byte stores straight from the
 //     accumulators and the online softmax statistics are two scalars per lane.
@@ -84,7 +99,7 @@ extern "C" int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, vo
 #define GH_TRSTORE true
 #endif
 template <int KS, bool STATS, int ACT, bool TRSTORE = GH_TRSTORE>
-__global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__restrict__ x, long ldx,
+__global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float *__restrict__ x, long ldx,
                                                               const _Float16 *__restrict__ Whi,
                                                               const _Float16 *__restrict__ Wlo,
                                                               const float *__restrict__ winv,
@@ -94,29 +109,29 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
 {
     constexpr int KP = 16 * KS;                    // padded K (halves per weight row in Whi/Wlo)
     constexpr int LD = KP + 8;                     // LDS row stride in halves: (KP+8)*2 B = odd multiple of 16 B
-    constexpr int RING = KS <= 9 ? 3 : 2;          // weight-tile slots (a tile is 64 x (KP+8) halves, twice): LDS budget
+    constexpr int RING = (KS <= 9 && GH_RINGMAX >= 3) ? 3 : 2;          // weight-tile slots (a tile is 64 x (KP+8) halves, twice): LDS budget
     constexpr int PPR = KP / 8 + 1;                // 16-byte pieces per LDS row (the last one is padding)
-    constexpr int BIAS_MAX = 2048 + GH_BN;
+    constexpr int BIAS_MAX = GH_BIASMAX + GH_BN;
     __shared__ __attribute__((aligned(16))) _Float16 wsh[RING][GH_BN * LD];
     __shared__ __attribute__((aligned(16))) _Float16 wsl[RING][GH_BN * LD];
     __shared__ float2 red[2][GH_BM];
     __shared__ __attribute__((aligned(16))) float bias_lds[BIAS_MAX];   // zero padded to whole tiles
     __shared__ __attribute__((aligned(16))) float winv_lds[BIAS_MAX];   // inverse scales of the weight rows (= columns here)
     constexpr int TP = 36;                          // floats per row of a wave's 32 x 32 store patch (144 B: no bank clash)
-    constexpr bool TR = TRSTORE && KS <= 8;         // (K > 128: the weight ring leaves no room for the patches)
-    __shared__ __attribute__((aligned(16))) float patch[TR ? 8 * 32 * TP : 4];
+    constexpr bool TR = TRSTORE && KS <= (GH_NWM > 4 ? 6 : 8);         // (K > 128: the weight ring leaves no room for the patches)
+    __shared__ __attribute__((aligned(16))) float patch[TR ? 2 * GH_NWM * 32 * TP : 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long m0 = (long)blockIdx.x * GH_BM;
     const int ntiles = (N + GH_BN - 1) / GH_BN;
     auto tile_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    for (int i = tid; i < ntiles * GH_BN; i += 576) {
+    for (int i = tid; i < ntiles * GH_BN; i += GH_THREADS) {
         bias_lds[i] = (bias && i < N) ? bias[i] : 0.0f;
         winv_lds[i] = i < N ? winv[i] : 0.0f;
     }
 
-    if (wave == 8) {
+    if (wave == 2 * GH_NWM) {
         // =============================== loader wave ===============================
         // one tile = 64 rows x PPR pieces per array = PPR chunks of 64 pieces (1 KiB) each, contiguous in LDS;
         // columns beyond N re-read row N-1 (their products are never stored nor counted)
@@ -362,7 +377,7 @@ __global__ void __launch_bounds__(576) gemm_rows_f16x3_kernel(const float *__res
         // matrix pipe at the same time and the vector unit at the same time.  So the upper four run a tile period the other way
         // round -- the epilogue of the previous tile FIRST, then this tile's MFMAs -- and each half's MFMAs run under the other
         // half's epilogue.
-        if (GH_PHASE == 0 || wave < 4) {
+        if (GH_PHASE == 0 || wave < GH_NWM) {
             for (; nt + 1 <= nfast; nt += 2) {
                 accB = mma(nt);
                 if (GH_PHASE == 2) __builtin_amdgcn_sched_barrier(0);
@@ -428,7 +443,7 @@ template <int KS>
 static int launch_f16x3(const float *x, long ldx, const _Float16 *hi, const _Float16 *lo, const float *winv, const float *bias, float *y,
                         long ldy, long M, int K, int N, float2 *stats, int act, hipStream_t s)
 {
-    dim3 grid((unsigned)((M + GH_BM - 1) / GH_BM)), block(576);
+    dim3 grid((unsigned)((M + GH_BM - 1) / GH_BM)), block(GH_THREADS);
 #define F16X3_LAUNCH(ST, A) \
     hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, ST, A>), grid, block, 0, s, x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, stats)
     if (stats) F16X3_LAUNCH(true, SLK_ACT_LINEAR);
@@ -449,7 +464,7 @@ static int dispatch_f16x3(const float *x, long ldx, const void *W_hi, const void
         return SLK_ERR_INVALID_ARG;
     if (stats && act != SLK_ACT_LINEAR) return SLK_ERR_INVALID_ARG;
     if (M == 0) return SLK_OK;
-    if ((M + GH_BM - 1) / GH_BM > 0x7fffffffL || N > 2048) return SLK_ERR_UNSUPPORTED;   // bias vector is staged in LDS
+    if ((M + GH_BM - 1) / GH_BM > 0x7fffffffL || N > GH_BIASMAX) return SLK_ERR_UNSUPPORTED;   // bias vector is staged in LDS
     const _Float16 *hi = static_cast<const _Float16 *>(W_hi), *lo = static_cast<const _Float16 *>(W_lo);
     float2 *st = reinterpret_cast<float2 *>(stats);
     hipStream_t s = slk_stream(stream);
