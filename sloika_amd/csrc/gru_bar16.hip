@@ -18,6 +18,7 @@
 // Layout of the 16x16x32 tiles (weights = A, state of the 4 chunks in all four column groups = B, lane (c, q, g) keeps
 // neuron 4g+q of its tile) and the packed operand images are those of gru_fused16.hip.
 #include <limits.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -48,6 +49,18 @@ __device__ __forceinline__ float tanh5(float x)
 __device__ __forceinline__ float sigmoid4(float x)
 {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
+
+// Row 4g+q of a tile's accumulator for the lane (g, q, c) when only column group 0 (lanes q = 0) holds the product: lane
+// quartet q of every 16-lane row takes register q of the lanes four, eight, twelve places below it (bank-masked DPP moves
+// -- three instructions, as many as the three selects they replace).
+__device__ __forceinline__ float gather4(const f32x4 &a)
+{
+    int r = __float_as_int(a[0]);
+    r = __builtin_amdgcn_update_dpp(r, __float_as_int(a[1]), 0x114, 0xf, 0x2, false);      // row_shr:4  -> quartet 1
+    r = __builtin_amdgcn_update_dpp(r, __float_as_int(a[2]), 0x118, 0xf, 0x4, false);      // row_shr:8  -> quartet 2
+    r = __builtin_amdgcn_update_dpp(r, __float_as_int(a[3]), 0x11c, 0xf, 0x8, false);      // row_shr:12 -> quartet 3
+    return __int_as_float(r);
 }
 
 template <int V>
@@ -132,6 +145,13 @@ extern "C" int slk_debug_read_bar16(unsigned long long *host_out)
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_bar16), sizeof(unsigned long long) * 64) == hipSuccess ? SLK_OK
                                                                                                                 : SLK_ERR_LAUNCH;
 }
+// ABL & 32: every workgroup records where it ran and for how long (shader clock and the 100 MHz wall clock)
+__device__ unsigned long long slk_dbg_bar16_wg[1024][4];
+extern "C" int slk_debug_read_bar16_wg(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_bar16_wg), sizeof(unsigned long long) * 4096) == hipSuccess ? SLK_OK
+                                                                                                                    : SLK_ERR_LAUNCH;
+}
 #define BSTAMP(i)                                                                     \
     if constexpr (DIAG) {                                                             \
         unsigned long long tnow;                                                      \
@@ -190,13 +210,23 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
     __shared__ __attribute__((aligned(16))) unsigned xop_hi[2 * OPIMG], xop_lo[2 * OPIMG];
     __shared__ __attribute__((aligned(16))) float xinv_lds[2 * 16];
     __shared__ __attribute__((aligned(16))) float vbuf[R * VSTEP];
-    __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * N], h_lo[2 * N], rh_hi[2 * N], rh_lo[2 * N];
+    // + 4: sixteen zero bytes behind each image, the operand of the lanes whose columns stay empty (ZC below)
+    __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * N + 4], h_lo[2 * N + 4], rh_hi[2 * N + 4], rh_lo[2 * N + 4];
+    // ZC (ABL & 64, an experiment kept for the record): the state enters the recurrent MFMAs in column group 0 only (lanes
+    // q = 0 read it, the others read zeros; gather4 instead of sel4).  When the kernel fills the chip its clock is set by the
+    // power limit (tools/bar16_wg_times.py: 1.83-2.39 GHz at B = 1024 depending on the device and the moment, 2.38-2.41 GHz
+    // at B = 256, always the same 1880 cycles per step), and a matrix pipe multiplying zeros draws less -- but alternating
+    // launches on one device give it +1-2 % of clock for +1.8 % of cycles (the DPP moves), in the pipeline nothing.
+    constexpr bool ZC = (ABL & 64) != 0;
     __shared__ __attribute__((aligned(16))) float bias_lds[3 * N], invw_lds[3 * N];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
+    unsigned long long wg_t0 = 0, wg_r0 = 0;
+    if constexpr (ABL & 32) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0), "=s"(wg_r0)::"memory");
 
-    for (int i = tid; i < 2 * N; i += 256) { h_hi[i] = 0u; h_lo[i] = 0u; }             // h(-1) = 0
+    for (int i = tid; i < 2 * N + 4; i += 256) { h_hi[i] = 0u; h_lo[i] = 0u; }         // h(-1) = 0
+    if (tid < 4) { rh_hi[2 * N + tid] = 0u; rh_lo[2 * N + tid] = 0u; }
     for (int i = tid; i < 3 * N; i += 256) bias_lds[i] = bias ? bias[i] : 0.0f;
 
     // ---------------- projection pieces shared by both kinds of wave ----------------
@@ -305,7 +335,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         }
         int boff[KBS];
 #pragma unroll
-        for (int i = 0; i < KBS; i++) boff[i] = ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
+        for (int i = 0; i < KBS; i++) boff[i] = (ZC && q != 0) ? 2 * N : ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
         const int wd = ((w * 4 + g) * 4 + c) * 4 + q;                                           // my packed pair, in dwords
         const int n0 = 32 * w + 4 * g + q;                                                      // my neuron of tile 2w (+16: 2w+1)
         const int voff = (g * 4 + c) * 4 + q;                                                   // my element of a vI tile
@@ -360,6 +390,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 ::mfma3x2(w0_hi, w0_lo, w1_hi, w1_lo, h_hi_, h_lo_, acc0, acc1);
             }
         };
+        auto pick = [&](const f32x4 &a) { if constexpr (ZC) return gather4(a); else return sel4(a, q); };
         auto step = [&](auto PHC, const int s, const int G) {
             constexpr int ph = decltype(PHC)::value;
             constexpr bool PROJ = CT > 0 && ph < KBLK;
@@ -414,7 +445,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 mfma3x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i], accZ[0], accZ[1]);
             float rr[2];
 #pragma unroll
-            for (int p = 0; p < 2; p++) rr[p] = (ABL & 4) ? fmaf(sel4(accR[p], q), inv_r[p], vr[p]) * 0.01f : sigmoid4(fmaf(sel4(accR[p], q), inv_r[p], vr[p]));
+            for (int p = 0; p < 2; p++) rr[p] = (ABL & 4) ? fmaf(pick(accR[p]), inv_r[p], vr[p]) * 0.01f : sigmoid4(fmaf(pick(accR[p]), inv_r[p], vr[p]));
             {
                 unsigned hi, lo;
                 split2(rr[0] * hold[0], rr[1] * hold[1], hi, lo);
@@ -467,7 +498,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             float zz[2], omz[2], zh[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                zz[p] = (ABL & 4) ? fmaf(sel4(accZ[p], q), inv_z[p], vz[p]) * 0.01f : sigmoid4(fmaf(sel4(accZ[p], q), inv_z[p], vz[p]));
+                zz[p] = (ABL & 4) ? fmaf(pick(accZ[p]), inv_z[p], vz[p]) * 0.01f : sigmoid4(fmaf(pick(accZ[p]), inv_z[p], vz[p]));
                 omz[p] = 1.0f - zz[p];
                 zh[p] = zz[p] * hold[p];
                 asm volatile("" : "+v"(zh[p]), "+v"(omz[p]));                 // pinned here: not sunk to the blend below
@@ -482,7 +513,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             float hn[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                const float hbar = (ABL & 4) ? fmaf(sel4(accC[p], q), inv_c[p], vc[p]) * 0.01f : tanh5(fmaf(sel4(accC[p], q), inv_c[p], vc[p]));
+                const float hbar = (ABL & 4) ? fmaf(pick(accC[p]), inv_c[p], vc[p]) * 0.01f : tanh5(fmaf(pick(accC[p]), inv_c[p], vc[p]));
                 hn[p] = fmaf(omz[p], hbar, zh[p]);                            // layers.py:1020
             }
             {
@@ -516,6 +547,18 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         if constexpr (DIAG) {
             if (blockIdx.x == 0 && lane == 0)
                 for (int i = 0; i < 16; i++) slk_dbg_bar16[wave][i] = sacc[i];
+        }
+        if constexpr (ABL & 32) {
+            unsigned long long t1, r1;
+            unsigned hwid, xcc;
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_getreg_b32 %2, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %3, hwreg(HW_REG_XCC_ID)\n\ts_waitcnt lgkmcnt(0)"
+                         : "=s"(t1), "=s"(r1), "=s"(hwid), "=s"(xcc)::"memory");
+            if (wave == 0 && lane == 0 && blockIdx.x < 1024) {
+                slk_dbg_bar16_wg[blockIdx.x][0] = t1 - wg_t0;
+                slk_dbg_bar16_wg[blockIdx.x][1] = r1 - wg_r0;
+                slk_dbg_bar16_wg[blockIdx.x][2] = ((unsigned long long)xcc << 32) | hwid;
+                slk_dbg_bar16_wg[blockIdx.x][3] = wg_r0;
+            }
         }
     } else {
         // =================================================================================================
@@ -730,7 +773,10 @@ static int launch_bar16(const float *x, long ldx, const float *iW, const float *
                         float *y, long ldy, int T, int B, int reverse, const int *lens, float *zr_out, hipStream_t s)
 {
     if constexpr (I == 96 && N == 96) {
-        const int dv = reverse >> 1;                    // diagnostic launches (undocumented bits, tools/bar16_check.py)
+        // diagnostic launches (undocumented bits, tools/bar16_check.py; SLOIKA_AMD_BAR16_DIAG forces one for every launch of a
+        // process so that tools/bar16_wg_times.py --pipeline can read the clock the kernel gets inside the whole step)
+        static const int forced = getenv("SLOIKA_AMD_BAR16_DIAG") ? atoi(getenv("SLOIKA_AMD_BAR16_DIAG")) : 0;
+        const int dv = forced ? forced : reverse >> 1;
 #define DIAG_LAUNCH(CODE, STAMPS, ABLV)                                                                                   \
         if (dv == CODE) {                                                                                                 \
             static const size_t dyn = exclusive_cu_lds_bar(gru_bar16_kernel<I, N, false, STAMPS, ABLV>);                  \
@@ -740,6 +786,8 @@ static int launch_bar16(const float *x, long ldx, const float *iW, const float *
         }
         DIAG_LAUNCH(1, true, 0) DIAG_LAUNCH(2, false, 1) DIAG_LAUNCH(3, false, 2) DIAG_LAUNCH(4, false, 4) DIAG_LAUNCH(5, false, 8)
         DIAG_LAUNCH(6, false, 16) DIAG_LAUNCH(7, false, 9) DIAG_LAUNCH(8, false, 3) DIAG_LAUNCH(9, false, 11) DIAG_LAUNCH(10, false, 31)
+        DIAG_LAUNCH(11, false, 32) DIAG_LAUNCH(12, false, 34) DIAG_LAUNCH(13, false, 40) DIAG_LAUNCH(14, false, 42) DIAG_LAUNCH(15, false, 36)
+        DIAG_LAUNCH(16, false, 96)
 #undef DIAG_LAUNCH
     }
     if (zr_out) {
