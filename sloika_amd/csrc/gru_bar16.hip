@@ -20,122 +20,7 @@
 #include <limits.h>
 #include <stdlib.h>
 
-#include <type_traits>
-
-#include "f16split.h"
-
-template <bool REAL = true>
-__device__ __forceinline__ void lds_bar()
-{
-    if constexpr (REAL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-// barrier for a wave whose two youngest LDS operations are reads of its OWN data: LDS executes a wave's operations in
-// order, so everything older -- the writes the other waves are waiting for -- has been performed once at most two remain
-template <bool REAL = true>
-__device__ __forceinline__ void lds_bar_2reads()
-{
-    if constexpr (REAL) asm volatile("s_waitcnt lgkmcnt(2)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-}
-__device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }
-// tanh through one exp, 1 - 2/(exp(2x)+1), written so that it is five instructions (the same values as slk_tanh: 2x and
-// 2r are exact)
-__device__ __forceinline__ float tanh5(float x)
-{
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-}
-__device__ __forceinline__ float sigmoid4(float x)
-{
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
-}
-
-// Row 4g+q of a tile's accumulator for the lane (g, q, c) when only column group 0 (lanes q = 0) holds the product: lane
-// quartet q of every 16-lane row takes register q of the lanes four, eight, twelve places below it (bank-masked DPP moves
-// -- three instructions, as many as the three selects they replace).
-__device__ __forceinline__ float gather4(const f32x4 &a)
-{
-    int r = __float_as_int(a[0]);
-    r = __builtin_amdgcn_update_dpp(r, __float_as_int(a[1]), 0x114, 0xf, 0x2, false);      // row_shr:4  -> quartet 1
-    r = __builtin_amdgcn_update_dpp(r, __float_as_int(a[2]), 0x118, 0xf, 0x4, false);      // row_shr:8  -> quartet 2
-    r = __builtin_amdgcn_update_dpp(r, __float_as_int(a[3]), 0x11c, 0xf, 0x8, false);      // row_shr:12 -> quartet 3
-    return __int_as_float(r);
-}
-
-template <int V>
-using ic = std::integral_constant<int, V>;
-template <int B_, int E_, class F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (B_ < E_) {
-        f(ic<B_>{});
-        static_for<B_ + 1, E_>(f);
-    }
-}
-
-// acc0 += W0.h, acc1 += W1.h as 3-term splits with the two accumulation chains interleaved: consecutive MFMAs never depend on
-// each other (per accumulator the order of the terms is that of mfma3)
-__device__ __forceinline__ void mfma3x2(const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi, const half8 &w1_lo,
-                                        const half8 &h_hi, const half8 &h_lo, f32x4 &acc0, f32x4 &acc1)
-{
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0_hi, h_lo, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1_hi, h_lo, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0_lo, h_hi, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1_lo, h_hi, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0_hi, h_hi, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1_hi, h_hi, acc1, 0, 0, 0);
-}
-// the same for NT tiles of the projection and K block kb of their weights
-template <int NT, int KBLK_>
-__device__ __forceinline__ void mfma3xn(const half8 (*w_hi)[KBLK_], const half8 (*w_lo)[KBLK_], int kb, const half8 &x_hi,
-                                        const half8 &x_lo, f32x4 *acc)
-{
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[t][kb], x_lo, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo[t][kb], x_hi, acc[t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[t][kb], x_hi, acc[t], 0, 0, 0);
-}
-
-// Projection weights in ACCUMULATION registers (a wave alone on its SIMD has 256 of them next to its 256 ordinary ones), named
-// directly as the MFMA's A operand.  hipcc treats those registers as spill space and copies every operand back (four
-// v_accvgpr_read per operand and use); operands only ever used through an "a" constraint stay where they are.
-__device__ __forceinline__ half8 to_acc_regs(half8 v)
-{
-    half8 a;
-    asm volatile("" : "=a"(a) : "0"(v));
-    return a;
-}
-// a whole tile: acc = sum over K blocks of the 3-term split, first MFMA with a zero C operand (no VALU write of the accumulator
-// in front of an instruction the compiler does not know to be an MFMA), then let the matrix pipe drain before ordinary
-// instructions read the result (the compiler's hazard bookkeeping does not see asm)
-template <int KBLK_>
-__device__ __forceinline__ f32x4 tile_mfma_acc(const half8 *w_hi, const half8 *w_lo, const half8 *x_hi, const half8 *x_lo)
-{
-    f32x4 acc;
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w_hi[0]), "v"(x_lo[0]));
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_lo[0]), "v"(x_hi[0]));
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi[0]), "v"(x_hi[0]));
-#pragma unroll
-    for (int kb = 1; kb < KBLK_; kb++) {
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi[kb]), "v"(x_lo[kb]));
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_lo[kb]), "v"(x_hi[kb]));
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi[kb]), "v"(x_hi[kb]));
-    }
-    return acc;
-}
-__device__ __forceinline__ void mfma_drain(f32x4 &a) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a)); }
-// one K block of one tile, accumulator kept across steps (chain waves); FIRST: start from zero
-template <bool FIRST>
-__device__ __forceinline__ void block_mfma_acc(f32x4 &acc, const half8 &w_hi, const half8 &w_lo, const half8 &x_hi, const half8 &x_lo)
-{
-    if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "a"(w_hi), "v"(x_lo));
-    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi), "v"(x_lo));
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_lo), "v"(x_hi));
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi), "v"(x_hi));
-}
+#include "bar16_common.h"
 
 // Diagnostic instantiation: shader-clock cycles the waves of workgroup 0 spend in each section of a step, summed over the scan
 // (tools/bar16_check.py reads them).  The production instantiation carries none of this.
@@ -802,6 +687,24 @@ static int launch_bar16(const float *x, long ldx, const float *iW, const float *
     return slk_launch_status();
 }
 
+extern "C" int slk_gru_bar16d_launch(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+                                     float *y, long ldy, int T, int B, int insize, int n, int reverse, const int32_t *lens,
+                                     float *zr_out, hipStream_t s);
+
+// More workgroups of four chunks than CUs would run one after the other: such batches take the eight-chunk plan of
+// gru_bar16d.hip (SLOIKA_AMD_GRU_DUAL=0 / 1 forces one or the other).
+static bool bar16_use_dual(int B)
+{
+    static const int forced = getenv("SLOIKA_AMD_GRU_DUAL") ? atoi(getenv("SLOIKA_AMD_GRU_DUAL")) : -1;
+    if (forced >= 0) return forced != 0;
+    static const int ncu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n > 0 ? n : 256;
+    }();
+    return (B + 3) / 4 > ncu;
+}
+
 // Same contract as slk_gru_fused16_f32 (include/sloika_amd.h); SLK_ERR_UNSUPPORTED when no instantiation covers the request.
 extern "C" int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
                                  const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse, int act,
@@ -812,6 +715,12 @@ extern "C" int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, cons
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
     if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;   // 16-byte DMA pieces
     hipStream_t s = slk_stream(stream);
+    const int plan = (reverse >> 8) & 3;                 // undocumented (tools/bar16d_check.py): 1 = four-chunk plan, 2 = eight-chunk plan
+    reverse &= 0xff;
+    if (plan == 2 || (plan == 0 && (reverse >> 1) == 0 && bar16_use_dual(B))) {
+        const int rc = slk_gru_bar16d_launch(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse, lens, zr_out, s);
+        if (rc != SLK_ERR_UNSUPPORTED) return rc;
+    }
 #define BAR16(II, NN) \
     if (insize == II && n == NN) return launch_bar16<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s);
     BAR16(96, 96) BAR16(64, 64) BAR16(32, 96) BAR16(128, 96) BAR16(64, 96) BAR16(48, 32) BAR16(16, 64)

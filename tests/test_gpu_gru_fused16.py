@@ -18,20 +18,24 @@ def _params(rs, I, n, bias=True, scale=1.0):
     return iW, sW, sW2, b
 
 
-#: the two execution plans of the same arithmetic: LDS progress counters (gru_fused16.hip) and barrier-stepped (gru_bar16.hip)
+#: the execution plans of the same arithmetic: LDS progress counters (gru_fused16.hip), barrier-stepped with four chunks per
+#: workgroup (gru_bar16.hip) and with eight (gru_bar16d.hip, what batches beyond one workgroup per CU run: forced here through
+#: bits 8-9 of `reverse` so that the small cases exercise it too)
 ENTRY = "slk_gru_bar16_f32"
+PLAN = 0
 
 
-@pytest.fixture(autouse=True, params=["slk_gru_bar16_f32", "slk_gru_fused16_f32"])
+@pytest.fixture(autouse=True, params=["slk_gru_bar16_f32", "slk_gru_fused16_f32", "slk_gru_bar16_f32:8"])
 def _entry(request):
-    global ENTRY
-    ENTRY = request.param
+    global ENTRY, PLAN
+    ENTRY, _, eight = request.param.partition(":")
+    PLAN = 2 if eight else 0
     yield
 
 
 def _call(L, x, ldx, iW, sW, sW2, b, y, ldy, T, B, I, n, reverse, lens=None, zr=None):
     return getattr(L, ENTRY)(x, ldx, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), None if b is None else b.data_ptr(),
-                                 y, ldy, T, B, I, n, int(reverse), 1, 2, None if lens is None else lens.data_ptr(),
+                                 y, ldy, T, B, I, n, int(reverse) | (PLAN << 8), 1, 2, None if lens is None else lens.data_ptr(),
                                  None if zr is None else zr.data_ptr(), stream())
 
 
@@ -255,3 +259,33 @@ def test_fused16_launches_are_deterministic(I, n):
                     first = got
                 else:
                     assert torch.equal(first[0], got[0]) and torch.equal(first[1], got[1]), (reverse, lp is not None, rep)
+
+
+@pytest.mark.parametrize("I,n", [(96, 96), (64, 64), (32, 96), (48, 32)])
+def test_eight_chunk_plan_is_bit_identical(I, n):
+    """gru_bar16d.hip computes every (neuron, chunk) pair with the same instructions in the same order as gru_bar16.hip: the two
+    plans must agree bit for bit -- states and saved gates, ragged and reversed, batch sizes around the multiples of eight and a
+    batch (2048 + 3 chunks) that takes the eight-chunk plan by itself."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(7 * I + n)
+    iW = torch.randn(3 * n, I, device="cuda", generator=g) / np.sqrt(I + n)
+    bb = torch.randn(3 * n, device="cuda", generator=g)
+    sW = 2 * torch.randn(2 * n, n, device="cuda", generator=g) / np.sqrt(2 * n)
+    sW2 = 2 * torch.randn(n, n, device="cuda", generator=g) / np.sqrt(2 * n)
+    for T, B in [(1, 1), (5, 7), (9, 8), (13, 17), (37, 2051)]:
+        x = torch.randn(T, B, I, device="cuda", generator=g)
+        lens = torch.randint(1, T + 1, (B,), device="cuda", dtype=torch.int32, generator=g)
+        for reverse in (0, 1):
+            for lp in (None, lens):
+                got = []
+                for plan in (1, 2, 0):
+                    y = torch.full((T, B, n), float("nan"), device="cuda")
+                    zr = torch.full((T * B, 2 * n), float("nan"), device="cuda")
+                    rc = L.slk_gru_bar16_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B,
+                                             I, n, reverse | (plan << 8), 1, 2, None if lp is None else lp.data_ptr(), zr.data_ptr(), stream())
+                    assert rc == 0
+                    got.append((torch.nan_to_num(y, nan=9.0), torch.nan_to_num(zr, nan=9.0)))
+                for other in got[1:]:
+                    assert torch.equal(got[0][0], other[0]) and torch.equal(got[0][1], other[1]), (T, B, reverse, lp is not None)

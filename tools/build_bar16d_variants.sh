@@ -1,0 +1,15 @@
+#!/bin/bash
+# Variants of csrc/gru_bar16d.hip in ONE shared library for tools/bar16d_variants.py (in-process A/B; timings of one binary differ
+# by ~10 % between boxes).   usage: tools/build_bar16d_variants.sh "<flags of v0>" "<flags of v1>" ...   e.g. "" "-DBAR16D_ABL=1"
+set -e
+cd "$(dirname "$0")/.."
+V=tools/_build/variants; mkdir -p $V
+objs=(); i=0
+for flags in "$@"; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=off $flags \
+      -Dslk_gru_bar16d_launch=slk_d_v$i -Dgru_bar16d_kernel=gru_d_k$i -Dslk_dbg_bar16d=slk_dbg_d$i -Dslk_debug_read_bar16d=slk_debug_read_d$i -c sloika_amd/csrc/gru_bar16d.hip -o $V/d_$i.o &
+  objs+=($V/d_$i.o); i=$((i+1))
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o tools/_build/libbar16d_variants.so "${objs[@]}"
+echo built $i variants
