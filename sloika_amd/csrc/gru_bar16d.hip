@@ -31,7 +31,7 @@ typedef float f32x2d __attribute__((ext_vector_type(2)));
 #define BAR16D_HOOKS 0
 #endif
 #ifndef BAR16D_CT
-#define BAR16D_CT 3
+#define BAR16D_CT 2
 #endif
 __device__ unsigned long long slk_dbg_bar16d[4][16];
 extern "C" int slk_debug_read_bar16d(unsigned long long *host_out)
@@ -136,21 +136,15 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
     constexpr int KBLK = (I + 31) / 32;
     constexpr int GS = 4;                                // steps per projection group (16 MFMA columns = 4 steps x 4 chunks of a set)
     constexpr int R = 2 * GS;                            // vI ring: group G+1 is written while group G is consumed
-    constexpr int CT = NCW == 3 ? BAR16D_CT : 0;         // projection tiles of a chain wave (weights in accumulation registers)
+    constexpr int CT = NCW == 3 ? (KBLK == 4 ? 3 : BAR16D_CT) : 0;   // projection tiles of a chain wave (KBLK = 4: the service wave's registers hold 9 tiles, not 12) (weights in accumulation registers)
     constexpr int ST = (NT16 - NCW * CT) / NSW;          // ... of a service wave
     constexpr int NACAP = 240 / (8 * KBLK);              // 256 accumulation registers, 2 * KBLK * 4 per tile
     constexpr int NA = ST < NACAP ? ST : NACAP;
     static_assert(NCW * CT + NSW * ST == NT16, "tile assignment");
     static_assert(KBLK <= 4 && ST <= 21, "interval plan");
-    constexpr int XIMG = 4 * I;                          // floats of one step's x image of a set: [k/4][chunk][k%4]
-    constexpr int XBLK = GS * XIMG;                      // one block = one group of one set
-    constexpr int XSLOTS = 3;                            // block G+2 is split while block G+3 arrives in block G's slot
-    constexpr int NREQ = GS * I / 64;                    // 1 KiB DMA requests per block and set
-    static_assert((GS * I) % 64 == 0 && 2 * NREQ <= 16, "x block requests");
     constexpr int OPIMG = GS * KBLK * 64;                // dwords of one operand image: [step][k block][k group][chunk][8 halves]
     constexpr int VSTEP = NT16 * 64;                     // floats of one step's vI of a set: [tile][g][chunk][r]
 
-    __shared__ __attribute__((aligned(16))) float xraw[XSLOTS * 2 * XBLK];
     __shared__ __attribute__((aligned(16))) unsigned xop_hi[2 * 2 * OPIMG], xop_lo[2 * 2 * OPIMG];      // [group & 1][set]
     __shared__ __attribute__((aligned(16))) float xinv_lds[2 * 2 * 16];
     __shared__ __attribute__((aligned(16))) float vbuf[R * 2 * VSTEP];                                   // [step % R][set]
@@ -533,46 +527,46 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
 #pragma unroll
         for (int t = NA; t < ST; t++) load_tile(tile0 + t, pw_hi[t - NA], pw_lo[t - NA]);
 
-        // x DMA: block blk = the four steps of group blk; request j < NREQ serves set 0, the others set 1; request jj of a set
-        // moves pieces 64 jj .. 64 jj + 63, piece p = (step kk, 16-byte column qq, chunk cc); (p % I) & 3 = lane & 3: a lane
-        // always serves the same chunk of a set
-        const int dcc = lane & 3;
-        int dbc[2], dTc[2];
+        // x of a group and set: the leader's lane (row pcol = (step, chunk), k group kg) loads ITS eight floats of every K block
+        // straight into registers (the four lanes of a row and K block cover one 128-byte line) a group ahead of the split --
+        // no staging in LDS, no LDS-DMA (measured here: ~150 cycles of the wave per 1-KiB request).  Ordinary loads: the
+        // compiler waits for them where the split first uses them, a group later.
+        int xbc[2], xTc[2];
 #pragma unroll
         for (int sset = 0; sset < 2; sset++) {
-            dbc[sset] = min(b0 + 4 * sset + dcc, B - 1);
-            dTc[sset] = lens ? min(max(lens[dbc[sset]], 1), T) : T;
+            xbc[sset] = min(b0 + 4 * sset + pc, B - 1);
+            xTc[sset] = lens ? min(max(lens[xbc[sset]], 1), T) : T;
         }
-        auto dma_request = [&](int blk, int j) {
-            const int sset = j >= NREQ, jj = j - sset * NREQ;
-            const int p = 64 * jj + lane;
-            const int kk = p / I, qq = (p % I) >> 2;
+        f32x4 xr[2][KBLK][2];
+        auto load_x = [&](int G2, auto SC) {
+            constexpr int sset = decltype(SC)::value;
             // steps past the chunk's end re-read its last valid row (their results are never stored)
-            const int tc = sset ? dTc[1] : dTc[0];
-            const int ss = min(blk * GS + kk, tc - 1);
-            const int tt = reverse ? tc - 1 - ss : ss;
-            const float *src = x + ((size_t)tt * B + (sset ? dbc[1] : dbc[0])) * ldx + 4 * qq;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)&xraw[((blk % XSLOTS) * 2 + sset) * XBLK + 256 * jj],
-                                             16, 0, 0);
+            const int ss = min(G2 * GS + pstep, xTc[sset] - 1);
+            const int tt = reverse ? xTc[sset] - 1 - ss : ss;
+            const float *row = x + ((size_t)tt * B + xbc[sset]) * ldx;
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+                const int k0 = 32 * kb + 8 * kg;
+                const bool kok = (I % 32 == 0) || k0 < I;
+                const float *src = row + (kok ? k0 : 0);
+                xr[sset][kb][0] = *reinterpret_cast<const f32x4 *>(src);
+                xr[sset][kb][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+            }
         };
-        // split of group G2's x rows of a set: lane = (row pcol = (step, chunk), k group kg); element x[chunk][k] of a step's
-        // image sits at 16 (k>>2) + 4 chunk + (k&3)
+        // split of a set's rows
         float xs = 1.0f;
         float raw[KBLK][8];                              // the rows as read for the scale, kept for the split
-        auto split_scale = [&](int G2, int sset) {       // pass 1: the row's power-of-two scale
-            const float *img = xraw + ((G2 % XSLOTS) * 2 + sset) * XBLK + pstep * XIMG + 4 * pc;
+        auto split_scale = [&](int G2, auto SC) {        // pass 1: the row's power-of-two scale
+            constexpr int sset = decltype(SC)::value;
             float amax = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < KBLK; kb++) {
                 const int k0 = 32 * kb + 8 * kg;
                 const bool kok = (I % 32 == 0) || k0 < I;
-                const float *src = img + 4 * (kok ? k0 : 0);
-                const f32x4 u0 = *reinterpret_cast<const f32x4 *>(src), u1 = *reinterpret_cast<const f32x4 *>(src + 16);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    raw[kb][j] = kok ? u0[j] : 0.0f;
-                    raw[kb][4 + j] = kok ? u1[j] : 0.0f;
+                    raw[kb][j] = kok ? xr[sset][kb][0][j] : 0.0f;
+                    raw[kb][4 + j] = kok ? xr[sset][kb][1][j] : 0.0f;
                     amax = fmaxf(amax, fmaxf(fabsf(raw[kb][j]), fabsf(raw[kb][4 + j])));
                 }
             }
@@ -600,17 +594,16 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
 
         __syncthreads();
         if (leader) {
-            const int nb0 = min(XSLOTS, NG);
-            for (int blk = 0; blk < nb0; blk++)
-                for (int j = 0; j < 2 * NREQ; j++) dma_request(blk, j);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (int G2 = 0; G2 < 2; G2++) {
-                for (int sset = 0; sset < 2; sset++) {
-                    split_scale(G2, sset);
+            static_for<0, 2>([&](auto GC) {
+                static_for<0, 2>([&](auto SC) {
+                    load_x(decltype(GC)::value, SC);
+                    split_scale(decltype(GC)::value, SC);
 #pragma unroll
-                    for (int kb = 0; kb < KBLK; kb++) split_block(G2, sset, kb);
-                }
-            }
+                    for (int kb = 0; kb < KBLK; kb++) split_block(decltype(GC)::value, decltype(SC)::value, kb);
+                });
+            });
+            load_x(2, ic<0>{});                          // group 2: split during group 0
+            load_x(2, ic<1>{});
         }
         lds_bar();
         half8 xh[2][KBLK], xl[2][KBLK];
@@ -680,12 +673,13 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
             if constexpr ((S0 || S1) && !(BAR16D_ABL & 2) && (hi == lo || !BAR16D_HOOKS)) {   // the split on its own, then the tiles
                 static_for<lo, hi>([&](auto TC) { project_tile(TC, G1, no_hook); });
                 if (leader && G1 > 0) {
-                    if constexpr (kb == 0) split_scale(G1 + 1, sset);
+                    if constexpr (kb == 0) split_scale(G1 + 1, ic<sset>{});
                     split_block(G1 + 1, sset, kb);
+                    if constexpr (kb == KBLK - 1) load_x(G1 + 2, ic<sset>{});
                 }
             } else if constexpr ((S0 || S1) && !(BAR16D_ABL & 2)) {
                 if (leader && G1 > 0) {
-                    if constexpr (kb == 0) split_scale(G1 + 1, sset);
+                    if constexpr (kb == 0) split_scale(G1 + 1, ic<sset>{});
                     project_tile(ic<lo>{}, G1, [&](auto HC) {
                         constexpr int i = decltype(HC)::value;
                         if constexpr ((i & 1) && i < 16) split_piece(kb, i >> 1);
@@ -697,6 +691,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                             split_store(G1 + 1, sset, kb);
                         }
                     });
+                    if constexpr (kb == KBLK - 1) load_x(G1 + 2, ic<sset>{});
                 } else {
                     project_tile(ic<lo>{}, G1, no_hook);
                 }
@@ -718,16 +713,6 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
             lds_bar();
             DSTAMP_OUT(k)
             if constexpr (BAR16D_ABL & 1) return;
-            if (leader) {
-                if constexpr (k == 0) {
-                    // block G+2 (split from here on) was requested during group G-1 and nothing since
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                if (G + XSLOTS < NG) {
-                    if (2 * k < 2 * NREQ) dma_request(G + XSLOTS, 2 * k);
-                    if (2 * k + 1 < 2 * NREQ) dma_request(G + XSLOTS, 2 * k + 1);
-                }
-            }
             if constexpr (k == 0) load_operands(G + 1);
             project_interval(KC, G + 1);
         };
@@ -766,7 +751,7 @@ extern "C" int slk_gru_bar16d_launch(const float *x, long ldx, const float *iW, 
     if ((ldy & 1) || (reinterpret_cast<uintptr_t>(y) & 7)) return SLK_ERR_UNSUPPORTED;          // 8-byte state stores
 #define BAR16D(II, NN) \
     if (insize == II && n == NN) return launch_bar16d<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s);
-    BAR16D(96, 96) BAR16D(64, 64) BAR16D(32, 96) BAR16D(64, 96) BAR16D(48, 32) BAR16D(16, 64)
+    BAR16D(96, 96) BAR16D(64, 64) BAR16D(32, 96) BAR16D(128, 96) BAR16D(64, 96) BAR16D(48, 32) BAR16D(16, 64)
 #undef BAR16D
     return SLK_ERR_UNSUPPORTED;
 }
