@@ -119,3 +119,21 @@ __device__ __forceinline__ void block_mfma_acc(f32x4 &acc, const half8 &w_hi, co
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi), "v"(x_hi));
 }
 
+// z products of one K block for the wave's two tiles, weights in accumulation registers, the two accumulation chains interleaved
+// (per accumulator the order of the terms is that of mfma3)
+template <bool FIRST>
+__device__ __forceinline__ void z_block_mfma(f32x4 &a0, f32x4 &a1, const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi,
+                                             const half8 &w1_lo, const half8 &bh, const half8 &bl)
+{
+    if constexpr (FIRST) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a0) : "a"(w0_hi), "v"(bl));
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a1) : "a"(w1_hi), "v"(bl));
+    } else {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_hi), "v"(bl));
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bl));
+    }
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_lo), "v"(bh));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_lo), "v"(bh));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_hi), "v"(bh));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bh));
+}

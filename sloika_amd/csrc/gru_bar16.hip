@@ -207,6 +207,17 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 }
             }
         }
+        // ZACC (ABL & 128, an experiment kept for the record): the update gate's weights in accumulation registers, its MFMAs as
+        // asm -- what gru_bar16d.hip needs to make room for its second value per gate.  Here it frees 48 registers the wave
+        // does not need: 1898 instead of 1880 cycles per step (alternating launches, tools/bar16_wg_times.py --ab).
+        constexpr bool ZACC = (ABL & 128) != 0;
+        if constexpr (ZACC) {
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+#pragma unroll
+                for (int i = 0; i < KBS; i++) { wz_hi[p][i] = to_acc_regs(wz_hi[p][i]); wz_lo[p][i] = to_acc_regs(wz_lo[p][i]); }
+            }
+        }
         constexpr int CTA = CT > 0 ? CT : 1;
         half8 pw_hi[CTA][KBLK], pw_lo[CTA][KBLK];
         f32x4 pacc[CTA];
@@ -325,9 +336,16 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 __builtin_amdgcn_sched_barrier(0);
             }
             BSTAMP(2)
+            if constexpr (ZACC && !(ABL & 2)) {
+                static_for<0, KBS - 1>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    z_block_mfma<i == 0>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i]);
+                });
+            } else {
 #pragma unroll
-            for (int i = 0; i < KBS - 1; i++)
-                mfma3x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i], accZ[0], accZ[1]);
+                for (int i = 0; i < KBS - 1; i++)
+                    mfma3x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i], accZ[0], accZ[1]);
+            }
             float rr[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) rr[p] = (ABL & 4) ? fmaf(pick(accR[p]), inv_r[p], vr[p]) * 0.01f : sigmoid4(fmaf(pick(accR[p]), inv_r[p], vr[p]));
@@ -366,8 +384,12 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 xl = ldH(xop_lo, ob);
             }
             __builtin_amdgcn_sched_barrier(0);
-            mfma3x2(wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1], bl[KBS - 1], accZ[0],
-                    accZ[1]);
+            if constexpr (ZACC && !(ABL & 2))
+                z_block_mfma<KBS == 1>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1],
+                                       bl[KBS - 1]);
+            else
+                mfma3x2(wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1], bl[KBS - 1], accZ[0],
+                        accZ[1]);
             f32x4 accC[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             mfma3x2(wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0], accC[0], accC[1]);
             __builtin_amdgcn_sched_barrier(0);
@@ -380,6 +402,11 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
 #pragma unroll
             for (int i = 1; i < KBS; i++)
                 mfma3x2(wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i], accC[0], accC[1]);
+            // asm MFMAs wrote the z accumulators: six candidate MFMAs (or the drain) have been issued since the last of them
+            if constexpr (ZACC && !(ABL & 2)) {
+                if constexpr (KBS == 1) { mfma_drain(accZ[0]); mfma_drain(accZ[1]); }
+                else asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]));
+            }
             float zz[2], omz[2], zh[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
@@ -672,7 +699,7 @@ static int launch_bar16(const float *x, long ldx, const float *iW, const float *
         DIAG_LAUNCH(1, true, 0) DIAG_LAUNCH(2, false, 1) DIAG_LAUNCH(3, false, 2) DIAG_LAUNCH(4, false, 4) DIAG_LAUNCH(5, false, 8)
         DIAG_LAUNCH(6, false, 16) DIAG_LAUNCH(7, false, 9) DIAG_LAUNCH(8, false, 3) DIAG_LAUNCH(9, false, 11) DIAG_LAUNCH(10, false, 31)
         DIAG_LAUNCH(11, false, 32) DIAG_LAUNCH(12, false, 34) DIAG_LAUNCH(13, false, 40) DIAG_LAUNCH(14, false, 42) DIAG_LAUNCH(15, false, 36)
-        DIAG_LAUNCH(16, false, 96)
+        DIAG_LAUNCH(16, false, 96) DIAG_LAUNCH(17, false, 128) DIAG_LAUNCH(18, false, 160)
 #undef DIAG_LAUNCH
     }
     if (zr_out) {

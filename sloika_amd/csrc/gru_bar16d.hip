@@ -59,25 +59,6 @@ extern "C" int slk_debug_read_bar16d(unsigned long long *host_out)
         tprev = tnow;                                                                 \
     }
 
-// z products of one K block for the wave's two tiles, weights in accumulation registers, the two accumulation chains interleaved
-// (per accumulator the order of the terms is that of mfma3)
-template <bool FIRST>
-__device__ __forceinline__ void z_block_mfma(f32x4 &a0, f32x4 &a1, const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi,
-                                             const half8 &w1_lo, const half8 &bh, const half8 &bl)
-{
-    if constexpr (FIRST) {
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a0) : "a"(w0_hi), "v"(bl));
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a1) : "a"(w1_hi), "v"(bl));
-    } else {
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_hi), "v"(bl));
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bl));
-    }
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_lo), "v"(bh));
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_lo), "v"(bh));
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_hi), "v"(bh));
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bh));
-}
-
 // One projection tile for both sets, weights in accumulation registers: the two accumulation chains alternate (consecutive
 // MFMAs never depend on each other) and hook(ic<i>) runs after MFMA i = 0 .. 6 KBLK - 1 -- the matrix pipe keeps the wave's issue
 // port for 4 cycles of every 16, the leader's split of x is cut into pieces that fill the rest.
