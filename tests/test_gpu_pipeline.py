@@ -121,11 +121,13 @@ def test_raw_chunk_worker_and_seqprinter(oracle, golden_bio, golden_decode):
     assert sp.fh.getvalue() == g["text"] and nb == g["nbases"]
 
 
-@pytest.mark.parametrize("name,B", [("raw_0.98_rgrgr", 1024), ("baseline_raw_gru", 256)])
+@pytest.mark.parametrize("name,B", [("raw_0.98_rgrgr", 1024), ("baseline_raw_gru", 256), ("raw_0.98_rgrgr", 2048)])
 def test_full_size_batch_sampled_chunks_vs_oracle(oracle, name, B):
     """BASELINE.json configs[2] / configs[1] at FULL size (4000-sample chunks, batch 1024 / 256): eight chunks picked at
     random out of the batch are compared with the oracle run on those chunks alone -- posteriors relative to each row's
-    maximum, and the decoded paths against the oracle's decoder on the device's own log-posteriors."""
+    maximum, and the decoded paths against the oracle's decoder on the device's own log-posteriors.  Batch 2048 is two
+    batches handed over as one call (bench.py's `as_one_batch`): the recurrent layers run eight chunks per workgroup and the
+    decoder one wave per chunk."""
     torch = need_gpu()
     from sloika_amd import _lib, models, pipeline
     net = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=13))
@@ -163,3 +165,17 @@ def test_full_size_batch_properties():
     for lo, hi in ((0, 4), (13, 14), (60, 64)):
         s, p, l = bc.call_chunks(dev(chunks[lo:hi]))
         assert torch.equal(p, p_all[lo:hi]) and torch.equal(l, l_all[lo:hi]) and torch.equal(s, s_all[lo:hi])
+
+
+def test_double_batch_equals_two_batches():
+    """Two batches of 1024 chunks as ONE call take other kernels than each on its own (csrc/gru_bar16d.hip, the one-wave-per-
+    chunk decoder) -- and must give the same bits: paths, lengths and scores."""
+    torch = need_gpu()
+    from sloika_amd import models, pipeline
+    net = models.randomise_zero_layers(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=21))
+    bc = pipeline.Basecaller(net)
+    chunks = dev(pipeline.synthetic_chunks(2048, chunk_len=2000, seed=5))
+    s2, p2, l2 = bc.call_chunks(chunks)
+    for lo in (0, 1024):
+        s1, p1, l1 = bc.call_chunks(chunks[lo:lo + 1024])
+        assert torch.equal(p1, p2[lo:lo + 1024]) and torch.equal(l1, l2[lo:lo + 1024]) and torch.equal(s1, s2[lo:lo + 1024])
