@@ -137,3 +137,29 @@ __device__ __forceinline__ void z_block_mfma(f32x4 &a0, f32x4 &a1, const half8 &
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_hi), "v"(bh));
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bh));
 }
+// the same with hook(ic<BASE + i>) after MFMA i = 0..5: pieces of the wave's vector work that fill the issue gaps (a wave whose
+// MFMAs follow each other directly waits 16 cycles per instruction for the pipe)
+template <bool FIRST, int BASE, class F>
+__device__ __forceinline__ void z_block_mfma_hooked(f32x4 &a0, f32x4 &a1, const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi,
+                                                    const half8 &w1_lo, const half8 &bh, const half8 &bl, F &&hook)
+{
+    if constexpr (FIRST) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a0) : "a"(w0_hi), "v"(bl));
+        hook(ic<BASE + 0>{});
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a1) : "a"(w1_hi), "v"(bl));
+        hook(ic<BASE + 1>{});
+    } else {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_hi), "v"(bl));
+        hook(ic<BASE + 0>{});
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bl));
+        hook(ic<BASE + 1>{});
+    }
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_lo), "v"(bh));
+    hook(ic<BASE + 2>{});
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_lo), "v"(bh));
+    hook(ic<BASE + 3>{});
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_hi), "v"(bh));
+    hook(ic<BASE + 4>{});
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bh));
+    hook(ic<BASE + 5>{});
+}
