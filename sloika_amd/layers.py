@@ -113,6 +113,11 @@ RECURRENT_F16 = os.environ.get("SLOIKA_AMD_RECURRENT_F32", "0") != "1"
 GRU_PLAN = os.environ.get("SLOIKA_AMD_GRU_PLAN", "bar")
 
 
+#: bits 8-9 of the `reverse` argument of slk_gru_bar16_f32 (0 = plan by batch size, 2 = eight chunks per workgroup): set by
+#: Parallel while it runs the directions of a birnn side by side at a batch where only the eight-chunk plan lets them share the chip
+_GRU_PLAN_BITS = 0
+
+
 def gru_f16_entry():
     """The C-ABI entry of the fp16-split fused Gru kernel selected by GRU_PLAN."""
     if GRU_PLAN not in ("bar", "flags"):
@@ -822,7 +827,8 @@ class Gru(RNN):
                                      f16x3_flops=6.0 * rows * n * (n + self.insize)) as reg:
                     rc = gru_f16_entry()(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
                                          self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
-                                         y.data_ptr(), _row_stride(y), T, B, self.insize, n, int(reverse),
+                                         y.data_ptr(), _row_stride(y), T, B, self.insize, n,
+                                         int(reverse) | ((_GRU_PLAN_BITS << 8) if GRU_PLAN == "bar" else 0),
                                          activation.act_id(self.fun), activation.act_id(self.gatefun),
                                          None if lens is None else lens.data_ptr(), None, _stream())
                     if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
@@ -958,17 +964,23 @@ class Parallel(Layer):
             main = torch.cuda.current_stream(x.device)
             ready = torch.cuda.Event()
             ready.record(main)
-            for i, layer in enumerate(self.layers):
-                st = main if i == 0 else streams[i - 1]
-                if st is not main:
-                    st.wait_event(ready)
-                with torch.cuda.stream(st):
-                    layer._forward(x, outs[:, :, off:off + layer.size], reverse)
-                if st is not main:
-                    done = torch.cuda.Event()
-                    done.record(st)
-                    main.wait_event(done)
-                off += layer.size
+            global _GRU_PLAN_BITS
+            keep = _GRU_PLAN_BITS
+            _GRU_PLAN_BITS = self._side_plan
+            try:
+                for i, layer in enumerate(self.layers):
+                    st = main if i == 0 else streams[i - 1]
+                    if st is not main:
+                        st.wait_event(ready)
+                    with torch.cuda.stream(st):
+                        layer._forward(x, outs[:, :, off:off + layer.size], reverse)
+                    if st is not main:
+                        done = torch.cuda.Event()
+                        done.record(st)
+                        main.wait_event(done)
+                    off += layer.size
+            finally:
+                _GRU_PLAN_BITS = keep
             return outs
         cat = torch.cat([layer._forward(x, None, reverse) for layer in self.layers], dim=2)
         if out is not None:
@@ -989,8 +1001,14 @@ class Parallel(Layer):
             if not isinstance(inner, (Gru, Lstm)):
                 return None
         ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+        self._side_plan = 0
         if ((B + 3) // 4) * len(self.layers) > ncu:
-            return None
+            # too many four-chunk workgroups to run together; eight chunks per workgroup (csrc/gru_bar16d.hip: 1.4 x the step
+            # time for twice the chunks) may still let the directions share the chip: B = 1024, two directions -> 2 x 128
+            grus = all(isinstance(l.layer if isinstance(l, Reverse) else l, Gru) for l in self.layers)
+            if not (grus and SPLIT_F16 and RECURRENT_F16 and GRU_PLAN == "bar" and ((B + 7) // 8) * len(self.layers) <= ncu):
+                return None
+            self._side_plan = 2
         key = (x.device.index, len(self.layers))
         if key not in Parallel._streams_cache:
             Parallel._streams_cache[key] = [torch.cuda.Stream(device=x.device) for _ in range(len(self.layers) - 1)]

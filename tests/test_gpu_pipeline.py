@@ -121,13 +121,15 @@ def test_raw_chunk_worker_and_seqprinter(oracle, golden_bio, golden_decode):
     assert sp.fh.getvalue() == g["text"] and nb == g["nbases"]
 
 
-@pytest.mark.parametrize("name,B", [("raw_0.98_rgrgr", 1024), ("baseline_raw_gru", 256), ("raw_0.98_rgrgr", 2048)])
+@pytest.mark.parametrize("name,B", [("raw_0.98_rgrgr", 1024), ("baseline_raw_gru", 256), ("raw_0.98_rgrgr", 2048),
+                                    ("bigger_raw_gru", 1024)])
 def test_full_size_batch_sampled_chunks_vs_oracle(oracle, name, B):
     """BASELINE.json configs[2] / configs[1] at FULL size (4000-sample chunks, batch 1024 / 256): eight chunks picked at
     random out of the batch are compared with the oracle run on those chunks alone -- posteriors relative to each row's
     maximum, and the decoded paths against the oracle's decoder on the device's own log-posteriors.  Batch 2048 is two
     batches handed over as one call (bench.py's `as_one_batch`): the recurrent layers run eight chunks per workgroup and the
-    decoder one wave per chunk."""
+    decoder one wave per chunk.  bigger_raw_gru at batch 1024 (configs[3] per GPU) runs the two directions of each birnn side
+    by side, eight chunks per workgroup each."""
     torch = need_gpu()
     from sloika_amd import _lib, models, pipeline
     net = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=13))
