@@ -251,7 +251,7 @@ def main():
     net = models.randomise_zero_layers(models.build_model(args.model, klen=5, sd=0.5, seed=11))
     nstream = max(1, args.streams)
     nslot = max(nstream, 2 if (args.overlap_steps > 0 and nstream == 1) else 1)     # the two_in_flight leg needs a second slot
-    bcs = [pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0) for _ in range(nslot)]
+    bcs = [pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, in_flight=nstream) for _ in range(nslot)]
     bc = bcs[0]
     streams = ([torch.cuda.Stream() for _ in range(nslot)] if nstream > 1
                else [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nslot - 1)])
@@ -348,9 +348,12 @@ def main():
         finally:
             _layers.SPLIT_F16, _layers.Softmax.split_f16 = keep
 
-    # the same workload with two batches in flight (two streams): batch i decodes while batch i+1 runs its recurrent layers
+    # the same workload with two batches in flight (two streams, Basecaller(in_flight=2)): batch i decodes while batch i+1 runs
+    # its recurrent layers, and two batches' recurrent layers share the chip on the eight-chunk plan
     overlap = None
     if args.overlap_steps > 0 and nstream == 1:
+        for bco in bcs:                       # every Basecaller is told that two batches are in flight (eight-chunk Gru plan)
+            bco.in_flight = 2
         for i in range(4):                    # the second slot allocates its buffers on first use
             step(i, 2)
         barrier()
@@ -363,6 +366,8 @@ def main():
             tm = torch.tensor([dto], dtype=torch.float64, device="cuda")
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dto = float(tm.item())
+        for bco in bcs:
+            bco.in_flight = nstream
         overlap = {"ms_per_step": dto / args.overlap_steps * 1e3, "value": world * B * L * args.overlap_steps / dto,
                    "unit": "samples/s", "steps": args.overlap_steps, "streams_per_gpu": 2}
         # ... and with the two batches handed over as ONE call of 2B chunks: a recurrent layer then runs the eight-chunk plan

@@ -13,13 +13,19 @@ from . import _lib, batch, decode, layers
 
 
 class Basecaller(object):
-    def __init__(self, network, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, normalisation='per-chunk'):
-        """skip default 0.0 is the CLI default (bin/basecall_network.py:38)."""
+    def __init__(self, network, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, normalisation='per-chunk', in_flight=1):
+        """skip default 0.0 is the CLI default (bin/basecall_network.py:38).
+
+        in_flight: how many batches the caller keeps in flight at a time, each on a HIP stream of its own (one Basecaller
+        per stream).  With two or more, a Gru layer runs eight chunks per workgroup (csrc/gru_bar16d.hip) whenever that lets
+        the layers of all the batches share the chip -- batch 1024, two in flight: 2 x 128 workgroups on 256 CUs -- instead of
+        one workgroup per four chunks each taking the whole device in turn."""
         if not isinstance(network, layers.Layer):
             raise TypeError("network must be a sloika_amd.layers.Layer")
         self.network = network
         self.kmer_len, self.nbase, self.min_prob, self.skip = kmer_len, nbase, min_prob, skip
         self.normalisation = normalisation
+        self.in_flight = max(1, int(in_flight))
         self._ws = decode.ViterbiWorkspace()
         _lib.lib()
 
@@ -40,8 +46,18 @@ class Basecaller(object):
         else:
             x = batch.normalise_chunks(cd, self.normalisation, out_layout='network')
             rest = seq[:upto]
-        for layer in rest:
-            x = layer._forward(x, None, False)
+        keep = layers._GRU_PLAN_BITS
+        if self.in_flight > 1 and keep == 0:
+            import torch
+            ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+            nchunk = x.shape[1]
+            if ((nchunk + 3) // 4) * self.in_flight > ncu and ((nchunk + 7) // 8) * self.in_flight <= ncu:
+                layers._GRU_PLAN_BITS = 2
+        try:
+            for layer in rest:
+                x = layer._forward(x, None, False)
+        finally:
+            layers._GRU_PLAN_BITS = keep
         return x
 
     def posteriors(self, chunks):

@@ -181,3 +181,15 @@ def test_double_batch_equals_two_batches():
     for lo in (0, 1024):
         s1, p1, l1 = bc.call_chunks(chunks[lo:lo + 1024])
         assert torch.equal(p1, p2[lo:lo + 1024]) and torch.equal(l1, l2[lo:lo + 1024]) and torch.equal(s1, s2[lo:lo + 1024])
+
+
+def test_in_flight_hint_changes_the_plan_not_the_result():
+    """Basecaller(in_flight=2) runs the Gru layers of a 1024-chunk batch eight chunks per workgroup (half the chip per batch):
+    same bits as the default."""
+    torch = need_gpu()
+    from sloika_amd import models, pipeline
+    net = models.randomise_zero_layers(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=22))
+    chunks = dev(pipeline.synthetic_chunks(1024, chunk_len=1500, seed=6))
+    s1, p1, l1 = pipeline.Basecaller(net).call_chunks(chunks)
+    s2, p2, l2 = pipeline.Basecaller(net, in_flight=2).call_chunks(chunks)
+    assert torch.equal(p1, p2) and torch.equal(l1, l2) and torch.equal(s1, s2)
