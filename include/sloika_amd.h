@@ -205,6 +205,13 @@ int slk_gru_fused_ragged_f32(const float *x, long ldx, const float *iW, const fl
                              int gate_act, const int32_t *lens, slk_stream_t stream);
 int slk_gru_recurrent_ragged_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
                                  int n, int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream);
+/* The same scan (Gru.step over a projection vI [T*B][ldv >= 3n] = x.iW^T + b in HBM; sloika/layers.py:1010-1021) for layers
+ * too wide for the fused kernels, on the execution plan of slk_gru_bar16_f32: recurrent products as 3-term fp16 splits, four
+ * waves stepping through two barriers per step (csrc/gru_scan16.hip).  n = 112 or 128 (models/pretrained.pkl,
+ * models/raw_1.00_rGr.py zero-padded), tanh / sigmoid; anything else SLK_ERR_UNSUPPORTED (-> slk_gru_recurrent_f32).
+ * lens (int32 [B], device) or NULL as for slk_gru_recurrent_ragged_f32.                                                  */
+int slk_gru_scan16_f32(const float *vI, long ldv, const float *sW, const float *sW2, float *y, long ldy, int T, int B, int n,
+                       int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream);
 /* Force the portable (non-MFMA) recurrence kernel: 0 = auto, 1 = force generic.  Testing aid; passed per call
  * through the `_ex` form so that there is still no global state.                                            */
 int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T,

@@ -1,0 +1,249 @@
+// gru_scan16.hip -- the scan of Gru.step (sloika/layers.py:1010-1021) for layers too wide for the fused kernels (n = 112 / 128:
+// models/pretrained.pkl, models/raw_1.00_rGr.py), on the execution plan of gru_bar16.hip: four waves per workgroup, one per
+// SIMD, two s_barrier per step, recurrent products as 3-term fp16 splits on v_mfma_f32_16x16x32_f16, states exchanged as packed
+// hi/lo halves through LDS, a lane owning one (neuron, chunk) pair per tile.
+//
+// What is different: at n = 128 all four waves are chain waves (32 neurons each, four 32-wide K blocks), so nobody is left to
+// compute the input projection -- it comes from HBM (vI = x.iW^T + b, written by the row GEMM), read by the lane that needs it
+// two steps ahead -- and the weights of a wave (2 tiles x 3 gates x 4 K blocks x hi/lo = 192 registers) do not fit next to
+// its working set: the update gate's and the candidate's live in accumulation registers and their MFMAs are asm (bar16_common.h).
+// Sizes below 128 (a multiple of 16) run with zero weights for the missing neurons: their state stays exactly 0.
+#include <limits.h>
+
+#include "bar16_common.h"
+
+// one float per lane from HBM, not tracked by the compiler: the caller counts (s_waitcnt vmcnt(n), then pin_f)
+__device__ __forceinline__ void gload1(float &dst, const float *src) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); }
+__device__ __forceinline__ void pin_f(float &v) { asm volatile("" : "+v"(v)); }
+
+template <int N>
+__global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restrict__ vI, long ldv, const float *__restrict__ sW,
+                                                            const float *__restrict__ sW2, float *__restrict__ h_out, long ldh, int T,
+                                                            int B, int n, int reverse, const int *__restrict__ lens)
+{
+    static_assert(N == 128, "four chain waves of 32 neurons");
+    constexpr int KBS = N / 32;
+
+    __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * N], h_lo[2 * N], rh_hi[2 * N], rh_lo[2 * N];
+
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int b0 = blockIdx.x * 4;
+    for (int i = tid; i < 2 * N; i += 256) { h_hi[i] = 0u; h_lo[i] = 0u; }             // h(-1) = 0
+    auto ldH = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
+
+    const int c = lane & 3, q = (lane >> 2) & 3, g = lane >> 4;
+    // recurrent weights: A operands, K blocks in the rotated order w, w+1, ... (element (g, j) of block kb is neuron
+    // 32 kb + 16 (j&1) + 4 g + (j>>1), the order the owners' packed writes create), rows scaled to [1, 2)
+    half8 wz_hi[2][KBS], wz_lo[2][KBS], wr_hi[2][KBS], wr_lo[2][KBS], wc_hi[2][KBS], wc_lo[2][KBS];
+    float inv_z[2], inv_r[2], inv_c[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int row = 32 * w + 16 * p + (lane & 15);
+        const bool rok = row < n;
+        float vz[KBS][8], vr[KBS][8], vc[KBS][8];
+        float mz = 0.0f, mr = 0.0f, mc = 0.0f;
+#pragma unroll
+        for (int i = 0; i < KBS; i++) {
+            const int kb = (w + i) % KBS;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = 32 * kb + 16 * (j & 1) + 4 * g + (j >> 1);
+                const bool ok = rok && k < n;
+                vz[i][j] = ok ? sW[(size_t)row * n + k] : 0.0f;
+                vr[i][j] = ok ? sW[(size_t)(n + row) * n + k] : 0.0f;
+                vc[i][j] = ok ? sW2[(size_t)row * n + k] : 0.0f;
+                mz = fmaxf(mz, fabsf(vz[i][j])); mr = fmaxf(mr, fabsf(vr[i][j])); mc = fmaxf(mc, fabsf(vc[i][j]));
+            }
+        }
+        float iz, ir, ic_;
+        const float sz = pow2_scale(kgroup_max(mz), iz), sr = pow2_scale(kgroup_max(mr), ir), sc = pow2_scale(kgroup_max(mc), ic_);
+        inv_z[p] = __shfl(iz, 4 * g + q); inv_r[p] = __shfl(ir, 4 * g + q); inv_c[p] = __shfl(ic_, 4 * g + q);
+#pragma unroll
+        for (int i = 0; i < KBS; i++) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float az = vz[i][j] * sz, ar = vr[i][j] * sr, ac = vc[i][j] * sc;
+                const _Float16 hz = (_Float16)az, hr = (_Float16)ar, hc = (_Float16)ac;
+                wz_hi[p][i][j] = hz; wz_lo[p][i][j] = (_Float16)(az - (float)hz);
+                wr_hi[p][i][j] = hr; wr_lo[p][i][j] = (_Float16)(ar - (float)hr);
+                wc_hi[p][i][j] = hc; wc_lo[p][i][j] = (_Float16)(ac - (float)hc);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+#pragma unroll
+        for (int i = 0; i < KBS; i++) {
+            wz_hi[p][i] = to_acc_regs(wz_hi[p][i]); wz_lo[p][i] = to_acc_regs(wz_lo[p][i]);
+            wc_hi[p][i] = to_acc_regs(wc_hi[p][i]); wc_lo[p][i] = to_acc_regs(wc_lo[p][i]);
+        }
+    }
+    int boff[KBS];
+#pragma unroll
+    for (int i = 0; i < KBS; i++) boff[i] = ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
+    const int wd = ((w * 4 + g) * 4 + c) * 4 + q;                                           // my packed pair, in dwords
+    const int n0 = 32 * w + 4 * g + q;                                                      // my neuron of tile 2w (+16: 2w+1)
+    const bool nok0 = n0 < n, nok1 = n0 + 16 < n;
+    // my chunk's rows (ragged batch: chunk bc is Tc <= T steps long; a reversed scan starts at ITS last step)
+    const int bc = b0 + c;
+    const bool live = bc < B;
+    const int bcc = live ? bc : B - 1;
+    const int Tc = (lens && live) ? min(max(lens[bc], 1), T) : T;
+    const long hstep = (reverse ? -1L : 1L) * (long)B * ldh;
+    float *hp = h_out + ((size_t)(reverse ? Tc - 1 : 0) * B + bcc) * ldh + n0;
+    // vI of step s for my two (neuron, chunk) pairs: z | r | c blocks of n floats per row; steps past the chunk's end re-read its
+    // last row (their results are never stored), neurons past n are zero
+    // Four register sets, step s uses set s % 4 and requests step s + 3 into the set step s - 1 used: no copies of values still in
+    // flight.  The loads are asm (the compiler would wait for ALL outstanding memory operations at the first use -- the wave also has
+    // stores in flight); loads complete in order among themselves, so once at most 18 operations are outstanding (the loads of the
+    // three younger steps) those of the current step have arrived, whatever the stores do.
+    struct VI { float z[2], r[2], c[2]; };
+    VI vs[4];
+    auto load_vi = [&](int s, VI &v) {
+        const int ss = min(s, Tc - 1);
+        const int tt = reverse ? Tc - 1 - ss : ss;
+        const float *row = vI + ((size_t)tt * B + bcc) * ldv + (nok0 ? n0 : 0);
+        const float *row1 = row + (nok1 ? 16 : 0);
+        gload1(v.z[0], row); gload1(v.r[0], row + n); gload1(v.c[0], row + 2 * n);
+        gload1(v.z[1], row1); gload1(v.r[1], row1 + n); gload1(v.c[1], row1 + 2 * n);
+    };
+    load_vi(0, vs[0]);
+    load_vi(1, vs[1]);
+    load_vi(2, vs[2]);
+
+    __syncthreads();                                     // LDS initialised
+    float hold[2] = {0.0f, 0.0f};
+    half8 oh = {0, 0, 0, 0, 0, 0, 0, 0}, ol = {0, 0, 0, 0, 0, 0, 0, 0};      // my own K block of h(s-1) as B operand
+    auto step = [&](auto PHC, const int s) {
+        constexpr int ph = decltype(PHC)::value;
+        VI &cur = vs[ph];
+        // ------------------------------ interval A ------------------------------
+        lds_bar_2reads();
+        half8 bh[KBS], bl[KBS];
+        bh[0] = oh;
+        bl[0] = ol;
+#pragma unroll
+        for (int i = 1; i < KBS; i++) { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+        load_vi(s + 3, vs[(ph + 3) & 3]);                // three steps ahead
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2], accC[2];
+        mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
+        z_block_mfma<true>(accZ[0], accZ[1], wz_hi[0][0], wz_lo[0][0], wz_hi[1][0], wz_lo[1][0], bh[0], bl[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 1; i < KBS; i++)
+            mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // z products of blocks 1 .. KBS-2 under the r epilogue
+        static_for<1, KBS - 1>([&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            z_block_mfma<false>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i]);
+        });
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");                 // this step's vI (see above)
+        pin_f(cur.z[0]); pin_f(cur.z[1]); pin_f(cur.r[0]); pin_f(cur.r[1]); pin_f(cur.c[0]); pin_f(cur.c[1]);
+        float rr[2];
+        rr[0] = nok0 ? sigmoid4(fmaf(sel4(accR[0], q), inv_r[0], cur.r[0])) : 0.0f;
+        rr[1] = nok1 ? sigmoid4(fmaf(sel4(accR[1], q), inv_r[1], cur.r[1])) : 0.0f;
+        {
+            unsigned hi, lo;
+            split2(rr[0] * hold[0], rr[1] * hold[1], hi, lo);
+            lds_fence();
+            rh_hi[wd] = hi;
+            rh_lo[wd] = lo;
+        }
+        half8 ch[KBS], cl[KBS];
+        ch[0] = ldH(rh_hi, boff[0]);                     // my own block, straight back (LDS executes a wave's operations in order)
+        cl[0] = ldH(rh_lo, boff[0]);
+        lds_fence();
+        // ------------------------------ interval B ------------------------------
+        lds_bar_2reads();
+#pragma unroll
+        for (int i = 1; i < KBS; i++) { ch[i] = ldH(rh_hi, boff[i]); cl[i] = ldH(rh_lo, boff[i]); }
+        __builtin_amdgcn_sched_barrier(0);
+        z_block_mfma<false>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1],
+                            bl[KBS - 1]);
+        z_block_mfma<true>(accC[0], accC[1], wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 1; i < KBS; i++) { keep(ch[i]); keep(cl[i]); }
+        __builtin_amdgcn_sched_barrier(0);
+        z_block_mfma<false>(accC[0], accC[1], wc_hi[0][1], wc_lo[0][1], wc_hi[1][1], wc_lo[1][1], ch[1], cl[1]);
+        // the z accumulators: twelve MFMAs have been issued since their last one
+        asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]));
+        float zz[2], omz[2], zh[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            zz[p] = sigmoid4(fmaf(sel4(accZ[p], q), inv_z[p], cur.z[p]));
+            omz[p] = 1.0f - zz[p];
+            zh[p] = zz[p] * hold[p];
+            asm volatile("" : "+v"(zh[p]), "+v"(omz[p]));                 // pinned here: not sunk to the blend below
+        }
+        static_for<2, KBS>([&](auto IC) {
+            constexpr int i = decltype(IC)::value;
+            z_block_mfma<false>(accC[0], accC[1], wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i]);
+        });
+        mfma_drain(accC[0]);
+        mfma_drain(accC[1]);
+        float hn[2];
+        {
+            const float hb0 = tanh5(fmaf(sel4(accC[0], q), inv_c[0], cur.c[0])), hb1 = tanh5(fmaf(sel4(accC[1], q), inv_c[1], cur.c[1]));
+            hn[0] = nok0 ? fmaf(omz[0], hb0, zh[0]) : 0.0f;               // layers.py:1020
+            hn[1] = nok1 ? fmaf(omz[1], hb1, zh[1]) : 0.0f;
+        }
+        {
+            unsigned hi, lo;
+            split2(hn[0], hn[1], hi, lo);
+            lds_fence();
+            h_hi[wd] = hi;
+            h_lo[wd] = lo;
+        }
+        oh = ldH(h_hi, boff[0]);
+        ol = ldH(h_lo, boff[0]);
+        lds_fence();
+        if (live && s < Tc) {
+            if (nok0) hp[0] = hn[0];
+            if (nok1) hp[16] = hn[1];
+        }
+        hp += hstep;
+        hold[0] = hn[0];
+        hold[1] = hn[1];
+    };
+    for (int s = 0; s < T; s += 4) {
+        step(ic<0>{}, s);
+        if (s + 1 < T) step(ic<1>{}, s + 1);
+        if (s + 2 < T) step(ic<2>{}, s + 2);
+        if (s + 3 < T) step(ic<3>{}, s + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing of mine may land in registers after the wave has ended
+}
+
+// One workgroup per CU: ask for enough dynamic LDS that two cannot share a CU (each wave is compiled for a whole SIMD's registers).
+static size_t scan16_exclusive_lds()
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(gru_scan16_kernel<128>)) != hipSuccess) return 0;
+    const size_t half_cu = 80 * 1024 + 512;
+    const size_t dyn = attr.sharedSizeBytes >= half_cu ? 0 : half_cu - attr.sharedSizeBytes;
+    if (dyn && hipFuncSetAttribute(reinterpret_cast<const void *>(gru_scan16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)dyn) != hipSuccess)
+        return 0;
+    return dyn;
+}
+
+// include/sloika_amd.h
+extern "C" int slk_gru_scan16_f32(const float *vI, long ldv, const float *sW, const float *sW2, float *y, long ldy, int T, int B, int n,
+                                  int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream)
+{
+    if (!vI || !sW || !sW2 || !y || T < 1 || B < 1 || n < 1 || ldv < 3L * n || ldy < n) return SLK_ERR_INVALID_ARG;
+    if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
+    if (n % 16 || n <= 96 || n > 128) return SLK_ERR_UNSUPPORTED;
+    static const size_t dyn = scan16_exclusive_lds();
+    hipLaunchKernelGGL((gru_scan16_kernel<128>), dim3((B + 3) / 4), dim3(256), dyn, slk_stream(stream), vI, ldv, sW, sW2, y, ldy, T, B, n,
+                       reverse & 1, lens);
+    return slk_launch_status();
+}

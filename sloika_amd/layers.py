@@ -858,7 +858,15 @@ class Gru(RNN):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 3 * n, "gru_input_gemm", "Gru")
         with profiler.region("gru_recurrent", 6.0 * rows * n * n, 4.0 * rows * 4 * n):
-            if lens is None:
+            rc = _lib.SLK_ERR_UNSUPPORTED
+            if SPLIT_F16 and RECURRENT_F16:
+                # n = 112 / 128: the barrier-stepped scan on the fp16 split (csrc/gru_scan16.hip)
+                rc = L.slk_gru_scan16_f32(ws.data_ptr(), 3 * n, self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), y.data_ptr(),
+                                          _row_stride(y), T, B, n, int(reverse), activation.act_id(self.fun),
+                                          activation.act_id(self.gatefun), None if lens is None else lens.data_ptr(), _stream())
+            if rc != _lib.SLK_ERR_UNSUPPORTED:
+                pass
+            elif lens is None:
                 rc = L.slk_gru_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
                                              y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
                                              activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
