@@ -12,6 +12,11 @@
 
 #include "bar16_common.h"
 
+// 1: the update gate's products with the wave's own K block right behind the reset gate's, inside the LDS round trip (0: behind the
+// reset gate's other blocks; measured equal)
+#ifndef SCAN16_Z0_EARLY
+#define SCAN16_Z0_EARLY 1
+#endif
 // one float per lane from HBM, not tracked by the compiler: the caller counts (s_waitcnt vmcnt(n), then pin_f)
 __device__ __forceinline__ void gload1(float &dst, const float *src) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); }
 __device__ __forceinline__ void pin_f(float &v) { asm volatile("" : "+v"(v)); }
@@ -128,7 +133,9 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         __builtin_amdgcn_sched_barrier(0);
         f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2], accC[2];
         mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
+#if SCAN16_Z0_EARLY
         z_block_mfma<true>(accZ[0], accZ[1], wz_hi[0][0], wz_lo[0][0], wz_hi[1][0], wz_lo[1][0], bh[0], bl[0]);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -138,7 +145,10 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         for (int i = 1; i < KBS; i++)
             mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
         __builtin_amdgcn_sched_barrier(0);
-        // z products of blocks 1 .. KBS-2 under the r epilogue
+        // z products of blocks 0 .. KBS-2 under the r epilogue
+#if !SCAN16_Z0_EARLY
+        z_block_mfma<true>(accZ[0], accZ[1], wz_hi[0][0], wz_lo[0][0], wz_hi[1][0], wz_lo[1][0], bh[0], bl[0]);
+#endif
         static_for<1, KBS - 1>([&](auto IC) {
             constexpr int i = decltype(IC)::value;
             z_block_mfma<false>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i]);
