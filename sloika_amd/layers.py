@@ -116,6 +116,17 @@ GRU_PLAN = os.environ.get("SLOIKA_AMD_GRU_PLAN", "bar")
 #: bits 8-9 of the `reverse` argument of slk_gru_bar16_f32 (0 = plan by batch size, 2 = eight chunks per workgroup): set by
 #: Parallel while it runs the directions of a birnn side by side at a batch where only the eight-chunk plan lets them share the chip
 _GRU_PLAN_BITS = 0
+#: batches the caller keeps in flight on streams of their own (pipeline.Basecaller(in_flight=N) sets it around a forward pass): a
+#: recurrent layer then counts N times its workgroups when it decides whether they fit the device's CUs together
+_IN_FLIGHT = 1
+
+
+def _gru_plan_for(B, share, ncu):
+    """Plan bits for `share` Gru launches of batch B that are meant to run at the same time: 0 when their four-chunk
+    workgroups fit the CUs together (or nothing helps), 2 when only the eight-chunk ones do."""
+    if ((B + 3) // 4) * share <= ncu:
+        return 0
+    return 2 if ((B + 7) // 8) * share <= ncu else 0
 
 
 def gru_f16_entry():
@@ -761,6 +772,15 @@ class Gru(RNN):
             params += [self.b]
         return params
 
+    @staticmethod
+    def _plan_bits(x, B):
+        """Bits 8-9 of `reverse` for slk_gru_bar16_f32: what Parallel decided for its side-by-side sub-layers, else eight chunks
+        per workgroup when that is what lets the batches in flight share the chip."""
+        if _GRU_PLAN_BITS or _IN_FLIGHT <= 1:
+            return _GRU_PLAN_BITS
+        import torch
+        return _gru_plan_for(B, _IN_FLIGHT, torch.cuda.get_device_properties(x.device).multi_processor_count)
+
     def _padded(self):
         """Zero-padded copy of this layer with input and output sizes rounded up to multiples of 16 (what the MFMA
         kernels are instantiated for).  Padding neurons see zero weights and zero bias, so their state stays exactly 0
@@ -828,7 +848,7 @@ class Gru(RNN):
                     rc = gru_f16_entry()(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
                                          self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
                                          y.data_ptr(), _row_stride(y), T, B, self.insize, n,
-                                         int(reverse) | ((_GRU_PLAN_BITS << 8) if GRU_PLAN == "bar" else 0),
+                                         int(reverse) | ((self._plan_bits(x, B) << 8) if GRU_PLAN == "bar" else 0),
                                          activation.act_id(self.fun), activation.act_id(self.gatefun),
                                          None if lens is None else lens.data_ptr(), None, _stream())
                     if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
@@ -1010,14 +1030,16 @@ class Parallel(Layer):
                 return None
         ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
         self._side_plan = 0
-        if ((B + 3) // 4) * len(self.layers) > ncu:
+        share = len(self.layers) * max(1, _IN_FLIGHT)
+        if ((B + 3) // 4) * share > ncu:
             # too many four-chunk workgroups to run together; eight chunks per workgroup (csrc/gru_bar16d.hip: 1.4 x the step
             # time for twice the chunks) may still let the directions share the chip: B = 1024, two directions -> 2 x 128
             grus = all(isinstance(l.layer if isinstance(l, Reverse) else l, Gru) for l in self.layers)
-            if not (grus and SPLIT_F16 and RECURRENT_F16 and GRU_PLAN == "bar" and ((B + 7) // 8) * len(self.layers) <= ncu):
+            if not (grus and SPLIT_F16 and RECURRENT_F16 and GRU_PLAN == "bar" and _gru_plan_for(B, share, ncu) == 2):
                 return None
             self._side_plan = 2
-        key = (x.device.index, len(self.layers))
+        # side streams belong to the stream the caller runs on: batches in flight on different streams must not meet on one
+        key = (x.device.index, len(self.layers), torch.cuda.current_stream(x.device).cuda_stream)
         if key not in Parallel._streams_cache:
             Parallel._streams_cache[key] = [torch.cuda.Stream(device=x.device) for _ in range(len(self.layers) - 1)]
         return Parallel._streams_cache[key]

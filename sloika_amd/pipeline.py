@@ -46,18 +46,13 @@ class Basecaller(object):
         else:
             x = batch.normalise_chunks(cd, self.normalisation, out_layout='network')
             rest = seq[:upto]
-        keep = layers._GRU_PLAN_BITS
-        if self.in_flight > 1 and keep == 0:
-            import torch
-            ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
-            nchunk = x.shape[1]
-            if ((nchunk + 3) // 4) * self.in_flight > ncu and ((nchunk + 7) // 8) * self.in_flight <= ncu:
-                layers._GRU_PLAN_BITS = 2
+        keep = layers._IN_FLIGHT
+        layers._IN_FLIGHT = self.in_flight
         try:
             for layer in rest:
                 x = layer._forward(x, None, False)
         finally:
-            layers._GRU_PLAN_BITS = keep
+            layers._IN_FLIGHT = keep
         return x
 
     def posteriors(self, chunks):
