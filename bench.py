@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--overlap-steps", type=int, default=10,
                     help="steps timed after the main region with TWO batches in flight on two streams, for the `two_in_flight` "
                          "entry of the line (0 = skip); the main region and `value` always use --streams (default 1)")
+    ap.add_argument("--small-batch-steps", type=int, default=6,
+                    help="steps of BASELINE.json configs[1] (baseline_raw_gru, batch 256) timed after the main region, one batch at "
+                         "a time and four in flight, for the `batch256` field (default workload on one GPU only; 0 = skip)")
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (BASELINE.json configs[4]: forward + backward + ADAMski, "
                          "gradient all-reduce over RCCL when --gpus > 1); prints the same kind of JSON line")
@@ -406,6 +409,48 @@ def main():
                                        "note": "ms_per_step is per %d chunks; one call carries two batches" % B}
             del pair
 
+    # BASELINE.json configs[1] -- the batch north_star quotes (baseline_raw_gru, 256 chunks of 4000 samples): every stage is
+    # latency bound at that size (64 workgroups per recurrent launch, 256 decoder workgroups), so the device only fills up with
+    # several batches in flight
+    small = None
+    if (args.small_batch_steps > 0 and world == 1 and nstream == 1 and args.model == "raw_0.98_rgrgr" and args.batch == 1024
+            and not args.with_bases):
+        net1 = models.randomise_zero_layers(models.build_model("baseline_raw_gru", klen=5, sd=0.5, seed=11))
+        B1, nfl = 256, 4
+        bcs1 = [pipeline.Basecaller(net1, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0) for _ in range(nfl)]
+        st1 = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nfl - 1)]
+        dev1 = [torch.from_numpy(pipeline.synthetic_chunks(B1, chunk_len=L, seed=0xfeed, first_chunk=i * B1)).cuda() for i in range(nfl)]
+        tout1 = bcs1[0].network.layers[0].out_len(L)
+        host1 = [torch.empty((B1, tout1), dtype=torch.int32).pin_memory() for _ in range(nfl)]
+
+        def step1(i, nact):
+            k = i % nact
+            with torch.cuda.stream(st1[k]):
+                scores, paths, lens = bcs1[k].call_chunks(dev1[k])
+                paths.record_stream(copy_stream)
+                done = torch.cuda.Event()
+                done.record(st1[k])
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done)
+                host1[k][:, : paths.shape[1]].copy_(paths, non_blocking=True)
+
+        small = {"workload": "baseline_raw_gru inference, %d-sample chunks, batch %d (BASELINE.json configs[1])" % (L, B1)}
+        for nact, key in ((1, "one_at_a_time"), (nfl, "four_in_flight")):
+            for bco in bcs1:
+                bco.in_flight = nact
+            for i in range(2 * nact):
+                step1(i, nact)
+            barrier()
+            t4 = time.perf_counter()
+            nst = args.small_batch_steps * nact
+            for i in range(nst):
+                step1(i, nact)
+            barrier()
+            d4 = time.perf_counter() - t4
+            small[key] = {"ms_per_step": d4 / nst * 1e3, "value": B1 * L * nst / d4, "unit": "samples/s", "steps": nst,
+                          "streams_per_gpu": nact}
+        del bcs1, dev1
+
     stages = rec.summary() if rec is not None else {}
     roofline = None
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/collect_pmc.sh);
@@ -465,6 +510,7 @@ def main():
             "cpu_baseline": cpu,
             "exact_f32": exact,
             "two_in_flight": overlap,
+            "batch256": small,
             "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())},
             "e2e_algorithmic_tflops": (gemm_flops / (dt / args.steps) / 1e12) if stages else None,
         }
