@@ -117,7 +117,8 @@ GRU_PLAN = os.environ.get("SLOIKA_AMD_GRU_PLAN", "bar")
 #: Parallel while it runs the directions of a birnn side by side at a batch where only the eight-chunk plan lets them share the chip
 _GRU_PLAN_BITS = 0
 #: batches the caller keeps in flight on streams of their own (pipeline.Basecaller(in_flight=N) sets it around a forward pass): a
-#: recurrent layer then counts N times its workgroups when it decides whether they fit the device's CUs together
+#: recurrent layer then counts N times its workgroups when it decides whether they fit the device's CUs together.  (Both are
+#: process-wide, like the reference's module-level Theano configuration: one Python thread issues the launches of a process.)
 _IN_FLIGHT = 1
 
 
