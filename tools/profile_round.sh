@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 mkdir -p gpurun_out
 python3 bench.py --steps 20 --warmup 3 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 rm -rf gpurun_out/prof_${tag}
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --steps 10 --warmup 3 --cpu-chunks 0 --exact-steps 0 --overlap-steps 0 > gpurun_out/prof_${tag}.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --steps 10 --warmup 3 --cpu-chunks 0 --exact-steps 0 --overlap-steps 0 --small-batch-steps 0 > gpurun_out/prof_${tag}.log 2>&1
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
 bash tools/collect_pmc.sh
 python3 tools/pmc_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/${tag}_pmc_traffic.json
