@@ -37,6 +37,12 @@ typedef float f32x2d __attribute__((ext_vector_type(2)));
 #ifndef BAR16D_ZHOOK
 #define BAR16D_ZHOOK 0
 #endif
+// which gate's weights live in accumulation registers (its MFMAs are asm, placed where the source puts them): 0 = the update gate,
+// 1 = the candidate (its MFMAs come in one run in front of its epilogue anyway; the update gate's stay the compiler's to interleave):
+// measured 2912 against 2782 cycles per step
+#ifndef BAR16D_CACC
+#define BAR16D_CACC 0
+#endif
 __device__ unsigned long long slk_dbg_bar16d[4][16];
 extern "C" int slk_debug_read_bar16d(unsigned long long *host_out)
 {
@@ -245,7 +251,10 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
 #pragma unroll
         for (int p = 0; p < 2; p++) {
 #pragma unroll
-            for (int i = 0; i < KBS; i++) { wz_hi[p][i] = to_acc_regs(wz_hi[p][i]); wz_lo[p][i] = to_acc_regs(wz_lo[p][i]); }
+            for (int i = 0; i < KBS; i++) {
+                if constexpr (BAR16D_CACC) { wc_hi[p][i] = to_acc_regs(wc_hi[p][i]); wc_lo[p][i] = to_acc_regs(wc_lo[p][i]); }
+                else { wz_hi[p][i] = to_acc_regs(wz_hi[p][i]); wz_lo[p][i] = to_acc_regs(wz_lo[p][i]); }
+            }
         }
         constexpr int CTA = CT > 0 ? CT : 1;
         half8 pw_hi[CTA][KBLK], pw_lo[CTA][KBLK];
@@ -382,7 +391,13 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                     z_block_mfma_hooked<i == 0, 6 * i>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i], r_piece);
                 });
             } else {
-                if constexpr (KBS > 1) {
+                if constexpr (BAR16D_CACC) {
+                    accZ[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    accZ[1] = accZ[0];
+#pragma unroll
+                    for (int i = 0; i < KBS - 1; i++)
+                        mfma3x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i], accZ[0], accZ[1]);
+                } else if constexpr (KBS > 1) {
                     mfma_z(ic<1>{}, 0, bh[0], bl[0], accZ[0], accZ[1]);
 #pragma unroll
                     for (int i = 1; i < KBS - 1; i++) mfma_z(ic<0>{}, i, bh[i], bl[i], accZ[0], accZ[1]);
@@ -394,6 +409,13 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 }
                 split2(rr[0][0] * hold[0][0], rr[1][0] * hold[1][0], rhi.x, rlo.x);
                 split2(rr[0][1] * hold[0][1], rr[1][1] * hold[1][1], rhi.y, rlo.y);
+                if constexpr (BAR16D_CACC) {             // one MFMA, then up to four VALU instructions, for as long as both last
+#pragma unroll
+                    for (int i = 0; i < 6 * (KBS - 1); i++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                }
             }
             lds_fence();
             *reinterpret_cast<uint2 *>(&rh_hi[wd]) = rhi;
@@ -427,10 +449,18 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (KBS > 1) mfma_z(ic<0>{}, KBS - 1, bh[KBS - 1], bl[KBS - 1], accZ[0], accZ[1]);
-            else mfma_z(ic<1>{}, 0, bh[0], bl[0], accZ[0], accZ[1]);
-            f32x4 accC[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            mfma3x2(wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0], accC[0], accC[1]);
+            f32x4 accC[2];
+            if constexpr (BAR16D_CACC) {
+                if constexpr (KBS == 1) { accZ[0] = f32x4{0.f, 0.f, 0.f, 0.f}; accZ[1] = accZ[0]; }
+                mfma3x2(wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1], bl[KBS - 1], accZ[0], accZ[1]);
+                z_block_mfma<true>(accC[0], accC[1], wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0]);
+            } else {
+                if constexpr (KBS > 1) mfma_z(ic<0>{}, KBS - 1, bh[KBS - 1], bl[KBS - 1], accZ[0], accZ[1]);
+                else mfma_z(ic<1>{}, 0, bh[0], bl[0], accZ[0], accZ[1]);
+                accC[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                accC[1] = accC[0];
+                mfma3x2(wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0], accC[0], accC[1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -440,17 +470,25 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 for (int sset = 0; sset < 2; sset++) { keep(xh[sset]); keep(xl[sset]); pxh[sset] = xh[sset]; pxl[sset] = xl[sset]; }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (KBS > 1) {
-                mfma3x2(wc_hi[0][1], wc_lo[0][1], wc_hi[1][1], wc_lo[1][1], ch[1], cl[1], accC[0], accC[1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // the z accumulators came from asm MFMAs the compiler does not know as such: twelve MFMAs (or the drain) have been
-            // issued since the last of them, and nothing that reads them may move above this point
-            if constexpr (KBS == 1) { mfma_drain(accZ[0]); mfma_drain(accZ[1]); }
-            else asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]));
+            if constexpr (BAR16D_CACC) {
+                // the candidate's products with the other waves' blocks: asm, in source order, the update gate's epilogue behind the first
+                static_for<1, KBS>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    z_block_mfma<false>(accC[0], accC[1], wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i]);
+                });
+            } else {
+                if constexpr (KBS > 1) {
+                    mfma3x2(wc_hi[0][1], wc_lo[0][1], wc_hi[1][1], wc_lo[1][1], ch[1], cl[1], accC[0], accC[1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the z accumulators came from asm MFMAs the compiler does not know as such: twelve MFMAs (or the drain) have been
+                // issued since the last of them, and nothing that reads them may move above this point
+                if constexpr (KBS == 1) { mfma_drain(accZ[0]); mfma_drain(accZ[1]); }
+                else asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]));
 #pragma unroll
-            for (int i = 2; i < KBS; i++)
-                mfma3x2(wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i], accC[0], accC[1]);
+                for (int i = 2; i < KBS; i++)
+                    mfma3x2(wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i], accC[0], accC[1]);
+            }
             float zz[2][2], omz[2][2], zh[2][2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
@@ -462,11 +500,16 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                     asm volatile("" : "+v"(zh[p][j]), "+v"(omz[p][j]));        // pinned here: not sunk to the blend below
                 }
             }
-            // one MFMA, then up to four VALU instructions, for as long as both last
+            if constexpr (BAR16D_CACC) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_drain(accC[0]);
+                mfma_drain(accC[1]);
+            } else {                                     // one MFMA, then up to four VALU instructions, for as long as both last
 #pragma unroll
-            for (int i = 0; i < 6 * (KBS - 2); i++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                for (int i = 0; i < 6 * (KBS - 2); i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             float hn[2][2];
