@@ -14,11 +14,21 @@
 
 // 1: the update gate's products with the wave's own K block right behind the reset gate's, inside the LDS round trip (0: behind the
 // reset gate's other blocks; measured equal)
+// timing experiments (results garbage): 1 = do not wait for the projection loads, 2 = no stores, 4 = no projection loads at all
+#ifndef SCAN16_ABL
+#define SCAN16_ABL 0
+#endif
 #ifndef SCAN16_Z0_EARLY
 #define SCAN16_Z0_EARLY 1
 #endif
 // one float per lane from HBM, not tracked by the compiler: the caller counts (s_waitcnt vmcnt(n), then pin_f)
 __device__ __forceinline__ void gload1(float &dst, const float *src) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); }
+// the same with the row's base address in scalar registers and the lane's part as an unsigned 32-bit byte offset: nothing but one
+// add per step is left of the address arithmetic
+__device__ __forceinline__ void gload1_s(float &dst, unsigned voff, const float *sbase)
+{
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
 __device__ __forceinline__ void pin_f(float &v) { asm volatile("" : "+v"(v)); }
 
 template <int N>
@@ -104,13 +114,19 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
     // three younger steps) those of the current step have arrived, whatever the stores do.
     struct VI { float z[2], r[2], c[2]; };
     VI vs[4];
-    auto load_vi = [&](int s, VI &v) {
-        const int ss = min(s, Tc - 1);
-        const int tt = reverse ? Tc - 1 - ss : ss;
-        const float *row = vI + ((size_t)tt * B + bcc) * ldv + (nok0 ? n0 : 0);
-        const float *row1 = row + (nok1 ? 16 : 0);
-        gload1(v.z[0], row); gload1(v.r[0], row + n); gload1(v.c[0], row + 2 * n);
-        gload1(v.z[1], row1); gload1(v.r[1], row1 + n); gload1(v.c[1], row1 + 2 * n);
+    // addresses: three wave-uniform bases (z | r | c block of row 0) + this lane's byte offset of the step being requested, which
+    // advances by one time step per request until the chunk's last row (requests past it re-read that row); the caller refuses
+    // projections of 4 GiB and more
+    const float *sb_z = vI, *sb_r = vI + n, *sb_c = vI + 2 * n;
+    const unsigned tile1 = nok1 ? 64u : 0u;                                       // bytes to my neuron of tile 2w+1
+    unsigned voff = (unsigned)((((size_t)(reverse ? Tc - 1 : 0) * B + bcc) * ldv + (nok0 ? n0 : 0)) * sizeof(float));
+    const unsigned vstep = (unsigned)((size_t)B * ldv * sizeof(float));
+    int vnext = 0;                                                                // step the next request is for
+    auto load_vi = [&](int, VI &v) {
+        gload1_s(v.z[0], voff, sb_z); gload1_s(v.r[0], voff, sb_r); gload1_s(v.c[0], voff, sb_c);
+        gload1_s(v.z[1], voff + tile1, sb_z); gload1_s(v.r[1], voff + tile1, sb_r); gload1_s(v.c[1], voff + tile1, sb_c);
+        vnext++;
+        if (vnext < Tc) voff = reverse ? voff - vstep : voff + vstep;
     };
     load_vi(0, vs[0]);
     load_vi(1, vs[1]);
@@ -129,7 +145,7 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         bl[0] = ol;
 #pragma unroll
         for (int i = 1; i < KBS; i++) { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
-        load_vi(s + 3, vs[(ph + 3) & 3]);                // three steps ahead
+        if constexpr (!(SCAN16_ABL & 4)) load_vi(s + 3, vs[(ph + 3) & 3]);                // three steps ahead
         __builtin_amdgcn_sched_barrier(0);
         f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2], accC[2];
         mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
@@ -153,7 +169,7 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
             constexpr int i = decltype(IC)::value;
             z_block_mfma<false>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i]);
         });
-        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");                 // this step's vI (see above)
+        if constexpr (!(SCAN16_ABL & 5)) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");                 // this step's vI (see above)
         pin_f(cur.z[0]); pin_f(cur.z[1]); pin_f(cur.r[0]); pin_f(cur.r[1]); pin_f(cur.c[0]); pin_f(cur.c[1]);
         float rr[2];
         rr[0] = nok0 ? sigmoid4(fmaf(sel4(accR[0], q), inv_r[0], cur.r[0])) : 0.0f;
@@ -215,7 +231,7 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         oh = ldH(h_hi, boff[0]);
         ol = ldH(h_lo, boff[0]);
         lds_fence();
-        if (live && s < Tc) {
+        if (live && s < Tc && !(SCAN16_ABL & 2)) {
             if (nok0) hp[0] = hn[0];
             if (nok1) hp[16] = hn[1];
         }
@@ -252,6 +268,7 @@ extern "C" int slk_gru_scan16_f32(const float *vI, long ldv, const float *sW, co
     if (!vI || !sW || !sW2 || !y || T < 1 || B < 1 || n < 1 || ldv < 3L * n || ldy < n) return SLK_ERR_INVALID_ARG;
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
     if (n % 16 || n <= 96 || n > 128) return SLK_ERR_UNSUPPORTED;
+    if ((unsigned long long)T * B * ldv * sizeof(float) >= (1ull << 32)) return SLK_ERR_UNSUPPORTED;       // 32-bit lane offsets
     static const size_t dyn = scan16_exclusive_lds();
     hipLaunchKernelGGL((gru_scan16_kernel<128>), dim3((B + 3) / 4), dim3(256), dyn, slk_stream(stream), vI, ldv, sW, sW2, y, ldy, T, B, n,
                        reverse & 1, lens);
