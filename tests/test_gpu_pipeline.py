@@ -193,3 +193,10 @@ def test_in_flight_hint_changes_the_plan_not_the_result():
     s1, p1, l1 = pipeline.Basecaller(net).call_chunks(chunks)
     s2, p2, l2 = pipeline.Basecaller(net, in_flight=2).call_chunks(chunks)
     assert torch.equal(p1, p2) and torch.equal(l1, l2) and torch.equal(s1, s2)
+    # a birnn model at the batch north_star quotes, four in flight: the two directions of each birnn run side by side on the
+    # eight-chunk plan (4 batches x 2 directions x 32 workgroups = the device's CUs)
+    net = models.randomise_zero_layers(models.build_model("baseline_raw_gru", klen=5, sd=0.5, seed=23))
+    chunks = dev(pipeline.synthetic_chunks(256, chunk_len=1200, seed=7))
+    s1, p1, l1 = pipeline.Basecaller(net).call_chunks(chunks)
+    s4, p4, l4 = pipeline.Basecaller(net, in_flight=4).call_chunks(chunks)
+    assert torch.equal(p1, p4) and torch.equal(l1, l4) and torch.equal(s1, s4)
