@@ -163,3 +163,34 @@ __device__ __forceinline__ void z_block_mfma_hooked(f32x4 &a0, f32x4 &a1, const 
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bh));
     hook(ic<BASE + 5>{});
 }
+
+// One projection tile for both sets, weights in accumulation registers: the two accumulation chains alternate (consecutive
+// MFMAs never depend on each other) and hook(ic<i>) runs after MFMA i = 0 .. 6 KBLK - 1 -- the matrix pipe keeps the wave's issue
+// port for 4 cycles of every 16, the leader's split of x is cut into pieces that fill the rest.
+template <int KBLK_, class F>
+__device__ __forceinline__ void tile2_mfma_acc(f32x4 &a0, f32x4 &a1, const half8 *w_hi, const half8 *w_lo, const half8 *x0_hi,
+                                               const half8 *x0_lo, const half8 *x1_hi, const half8 *x1_lo, F &&hook)
+{
+    static_for<0, KBLK_>([&](auto KBC) {
+        constexpr int kb = decltype(KBC)::value;
+        if constexpr (kb == 0) {
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a0) : "a"(w_hi[0]), "v"(x0_lo[0]));
+            hook(ic<0>{});
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a1) : "a"(w_hi[0]), "v"(x1_lo[0]));
+            hook(ic<1>{});
+        } else {
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w_hi[kb]), "v"(x0_lo[kb]));
+            hook(ic<6 * kb>{});
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w_hi[kb]), "v"(x1_lo[kb]));
+            hook(ic<6 * kb + 1>{});
+        }
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w_lo[kb]), "v"(x0_hi[kb]));
+        hook(ic<6 * kb + 2>{});
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w_lo[kb]), "v"(x1_hi[kb]));
+        hook(ic<6 * kb + 3>{});
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w_hi[kb]), "v"(x0_hi[kb]));
+        hook(ic<6 * kb + 4>{});
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w_hi[kb]), "v"(x1_hi[kb]));
+        hook(ic<6 * kb + 5>{});
+    });
+}

@@ -718,18 +718,24 @@ extern "C" int slk_gru_bar16d_launch(const float *x, long ldx, const float *iW, 
                                      float *y, long ldy, int T, int B, int insize, int n, int reverse, const int32_t *lens,
                                      float *zr_out, hipStream_t s);
 
+extern "C" int slk_gru_bar16q_launch(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+                                     float *y, long ldy, int T, int B, int insize, int n, int reverse, const int32_t *lens,
+                                     float *zr_out, hipStream_t s);
+
 // More workgroups of four chunks than CUs would run one after the other: such batches take the eight-chunk plan of
-// gru_bar16d.hip (SLOIKA_AMD_GRU_DUAL=0 / 1 forces one or the other).
-static bool bar16_use_dual(int B)
+// gru_bar16d.hip, and the sixteen-chunk plan of gru_bar16q.hip when the eight-chunk workgroups do not fit either
+// (SLOIKA_AMD_GRU_DUAL=0 / 1 / 2 forces four / eight / sixteen chunks).  Returns chunks per workgroup divided by four.
+static int bar16_auto_plan(int B)
 {
     static const int forced = getenv("SLOIKA_AMD_GRU_DUAL") ? atoi(getenv("SLOIKA_AMD_GRU_DUAL")) : -1;
-    if (forced >= 0) return forced != 0;
+    if (forced >= 0) return forced == 0 ? 1 : (forced == 1 ? 2 : 4);
     static const int ncu = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
         return n > 0 ? n : 256;
     }();
-    return (B + 3) / 4 > ncu;
+    if ((B + 3) / 4 <= ncu) return 1;
+    return (B + 7) / 8 <= ncu ? 2 : 4;
 }
 
 // Same contract as slk_gru_fused16_f32 (include/sloika_amd.h); SLK_ERR_UNSUPPORTED when no instantiation covers the request.
@@ -742,9 +748,14 @@ extern "C" int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, cons
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
     if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;   // 16-byte DMA pieces
     hipStream_t s = slk_stream(stream);
-    const int plan = (reverse >> 8) & 3;                 // undocumented (tools/bar16d_check.py): 1 = four-chunk plan, 2 = eight-chunk plan
+    const int plan = (reverse >> 8) & 3;                 // include/sloika_amd.h: 0 = by batch size, 1 / 2 / 3 = four / eight / sixteen chunks
     reverse &= 0xff;
-    if (plan == 2 || (plan == 0 && (reverse >> 1) == 0 && bar16_use_dual(B))) {
+    const int per4 = plan == 1 ? 1 : plan == 2 ? 2 : plan == 3 ? 4 : ((reverse >> 1) == 0 ? bar16_auto_plan(B) : 1);
+    if (per4 == 4) {
+        const int rc = slk_gru_bar16q_launch(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse, lens, zr_out, s);
+        if (rc != SLK_ERR_UNSUPPORTED) return rc;
+    }
+    if (per4 >= 2) {
         const int rc = slk_gru_bar16d_launch(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse, lens, zr_out, s);
         if (rc != SLK_ERR_UNSUPPORTED) return rc;
     }

@@ -20,16 +20,16 @@ def _params(rs, I, n, bias=True, scale=1.0):
 
 #: the execution plans of the same arithmetic: LDS progress counters (gru_fused16.hip), barrier-stepped with four chunks per
 #: workgroup (gru_bar16.hip) and with eight (gru_bar16d.hip, what batches beyond one workgroup per CU run: forced here through
-#: bits 8-9 of `reverse` so that the small cases exercise it too)
+#: bits 8-9 of `reverse` so that the small cases exercise it too) and with sixteen (gru_bar16q.hip, batches beyond eight chunks per CU)
 ENTRY = "slk_gru_bar16_f32"
 PLAN = 0
 
 
-@pytest.fixture(autouse=True, params=["slk_gru_bar16_f32", "slk_gru_fused16_f32", "slk_gru_bar16_f32:8"])
+@pytest.fixture(autouse=True, params=["slk_gru_bar16_f32", "slk_gru_fused16_f32", "slk_gru_bar16_f32:8", "slk_gru_bar16_f32:16"])
 def _entry(request):
     global ENTRY, PLAN
-    ENTRY, _, eight = request.param.partition(":")
-    PLAN = 2 if eight else 0
+    ENTRY, _, chunks = request.param.partition(":")
+    PLAN = {"": 0, "8": 2, "16": 3}[chunks]
     yield
 
 
@@ -263,9 +263,10 @@ def test_fused16_launches_are_deterministic(I, n):
 
 @pytest.mark.parametrize("I,n", [(96, 96), (64, 64), (32, 96), (48, 32)])
 def test_eight_chunk_plan_is_bit_identical(I, n):
-    """gru_bar16d.hip computes every (neuron, chunk) pair with the same instructions in the same order as gru_bar16.hip: the two
-    plans must agree bit for bit -- states and saved gates, ragged and reversed, batch sizes around the multiples of eight and a
-    batch (2048 + 3 chunks) that takes the eight-chunk plan by itself."""
+    """gru_bar16d.hip (eight chunks per workgroup) and gru_bar16q.hip (sixteen) compute every (neuron, chunk) pair with the same
+    instructions in the same order as gru_bar16.hip: the plans must agree bit for bit -- states and saved gates, ragged and
+    reversed, batch sizes around the multiples of eight and sixteen and batches (2048 + 3, 4096 + 4 chunks) that take the eight-
+    and the sixteen-chunk plan by themselves."""
     torch = need_gpu()
     from sloika_amd import _lib
     L = _lib.lib()
@@ -274,13 +275,13 @@ def test_eight_chunk_plan_is_bit_identical(I, n):
     bb = torch.randn(3 * n, device="cuda", generator=g)
     sW = 2 * torch.randn(2 * n, n, device="cuda", generator=g) / np.sqrt(2 * n)
     sW2 = 2 * torch.randn(n, n, device="cuda", generator=g) / np.sqrt(2 * n)
-    for T, B in [(1, 1), (5, 7), (9, 8), (13, 17), (37, 2051)]:
+    for T, B in [(1, 1), (5, 7), (9, 8), (13, 17), (2, 33), (37, 2051), (6, 4100)]:
         x = torch.randn(T, B, I, device="cuda", generator=g)
         lens = torch.randint(1, T + 1, (B,), device="cuda", dtype=torch.int32, generator=g)
         for reverse in (0, 1):
             for lp in (None, lens):
                 got = []
-                for plan in (1, 2, 0):
+                for plan in (1, 2, 3, 0):
                     y = torch.full((T, B, n), float("nan"), device="cuda")
                     zr = torch.full((T * B, 2 * n), float("nan"), device="cuda")
                     rc = L.slk_gru_bar16_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B,
