@@ -408,6 +408,34 @@ def main():
                                        "unit": "samples/s", "steps": 2 * npair, "chunks_per_call": 2 * B,
                                        "note": "ms_per_step is per %d chunks; one call carries two batches" % B}
             del pair
+            # ... and four batches as one call of 4B chunks: the recurrent layers run sixteen chunks per workgroup
+            # (csrc/gru_bar16q.hip: every column of the recurrent MFMAs a different chunk)
+            quad = torch.cat([dev[i % nbuf] for i in range(4)], dim=0)
+            out4 = torch.empty((4 * B, tout), dtype=torch.int32).pin_memory()
+            def step_quad():
+                scores, paths, lens = bc.call_chunks(quad)
+                paths.record_stream(copy_stream)
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream())
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(done)
+                    out4[:, : paths.shape[1]].copy_(paths, non_blocking=True)
+            nquad = max(1, args.overlap_steps // 4)
+            step_quad()
+            barrier()
+            t5 = time.perf_counter()
+            for _ in range(nquad):
+                step_quad()
+            barrier()
+            dtq = time.perf_counter() - t5
+            if dist is not None:
+                tm = torch.tensor([dtq], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dtq = float(tm.item())
+            overlap["four_as_one_batch"] = {"ms_per_step": dtq / (4 * nquad) * 1e3, "value": world * 4 * B * L * nquad / dtq,
+                                            "unit": "samples/s", "steps": 4 * nquad, "chunks_per_call": 4 * B,
+                                            "note": "ms_per_step is per %d chunks; one call carries four batches" % B}
+            del quad
 
     # BASELINE.json configs[1] -- the batch north_star quotes (baseline_raw_gru, 256 chunks of 4000 samples): every stage is
     # latency bound at that size (64 workgroups per recurrent launch, 256 decoder workgroups), so the device only fills up with

@@ -191,8 +191,9 @@ int slk_gru_fused16_f32(const float *x, long ldx, const float *iW, const float *
  * few 1e-7 (the three split terms are summed in a different order).  This is the plan sloika_amd.layers.Gru runs;
  * SLK_ERR_UNSUPPORTED for shapes without an instantiation (the same list as slk_gru_fused16_f32).
  * A workgroup takes four chunks; a batch with more such workgroups than the device has CUs runs the eight-chunk plan of
- * csrc/gru_bar16d.hip instead (two four-chunk tiles through the same MFMAs; bit-identical results).  Bits 8-9 of `reverse`
- * force a plan: 0 = by batch size, 1 = four chunks per workgroup, 2 = eight (environment: SLOIKA_AMD_GRU_DUAL=0|1).     */
+ * csrc/gru_bar16d.hip instead (two four-chunk tiles through the same MFMAs), one with more eight-chunk workgroups than CUs
+ * the sixteen-chunk plan of csrc/gru_bar16q.hip (bit-identical results).  Bits 8-9 of `reverse` force a plan: 0 = by batch
+ * size, 1 / 2 / 3 = four / eight / sixteen chunks per workgroup (environment: SLOIKA_AMD_GRU_DUAL=0|1|2).               */
 int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                       float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                       const int32_t *lens, float *zr_out, slk_stream_t stream);

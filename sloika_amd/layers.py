@@ -113,7 +113,7 @@ RECURRENT_F16 = os.environ.get("SLOIKA_AMD_RECURRENT_F32", "0") != "1"
 GRU_PLAN = os.environ.get("SLOIKA_AMD_GRU_PLAN", "bar")
 
 
-#: bits 8-9 of the `reverse` argument of slk_gru_bar16_f32 (0 = plan by batch size, 2 = eight chunks per workgroup): set by
+#: bits 8-9 of the `reverse` argument of slk_gru_bar16_f32 (0 = plan by batch size, 2 / 3 = eight / sixteen chunks per workgroup): set by
 #: Parallel while it runs the directions of a birnn side by side at a batch where only the eight-chunk plan lets them share the chip
 _GRU_PLAN_BITS = 0
 #: batches the caller keeps in flight on streams of their own (pipeline.Basecaller(in_flight=N) sets it around a forward pass): a
@@ -124,10 +124,12 @@ _IN_FLIGHT = 1
 
 def _gru_plan_for(B, share, ncu):
     """Plan bits for `share` Gru launches of batch B that are meant to run at the same time: 0 when their four-chunk
-    workgroups fit the CUs together (or nothing helps), 2 when only the eight-chunk ones do."""
+    workgroups fit the CUs together (or nothing helps), 2 when only the eight-chunk ones do, 3 when only the sixteen-chunk ones."""
     if ((B + 3) // 4) * share <= ncu:
         return 0
-    return 2 if ((B + 7) // 8) * share <= ncu else 0
+    if ((B + 7) // 8) * share <= ncu:
+        return 2
+    return 3 if ((B + 15) // 16) * share <= ncu else 0
 
 
 def gru_f16_entry():
@@ -1036,9 +1038,10 @@ class Parallel(Layer):
             # too many four-chunk workgroups to run together; eight chunks per workgroup (csrc/gru_bar16d.hip: 1.4 x the step
             # time for twice the chunks) may still let the directions share the chip: B = 1024, two directions -> 2 x 128
             grus = all(isinstance(l.layer if isinstance(l, Reverse) else l, Gru) for l in self.layers)
-            if not (grus and SPLIT_F16 and RECURRENT_F16 and GRU_PLAN == "bar" and _gru_plan_for(B, share, ncu) == 2):
+            plan = _gru_plan_for(B, share, ncu)
+            if not (grus and SPLIT_F16 and RECURRENT_F16 and GRU_PLAN == "bar" and plan):
                 return None
-            self._side_plan = 2
+            self._side_plan = plan
         # side streams belong to the stream the caller runs on: batches in flight on different streams must not meet on one
         key = (x.device.index, len(self.layers), torch.cuda.current_stream(x.device).cuda_stream)
         if key not in Parallel._streams_cache:

@@ -122,13 +122,13 @@ def test_raw_chunk_worker_and_seqprinter(oracle, golden_bio, golden_decode):
 
 
 @pytest.mark.parametrize("name,B", [("raw_0.98_rgrgr", 1024), ("baseline_raw_gru", 256), ("raw_0.98_rgrgr", 2048),
-                                    ("bigger_raw_gru", 1024)])
+                                    ("bigger_raw_gru", 1024), ("raw_0.98_rgrgr", 4096)])
 def test_full_size_batch_sampled_chunks_vs_oracle(oracle, name, B):
     """BASELINE.json configs[2] / configs[1] at FULL size (4000-sample chunks, batch 1024 / 256): eight chunks picked at
     random out of the batch are compared with the oracle run on those chunks alone -- posteriors relative to each row's
     maximum, and the decoded paths against the oracle's decoder on the device's own log-posteriors.  Batch 2048 is two
     batches handed over as one call (bench.py's `as_one_batch`): the recurrent layers run eight chunks per workgroup and the
-    decoder one wave per chunk.  bigger_raw_gru at batch 1024 (configs[3] per GPU) runs the two directions of each birnn side
+    decoder one wave per chunk; batch 4096 is four batches as one call (sixteen chunks per workgroup).  bigger_raw_gru at batch 1024 (configs[3] per GPU) runs the two directions of each birnn side
     by side, eight chunks per workgroup each."""
     torch = need_gpu()
     from sloika_amd import _lib, models, pipeline
@@ -170,17 +170,19 @@ def test_full_size_batch_properties():
 
 
 def test_double_batch_equals_two_batches():
-    """Two batches of 1024 chunks as ONE call take other kernels than each on its own (csrc/gru_bar16d.hip, the one-wave-per-
-    chunk decoder) -- and must give the same bits: paths, lengths and scores."""
+    """Two or four batches of 1024 chunks as ONE call take other kernels than each on its own (csrc/gru_bar16d.hip /
+    gru_bar16q.hip, the one-wave-per-chunk decoder) -- and must give the same bits: paths, lengths and scores."""
     torch = need_gpu()
     from sloika_amd import models, pipeline
     net = models.randomise_zero_layers(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=21))
     bc = pipeline.Basecaller(net)
-    chunks = dev(pipeline.synthetic_chunks(2048, chunk_len=2000, seed=5))
-    s2, p2, l2 = bc.call_chunks(chunks)
-    for lo in (0, 1024):
+    chunks = dev(pipeline.synthetic_chunks(4096, chunk_len=2000, seed=5))
+    s4, p4, l4 = bc.call_chunks(chunks)                      # four batches as one call: sixteen chunks per workgroup
+    s2, p2, l2 = bc.call_chunks(chunks[:2048])               # two: eight
+    assert torch.equal(p2, p4[:2048]) and torch.equal(l2, l4[:2048]) and torch.equal(s2, s4[:2048])
+    for lo in (0, 1024, 3072):
         s1, p1, l1 = bc.call_chunks(chunks[lo:lo + 1024])
-        assert torch.equal(p1, p2[lo:lo + 1024]) and torch.equal(l1, l2[lo:lo + 1024]) and torch.equal(s1, s2[lo:lo + 1024])
+        assert torch.equal(p1, p4[lo:lo + 1024]) and torch.equal(l1, l4[lo:lo + 1024]) and torch.equal(s1, s4[lo:lo + 1024])
 
 
 def test_in_flight_hint_changes_the_plan_not_the_result():
