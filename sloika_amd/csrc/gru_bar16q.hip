@@ -18,6 +18,11 @@
 
 #include "bar16_common.h"
 
+// timing experiments (tools/build_bar16q_variants.sh; results are garbage): 1 = service waves only keep the barriers, 2 = chain waves
+// skip their share of the projection, 4 = no stores to h_out
+#ifndef BAR16Q_ABL
+#define BAR16Q_ABL 0
+#endif
 // first tile of interval k (of four) when a service wave has st tiles per group and set; the leader splits set 0 in interval 0 and
 // set 1 in interval 2
 __host__ __device__ constexpr int tile_first_q(int st, int k)
@@ -232,7 +237,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
         // projects K block k of the NEXT group (when k < KBLK); the operands of a slot are fetched one slot earlier
         auto proj_slot = [&](auto KC) {
             constexpr int k = decltype(KC)::value;
-            if constexpr (CT > 0 && k < KBLK) {
+            if constexpr (CT > 0 && k < KBLK && !(BAR16Q_ABL & 2)) {
 #pragma unroll
                 for (int sset = 0; sset < 2; sset++) {
 #pragma unroll
@@ -315,12 +320,15 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
             cl[0] = ldH(rh_lo, boff[0]);
             lds_fence();
             // one MFMA, then up to four VALU instructions, for as long as both last
+#ifndef BAR16Q_ZV
+#define BAR16Q_ZV 4
+#endif
 #pragma unroll
             for (int i = 0; i < 6 * KBS; i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, BAR16Q_ZV, 0);
             }
-            const bool store = live && s < Tc;
+            const bool store = live && s < Tc && !(BAR16Q_ABL & 4);
             if constexpr (SAVE) {
                 if (store) {
                     *reinterpret_cast<f32x4 *>(zp + N) = f32x4{rr[0][0], rr[0][1], rr[0][2], rr[0][3]};
@@ -566,6 +574,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
         auto interval = [&](auto KC, const int G) {
             constexpr int k = decltype(KC)::value;
             lds_bar();
+            if constexpr (BAR16Q_ABL & 1) return;
             if constexpr (k == 0) load_operands(G + 1);
             project_interval(KC, G + 1);
         };
