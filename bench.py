@@ -257,7 +257,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
     net = models.randomise_zero_layers(models.build_model(args.model, klen=5, sd=0.5, seed=11))
     nstream = max(1, args.streams)
-    nslot = max(nstream, 2 if (args.overlap_steps > 0 and nstream == 1) else 1)     # the two_in_flight leg needs a second slot
+    nslot = max(nstream, 4 if (args.overlap_steps > 0 and nstream == 1) else 1)     # the in-flight legs need up to four slots
     bcs = [pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, in_flight=nstream) for _ in range(nslot)]
     bc = bcs[0]
     streams = ([torch.cuda.Stream() for _ in range(nslot)] if nstream > 1
@@ -373,10 +373,28 @@ def main():
             tm = torch.tensor([dto], dtype=torch.float64, device="cuda")
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
             dto = float(tm.item())
-        for bco in bcs:
-            bco.in_flight = nstream
         overlap = {"ms_per_step": dto / args.overlap_steps * 1e3, "value": world * B * L * args.overlap_steps / dto,
                    "unit": "samples/s", "steps": args.overlap_steps, "streams_per_gpu": 2}
+        # ... four in flight on four streams: each batch's recurrent layers take a quarter of the chip on the sixteen-chunk plan
+        for bco in bcs:
+            bco.in_flight = 4
+        for i in range(8):
+            step(i, 4)
+        barrier()
+        t6 = time.perf_counter()
+        n4 = 2 * args.overlap_steps
+        for i in range(n4):
+            step(i, 4)
+        barrier()
+        dt4 = time.perf_counter() - t6
+        if dist is not None:
+            tm = torch.tensor([dt4], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            dt4 = float(tm.item())
+        overlap["four_in_flight"] = {"ms_per_step": dt4 / n4 * 1e3, "value": world * B * L * n4 / dt4, "unit": "samples/s",
+                                     "steps": n4, "streams_per_gpu": 4}
+        for bco in bcs:
+            bco.in_flight = nstream
         # ... and with the two batches handed over as ONE call of 2B chunks: a recurrent layer then runs the eight-chunk plan
         # (csrc/gru_bar16d.hip: one workgroup per CU takes a 4-chunk tile of EACH batch through the same MFMAs) instead of two
         # rounds of four-chunk workgroups.  Only the paths of the first B chunks are copied out per B chunks of work, as above.
