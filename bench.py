@@ -21,8 +21,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # HIP maps streams onto 4 hardware queues by default; batches in flight on their own streams, each with side streams for the
 # directions of a birnn and one for copies, serialise on them (baseline_raw_gru, B = 256, four in flight: 191 M samples/s
-# with 4 queues, 345 M with 16).  Read by the HIP runtime when it starts, so set before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# with 4 queues, 345 M with 16; eight in flight: 322 M with 16, 417 M with 32).  Read by the HIP runtime when it starts, so set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 
@@ -60,7 +60,7 @@ def parse():
                          "entry of the line (0 = skip); the main region and `value` always use --streams (default 1)")
     ap.add_argument("--small-batch-steps", type=int, default=6,
                     help="steps of BASELINE.json configs[1] (baseline_raw_gru, batch 256) timed after the main region, one batch at "
-                         "a time and four in flight, for the `batch256` field (default workload on one GPU only; 0 = skip)")
+                         "a time and eight in flight, for the `batch256` field (default workload on one GPU only; 0 = skip)")
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (BASELINE.json configs[4]: forward + backward + ADAMski, "
                          "gradient all-reduce over RCCL when --gpus > 1); prints the same kind of JSON line")
@@ -462,7 +462,7 @@ def main():
     if (args.small_batch_steps > 0 and world == 1 and nstream == 1 and args.model == "raw_0.98_rgrgr" and args.batch == 1024
             and not args.with_bases):
         net1 = models.randomise_zero_layers(models.build_model("baseline_raw_gru", klen=5, sd=0.5, seed=11))
-        B1, nfl = 256, 4
+        B1, nfl = 256, 8
         bcs1 = [pipeline.Basecaller(net1, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0) for _ in range(nfl)]
         st1 = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nfl - 1)]
         dev1 = [torch.from_numpy(pipeline.synthetic_chunks(B1, chunk_len=L, seed=0xfeed, first_chunk=i * B1)).cuda() for i in range(nfl)]
@@ -481,7 +481,7 @@ def main():
                 host1[k][:, : paths.shape[1]].copy_(paths, non_blocking=True)
 
         small = {"workload": "baseline_raw_gru inference, %d-sample chunks, batch %d (BASELINE.json configs[1])" % (L, B1)}
-        for nact, key in ((1, "one_at_a_time"), (nfl, "four_in_flight")):
+        for nact, key in ((1, "one_at_a_time"), (nfl, "eight_in_flight")):
             for bco in bcs1:
                 bco.in_flight = nact
             for i in range(2 * nact):
