@@ -608,7 +608,7 @@ extern "C" int slk_gru_bar16q_launch(const float *x, long ldx, const float *iW, 
     if ((ldy & 3) || (reinterpret_cast<uintptr_t>(y) & 15)) return SLK_ERR_UNSUPPORTED;         // 16-byte state stores
 #define BAR16Q(II, NN) \
     if (insize == II && n == NN) return launch_bar16q<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s);
-    BAR16Q(96, 96) BAR16Q(64, 64) BAR16Q(32, 96) BAR16Q(64, 96)
+    BAR16Q(96, 96) BAR16Q(64, 64) BAR16Q(32, 96) BAR16Q(128, 96) BAR16Q(64, 96) BAR16Q(48, 32) BAR16Q(16, 64)
 #undef BAR16Q
     return SLK_ERR_UNSUPPORTED;
 }
