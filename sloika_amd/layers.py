@@ -1045,6 +1045,8 @@ class Parallel(Layer):
         # side streams belong to the stream the caller runs on: batches in flight on different streams must not meet on one
         key = (x.device.index, len(self.layers), torch.cuda.current_stream(x.device).cuda_stream)
         if key not in Parallel._streams_cache:
+            if len(Parallel._streams_cache) >= 64:                 # callers that keep creating streams: do not keep theirs for ever
+                Parallel._streams_cache.clear()
             Parallel._streams_cache[key] = [torch.cuda.Stream(device=x.device) for _ in range(len(self.layers) - 1)]
         return Parallel._streams_cache[key]
 
