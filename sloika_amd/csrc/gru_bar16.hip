@@ -110,6 +110,10 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
     unsigned long long wg_t0 = 0, wg_r0 = 0;
     if constexpr (ABL & 32) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0), "=s"(wg_r0)::"memory");
 
+    if constexpr (ABL & 256) {                           // experiment: workgroups out of phase (do 256 CUs bursting in step cost clock?)
+        const int ph = (blockIdx.x * 7) & 15;
+        for (int i = 0; i < ph; i++) __builtin_amdgcn_s_sleep(2);               // 16 x 64 x 2 cycles: up to ~one step
+    }
     for (int i = tid; i < 2 * N + 4; i += 256) { h_hi[i] = 0u; h_lo[i] = 0u; }         // h(-1) = 0
     if (tid < 4) { rh_hi[2 * N + tid] = 0u; rh_lo[2 * N + tid] = 0u; }
     for (int i = tid; i < 3 * N; i += 256) bias_lds[i] = bias ? bias[i] : 0.0f;
@@ -699,7 +703,7 @@ static int launch_bar16(const float *x, long ldx, const float *iW, const float *
         DIAG_LAUNCH(1, true, 0) DIAG_LAUNCH(2, false, 1) DIAG_LAUNCH(3, false, 2) DIAG_LAUNCH(4, false, 4) DIAG_LAUNCH(5, false, 8)
         DIAG_LAUNCH(6, false, 16) DIAG_LAUNCH(7, false, 9) DIAG_LAUNCH(8, false, 3) DIAG_LAUNCH(9, false, 11) DIAG_LAUNCH(10, false, 31)
         DIAG_LAUNCH(11, false, 32) DIAG_LAUNCH(12, false, 34) DIAG_LAUNCH(13, false, 40) DIAG_LAUNCH(14, false, 42) DIAG_LAUNCH(15, false, 36)
-        DIAG_LAUNCH(16, false, 96) DIAG_LAUNCH(17, false, 128) DIAG_LAUNCH(18, false, 160)
+        DIAG_LAUNCH(16, false, 96) DIAG_LAUNCH(17, false, 128) DIAG_LAUNCH(18, false, 160) DIAG_LAUNCH(19, false, 288)
 #undef DIAG_LAUNCH
     }
     if (zr_out) {
