@@ -17,7 +17,8 @@ codes = {11: "production", 12: "chain waves without MFMAs", 13: "service waves i
          15: "cheap activations", 16: "state in column group 0 only, zeros in the other three (ZC experiment)", 18: "update-gate weights in accumulation registers (ZACC experiment)", 19: "workgroups started out of phase"}
 runs = [(1024, c) for c in (11, 16, 11, 16, 11, 16)] + [(768, 11), (256, 11)] + [(1024, c) for c in (12, 13, 14, 15, 11, 16)]
 WARM = 20
-if '--ab' in sys.argv: runs = [(1024, c) for c in (11, 19) * 8]
+abc = int(sys.argv[sys.argv.index('--ab') + 1]) if '--ab' in sys.argv and len(sys.argv) > sys.argv.index('--ab') + 1 else 16
+if '--ab' in sys.argv: runs = [(1024, c) for c in (11, abc) * 8]
 for B, code in runs:
     x = torch.randn(T, B, I, device='cuda', generator=g)
     y = torch.empty(T, B, n, device='cuda')
@@ -37,7 +38,7 @@ for B, code in runs:
     ms = real / 100e3                                     # 100 MHz wall clock
     mhz = cyc / real * 100.0
     if '--ab' in sys.argv:
-        print("%-12s event %.3f ms, clock median %.0f MHz, cycles/step %.0f" % ("production" if code == 11 else "staggered workgroups", e0.elapsed_time(e1), np.median(mhz), np.median(cyc) / T), flush=True)
+        print("%-12s event %.3f ms, clock median %.0f MHz, cycles/step %.0f" % ("production" if code == 11 else codes.get(code, str(code))[:28], e0.elapsed_time(e1), np.median(mhz), np.median(cyc) / T), flush=True)
         continue
     print("[%s]" % codes[code])
     print("B=%d: event %.3f ms; workgroups: %.3f..%.3f ms (median %.3f), shader clock %.0f..%.0f MHz (median %.0f), start spread %.1f us"
