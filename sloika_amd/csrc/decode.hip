@@ -16,6 +16,7 @@
 // and as ONE 16-BIT WORD per (t, four states) by the two nbase-4 kernels (see viterbi_forward4_kernel), and walked by a second
 // kernel that stages time-blocks of it in LDS.
 #include "common.h"
+#include "decode_internal.h"
 
 #define VIT_ETA 1e-10f
 #define VIT_STAY 255
@@ -852,6 +853,19 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
     else
         hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, false>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
                            len_out, lens);
+    return slk_launch_status();
+}
+
+int slk_backtrace_packed4(const uint8_t *tb, const int32_t *best, int T, int B, int nkmer, int32_t *path_out, int32_t *len_out,
+                          const int *lens, hipStream_t s)
+{
+    const int rowbytes = nkmer / 2;
+    int tblk = VBT_BLOCK / rowbytes;
+    if (tblk < 1) return SLK_ERR_UNSUPPORTED;
+    const int dma = (VBT_BLOCK % rowbytes == 0) && (rowbytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
+    if (tblk > T) tblk = T;
+    hipLaunchKernelGGL((viterbi_backtrace_kernel<4, true>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+                       len_out, lens);
     return slk_launch_status();
 }
 

@@ -1,0 +1,614 @@
+// softmax_viterbi.hip -- the Softmax layer's projection, softmax, prepare_post, log and the k-mer Viterbi forward pass in ONE
+// kernel: the [T', B, 1025] logits (3.4 GB at B = 1024) never exist in HBM.
+//
+//   layers.Softmax.run        sloika/layers.py:309-314    x.W^T + b, exp(t - max) / sum
+//   decode.prepare_post       sloika/decode.py:21-36      min_prob + (1 - min_prob) * post
+//   decode.viterbi            sloika/decode.py:39-82      log(post + 1e-10), forward max-plus DP, traceback
+//
+// (the backtrace, decode.py:84-91, is decode.hip's viterbi_backtrace_kernel on the packed traceback this kernel writes.)
+//
+// Plan (nbase 4, klen 5: 1024 k-mers + blank; K = insize a multiple of 16, <= 128):
+//   * one 512-thread workgroup = TWO chunks, walked through time in blocks of 16 steps.  The projection of a block is ONE
+//     32-row MFMA tile row (v_mfma_f32_32x32x16_f16, A = x rows, B = weight columns, three fp16 terms per product as in
+//     gemm_rows_f16x3.hip): rows 0-3, 8-11, 16-19, 24-27 are the 16 steps of the first chunk, the others those of the
+//     second, so the accumulators of lane half h (lanes 32h .. 32h+31) ARE the logits of chunk h -- register i of a tile is
+//     step i.  Wave w computes the four tiles whose column c is k-mer 4*(32w + c) + n, n = 0..3: lane (w, c, h) holds, for
+//     chunk h, the 16 steps x 4 to-states 4j .. 4j+3 (j = 32w + c) that thread j of viterbi_forward4_kernel owns.  The logits
+//     go from the matrix pipe to the dynamic programme without leaving the registers of the lane that consumes them.
+//   * the block AFTER the one being decoded is produced meanwhile (same waves, same basic blocks: MFMAs, exponentials and
+//     logarithms fill the issue slots the dependent max-plus chain leaves empty): step 0 splits the x rows into fp16 hi/lo
+//     operand images in LDS (row scales by powers of two, f16split.h), steps 1-9 run the 12 * K/16 MFMAs per wave with the
+//     weight fragments streamed from L2 three pairs ahead (pre-packed in fragment order: one 1-KiB coalesced load per
+//     fragment), steps 10-13 reduce the row maximum and the row sum over the 32 lanes of a half (a halving butterfly on
+//     v_permlane16_swap + DPP) and over the eight waves (through LDS, on the barriers the DP has anyway), steps 14-15 turn
+//     the exponentials into log-posteriors.
+//   * the blank column (state 0) is a float32 dot product on the vector unit (one row per 16-lane DPP row).
+//   * the DP itself is viterbi_forward4_kernel's (decode.hip): ping-pong score vectors in LDS (bank-conflict-free padding),
+//     one barrier per step, quad-DPP skip arg-max, first-maximum tie rules of np.argmax, packed 16-bit traceback staged in
+//     LDS and written as 8-KB runs.  Given its log-posteriors the paths and float32 scores are bit-identical to the
+//     reference's; the log-posteriors themselves can be dumped (lp_dump) so that tests decode THEM with the oracle.
+#include "f16split.h"
+#include <type_traits>
+
+#include "decode_internal.h"
+
+#define SV_THREADS 512
+#define SV_BLK 16
+#define SV_NK 1024
+#define SV_VP 1152              /* padded score vector: element i lives at i + 8 * (i >> 6) */
+#define SV_D 3                  /* weight fragment pairs in flight per wave */
+#define SV_ETA 1e-10f
+#define SV_LOG2E 1.4426950408889634f
+#define SV_LN2 0.6931471805599453f
+// timing-only builds of tools/build_sv_variants.sh (results are then garbage): 1 no MFMAs, 2 no weight loads, 4 no dynamic
+// programme, 8 no exponentials / logarithms, 16 no row reductions, 32 no operand preparation
+#ifndef SV_ABL
+#define SV_ABL 0
+#endif
+
+template <int K> using ic = std::integral_constant<int, K>;
+
+// ---- the packed weights: [wave 8][tile 4][K block KS][hi 1 KiB | lo 1 KiB] fragments, then per k-mer column the inverse
+// ---- scale and the bias, then the blank column's float32 weights and bias
+__host__ __device__ static inline size_t sv_frag_bytes(int KS) { return (size_t)8 * 4 * KS * 2048; }
+__host__ __device__ static inline size_t sv_pack_bytes(int KS) { return sv_frag_bytes(KS) + 2 * 4096 + (size_t)64 * KS + 16; }
+
+// one wave per fragment (w, n, s); the last block writes the blank column
+__global__ void __launch_bounds__(64) sv_pack_kernel(const float *__restrict__ W, const float *__restrict__ bias, int K, int KS,
+                                                     uint8_t *__restrict__ pack)
+{
+    const int lane = threadIdx.x, c = lane & 31, hk = lane >> 5;
+    const size_t frag = sv_frag_bytes(KS);
+    float *cinv = reinterpret_cast<float *>(pack + frag), *cbias = cinv + 1024, *w0 = cbias + 1024;
+    if ((int)blockIdx.x == 32 * KS) {
+        for (int k = lane; k < 16 * KS; k += 64) w0[k] = k < K ? W[k] : 0.0f;
+        if (lane == 0) w0[16 * KS] = bias ? bias[0] : 0.0f;
+        return;
+    }
+    const int s = blockIdx.x % KS, n = (blockIdx.x / KS) & 3, w = blockIdx.x / (4 * KS);
+    const int kmer = 4 * (32 * w + c) + n;
+    const float *row = W + (size_t)(1 + kmer) * K;
+    float amax = 0.0f;
+    for (int k = 0; k < K; k++) amax = fmaxf(amax, fabsf(row[k]));
+    float inv;
+    const float sc = pow2_scale(amax, inv);
+    half8 hi, lo;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        const int k = 16 * s + 8 * hk + jj;
+        float v = k < K ? row[k] * sc : 0.0f;
+        keepf(v);
+        const _Float16 hv = (_Float16)v;
+        hi[jj] = hv;
+        lo[jj] = (_Float16)(v - (float)hv);
+    }
+    uint8_t *dst = pack + ((size_t)(w * 4 + n) * KS + s) * 2048 + lane * 16;
+    *reinterpret_cast<half8 *>(dst) = hi;
+    *reinterpret_cast<half8 *>(dst + 1024) = lo;
+    if (s == 0 && hk == 0) {
+        cinv[kmer] = inv;
+        cbias[kmer] = bias ? bias[1 + kmer] : 0.0f;
+    }
+}
+
+// ---- reductions over the 32 lanes of a wave half, 16 values at a time: every stage halves the number of values a lane
+// ---- carries (it keeps the half its selector bit names and receives the partner's contribution to it), so 16 values cost
+// ---- 8 + 4 + 2 + 1 + 1 exchanges instead of 16 x 5.  Returns the reduced value of index (lane & 31) >> 1.
+template <bool SUM> __device__ __forceinline__ float sv_op(float a, float b) { return SUM ? a + b : fmaxf(a, b); }
+template <int CTRL> __device__ __forceinline__ float sv_dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <bool SUM> __device__ __forceinline__ float sv_half_reduce16(const float (&v)[16], int lane)
+{
+    float a[8], b[4], c[2];
+    // lanes l and l ^ 16: v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its
+    // second, so (value i, value i + 8) -> even rows hold both halves of value i, odd rows both halves of value i + 8
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
+        a[i] = sv_op<SUM>(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    const bool s8 = lane & 8, s4 = lane & 4, s2 = lane & 2;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {                       // partner l ^ 8 (row_ror:8)
+        const float send = s8 ? a[i] : a[i + 4], keepv = s8 ? a[i + 4] : a[i];
+        b[i] = sv_op<SUM>(keepv, sv_dpp<0x128>(send));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                       // partner 7 - l within eight lanes (row_half_mirror): bit 2 differs
+        const float send = s4 ? b[i] : b[i + 2], keepv = s4 ? b[i + 2] : b[i];
+        c[i] = sv_op<SUM>(keepv, sv_dpp<0x141>(send));
+    }
+    const float send = s2 ? c[0] : c[1], keepv = s2 ? c[1] : c[0];
+    const float d = sv_op<SUM>(keepv, sv_dpp<0x4E>(send));          // partner l ^ 2 (quad_perm [2,3,0,1])
+    return sv_op<SUM>(d, sv_dpp<0xB1>(d));                          // partner l ^ 1: both lanes end with the same value
+}
+// all 16 lanes of a DPP row receive the row's maximum / sum
+template <bool SUM> __device__ __forceinline__ float sv_row_allreduce(float v)
+{
+    v = sv_op<SUM>(v, sv_dpp<0x128>(v));
+    v = sv_op<SUM>(v, sv_dpp<0x124>(v));
+    v = sv_op<SUM>(v, sv_dpp<0x122>(v));
+    return sv_op<SUM>(v, sv_dpp<0x121>(v));
+}
+
+__device__ __forceinline__ float sv_log(float x) { return __builtin_amdgcn_logf(x) * SV_LN2; }
+// decode.py:36 and :56 on a posterior p, float32 like numpy (no contraction)
+__device__ __forceinline__ float sv_logpost(float p, float min_prob, float one_m)
+{
+    return sv_log(__fadd_rn(__fadd_rn(min_prob, __fmul_rn(one_m, p)), SV_ETA));
+}
+
+template <int KS>
+__global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float *__restrict__ x, long ldx, int T, int B,
+                                                                     const uint8_t *__restrict__ pack, float skip_pen,
+                                                                     float min_prob, float one_m, uint8_t *__restrict__ tb,
+                                                                     int32_t *__restrict__ best_out,
+                                                                     float *__restrict__ score_out,
+                                                                     const int *__restrict__ lens,
+                                                                     float *__restrict__ lp_dump)
+{
+    constexpr int NP = 4 * KS;                                  // weight fragment pairs per wave and block
+    constexpr int OFF_V = 0;                                    // [chunk 2][parity 2][SV_VP] float
+    constexpr int OFF_TBS = OFF_V + 2 * 2 * SV_VP * 4;          // [parity 2][chunk 2][step 16][256] uint16
+    constexpr int OFF_A = OFF_TBS + 2 * 2 * 16 * 512;           // [KS][hi, lo][64 lanes][16 B]
+    constexpr int OFF_CINV = OFF_A + KS * 2048;                 // [1024] float
+    constexpr int OFF_CBIAS = OFF_CINV + 4096;                  // [1024] float
+    constexpr int OFF_W0 = OFF_CBIAS + 4096;                    // [16 KS] float, then the blank bias
+    constexpr int OFF_XINV = OFF_W0 + 64 * KS + 16;             // [chunk 2][step 16] float
+    constexpr int OFF_L0 = OFF_XINV + 128;                      // [2][16] blank logits
+    constexpr int OFF_REDA = OFF_L0 + 128;                      // [2][16][wave 8] partial maxima
+    constexpr int OFF_REDB = OFF_REDA + 1024;                   // [2][16][8] partial sums
+    constexpr int OFF_FINM = OFF_REDB + 1024;                   // [2][16] row maxima
+    constexpr int OFF_FININV = OFF_FINM + 128;                  // [2][16] 1 / row sums
+    constexpr int OFF_LP0 = OFF_FININV + 128;                   // [parity 2][2][16] blank log-posteriors
+    constexpr int OFF_REDV = OFF_LP0 + 256;                     // [2][8]
+    constexpr int OFF_REDI = OFF_REDV + 64;                     // [2][8]
+    constexpr int SMEM = OFF_REDI + 64;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, hch = lane >> 5;
+    const int j = 32 * wave + c, q = j >> 2, cc = j & 3;
+    const int b0 = 2 * blockIdx.x;
+    const int Tpad = T;
+    const int Tc0 = lens ? min(max(lens[b0], 1), T) : T;
+    const int Tc1 = b0 + 1 < B ? (lens ? min(max(lens[b0 + 1], 1), T) : T) : 0;
+    const int nblk = (max(Tc0, Tc1) + SV_BLK - 1) / SV_BLK;
+    const int Tc_own = hch ? Tc1 : Tc0;
+    const int b_own = b0 + hch;
+
+    float *const vb = reinterpret_cast<float *>(smem + OFF_V) + hch * 2 * SV_VP;
+    uint16_t *const tbs = reinterpret_cast<uint16_t *>(smem + OFF_TBS);
+    const float *const lp0b = reinterpret_cast<const float *>(smem + OFF_LP0) + hch * 16;
+    const int o_step = j + 8 * (j >> 6), o_skip = cc * 72 + q, o_own = 4 * j + 8 * (j >> 4);
+    auto bar = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+    // ---- constants of the whole kernel into LDS ----
+    {
+        const float *src = reinterpret_cast<const float *>(pack + sv_frag_bytes(KS));
+        float *dst = reinterpret_cast<float *>(smem + OFF_CINV);
+        for (int i = tid; i < 2048 + 16 * KS + 4; i += SV_THREADS) dst[i] = src[i];
+    }
+
+    // ---- production of a block: state ----
+    // buffer loads: descriptor of the fragment area (uniform), the wave's and the fragment's offset in the scalar offset, the
+    // lane's 16 bytes in the vector offset -- no per-fragment 64-bit pointers in vector registers
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(pack), 0, (int)sv_frag_bytes(KS), 0x00020000);
+    const int wwave = wave * 4 * KS * 2048;
+    const int wlane = lane * 16;
+    half8 wfh[SV_D], wfl[SV_D];
+    f32x16 acc[4];
+    float val[4][16];                                          // logits -> exponentials -> log-posteriors of the block in the making
+    float4 xr0, xr1;                                           // this lane's eight x values of the next block
+    const int kb = lane & 15, r4 = lane >> 4;
+    const int pa_chunk = wave & 1, pa_step = r4 + 4 * (wave >> 1), rho = 4 * wave + r4;
+    const bool pa_act = kb < 2 * KS;
+    const int pa_b = min(b0 + pa_chunk, B - 1);
+
+    auto load_x = [&](int blk) {
+        const int t = min(SV_BLK * blk + pa_step, T - 1);
+        const float *src = x + ((size_t)t * B + pa_b) * ldx + 8 * min(kb, 2 * KS - 1);
+        xr0 = *reinterpret_cast<const float4 *>(src);
+        xr1 = *reinterpret_cast<const float4 *>(src + 4);
+    };
+    // x rows of the block -> fp16 hi/lo A-operand images, row scales, blank logits
+    auto prepare_a = [&]() {
+        float xv[8] = {xr0.x, xr0.y, xr0.z, xr0.w, xr1.x, xr1.y, xr1.z, xr1.w};
+#pragma unroll
+        for (int i = 0; i < 8; i++) xv[i] = pa_act ? xv[i] : 0.0f;
+        float amax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(xv[i]));
+        amax = sv_row_allreduce<false>(amax);
+        float inv;
+        const float sc = pow2_scale(amax, inv);
+        const float *w0 = reinterpret_cast<const float *>(smem + OFF_W0);
+        const float4 wa = *reinterpret_cast<const float4 *>(w0 + 8 * min(kb, 2 * KS - 1));
+        const float4 wb = *reinterpret_cast<const float4 *>(w0 + 8 * min(kb, 2 * KS - 1) + 4);
+        float dot = xv[0] * wa.x;
+        dot = fmaf(xv[1], wa.y, dot);
+        dot = fmaf(xv[2], wa.z, dot);
+        dot = fmaf(xv[3], wa.w, dot);
+        dot = fmaf(xv[4], wb.x, dot);
+        dot = fmaf(xv[5], wb.y, dot);
+        dot = fmaf(xv[6], wb.z, dot);
+        dot = fmaf(xv[7], wb.w, dot);
+        dot = sv_row_allreduce<true>(dot);
+        half8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            float v = xv[i] * sc;
+            keepf(v);
+            const _Float16 hv = (_Float16)v;
+            hi[i] = hv;
+            lo[i] = (_Float16)(v - (float)hv);
+        }
+        if (pa_act) {
+            uint8_t *dst = smem + OFF_A + (kb >> 1) * 2048 + (rho + 32 * (kb & 1)) * 16;
+            *reinterpret_cast<half8 *>(dst) = hi;
+            *reinterpret_cast<half8 *>(dst + 1024) = lo;
+        }
+        if (kb == 0) {
+            reinterpret_cast<float *>(smem + OFF_XINV)[pa_chunk * 16 + pa_step] = inv;
+            reinterpret_cast<float *>(smem + OFF_L0)[pa_chunk * 16 + pa_step] = dot + w0[16 * KS];
+        }
+    };
+    auto wload = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p < NP && !(SV_ABL & 2)) {
+            wfh[p % SV_D] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, wwave + p * 2048, 0));
+            wfl[p % SV_D] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, wwave + p * 2048 + 1024, 0));
+        }
+    };
+    // fragment pair p = (tile n, K block s): three MFMAs, small terms first (gemm_rows_f16x3.hip)
+    auto mma_pair = [&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int n = p / KS, s = p % KS;
+        const half8 ahi = *reinterpret_cast<const half8 *>(smem + OFF_A + s * 2048 + lane * 16);
+        const half8 alo = *reinterpret_cast<const half8 *>(smem + OFF_A + s * 2048 + 1024 + lane * 16);
+        if constexpr (s == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[n][i] = 0.0f;
+        }
+        if constexpr (!(SV_ABL & 1)) {
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, wfh[p % SV_D], acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wfl[p % SV_D], acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wfh[p % SV_D], acc[n], 0, 0, 0);
+        } else {
+            acc[n][0] += (float)ahi[0] + (float)alo[1] + (float)wfh[p % SV_D][0] + (float)wfl[p % SV_D][1];
+        }
+        wload(ic<p + SV_D>{});
+    };
+    auto mma_range = [&](auto lo_c, auto hi_c, auto &&self) {
+        constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+        if constexpr (lo < hi) {
+            mma_pair(ic<lo>{});
+            self(ic<lo + 1>{}, hi_c, self);
+        }
+    };
+    auto load16 = [&](int off, float (&out)[16]) {             // this chunk's 16 per-step values
+        const float4 *p = reinterpret_cast<const float4 *>(smem + off) + hch * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4 v = p[i];
+            out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
+        }
+    };
+    // scaled accumulators -> logits (gemm_rows_f16x3.hip's finish), partial row maxima
+    auto finish_max = [&]() {
+        float xinv[16];
+        load16(OFF_XINV, xinv);
+        const float4 ci = reinterpret_cast<const float4 *>(smem + OFF_CINV)[j];
+        const float4 cb = reinterpret_cast<const float4 *>(smem + OFF_CBIAS)[j];
+        const float civ[4] = {ci.x, ci.y, ci.z, ci.w}, cbv[4] = {cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) val[n][i] = fmaf(acc[n][i] * xinv[i], civ[n], cbv[n]);
+        float m[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) m[i] = fmaxf(fmaxf(val[0][i], val[1][i]), fmaxf(val[2][i], val[3][i]));
+        const float r = (SV_ABL & 16) ? m[0] + m[15] : sv_half_reduce16<false>(m, lane);
+        if (!(c & 1)) reinterpret_cast<float *>(smem + OFF_REDA)[(hch * 16 + (c >> 1)) * 8 + wave] = r;
+    };
+    auto final_max = [&]() {                                   // 32 lanes: one (chunk, step) each
+        if (tid < 32) {
+            const float4 *p = reinterpret_cast<const float4 *>(smem + OFF_REDA) + 2 * tid;
+            const float4 a = p[0], b = p[1];
+            float m = fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
+            m = fmaxf(m, reinterpret_cast<const float *>(smem + OFF_L0)[tid]);
+            reinterpret_cast<float *>(smem + OFF_FINM)[tid] = m;
+        }
+    };
+    auto exp_sum = [&]() {
+        float m[16];
+        load16(OFF_FINM, m);
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                val[n][i] = (SV_ABL & 8) ? (val[n][i] - m[i]) * SV_LOG2E : __builtin_amdgcn_exp2f((val[n][i] - m[i]) * SV_LOG2E);
+        float s[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) s[i] = ((val[0][i] + val[1][i]) + val[2][i]) + val[3][i];
+        const float r = (SV_ABL & 16) ? s[0] + s[15] : sv_half_reduce16<true>(s, lane);
+        if (!(c & 1)) reinterpret_cast<float *>(smem + OFF_REDB)[(hch * 16 + (c >> 1)) * 8 + wave] = r;
+    };
+    auto final_sum = [&](int nb) {
+        if (tid < 32) {
+            const float4 *p = reinterpret_cast<const float4 *>(smem + OFF_REDB) + 2 * tid;
+            const float4 a = p[0], b = p[1];
+            const float m = reinterpret_cast<const float *>(smem + OFF_FINM)[tid];
+            const float e0 = __builtin_amdgcn_exp2f((reinterpret_cast<const float *>(smem + OFF_L0)[tid] - m) * SV_LOG2E);
+            const float ssum = (((((((a.x + a.y) + a.z) + a.w) + b.x) + b.y) + b.z) + b.w) + e0;
+            const float inv = 1.0f / ssum;
+            reinterpret_cast<float *>(smem + OFF_FININV)[tid] = inv;
+            const float l0 = sv_logpost(e0 * inv, min_prob, one_m);
+            reinterpret_cast<float *>(smem + OFF_LP0)[(nb & 1) * 32 + tid] = l0;
+            if (lp_dump) {
+                const int t = SV_BLK * nb + (tid & 15), bb = b0 + (tid >> 4);
+                if (t < T && bb < B) lp_dump[((size_t)t * B + bb) * (SV_NK + 1)] = l0;
+            }
+        }
+    };
+    auto to_logpost = [&](auto n0c) {
+        constexpr int n0 = decltype(n0c)::value;
+        float inv[16];
+        load16(OFF_FININV, inv);
+#pragma unroll
+        for (int n = n0; n < n0 + 2; n++)
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                val[n][i] = (SV_ABL & 8) ? val[n][i] * inv[i] + min_prob : sv_logpost(val[n][i] * inv[i], min_prob, one_m);
+    };
+    auto dump_block = [&](int nb) {
+        if (lp_dump && b_own < B) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int t = SV_BLK * nb + i;
+                if (t < T) {
+                    float *dst = lp_dump + ((size_t)t * B + b_own) * (SV_NK + 1) + 1 + 4 * j;
+                    dst[0] = val[0][i]; dst[1] = val[1][i]; dst[2] = val[2][i]; dst[3] = val[3][i];
+                }
+            }
+        }
+    };
+    // side work of step k of a period: the production of block nb
+    auto side = [&](auto kc, int nb) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k == 0) {
+            if constexpr (!(SV_ABL & 32)) prepare_a();
+            wload(ic<0>{});
+            wload(ic<1>{});
+            wload(ic<2>{});
+        } else if constexpr (k <= 9) {
+            mma_range(ic<((k - 1) * NP) / 9>{}, ic<(k * NP) / 9>{}, mma_range);
+        } else if constexpr (k == 10) {
+            finish_max();
+        } else if constexpr (k == 11) {
+            final_max();
+            load_x(nb + 1);
+        } else if constexpr (k == 12) {
+            exp_sum();
+        } else if constexpr (k == 13) {
+            final_sum(nb);
+        } else if constexpr (k == 14) {
+            to_logpost(ic<0>{});
+        } else {
+            to_logpost(ic<2>{});
+            dump_block(nb);
+        }
+    };
+
+    // ---- the dynamic programme: step t0 + k of block cb, log-posteriors lp[n][k] (viterbi_forward4_kernel::step) ----
+    float lp[4][16];
+    auto dp_step = [&](auto kc, int t0, int par) {
+        constexpr int k = decltype(kc)::value;
+        const float *vold = vb + ((k & 1) ^ 1) * SV_VP;
+        float *vnew = vb + (k & 1) * SV_VP;
+        // step maximum over a (first maximum wins: np.argmax, decode.py:67-68)
+        float sstep = vold[o_step];
+        int sarg = 0;
+#pragma unroll
+        for (int a = 1; a < 4; a++) {
+            const float xx = vold[a * 288 + o_step];
+            if (xx > sstep) { sstep = xx; sarg = a; }
+        }
+        // skip maximum over ab = a*4 + b: this thread's share is b = cc
+        float kbest = vold[o_skip];
+        int karg = cc;
+#pragma unroll
+        for (int a = 1; a < 4; a++) {
+            const float xx = vold[a * 288 + o_skip];
+            if (xx > kbest) { kbest = xx; karg = a * 4 + cc; }
+        }
+        const float4 own = *reinterpret_cast<const float4 *>(&vold[o_own]);
+        const float lp0 = lp0b[par * 32 + k];
+        {   // quad exchange: lane ^ 1, then lane ^ 2 (first maximum in ab order wins, decode.py:72-73)
+            float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(kbest), 0xB1, 0xf, 0xf, false));
+            int ok = __builtin_amdgcn_update_dpp(0, karg, 0xB1, 0xf, 0xf, false);
+            bool take = (ov > kbest) | ((ov == kbest) & (ok < karg));
+            kbest = take ? ov : kbest;
+            karg = take ? ok : karg;
+            ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(kbest), 0x4E, 0xf, 0xf, false));
+            ok = __builtin_amdgcn_update_dpp(0, karg, 0x4E, 0xf, 0xf, false);
+            take = (ov > kbest) | ((ov == kbest) & (ok < karg));
+            kbest = take ? ov : kbest;
+            karg = take ? ok : karg;
+        }
+        const float sskip = kbest - skip_pen;                       // decode.py:72
+        const float mx = fmaxf(sstep, sskip);
+        const uint32_t how = sstep > sskip ? 1u : 2u;               // decode.py:76 (tie -> skip)
+        const float ownv[4] = {own.x, own.y, own.z, own.w};
+        float nw[4];
+        uint32_t packed = ((uint32_t)sarg << 8) | ((uint32_t)karg << 10);
+        const bool live = t0 + k < Tc_own;                          // ragged batch: a chunk past its end keeps its scores
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const float nv = lp[n][k] + mx;                         // decode.py:75
+            const float stay = ownv[n] + lp0;                       // decode.py:80
+            const bool move = nv > stay;                            // decode.py:81 (tie -> stay)
+            packed |= (move ? how : 0u) << (2 * n);
+            float r = move ? nv : stay;
+            if constexpr (k == 0) r = t0 == 0 ? lp[n][0] : r;       // t = 0: v = lpost[0][1:] (decode.py:57)
+            nw[n] = live ? r : ownv[n];
+        }
+        *reinterpret_cast<float4 *>(&vnew[o_own]) = make_float4(nw[0], nw[1], nw[2], nw[3]);
+        tbs[((par * 2 + hch) * 16 + k) * 256 + j] = (uint16_t)packed;
+    };
+    // rows of block blk (staged with parity par) -> HBM, 8 KB per chunk
+    auto flush_tb = [&](int blk, int par) {
+#pragma unroll
+        for (int u0 = 0; u0 < 1024; u0 += SV_THREADS) {
+            const int u = u0 + tid, hc = u >> 9, rest = u & 511, t = SV_BLK * blk + (rest >> 5);
+            const int tc = hc ? Tc1 : Tc0;
+            if (t >= 1 && t < tc)
+                *reinterpret_cast<uint4 *>(tb + ((size_t)(b0 + hc) * Tpad + SV_BLK * blk) * (SV_NK / 2) + rest * 16) =
+                    *reinterpret_cast<const uint4 *>(smem + OFF_TBS + ((par * 2 + hc) * 16) * 512 + rest * 16);
+        }
+    };
+
+    auto period = [&](auto dpc, auto prodc, int cb) {
+        constexpr bool DP = decltype(dpc)::value, PROD = decltype(prodc)::value;
+        const int t0 = SV_BLK * cb, par = cb & 1, nb = cb + 1;
+#define SV_STEP(K)                                       \
+    do {                                                 \
+        if constexpr (PROD) side(ic<K>{}, nb);           \
+        if constexpr (DP && !(SV_ABL & 4)) dp_step(ic<K>{}, t0, par); \
+        bar();                                           \
+    } while (0)
+        SV_STEP(0);
+        SV_STEP(1);
+        SV_STEP(2);
+        SV_STEP(3);
+        SV_STEP(4);
+        SV_STEP(5);
+        SV_STEP(6);
+        SV_STEP(7);
+        SV_STEP(8);
+        SV_STEP(9);
+        SV_STEP(10);
+        SV_STEP(11);
+        if (DP && cb >= 1) flush_tb(cb - 1, par ^ 1);               // here no weight load is in flight
+        SV_STEP(12);
+        SV_STEP(13);
+        SV_STEP(14);
+        SV_STEP(15);
+#undef SV_STEP
+    };
+    auto adopt = [&]() {
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) lp[n][i] = val[n][i];
+    };
+
+    load_x(0);
+    bar();                                                      // constants staged
+    period(std::false_type{}, std::true_type{}, -1);
+    adopt();
+    for (int cb = 0; cb + 1 < nblk; cb++) {
+        period(std::true_type{}, std::true_type{}, cb);
+        adopt();
+    }
+    period(std::true_type{}, std::false_type{}, nblk - 1);
+    flush_tb(nblk - 1, (nblk - 1) & 1);
+
+    // ---- first argmax of the final scores (np.argmax, decode.py:85); the last step of a block writes parity 1 ----
+    {
+        const float4 fv = *reinterpret_cast<const float4 *>(&vb[SV_VP + o_own]);
+        const float f[4] = {fv.x, fv.y, fv.z, fv.w};
+        float bv = f[0];
+        int bi = 4 * j;
+#pragma unroll
+        for (int n = 1; n < 4; n++)
+            if (f[n] > bv) { bv = f[n]; bi = 4 * j + n; }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        float *redv = reinterpret_cast<float *>(smem + OFF_REDV) + hch * 8;
+        int *redi = reinterpret_cast<int *>(smem + OFF_REDI) + hch * 8;
+        if (c == 0) { redv[wave] = bv; redi[wave] = bi; }
+        bar();
+        if (wave == 0 && c == 0 && b_own < B) {
+            bv = redv[0];
+            bi = redi[0];
+            for (int w = 1; w < 8; w++)
+                if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
+            score_out[b_own] = bv;
+            best_out[b_own] = bi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+static bool sv_shape_ok(int K, int nbase, int klen) { return nbase == 4 && klen == 5 && K >= 16 && K <= 128 && K % 16 == 0; }
+
+extern "C" size_t slk_softmax_viterbi_pack_bytes(int K, int nbase, int klen)
+{
+    if (!sv_shape_ok(K, nbase, klen)) return 0;
+    return (sv_pack_bytes(K / 16) + 255) & ~(size_t)255;
+}
+
+extern "C" int slk_softmax_viterbi_pack_f32(const float *W, const float *bias, int K, int nbase, int klen, void *pack,
+                                            slk_stream_t stream)
+{
+    if (!W || !pack || K < 1 || nbase < 2 || klen < 1) return SLK_ERR_INVALID_ARG;
+    if (!sv_shape_ok(K, nbase, klen)) return SLK_ERR_UNSUPPORTED;
+    const int KS = K / 16;
+    hipLaunchKernelGGL(sv_pack_kernel, dim3(32 * KS + 1), dim3(64), 0, slk_stream(stream), W, bias, K, KS,
+                       static_cast<uint8_t *>(pack));
+    return slk_launch_status();
+}
+
+template <int KS>
+static int sv_launch(const float *x, long ldx, int T, int B, const uint8_t *pack, float skip_pen, float min_prob, uint8_t *tb,
+                     int32_t *best, float *score_out, const int *lens, float *lp_dump, hipStream_t s)
+{
+    hipLaunchKernelGGL((softmax_viterbi_kernel<KS>), dim3((B + 1) / 2), dim3(SV_THREADS), 0, s, x, ldx, T, B, pack, skip_pen,
+                       min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
+    return slk_launch_status();
+}
+
+extern "C" int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pack, int K, int T, int B, int nbase, int klen,
+                                       float skip_pen, float min_prob, const int32_t *lens, void *workspace,
+                                       size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out,
+                                       float *lp_dump, slk_stream_t stream)
+{
+    if (!x || !pack || !score_out || !path_out || !len_out || T < 1 || B < 1 || K < 1 || ldx < K || nbase < 2 || klen < 3)
+        return SLK_ERR_INVALID_ARG;
+    if (!sv_shape_ok(K, nbase, klen) || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;
+    const size_t need = slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen);
+    if (!workspace || workspace_bytes < need) return SLK_ERR_WORKSPACE;
+    uint8_t *tb = static_cast<uint8_t *>(workspace);
+    const size_t tbbytes = ((size_t)B * T * SV_NK + 255) & ~(size_t)255;
+    int32_t *best = reinterpret_cast<int32_t *>(tb + tbbytes);
+    const uint8_t *pk = static_cast<const uint8_t *>(pack);
+    hipStream_t s = slk_stream(stream);
+    int rc;
+    switch (K / 16) {
+#define SV_CASE(KS) case KS: rc = sv_launch<KS>(x, ldx, T, B, pk, skip_pen, min_prob, tb, best, score_out, lens, lp_dump, s); break;
+#ifdef SV_ONLY_KS          /* development builds: one instantiation */
+    SV_CASE(SV_ONLY_KS)
+#else
+    SV_CASE(1) SV_CASE(2) SV_CASE(3) SV_CASE(4) SV_CASE(5) SV_CASE(6) SV_CASE(7) SV_CASE(8)
+#endif
+#undef SV_CASE
+    default: return SLK_ERR_UNSUPPORTED;
+    }
+    if (rc != SLK_OK) return rc;
+#ifdef SV_NO_BACKTRACE
+    return rc;
+#else
+    return slk_backtrace_packed4(tb, best, T, B, SV_NK, path_out, len_out, lens, s);
+#endif
+}

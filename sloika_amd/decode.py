@@ -138,6 +138,43 @@ def viterbi_logits_batch(logits, stats, klen, T, B, ld=None, skip_pen=0.0, nbase
     return scores, paths, lens
 
 
+def viterbi_fused_batch(x, pack, klen, skip_pen=0.0, nbase=4, min_prob=1e-5, workspace=None, lengths=None, lp_dump=None):
+    """basecall.decode_post(softmax layer(x)) over the batch axis from the Softmax layer's INPUT x [T, B, insize] and its
+    packed weights (layers.Softmax.viterbi_pack): projection, softmax (layers.py:309-314), prepare_post (decode.py:21-36),
+    log and the Viterbi forward pass (decode.py:39-82) in one kernel (csrc/softmax_viterbi.hip), then the backtrace
+    (decode.py:84-91).  The logits are never written.  `lp_dump`: optional float32 device tensor [T, B, nstate] that
+    receives the log-posteriors the dynamic programme consumed.  Same outputs as viterbi_logits_batch."""
+    import torch
+    from . import device as D
+    if klen < 3:
+        raise ValueError("Kmer not long enough to apply Viterbi with skips")
+    if x.dim() != 3 or x.dtype != torch.float32 or not x.is_cuda or x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
+        raise ValueError("x must be a float32 device tensor [time, batch, features] with uniformly spaced rows")
+    T, B, K = x.shape
+    S = sv.nstate(klen, transducer=True, nbase=nbase)
+    L = _lib.lib()
+    nbytes = L.slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen)
+    if nbytes == 0:
+        raise ValueError("unsupported klen/nbase for the Viterbi kernel")
+    ws = (workspace or ViterbiWorkspace()).get(nbytes, x.device)
+    scores = torch.empty(B, dtype=torch.float32, device=x.device)
+    paths = torch.empty((B, T), dtype=torch.int32, device=x.device)
+    lens = torch.empty(B, dtype=torch.int32, device=x.device)
+    if lengths is not None and (lengths.dtype != torch.int32 or lengths.numel() != B or not lengths.is_cuda):
+        raise ValueError("lengths must be an int32 device tensor with one entry per chunk")
+    if lp_dump is not None and (lp_dump.dtype != torch.float32 or lp_dump.numel() != T * B * S or not lp_dump.is_contiguous()):
+        raise ValueError("lp_dump must be a contiguous float32 device tensor [T, B, nstate]")
+    rows = float(T) * B
+    with profiler.region("softmax_viterbi", 2.0 * rows * K * S, rows * (4.0 * K + 1.0 * (nbase ** klen)),
+                         f16x3_flops=2.0 * rows * K * S):
+        rc = L.slk_softmax_viterbi_f32(x.data_ptr(), x.stride(1), pack.data_ptr(), K, T, B, nbase, klen, float(skip_pen),
+                                       float(min_prob), lengths.data_ptr() if lengths is not None else None, ws.data_ptr(),
+                                       nbytes, scores.data_ptr(), paths.data_ptr(), lens.data_ptr(),
+                                       lp_dump.data_ptr() if lp_dump is not None else None, D.stream_ptr())
+    _lib.check(rc, "decode.viterbi_fused")
+    return scores, paths, lens
+
+
 def viterbi(post, klen, skip_pen=0.0, log=False, nbase=4):
     """Viterbi decoding of a kmer transducer (decode.py:39-93).
 

@@ -139,21 +139,43 @@ def gru_f16_entry():
     L = _lib.lib()
     return L.slk_gru_bar16_f32 if GRU_PLAN == "bar" else L.slk_gru_fused16_f32
 
+def _derived_cache(owner, attr, params, build):
+    """Device tensors derived from the Shared leaves `params` (fp16 splits, re-laid-out weights, zero-padded twins), kept on
+    `owner` under `attr` and re-made by `build()` whenever a leaf's device buffer OR its version (Shared.set_value) changes.
+    The kernels that build them run on the stream of the first caller: an event recorded behind them is kept with the cache
+    and a caller on any other stream waits for it before its kernels read the tensors (several Basecallers, one per stream,
+    share one network)."""
+    import torch
+    key = tuple((p.dev(), getattr(p, "_version", 0)) for p in params)
+    cache = owner.__dict__.get(attr)
+    stale = cache is None or len(cache[0]) != len(key) or any(a[0] is not b[0] or a[1] != b[1] for a, b in zip(cache[0], key))
+    cur = torch.cuda.current_stream()
+    if stale:
+        tensors = build()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        owner.__dict__[attr] = cache = (key, tensors, ev, cur)
+    elif cache[3] != cur and not cache[2].query():
+        cur.wait_event(cache[2])
+    return cache[1]
+
+
 def _split_f16_cached(owner, attr, param, rows, k):
     """fp16 hi/lo parts of the [rows][k] weight `param` (rows scaled by powers of two) and the inverse row scales, on the
     device, re-made whenever the parameter changes."""
     import torch
-    wd = param.dev()
-    cache = owner.__dict__.get(attr)
-    if cache is None or cache[0] is not wd:
+
+    def build():
+        wd = param.dev()
         kp = (k + 15) // 16 * 16
         hi = torch.empty((rows, kp), dtype=torch.float16, device=wd.device)
         lo = torch.empty((rows, kp), dtype=torch.float16, device=wd.device)
         inv = torch.empty((rows,), dtype=torch.float32, device=wd.device)
         _lib.check(_lib.lib().slk_split_f16x2_f32(wd.data_ptr(), rows, k, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(),
                                                   _stream()), "split_f16")
-        owner.__dict__[attr] = cache = (wd, hi, lo, inv)
-    return cache[1], cache[2], cache[3]
+        return hi, lo, inv
+
+    return _derived_cache(owner, attr, (param,), build)
 
 
 def _projection(owner, x, W, b, ws_ptr, rows, k, n_out, stage, name):
@@ -449,8 +471,28 @@ class Softmax(Layer):
 
     def __getstate__(self):
         d = dict(self.__dict__)
-        d.pop("_w16", None)          # device cache: never pickled
+        d.pop("_w16", None)          # device caches: never pickled
+        d.pop("_svpack", None)
         return d
+
+    def viterbi_pack(self, nbase, klen):
+        """The weights as csrc/softmax_viterbi.hip wants them (MFMA fragment order, fp16 hi/lo, column scales) for decoding
+        straight from this layer's INPUT (decode.viterbi_fused_batch), or None where that kernel does not apply (state count
+        other than 4^5 + 1, insize not a multiple of 16 up to 128, all-fp32 arithmetic requested)."""
+        import torch
+        L = _lib.lib()
+        nbytes = L.slk_softmax_viterbi_pack_bytes(self.insize, nbase, klen) if self.split_f16 else 0
+        if nbytes == 0 or self.size != nbase ** klen + 1:
+            return None
+
+        def build():
+            wd, bd = self.W.dev(), self.b.dev()
+            pack = torch.empty(nbytes, dtype=torch.uint8, device=wd.device)
+            _lib.check(L.slk_softmax_viterbi_pack_f32(wd.data_ptr(), bd.data_ptr(), self.insize, nbase, klen, pack.data_ptr(),
+                                                      _stream()), "softmax_viterbi_pack")
+            return pack
+
+        return _derived_cache(self, "_svpack", (self.W, self.b), build)
 
     def _logits(self, x, ld):
         """tmp = x.W^T + b (layers.py:310) with rows `ld` floats apart, and per-row (max, 1/sum exp) [T*B,2]."""
