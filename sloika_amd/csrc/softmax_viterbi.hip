@@ -35,8 +35,37 @@
 #define SV_THREADS 512
 #define SV_BLK 16
 #define SV_NK 1024
-#define SV_VP 1152              /* padded score vector: element i lives at i + 8 * (i >> 6) */
+#define SV_AS 320               /* floats between the four first-base blocks of a score vector (5 x 64 dwords: ds_read2st64) */
+#define SV_VP (4 * SV_AS)       /* padded score vector: element a*256 + r lives at a*SV_AS + r + 8 * (r >> 6) */
+#ifndef SV_D
 #define SV_D 3                  /* weight fragment pairs in flight per wave */
+#endif
+// diagnostic build (tools only): workgroup 0, wave 0 stamps the shader clock after every step's barrier into lp_dump (then a
+// buffer of uint64 [periods][16], not a log-posterior dump)
+#ifdef SV_DIAG
+#define SV_STAMP(K)                                                                                      \
+    do {                                                                                                 \
+        if (blockIdx.x == 0 && tid == 0 && lp_dump)                                                      \
+            reinterpret_cast<unsigned long long *>(lp_dump)[(cb + 1) * 16 + K] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+// extra stamps inside steps: slot 0..15 of a second table behind the first (offset 64 periods... see tools/sv_variants.py)
+#define SV_STAMP2(S)                                                                                     \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (blockIdx.x == 0 && tid == 0 && lp_dump)                                                      \
+            reinterpret_cast<unsigned long long *>(lp_dump)[4096 + (cb + 1) * 16 + S] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define SV_STAMP(K) do { } while (0)
+#define SV_STAMP2(S) do { } while (0)
+#endif
+#ifndef SV_ORDER
+#define SV_ORDER 1
+#endif
+#ifndef SV_MMA_STEPS
+#define SV_MMA_STEPS 10         /* steps 1 .. SV_MMA_STEPS of a period carry the MFMAs of the next block */
+#endif
 #define SV_ETA 1e-10f
 #define SV_LOG2E 1.4426950408889634f
 #define SV_LN2 0.6931471805599453f
@@ -49,7 +78,7 @@
 template <int K> using ic = std::integral_constant<int, K>;
 
 // ---- the packed weights: [wave 8][tile 4][K block KS][hi 1 KiB | lo 1 KiB] fragments, then per k-mer column the inverse
-// ---- scale and the bias, then the blank column's float32 weights and bias
+// ---- scale and the bias (both times log2 e), then the blank column's float32 weights and bias
 __host__ __device__ static inline size_t sv_frag_bytes(int KS) { return (size_t)8 * 4 * KS * 2048; }
 __host__ __device__ static inline size_t sv_pack_bytes(int KS) { return sv_frag_bytes(KS) + 2 * 4096 + (size_t)64 * KS + 16; }
 
@@ -86,8 +115,8 @@ __global__ void __launch_bounds__(64) sv_pack_kernel(const float *__restrict__ W
     *reinterpret_cast<half8 *>(dst) = hi;
     *reinterpret_cast<half8 *>(dst + 1024) = lo;
     if (s == 0 && hk == 0) {
-        cinv[kmer] = inv;
-        cbias[kmer] = bias ? bias[1 + kmer] : 0.0f;
+        cinv[kmer] = inv * SV_LOG2E;                 // the kernel works on logits in units of log 2 (exp2 needs no multiply)
+        cbias[kmer] = bias ? bias[1 + kmer] * SV_LOG2E : 0.0f;
     }
 }
 
@@ -133,6 +162,31 @@ template <bool SUM> __device__ __forceinline__ float sv_row_allreduce(float v)
     return sv_op<SUM>(v, sv_dpp<0x121>(v));
 }
 
+// v_max_f32 on values that come straight from memory: fmaxf() would first canonicalise every operand (v_max_f32 x, x, x -- the
+// IEEE rule for signalling NaNs), doubling the instruction count of the score chain.  The DPP forms take the partner lane's
+// value as first operand; hipcc pads nothing inside asm, so the two wait states between a vector write and a DPP read are here.
+__device__ __forceinline__ float sv_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float sv_max3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float sv_quad_max(float a)           // maximum over the four lanes of a quad
+{
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(r)
+        : "v"(a));
+    return r;
+}
+
 __device__ __forceinline__ float sv_log(float x) { return __builtin_amdgcn_logf(x) * SV_LN2; }
 // decode.py:36 and :56 on a posterior p, float32 like numpy (no contraction)
 __device__ __forceinline__ float sv_logpost(float p, float min_prob, float one_m)
@@ -140,7 +194,7 @@ __device__ __forceinline__ float sv_logpost(float p, float min_prob, float one_m
     return sv_log(__fadd_rn(__fadd_rn(min_prob, __fmul_rn(one_m, p)), SV_ETA));
 }
 
-template <int KS>
+template <int KS, bool DUMP>
 __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float *__restrict__ x, long ldx, int T, int B,
                                                                      const uint8_t *__restrict__ pack, float skip_pen,
                                                                      float min_prob, float one_m, uint8_t *__restrict__ tb,
@@ -158,11 +212,10 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     constexpr int OFF_W0 = OFF_CBIAS + 4096;                    // [16 KS] float, then the blank bias
     constexpr int OFF_XINV = OFF_W0 + 64 * KS + 16;             // [chunk 2][step 16] float
     constexpr int OFF_L0 = OFF_XINV + 128;                      // [2][16] blank logits
-    constexpr int OFF_REDA = OFF_L0 + 128;                      // [2][16][wave 8] partial maxima
-    constexpr int OFF_REDB = OFF_REDA + 1024;                   // [2][16][8] partial sums
-    constexpr int OFF_FINM = OFF_REDB + 1024;                   // [2][16] row maxima
-    constexpr int OFF_FININV = OFF_FINM + 128;                  // [2][16] 1 / row sums
-    constexpr int OFF_LP0 = OFF_FININV + 128;                   // [parity 2][2][16] blank log-posteriors
+    constexpr int OFF_REDA = OFF_L0 + 128;                      // [chunk 2][wave 8][step 16] maxima over a wave's 128 columns
+    constexpr int OFF_REDB = OFF_REDA + 1024;                   // [2][8][16] sums of exp(logit - wave maximum)
+    constexpr int OFF_FAC = OFF_REDB + 1024;                    // [2][8][16] exp(wave maximum - row maximum) / row sum
+    constexpr int OFF_LP0 = OFF_FAC + 1024;                     // [parity 2][2][16] blank log-posteriors
     constexpr int OFF_REDV = OFF_LP0 + 256;                     // [2][8]
     constexpr int OFF_REDI = OFF_REDV + 64;                     // [2][8]
     constexpr int SMEM = OFF_REDI + 64;
@@ -177,13 +230,15 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     const int Tc0 = lens ? min(max(lens[b0], 1), T) : T;
     const int Tc1 = b0 + 1 < B ? (lens ? min(max(lens[b0 + 1], 1), T) : T) : 0;
     const int nblk = (max(Tc0, Tc1) + SV_BLK - 1) / SV_BLK;
-    const int Tc_own = hch ? Tc1 : Tc0;
     const int b_own = b0 + hch;
+    // decode.py:36 and :56: log(min_prob + (1 - min_prob) p + 1e-10) as log(fma(e, factor (1 - min_prob), min_prob + 1e-10))
+    const float mp_eta = __fadd_rn(min_prob, SV_ETA);
 
     float *const vb = reinterpret_cast<float *>(smem + OFF_V) + hch * 2 * SV_VP;
     uint16_t *const tbs = reinterpret_cast<uint16_t *>(smem + OFF_TBS);
     const float *const lp0b = reinterpret_cast<const float *>(smem + OFF_LP0) + hch * 16;
-    const int o_step = j + 8 * (j >> 6), o_skip = cc * 72 + q, o_own = 4 * j + 8 * (j >> 4);
+    const int o_step = j + 8 * (j >> 6), o_skip = cc * 72 + q;
+    const int o_own = (j >> 6) * SV_AS + 4 * (j & 63) + 8 * ((j & 63) >> 4);     // states 4j .. 4j+3: block a = j >> 6
     auto bar = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     // ---- constants of the whole kernel into LDS ----
@@ -202,7 +257,8 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     const int wlane = lane * 16;
     half8 wfh[SV_D], wfl[SV_D];
     f32x16 acc[4];
-    float val[4][16];                                          // logits -> exponentials -> log-posteriors of the block in the making
+    float val[4][16];                                          // logits -> exponentials of the block in the making
+    float lp[4][16];                                           // log-posteriors of the block being decoded
     float4 xr0, xr1;                                           // this lane's eight x values of the next block
     const int kb = lane & 15, r4 = lane >> 4;
     const int pa_chunk = wave & 1, pa_step = r4 + 4 * (wave >> 1), rho = 4 * wave + r4;
@@ -254,7 +310,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         }
         if (kb == 0) {
             reinterpret_cast<float *>(smem + OFF_XINV)[pa_chunk * 16 + pa_step] = inv;
-            reinterpret_cast<float *>(smem + OFF_L0)[pa_chunk * 16 + pa_step] = dot + w0[16 * KS];
+            reinterpret_cast<float *>(smem + OFF_L0)[pa_chunk * 16 + pa_step] = (dot + w0[16 * KS]) * SV_LOG2E;
         }
     };
     auto wload = [&](auto pc) {
@@ -283,6 +339,13 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         }
         wload(ic<p + SV_D>{});
     };
+    auto wload_first = [&](auto pc, auto &&self) {
+        constexpr int p = decltype(pc)::value;
+        if constexpr (p < SV_D) {
+            wload(pc);
+            self(ic<p + 1>{}, self);
+        }
+    };
     auto mma_range = [&](auto lo_c, auto hi_c, auto &&self) {
         constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
         if constexpr (lo < hi) {
@@ -298,7 +361,21 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
         }
     };
-    // scaled accumulators -> logits (gemm_rows_f16x3.hip's finish), partial row maxima
+    // Softmax over the 1025 columns of a row in the online form: a wave normalises its 128 columns by ITS maximum (known to all
+    // its lanes after one butterfly + a round trip through the wave's own LDS row, no barrier), the eight partial
+    // (maximum, sum) pairs of a row meet once, and every wave gets back the factor exp(m_wave - m_row) / sum_row that turns its
+    // exponentials into posteriors -- one exchange between waves instead of one for the maximum and one for the sum.
+    float *const my_max = reinterpret_cast<float *>(smem + OFF_REDA) + (hch * 8 + wave) * 16;
+    float *const my_sum = reinterpret_cast<float *>(smem + OFF_REDB) + (hch * 8 + wave) * 16;
+    const float *const my_fac = reinterpret_cast<const float *>(smem + OFF_FAC) + (hch * 8 + wave) * 16;
+    auto load16p = [&](const float *p, float (&out)[16]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4 v = reinterpret_cast<const float4 *>(p)[i];
+            out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
+        }
+    };
+    // scaled accumulators -> logits (gemm_rows_f16x3.hip's finish), the wave's maxima
     auto finish_max = [&]() {
         float xinv[16];
         load16(OFF_XINV, xinv);
@@ -313,66 +390,88 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
 #pragma unroll
         for (int i = 0; i < 16; i++) m[i] = fmaxf(fmaxf(val[0][i], val[1][i]), fmaxf(val[2][i], val[3][i]));
         const float r = (SV_ABL & 16) ? m[0] + m[15] : sv_half_reduce16<false>(m, lane);
-        if (!(c & 1)) reinterpret_cast<float *>(smem + OFF_REDA)[(hch * 16 + (c >> 1)) * 8 + wave] = r;
-    };
-    auto final_max = [&]() {                                   // 32 lanes: one (chunk, step) each
-        if (tid < 32) {
-            const float4 *p = reinterpret_cast<const float4 *>(smem + OFF_REDA) + 2 * tid;
-            const float4 a = p[0], b = p[1];
-            float m = fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
-            m = fmaxf(m, reinterpret_cast<const float *>(smem + OFF_L0)[tid]);
-            reinterpret_cast<float *>(smem + OFF_FINM)[tid] = m;
-        }
+        if (!(c & 1)) my_max[c >> 1] = r;
     };
     auto exp_sum = [&]() {
+        asm volatile("" ::: "memory");                         // the wave's own LDS writes above, read back in order
         float m[16];
-        load16(OFF_FINM, m);
+        load16p(my_max, m);
 #pragma unroll
         for (int n = 0; n < 4; n++)
 #pragma unroll
             for (int i = 0; i < 16; i++)
-                val[n][i] = (SV_ABL & 8) ? (val[n][i] - m[i]) * SV_LOG2E : __builtin_amdgcn_exp2f((val[n][i] - m[i]) * SV_LOG2E);
+                val[n][i] = (SV_ABL & 8) ? val[n][i] - m[i] : __builtin_amdgcn_exp2f(val[n][i] - m[i]);
         float s[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) s[i] = ((val[0][i] + val[1][i]) + val[2][i]) + val[3][i];
         const float r = (SV_ABL & 16) ? s[0] + s[15] : sv_half_reduce16<true>(s, lane);
-        if (!(c & 1)) reinterpret_cast<float *>(smem + OFF_REDB)[(hch * 16 + (c >> 1)) * 8 + wave] = r;
+        if (!(c & 1)) my_sum[c >> 1] = r;
     };
-    auto final_sum = [&](int nb) {
-        if (tid < 32) {
-            const float4 *p = reinterpret_cast<const float4 *>(smem + OFF_REDB) + 2 * tid;
-            const float4 a = p[0], b = p[1];
-            const float m = reinterpret_cast<const float *>(smem + OFF_FINM)[tid];
-            const float e0 = __builtin_amdgcn_exp2f((reinterpret_cast<const float *>(smem + OFF_L0)[tid] - m) * SV_LOG2E);
-            const float ssum = (((((((a.x + a.y) + a.z) + a.w) + b.x) + b.y) + b.z) + b.w) + e0;
-            const float inv = 1.0f / ssum;
-            reinterpret_cast<float *>(smem + OFF_FININV)[tid] = inv;
-            const float l0 = sv_logpost(e0 * inv, min_prob, one_m);
-            reinterpret_cast<float *>(smem + OFF_LP0)[(nb & 1) * 32 + tid] = l0;
-            if (lp_dump) {
-                const int t = SV_BLK * nb + (tid & 15), bb = b0 + (tid >> 4);
-                if (t < T && bb < B) lp_dump[((size_t)t * B + bb) * (SV_NK + 1)] = l0;
+    auto row_stats = [&](int nb) {                             // 256 lanes: (chunk, step) x the eight waves' shares
+        if (tid < 256) {
+            const int ch = tid >> 7, st = (tid >> 3) & 15, w = tid & 7, row = ch * 16 + st;
+            const float l0 = reinterpret_cast<const float *>(smem + OFF_L0)[row];
+            const float mw = reinterpret_cast<const float *>(smem + OFF_REDA)[(ch * 8 + w) * 16 + st];
+            const float sw = reinterpret_cast<const float *>(smem + OFF_REDB)[(ch * 8 + w) * 16 + st];
+            // maximum over the eight lanes of the group (row_ror 4, 2, 1 stay inside it only for max/sum over a full rotation
+            // of 8: use the half-row mirror and the quad permutations instead)
+            float m = fmaxf(mw, sv_dpp<0x141>(mw));                 // 7 - l within eight lanes
+            m = fmaxf(m, sv_dpp<0x4E>(m));                          // l ^ 2
+            m = fmaxf(m, sv_dpp<0xB1>(m));                          // l ^ 1
+            m = fmaxf(m, l0);
+            const float ew = __builtin_amdgcn_exp2f(mw - m);
+            const float e0 = __builtin_amdgcn_exp2f(l0 - m);
+            float ssum = sw * ew;
+            ssum += sv_dpp<0x141>(ssum);
+            ssum += sv_dpp<0x4E>(ssum);
+            ssum += sv_dpp<0xB1>(ssum);
+            ssum += e0;
+            // Ragged batch: a chunk past its own end keeps its scores.  Its steps get NaN log-posteriors and a zero blank one, so
+            // that "move" (a > comparison) is false and "stay" adds nothing -- no per-state guard in the dynamic programme.
+            const bool dead = SV_BLK * nb + st >= (ch ? Tc1 : Tc0);
+            const float inv = dead ? __builtin_nanf("") : 1.0f / ssum;
+            reinterpret_cast<float *>(smem + OFF_FAC)[(ch * 8 + w) * 16 + st] = ew * (inv * one_m);
+            if (w == 0) {
+                const float lb = dead ? 0.0f : sv_log(fmaf(e0, inv * one_m, mp_eta));
+                reinterpret_cast<float *>(smem + OFF_LP0)[(nb & 1) * 32 + row] = lb;
+#ifndef SV_DIAG
+                if constexpr (DUMP) {
+                    const int t = SV_BLK * nb + st, bb = b0 + ch;
+                    if (t < T && bb < B) lp_dump[((size_t)t * B + bb) * (SV_NK + 1)] = lb;
+                }
+#endif
             }
         }
     };
-    auto to_logpost = [&](auto n0c) {
-        constexpr int n0 = decltype(n0c)::value;
-        float inv[16];
-        load16(OFF_FININV, inv);
+    // exponentials -> log-posteriors, written over the log-posteriors the dynamic programme has already consumed: entry [n][i]
+    // of the block being decoded is dead once step i has run
+    auto to_logpost = [&](auto n0c, auto n1c, auto i0c, auto i1c) {
+        constexpr int n0 = decltype(n0c)::value, n1 = decltype(n1c)::value, i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;
+        float fac[16];
+        load16p(my_fac, fac);
 #pragma unroll
-        for (int n = n0; n < n0 + 2; n++)
+        for (int n = n0; n < n1; n++)
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                val[n][i] = (SV_ABL & 8) ? val[n][i] * inv[i] + min_prob : sv_logpost(val[n][i] * inv[i], min_prob, one_m);
+            for (int i = i0; i < i1; i++)
+                lp[n][i] = (SV_ABL & 8) ? val[n][i] * fac[i] + min_prob : sv_log(fmaf(val[n][i], fac[i], mp_eta));
+        // the values are first used a period later: without this the compiler sinks the whole transform to the loop's end,
+        // out of the steps whose waiting time it is meant to fill
+#pragma unroll
+        for (int n = n0; n < n1; n++)
+#pragma unroll
+            for (int i = i0; i < i1; i++) keepf(lp[n][i]);
     };
     auto dump_block = [&](int nb) {
-        if (lp_dump && b_own < B) {
+#ifdef SV_DIAG
+        return;
+#endif
+        if (DUMP && b_own < B) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int t = SV_BLK * nb + i;
                 if (t < T) {
                     float *dst = lp_dump + ((size_t)t * B + b_own) * (SV_NK + 1) + 1 + 4 * j;
-                    dst[0] = val[0][i]; dst[1] = val[1][i]; dst[2] = val[2][i]; dst[3] = val[3][i];
+                    dst[0] = lp[0][i]; dst[1] = lp[1][i]; dst[2] = lp[2][i]; dst[3] = lp[3][i];
                 }
             }
         }
@@ -381,105 +480,126 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     auto side = [&](auto kc, int nb) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k == 0) {
+            const int cb = nb - 1;
+            (void)cb;
+            SV_STAMP2(4);
             if constexpr (!(SV_ABL & 32)) prepare_a();
-            wload(ic<0>{});
-            wload(ic<1>{});
-            wload(ic<2>{});
-        } else if constexpr (k <= 9) {
-            mma_range(ic<((k - 1) * NP) / 9>{}, ic<(k * NP) / 9>{}, mma_range);
-        } else if constexpr (k == 10) {
-            finish_max();
+            SV_STAMP2(5);
+            wload_first(ic<0>{}, wload_first);
+            SV_STAMP2(6);
+        } else if constexpr (k <= SV_MMA_STEPS) {
+            mma_range(ic<((k - 1) * NP) / SV_MMA_STEPS>{}, ic<(k * NP) / SV_MMA_STEPS>{}, mma_range);
         } else if constexpr (k == 11) {
-            final_max();
-            load_x(nb + 1);
+            finish_max();
         } else if constexpr (k == 12) {
+            const int cb = nb - 1;
+            (void)cb;
+            SV_STAMP2(7);
+            load_x(nb + 1);                                    // four steps ahead of its use (HBM latency)
             exp_sum();
+            SV_STAMP2(8);
         } else if constexpr (k == 13) {
-            final_sum(nb);
+            row_stats(nb);
         } else if constexpr (k == 14) {
-            to_logpost(ic<0>{});
-        } else {
-            to_logpost(ic<2>{});
-            dump_block(nb);
+            to_logpost(ic<0>{}, ic<2>{}, ic<0>{}, ic<14>{});
+        } else if constexpr (k == 15) {
+            to_logpost(ic<2>{}, ic<4>{}, ic<0>{}, ic<15>{});
         }
+    };
+    auto side_tail = [&](int nb) {                             // after the last step of the block being decoded
+        to_logpost(ic<0>{}, ic<2>{}, ic<14>{}, ic<16>{});
+        to_logpost(ic<2>{}, ic<4>{}, ic<15>{}, ic<16>{});
+        dump_block(nb);
     };
 
     // ---- the dynamic programme: step t0 + k of block cb, log-posteriors lp[n][k] (viterbi_forward4_kernel::step) ----
-    float lp[4][16];
-    auto dp_step = [&](auto kc, int t0, int par) {
+    float own[4] = {0.0f, 0.0f, 0.0f, 0.0f};                   // this thread's four scores of the previous step (also in LDS for the others)
+    struct DpIn { float vs0, vs1, vs2, vs3, vk0, vk1, vk2, vk3, lp0; };
+    auto dp_read = [&](auto kc, int par) {
         constexpr int k = decltype(kc)::value;
         const float *vold = vb + ((k & 1) ^ 1) * SV_VP;
+        DpIn d;
+        d.vs0 = vold[o_step]; d.vs1 = vold[SV_AS + o_step]; d.vs2 = vold[2 * SV_AS + o_step]; d.vs3 = vold[3 * SV_AS + o_step];
+        d.vk0 = vold[o_skip]; d.vk1 = vold[SV_AS + o_skip]; d.vk2 = vold[2 * SV_AS + o_skip]; d.vk3 = vold[3 * SV_AS + o_skip];
+        d.lp0 = lp0b[par * 32 + k];
+        return d;
+    };
+    auto dp_compute = [&](auto kc, int t0, int par, const DpIn &d) {
+        constexpr int k = decltype(kc)::value;
         float *vnew = vb + (k & 1) * SV_VP;
-        // step maximum over a (first maximum wins: np.argmax, decode.py:67-68)
-        float sstep = vold[o_step];
-        int sarg = 0;
-#pragma unroll
-        for (int a = 1; a < 4; a++) {
-            const float xx = vold[a * 288 + o_step];
-            if (xx > sstep) { sstep = xx; sarg = a; }
-        }
-        // skip maximum over ab = a*4 + b: this thread's share is b = cc
-        float kbest = vold[o_skip];
-        int karg = cc;
-#pragma unroll
-        for (int a = 1; a < 4; a++) {
-            const float xx = vold[a * 288 + o_skip];
-            if (xx > kbest) { kbest = xx; karg = a * 4 + cc; }
-        }
-        const float4 own = *reinterpret_cast<const float4 *>(&vold[o_own]);
-        const float lp0 = lp0b[par * 32 + k];
-        {   // quad exchange: lane ^ 1, then lane ^ 2 (first maximum in ab order wins, decode.py:72-73)
-            float ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(kbest), 0xB1, 0xf, 0xf, false));
-            int ok = __builtin_amdgcn_update_dpp(0, karg, 0xB1, 0xf, 0xf, false);
-            bool take = (ov > kbest) | ((ov == kbest) & (ok < karg));
-            kbest = take ? ov : kbest;
-            karg = take ? ok : karg;
-            ov = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(kbest), 0x4E, 0xf, 0xf, false));
-            ok = __builtin_amdgcn_update_dpp(0, karg, 0x4E, 0xf, 0xf, false);
-            take = (ov > kbest) | ((ov == kbest) & (ok < karg));
-            kbest = take ? ov : kbest;
-            karg = take ? ok : karg;
-        }
+        // Values first, arguments beside them: the score chain is max, max, two quad maxima, one subtraction, one maximum, one
+        // addition, one compare, one select; which predecessor attained a maximum only feeds the traceback word.
+        const float vs0 = d.vs0, vs1 = d.vs1, vs2 = d.vs2, vs3 = d.vs3, vk0 = d.vk0, vk1 = d.vk1, vk2 = d.vk2, vk3 = d.vk3;
+        const float lp0 = d.lp0;
+        // step maximum over a; the first a that attains it (np.argmax, decode.py:67-68)
+        const float sstep = sv_max(sv_max3(vs0, vs1, vs2), vs3);
+        int sarg = vs2 == sstep ? 2 : 3;
+        sarg = vs1 == sstep ? 1 : sarg;
+        sarg = vs0 == sstep ? 0 : sarg;
+        // skip maximum over ab = a*4 + b (decode.py:72-73): this thread's share is b = cc, the quad holds the other three; the
+        // first ab that attains the maximum = the smallest key among the lanes whose share attains it
+        const float kpart = sv_max(sv_max3(vk0, vk1, vk2), vk3);
+        int kl = vk2 == kpart ? 8 + cc : 12 + cc;
+        kl = vk1 == kpart ? 4 + cc : kl;
+        kl = vk0 == kpart ? cc : kl;
+        const float kbest = sv_quad_max(kpart);
+        int karg = kpart == kbest ? kl : 16;
+        karg = min(karg, __builtin_amdgcn_update_dpp(0, karg, 0xB1, 0xf, 0xf, false));
+        karg = min(karg, __builtin_amdgcn_update_dpp(0, karg, 0x4E, 0xf, 0xf, false));
         const float sskip = kbest - skip_pen;                       // decode.py:72
-        const float mx = fmaxf(sstep, sskip);
-        const uint32_t how = sstep > sskip ? 1u : 2u;               // decode.py:76 (tie -> skip)
-        const float ownv[4] = {own.x, own.y, own.z, own.w};
+        const float mx = sv_max(sstep, sskip);
+        const bool bystep = sstep > sskip;                          // decode.py:76 (tie -> skip)
         float nw[4];
-        uint32_t packed = ((uint32_t)sarg << 8) | ((uint32_t)karg << 10);
-        const bool live = t0 + k < Tc_own;                          // ragged batch: a chunk past its end keeps its scores
+        uint32_t moves = 0;                                         // bit 2n: to-state n moves
 #pragma unroll
         for (int n = 0; n < 4; n++) {
             const float nv = lp[n][k] + mx;                         // decode.py:75
-            const float stay = ownv[n] + lp0;                       // decode.py:80
+            const float stay = own[n] + lp0;                        // decode.py:80
             const bool move = nv > stay;                            // decode.py:81 (tie -> stay)
-            packed |= (move ? how : 0u) << (2 * n);
+            moves |= move ? (1u << (2 * n)) : 0u;
             float r = move ? nv : stay;
             if constexpr (k == 0) r = t0 == 0 ? lp[n][0] : r;       // t = 0: v = lpost[0][1:] (decode.py:57)
-            nw[n] = live ? r : ownv[n];
+            nw[n] = r;
         }
+        // two bits per to-state: 0 stay, 1 step, 2 skip (viterbi_forward4_kernel's traceback word)
+        const uint32_t packed = (moves << (bystep ? 0 : 1)) | ((uint32_t)sarg << 8) | ((uint32_t)karg << 10);
+#pragma unroll
+        for (int n = 0; n < 4; n++) own[n] = nw[n];
         *reinterpret_cast<float4 *>(&vnew[o_own]) = make_float4(nw[0], nw[1], nw[2], nw[3]);
         tbs[((par * 2 + hch) * 16 + k) * 256 + j] = (uint16_t)packed;
     };
-    // rows of block blk (staged with parity par) -> HBM, 8 KB per chunk
+    // rows of block blk (staged with parity par) -> HBM, 8 KB per chunk: uniform base + the thread's 16 bytes
     auto flush_tb = [&](int blk, int par) {
+        const int t = SV_BLK * blk + (tid >> 5);
 #pragma unroll
-        for (int u0 = 0; u0 < 1024; u0 += SV_THREADS) {
-            const int u = u0 + tid, hc = u >> 9, rest = u & 511, t = SV_BLK * blk + (rest >> 5);
+        for (int hc = 0; hc < 2; hc++) {
             const int tc = hc ? Tc1 : Tc0;
+            uint8_t *dst = tb + ((size_t)(b0 + hc) * Tpad + SV_BLK * blk) * (SV_NK / 2);
+            const uint8_t *src = smem + OFF_TBS + ((par * 2 + hc) * 16) * 512;
             if (t >= 1 && t < tc)
-                *reinterpret_cast<uint4 *>(tb + ((size_t)(b0 + hc) * Tpad + SV_BLK * blk) * (SV_NK / 2) + rest * 16) =
-                    *reinterpret_cast<const uint4 *>(smem + OFF_TBS + ((par * 2 + hc) * 16) * 512 + rest * 16);
+                *reinterpret_cast<uint4 *>(dst + tid * 16) = *reinterpret_cast<const uint4 *>(src + tid * 16);
         }
     };
 
     auto period = [&](auto dpc, auto prodc, int cb) {
         constexpr bool DP = decltype(dpc)::value, PROD = decltype(prodc)::value;
         const int t0 = SV_BLK * cb, par = cb & 1, nb = cb + 1;
-#define SV_STEP(K)                                       \
-    do {                                                 \
-        if constexpr (PROD) side(ic<K>{}, nb);           \
-        if constexpr (DP && !(SV_ABL & 4)) dp_step(ic<K>{}, t0, par); \
-        bar();                                           \
+        // Order inside a step (SV_ORDER 1): the programme's LDS reads are requested first, the production work of the step runs
+        // while they are on their way, then the programme's arithmetic and its writes.  (0: production, then the programme.)
+#define SV_STEP(K)                                                                         \
+    do {                                                                                   \
+        if constexpr (DP && !(SV_ABL & 4) && SV_ORDER == 1) {                              \
+            const DpIn d = dp_read(ic<K>{}, par);                                          \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+            if constexpr (PROD) side(ic<K>{}, nb);                                         \
+            __builtin_amdgcn_sched_barrier(0);                                             \
+            dp_compute(ic<K>{}, t0, par, d);                                               \
+        } else {                                                                           \
+            if constexpr (PROD) side(ic<K>{}, nb);                                         \
+            if constexpr (DP && !(SV_ABL & 4)) dp_compute(ic<K>{}, t0, par, dp_read(ic<K>{}, par)); \
+        }                                                                                  \
+        bar();                                                                             \
+        SV_STAMP(K);                                                                       \
     } while (0)
         SV_STEP(0);
         SV_STEP(1);
@@ -493,28 +613,22 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         SV_STEP(9);
         SV_STEP(10);
         SV_STEP(11);
+        SV_STAMP2(0);
         if (DP && cb >= 1) flush_tb(cb - 1, par ^ 1);               // here no weight load is in flight
+        SV_STAMP2(1);
         SV_STEP(12);
         SV_STEP(13);
         SV_STEP(14);
         SV_STEP(15);
 #undef SV_STEP
+        SV_STAMP2(2);
+        if constexpr (PROD) side_tail(nb);
+        SV_STAMP2(3);
     };
-    auto adopt = [&]() {
-#pragma unroll
-        for (int n = 0; n < 4; n++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) lp[n][i] = val[n][i];
-    };
-
     load_x(0);
     bar();                                                      // constants staged
     period(std::false_type{}, std::true_type{}, -1);
-    adopt();
-    for (int cb = 0; cb + 1 < nblk; cb++) {
-        period(std::true_type{}, std::true_type{}, cb);
-        adopt();
-    }
+    for (int cb = 0; cb + 1 < nblk; cb++) period(std::true_type{}, std::true_type{}, cb);
     period(std::true_type{}, std::false_type{}, nblk - 1);
     flush_tb(nblk - 1, (nblk - 1) & 1);
 
@@ -574,8 +688,17 @@ template <int KS>
 static int sv_launch(const float *x, long ldx, int T, int B, const uint8_t *pack, float skip_pen, float min_prob, uint8_t *tb,
                      int32_t *best, float *score_out, const int *lens, float *lp_dump, hipStream_t s)
 {
-    hipLaunchKernelGGL((softmax_viterbi_kernel<KS>), dim3((B + 1) / 2), dim3(SV_THREADS), 0, s, x, ldx, T, B, pack, skip_pen,
-                       min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
+#ifdef SV_DIAG
+    constexpr bool diag = true;
+#else
+    constexpr bool diag = false;
+#endif
+    if (lp_dump && !diag)
+        hipLaunchKernelGGL((softmax_viterbi_kernel<KS, true>), dim3((B + 1) / 2), dim3(SV_THREADS), 0, s, x, ldx, T, B, pack,
+                           skip_pen, min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
+    else
+        hipLaunchKernelGGL((softmax_viterbi_kernel<KS, false>), dim3((B + 1) / 2), dim3(SV_THREADS), 0, s, x, ldx, T, B, pack,
+                           skip_pen, min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
     return slk_launch_status();
 }
 

@@ -57,6 +57,36 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             res[name].append(e0.elapsed_time(e1) / 5)
+    if os.environ.get("SV_DIAG"):
+        # variants built with -DSV_DIAG: per-step shader-clock stamps of workgroup 0, wave 0
+        dbg = torch.zeros(8192, dtype=torch.int64, device="cuda")
+        for name, f, pack in fns:
+            if "diag" not in name:          # only builds with -DSV_DIAG treat the dump pointer as a stamp table
+                continue
+            dbg.zero_()
+            for _ in range(3):
+                rc = f(x.data_ptr(), K, pack.data_ptr(), K, T, B, 4, 5, 0.0, 1e-5, None, ws.data_ptr(), nws, sc.data_ptr(),
+                       pa.data_ptr(), le.data_ptr(), dbg.data_ptr(), None)
+                assert rc == 0
+            torch.cuda.synchronize()
+            st = dbg.cpu().numpy().reshape(-1, 16)
+            nper = (T + 15) // 16 + 1
+            flat = st[:nper].reshape(-1).astype(np.int64)
+            d = np.diff(flat)
+            per = d[16 * 5:16 * (nper - 3)].reshape(-1, 16)      # main-loop periods; column k = duration of step k+1 (k = 15: next step 0)
+            med = np.median(per, axis=0)
+            print("%-20s steps 1..15,0: %s  | period %d cycles" % (name, " ".join("%4d" % v for v in med), int(med.sum())))
+            full = dbg.cpu().numpy()
+            s1 = full[:nper * 16].reshape(-1, 16)[6:nper - 3]
+            s2 = full[4096:4096 + nper * 16].reshape(-1, 16)[6:nper - 3]
+            if s2[:, :9].min() > 0:
+                def md(a):
+                    return int(np.median(a))
+                print("    after step 11 -> before flush %d, flush %d, to end of step 12 %d (exp_sum alone %d, from step start %d)" % (
+                    md(s2[:, 0] - s1[:, 11]), md(s2[:, 1] - s2[:, 0]), md(s1[:, 12] - s2[:, 1]), md(s2[:, 8] - s2[:, 7]), md(s2[:, 7] - s2[:, 1])))
+                print("    after step 15 -> tail start %d, tail %d; step 0: to prepare %d, prepare %d, wload %d, rest of step 0 %d" % (
+                    md(s2[:-1, 2] - s1[:-1, 15]), md(s2[:-1, 3] - s2[:-1, 2]), md(s2[1:, 4] - s2[:-1, 3]), md(s2[1:, 5] - s2[1:, 4]),
+                    md(s2[1:, 6] - s2[1:, 5]), md(s1[1:, 0] - s2[1:, 6])))
     for name in names:
         v = sorted(res[name])
         print("%-28s median %.3f ms  (min %.3f, max %.3f)" % (name, v[len(v) // 2], v[0], v[-1]))
