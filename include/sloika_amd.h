@@ -285,18 +285,22 @@ int slk_log_post_logits_f32(const float *logits, long ld, const float *stats, fl
  *   pack : the layer's weights W[nstate][K], b[nstate] (or NULL) re-laid-out once by slk_softmax_viterbi_pack_f32 into a
  *          buffer of slk_softmax_viterbi_pack_bytes(K, nbase, klen) bytes (fp16 hi/lo MFMA fragments, column scales)
  *   lens : per-chunk step counts for a ragged batch, or NULL
+ *   plan : chunks per workgroup: 0 (the build's default) or 2; 4 (two score chains per lane, half as many workgroups) is
+ *          compiled only with -DSV_WITH_NCH4 (measured no faster) and returns SLK_ERR_UNSUPPORTED otherwise; results do
+ *          not depend on it
  *   lp_dump : NULL, or [T][B][nstate] floats that receive the log-posteriors the dynamic programme consumed (tests decode
  *          THESE with the oracle: paths and scores are bit-exact functions of them)
  *   workspace: slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen)
  * Products are 3-term fp16 splits with float32 accumulation like slk_linear_rowstats_f16x3.  This build has the kernel for
- * nbase 4, klen 5 and K a multiple of 16 up to 128; anything else returns SLK_ERR_UNSUPPORTED (pack_bytes returns 0) and the
+ * nbase 4, klen 5 and K in {64, 96, 112, 128}; anything else returns SLK_ERR_UNSUPPORTED (pack_bytes returns 0) and the
  * caller uses slk_linear_rowstats_* + slk_viterbi_kmer_logits_f32.                                                        */
 size_t slk_softmax_viterbi_pack_bytes(int K, int nbase, int klen);
 int slk_softmax_viterbi_pack_f32(const float *W, const float *bias, int K, int nbase, int klen, void *pack,
                                  slk_stream_t stream);
 int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pack, int K, int T, int B, int nbase, int klen,
-                            float skip_pen, float min_prob, const int32_t *lens, void *workspace, size_t workspace_bytes,
-                            float *score_out, int32_t *path_out, int32_t *len_out, float *lp_dump, slk_stream_t stream);
+                            float skip_pen, float min_prob, const int32_t *lens, int plan, void *workspace,
+                            size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out, float *lp_dump,
+                            slk_stream_t stream);
 /* decode.prepare_post on its own: out = min_prob + (1-min_prob)*post (decode.py:36).                        */
 int slk_prepare_post_f32(const float *post, float *out, size_t count, float min_prob, slk_stream_t stream);
 /* decode.argmax (decode.py:5-18), batched: per (b) the states with argmax != blank, minus 1 if

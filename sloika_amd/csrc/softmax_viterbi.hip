@@ -61,7 +61,10 @@
 #define SV_STAMP2(S) do { } while (0)
 #endif
 #ifndef SV_ORDER
-#define SV_ORDER 1
+#define SV_ORDER 0
+#endif
+#ifndef SV_MIX
+#define SV_MIX 6                /* vector instructions the scheduler is asked to place behind every MFMA (SV_ORDER 2) */
 #endif
 #ifndef SV_MMA_STEPS
 #define SV_MMA_STEPS 10         /* steps 1 .. SV_MMA_STEPS of a period carry the MFMAs of the next block */
@@ -76,6 +79,9 @@
 #endif
 
 template <int K> using ic = std::integral_constant<int, K>;
+// two float32 values per vector instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): a wave64 vector instruction takes
+// four cycles of its SIMD whatever it does, so the element-wise passes over the logits are written on pairs
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- the packed weights: [wave 8][tile 4][K block KS][hi 1 KiB | lo 1 KiB] fragments, then per k-mer column the inverse
 // ---- scale and the bias (both times log2 e), then the blank column's float32 weights and bias
@@ -162,6 +168,7 @@ template <bool SUM> __device__ __forceinline__ float sv_row_allreduce(float v)
     return sv_op<SUM>(v, sv_dpp<0x121>(v));
 }
 
+// (Their results must not be read by compiler-generated DPP instructions: see prepare_a.)
 // v_max_f32 on values that come straight from memory: fmaxf() would first canonicalise every operand (v_max_f32 x, x, x -- the
 // IEEE rule for signalling NaNs), doubling the instruction count of the score chain.  The DPP forms take the partner lane's
 // value as first operand; hipcc pads nothing inside asm, so the two wait states between a vector write and a DPP read are here.
@@ -194,7 +201,18 @@ __device__ __forceinline__ float sv_logpost(float p, float min_prob, float one_m
     return sv_log(__fadd_rn(__fadd_rn(min_prob, __fmul_rn(one_m, p)), SV_ETA));
 }
 
-template <int KS, bool DUMP>
+// Schedule of a period (the BS steps of the block being decoded, during which the next block is produced); k = step:
+//   k = 0 .. MMA_LAST   the MFMAs (weight fragments three pairs ahead)         k = 1   operand images of the block after next
+//   k = FIN_K           accumulators -> logits, the wave's maxima              k = EXP_K  exponentials, the wave's sums, x request
+//   k = ROW_K           row statistics (needs every wave's sums: one barrier after EXP_K)
+//   k = LOG_K ..        exponentials -> log-posteriors (needs the factors: one barrier after ROW_K)
+template <int BS> struct SvSched;
+template <> struct SvSched<16> { static constexpr int MMA_LAST = 10, FIN_K = 11, EXP_K = 12, ROW_K = 13, LOG_K = 14; };
+template <> struct SvSched<8> { static constexpr int MMA_LAST = 4, FIN_K = 5, EXP_K = 5, ROW_K = 6, LOG_K = 7; };
+
+// NCH chunks per workgroup (2 or 4): lane half h decodes chunks h and, with four, h + 2 -- two independent score chains per
+// lane, twice the work between two barriers.  A block is BS = 32 / NCH steps of every chunk (the 32 rows of an MFMA tile).
+template <int KS, int NCH, bool DUMP>
 __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float *__restrict__ x, long ldx, int T, int B,
                                                                      const uint8_t *__restrict__ pack, float skip_pen,
                                                                      float min_prob, float one_m, uint8_t *__restrict__ tb,
@@ -203,42 +221,50 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
                                                                      const int *__restrict__ lens,
                                                                      float *__restrict__ lp_dump)
 {
+    constexpr int BS = 32 / NCH;                                // steps per block
+    constexpr int NPL = NCH / 2;                                // chunks per lane
+    using Sched = SvSched<BS>;
     constexpr int NP = 4 * KS;                                  // weight fragment pairs per wave and block
-    constexpr int OFF_V = 0;                                    // [chunk 2][parity 2][SV_VP] float
-    constexpr int OFF_TBS = OFF_V + 2 * 2 * SV_VP * 4;          // [parity 2][chunk 2][step 16][256] uint16
-    constexpr int OFF_A = OFF_TBS + 2 * 2 * 16 * 512;           // [KS][hi, lo][64 lanes][16 B]
-    constexpr int OFF_CINV = OFF_A + KS * 2048;                 // [1024] float
+    constexpr int OFF_V = 0;                                    // [chunk NCH][parity 2][SV_VP] float
+    constexpr int OFF_TBS = OFF_V + NCH * 2 * SV_VP * 4;        // [parity 2][chunk NCH][step BS][256] uint16
+    constexpr int OFF_A = OFF_TBS + 2 * 16 * 1024;              // [parity 2][KS][hi, lo][64 lanes][16 B]
+    constexpr int OFF_CINV = OFF_A + 2 * KS * 2048;             // [1024] float
     constexpr int OFF_CBIAS = OFF_CINV + 4096;                  // [1024] float
     constexpr int OFF_W0 = OFF_CBIAS + 4096;                    // [16 KS] float, then the blank bias
-    constexpr int OFF_XINV = OFF_W0 + 64 * KS + 16;             // [chunk 2][step 16] float
-    constexpr int OFF_L0 = OFF_XINV + 128;                      // [2][16] blank logits
-    constexpr int OFF_REDA = OFF_L0 + 128;                      // [chunk 2][wave 8][step 16] maxima over a wave's 128 columns
+    constexpr int OFF_XINV = OFF_W0 + 64 * KS + 16;             // [parity 2][half 2][16] float: inverse row scales
+    constexpr int OFF_L0 = OFF_XINV + 256;                      // [parity 2][2][16] blank logits
+    constexpr int OFF_REDA = OFF_L0 + 256;                      // [half 2][wave 8][16] maxima over a wave's 128 columns
     constexpr int OFF_REDB = OFF_REDA + 1024;                   // [2][8][16] sums of exp(logit - wave maximum)
     constexpr int OFF_FAC = OFF_REDB + 1024;                    // [2][8][16] exp(wave maximum - row maximum) / row sum
     constexpr int OFF_LP0 = OFF_FAC + 1024;                     // [parity 2][2][16] blank log-posteriors
-    constexpr int OFF_REDV = OFF_LP0 + 256;                     // [2][8]
-    constexpr int OFF_REDI = OFF_REDV + 64;                     // [2][8]
-    constexpr int SMEM = OFF_REDI + 64;
+    constexpr int OFF_REDV = OFF_LP0 + 256;                     // [chunk NCH][8]
+    constexpr int OFF_REDI = OFF_REDV + 128;                    // [chunk NCH][8]
+    constexpr int SMEM = OFF_REDI + 128;
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
+    // the 16 rows of a lane half: row i is step i % BS of chunk h + 2 * (i / BS)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, hch = lane >> 5;
     const int j = 32 * wave + c, q = j >> 2, cc = j & 3;
-    const int b0 = 2 * blockIdx.x;
+    const int b0 = NCH * blockIdx.x;
     const int Tpad = T;
-    const int Tc0 = lens ? min(max(lens[b0], 1), T) : T;
-    const int Tc1 = b0 + 1 < B ? (lens ? min(max(lens[b0 + 1], 1), T) : T) : 0;
-    const int nblk = (max(Tc0, Tc1) + SV_BLK - 1) / SV_BLK;
-    const int b_own = b0 + hch;
+    int Tcs[NCH];
+    int tmax = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+        Tcs[ch] = b0 + ch < B ? (lens ? min(max(lens[b0 + ch], 1), T) : T) : 0;
+        tmax = max(tmax, Tcs[ch]);
+    }
+    const int nblk = (tmax + BS - 1) / BS;
     // decode.py:36 and :56: log(min_prob + (1 - min_prob) p + 1e-10) as log(fma(e, factor (1 - min_prob), min_prob + 1e-10))
     const float mp_eta = __fadd_rn(min_prob, SV_ETA);
 
-    float *const vb = reinterpret_cast<float *>(smem + OFF_V) + hch * 2 * SV_VP;
     uint16_t *const tbs = reinterpret_cast<uint16_t *>(smem + OFF_TBS);
     const float *const lp0b = reinterpret_cast<const float *>(smem + OFF_LP0) + hch * 16;
     const int o_step = j + 8 * (j >> 6), o_skip = cc * 72 + q;
     const int o_own = (j >> 6) * SV_AS + 4 * (j & 63) + 8 * ((j & 63) >> 4);     // states 4j .. 4j+3: block a = j >> 6
+    auto vbase = [&](int p) __attribute__((always_inline)) { return reinterpret_cast<float *>(smem + OFF_V) + (hch + 2 * p) * 2 * SV_VP; };
     auto bar = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     // ---- constants of the whole kernel into LDS ----
@@ -259,26 +285,31 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     f32x16 acc[4];
     float val[4][16];                                          // logits -> exponentials of the block in the making
     float lp[4][16];                                           // log-posteriors of the block being decoded
-    float4 xr0, xr1;                                           // this lane's eight x values of the next block
+    float4 xr0, xr1;                                           // this lane's eight x values of a coming block
+    // operand preparation: wave w, 16-lane row r4 handles MFMA row rho = 4 w + r4 = lane half (w & 1), row i of that half
     const int kb = lane & 15, r4 = lane >> 4;
-    const int pa_chunk = wave & 1, pa_step = r4 + 4 * (wave >> 1), rho = 4 * wave + r4;
+    const int pa_half = wave & 1, pa_i = r4 + 4 * (wave >> 1), rho = 4 * wave + r4;
+    const int pa_chunk = pa_half + 2 * (pa_i / BS), pa_step = pa_i % BS;
     const bool pa_act = kb < 2 * KS;
     const int pa_b = min(b0 + pa_chunk, B - 1);
 
-    auto load_x = [&](int blk) {
-        const int t = min(SV_BLK * blk + pa_step, T - 1);
+    auto load_x = [&](int blk) __attribute__((always_inline)) {
+        const int t = min(BS * blk + pa_step, T - 1);
         const float *src = x + ((size_t)t * B + pa_b) * ldx + 8 * min(kb, 2 * KS - 1);
         xr0 = *reinterpret_cast<const float4 *>(src);
         xr1 = *reinterpret_cast<const float4 *>(src + 4);
     };
-    // x rows of the block -> fp16 hi/lo A-operand images, row scales, blank logits
-    auto prepare_a = [&]() {
+    // x rows of block blk -> fp16 hi/lo A-operand images, row scales, blank logits (all double buffered by block parity)
+    auto prepare_a = [&](int blk) __attribute__((always_inline)) {
+        const int par = blk & 1;
         float xv[8] = {xr0.x, xr0.y, xr0.z, xr0.w, xr1.x, xr1.y, xr1.z, xr1.w};
 #pragma unroll
         for (int i = 0; i < 8; i++) xv[i] = pa_act ? xv[i] : 0.0f;
         float amax = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(xv[i]));
+        // (no sv_max here: a DPP instruction that reads a register needs two wait states after the vector instruction that
+        // wrote it, and the compiler pads only behind instructions it emitted itself -- never feed its DPP from inline asm)
         amax = sv_row_allreduce<false>(amax);
         float inv;
         const float sc = pow2_scale(amax, inv);
@@ -304,16 +335,16 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             lo[i] = (_Float16)(v - (float)hv);
         }
         if (pa_act) {
-            uint8_t *dst = smem + OFF_A + (kb >> 1) * 2048 + (rho + 32 * (kb & 1)) * 16;
+            uint8_t *dst = smem + OFF_A + par * KS * 2048 + (kb >> 1) * 2048 + (rho + 32 * (kb & 1)) * 16;
             *reinterpret_cast<half8 *>(dst) = hi;
             *reinterpret_cast<half8 *>(dst + 1024) = lo;
         }
         if (kb == 0) {
-            reinterpret_cast<float *>(smem + OFF_XINV)[pa_chunk * 16 + pa_step] = inv;
-            reinterpret_cast<float *>(smem + OFF_L0)[pa_chunk * 16 + pa_step] = (dot + w0[16 * KS]) * SV_LOG2E;
+            reinterpret_cast<float *>(smem + OFF_XINV)[par * 32 + pa_half * 16 + pa_i] = inv;
+            reinterpret_cast<float *>(smem + OFF_L0)[par * 32 + pa_half * 16 + pa_i] = (dot + w0[16 * KS]) * SV_LOG2E;
         }
     };
-    auto wload = [&](auto pc) {
+    auto wload = [&](auto pc) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
         if constexpr (p < NP && !(SV_ABL & 2)) {
             wfh[p % SV_D] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, wwave + p * 2048, 0));
@@ -321,11 +352,12 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         }
     };
     // fragment pair p = (tile n, K block s): three MFMAs, small terms first (gemm_rows_f16x3.hip)
-    auto mma_pair = [&](auto pc) {
+    auto mma_pair = [&](auto pc, int apar) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
         constexpr int n = p / KS, s = p % KS;
-        const half8 ahi = *reinterpret_cast<const half8 *>(smem + OFF_A + s * 2048 + lane * 16);
-        const half8 alo = *reinterpret_cast<const half8 *>(smem + OFF_A + s * 2048 + 1024 + lane * 16);
+        const uint8_t *ab = smem + OFF_A + apar * KS * 2048 + s * 2048 + lane * 16;
+        const half8 ahi = *reinterpret_cast<const half8 *>(ab);
+        const half8 alo = *reinterpret_cast<const half8 *>(ab + 1024);
         if constexpr (s == 0) {
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[n][i] = 0.0f;
@@ -339,35 +371,20 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         }
         wload(ic<p + SV_D>{});
     };
-    auto wload_first = [&](auto pc, auto &&self) {
+    auto wload_first = [&](auto pc, auto &&self) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
         if constexpr (p < SV_D) {
             wload(pc);
             self(ic<p + 1>{}, self);
         }
     };
-    auto mma_range = [&](auto lo_c, auto hi_c, auto &&self) {
+    auto mma_range = [&](auto lo_c, auto hi_c, int apar, auto &&self) __attribute__((always_inline)) {
         constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
         if constexpr (lo < hi) {
-            mma_pair(ic<lo>{});
-            self(ic<lo + 1>{}, hi_c, self);
+            mma_pair(ic<lo>{}, apar);
+            self(ic<lo + 1>{}, hi_c, apar, self);
         }
     };
-    auto load16 = [&](int off, float (&out)[16]) {             // this chunk's 16 per-step values
-        const float4 *p = reinterpret_cast<const float4 *>(smem + off) + hch * 4;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float4 v = p[i];
-            out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
-        }
-    };
-    // Softmax over the 1025 columns of a row in the online form: a wave normalises its 128 columns by ITS maximum (known to all
-    // its lanes after one butterfly + a round trip through the wave's own LDS row, no barrier), the eight partial
-    // (maximum, sum) pairs of a row meet once, and every wave gets back the factor exp(m_wave - m_row) / sum_row that turns its
-    // exponentials into posteriors -- one exchange between waves instead of one for the maximum and one for the sum.
-    float *const my_max = reinterpret_cast<float *>(smem + OFF_REDA) + (hch * 8 + wave) * 16;
-    float *const my_sum = reinterpret_cast<float *>(smem + OFF_REDB) + (hch * 8 + wave) * 16;
-    const float *const my_fac = reinterpret_cast<const float *>(smem + OFF_FAC) + (hch * 8 + wave) * 16;
     auto load16p = [&](const float *p, float (&out)[16]) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -375,46 +392,66 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             out[4 * i] = v.x; out[4 * i + 1] = v.y; out[4 * i + 2] = v.z; out[4 * i + 3] = v.w;
         }
     };
+    // Softmax over the 1025 columns of a row in the online form: a wave normalises its 128 columns by ITS maximum (known to all
+    // its lanes after one butterfly + a round trip through the wave's own LDS row, no barrier), the eight partial
+    // (maximum, sum) pairs of a row meet once, and every wave gets back the factor exp(m_wave - m_row) / sum_row that turns its
+    // exponentials into posteriors -- one exchange between waves instead of one for the maximum and one for the sum.
+    // Logits are kept in units of log 2 (column scales and biases arrive multiplied by log2 e): exp is a bare v_exp_f32.
+    float *const my_max = reinterpret_cast<float *>(smem + OFF_REDA) + (hch * 8 + wave) * 16;
+    float *const my_sum = reinterpret_cast<float *>(smem + OFF_REDB) + (hch * 8 + wave) * 16;
+    const float *const my_fac = reinterpret_cast<const float *>(smem + OFF_FAC) + (hch * 8 + wave) * 16;
     // scaled accumulators -> logits (gemm_rows_f16x3.hip's finish), the wave's maxima
-    auto finish_max = [&]() {
+    auto finish_max = [&](int nb) __attribute__((always_inline)) {
         float xinv[16];
-        load16(OFF_XINV, xinv);
+        load16p(reinterpret_cast<const float *>(smem + OFF_XINV) + (nb & 1) * 32 + hch * 16, xinv);
         const float4 ci = reinterpret_cast<const float4 *>(smem + OFF_CINV)[j];
         const float4 cb = reinterpret_cast<const float4 *>(smem + OFF_CBIAS)[j];
         const float civ[4] = {ci.x, ci.y, ci.z, ci.w}, cbv[4] = {cb.x, cb.y, cb.z, cb.w};
 #pragma unroll
         for (int n = 0; n < 4; n++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) val[n][i] = fmaf(acc[n][i] * xinv[i], civ[n], cbv[n]);
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 a = {acc[n][i], acc[n][i + 1]}, xi = {xinv[i], xinv[i + 1]};
+                const f32x2 v = __builtin_elementwise_fma(a * xi, f32x2{civ[n], civ[n]}, f32x2{cbv[n], cbv[n]});
+                val[n][i] = v.x;
+                val[n][i + 1] = v.y;
+            }
         float m[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) m[i] = fmaxf(fmaxf(val[0][i], val[1][i]), fmaxf(val[2][i], val[3][i]));
         const float r = (SV_ABL & 16) ? m[0] + m[15] : sv_half_reduce16<false>(m, lane);
         if (!(c & 1)) my_max[c >> 1] = r;
     };
-    auto exp_sum = [&]() {
+    auto exp_sum = [&]() __attribute__((always_inline)) {
         asm volatile("" ::: "memory");                         // the wave's own LDS writes above, read back in order
         float m[16];
         load16p(my_max, m);
 #pragma unroll
         for (int n = 0; n < 4; n++)
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                val[n][i] = (SV_ABL & 8) ? val[n][i] - m[i] : __builtin_amdgcn_exp2f(val[n][i] - m[i]);
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 d = f32x2{val[n][i], val[n][i + 1]} - f32x2{m[i], m[i + 1]};
+                val[n][i] = (SV_ABL & 8) ? d.x : __builtin_amdgcn_exp2f(d.x);
+                val[n][i + 1] = (SV_ABL & 8) ? d.y : __builtin_amdgcn_exp2f(d.y);
+            }
         float s[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) s[i] = ((val[0][i] + val[1][i]) + val[2][i]) + val[3][i];
+        for (int i = 0; i < 16; i += 2) {
+            const f32x2 t = ((f32x2{val[0][i], val[0][i + 1]} + f32x2{val[1][i], val[1][i + 1]}) + f32x2{val[2][i], val[2][i + 1]}) +
+                            f32x2{val[3][i], val[3][i + 1]};
+            s[i] = t.x;
+            s[i + 1] = t.y;
+        }
         const float r = (SV_ABL & 16) ? s[0] + s[15] : sv_half_reduce16<true>(s, lane);
         if (!(c & 1)) my_sum[c >> 1] = r;
     };
-    auto row_stats = [&](int nb) {                             // 256 lanes: (chunk, step) x the eight waves' shares
+    auto row_stats = [&](int nb) __attribute__((always_inline)) {                             // 256 lanes: (half, row) x the eight waves' shares
         if (tid < 256) {
-            const int ch = tid >> 7, st = (tid >> 3) & 15, w = tid & 7, row = ch * 16 + st;
-            const float l0 = reinterpret_cast<const float *>(smem + OFF_L0)[row];
-            const float mw = reinterpret_cast<const float *>(smem + OFF_REDA)[(ch * 8 + w) * 16 + st];
-            const float sw = reinterpret_cast<const float *>(smem + OFF_REDB)[(ch * 8 + w) * 16 + st];
-            // maximum over the eight lanes of the group (row_ror 4, 2, 1 stay inside it only for max/sum over a full rotation
-            // of 8: use the half-row mirror and the quad permutations instead)
+            const int hh = tid >> 7, ri = (tid >> 3) & 15, w = tid & 7, row = hh * 16 + ri;
+            const int ch = hh + 2 * (ri / BS), st = ri % BS;
+            const float l0 = reinterpret_cast<const float *>(smem + OFF_L0)[(nb & 1) * 32 + row];
+            const float mw = reinterpret_cast<const float *>(smem + OFF_REDA)[(hh * 8 + w) * 16 + ri];
+            const float sw = reinterpret_cast<const float *>(smem + OFF_REDB)[(hh * 8 + w) * 16 + ri];
             float m = fmaxf(mw, sv_dpp<0x141>(mw));                 // 7 - l within eight lanes
             m = fmaxf(m, sv_dpp<0x4E>(m));                          // l ^ 2
             m = fmaxf(m, sv_dpp<0xB1>(m));                          // l ^ 1
@@ -428,105 +465,120 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             ssum += e0;
             // Ragged batch: a chunk past its own end keeps its scores.  Its steps get NaN log-posteriors and a zero blank one, so
             // that "move" (a > comparison) is false and "stay" adds nothing -- no per-state guard in the dynamic programme.
-            const bool dead = SV_BLK * nb + st >= (ch ? Tc1 : Tc0);
+            int tc = Tcs[0];
+#pragma unroll
+            for (int k2 = 1; k2 < NCH; k2++) tc = ch == k2 ? Tcs[k2] : tc;
+            const bool dead = BS * nb + st >= tc;
             const float inv = dead ? __builtin_nanf("") : 1.0f / ssum;
-            reinterpret_cast<float *>(smem + OFF_FAC)[(ch * 8 + w) * 16 + st] = ew * (inv * one_m);
+            reinterpret_cast<float *>(smem + OFF_FAC)[(hh * 8 + w) * 16 + ri] = ew * (inv * one_m);
             if (w == 0) {
                 const float lb = dead ? 0.0f : sv_log(fmaf(e0, inv * one_m, mp_eta));
                 reinterpret_cast<float *>(smem + OFF_LP0)[(nb & 1) * 32 + row] = lb;
 #ifndef SV_DIAG
                 if constexpr (DUMP) {
-                    const int t = SV_BLK * nb + st, bb = b0 + ch;
+                    const int t = BS * nb + st, bb = b0 + ch;
                     if (t < T && bb < B) lp_dump[((size_t)t * B + bb) * (SV_NK + 1)] = lb;
                 }
 #endif
             }
         }
     };
-    // exponentials -> log-posteriors, written over the log-posteriors the dynamic programme has already consumed: entry [n][i]
-    // of the block being decoded is dead once step i has run
-    auto to_logpost = [&](auto n0c, auto n1c, auto i0c, auto i1c) {
+    // exponentials -> log-posteriors, written over the log-posteriors the dynamic programme has already consumed: row i of the
+    // block being decoded is dead once step i % BS has run.  Rows with i0 <= i % BS < i1 of tiles n0 .. n1-1.
+    auto to_logpost = [&](auto n0c, auto n1c, auto i0c, auto i1c) __attribute__((always_inline)) {
         constexpr int n0 = decltype(n0c)::value, n1 = decltype(n1c)::value, i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;
-        float fac[16];
-        load16p(my_fac, fac);
+        if constexpr (n0 < n1 && i0 < i1) {
+            float fac[16];
+            load16p(my_fac, fac);
 #pragma unroll
-        for (int n = n0; n < n1; n++)
+            for (int n = n0; n < n1; n++)
 #pragma unroll
-            for (int i = i0; i < i1; i++)
-                lp[n][i] = (SV_ABL & 8) ? val[n][i] * fac[i] + min_prob : sv_log(fmaf(val[n][i], fac[i], mp_eta));
-        // the values are first used a period later: without this the compiler sinks the whole transform to the loop's end,
-        // out of the steps whose waiting time it is meant to fill
+                for (int i = 0; i < 16; i += 2) {
+                    const bool in0 = i % BS >= i0 && i % BS < i1, in1 = (i + 1) % BS >= i0 && (i + 1) % BS < i1;
+                    if (in0 && in1) {
+                        const f32x2 a = __builtin_elementwise_fma(f32x2{val[n][i], val[n][i + 1]}, f32x2{fac[i], fac[i + 1]},
+                                                                  f32x2{mp_eta, mp_eta});
+                        const f32x2 l = f32x2{__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)} * SV_LN2;
+                        lp[n][i] = (SV_ABL & 8) ? a.x : l.x;
+                        lp[n][i + 1] = (SV_ABL & 8) ? a.y : l.y;
+                    } else {
+                        if (in0) lp[n][i] = sv_log(fmaf(val[n][i], fac[i], mp_eta));
+                        if (in1) lp[n][i + 1] = sv_log(fmaf(val[n][i + 1], fac[i + 1], mp_eta));
+                    }
+                }
+            // the values are first used a period later: without this the compiler sinks the whole transform to the loop's end,
+            // out of the steps whose waiting time it is meant to fill
 #pragma unroll
-        for (int n = n0; n < n1; n++)
+            for (int n = n0; n < n1; n++)
 #pragma unroll
-            for (int i = i0; i < i1; i++) keepf(lp[n][i]);
+                for (int i = 0; i < 16; i++)
+                    if (i % BS >= i0 && i % BS < i1) keepf(lp[n][i]);
+        }
     };
-    auto dump_block = [&](int nb) {
+    auto dump_block = [&](int nb) __attribute__((always_inline)) {
 #ifdef SV_DIAG
         return;
 #endif
-        if (DUMP && b_own < B) {
+        if constexpr (DUMP) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const int t = SV_BLK * nb + i;
-                if (t < T) {
-                    float *dst = lp_dump + ((size_t)t * B + b_own) * (SV_NK + 1) + 1 + 4 * j;
+                const int t = BS * nb + i % BS, bb = b0 + hch + 2 * (i / BS);
+                if (t < T && bb < B) {
+                    float *dst = lp_dump + ((size_t)t * B + bb) * (SV_NK + 1) + 1 + 4 * j;
                     dst[0] = lp[0][i]; dst[1] = lp[1][i]; dst[2] = lp[2][i]; dst[3] = lp[3][i];
                 }
             }
         }
     };
-    // side work of step k of a period: the production of block nb
-    auto side = [&](auto kc, int nb) {
+    // side work of step k of a period: the production of block nb (and the operand images of block nb + 1)
+    auto side = [&](auto kc, int nb) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        if constexpr (k == 0) {
-            const int cb = nb - 1;
-            (void)cb;
-            SV_STAMP2(4);
-            if constexpr (!(SV_ABL & 32)) prepare_a();
-            SV_STAMP2(5);
-            wload_first(ic<0>{}, wload_first);
-            SV_STAMP2(6);
-        } else if constexpr (k <= SV_MMA_STEPS) {
-            mma_range(ic<((k - 1) * NP) / SV_MMA_STEPS>{}, ic<(k * NP) / SV_MMA_STEPS>{}, mma_range);
-        } else if constexpr (k == 11) {
-            finish_max();
-        } else if constexpr (k == 12) {
-            const int cb = nb - 1;
-            (void)cb;
-            SV_STAMP2(7);
-            load_x(nb + 1);                                    // four steps ahead of its use (HBM latency)
+        constexpr int NM = Sched::MMA_LAST + 1;
+        if constexpr (k == 0) wload_first(ic<0>{}, wload_first);
+        if constexpr (k <= Sched::MMA_LAST) mma_range(ic<(k * NP) / NM>{}, ic<((k + 1) * NP) / NM>{}, nb & 1, mma_range);
+        if constexpr (k == 1 && !(SV_ABL & 32)) prepare_a(nb + 1);
+        if constexpr (k == Sched::FIN_K) finish_max(nb);
+        if constexpr (k == Sched::EXP_K) {
+            load_x(nb + 2);                                    // its operand images are made in step 1 of the next period
             exp_sum();
-            SV_STAMP2(8);
-        } else if constexpr (k == 13) {
-            row_stats(nb);
-        } else if constexpr (k == 14) {
-            to_logpost(ic<0>{}, ic<2>{}, ic<0>{}, ic<14>{});
-        } else if constexpr (k == 15) {
-            to_logpost(ic<2>{}, ic<4>{}, ic<0>{}, ic<15>{});
+        }
+        if constexpr (k == Sched::ROW_K) row_stats(nb);
+        if constexpr (BS == 16) {
+            if constexpr (k == 14) to_logpost(ic<0>{}, ic<2>{}, ic<0>{}, ic<14>{});
+            if constexpr (k == 15) to_logpost(ic<2>{}, ic<4>{}, ic<0>{}, ic<15>{});
+        } else {
+            if constexpr (k == 7) to_logpost(ic<0>{}, ic<4>{}, ic<0>{}, ic<7>{});
         }
     };
-    auto side_tail = [&](int nb) {                             // after the last step of the block being decoded
-        to_logpost(ic<0>{}, ic<2>{}, ic<14>{}, ic<16>{});
-        to_logpost(ic<2>{}, ic<4>{}, ic<15>{}, ic<16>{});
+    auto side_tail = [&](int nb) __attribute__((always_inline)) {                             // after the last step of the block being decoded
+        if constexpr (BS == 16) {
+            to_logpost(ic<0>{}, ic<2>{}, ic<14>{}, ic<16>{});
+            to_logpost(ic<2>{}, ic<4>{}, ic<15>{}, ic<16>{});
+        } else {
+            to_logpost(ic<0>{}, ic<4>{}, ic<7>{}, ic<8>{});
+        }
         dump_block(nb);
     };
 
-    // ---- the dynamic programme: step t0 + k of block cb, log-posteriors lp[n][k] (viterbi_forward4_kernel::step) ----
-    float own[4] = {0.0f, 0.0f, 0.0f, 0.0f};                   // this thread's four scores of the previous step (also in LDS for the others)
+    // ---- the dynamic programme: step t0 + k of block cb, log-posteriors lp[n][p BS + k] (viterbi_forward4_kernel::step) ----
+    float own[NPL][4];                                         // this thread's four scores of the previous step, per chunk
+#pragma unroll
+    for (int p = 0; p < NPL; p++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) own[p][n] = 0.0f;
     struct DpIn { float vs0, vs1, vs2, vs3, vk0, vk1, vk2, vk3, lp0; };
-    auto dp_read = [&](auto kc, int par) {
+    auto dp_read = [&](auto kc, int par, int p) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        const float *vold = vb + ((k & 1) ^ 1) * SV_VP;
+        const float *vold = vbase(p) + ((k & 1) ^ 1) * SV_VP;
         DpIn d;
         d.vs0 = vold[o_step]; d.vs1 = vold[SV_AS + o_step]; d.vs2 = vold[2 * SV_AS + o_step]; d.vs3 = vold[3 * SV_AS + o_step];
         d.vk0 = vold[o_skip]; d.vk1 = vold[SV_AS + o_skip]; d.vk2 = vold[2 * SV_AS + o_skip]; d.vk3 = vold[3 * SV_AS + o_skip];
-        d.lp0 = lp0b[par * 32 + k];
+        d.lp0 = lp0b[par * 32 + p * BS + k];
         return d;
     };
-    auto dp_compute = [&](auto kc, int t0, int par, const DpIn &d) {
+    auto dp_compute = [&](auto kc, int t0, int par, int p, const DpIn &d) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        float *vnew = vb + (k & 1) * SV_VP;
+        float *vnew = vbase(p) + (k & 1) * SV_VP;
         // Values first, arguments beside them: the score chain is max, max, two quad maxima, one subtraction, one maximum, one
         // addition, one compare, one select; which predecessor attained a maximum only feeds the traceback word.
         const float vs0 = d.vs0, vs1 = d.vs1, vs2 = d.vs2, vs3 = d.vs3, vk0 = d.vk0, vk1 = d.vk1, vk2 = d.vk2, vk3 = d.vk3;
@@ -553,53 +605,81 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         uint32_t moves = 0;                                         // bit 2n: to-state n moves
 #pragma unroll
         for (int n = 0; n < 4; n++) {
-            const float nv = lp[n][k] + mx;                         // decode.py:75
-            const float stay = own[n] + lp0;                        // decode.py:80
+            const float nv = lp[n][p * BS + k] + mx;                // decode.py:75
+            const float stay = own[p][n] + lp0;                     // decode.py:80
             const bool move = nv > stay;                            // decode.py:81 (tie -> stay)
             moves |= move ? (1u << (2 * n)) : 0u;
             float r = move ? nv : stay;
-            if constexpr (k == 0) r = t0 == 0 ? lp[n][0] : r;       // t = 0: v = lpost[0][1:] (decode.py:57)
+            if constexpr (k == 0) r = t0 == 0 ? lp[n][p * BS] : r;  // t = 0: v = lpost[0][1:] (decode.py:57)
             nw[n] = r;
         }
         // two bits per to-state: 0 stay, 1 step, 2 skip (viterbi_forward4_kernel's traceback word)
         const uint32_t packed = (moves << (bystep ? 0 : 1)) | ((uint32_t)sarg << 8) | ((uint32_t)karg << 10);
 #pragma unroll
-        for (int n = 0; n < 4; n++) own[n] = nw[n];
+        for (int n = 0; n < 4; n++) own[p][n] = nw[n];
         *reinterpret_cast<float4 *>(&vnew[o_own]) = make_float4(nw[0], nw[1], nw[2], nw[3]);
-        tbs[((par * 2 + hch) * 16 + k) * 256 + j] = (uint16_t)packed;
+        tbs[((par * NCH + hch + 2 * p) * BS + k) * 256 + j] = (uint16_t)packed;
     };
-    // rows of block blk (staged with parity par) -> HBM, 8 KB per chunk: uniform base + the thread's 16 bytes
-    auto flush_tb = [&](int blk, int par) {
-        const int t = SV_BLK * blk + (tid >> 5);
+    // rows of block blk (staged with parity par) -> HBM: per chunk BS rows of 512 bytes, contiguous on both sides
+    auto flush_tb = [&](int blk, int par) __attribute__((always_inline)) {
 #pragma unroll
-        for (int hc = 0; hc < 2; hc++) {
-            const int tc = hc ? Tc1 : Tc0;
-            uint8_t *dst = tb + ((size_t)(b0 + hc) * Tpad + SV_BLK * blk) * (SV_NK / 2);
-            const uint8_t *src = smem + OFF_TBS + ((par * 2 + hc) * 16) * 512;
+        for (int pass = 0; pass < 2; pass++) {
+            constexpr int PER_CHUNK = BS * 512;                     // bytes
+            const int off = pass * 8192 + tid * 16;
+            const int ch = off / PER_CHUNK, rest = off % PER_CHUNK, t = BS * blk + rest / 512;
+            int tc = Tcs[0];
+#pragma unroll
+            for (int k2 = 1; k2 < NCH; k2++) tc = ch == k2 ? Tcs[k2] : tc;
+            uint8_t *dst = tb + ((size_t)(b0 + ch) * Tpad + BS * blk) * (SV_NK / 2) + rest;
             if (t >= 1 && t < tc)
-                *reinterpret_cast<uint4 *>(dst + tid * 16) = *reinterpret_cast<const uint4 *>(src + tid * 16);
+                *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(smem + OFF_TBS + par * 16384 + off);
         }
     };
 
-    auto period = [&](auto dpc, auto prodc, int cb) {
+    // MFMA steps: one MFMA, then a group of the programme's vector instructions (the wave issues in order: MFMAs back to back
+    // would keep it from its vector work for 32 cycles each, vector work first would leave the matrix pipe idle)
+    auto mix_hint = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int NM = Sched::MMA_LAST + 1;
+        if constexpr (k <= Sched::MMA_LAST) {
+            constexpr int npairs = ((k + 1) * NP) / NM - (k * NP) / NM;
+#pragma unroll
+            for (int i = 0; i < npairs; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the pair's A operands
+#pragma unroll
+                for (int m = 0; m < 3; m++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, SV_MIX, 0);   // vector instructions
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // the fragment loads three pairs ahead
+            }
+        }
+    };
+    auto period = [&](auto dpc, auto prodc, int cb) __attribute__((always_inline)) {
         constexpr bool DP = decltype(dpc)::value, PROD = decltype(prodc)::value;
-        const int t0 = SV_BLK * cb, par = cb & 1, nb = cb + 1;
-        // Order inside a step (SV_ORDER 1): the programme's LDS reads are requested first, the production work of the step runs
-        // while they are on their way, then the programme's arithmetic and its writes.  (0: production, then the programme.)
+        const int t0 = BS * cb, par = cb & 1, nb = cb + 1;
+        // Order inside a step: the programme's LDS reads are requested first, the production work of the step runs while they
+        // are on their way, then the programme's arithmetic and its writes.
 #define SV_STEP(K)                                                                         \
     do {                                                                                   \
-        if constexpr (DP && !(SV_ABL & 4) && SV_ORDER == 1) {                              \
-            const DpIn d = dp_read(ic<K>{}, par);                                          \
-            __builtin_amdgcn_sched_barrier(0);                                             \
-            if constexpr (PROD) side(ic<K>{}, nb);                                         \
-            __builtin_amdgcn_sched_barrier(0);                                             \
-            dp_compute(ic<K>{}, t0, par, d);                                               \
-        } else {                                                                           \
-            if constexpr (PROD) side(ic<K>{}, nb);                                         \
-            if constexpr (DP && !(SV_ABL & 4)) dp_compute(ic<K>{}, t0, par, dp_read(ic<K>{}, par)); \
+        if constexpr ((K) < BS) {                                                          \
+            if constexpr (DP && !(SV_ABL & 4)) {                                           \
+                DpIn d[NPL];                                                               \
+                _Pragma("unroll") for (int p = 0; p < NPL; p++) d[p] = dp_read(ic<K>{}, par, p); \
+                if constexpr (SV_ORDER >= 1) __builtin_amdgcn_sched_barrier(0);            \
+                if constexpr (PROD) side(ic<K>{}, nb);                                     \
+                if constexpr (SV_ORDER == 1) __builtin_amdgcn_sched_barrier(0);            \
+                _Pragma("unroll") for (int p = 0; p < NPL; p++) dp_compute(ic<K>{}, t0, par, p, d[p]); \
+                if constexpr (PROD && SV_ORDER == 2) mix_hint(ic<K>{});                    \
+            } else {                                                                       \
+                if constexpr (PROD) side(ic<K>{}, nb);                                     \
+            }                                                                              \
+            bar();                                                                         \
+            SV_STAMP(K);                                                                   \
+            if constexpr ((K) == Sched::FIN_K - 1) {                                       \
+                if (DP && cb >= 1) flush_tb(cb - 1, par ^ 1);                              \
+            }                                                                              \
         }                                                                                  \
-        bar();                                                                             \
-        SV_STAMP(K);                                                                       \
     } while (0)
         SV_STEP(0);
         SV_STEP(1);
@@ -613,28 +693,29 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         SV_STEP(9);
         SV_STEP(10);
         SV_STEP(11);
-        SV_STAMP2(0);
-        if (DP && cb >= 1) flush_tb(cb - 1, par ^ 1);               // here no weight load is in flight
-        SV_STAMP2(1);
         SV_STEP(12);
         SV_STEP(13);
         SV_STEP(14);
         SV_STEP(15);
 #undef SV_STEP
-        SV_STAMP2(2);
         if constexpr (PROD) side_tail(nb);
-        SV_STAMP2(3);
     };
+
     load_x(0);
     bar();                                                      // constants staged
+    prepare_a(0);
+    load_x(1);
+    bar();
     period(std::false_type{}, std::true_type{}, -1);
     for (int cb = 0; cb + 1 < nblk; cb++) period(std::true_type{}, std::true_type{}, cb);
     period(std::true_type{}, std::false_type{}, nblk - 1);
     flush_tb(nblk - 1, (nblk - 1) & 1);
 
     // ---- first argmax of the final scores (np.argmax, decode.py:85); the last step of a block writes parity 1 ----
-    {
-        const float4 fv = *reinterpret_cast<const float4 *>(&vb[SV_VP + o_own]);
+#pragma unroll
+    for (int p = 0; p < NPL; p++) {
+        const int ch = hch + 2 * p;
+        const float4 fv = *reinterpret_cast<const float4 *>(&vbase(p)[SV_VP + o_own]);
         const float f[4] = {fv.x, fv.y, fv.z, fv.w};
         float bv = f[0];
         int bi = 4 * j;
@@ -647,25 +728,29 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             const int oi = __shfl_xor(bi, o);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        float *redv = reinterpret_cast<float *>(smem + OFF_REDV) + hch * 8;
-        int *redi = reinterpret_cast<int *>(smem + OFF_REDI) + hch * 8;
+        float *redv = reinterpret_cast<float *>(smem + OFF_REDV) + ch * 8;
+        int *redi = reinterpret_cast<int *>(smem + OFF_REDI) + ch * 8;
         if (c == 0) { redv[wave] = bv; redi[wave] = bi; }
-        bar();
-        if (wave == 0 && c == 0 && b_own < B) {
-            bv = redv[0];
-            bi = redi[0];
-            for (int w = 1; w < 8; w++)
-                if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
-            score_out[b_own] = bv;
-            best_out[b_own] = bi;
-        }
+    }
+    bar();
+    if (tid < NCH && b0 + tid < B) {
+        const float *redv = reinterpret_cast<const float *>(smem + OFF_REDV) + tid * 8;
+        const int *redi = reinterpret_cast<const int *>(smem + OFF_REDI) + tid * 8;
+        float bv = redv[0];
+        int bi = redi[0];
+        for (int w = 1; w < 8; w++)
+            if (redv[w] > bv || (redv[w] == bv && redi[w] < bi)) { bv = redv[w]; bi = redi[w]; }
+        score_out[b0 + tid] = bv;
+        best_out[b0 + tid] = bi;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
-static bool sv_shape_ok(int K, int nbase, int klen) { return nbase == 4 && klen == 5 && K >= 16 && K <= 128 && K % 16 == 0; }
+// insize 64, 96, 112, 128: the Softmax layers of the shipped raw models (baseline_raw_gru, raw_0.98_rgrgr, pretrained.pkl /
+// raw_1.00_rGr padded, bigger_raw_gru)
+static bool sv_shape_ok(int K, int nbase, int klen) { return nbase == 4 && klen == 5 && (K == 64 || K == 96 || K == 112 || K == 128); }
 
 extern "C" size_t slk_softmax_viterbi_pack_bytes(int K, int nbase, int klen)
 {
@@ -684,7 +769,7 @@ extern "C" int slk_softmax_viterbi_pack_f32(const float *W, const float *bias, i
     return slk_launch_status();
 }
 
-template <int KS>
+template <int KS, int NCH>
 static int sv_launch(const float *x, long ldx, int T, int B, const uint8_t *pack, float skip_pen, float min_prob, uint8_t *tb,
                      int32_t *best, float *score_out, const int *lens, float *lp_dump, hipStream_t s)
 {
@@ -694,21 +779,26 @@ static int sv_launch(const float *x, long ldx, int T, int B, const uint8_t *pack
     constexpr bool diag = false;
 #endif
     if (lp_dump && !diag)
-        hipLaunchKernelGGL((softmax_viterbi_kernel<KS, true>), dim3((B + 1) / 2), dim3(SV_THREADS), 0, s, x, ldx, T, B, pack,
-                           skip_pen, min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
+        hipLaunchKernelGGL((softmax_viterbi_kernel<KS, NCH, true>), dim3((B + NCH - 1) / NCH), dim3(SV_THREADS), 0, s, x, ldx, T, B,
+                           pack, skip_pen, min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
     else
-        hipLaunchKernelGGL((softmax_viterbi_kernel<KS, false>), dim3((B + 1) / 2), dim3(SV_THREADS), 0, s, x, ldx, T, B, pack,
-                           skip_pen, min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
+        hipLaunchKernelGGL((softmax_viterbi_kernel<KS, NCH, false>), dim3((B + NCH - 1) / NCH), dim3(SV_THREADS), 0, s, x, ldx, T,
+                           B, pack, skip_pen, min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
     return slk_launch_status();
 }
 
 extern "C" int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pack, int K, int T, int B, int nbase, int klen,
-                                       float skip_pen, float min_prob, const int32_t *lens, void *workspace,
+                                       float skip_pen, float min_prob, const int32_t *lens, int plan, void *workspace,
                                        size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out,
                                        float *lp_dump, slk_stream_t stream)
 {
-    if (!x || !pack || !score_out || !path_out || !len_out || T < 1 || B < 1 || K < 1 || ldx < K || nbase < 2 || klen < 3)
+    if (!x || !pack || !score_out || !path_out || !len_out || T < 1 || B < 1 || K < 1 || ldx < K || nbase < 2 || klen < 3 ||
+        (plan != 0 && plan != 2 && plan != 4))
         return SLK_ERR_INVALID_ARG;
+#ifndef SV_WITH_NCH4
+    if (plan == 4) return SLK_ERR_UNSUPPORTED;    // four chunks per workgroup: measured equal to two (a vector instruction
+                                                  // costs its SIMD four cycles either way), so production builds leave it out
+#endif
     if (!sv_shape_ok(K, nbase, klen) || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;
     const size_t need = slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen);
     if (!workspace || workspace_bytes < need) return SLK_ERR_WORKSPACE;
@@ -718,12 +808,24 @@ extern "C" int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pac
     const uint8_t *pk = static_cast<const uint8_t *>(pack);
     hipStream_t s = slk_stream(stream);
     int rc;
+#ifdef SV_WITH_NCH4
+    const bool four = plan == 4;
+#endif
     switch (K / 16) {
-#define SV_CASE(KS) case KS: rc = sv_launch<KS>(x, ldx, T, B, pk, skip_pen, min_prob, tb, best, score_out, lens, lp_dump, s); break;
+#ifdef SV_WITH_NCH4
+#define SV_CASE(KS)                                                                                                              \
+    case KS:                                                                                                                     \
+        rc = four ? sv_launch<KS, 4>(x, ldx, T, B, pk, skip_pen, min_prob, tb, best, score_out, lens, lp_dump, s)                \
+                  : sv_launch<KS, 2>(x, ldx, T, B, pk, skip_pen, min_prob, tb, best, score_out, lens, lp_dump, s);               \
+        break;
+#else
+#define SV_CASE(KS)                                                                                                              \
+    case KS: rc = sv_launch<KS, 2>(x, ldx, T, B, pk, skip_pen, min_prob, tb, best, score_out, lens, lp_dump, s); break;
+#endif
 #ifdef SV_ONLY_KS          /* development builds: one instantiation */
     SV_CASE(SV_ONLY_KS)
 #else
-    SV_CASE(1) SV_CASE(2) SV_CASE(3) SV_CASE(4) SV_CASE(5) SV_CASE(6) SV_CASE(7) SV_CASE(8)
+    SV_CASE(4) SV_CASE(6) SV_CASE(7) SV_CASE(8)
 #endif
 #undef SV_CASE
     default: return SLK_ERR_UNSUPPORTED;

@@ -138,12 +138,13 @@ def viterbi_logits_batch(logits, stats, klen, T, B, ld=None, skip_pen=0.0, nbase
     return scores, paths, lens
 
 
-def viterbi_fused_batch(x, pack, klen, skip_pen=0.0, nbase=4, min_prob=1e-5, workspace=None, lengths=None, lp_dump=None):
+def viterbi_fused_batch(x, pack, klen, skip_pen=0.0, nbase=4, min_prob=1e-5, workspace=None, lengths=None, lp_dump=None, plan=0):
     """basecall.decode_post(softmax layer(x)) over the batch axis from the Softmax layer's INPUT x [T, B, insize] and its
     packed weights (layers.Softmax.viterbi_pack): projection, softmax (layers.py:309-314), prepare_post (decode.py:21-36),
     log and the Viterbi forward pass (decode.py:39-82) in one kernel (csrc/softmax_viterbi.hip), then the backtrace
     (decode.py:84-91).  The logits are never written.  `lp_dump`: optional float32 device tensor [T, B, nstate] that
-    receives the log-posteriors the dynamic programme consumed.  Same outputs as viterbi_logits_batch."""
+    receives the log-posteriors the dynamic programme consumed.  `plan`: chunks per workgroup (2, 4, or 0 = by batch size; the
+    results do not depend on it).  Same outputs as viterbi_logits_batch."""
     import torch
     from . import device as D
     if klen < 3:
@@ -168,7 +169,7 @@ def viterbi_fused_batch(x, pack, klen, skip_pen=0.0, nbase=4, min_prob=1e-5, wor
     with profiler.region("softmax_viterbi", 2.0 * rows * K * S, rows * (4.0 * K + 1.0 * (nbase ** klen)),
                          f16x3_flops=2.0 * rows * K * S):
         rc = L.slk_softmax_viterbi_f32(x.data_ptr(), x.stride(1), pack.data_ptr(), K, T, B, nbase, klen, float(skip_pen),
-                                       float(min_prob), lengths.data_ptr() if lengths is not None else None, ws.data_ptr(),
+                                       float(min_prob), lengths.data_ptr() if lengths is not None else None, int(plan), ws.data_ptr(),
                                        nbytes, scores.data_ptr(), paths.data_ptr(), lens.data_ptr(),
                                        lp_dump.data_ptr() if lp_dump is not None else None, D.stream_ptr())
     _lib.check(rc, "decode.viterbi_fused")

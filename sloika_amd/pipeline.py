@@ -7,13 +7,21 @@ This is the batched restatement of bin/basecall_network.py `raw` (sloika/basecal
 BASELINE.json's metric is quoted on.  All arithmetic happens in the HIP kernels behind include/sloika_amd.h;
 torch only owns the buffers and the stream.
 """
+import os
+
 import numpy as np
 
 from . import _lib, batch, decode, layers
 
+#: decode straight from the Softmax layer's input (csrc/softmax_viterbi.hip: projection, softmax, prepare_post, log and the
+#: Viterbi forward pass in one kernel, the logits never written) where that kernel applies; SLOIKA_AMD_FUSED_DECODE=0 keeps the
+#: projection kernel + decoder pair
+FUSED_DECODE = os.environ.get("SLOIKA_AMD_FUSED_DECODE", "1") != "0"
+
 
 class Basecaller(object):
-    def __init__(self, network, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, normalisation='per-chunk', in_flight=1):
+    def __init__(self, network, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, normalisation='per-chunk', in_flight=1,
+                 fused_decode=None):
         """skip default 0.0 is the CLI default (bin/basecall_network.py:38).
 
         in_flight: how many batches the caller keeps in flight at a time, each on a HIP stream of its own (one Basecaller
@@ -26,6 +34,7 @@ class Basecaller(object):
         self.kmer_len, self.nbase, self.min_prob, self.skip = kmer_len, nbase, min_prob, skip
         self.normalisation = normalisation
         self.in_flight = max(1, int(in_flight))
+        self.fused_decode = FUSED_DECODE if fused_decode is None else bool(fused_decode)
         self._ws = decode.ViterbiWorkspace()
         _lib.lib()
 
@@ -61,15 +70,32 @@ class Basecaller(object):
         n = len(net.layers) if isinstance(net, layers.Serial) else 1
         return self._hidden(chunks, n)
 
-    def call_chunks(self, chunks):
+    def _fused_pack(self, last, hid):
+        """The Softmax layer's weights packed for csrc/softmax_viterbi.hip, or None when that kernel does not apply."""
+        if not self.fused_decode or hid.stride(1) % 4 or hid.data_ptr() % 16:
+            return None
+        if hid.stride(2) != 1 or hid.stride(0) != hid.shape[1] * hid.stride(1):
+            return None
+        return last.viterbi_pack(self.nbase, self.kmer_len)
+
+    def call_chunks(self, chunks, lp_dump=None):
         """-> device tensors (scores float32 [B], paths int32 [B, T'] (-1 padded), lens int32 [B]).
 
-        When the network ends in a Softmax layer the decoder consumes its logits + row statistics, so the normalised
-        posterior (3.4 GB at B=1024) is never written; the result is bit-identical to decoding `posteriors()`."""
+        When the network ends in a Softmax layer whose shape csrc/softmax_viterbi.hip covers, the decoder starts from that
+        layer's INPUT and neither the logits nor the posterior (3.4 GB each at B=1024) are ever written; `lp_dump`, a float32
+        device tensor [T', B, nstate], then receives the log-posteriors the dynamic programme consumed (tests).  Otherwise
+        (and with fused_decode=False) the decoder consumes the layer's logits + row statistics, bit-identical to decoding
+        `posteriors()`."""
         net = self.network
         last = net.layers[-1] if isinstance(net, layers.Serial) else None
         if type(last) is layers.Softmax and len(net.layers) > 1:
             hid = self._hidden(chunks, len(net.layers) - 1)
+            pack = self._fused_pack(last, hid)
+            if pack is not None:
+                return decode.viterbi_fused_batch(hid, pack, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
+                                                  min_prob=self.min_prob, workspace=self._ws, lp_dump=lp_dump)
+            if lp_dump is not None:
+                raise ValueError("lp_dump needs the fused decoder (csrc/softmax_viterbi.hip does not cover this network)")
             logits, stats, ld = last.logits_and_stats(hid)
             T, B = hid.shape[0], hid.shape[1]
             return decode.viterbi_logits_batch(logits, stats, self.kmer_len, T, B, ld=ld, skip_pen=self.skip,
@@ -111,11 +137,18 @@ class Basecaller(object):
             for layer in net.layers[:-1]:
                 hid = layer._forward(hid, None, False)
             lengths = layers.ragged.current
-            logits, stats, ld = net.layers[-1].logits_and_stats(hid)
+            pack = self._fused_pack(net.layers[-1], hid)
+            if pack is None:
+                logits, stats, ld = net.layers[-1].logits_and_stats(hid)
         T = hid.shape[0]
-        scores, paths, lens = decode.viterbi_logits_batch(logits, stats, self.kmer_len, T, B, ld=ld, skip_pen=self.skip,
-                                                          nbase=self.nbase, min_prob=self.min_prob, workspace=self._ws,
-                                                          lengths=lengths.contiguous())
+        if pack is not None:
+            scores, paths, lens = decode.viterbi_fused_batch(hid, pack, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
+                                                             min_prob=self.min_prob, workspace=self._ws,
+                                                             lengths=lengths.contiguous())
+        else:
+            scores, paths, lens = decode.viterbi_logits_batch(logits, stats, self.kmer_len, T, B, ld=ld, skip_pen=self.skip,
+                                                              nbase=self.nbase, min_prob=self.min_prob, workspace=self._ws,
+                                                              lengths=lengths.contiguous())
         return scores, paths, lens, nsamp
 
     def call_chunks_host(self, chunks):

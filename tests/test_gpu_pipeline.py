@@ -29,7 +29,7 @@ def _logits_reference(oracle, net, x):
 def _check_end_to_end(oracle, net, chunks, klen=5, skip=0.0, tol=TOL):
     torch = need_gpu()
     from sloika_amd import _lib, pipeline, decode
-    bc = pipeline.Basecaller(net, kmer_len=klen, skip=skip)
+    bc = pipeline.Basecaller(net, kmer_len=klen, skip=skip, fused_decode=False)
     cd = dev(chunks)
     post = bc.posteriors(cd)
     x = oracle.med_mad_normalise(chunks)
@@ -57,7 +57,32 @@ def _check_end_to_end(oracle, net, chunks, klen=5, skip=0.0, tol=TOL):
     assert np.array_equal(lens.cpu().numpy(), o_lens)
     assert np.array_equal(paths.cpu().numpy(), o_paths)
     assert np.array_equal(scores.cpu().numpy(), o_scores)
+    _check_fused_decode(oracle, net, cd, lp, klen, skip)
     return err
+
+
+def _check_fused_decode(oracle, net, cd, lp_two_kernel, klen=5, skip=0.0, pick=None):
+    """The default path: decoding straight from the Softmax layer's input (csrc/softmax_viterbi.hip).  Its log-posteriors
+    (dumped) agree with those of the two-kernel path, and its paths / scores are the oracle decoder's on ITS log-posteriors,
+    bit for bit.  `pick`: chunk indices to check (all when None)."""
+    torch = need_gpu()
+    from sloika_amd import pipeline
+    bcf = pipeline.Basecaller(net, kmer_len=klen, skip=skip)
+    last = net.layers[-1]
+    if last.viterbi_pack(4, klen) is None:
+        return                                                       # shape outside the fused kernel: nothing more to check
+    T, B = lp_two_kernel.shape[0], cd.shape[0]
+    dump = torch.empty((T, B, last.size), dtype=torch.float32, device="cuda")
+    scores, paths, lens = bcf.call_chunks(cd, lp_dump=dump)
+    s0, p0, l0 = bcf.call_chunks(cd)                                 # the instantiation without the dump
+    assert torch.equal(scores, s0) and torch.equal(paths, p0) and torch.equal(lens, l0)
+    sel = np.arange(B) if pick is None else pick
+    d = dump[:, torch.from_numpy(sel).cuda(), :].contiguous()
+    assert (d - lp_two_kernel).abs().max().item() < 2e-5
+    o_scores, o_paths, o_lens = oracle.viterbi_batch(d.cpu().numpy(), klen, skip_pen=skip)
+    assert np.array_equal(lens.cpu().numpy()[sel], o_lens)
+    assert np.array_equal(paths.cpu().numpy()[sel], o_paths)
+    assert np.array_equal(scores.cpu().numpy()[sel], o_scores)
 
 
 @pytest.mark.parametrize("name,nchunk,chunk_len", [("raw_0.98_rgrgr", 6, 1000), ("baseline_raw_gru", 5, 600),
@@ -133,7 +158,7 @@ def test_full_size_batch_sampled_chunks_vs_oracle(oracle, name, B):
     torch = need_gpu()
     from sloika_amd import _lib, models, pipeline
     net = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=13))
-    bc = pipeline.Basecaller(net)
+    bc = pipeline.Basecaller(net, fused_decode=False)
     chunks = pipeline.synthetic_chunks(B, chunk_len=4000, seed=77)
     cd = dev(chunks)
     post = bc.posteriors(cd)
@@ -152,6 +177,8 @@ def test_full_size_batch_sampled_chunks_vs_oracle(oracle, name, B):
     assert np.array_equal(lens.cpu().numpy()[pick], o_lens)
     assert np.array_equal(paths.cpu().numpy()[pick], o_paths)
     assert np.array_equal(scores.cpu().numpy()[pick], o_scores)
+    del post
+    _check_fused_decode(oracle, net, cd, lp, pick=pick)
 
 
 def test_full_size_batch_properties():

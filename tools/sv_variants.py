@@ -16,6 +16,8 @@ def main():
     names = sys.argv[1:]
     K = int(os.environ.get("SV_KS", "6")) * 16
     T, B, S = int(os.environ.get("SV_T", "800")), int(os.environ.get("SV_B", "1024")), 1025
+    PLAN = int(os.environ.get("SV_PLAN", "0"))
+    BS = 8 if (PLAN == 4 or (PLAN == 0 and B >= 1024)) else 16
     lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libsv_variants.so"))
     rs = np.random.RandomState(1)
     x = torch.tanh(torch.randn((T, B, K), device="cuda"))
@@ -37,15 +39,15 @@ def main():
         pk.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
         assert pk(W.data_ptr(), b.data_ptr(), K, 4, 5, pack.data_ptr(), None) == 0
         f = getattr(lib, "slk_sv_v%d" % i)
-        f.argtypes = [vp, C.c_long, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, C.c_size_t,
-                      vp, vp, vp, vp, vp]
+        f.argtypes = [vp, C.c_long, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, C.c_int, vp,
+                      C.c_size_t, vp, vp, vp, vp, vp]
         fns.append((name, f, pack))
     torch.cuda.synchronize()
     res = {n: [] for n in names}
     for rnd in range(5):
         for name, f, pack in fns:
             def call():
-                rc = f(x.data_ptr(), K, pack.data_ptr(), K, T, B, 4, 5, 0.0, 1e-5, None, ws.data_ptr(), nws, sc.data_ptr(),
+                rc = f(x.data_ptr(), K, pack.data_ptr(), K, T, B, 4, 5, 0.0, 1e-5, None, PLAN, ws.data_ptr(), nws, sc.data_ptr(),
                        pa.data_ptr(), le.data_ptr(), None, None)
                 assert rc == 0, rc
             call()
@@ -65,12 +67,12 @@ def main():
                 continue
             dbg.zero_()
             for _ in range(3):
-                rc = f(x.data_ptr(), K, pack.data_ptr(), K, T, B, 4, 5, 0.0, 1e-5, None, ws.data_ptr(), nws, sc.data_ptr(),
+                rc = f(x.data_ptr(), K, pack.data_ptr(), K, T, B, 4, 5, 0.0, 1e-5, None, PLAN, ws.data_ptr(), nws, sc.data_ptr(),
                        pa.data_ptr(), le.data_ptr(), dbg.data_ptr(), None)
                 assert rc == 0
             torch.cuda.synchronize()
             st = dbg.cpu().numpy().reshape(-1, 16)
-            nper = (T + 15) // 16 + 1
+            nper = (T + BS - 1) // BS + 1
             flat = st[:nper].reshape(-1).astype(np.int64)
             d = np.diff(flat)
             per = d[16 * 5:16 * (nper - 3)].reshape(-1, 16)      # main-loop periods; column k = duration of step k+1 (k = 15: next step 0)
