@@ -243,6 +243,11 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
             const half8 bl = *reinterpret_cast<const half8 *>(tl + 16 * s);
             // D[m = W column][n = x row]; small terms first so that they are not absorbed by the large one
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, alo[s], acc, 0, 0, 0);
+            // The first MFMA of a tile has C = 0 and a freshly defined destination: where one of its operands is not used again
+            // (alo[0] in the last tile of a workgroup) hipcc (ROCm 7.2) lets the destination overlap that operand's registers,
+            // which gfx950 does not execute safely for this 16-pass instruction (csrc/softmax_viterbi.hip has the story).  An
+            // empty asm that takes the result and the operands keeps them apart.
+            if (s == 0) asm volatile("" : "+v"(acc) : "v"(alo[0]), "v"(bh));
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ahi[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ahi[s], acc, 0, 0, 0);
         }

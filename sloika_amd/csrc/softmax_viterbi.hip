@@ -351,24 +351,40 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             wfl[p % SV_D] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, wwave + p * 2048 + 1024, 0));
         }
     };
-    // fragment pair p = (tile n, K block s): three MFMAs, small terms first (gemm_rows_f16x3.hip)
+    // fragment pair p = (tile n, K block s): three MFMAs, small terms first (gemm_rows_f16x3.hip).
+    //
+    // Register hygiene around v_mfma_f32_32x32x16_f16 (hipcc of ROCm 7.2, gfx950).  The first MFMA of a tile has C = 0 and a
+    // destination that is defined right there, so the allocator may place it on registers that have just died: the
+    // instruction's own `alo` operand, or the operands of the MFMAs issued just before it (v_mfma v[34:49], v[34:37], ..., 0
+    // two lines behind an MFMA that reads v[34:37]).  The compiler considers both safe; the hardware does not execute them
+    // safely: whenever the matrix pipe was contended, row 30 of a tile came out computed from overwritten operand registers --
+    // one register of sixteen lanes, in some waves, in some runs (found by repeating tests/test_gpu_fused_decode.py's K = 64
+    // cases and by tools/mfma_overlap_scan.py on the ISA).  So the operands of a pair (and of the pair before it) are kept
+    // alive until the NEXT pair's first MFMA has been issued: an empty asm takes that MFMA's result together with them.
+    half8 pahi = {}, palo = {}, pwfh = {}, pwfl = {};           // the previous pair's operands
     auto mma_pair = [&](auto pc, int apar) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
         constexpr int n = p / KS, s = p % KS;
         const uint8_t *ab = smem + OFF_A + apar * KS * 2048 + s * 2048 + lane * 16;
         const half8 ahi = *reinterpret_cast<const half8 *>(ab);
         const half8 alo = *reinterpret_cast<const half8 *>(ab + 1024);
+        const half8 wh = wfh[p % SV_D], wl = wfl[p % SV_D];
         if constexpr (s == 0) {
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[n][i] = 0.0f;
         }
         if constexpr (!(SV_ABL & 1)) {
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, wfh[p % SV_D], acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wfl[p % SV_D], acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wfh[p % SV_D], acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, wh, acc[n], 0, 0, 0);
+            asm volatile("" : "+v"(acc[n]) : "v"(alo), "v"(pahi), "v"(palo), "v"(pwfh), "v"(pwfl));
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wl, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wh, acc[n], 0, 0, 0);
         } else {
-            acc[n][0] += (float)ahi[0] + (float)alo[1] + (float)wfh[p % SV_D][0] + (float)wfl[p % SV_D][1];
+            acc[n][0] += (float)ahi[0] + (float)alo[1] + (float)wh[0] + (float)wl[1];
         }
+        pahi = ahi;
+        palo = alo;
+        pwfh = wh;
+        pwfl = wl;
         wload(ic<p + SV_D>{});
     };
     auto wload_first = [&](auto pc, auto &&self) __attribute__((always_inline)) {
@@ -704,7 +720,13 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     load_x(0);
     bar();                                                      // constants staged
     prepare_a(0);
+#ifdef SV_DBG_A
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     load_x(1);
+#ifdef SV_DBG_B
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     bar();
     period(std::false_type{}, std::true_type{}, -1);
     for (int cb = 0; cb + 1 < nblk; cb++) period(std::true_type{}, std::true_type{}, cb);

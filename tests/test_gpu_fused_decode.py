@@ -37,7 +37,7 @@ def _softmax_layer(rs, K, S=1025, wscale=0.5):
     return sm, W, b
 
 
-def _check(oracle, rs, T, B, K, skip=0.0, ragged=False, wscale=0.5, xscale=1.0):
+def _check(oracle, rs, T, B, K, skip=0.0, ragged=False, wscale=0.5, xscale=1.0, lp_tol=LP_TOL, post_tol=POST_TOL):
     torch = need_gpu()
     from sloika_amd import decode
     sm, W, b = _softmax_layer(rs, K, wscale=wscale)
@@ -61,8 +61,8 @@ def _check(oracle, rs, T, B, K, skip=0.0, ragged=False, wscale=0.5, xscale=1.0):
     scn, pan, len_ = sc.cpu().numpy(), pa.cpu().numpy(), le.cpu().numpy()
     for bb in range(B):
         Tb = int(ln[bb])
-        assert np.abs(lp[:Tb, bb] - ref[:Tb, bb]).max() < LP_TOL
-        assert np.abs(np.exp(lp[:Tb, bb]) - np.exp(ref[:Tb, bb])).max() < POST_TOL
+        assert np.abs(lp[:Tb, bb] - ref[:Tb, bb]).max() < lp_tol
+        assert np.abs(np.exp(lp[:Tb, bb]) - np.exp(ref[:Tb, bb])).max() < post_tol
         o_s, o_p, o_l = oracle.viterbi_batch(np.ascontiguousarray(lp[:Tb, bb:bb + 1]), 5, skip_pen=skip)
         assert o_l[0] == len_[bb]
         assert np.array_equal(o_p[0, :o_l[0]], pan[bb, :len_[bb]]) and (pan[bb, len_[bb]:] == -1).all()
@@ -92,7 +92,8 @@ def test_fused_decode_against_oracle_on_its_log_posteriors(oracle, T, B, K, skip
 
 def test_fused_decode_operand_ranges(oracle):
     """Row scaling of x and column scaling of W: large weights (the trained pickle reaches 6), tiny and huge activations."""
-    _check(oracle, np.random.RandomState(5), 40, 4, 96, wscale=3.0)
+    # logits of magnitude ~50: one float32 ulp of the logit is 4e-6, and so is the posterior's absolute error
+    _check(oracle, np.random.RandomState(5), 40, 4, 96, wscale=3.0, lp_tol=1e-4, post_tol=1e-5)
     _check(oracle, np.random.RandomState(6), 40, 4, 112, wscale=0.5, xscale=1e-3)
     _check(oracle, np.random.RandomState(7), 40, 4, 64, wscale=0.02, xscale=50.0)
 
@@ -148,3 +149,24 @@ def test_fused_decode_full_size_sampled_chunks(oracle):
     assert np.array_equal(le.cpu().numpy()[pick], o_l)
     assert np.array_equal(pa.cpu().numpy()[pick], o_p)
     assert np.array_equal(sc.cpu().numpy()[pick], o_s)
+
+
+def test_fused_decode_repeats_bit_for_bit():
+    """Race / hazard screen: the same call repeated gives the same bits, with and without the dump (two instantiations of the
+    kernel), at the insize where a destination/operand register overlap of v_mfma_f32_32x32x16_f16 once corrupted a row in
+    some runs (csrc/softmax_viterbi.hip, mma_pair), and at full size."""
+    torch = need_gpu()
+    from sloika_amd import decode
+    for (T, B, K, reps) in ((40, 4, 64, 12), (40, 5, 96, 6), (40, 4, 112, 6), (40, 4, 128, 6), (800, 1024, 64, 3), (800, 1024, 96, 3)):
+        rs = np.random.RandomState(K + T)
+        sm, W, b = _softmax_layer(rs, K)
+        pack = sm.viterbi_pack(4, 5)
+        xd = torch.tanh(torch.randn((T, B, K), device="cuda", generator=torch.Generator(device="cuda").manual_seed(K)))
+        dump = torch.empty((T, B, 1025), dtype=torch.float32, device="cuda")
+        first = None
+        for rep in range(reps):
+            sc, pa, le = decode.viterbi_fused_batch(xd, pack, 5, lp_dump=dump if rep % 2 else None)
+            if first is None:
+                first = (sc.clone(), pa.clone(), le.clone())
+            else:
+                assert torch.equal(sc, first[0]) and torch.equal(pa, first[1]) and torch.equal(le, first[2]), (T, B, K, rep)

@@ -1,0 +1,26 @@
+"""ISA-level screen of the kernels built on v_mfma_f32_32x32x16_f16: hipcc (ROCm 7.2) may give a freshly defined MFMA
+destination (C = 0) the registers of an operand that dies at that instruction or at the MFMA just before it; on MI355X that
+corrupted rows under matrix-pipe contention (csrc/softmax_viterbi.hip, mma_pair).  The sources keep the operands alive with
+empty asm statements; this test compiles them to ISA (hipcc cross-compiles without a GPU) and checks that no such overlap is
+left."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.parametrize("src,flags", [("softmax_viterbi.hip", ["-DSV_ONLY_KS=4"]), ("softmax_viterbi.hip", ["-DSV_ONLY_KS=6"]),
+                                       ("gemm_rows_f16x3.hip", [])])
+def test_no_mfma_destination_over_live_operands(tmp_path, src, flags):
+    import mfma_overlap_scan
+    from sloika_amd import build
+    out = str(tmp_path / (src + ".s"))
+    cmd = [build.hipcc()] + build.FLAGS + flags + ["--cuda-device-only", "-S", os.path.join(build.CSRC, src), "-o", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    own, war = mfma_overlap_scan.scan(out)
+    assert own == 0 and war == 0, "%s: %d MFMA destinations over their own operands, %d over the preceding MFMA's" % (src, own, war)
