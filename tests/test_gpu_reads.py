@@ -81,6 +81,32 @@ def test_fp16_split_projections_do_not_change_the_call():
     assert out[0][0] == pytest.approx(out[1][0], rel=1e-5) and out[0][0] != 0.0
 
 
+def _check_against_single_reads(bc, calc_post, reads, scores, paths, lens, nsamp, skip):
+    """Every read of the padded batch against (1) the same decoder on that read ALONE (a batch of one: bit for bit -- this is
+    the property that makes batching exact) and (2) the reference-shaped whole-read worker basecall.raw_read_worker, which
+    goes through the materialised posterior (calc_post -> decode_post, sloika/basecall.py:117-119): bit for bit when the batch
+    decoder is the logits decoder too, and to float32 accumulation accuracy when it is the fused kernel of
+    csrc/softmax_viterbi.hip (its log-posteriors differ from the posterior path's in the last bits)."""
+    from sloika_amd import basecall, layers
+    last = bc.network.layers[-1]
+    fused = bc.fused_decode and type(last) is layers.Softmax and last.viterbi_pack(bc.nbase, bc.kmer_len) is not None
+    for b, r in enumerate(reads):
+        s1, p1, l1, n1 = bc.call_reads([r])
+        assert n1[0] == nsamp[b]
+        assert int(l1[0]) == int(lens[b]) and p1.cpu().numpy()[0, :int(l1[0])].tolist() == paths[b, :lens[b]].tolist(), b
+        assert float(s1[0]) == float(scores[b]), b
+        assert (paths[b, lens[b]:] == -1).all()
+        _, score1, call1, nw = basecall.raw_read_worker(calc_post, r, trim=(0, 0), kmer_len=5, skip=skip, name="r%d" % b)
+        assert nw == nsamp[b]
+        if fused:
+            assert float(scores[b]) == pytest.approx(float(score1), rel=2e-6, abs=1e-3), b
+            same = paths[b, :lens[b]].tolist() == [int(c) for c in call1]
+            assert same or abs(int(lens[b]) - len(call1)) <= max(2, len(call1) // 500), b     # a near tie may resolve the other way
+        else:
+            assert int(lens[b]) == len(call1) and paths[b, :lens[b]].tolist() == [int(c) for c in call1], b
+            assert float(scores[b]) == float(score1), b
+
+
 def test_ragged_batch_of_reads_equals_one_by_one():
     """Whole reads of different lengths in one padded batch (pipeline.Basecaller.call_reads: per-read lengths through the
     conv stride, reversed GRU scans starting at each read's own end, per-read Viterbi) must reproduce, bit for bit, what
@@ -99,13 +125,7 @@ def test_ragged_batch_of_reads_equals_one_by_one():
     scores, paths, lens, nsamp = bc.call_reads(reads)
     scores, paths, lens = scores.cpu().numpy(), paths.cpu().numpy(), lens.cpu().numpy()
     assert nsamp == [len(r) - len(r) % 100 for r in reads]          # trim_open_pore keeps whole 100-sample windows
-    for b, r in enumerate(reads):
-        _, score1, call1, n1 = basecall.raw_read_worker(calc_post, r, trim=(0, 0), kmer_len=5, skip=5.0, name="r%d" % b)
-        assert n1 == nsamp[b]
-        assert int(lens[b]) == len(call1), b
-        assert paths[b, :lens[b]].tolist() == [int(c) for c in call1], b
-        assert (paths[b, lens[b]:] == -1).all()
-        assert float(scores[b]) == float(score1), b
+    _check_against_single_reads(bc, calc_post, reads, scores, paths, lens, nsamp, skip=5.0)
     # the same reads in another order and batch composition give the same calls
     scores2, paths2, lens2, _ = bc.call_reads([reads[3], reads[0]])
     assert paths2.cpu().numpy()[1, :int(lens2[1])].tolist() == paths[0, :lens[0]].tolist()
@@ -125,8 +145,4 @@ def test_ragged_batch_other_architectures(model):
     bc = pipeline.Basecaller(net, kmer_len=5, min_prob=1e-5, skip=0.0)
     scores, paths, lens, nsamp = bc.call_reads(reads)
     scores, paths, lens = scores.cpu().numpy(), paths.cpu().numpy(), lens.cpu().numpy()
-    for b, r in enumerate(reads):
-        _, score1, call1, n1 = basecall.raw_read_worker(calc_post, r, trim=(0, 0), kmer_len=5, skip=0.0, name="r%d" % b)
-        assert n1 == nsamp[b] and int(lens[b]) == len(call1), (model, b)
-        assert paths[b, :lens[b]].tolist() == [int(c) for c in call1], (model, b)
-        assert float(scores[b]) == float(score1), (model, b)
+    _check_against_single_reads(bc, calc_post, reads, scores, paths, lens, nsamp, skip=0.0)
