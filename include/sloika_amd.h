@@ -30,6 +30,9 @@ extern "C" {
 #endif
 
 #define SLK_ABI_VERSION 1
+/* Every entry point below is exported; nothing else in libsloika_amd.so is (the library is built with
+ * -fvisibility=hidden, tests/test_cabi.py compares the export table with this header both ways).          */
+#define SLK_API __attribute__((visibility("default")))
 
 #define SLK_OK 0
 #define SLK_ERR_INVALID_ARG (-1) /* bad shape / null pointer: the reference raises AssertionError here      */
@@ -64,13 +67,17 @@ enum slk_activation {
 
 typedef void *slk_stream_t; /* hipStream_t */
 
-int slk_abi_version(void);
-const char *slk_error_string(int code);
+SLK_API int slk_abi_version(void);
+SLK_API const char *slk_error_string(int code);
 /* Number of HIP devices visible (host call; does not create a context when 0).                               */
-int slk_device_count(void);
+SLK_API int slk_device_count(void);
+/* Device self-test: one v_mfma_f32_4x4x1_16b_f32 on 64 lanes, a[lane], b[lane] -> d[4][64], with the CBSZ / ABID broadcast
+ * modifiers the exact-fp32 recurrent kernels rely on (cbsz, abid in {(0,0), (4,0), (4,3), (4,15), (3,0), (3,5), (2,1), (2,3)}):
+ * lets an integrator confirm on the installed device the operand layout those kernels assume.                              */
+SLK_API int slk_selftest_mfma4_f32(const float *a, const float *b, float *d, int cbsz, int abid, slk_stream_t stream);
 
 /* Elementwise activation y[i] = act(x[i]) (sloika/activation.py); in place allowed (y == x).                 */
-int slk_activation_f32(const float *x, float *y, size_t count, int act, slk_stream_t stream);
+SLK_API int slk_activation_f32(const float *x, float *y, size_t count, int act, slk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * a1. Chunk front end: per-chunk median/MAD normalisation.
@@ -85,12 +92,12 @@ int slk_activation_f32(const float *x, float *y, size_t count, int act, slk_stre
  * Results are bit-identical to numpy's float32 evaluation.  Any chunk_len (LDS sort up to 32768 samples, exact radix
  * selection beyond: whole reads).  -0.0 and +0.0 are distinct keys in the selection; NaNs are not supported.
  * ------------------------------------------------------------------------------------------------------- */
-int slk_med_mad_normalise_f32(const float *signal, int nchunk, int chunk_len, float *out,
+SLK_API int slk_med_mad_normalise_f32(const float *signal, int nchunk, int chunk_len, float *out,
                               long out_chunk_stride, long out_sample_stride, float *med_out, float *mad_out,
                               slk_stream_t stream);
 /* Standard deviation of each of nwin consecutive windows of `win` samples (population form, numpy's .std()):
  * batch.trim_open_pore(var_method='std'), sloika/batch.py:210-211.  out:[nwin].                                    */
-int slk_window_std_f32(const float *signal, int nwin, int win, float *out, slk_stream_t stream);
+SLK_API int slk_window_std_f32(const float *signal, int nwin, int win, float *out, slk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * a3. Convolution.run  (sloika/layers.py:417-419 -> sloika/conv.py:66-77,90-111)
@@ -100,13 +107,13 @@ int slk_window_std_f32(const float *signal, int nwin, int win, float *out, slk_s
  *       reference layout; x_t_stride=1, x_b_stride=T reads chunk-major signal when Cin == 1)
  *   W : [Cout][Cin][winlen]   bias: [Cout] or NULL   y : [Tout][B][Cout], Tout = slk_conv1d_out_len(...)
  * ------------------------------------------------------------------------------------------------------- */
-int slk_conv1d_out_len(int T, int winlen, int stride, int pad_l, int pad_r);
-int slk_conv1d_f32(const float *x, long x_t_stride, long x_b_stride, const float *W, const float *bias, float *y,
+SLK_API int slk_conv1d_out_len(int T, int winlen, int stride, int pad_l, int pad_r);
+SLK_API int slk_conv1d_f32(const float *x, long x_t_stride, long x_b_stride, const float *W, const float *bias, float *y,
                    int T, int B, int Cin, int Cout, int winlen, int stride, int pad_l, int pad_r, int act,
                    slk_stream_t stream);
 
 /* a3b. Window.run (sloika/layers.py:346-351): zero pad w/2 both ends, y[t][b][k*F+f] = xpad[t+k][b][f].      */
-int slk_window_f32(const float *x, float *y, int T, int B, int F, int w, slk_stream_t stream);
+SLK_API int slk_window_f32(const float *x, float *y, int T, int B, int F, int w, slk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * a6. FeedForward.run (sloika/layers.py:157-158) and every other `tensordot(x, W, axes=(2,1)) + b`:
@@ -114,18 +121,18 @@ int slk_window_f32(const float *x, float *y, int T, int B, int F, int w, slk_str
  *   x rows are ldx floats apart, y rows ldy floats apart (lets Parallel/birnn outputs be written straight
  *   into their slice of the concatenated tensor, sloika/layers.py:1486-1487).  W:[N][K] dense.  fp32 MFMA.
  * ------------------------------------------------------------------------------------------------------- */
-int slk_gemm_bias_act_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long ldy,
+SLK_API int slk_gemm_bias_act_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long ldy,
                           long M, int K, int N, int act, slk_stream_t stream);
 
 /* Softmax.run (sloika/layers.py:309-314): logits = x.W^T + b; p = exp(l - max) / sum.  y:[M][N] dense.      */
-int slk_linear_softmax_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long M, int K,
+SLK_API int slk_linear_softmax_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long M, int K,
                            int N, slk_stream_t stream);
 /* x-stationary variant for wide outputs (csrc/gemm_rows.hip): logits y[r][j] = x[r].W[j] + b[j] with row stride ldy,
  * plus (when stats != NULL) stats[r] = (max_j, 1 / sum_j exp(y[r][j] - max_j)) accumulated on the fly.  K <= 128, else
  * SLK_ERR_UNSUPPORTED.  slk_softmax_from_stats_f32 turns (logits, stats) into the posterior exp(l - max) * inv_sum.    */
-int slk_linear_rowstats_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long ldy, long M, int K,
+SLK_API int slk_linear_rowstats_f32(const float *x, long ldx, const float *W, const float *bias, float *y, long ldy, long M, int K,
                             int N, float *stats /* [M][2] or NULL */, slk_stream_t stream);
-int slk_softmax_from_stats_f32(const float *logits, long ld_in, const float *stats, float *post, long ld_out, long M,
+SLK_API int slk_softmax_from_stats_f32(const float *logits, long ld_in, const float *stats, float *post, long ld_out, long M,
                                int N, slk_stream_t stream);
 /* Same contraction on the FP16 matrix pipe with float32-grade accuracy (csrc/gemm_rows_f16x3.hip): operands split
  * v = hi + lo in fp16, x.w ~= x_hi.w_hi + x_hi.w_lo + x_lo.w_hi accumulated in float32 -- ~5x the fp32-MFMA
@@ -134,20 +141,20 @@ int slk_softmax_from_stats_f32(const float *logits, long ld_in, const float *sta
  * magnitude into [1, 2) (inv_scale[N] receives the inverse scales); the kernels scale every row of x the same way and undo
  * both on the float32 accumulators, so operands of ANY finite float32 magnitude are handled (fp16 alone overflows at 65504
  * and loses its lo half below 6e-5).                                                                                 */
-int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, void *lo, float *inv_scale, slk_stream_t stream);
-int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
+SLK_API int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, void *lo, float *inv_scale, slk_stream_t stream);
+SLK_API int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
                               const float *bias, float *y, long ldy, long M, int K, int N,
                               float *stats /* [M][2] or NULL */, slk_stream_t stream);
 /* FeedForward.run (sloika/layers.py:157-158) on the same kernel: y = act(x.W^T + b); act one of linear / tanh / sigmoid /
  * relu / elu, otherwise SLK_ERR_UNSUPPORTED (use slk_gemm_bias_act_f32).  Both: K <= 192, N <= 2048.                  */
-int slk_gemm_bias_act_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
+SLK_API int slk_gemm_bias_act_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
                             const float *bias, float *y, long ldy, long M, int K, int N, int act, slk_stream_t stream);
 /* In-place row softmax of y:[M][N] (the second half of the above, exposed for testing).                     */
-int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream);
+SLK_API int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream);
 /* Row statistics only: stats[r] = (max_j logits[r][j], 1 / sum_j exp(logits[r][j] - max)); the posterior
  * exp(l - max) * inv_sum rebuilt from them is bit-identical to what slk_softmax_rows_f32 writes.  Lets the decoder
  * consume logits directly so the normalised posterior is never written (slk_viterbi_kmer_logits_f32).            */
-int slk_softmax_rowstats_f32(const float *logits, long M, int N, float *stats /* [M][2] */, slk_stream_t stream);
+SLK_API int slk_softmax_rowstats_f32(const float *logits, long M, int N, float *stats /* [M][2] */, slk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * a4. Gru  (sloika/layers.py:952-1021; step :1010-1021; zero initial state :85-88; Reverse :1449-1450)
@@ -161,10 +168,10 @@ int slk_softmax_rowstats_f32(const float *logits, long M, int N, float *stats /*
  *   h_out[(t*B + b)*ldh + j]  (ldh >= n).
  * slk_gru_f32 = projection + recurrence; workspace >= slk_gru_workspace_bytes(T,B,n).
  * ------------------------------------------------------------------------------------------------------- */
-int slk_gru_recurrent_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
+SLK_API int slk_gru_recurrent_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
                           int n, int reverse, int act, int gate_act, slk_stream_t stream);
-size_t slk_gru_workspace_bytes(int T, int B, int n);
-int slk_gru_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+SLK_API size_t slk_gru_workspace_bytes(int T, int B, int n);
+SLK_API int slk_gru_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                 float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                 void *workspace, size_t workspace_bytes, slk_stream_t stream);
 /* Whole layer in one persistent kernel (projection waves + recurrent waves, csrc/gru_fused.hip): no workspace, the
@@ -173,7 +180,7 @@ int slk_gru_f32(const float *x, long ldx, const float *iW, const float *sW, cons
  * plain fp32 arithmetic throughout use slk_gemm_bias_act_f32 + slk_gru_recurrent_f32.  Returns SLK_ERR_UNSUPPORTED
  * when (insize, n, activations, alignment) has no fused instantiation; slk_gru_f32 tries it first and falls back to
  * projection GEMM + slk_gru_recurrent_f32.                                                                          */
-int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+SLK_API int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                       float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                       slk_stream_t stream);
 /* The same layer with the RECURRENCE on the fp16 matrix pipe as well (csrc/gru_fused16.hip): every float32 operand of
@@ -182,7 +189,7 @@ int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW
  * row of x and of the three weight matrices is scaled by a power of two to a maximum in [1, 2) before its split and the
  * accumulators are scaled back, so inputs and weights of any finite float32 magnitude are safe.  lens: NULL, or ragged lengths as slk_gru_fused_ragged_f32; zr_out: NULL, or [T*B][2n] = [z | r] of every
  * step as slk_gru_fused_train_f32.  n in {32, 64, 96}; SLK_ERR_UNSUPPORTED for shapes without an instantiation.     */
-int slk_gru_fused16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+SLK_API int slk_gru_fused16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                         float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                         const int32_t *lens, float *zr_out, slk_stream_t stream);
 /* The same arithmetic and contract as slk_gru_fused16_f32 on a different execution plan (csrc/gru_bar16.hip): four waves
@@ -194,28 +201,28 @@ int slk_gru_fused16_f32(const float *x, long ldx, const float *iW, const float *
  * csrc/gru_bar16d.hip instead (two four-chunk tiles through the same MFMAs), one with more eight-chunk workgroups than CUs
  * the sixteen-chunk plan of csrc/gru_bar16q.hip (bit-identical results).  Bits 8-9 of `reverse` force a plan: 0 = by batch
  * size, 1 / 2 / 3 = four / eight / sixteen chunks per workgroup (environment: SLOIKA_AMD_GRU_DUAL=0|1|2).               */
-int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+SLK_API int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                       float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                       const int32_t *lens, float *zr_out, slk_stream_t stream);
 /* Ragged batches (whole reads of different lengths, zero-padded to T steps; the reference calls reads one at a time,
  * sloika/basecall.py:88-121): lens[b] in [1, T] (int32, device) is the number of valid steps of chunk b.  Steps
  * t >= lens[b] of y / h_out are left untouched, and with reverse = 1 the scan of chunk b starts at ITS last step,
  * i.e. each chunk gets exactly what a call on the unpadded chunk alone would produce.                                */
-int slk_gru_fused_ragged_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
+SLK_API int slk_gru_fused_ragged_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
                              const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse, int act,
                              int gate_act, const int32_t *lens, slk_stream_t stream);
-int slk_gru_recurrent_ragged_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
+SLK_API int slk_gru_recurrent_ragged_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
                                  int n, int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream);
 /* The same scan (Gru.step over a projection vI [T*B][ldv >= 3n] = x.iW^T + b in HBM; sloika/layers.py:1010-1021) for layers
  * too wide for the fused kernels, on the execution plan of slk_gru_bar16_f32: recurrent products as 3-term fp16 splits, four
  * waves stepping through two barriers per step (csrc/gru_scan16.hip).  n = 112 or 128 (models/pretrained.pkl,
  * models/raw_1.00_rGr.py zero-padded), tanh / sigmoid; anything else SLK_ERR_UNSUPPORTED (-> slk_gru_recurrent_f32).
  * lens (int32 [B], device) or NULL as for slk_gru_recurrent_ragged_f32.                                                  */
-int slk_gru_scan16_f32(const float *vI, long ldv, const float *sW, const float *sW2, float *y, long ldy, int T, int B, int n,
+SLK_API int slk_gru_scan16_f32(const float *vI, long ldv, const float *sW, const float *sW2, float *y, long ldy, int T, int B, int n,
                        int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream);
 /* Force the portable (non-MFMA) recurrence kernel: 0 = auto, 1 = force generic.  Testing aid; passed per call
  * through the `_ex` form so that there is still no global state.                                            */
-int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T,
+SLK_API int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T,
                              int B, int n, int reverse, int act, int gate_act, int force_generic,
                              slk_stream_t stream);
 
@@ -225,13 +232,13 @@ int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const float *sW2,
  *   vW[t][b][j*4+g] = x_t . iW[j*4+g] + b[j*4+g]  (from slk_gemm_bias_act_f32);  sW:[4n][n];
  *   p may be NULL (has_peep=False).  Output = the `out` half of the state (layers.py:697).
  * ------------------------------------------------------------------------------------------------------- */
-int slk_lstm_recurrent_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
+SLK_API int slk_lstm_recurrent_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
                            int n, int reverse, int act, int gate_act, slk_stream_t stream);
-int slk_lstm_recurrent_ragged_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
+SLK_API int slk_lstm_recurrent_ragged_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
                                   int n, int reverse, int act, int gate_act, const int32_t *lens /* see slk_gru_fused_ragged_f32 */,
                                   slk_stream_t stream);
-size_t slk_lstm_workspace_bytes(int T, int B, int n);
-int slk_lstm_f32(const float *x, long ldx, const float *iW, const float *sW, const float *bias, const float *p,
+SLK_API size_t slk_lstm_workspace_bytes(int T, int B, int n);
+SLK_API int slk_lstm_f32(const float *x, long ldx, const float *iW, const float *sW, const float *bias, const float *p,
                  float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                  void *workspace, size_t workspace_bytes, slk_stream_t stream);
 
@@ -255,28 +262,28 @@ int slk_lstm_f32(const float *x, long ldx, const float *iW, const float *sW, con
 #define SLK_POST_PLAIN 1
 #define SLK_POST_LOG 2
 #define SLK_POST_LN 3 /* slk_log_post_f32 only: lp = log(post), no eta (np.log(trans), sloika/transducer.py:30) */
-size_t slk_viterbi_kmer_workspace_bytes(int T, int B, int nbase, int klen);
-int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, int klen, float skip_pen, int input_mode,
+SLK_API size_t slk_viterbi_kmer_workspace_bytes(int T, int B, int nbase, int klen);
+SLK_API int slk_viterbi_kmer_f32(const float *post, int T, int B, int nbase, int klen, float skip_pen, int input_mode,
                          float min_prob, void *workspace, size_t workspace_bytes, float *score_out,
                          int32_t *path_out, int32_t *len_out, slk_stream_t stream);
-int slk_log_post_f32(const float *post, float *lpost, size_t count, int input_mode, float min_prob,
+SLK_API int slk_log_post_f32(const float *post, float *lpost, size_t count, int input_mode, float min_prob,
                      slk_stream_t stream);
 /* Softmax.run + decode_post in one pass over the LOGITS (sloika/layers.py:309-314 + sloika/basecall.py:26-51):
  * logits: rows (t,b) of nstate floats, `ld` floats apart, = x.W^T + b;  stats:[T*B][2] from slk_linear_rowstats_f32
  * (or slk_softmax_rowstats_f32 for dense logits).  Same outputs as
  * slk_viterbi_kmer_f32(SLK_POST_RAW) on the normalised posterior, bit for bit.  slk_log_post_logits_f32 exposes the
  * log-posterior it decodes (for tests).                                                                          */
-int slk_viterbi_kmer_logits_f32(const float *logits, long ld /* floats between rows, >= nstate */, const float *stats,
+SLK_API int slk_viterbi_kmer_logits_f32(const float *logits, long ld /* floats between rows, >= nstate */, const float *stats,
                                 int T, int B, int nbase, int klen, float skip_pen, float min_prob, void *workspace,
                                 size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out,
                                 slk_stream_t stream);
 /* Ragged form (see slk_gru_fused_ragged_f32): chunk b is decoded over its first lens[b] steps only; path_out rows keep
  * the padded length T.                                                                                               */
-int slk_viterbi_kmer_logits_ragged_f32(const float *logits, long ld, const float *stats, int T, int B, int nbase, int klen,
+SLK_API int slk_viterbi_kmer_logits_ragged_f32(const float *logits, long ld, const float *stats, int T, int B, int nbase, int klen,
                                        float skip_pen, float min_prob, const int32_t *lens, void *workspace,
                                        size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out,
                                        slk_stream_t stream);
-int slk_log_post_logits_f32(const float *logits, long ld, const float *stats, float *lpost /* dense [rows][nstate] */,
+SLK_API int slk_log_post_logits_f32(const float *logits, long ld, const float *stats, float *lpost /* dense [rows][nstate] */,
                             size_t rows, int nstate, float min_prob, slk_stream_t stream);
 /* The same chain from the Softmax layer's INPUT: x.W^T + b, softmax, prepare_post, log and the Viterbi forward pass in one
  * kernel, so that the [T][B][nstate] logits never exist in memory (sloika/layers.py:309-314 -> sloika/decode.py:21-36 ->
@@ -294,18 +301,18 @@ int slk_log_post_logits_f32(const float *logits, long ld, const float *stats, fl
  * Products are 3-term fp16 splits with float32 accumulation like slk_linear_rowstats_f16x3.  This build has the kernel for
  * nbase 4, klen 5 and K in {64, 96, 112, 128}; anything else returns SLK_ERR_UNSUPPORTED (pack_bytes returns 0) and the
  * caller uses slk_linear_rowstats_* + slk_viterbi_kmer_logits_f32.                                                        */
-size_t slk_softmax_viterbi_pack_bytes(int K, int nbase, int klen);
-int slk_softmax_viterbi_pack_f32(const float *W, const float *bias, int K, int nbase, int klen, void *pack,
+SLK_API size_t slk_softmax_viterbi_pack_bytes(int K, int nbase, int klen);
+SLK_API int slk_softmax_viterbi_pack_f32(const float *W, const float *bias, int K, int nbase, int klen, void *pack,
                                  slk_stream_t stream);
-int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pack, int K, int T, int B, int nbase, int klen,
+SLK_API int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pack, int K, int T, int B, int nbase, int klen,
                             float skip_pen, float min_prob, const int32_t *lens, int plan, void *workspace,
                             size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out, float *lp_dump,
                             slk_stream_t stream);
 /* decode.prepare_post on its own: out = min_prob + (1-min_prob)*post (decode.py:36).                        */
-int slk_prepare_post_f32(const float *post, float *out, size_t count, float min_prob, slk_stream_t stream);
+SLK_API int slk_prepare_post_f32(const float *post, float *out, size_t count, float min_prob, slk_stream_t stream);
 /* decode.argmax (decode.py:5-18), batched: per (b) the states with argmax != blank, minus 1 if
  * zero_is_blank; same output convention as slk_viterbi_kmer_f32.                                            */
-int slk_argmax_decode_f32(const float *post, int T, int B, int nstate, int zero_is_blank, int32_t *path_out,
+SLK_API int slk_argmax_decode_f32(const float *post, int T, int B, int nstate, int zero_is_blank, int32_t *path_out,
                           int32_t *len_out, slk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -316,7 +323,7 @@ int slk_argmax_decode_f32(const float *post, int T, int B, int nstate, int zero_
  *   repeated state unless always_move).  paths:[B][ld] int32, lens:[B]; alphabet: the letters packed little-endian in 8
  *   bytes; out:[B][cap] bytes with cap >= klen * max(lens); nbases[b] = letters written for read b.
  * ------------------------------------------------------------------------------------------------------- */
-int slk_paths_to_bases(const int32_t *paths, long ld, const int32_t *lens, int B, int klen, int nbase, int always_move,
+SLK_API int slk_paths_to_bases(const int32_t *paths, long ld, const int32_t *lens, int B, int klen, int nbase, int always_move,
                        unsigned long long alphabet, uint8_t *out, long cap, int32_t *nbases, slk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -328,10 +335,10 @@ int slk_paths_to_bases(const int32_t *paths, long ld, const int32_t *lens, int B
  *     float32 score vector, transducer.py:39-41,63-64); score_out:[1]; path_out:[nev] int32.
  *     workspace >= slk_map_to_sequence_workspace_bytes(nev, npos).  npos >= 3.
  * ------------------------------------------------------------------------------------------------------- */
-int slk_slip_update_f32(const float *x, int n, float slip, float *from_score, int64_t *from_pos,
+SLK_API int slk_slip_update_f32(const float *x, int n, float slip, float *from_score, int64_t *from_pos,
                         slk_stream_t stream);
-size_t slk_map_to_sequence_workspace_bytes(int nev, int npos);
-int slk_map_to_sequence_f32(const float *ltrans, int nev, int nst, const int32_t *seq, int npos, float slip,
+SLK_API size_t slk_map_to_sequence_workspace_bytes(int nev, int npos);
+SLK_API int slk_map_to_sequence_f32(const float *ltrans, int nev, int nst, const int32_t *seq, int npos, float slip,
                             const double *prior_initial, const double *prior_final, void *workspace,
                             size_t workspace_bytes, float *score_out, int32_t *path_out, slk_stream_t stream);
 /* Batched form of the same call (the reference remaps reads one by one: bin/chunkify.py `remap` ->
@@ -341,7 +348,7 @@ int slk_map_to_sequence_f32(const float *ltrans, int nev, int nst, const int32_t
  *   ws_off:[nread] int64 -- offset (in int32 elements) of read b's nev_b*npos_b traceback inside `workspace`;
  *   max_npos = the longest sequence (sizes the LDS request; npos <= 3276); score_out:[nread].
  * A read with fewer than 3 positions or no events gets score -inf and its path is left untouched. */
-int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *ev_off, const int32_t *seq,
+SLK_API int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *ev_off, const int32_t *seq,
                                   const int64_t *pos_off, int nread, int max_npos, float slip,
                                   const double *prior_initial, const double *prior_final, void *workspace,
                                   const int64_t *ws_off, float *score_out, int32_t *path_out, slk_stream_t stream);
@@ -379,13 +386,13 @@ int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *e
  *   g = clip(grad * gscale + 2 l2 param).   slk_sgd_update_f32: updates.py:9-33.
  * ------------------------------------------------------------------------------------------------------- */
 /* Forward pass that also saves the gates: slk_gru_fused_f32 + zr_out:[T*B][2n] = [z | r] of every step. */
-int slk_gru_fused_train_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
+SLK_API int slk_gru_fused_train_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                             float *y, long ldy, float *zr_out, int T, int B, int insize, int n, int reverse, int act,
                             int gate_act, slk_stream_t stream);
-int slk_train_pack_xh_f32(const float *x, long ldx, const float *h, long ldh, float *xh, int T, int B, int insize, int n,
+SLK_API int slk_train_pack_xh_f32(const float *x, long ldx, const float *h, long ldh, float *xh, int T, int B, int insize, int n,
                           int reverse, slk_stream_t stream);
-int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *xrh, long M, int insize, int n, slk_stream_t stream);
-int slk_gru_backward_f32(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h, long ldh,
+SLK_API int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *xrh, long M, int insize, int n, slk_stream_t stream);
+SLK_API int slk_gru_backward_f32(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h, long ldh,
                          const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n, int reverse,
                          int act, int gate_act, slk_stream_t stream);
 /* Lstm (layers.py:677-697) in the reverse pass.  sum:[M][4n] = [x_t | out_{t-1}] . [iW | sW]^T + b (a GEMM over
@@ -394,39 +401,39 @@ int slk_gru_backward_f32(const float *dy, long lddy, const float *hprev, long ld
  *     cell:[M][n] = c_t.   peep:[3][n] or NULL.
  *   slk_lstm_backward_f32: the reverse scan -> dsum:[M][4n] = dL/dsum, dpeep:[B][3][n] per-chunk peephole gradients.
  *     n in {16,32,48,64,96,128}, tanh / sigmoid.  Then diW = dsum^T x, dsW = dsum^T out_prev, db = dsum^T 1, dx = dsum . iW. */
-int slk_lstm_gates_f32(const float *sum, const float *peep, float *gates, float *cell, int T, int B, int n, int reverse,
+SLK_API int slk_lstm_gates_f32(const float *sum, const float *peep, float *gates, float *cell, int T, int B, int n, int reverse,
                        slk_stream_t stream);
-int slk_lstm_backward_f32(const float *dy, long lddy, const float *gates, const float *cell, const float *sW, const float *peep,
+SLK_API int slk_lstm_backward_f32(const float *dy, long lddy, const float *gates, const float *cell, const float *sW, const float *peep,
                           float *dsum, float *dpeep, int T, int B, int n, int reverse, int act, int gate_act,
                           slk_stream_t stream);
-int slk_softmax_xent_grad_f32(float *logits, long ld, const float *stats, const int32_t *labels, const float *weights, int T,
+SLK_API int slk_softmax_xent_grad_f32(float *logits, long ld, const float *stats, const int32_t *labels, const float *weights, int T,
                               int B, int nstate, int drop, float min_prob, float *loss_rows, float *correct_rows,
                               slk_stream_t stream);
-int slk_reduce_sum_f32(const float *x, size_t n, int square, double *out, slk_stream_t stream);
-size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2);
-int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
+SLK_API int slk_reduce_sum_f32(const float *x, size_t n, int square, double *out, slk_stream_t stream);
+SLK_API size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2);
+SLK_API int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
                     float *colsum /* [N1] or NULL */, void *workspace, size_t workspace_bytes, slk_stream_t stream);
 /* The same contraction with every float32 operand cut into three bf16 pieces and each product evaluated as six bf16 MFMA terms
  * in float32 accumulators (v_mfma_f32_32x32x16_bf16): float32-grade results (terms below 2^-24 of a product are dropped), no
  * scaling needed (bf16 has float32's exponent range), ~2x the speed of the fp32 MFMA form.  Same workspace.               */
-int slk_gemm_tn_bf16x6_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
+SLK_API int slk_gemm_tn_bf16x6_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
                            float *colsum, void *workspace, size_t workspace_bytes, slk_stream_t stream);
-int slk_act_backward_f32(const float *dy, const float *y, float *out, size_t n, int act, slk_stream_t stream);
-int slk_add_inplace_f32(float *y, const float *x, size_t n, slk_stream_t stream);   /* y += x: dL/dx of Parallel branches */
-int slk_train_im2col_cin1_f32(const float *x, long x_t_stride, long x_b_stride, int T, int B, int winlen, int stride,
+SLK_API int slk_act_backward_f32(const float *dy, const float *y, float *out, size_t n, int act, slk_stream_t stream);
+SLK_API int slk_add_inplace_f32(float *y, const float *x, size_t n, slk_stream_t stream);   /* y += x: dL/dx of Parallel branches */
+SLK_API int slk_train_im2col_cin1_f32(const float *x, long x_t_stride, long x_b_stride, int T, int B, int winlen, int stride,
                               int pad_lo, int pad_hi, float *cols, slk_stream_t stream);
 /* Any number of input features (a Convolution that is not the first layer, or multi-feature input): x:[T][B][Cin], rows ldx
  * floats apart; cols[(t*B + b)][c*winlen + k] = x(t*stride + k - pad_lo, b, c), zero outside the signal (the flattened column
  * order of Convolution.W:[Cout][Cin][winlen], conv.py:66-111), so dL/dW = dpre^T cols and dL/dcols = dpre . W; col2im is the
  * adjoint (dx(t', b, c) = sum of the dcols entries whose window covers t'), a gather in a fixed order.                     */
-int slk_train_im2col_f32(const float *x, long ldx, int T, int B, int Cin, int winlen, int stride, int pad_lo, int pad_hi,
+SLK_API int slk_train_im2col_f32(const float *x, long ldx, int T, int B, int Cin, int winlen, int stride, int pad_lo, int pad_hi,
                          float *cols, slk_stream_t stream);
-int slk_train_col2im_f32(const float *dcols, int T, int B, int Cin, int winlen, int stride, int pad_lo, int pad_hi, float *dx,
+SLK_API int slk_train_col2im_f32(const float *dcols, int T, int B, int Cin, int winlen, int stride, int pad_lo, int pad_hi, float *dx,
                          long lddx, slk_stream_t stream);
-int slk_adamski_update_f32(float *param, const float *grad, float *momentum, float *variance, size_t n, float lr_t,
+SLK_API int slk_adamski_update_f32(float *param, const float *grad, float *momentum, float *variance, size_t n, float lr_t,
                            float momentum_decay, float decay1, float decay2, float epsilon, float clip, float l2,
                            float gscale, slk_stream_t stream);
-int slk_sgd_update_f32(float *param, const float *grad, float *vel, size_t n, float rate, float momentum, float clip,
+SLK_API int slk_sgd_update_f32(float *param, const float *grad, float *vel, size_t n, float rate, float momentum, float clip,
                        float l2, float gscale, slk_stream_t stream);
 
 #ifdef __cplusplus

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libsloika_amd.so")
+#: SLOIKA_AMD_LIB: another build of the same C ABI (tools/build_diag_lib.sh: the diagnostic build the scripts under tools/ use)
+LIB_PATH = os.environ.get("SLOIKA_AMD_LIB") or os.path.join(_HERE, "_build", "libsloika_amd.so")
 
 SLK_OK = 0
 SLK_ERR_INVALID_ARG = -1
@@ -25,6 +26,7 @@ PROTOTYPES = {
     "slk_abi_version": (_i, []),
     "slk_error_string": (C.c_char_p, [_i]),
     "slk_device_count": (_i, []),
+    "slk_selftest_mfma4_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "slk_med_mad_normalise_f32": (_i, [_vp, _i, _i, _vp, _l, _l, _vp, _vp, _vp]),
     "slk_window_std_f32": (_i, [_vp, _i, _i, _vp, _vp]),
     "slk_conv1d_out_len": (_i, [_i, _i, _i, _i, _i]),

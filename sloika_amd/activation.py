@@ -32,6 +32,8 @@ class Activation(object):
 
 
 def _lookup(name):
+    if name not in _NAMES:               # a pickle's reducer: activation functions only, never another global of this module
+        raise ValueError("not an activation function: %r" % (name,))
     return globals()[name]
 
 

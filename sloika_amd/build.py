@@ -18,7 +18,8 @@ OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libsloika_amd.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
-         "-fno-fast-math", "-ffp-contract=off"]
+         "-fno-fast-math", "-ffp-contract=off", "-fvisibility=hidden"]
+# -fvisibility=hidden: the library exports what include/sloika_amd.h declares (SLK_API) and nothing else.
 # IEEE divide/sqrt, no reassociation, and NO implicit fma contraction (hipcc's default is -ffp-contract=fast, and
 # __fmul_rn/__fadd_rn are plain operators in the HIP headers): prepare_post, the normalisation and the DP kernels
 # must round exactly like numpy's float32 evaluation.  Kernels that want fused multiply-adds call fmaf / MFMA.

@@ -16,6 +16,22 @@ static inline int slk_launch_status()
     return e == hipSuccess ? SLK_OK : SLK_ERR_LAUNCH;
 }
 
+// A value derived from per-device state (function attributes set with hipFuncSetAttribute, the CU count ...), evaluated once per
+// HIP device of the calling thread instead of once per process: a process may drive several GPUs.
+#define SLK_MAX_DEVICES 64
+#define SLK_PER_DEVICE(TYPE, EXPR)                                                                 \
+    ([&]() -> TYPE {                                                                               \
+        static TYPE v_[SLK_MAX_DEVICES];                                                           \
+        static unsigned char ok_[SLK_MAX_DEVICES];                                                 \
+        int d_ = 0;                                                                                \
+        if (hipGetDevice(&d_) != hipSuccess || d_ < 0 || d_ >= SLK_MAX_DEVICES) return (EXPR);     \
+        if (!ok_[d_]) {                                                                            \
+            v_[d_] = (EXPR);                                                                       \
+            ok_[d_] = 1;                                                                           \
+        }                                                                                          \
+        return v_[d_];                                                                             \
+    }())
+
 static inline hipStream_t slk_stream(slk_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- activations: sloika/activation.py:8-115 ------------------------------------------------------------
@@ -35,9 +51,15 @@ __device__ __forceinline__ float slk_tanh(float x)
     return fmaf(-2.0f, slk_rcp(e + 1.0f), 1.0f);
 }
 
-// elu's negative branch as exp(x) - 1 through v_exp_f32 (absolute error <= 1 ulp of 1.0 = 6e-8; expm1f's relative accuracy
-// near zero costs ~25 instructions per value, and these outputs feed layers compared at 1e-4 absolute)
-__device__ __forceinline__ float slk_elu(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+// elu's negative branch (activation.py:52-57 uses T.expm1): exp(x) - 1 through v_exp_f32 has an ABSOLUTE error of one ulp of
+// 1.0 (6e-8), i.e. no relative accuracy left for tiny |x| -- and training multiplies by y + 1 and feeds small gradients through
+// it.  Below 2^-10 the two-term series x + x^2/2 is exact to float32 (the next term is < 2e-7 of x); expm1f itself costs ~25
+// instructions per value.
+__device__ __forceinline__ float slk_elu(float x)
+{
+    if (x > 0.0f) return x;
+    return x > -0.0009765625f ? fmaf(0.5f * x, x, x) : __expf(x) - 1.0f;
+}
 
 template <int ACT>
 __device__ __forceinline__ float slk_act_t(float x)

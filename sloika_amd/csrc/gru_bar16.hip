@@ -24,19 +24,24 @@
 
 // Diagnostic instantiation: shader-clock cycles the waves of workgroup 0 spend in each section of a step, summed over the scan
 // (tools/bar16_check.py reads them).  The production instantiation carries none of this.
+// (Diagnostic launches and the readers of these tables exist only in builds with -DSLK_DIAG: tools/build_diag_lib.sh.)
 __device__ unsigned long long slk_dbg_bar16[4][16];
-extern "C" int slk_debug_read_bar16(unsigned long long *host_out)
+#ifdef SLK_DIAG
+extern "C" SLK_API int slk_debug_read_bar16(unsigned long long *host_out)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_bar16), sizeof(unsigned long long) * 64) == hipSuccess ? SLK_OK
                                                                                                                 : SLK_ERR_LAUNCH;
 }
+#endif
 // ABL & 32: every workgroup records where it ran and for how long (shader clock and the 100 MHz wall clock)
 __device__ unsigned long long slk_dbg_bar16_wg[1024][4];
-extern "C" int slk_debug_read_bar16_wg(unsigned long long *host_out)
+#ifdef SLK_DIAG
+extern "C" SLK_API int slk_debug_read_bar16_wg(unsigned long long *host_out)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_bar16_wg), sizeof(unsigned long long) * 4096) == hipSuccess ? SLK_OK
                                                                                                                     : SLK_ERR_LAUNCH;
 }
+#endif
 #define BSTAMP(i)                                                                     \
     if constexpr (DIAG) {                                                             \
         unsigned long long tnow;                                                      \
@@ -688,6 +693,7 @@ template <int I, int N>
 static int launch_bar16(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
                         float *y, long ldy, int T, int B, int reverse, const int *lens, float *zr_out, hipStream_t s)
 {
+#ifdef SLK_DIAG
     if constexpr (I == 96 && N == 96) {
         // diagnostic launches (undocumented bits, tools/bar16_check.py; SLOIKA_AMD_BAR16_DIAG forces one for every launch of a
         // process so that tools/bar16_wg_times.py --pipeline can read the clock the kernel gets inside the whole step)
@@ -695,7 +701,7 @@ static int launch_bar16(const float *x, long ldx, const float *iW, const float *
         const int dv = forced ? forced : reverse >> 1;
 #define DIAG_LAUNCH(CODE, STAMPS, ABLV)                                                                                   \
         if (dv == CODE) {                                                                                                 \
-            static const size_t dyn = exclusive_cu_lds_bar(gru_bar16_kernel<I, N, false, STAMPS, ABLV>);                  \
+            const size_t dyn = SLK_PER_DEVICE(size_t, exclusive_cu_lds_bar(gru_bar16_kernel<I, N, false, STAMPS, ABLV>));                  \
             hipLaunchKernelGGL((gru_bar16_kernel<I, N, false, STAMPS, ABLV>), dim3((B + 3) / 4), dim3(256), dyn, s, x, ldx, \
                                iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, lens, zr_out);                                \
             return slk_launch_status();                                                                                    \
@@ -706,12 +712,13 @@ static int launch_bar16(const float *x, long ldx, const float *iW, const float *
         DIAG_LAUNCH(16, false, 96) DIAG_LAUNCH(17, false, 128) DIAG_LAUNCH(18, false, 160) DIAG_LAUNCH(19, false, 288)
 #undef DIAG_LAUNCH
     }
+#endif
     if (zr_out) {
-        static const size_t dyn = exclusive_cu_lds_bar(gru_bar16_kernel<I, N, true>);
+        const size_t dyn = SLK_PER_DEVICE(size_t, exclusive_cu_lds_bar(gru_bar16_kernel<I, N, true>));
         hipLaunchKernelGGL((gru_bar16_kernel<I, N, true>), dim3((B + 3) / 4), dim3(256), dyn, s, x, ldx, iW, bias, sW, sW2, y,
                            ldy, T, B, reverse & 1, lens, zr_out);
     } else {
-        static const size_t dyn = exclusive_cu_lds_bar(gru_bar16_kernel<I, N, false>);
+        const size_t dyn = SLK_PER_DEVICE(size_t, exclusive_cu_lds_bar(gru_bar16_kernel<I, N, false>));
         hipLaunchKernelGGL((gru_bar16_kernel<I, N, false>), dim3((B + 3) / 4), dim3(256), dyn, s, x, ldx, iW, bias, sW, sW2, y,
                            ldy, T, B, reverse & 1, lens, zr_out);
     }
@@ -733,11 +740,11 @@ static int bar16_auto_plan(int B)
 {
     static const int forced = getenv("SLOIKA_AMD_GRU_DUAL") ? atoi(getenv("SLOIKA_AMD_GRU_DUAL")) : -1;
     if (forced >= 0) return forced == 0 ? 1 : (forced == 1 ? 2 : 4);
-    static const int ncu = [] {
+    const int ncu = SLK_PER_DEVICE(int, ([] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
         return n > 0 ? n : 256;
-    }();
+    }()));
     if ((B + 3) / 4 <= ncu) return 1;
     return (B + 7) / 8 <= ncu ? 2 : 4;
 }

@@ -44,11 +44,13 @@ typedef float f32x2d __attribute__((ext_vector_type(2)));
 #define BAR16D_CACC 0
 #endif
 __device__ unsigned long long slk_dbg_bar16d[4][16];
-extern "C" int slk_debug_read_bar16d(unsigned long long *host_out)
+#ifdef SLK_DIAG                          /* tools/build_diag_lib.sh */
+extern "C" SLK_API int slk_debug_read_bar16d(unsigned long long *host_out)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_bar16d), sizeof(unsigned long long) * 64) == hipSuccess ? SLK_OK
                                                                                                                  : SLK_ERR_LAUNCH;
 }
+#endif
 // DSTAMP_IN(k): about to enter the barrier that opens interval k; DSTAMP_OUT(k): through it
 #define DSTAMP_IN(k)                                                                  \
     if constexpr (BAR16D_ABL & 16) {                                                  \

@@ -37,17 +37,21 @@ __device__ unsigned long long slk_dbg_stamp[16];
         tprev = tnow;                                                                              \
     }
 
-extern "C" int slk_debug_read_stamps(unsigned long long *host_out)
+#ifdef SLK_DIAG                          /* tools/build_diag_lib.sh */
+extern "C" SLK_API int slk_debug_read_stamps(unsigned long long *host_out)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_stamp), sizeof(unsigned long long) * 16) == hipSuccess ? SLK_OK
                                                                                                                 : SLK_ERR_LAUNCH;
 }
+#endif
 
-extern "C" int slk_debug_read_clock(unsigned long long *host_out)
+#ifdef SLK_DIAG                          /* tools/build_diag_lib.sh */
+extern "C" SLK_API int slk_debug_read_clock(unsigned long long *host_out)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_clock), sizeof(unsigned long long) * 2) == hipSuccess ? SLK_OK
                                                                                                                : SLK_ERR_LAUNCH;
 }
+#endif
 
 // DIAG: diagnostic instantiation (per-phase s_memtime stamps, optional skipping of the projection MFMAs); the production
 // instantiation carries none of those branches -- a taken branch costs a lone wave an instruction refetch.
@@ -522,7 +526,7 @@ static int launch_fused(const float *x, long ldx, const float *iW, const float *
             return slk_launch_status();
         }
     }
-    static const size_t dyn_lds = exclusive_cu_lds(gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>);
+    const size_t dyn_lds = SLK_PER_DEVICE(size_t, exclusive_cu_lds(gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>));
     hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false>), dim3((B + 3) / 4), dim3(512), dyn_lds, s,
                        x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, 0, lens,
                        (float *)nullptr);
@@ -533,7 +537,7 @@ template <int I, int N>
 static int launch_fused_train(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
                               float *y, long ldy, float *zr_out, int T, int B, int reverse, hipStream_t s)
 {
-    static const size_t dyn_lds = exclusive_cu_lds(gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false, true>);
+    const size_t dyn_lds = SLK_PER_DEVICE(size_t, exclusive_cu_lds(gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false, true>));
     hipLaunchKernelGGL((gru_fused_kernel<I, N, SLK_ACT_TANH, SLK_ACT_SIGMOID, false, true>), dim3((B + 3) / 4), dim3(512),
                        dyn_lds, s, x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, SLK_ACT_TANH, SLK_ACT_SIGMOID, 0,
                        (const int *)nullptr, zr_out);

@@ -34,11 +34,13 @@
 // the scan (tools/bench_kernels.py --what gruf16 reads them).  The production instantiation carries none of this.
 __device__ unsigned long long slk_dbg_stamp16[16];
 __device__ unsigned long long slk_dbg_pstamp16[8][8];          // projection waves of workgroup 0: cycles per section
-extern "C" int slk_debug_read_pstamps16(unsigned long long *host_out)
+#ifdef SLK_DIAG                          /* tools/build_diag_lib.sh */
+extern "C" SLK_API int slk_debug_read_pstamps16(unsigned long long *host_out)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_pstamp16), sizeof(unsigned long long) * 64) == hipSuccess ? SLK_OK
                                                                                                                    : SLK_ERR_LAUNCH;
 }
+#endif
 #define PSTAMP(i)                                                                     \
     if constexpr (DIAG) {                                                             \
         unsigned long long tnow;                                                      \
@@ -48,11 +50,13 @@ extern "C" int slk_debug_read_pstamps16(unsigned long long *host_out)
         pacc[i] += tnow - ptprev;                                                     \
         ptprev = tnow;                                                                \
     }
-extern "C" int slk_debug_read_stamps16(unsigned long long *host_out)
+#ifdef SLK_DIAG                          /* tools/build_diag_lib.sh */
+extern "C" SLK_API int slk_debug_read_stamps16(unsigned long long *host_out)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_stamp16), sizeof(unsigned long long) * 16) == hipSuccess ? SLK_OK
                                                                                                                   : SLK_ERR_LAUNCH;
 }
+#endif
 #define STAMP16(i)                                                                    \
     if constexpr (DIAG) {                                                             \
         unsigned long long tnow;                                                      \
@@ -655,7 +659,7 @@ static int launch_fused16(const float *x, long ldx, const float *iW, const float
         const int dv = reverse >> 1;                    // diagnostic launches (undocumented bits, tools/bench_kernels.py)
 #define DIAG_LAUNCH(CODE, STAMPS, ABLV)                                                                                   \
         if (dv == CODE) {                                                                                                 \
-            static const size_t dyn = exclusive_cu_lds16(gru_fused16_kernel<I, N, false, STAMPS, ABLV>);                  \
+            const size_t dyn = SLK_PER_DEVICE(size_t, exclusive_cu_lds16(gru_fused16_kernel<I, N, false, STAMPS, ABLV>));                  \
             hipLaunchKernelGGL((gru_fused16_kernel<I, N, false, STAMPS, ABLV>), dim3((B + 3) / 4), dim3(512), dyn, s, x, ldx, \
                                iW, bias, sW, sW2, y, ldy, T, B, reverse & 1, lens, zr_out);                                \
             return slk_launch_status();                                                                                    \
@@ -665,11 +669,11 @@ static int launch_fused16(const float *x, long ldx, const float *iW, const float
 #undef DIAG_LAUNCH
     }
     if (zr_out) {
-        static const size_t dyn = exclusive_cu_lds16(gru_fused16_kernel<I, N, true>);
+        const size_t dyn = SLK_PER_DEVICE(size_t, exclusive_cu_lds16(gru_fused16_kernel<I, N, true>));
         hipLaunchKernelGGL((gru_fused16_kernel<I, N, true>), dim3((B + 3) / 4), dim3(512), dyn, s, x, ldx, iW, bias, sW, sW2, y,
                            ldy, T, B, reverse & 1, lens, zr_out);
     } else {
-        static const size_t dyn = exclusive_cu_lds16(gru_fused16_kernel<I, N, false>);
+        const size_t dyn = SLK_PER_DEVICE(size_t, exclusive_cu_lds16(gru_fused16_kernel<I, N, false>));
         hipLaunchKernelGGL((gru_fused16_kernel<I, N, false>), dim3((B + 3) / 4), dim3(512), dyn, s, x, ldx, iW, bias, sW, sW2, y,
                            ldy, T, B, reverse & 1, lens, zr_out);
     }

@@ -269,7 +269,7 @@ extern "C" int slk_gru_scan16_f32(const float *vI, long ldv, const float *sW, co
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
     if (n % 16 || n <= 96 || n > 128) return SLK_ERR_UNSUPPORTED;
     if ((unsigned long long)T * B * ldv * sizeof(float) >= (1ull << 32)) return SLK_ERR_UNSUPPORTED;       // 32-bit lane offsets
-    static const size_t dyn = scan16_exclusive_lds();
+    const size_t dyn = SLK_PER_DEVICE(size_t, scan16_exclusive_lds());
     hipLaunchKernelGGL((gru_scan16_kernel<128>), dim3((B + 3) / 4), dim3(256), dyn, slk_stream(stream), vI, ldv, sW, sW2, y, ldy, T, B, n,
                        reverse & 1, lens);
     return slk_launch_status();

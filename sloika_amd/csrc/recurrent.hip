@@ -439,7 +439,7 @@ extern "C" int slk_lstm_f32(const float *x, long ldx, const float *iW, const flo
 }
 
 // =====================================================================================================
-// Hardware-layout probe for v_mfma_f32_4x4x1_16b_f32 (used by tests/test_gpu_mfma_probe.py): returns the raw
+// Device self-test (include/sloika_amd.h): hardware-layout probe for v_mfma_f32_4x4x1_16b_f32 (tests/test_gpu_mfma_probe.py): returns the raw
 // accumulator so that the operand/broadcast assumptions of gru_mfma_kernel are checked on the device.
 // =====================================================================================================
 template <int CB, int AB>
@@ -450,7 +450,7 @@ __global__ void mfma4_probe_kernel(const float *a, const float *b, float *d)
     for (int i = 0; i < 4; i++) d[i * 64 + threadIdx.x] = c[i];
 }
 
-extern "C" int slk_debug_mfma4_probe(const float *a, const float *b, float *d, int cbsz, int abid, slk_stream_t stream)
+extern "C" int slk_selftest_mfma4_f32(const float *a, const float *b, float *d, int cbsz, int abid, slk_stream_t stream)
 {
     hipStream_t s = slk_stream(stream);
 #define PROBE(CB, AB)                                                                              \

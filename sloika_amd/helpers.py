@@ -59,6 +59,32 @@ _ALLOWED_GLOBALS = {
 }
 
 
+#: modules of this package (and, through compat, of `sloika`) whose classes / functions a model pickle may name
+_MODEL_MODULES = ("layers", "activation")
+
+
+def _model_global(module, name):
+    """Resolve `module.name` for a sloika / sloika_amd global of a model pickle: only layer classes (and the Shared leaf)
+    of sloika_amd.layers and the activation functions (and their `_lookup` reducer) of sloika_amd.activation.  Dotted names
+    are refused outright: protocol >= 4 resolves them attribute by attribute, which would reach `sloika_amd.build.subprocess`
+    or `sloika_amd._lib.os` -- any module a module of this package happens to import."""
+    from . import activation
+    if "." in name:
+        raise pickle.UnpicklingError("model file names the dotted global %s.%s; refusing to load it" % (module, name))
+    top, _, sub = module.partition(".")
+    if top not in ("sloika", "sloika_amd") or sub not in _MODEL_MODULES:
+        raise pickle.UnpicklingError("model file names %s.%s: only layers and activations may come from %s" % (module, name, top))
+    obj = getattr(layers if sub == "layers" else activation, name, None)
+    if sub == "layers":
+        ok = isinstance(obj, type) and obj.__module__ == layers.__name__ and (issubclass(obj, layers.Layer) or obj is layers.Shared)
+    else:
+        ok = obj is not None and (obj is activation._lookup or (callable(obj) and name in activation._NAMES))
+    if not ok:
+        raise pickle.UnpicklingError("model file names %s.%s, which is not a layer class or an activation function; refusing "
+                                     "to load it" % (module, name))
+    return obj
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module == "theano" or module.startswith("theano."):
@@ -66,12 +92,9 @@ class _Unpickler(pickle.Unpickler):
                 raise pickle.UnpicklingError(
                     "this file holds a COMPILED Theano function (sloika/helpers.py:40-47 output); it is not "
                     "portable -- pass the model pickle (a sloika.layers object) instead")
-            return type(name, (_Holder,), {"__module__": module})
-        if module == "sloika" or module.startswith("sloika."):
-            compat.install()
-            return super().find_class(module, name)
-        if module == "sloika_amd" or module.startswith("sloika_amd."):
-            return super().find_class(module, name)
+            return type(str(name).replace(".", "_"), (_Holder,), {"__module__": module})
+        if module in ("sloika", "sloika_amd") or module.startswith("sloika.") or module.startswith("sloika_amd."):
+            return _model_global(module, name)
         if (module, name) in _ALLOWED_GLOBALS:
             return super().find_class(module, name)
         raise pickle.UnpicklingError("model file names the global %s.%s, which a sloika model does not need; refusing to "

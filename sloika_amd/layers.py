@@ -113,13 +113,21 @@ RECURRENT_F16 = os.environ.get("SLOIKA_AMD_RECURRENT_F32", "0") != "1"
 GRU_PLAN = os.environ.get("SLOIKA_AMD_GRU_PLAN", "bar")
 
 
-#: bits 8-9 of the `reverse` argument of slk_gru_bar16_f32 (0 = plan by batch size, 2 / 3 = eight / sixteen chunks per workgroup): set by
-#: Parallel while it runs the directions of a birnn side by side at a batch where only the eight-chunk plan lets them share the chip
-_GRU_PLAN_BITS = 0
-#: batches the caller keeps in flight on streams of their own (pipeline.Basecaller(in_flight=N) sets it around a forward pass): a
-#: recurrent layer then counts N times its workgroups when it decides whether they fit the device's CUs together.  (Both are
-#: process-wide, like the reference's module-level Theano configuration: one Python thread issues the launches of a process.)
-_IN_FLIGHT = 1
+class _PlanHints(__import__("threading").local):
+    """Execution-plan hints of the forward pass that is running ON THIS HOST THREAD (a Basecaller per thread may run with its
+    own `in_flight`: two threads no longer race on a module global).  Results never depend on them, only speed.
+
+    gru_plan_bits  bits 8-9 of the `reverse` argument of slk_gru_bar16_f32 (0 = plan by batch size, 2 / 3 = eight / sixteen
+                   chunks per workgroup): set by Parallel while it runs the directions of a birnn side by side at a batch where
+                   only the eight-chunk plan lets them share the chip
+    in_flight      batches the caller keeps in flight on streams of their own (pipeline.Basecaller(in_flight=N) sets it around
+                   a forward pass): a recurrent layer then counts N times its workgroups when it decides whether they fit the
+                   device's CUs together"""
+    gru_plan_bits = 0
+    in_flight = 1
+
+
+_HINTS = _PlanHints()
 
 
 def _gru_plan_for(B, share, ncu):
@@ -821,20 +829,21 @@ class Gru(RNN):
     def _plan_bits(x, B):
         """Bits 8-9 of `reverse` for slk_gru_bar16_f32: what Parallel decided for its side-by-side sub-layers, else eight chunks
         per workgroup when that is what lets the batches in flight share the chip."""
-        if _GRU_PLAN_BITS or _IN_FLIGHT <= 1:
-            return _GRU_PLAN_BITS
+        if _HINTS.gru_plan_bits or _HINTS.in_flight <= 1:
+            return _HINTS.gru_plan_bits
         import torch
-        return _gru_plan_for(B, _IN_FLIGHT, torch.cuda.get_device_properties(x.device).multi_processor_count)
+        return _gru_plan_for(B, _HINTS.in_flight, torch.cuda.get_device_properties(x.device).multi_processor_count)
 
     def _padded(self):
         """Zero-padded copy of this layer with input and output sizes rounded up to multiples of 16 (what the MFMA
         kernels are instantiated for).  Padding neurons see zero weights and zero bias, so their state stays exactly 0
         (h0 = 0, candidate = fun(0) = 0 for tanh-like fun) and padded input columns multiply zero weights: the first
         `size` outputs are those of the unpadded layer.  Cached until a parameter changes."""
-        # the cache holds the device tensors themselves (an id() of a freed tensor can be reused by its successor)
-        key = tuple(p.dev() for p in (self.iW, self.sW, self.sW2, self.b))
+        # the cache holds the device tensors themselves (an id() of a freed tensor can be reused by its successor) and the
+        # parameters' versions (set_value on a buffer the optimiser owns writes in place: same tensor, new contents)
+        key = tuple((p.dev(), getattr(p, "_version", 0)) for p in (self.iW, self.sW, self.sW2, self.b))
         cache = getattr(self, "_pad_cache", None)
-        if cache is not None and all(a is b for a, b in zip(cache[0], key)):
+        if cache is not None and all(a[0] is b[0] and a[1] == b[1] for a, b in zip(cache[0], key)):
             return cache[1]
         n, i = self.size, self.insize
         n16, i16 = (n + 15) // 16 * 16, (i + 15) // 16 * 16
@@ -1037,9 +1046,8 @@ class Parallel(Layer):
             main = torch.cuda.current_stream(x.device)
             ready = torch.cuda.Event()
             ready.record(main)
-            global _GRU_PLAN_BITS
-            keep = _GRU_PLAN_BITS
-            _GRU_PLAN_BITS = self._side_plan
+            keep = _HINTS.gru_plan_bits
+            _HINTS.gru_plan_bits = self._side_plan
             try:
                 for i, layer in enumerate(self.layers):
                     st = main if i == 0 else streams[i - 1]
@@ -1053,7 +1061,7 @@ class Parallel(Layer):
                         main.wait_event(done)
                     off += layer.size
             finally:
-                _GRU_PLAN_BITS = keep
+                _HINTS.gru_plan_bits = keep
             return outs
         cat = torch.cat([layer._forward(x, None, reverse) for layer in self.layers], dim=2)
         if out is not None:
@@ -1075,7 +1083,7 @@ class Parallel(Layer):
                 return None
         ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
         self._side_plan = 0
-        share = len(self.layers) * max(1, _IN_FLIGHT)
+        share = len(self.layers) * max(1, _HINTS.in_flight)
         if ((B + 3) // 4) * share > ncu:
             # too many four-chunk workgroups to run together; eight chunks per workgroup (csrc/gru_bar16d.hip: 1.4 x the step
             # time for twice the chunks) may still let the directions share the chip: B = 1024, two directions -> 2 x 128

@@ -34,6 +34,9 @@ class Basecaller(object):
         self.kmer_len, self.nbase, self.min_prob, self.skip = kmer_len, nbase, min_prob, skip
         self.normalisation = normalisation
         self.in_flight = max(1, int(in_flight))
+        if self.in_flight > 2:
+            from . import device as D
+            D.want_hw_queues(4 * self.in_flight)
         self.fused_decode = FUSED_DECODE if fused_decode is None else bool(fused_decode)
         self._ws = decode.ViterbiWorkspace()
         _lib.lib()
@@ -55,13 +58,13 @@ class Basecaller(object):
         else:
             x = batch.normalise_chunks(cd, self.normalisation, out_layout='network')
             rest = seq[:upto]
-        keep = layers._IN_FLIGHT
-        layers._IN_FLIGHT = self.in_flight
+        keep = layers._HINTS.in_flight                   # (thread local: one forward pass per host thread at a time)
+        layers._HINTS.in_flight = self.in_flight
         try:
             for layer in rest:
                 x = layer._forward(x, None, False)
         finally:
-            layers._IN_FLIGHT = keep
+            layers._HINTS.in_flight = keep
         return x
 
     def posteriors(self, chunks):

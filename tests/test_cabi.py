@@ -30,6 +30,17 @@ def test_header_symbols_exported(built):
     assert not missing, "declared in include/sloika_amd.h but not exported: %s" % missing
 
 
+def test_library_exports_nothing_but_the_header(built):
+    """-fvisibility=hidden + SLK_API: the dynamic symbol table holds the declared entry points and no other slk_* name."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", built], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r"\b(slk_[A-Za-z0-9_]+)\b", out)))
+    assert exported == _declared()
+    others = [ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[1] in ("T", "t", "D", "B")
+              and not ln.split()[-1].startswith(("slk_", "_Z", "__hip", "_fini", "_init", "__"))]
+    assert not others, others
+
+
 def test_python_prototypes_cover_header(built):
     from sloika_amd import _lib
     assert sorted(_lib.PROTOTYPES) == _declared()

@@ -200,3 +200,18 @@ def test_raw_read_worker_whole_read(oracle):
     same = sum(a == b for a, b in zip(res[2], o_call))
     assert len(res[2]) == len(o_call) and same >= 0.99 * len(o_call)
     assert basecall.raw_read_worker(net.compile(), sig[:205], trim=(200, 10)) is None
+
+
+def test_elu_keeps_relative_accuracy_near_zero():
+    """activation.elu = expm1 on the negative side (sloika/activation.py:52-57).  exp(x) - 1 through the hardware exponential
+    is only accurate to an ulp of 1.0; tiny pre-activations (and the gradients that pass through y + 1 in training) need the
+    relative accuracy of expm1."""
+    need_gpu()
+    from sloika_amd import activation
+    x = -np.logspace(-9, 1, 400).astype(np.float32)
+    y = activation.elu(x)
+    ref = np.expm1(x.astype(np.float64))
+    assert np.abs(y - ref).max() < 1.5e-7
+    small = np.abs(x) < 1e-3
+    assert (np.abs(y[small] - ref[small]) / np.abs(ref[small])).max() < 1e-6
+    assert np.array_equal(activation.elu(np.array([0.0, 2.5, 1e-8], dtype=np.float32)), np.array([0.0, 2.5, 1e-8], dtype=np.float32))

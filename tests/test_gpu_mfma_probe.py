@@ -14,7 +14,7 @@ def _probe(a, b, cbsz, abid):
     torch = need_gpu()
     from sloika_amd import _lib
     L = _lib.lib()
-    fn = L.slk_debug_mfma4_probe
+    fn = L.slk_selftest_mfma4_f32
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     d = torch.zeros(256, dtype=torch.float32, device="cuda")

@@ -229,3 +229,26 @@ def test_in_flight_hint_changes_the_plan_not_the_result():
     s1, p1, l1 = pipeline.Basecaller(net).call_chunks(chunks)
     s4, p4, l4 = pipeline.Basecaller(net, in_flight=4).call_chunks(chunks)
     assert torch.equal(p1, p4) and torch.equal(l1, l4) and torch.equal(s1, s4)
+
+
+def test_first_calls_on_two_streams_without_warm_up():
+    """Two Basecallers sharing one network, each on a stream of its own, first calls issued back to back with nothing warmed
+    up: the device caches derived from the weights (fp16 splits, packed softmax weights, padded twins) are built on the
+    stream of the first caller, and the second stream must wait for them (layers._derived_cache records an event)."""
+    torch = need_gpu()
+    from sloika_amd import models, pipeline
+    for name, B in (("raw_0.98_rgrgr", 64), ("raw_1.00_rGr", 8), ("baseline_raw_gru", 32)):
+        chunks = dev(pipeline.synthetic_chunks(B, chunk_len=2000, seed=31))
+        net_ref = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=41))
+        ref = pipeline.Basecaller(net_ref).call_chunks(chunks)
+        torch.cuda.synchronize()
+        net = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=41))     # same weights, cold caches
+        bcs = [pipeline.Basecaller(net, in_flight=2) for _ in range(2)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = []
+        for k in range(2):
+            with torch.cuda.stream(streams[k]):
+                outs.append(bcs[k].call_chunks(chunks))
+        torch.cuda.synchronize()
+        for got in outs:
+            assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]) and torch.equal(got[0], ref[0]), name

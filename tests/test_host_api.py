@@ -176,3 +176,35 @@ def test_model_unpickler_refuses_code_execution(tmp_path):
     with pytest.raises(pickle.UnpicklingError):
         helpers.load_pickle(str(p))
     assert not (tmp_path / "pwned").exists()
+
+
+def test_model_unpickler_refuses_dotted_and_foreign_package_globals(tmp_path):
+    """Protocol >= 4 resolves a dotted global attribute by attribute: ('sloika_amd.build', 'subprocess.getoutput') would reach
+    any module this package imports.  Dotted names, modules other than layers / activation, and objects of those modules that
+    are not layer classes or activation functions are all refused; the legitimate globals still load."""
+    import io
+    import pickle
+    import pickletools  # noqa: F401
+    from sloika_amd import helpers, layers
+
+    def crafted(module, name, arg):
+        # PROTO 4, SHORT_BINUNICODE module, SHORT_BINUNICODE name, STACK_GLOBAL, SHORT_BINUNICODE arg, TUPLE1, REDUCE, STOP
+        def su(x):
+            b = x.encode()
+            return b"\x8c" + bytes([len(b)]) + b
+        return b"\x80\x04" + su(module) + su(name) + b"\x93" + su(arg) + b"\x85R."
+
+    marker = tmp_path / "pwned"
+    for module, name in (("sloika_amd.build", "subprocess.getoutput"), ("sloika_amd._lib", "os.system"),
+                         ("sloika.layers", "os.system"), ("sloika_amd.layers", "np.load"), ("sloika_amd.build", "build"),
+                         ("sloika_amd.layers", "reduce"), ("sloika_amd.activation", "np"), ("sloika_amd.helpers", "load_pickle")):
+        with pytest.raises(pickle.UnpicklingError):
+            helpers._Unpickler(io.BytesIO(crafted(module, name, "touch %s" % marker))).load()
+    assert not marker.exists()
+    with pytest.raises(ValueError):
+        helpers._Unpickler(io.BytesIO(crafted("sloika_amd.activation", "_lookup", "np"))).load()
+    # what model files do name
+    assert helpers._Unpickler(io.BytesIO(crafted("sloika_amd.activation", "_lookup", "tanh"))).load().__name__ == "tanh"
+    net = layers.Serial([layers.FeedForward(4, 3, has_bias=True, fun=__import__("sloika_amd").activation.tanh), layers.Softmax(3, 5)])
+    clone = helpers._Unpickler(io.BytesIO(pickle.dumps(net, protocol=4))).load()
+    assert isinstance(clone, layers.Serial) and clone.layers[0].fun.__name__ == "tanh"
