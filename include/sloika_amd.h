@@ -74,6 +74,10 @@ SLK_API int slk_device_count(void);
 /* Device self-test: one v_mfma_f32_4x4x1_16b_f32 on 64 lanes, a[lane], b[lane] -> d[4][64], with the CBSZ / ABID broadcast
  * modifiers the exact-fp32 recurrent kernels rely on (cbsz, abid in {(0,0), (4,0), (4,3), (4,15), (3,0), (3,5), (2,1), (2,3)}):
  * lets an integrator confirm on the installed device the operand layout those kernels assume.                              */
+/* Measurement aid: the shader clock the device holds at the moment the probe runs.  One wave reads the shader-cycle counter and
+ * the constant 100 MHz counter around `spins` x 127 sleep quanta; out2[0] / out2[1] x 100 = MHz (device memory, two uint64).
+ * Launched on a stream of its own beside a running workload it reports the clock under that load (bench.py `sustained`).     */
+SLK_API int slk_clock_probe(unsigned long long *out2, int spins, slk_stream_t stream);
 SLK_API int slk_selftest_mfma4_f32(const float *a, const float *b, float *d, int cbsz, int abid, slk_stream_t stream);
 
 /* Elementwise activation y[i] = act(x[i]) (sloika/activation.py); in place allowed (y == x).                 */
@@ -95,6 +99,13 @@ SLK_API int slk_activation_f32(const float *x, float *y, size_t count, int act, 
 SLK_API int slk_med_mad_normalise_f32(const float *signal, int nchunk, int chunk_len, float *out,
                               long out_chunk_stride, long out_sample_stride, float *med_out, float *mad_out,
                               slk_stream_t stream);
+/* The same per READ for a batch of whole reads of different lengths (sloika/basecall.py:117-118 normalises a read over its own
+ * length): read r is lens[r] samples at signal + r*in_stride; element (r, i), i < lens[r], goes to
+ * out[r*out_chunk_stride + i*out_sample_stride]; nothing else is written (the caller zero-fills a padded batch).  Exact order
+ * statistics by radix selection, any length >= 1; bit-identical to slk_med_mad_normalise_f32 on each read alone.            */
+SLK_API int slk_med_mad_normalise_ragged_f32(const float *signal, int nread, long in_stride, const int32_t *lens, float *out,
+                                             long out_chunk_stride, long out_sample_stride, float *med_out, float *mad_out,
+                                             slk_stream_t stream);
 /* Standard deviation of each of nwin consecutive windows of `win` samples (population form, numpy's .std()):
  * batch.trim_open_pore(var_method='std'), sloika/batch.py:210-211.  out:[nwin].                                    */
 SLK_API int slk_window_std_f32(const float *signal, int nwin, int win, float *out, slk_stream_t stream);

@@ -26,8 +26,10 @@ PROTOTYPES = {
     "slk_abi_version": (_i, []),
     "slk_error_string": (C.c_char_p, [_i]),
     "slk_device_count": (_i, []),
+    "slk_clock_probe": (_i, [_vp, _i, _vp]),
     "slk_selftest_mfma4_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "slk_med_mad_normalise_f32": (_i, [_vp, _i, _i, _vp, _l, _l, _vp, _vp, _vp]),
+    "slk_med_mad_normalise_ragged_f32": (_i, [_vp, _i, _l, _vp, _vp, _l, _l, _vp, _vp, _vp]),
     "slk_window_std_f32": (_i, [_vp, _i, _i, _vp, _vp]),
     "slk_conv1d_out_len": (_i, [_i, _i, _i, _i, _i]),
     "slk_conv1d_f32": (_i, [_vp, _l, _l, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

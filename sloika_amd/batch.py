@@ -102,6 +102,50 @@ def trim_open_pore(signal, max_op_fraction=0.3, var_method='mad', window_size=10
     return signal[first_win * window_size: (last_win + 1) * window_size]
 
 
+def trim_open_pore_many(signals, max_op_fraction=0.3, var_method='mad', window_size=100):
+    """trim_open_pore for a list of reads with ONE device call: the windows of all reads are concatenated, their MADs (or
+    standard deviations) computed together, and the percentile threshold + slicing done per read on the host exactly as in
+    trim_open_pore (sloika/batch.py:194-220).  Returns a list of views of the inputs."""
+    import torch
+    from . import device as D
+    assert var_method in TRIM_OPEN_PORE_LOCAL_VAR_METHODS, "var_method not understood: {}".format(var_method)
+    sigs = [np.asarray(s, dtype=np.float32) for s in signals]
+    nwin = [len(s) // window_size for s in sigs]
+    if min(nwin) < 1:
+        raise ValueError("a read is shorter than one window of %d samples" % window_size)
+    allw = np.concatenate([s[:n * window_size] for s, n in zip(sigs, nwin)]).reshape(-1, window_size)
+    wd = D.to_dev(allw)
+    if var_method == 'mad':
+        _, _, spread = normalise_chunks(wd, 'per-chunk', return_stats=True)
+    else:
+        spread = torch.empty((wd.shape[0],), dtype=torch.float32, device=wd.device)
+        _lib.check(_lib.lib().slk_window_std_f32(wd.data_ptr(), wd.shape[0], window_size, spread.data_ptr(), D.stream_ptr()),
+                   "window_std")
+    spread = spread.cpu().numpy()
+    out, lo = [], 0
+    for s, n in zip(sigs, nwin):
+        sp = spread[lo:lo + n]
+        lo += n
+        lively = np.flatnonzero(sp > np.percentile(sp, 100 * max_op_fraction))
+        out.append(s[int(lively[0]) * window_size: (int(lively[-1]) + 1) * window_size])
+    return out
+
+
+def normalise_reads_ragged(padded, lengths):
+    """Median/MAD normalisation of whole reads of different lengths over their OWN lengths (sloika/basecall.py:117-118) in one
+    launch: `padded` is a [B, Lmax] float32 device tensor (read b in its first lengths[b] samples), `lengths` an int32 device
+    tensor [B].  -> [Lmax, B, 1] network layout, zero behind every read's end."""
+    import torch
+    from . import device as D
+    B, lmax = padded.shape
+    out = torch.zeros((lmax, B, 1), dtype=torch.float32, device=padded.device)
+    with profiler.region("normalise", 0.0, 8.0 * B * lmax):
+        rc = _lib.lib().slk_med_mad_normalise_ragged_f32(padded.data_ptr(), B, padded.stride(0), lengths.data_ptr(), out.data_ptr(),
+                                                         1, B, None, None, D.stream_ptr())
+    _lib.check(rc, "normalise_reads_ragged")
+    return out
+
+
 def chunks_to_network_input(chunks):
     """[ml, chunk_len] -> [chunk_len, ml, 1] (the transpose of bin/train_network.py:304)."""
     import torch

@@ -160,6 +160,40 @@ __global__ void __launch_bounds__(1024) med_mad_radix_kernel(const float *__rest
     }
 }
 
+// Whole reads of DIFFERENT lengths, one workgroup each: read r is lens[r] samples at signal + r * in_stride; only its own samples
+// are written (a padded batch keeps the zeros the caller put behind them).
+__global__ void __launch_bounds__(1024) med_mad_radix_ragged_kernel(const float *__restrict__ signal, long in_stride,
+                                                                    const int *__restrict__ lens, float *__restrict__ out,
+                                                                    long out_chunk_stride, long out_sample_stride,
+                                                                    float *__restrict__ med_out, float *__restrict__ mad_out)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh[2];
+    const int c = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const int n = lens[c];
+    if (n < 1) return;
+    const float *sig = signal + (size_t)c * in_stride;
+    const float med = radix_median<false>(sig, n, 0.0f, hist, sh);
+    const float mad = 1.4826f * radix_median<true>(sig, n, med, hist, sh);
+    float *o = out + (size_t)c * out_chunk_stride;
+    for (int i = tid; i < n; i += nt) o[(size_t)i * out_sample_stride] = (sig[i] - med) / mad;
+    if (tid == 0) {
+        if (med_out) med_out[c] = med;
+        if (mad_out) mad_out[c] = mad;
+    }
+}
+
+extern "C" int slk_med_mad_normalise_ragged_f32(const float *signal, int nread, long in_stride, const int32_t *lens, float *out,
+                                                long out_chunk_stride, long out_sample_stride, float *med_out, float *mad_out,
+                                                slk_stream_t stream)
+{
+    if (!signal || !out || !lens || nread < 0 || in_stride < 1) return SLK_ERR_INVALID_ARG;
+    if (nread == 0) return SLK_OK;
+    hipLaunchKernelGGL(med_mad_radix_ragged_kernel, dim3(nread), dim3(1024), 0, slk_stream(stream), signal, in_stride, lens, out,
+                       out_chunk_stride, out_sample_stride, med_out, mad_out);
+    return slk_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Chunks of up to 4096 samples (the basecaller's 4000-sample chunks): no sort at all.  Each of 256 threads keeps 16 samples
 // in registers as order-preserving integer keys; the wanted order statistic is built from its most significant bit down,

@@ -114,28 +114,30 @@ class Basecaller(object):
         scores, paths, lens = self.call_chunks(chunks)
         return scores, bio.paths_to_bases(paths, lens, self.kmer_len, alphabet, always_move=True)
 
-    def call_reads(self, signals, trim=(0, 0), open_pore_fraction=0.0):
-        """Whole reads of different lengths in ONE batch (the reference calls them one at a time, basecall.py:88-121):
-        `signals` is a list of 1-D float arrays (already scaled, e.g. fast5.Fast5.get_read()); each is trimmed as raw_worker does, median/MAD
-        normalised over its own length, zero-padded to the longest, and the network + decoder run on the padded batch
-        with per-read lengths (layers.ragged), so every read gets exactly what a batch-1 call would give.
-        -> device tensors (scores [B], paths [B, T'max] (-1 padded), lens [B]) and the per-read sample counts."""
-        import torch
-        from . import device as D, util
-        net = self.network
-        if not isinstance(net, layers.Serial) or type(net.layers[-1]) is not layers.Softmax:
-            raise ValueError("call_reads needs a Serial network ending in a Softmax layer")
-        # basecall.py:111-112: trim_open_pore (which also cuts the read to whole 100-sample windows), then trim_array
-        sigs = [util.trim_array(np.asarray(batch.trim_open_pore(np.asarray(s, dtype=np.float32), open_pore_fraction)), *trim)
-                for s in signals]
-        nsamp = [len(s) for s in sigs]
-        if min(nsamp) < 1:
+    def _trim_reads(self, signals, trim, open_pore_fraction):
+        """basecall.py:111-112: trim_open_pore (which also cuts the read to whole 100-sample windows), then trim_array."""
+        from . import util
+        sigs = batch.trim_open_pore_many(signals, open_pore_fraction)
+        sigs = [util.trim_array(s, *trim) for s in sigs]
+        if min(len(s) for s in sigs) < 1:
             raise ValueError("empty read after trimming")
+        return sigs
+
+    def _call_trimmed(self, sigs):
+        """One padded batch of trimmed reads (host float32 arrays): pack, upload, per-read normalisation, network and decoder
+        with per-read lengths.  -> (scores, paths, lens) on the device."""
+        import torch
+        from . import device as D
+        net = self.network
+        nsamp = [len(s) for s in sigs]
         B, lmax = len(sigs), max(nsamp)
-        x = torch.zeros((lmax, B, 1), dtype=torch.float32, device=D.device())
-        for b, sig in enumerate(sigs):                       # per-read normalisation (basecall.py:117-118)
-            x[:nsamp[b], b:b + 1, :] = batch.normalise_chunks(D.to_dev(sig).reshape(1, -1), 'per-chunk', out_layout='network')
+        host = torch.zeros((B, lmax), dtype=torch.float32).pin_memory() if B * lmax >= (1 << 20) else torch.zeros((B, lmax))
+        hv = host.numpy()
+        for b, sig in enumerate(sigs):
+            hv[b, :nsamp[b]] = sig
+        padded = host.to(D.device(), non_blocking=True)
         with layers.ragged(nsamp) as ctx:
+            x = batch.normalise_reads_ragged(padded, ctx.lengths)      # per-read normalisation (basecall.py:117-118)
             hid = x
             for layer in net.layers[:-1]:
                 hid = layer._forward(hid, None, False)
@@ -145,14 +147,82 @@ class Basecaller(object):
                 logits, stats, ld = net.layers[-1].logits_and_stats(hid)
         T = hid.shape[0]
         if pack is not None:
-            scores, paths, lens = decode.viterbi_fused_batch(hid, pack, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
-                                                             min_prob=self.min_prob, workspace=self._ws,
-                                                             lengths=lengths.contiguous())
-        else:
-            scores, paths, lens = decode.viterbi_logits_batch(logits, stats, self.kmer_len, T, B, ld=ld, skip_pen=self.skip,
-                                                              nbase=self.nbase, min_prob=self.min_prob, workspace=self._ws,
-                                                              lengths=lengths.contiguous())
-        return scores, paths, lens, nsamp
+            return decode.viterbi_fused_batch(hid, pack, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
+                                              min_prob=self.min_prob, workspace=self._ws, lengths=lengths.contiguous())
+        return decode.viterbi_logits_batch(logits, stats, self.kmer_len, T, B, ld=ld, skip_pen=self.skip, nbase=self.nbase,
+                                           min_prob=self.min_prob, workspace=self._ws, lengths=lengths.contiguous())
+
+    def call_reads(self, signals, trim=(0, 0), open_pore_fraction=0.0):
+        """Whole reads of different lengths in ONE batch (the reference calls them one at a time, basecall.py:88-121):
+        `signals` is a list of 1-D float arrays (already scaled, e.g. fast5.Fast5.get_read()); each is trimmed as raw_worker does, median/MAD
+        normalised over its own length, zero-padded to the longest, and the network + decoder run on the padded batch
+        with per-read lengths (layers.ragged), so every read gets exactly what a batch-1 call would give.
+        -> device tensors (scores [B], paths [B, T'max] (-1 padded), lens [B]) and the per-read sample counts."""
+        net = self.network
+        if not isinstance(net, layers.Serial) or type(net.layers[-1]) is not layers.Softmax:
+            raise ValueError("call_reads needs a Serial network ending in a Softmax layer")
+        sigs = self._trim_reads(signals, trim, open_pore_fraction)
+        scores, paths, lens = self._call_trimmed(sigs)
+        return scores, paths, lens, [len(s) for s in sigs]
+
+    @staticmethod
+    def length_buckets(nsamp, max_batch=256, max_waste=0.08):
+        """Group read indices into batches of similar length: reads sorted by length, a batch closed when it holds `max_batch`
+        reads or when padding every member to the longest would waste more than `max_waste` of the batch's steps.  -> list of
+        index lists (longest reads first: the big batches start while the host still packs the small ones)."""
+        order = sorted(range(len(nsamp)), key=lambda i: -nsamp[i])
+        buckets, cur = [], []
+        for i in order:
+            if cur:
+                lmax = nsamp[cur[0]]
+                used = sum(nsamp[j] for j in cur) + nsamp[i]
+                if len(cur) >= max_batch or 1.0 - used / float(lmax * (len(cur) + 1)) > max_waste:
+                    buckets.append(cur)
+                    cur = []
+            cur.append(i)
+        if cur:
+            buckets.append(cur)
+        return buckets
+
+    @classmethod
+    def call_reads_bucketed(cls, network, signals, trim=(0, 0), open_pore_fraction=0.0, max_batch=256, max_waste=0.08, in_flight=2,
+                            **kwargs):
+        """Whole-read mode for MANY reads (what bin/basecall_network.py does with a pool of workers, basecall_network.py:100-104):
+        reads are bucketed by length (length_buckets), every bucket is one padded ragged batch, and the buckets alternate over
+        `in_flight` streams (one Basecaller each, sharing the network).  Each read gets bit for bit what call_reads([read])
+        gives.  -> (scores [N] float32, list of N int32 path arrays, sample counts [N], stats) all on the host; stats holds the
+        padded-step waste."""
+        import torch
+        bcs = [cls(network, in_flight=in_flight, **kwargs) for _ in range(max(1, in_flight))]
+        sigs = bcs[0]._trim_reads(signals, trim, open_pore_fraction)
+        nsamp = [len(s) for s in sigs]
+        buckets = cls.length_buckets(nsamp, max_batch, max_waste)
+        streams = [torch.cuda.Stream() for _ in bcs]
+        cur = torch.cuda.current_stream()
+        pending = []
+        for k, idx in enumerate(buckets):
+            s = streams[k % len(bcs)]
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                res = bcs[k % len(bcs)]._call_trimmed([sigs[i] for i in idx])
+                host = tuple(t.to("cpu", non_blocking=True) for t in res)
+                ev = torch.cuda.Event()
+                ev.record(s)
+            pending.append((idx, host, ev, res))
+        scores = np.empty(len(sigs), dtype=np.float32)
+        paths = [None] * len(sigs)
+        used = padded = 0
+        for idx, host, ev, res in pending:
+            ev.synchronize()
+            sc, pa, le = (h.numpy() for h in host)
+            for j, i in enumerate(idx):
+                scores[i] = sc[j]
+                paths[i] = pa[j, :le[j]].copy()
+            used += sum(nsamp[i] for i in idx)
+            padded += nsamp[idx[0]] * len(idx)
+        stats = {"reads": len(sigs), "batches": len(buckets), "samples": used, "padded_samples": padded,
+                 "padded_step_waste": 1.0 - used / float(padded)}
+        return scores, paths, nsamp, stats
 
     def call_chunks_host(self, chunks):
         scores, paths, lens = self.call_chunks(chunks)

@@ -146,3 +146,27 @@ def test_ragged_batch_other_architectures(model):
     scores, paths, lens, nsamp = bc.call_reads(reads)
     scores, paths, lens = scores.cpu().numpy(), paths.cpu().numpy(), lens.cpu().numpy()
     _check_against_single_reads(bc, calc_post, reads, scores, paths, lens, nsamp, skip=0.0)
+
+
+def test_bucketed_whole_read_mode_equals_single_reads():
+    """pipeline.Basecaller.call_reads_bucketed: many reads bucketed by length, ragged batches alternating over streams -- every
+    read gets, bit for bit, what a batch of one gives; the buckets respect the waste bound."""
+    need_gpu()
+    from sloika_amd import models, pipeline
+    net = models.randomise_zero_layers(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=17))
+    rs = np.random.RandomState(4)
+    lens = rs.randint(900, 6000, size=23)
+    lens[3] = lens[7] = 2500
+    base = pipeline.synthetic_chunks(4, chunk_len=7000, seed=12)
+    reads = [np.ascontiguousarray(base[i % 4][rs.randint(0, 900):][:n]) for i, n in enumerate(lens)]
+    scores, paths, nsamp, stats = pipeline.Basecaller.call_reads_bucketed(net, reads, max_batch=6, max_waste=0.1, in_flight=2,
+                                                                          kmer_len=5, skip=0.0)
+    assert stats["reads"] == 23 and stats["batches"] >= 4 and 0.0 <= stats["padded_step_waste"] <= 0.1
+    buckets = pipeline.Basecaller.length_buckets(nsamp, 6, 0.1)
+    assert sorted(i for b in buckets for i in b) == list(range(23)) and max(len(b) for b in buckets) <= 6
+    bc = pipeline.Basecaller(net, kmer_len=5, skip=0.0)
+    for i in (0, 3, 7, 11, 22):
+        s1, p1, l1, n1 = bc.call_reads([reads[i]])
+        assert n1[0] == nsamp[i]
+        assert p1.cpu().numpy()[0, :int(l1[0])].tolist() == paths[i].tolist(), i
+        assert float(s1[0]) == float(scores[i]), i
