@@ -8,7 +8,18 @@ One "step" = one pass of the hot path over one batch of synthetic 4000-sample ch
 N > 1: launched by torch.distributed.run, one rank per GPU; every rank processes its own batch (reads/chunks are
 independent units: no data-path collective, weak scaling); timing = max over ranks, value = whole-job samples/s.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how `roofline` and `cpu_baseline` are defined).
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how `roofline` and `cpu_baseline` are defined).  Besides the
+contract's fields the line carries, all measured in the same process on the same device:
+    roofline            dominant kernel of the workload: algorithmic flops / HIP-event duration against ITS pipe's peak
+    exact_f32           the same workload with every product in plain fp32 MFMA
+    in_flight           two / four batches in flight on streams of their own, two / four batches as one call
+    batch256            BASELINE.json configs[1] (baseline_raw_gru) AND the metric's model (raw_0.98_rgrgr) at the batch the
+                        north star quotes, one batch at a time and eight in flight, each with its own roofline
+    with_upload         the step including the PCIe upload of the next batch's raw signal (copy stream)
+    sustained           >= 10 s of back-to-back steps, one batch at a time and four in flight, with the shader clock sampled
+    whole_reads         the reference's own inference mode (whole reads, basecall.py:88-121): reads of 50k-115k samples,
+                        bucketed by length, ragged batches in flight
+    train               a few steps of the training step (BASELINE.json configs[4] on this GPU)
 """
 import argparse
 import json
@@ -19,9 +30,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# HIP maps streams onto 4 hardware queues by default; batches in flight on their own streams, each with side streams for the
-# directions of a birnn and one for copies, serialise on them (baseline_raw_gru, B = 256, four in flight: 191 M samples/s
-# with 4 queues, 345 M with 16; eight in flight: 322 M with 16, 417 M with 32).  Read by the HIP runtime when it starts, so set before torch is imported.
+# HIP maps streams onto 4 hardware queues by default; batches in flight on their own streams serialise on them (baseline_raw_gru,
+# B = 256, eight in flight: 191 M samples/s with 4 queues, 417 M with 32).  Read by the HIP runtime when it starts; importing
+# sloika_amd sets the same default.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
@@ -30,9 +41,9 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_*_f32 = the
 F16_MFMA_PEAK_TFLOPS = 2516.6     # dense fp16/bf16 MFMA = 16 x the fp32 rate (the ~2.5 PFLOP/s of the guide)
 HBM_PEAK_GBS = 8000.0              # spec; ~6300 achievable
 
-# GEMM-like flops per raw sample -- used for the end-to-end MFMA fraction
+# stages whose work is matrix products (priced against the MFMA peaks); the others against HBM
 MFMA_STAGES = ("gru_fused", "gru_recurrent", "gru_input_gemm", "lstm_recurrent", "lstm_input_gemm", "softmax_gemm",
-               "gemm_bias_act", "conv1d")
+               "gemm_bias_act", "conv1d", "softmax_viterbi")
 
 
 def parse():
@@ -47,26 +58,30 @@ def parse():
                     help="chunks per slab of the CPU-baseline sample (slabs repeat until ~12 s; 0 = skip)")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams per GPU; with 2, consecutive batches overlap (batch i decodes while batch i+1 "
-                         "runs its recurrent layers)")
+                    help="HIP streams per GPU for the MAIN region; with 2, consecutive batches overlap")
     ap.add_argument("--with-bases", action="store_true",
                     help="also turn the decoded paths into base sequences on the device (slk_paths_to_bases) and copy those "
                          "to the host, inside the timed step")
-    ap.add_argument("--exact-steps", type=int, default=5,
-                    help="steps of the all-fp32 arithmetic (SLOIKA_AMD_EXACT_F32=1) timed after the main region for the "
-                         "`exact_f32` entry of the line (0 = skip)")
-    ap.add_argument("--overlap-steps", type=int, default=10,
-                    help="steps timed after the main region with TWO batches in flight on two streams, for the `two_in_flight` "
-                         "entry of the line (0 = skip); the main region and `value` always use --streams (default 1)")
-    ap.add_argument("--small-batch-steps", type=int, default=6,
-                    help="steps of BASELINE.json configs[1] (baseline_raw_gru, batch 256) timed after the main region, one batch at "
-                         "a time and eight in flight, for the `batch256` field (default workload on one GPU only; 0 = skip)")
+    ap.add_argument("--stage-steps", type=int, default=10,
+                    help="steps of the separate pass with per-stage HIP events (roofline, stages_ms_per_step); the timed region "
+                         "itself carries no events")
+    ap.add_argument("--exact-steps", type=int, default=5, help="steps of the all-fp32 arithmetic for `exact_f32` (0 = skip)")
+    ap.add_argument("--overlap-steps", type=int, default=10, help="steps of the in-flight legs (0 = skip)")
+    ap.add_argument("--small-batch-steps", type=int, default=6, help="steps of the batch-256 legs (0 = skip)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of each sustained leg (0 = skip)")
+    ap.add_argument("--upload-steps", type=int, default=10, help="steps of the leg that uploads the next batch (0 = skip)")
+    ap.add_argument("--whole-reads", type=int, default=1024, help="synthetic whole reads of 50k-115k samples (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=5, help="training steps for the `train` field (0 = skip)")
+    ap.add_argument("--quick", action="store_true", help="only the main region, the stage pass and the CPU baseline")
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (BASELINE.json configs[4]: forward + backward + ADAMski, "
                          "gradient all-reduce over RCCL when --gpus > 1); prints the same kind of JSON line")
     return ap.parse_args()
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baselines (the oracle: test infrastructure, timed here as the reported CPU column)
+# ----------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
     """The oracle (CPU port of the same pipeline: C + OpenMP over chunks) on the host cores of this box.
     Bounded sample: slabs of `slab` chunks of the same synthetic workload until ~budget_s seconds of CPU work."""
@@ -137,17 +152,191 @@ def cpu_baseline_train(model_name, chunk_len, nchunk=48):
                       "(BLAS threads: %d), %.1f s" % (nchunk, chunk_len, cores, dt)}
 
 
-def main_train(args):
-    """One step = wrap_network's fg(x, labels, weights, rate) on one batch per GPU (bin/train_network.py:308)."""
-    import torch
+# ----------------------------------------------------------------------------------------------------------------------
+# helpers shared by the legs
+# ----------------------------------------------------------------------------------------------------------------------
+def roofline_of(stages, traffic_by_stage, note=None):
+    """The dominant stage (by device time) of a pass timed with HIP events: algorithmic work per launch / average launch
+    duration, against the peak of the pipe it runs on (matrix stages: the fp32 part at the fp32 MFMA peak, the part evaluated
+    as a 3-term fp16 split at three fp16 MFMAs per product; the others against HBM)."""
+    if not stages:
+        return None
+    dom = max(stages, key=lambda k: stages[k]["ms_total"])
+    d = stages[dom]
+    if dom in MFMA_STAGES and d["flops"] > 0:
+        flops = d["flops"] / d["calls"]
+        f16 = d.get("f16x3_flops", 0.0) / d["calls"]
+        t_min = (flops - f16) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + 3.0 * f16 / (F16_MFMA_PEAK_TFLOPS * 1e12)
+        ach = flops / (d["ms_avg"] * 1e-3) / 1e12
+        peak = flops / t_min / 1e12
+        out = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+               "traffic": traffic_by_stage.get(dom), "ms_per_launch": d["ms_avg"], "launches": d["calls"],
+               "mix": {"fp32_mfma_flops": flops - f16, "f16x3_flops": f16, "fp32_peak": FP32_MFMA_PEAK_TFLOPS,
+                       "f16_peak": F16_MFMA_PEAK_TFLOPS},
+               # SURVEY 8(d)'s yardstick for the NN stage (all flops at the fp32 MFMA peak), for comparison only
+               "frac_vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS}
+    else:
+        ach = d["bytes"] / d["calls"] / (d["ms_avg"] * 1e-3) / 1e9
+        out = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+               "traffic": traffic_by_stage.get(dom), "ms_per_launch": d["ms_avg"], "launches": d["calls"]}
+    if note:
+        out["note"] = note
+    return out
+
+
+def pmc_traffic(model, batch, chunk_len):
+    """HBM bytes per launch per stage from the committed rocprofv3 PMC passes of this same workload (tools/collect_pmc.sh);
+    only quoted when a file describes the configuration being run."""
+    for name in ("pmc_traffic.json", "pmc_traffic_%s_b%d.json" % (model, batch)):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                pmc = json.load(fh)
+            if pmc.get("workload") == [model, batch, chunk_len]:
+                return pmc.get("stage_bytes_per_launch", {})
+        except (OSError, ValueError):
+            pass
+    return {}
+
+
+class Runner(object):
+    """One workload resident on the device: `nslot` Basecallers sharing a network, each with a stream, a few distinct input
+    batches, pinned host buffers for the results.  step(i, nact) issues step i on stream i % nact."""
+
+    def __init__(self, torch, model_name, B, L, nslot, rank=0, with_bases=False, main_stream=True):
+        from sloika_amd import models, pipeline
+        self.torch, self.B, self.L, self.with_bases = torch, B, L, with_bases
+        self.net = models.randomise_zero_layers(models.build_model(model_name, klen=5, sd=0.5, seed=11))
+        self.bcs = [pipeline.Basecaller(self.net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0) for _ in range(nslot)]
+        self.streams = ([torch.cuda.current_stream()] if main_stream else []) + \
+            [torch.cuda.Stream() for _ in range(nslot - (1 if main_stream else 0))]
+        self.nbuf = 2
+        self.host_in = [pipeline.synthetic_chunks(B, chunk_len=L, seed=0xdeadbeef, first_chunk=(rank * self.nbuf + i) * B)
+                        for i in range(self.nbuf)]
+        self.dev = [torch.from_numpy(h).cuda() for h in self.host_in]
+        first = self.net.layers[0]
+        self.tout = first.out_len(L) if hasattr(first, "out_len") else L
+        self.out_host = [torch.empty((B, self.tout), dtype=torch.int32).pin_memory() for _ in range(nslot)]
+        self.copy_stream = torch.cuda.Stream()
+        self.copied = [None] * nslot
+        self.klen = 5
+        if with_bases:
+            self.bases_dev = [torch.empty((B, 5 * self.tout), dtype=torch.uint8, device="cuda") for _ in range(nslot)]
+            self.nbases_dev = [torch.empty((B,), dtype=torch.int32, device="cuda") for _ in range(nslot)]
+            self.bases_host = [torch.empty((B, 5 * self.tout), dtype=torch.uint8).pin_memory() for _ in range(nslot)]
+            self.nbases_host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(nslot)]
+            self.acgt = int.from_bytes(b"ACGT".ljust(8, b"\0"), "little")
+        # upload leg: the raw signal of the next batch comes from pinned host memory on the copy stream
+        self.pinned_in = None
+        self.upload_buf = None
+
+    def set_in_flight(self, n):
+        for bc in self.bcs:
+            bc.in_flight = n
+
+    def step(self, i, nact=1, src=None):
+        """The results leave for the host on a copy stream of their own: the next step's kernels do not queue behind a PCIe
+        transfer.  `paths` is a fresh tensor every step (record_stream keeps the allocator from reusing it before the copy has
+        run); the persistent base buffers are protected by the copy's event."""
+        torch = self.torch
+        from sloika_amd import _lib, profiler
+        k = i % nact
+        with torch.cuda.stream(self.streams[k]):
+            scores, paths, lens = self.bcs[k].call_chunks(self.dev[i % self.nbuf] if src is None else src)
+            paths.record_stream(self.copy_stream)
+            if self.with_bases:                                                 # base sequences, still on the device
+                if self.copied[k] is not None:
+                    self.streams[k].wait_event(self.copied[k])
+                with profiler.region("bases", 0.0, 5.0 * paths.numel()):
+                    _lib.check(_lib.lib().slk_paths_to_bases(paths.data_ptr(), paths.stride(0), lens.data_ptr(), self.B,
+                                                             self.klen, 4, 1, self.acgt, self.bases_dev[k].data_ptr(),
+                                                             self.klen * self.tout, self.nbases_dev[k].data_ptr(),
+                                                             self.streams[k].cuda_stream), "paths_to_bases")
+            done = torch.cuda.Event()
+            done.record(self.streams[k])
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(done)
+            self.out_host[k][:, : paths.shape[1]].copy_(paths, non_blocking=True)     # paths end up on the host
+            if self.with_bases:                                                      # ... and so do the base sequences
+                self.bases_host[k].copy_(self.bases_dev[k], non_blocking=True)
+                self.nbases_host[k].copy_(self.nbases_dev[k], non_blocking=True)
+            self.copied[k] = torch.cuda.Event()
+            self.copied[k].record(self.copy_stream)
+
+    def step_with_upload(self, i):
+        """step i on buffer i % 2 while the raw signal of step i + 1 is uploaded from pinned host memory into the other buffer."""
+        torch = self.torch
+        if self.pinned_in is None:
+            self.pinned_in = [torch.from_numpy(h).pin_memory() for h in self.host_in]
+            self.upload_buf = [torch.empty_like(self.dev[0]) for _ in range(2)]
+            self.uploaded = [None, None]
+            self.consumed = [None, None]
+            for j in range(2):
+                self.upload_buf[j].copy_(self.pinned_in[j % self.nbuf], non_blocking=True)
+        cur, nxt = i % 2, (i + 1) % 2
+        main = self.streams[0]
+        with torch.cuda.stream(self.copy_stream):
+            if self.consumed[nxt] is not None:
+                self.copy_stream.wait_event(self.consumed[nxt])               # the step that read this buffer has run
+            self.upload_buf[nxt].copy_(self.pinned_in[(i + 1) % self.nbuf], non_blocking=True)
+            self.uploaded[nxt] = torch.cuda.Event()
+            self.uploaded[nxt].record(self.copy_stream)
+        if self.uploaded[cur] is not None:
+            main.wait_event(self.uploaded[cur])
+        self.step(i, 1, src=self.upload_buf[cur])
+        self.consumed[cur] = torch.cuda.Event()
+        self.consumed[cur].record(main)
+
+
+class ClockProbe(object):
+    """The shader clock under load: slk_clock_probe launched on a high-priority stream of its own between steps."""
+
+    def __init__(self, torch, nmax=256):
+        from sloika_amd import _lib
+        self.torch, self.lib = torch, _lib.lib()
+        self.stream = torch.cuda.Stream(priority=-1)
+        self.buf = torch.zeros((nmax, 2), dtype=torch.int64, device="cuda")
+        self.n, self.nmax = 0, nmax
+
+    def sample(self):
+        if self.n < self.nmax:
+            self.lib.slk_clock_probe(self.buf[self.n].data_ptr(), 64, self.stream.cuda_stream)
+            self.n += 1
+
+    def result(self):
+        self.torch.cuda.synchronize()
+        v = self.buf[: self.n].cpu().numpy().astype(np.float64)
+        v = v[(v[:, 1] > 0)]
+        if not len(v):
+            return None
+        mhz = v[:, 0] / v[:, 1] * 100.0
+        return {"samples": int(len(mhz)), "min": float(mhz.min()), "mean": float(mhz.mean()), "max": float(mhz.max())}
+
+
+def synthetic_reads(n, seed=0x5eed):
+    """Whole reads with the length range of the reference's own test reads (test/unit/test_fast5.py:98-110: 51 129 ... 114 400
+    samples): log-uniform lengths in [50 000, 115 000], signal cut from a pool of long synthetic traces."""
+    from sloika_amd import pipeline
+    rs = np.random.RandomState(seed)
+    pool = pipeline.synthetic_chunks(48, chunk_len=120000, seed=seed)
+    lens = np.exp(rs.uniform(np.log(50000.0), np.log(115000.0), size=n)).astype(np.int64)
+    return [np.ascontiguousarray(pool[rs.randint(0, len(pool))][rs.randint(0, 5000):][:ln]) for ln in lens]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def main_train(args, as_field=False, torch=None, dist=None):
+    """One step = wrap_network's fg(x, labels, weights, rate) on one batch per GPU (bin/train_network.py:308).  With `as_field`
+    it runs a few steps inside the inference line's process and returns the summary instead of printing a line."""
     from sloika_amd import _lib, models, profiler, shard, train
-    rank, world, local_rank = shard.dist_info()
-    _lib.require_gpu()
-    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-    dist = None
-    if "WORLD_SIZE" in os.environ:          # under a launcher (also with one rank: the RCCL path is the path that runs)
-        import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
+    if not as_field:
+        import torch
+        rank, world, local_rank = shard.dist_info()
+        _lib.require_gpu()
+        torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+        if "WORLD_SIZE" in os.environ:          # under a launcher (also with one rank: the RCCL path is the path that runs)
+            import torch.distributed as dist
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        rank, world, _ = shard.dist_info()
     net = models.randomise_zero_layers(models.build_model(args.model, klen=5, sd=0.5, seed=11))     # same weights on every rank
     fg = train.wrap_network(net, min_prob=1e-30, l2=0.0, drop=20)                                  # train_network.py defaults
     B, L = args.batch, args.chunk_len
@@ -156,28 +345,43 @@ def main_train(args):
     x = torch.from_numpy(rs.normal(size=(L, B, net.insize)).astype(np.float32)).cuda()
     labels = torch.from_numpy(rs.randint(0, net.size, size=(To, B)).astype(np.int32)).cuda()
     weights = torch.ones((To, B), dtype=torch.float32, device="cuda")
+    steps = args.train_steps if as_field else args.steps
+    warm = 2 if as_field else args.warmup
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warm):
         fg(x, labels, weights, 1e-3)
     barrier()
-    rec = None if args.no_stage_timing else profiler.start()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         loss, acc = fg(x, labels, weights, 1e-3 / (1.0 + i / 5000.0))
     barrier()
     dt = time.perf_counter() - t0
-    if rec is not None:
-        profiler.stop()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    stages = rec.summary() if rec is not None else {}
+    # per-stage HIP events in a pass of their own
+    stages = {}
+    if not args.no_stage_timing:
+        rec = profiler.start()
+        ns = max(2, min(steps, 5))
+        for i in range(ns):
+            fg(x, labels, weights, 1e-3)
+        barrier()
+        profiler.stop()
+        stages = rec.summary()
+        for v in stages.values():
+            v["per_step"] = v["ms_total"] / ns
+    if as_field:
+        return {"workload": "%s training step (forward, backward, ADAMski), %d-sample chunks, batch %d" % (args.model, L, B),
+                "ms_per_step": dt / steps * 1e3, "value": world * B * L * steps / dt, "unit": "samples/s", "steps": steps,
+                "final_loss": float(loss),
+                "stages_ms_per_step": {k: v["per_step"] for k, v in sorted(stages.items())}}
     roofline = None
     # HBM bytes per step of every stage from the committed PMC passes of this same workload (tools/collect_pmc.sh --train)
     stage_traffic = {}
@@ -195,14 +399,14 @@ def main_train(args):
         f16 = d.get("f16x3_flops", 0.0) / d["calls"]
         t_min = (flops - f16) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + 3.0 * f16 / (F16_MFMA_PEAK_TFLOPS * 1e12)
         ach = flops / (d["ms_avg"] * 1e-3) / 1e12
-        per_launch = stage_traffic[dom] * args.steps / d["calls"] if dom in stage_traffic else None
+        per_launch = stage_traffic[dom] * ns / d["calls"] if dom in stage_traffic else None
         roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": flops / t_min / 1e12, "unit": "TFLOP/s",
                     "frac": ach / (flops / t_min / 1e12), "traffic": per_launch, "ms_per_launch": d["ms_avg"],
                     "launches": d["calls"]}
     if rank == 0:
         print(json.dumps({
-            "metric": "raw-signal samples/sec trained", "value": world * B * L * args.steps / dt, "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "raw-signal samples/sec trained", "value": world * B * L * steps / dt, "unit": "samples/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (forward products and the weight-gradient-free GEMMs as 3-term fp16 splits, f32 accumulation)",
             "data": "synthetic",
@@ -213,7 +417,7 @@ def main_train(args):
             "roofline": roofline,
             "cpu_baseline": cpu_baseline_train(args.model, L) if (world == 1 and args.cpu_chunks > 0) else None,
             "final_loss": loss,
-            "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())},
+            "stages_ms_per_step": {k: v["per_step"] for k, v in sorted(stages.items())},
             "stages_hbm_bytes_per_step": {k: stage_traffic[k] for k in sorted(stages) if k in stage_traffic} or None}))
     if dist is not None:
         dist.destroy_process_group()
@@ -247,7 +451,7 @@ def main():
     if args.train:
         return main_train(args)
     import torch
-    from sloika_amd import _lib, models, pipeline, profiler, shard
+    from sloika_amd import _lib, layers as _layers, pipeline, profiler, shard
     rank, world, local_rank = shard.dist_info()
     _lib.require_gpu()
     torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
@@ -255,291 +459,220 @@ def main():
     if "WORLD_SIZE" in os.environ:          # under a launcher (also with one rank: the RCCL path is the path that runs)
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
-    net = models.randomise_zero_layers(models.build_model(args.model, klen=5, sd=0.5, seed=11))
-    nstream = max(1, args.streams)
-    nslot = max(nstream, 4 if (args.overlap_steps > 0 and nstream == 1) else 1)     # the in-flight legs need up to four slots
-    bcs = [pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, in_flight=nstream) for _ in range(nslot)]
-    bc = bcs[0]
-    streams = ([torch.cuda.Stream() for _ in range(nslot)] if nstream > 1
-               else [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nslot - 1)])
     B, L = args.batch, args.chunk_len
-    # a few distinct batches so that steps do not all hit the same cache lines
-    nbuf = 2
-    host = [pipeline.synthetic_chunks(B, chunk_len=L, seed=0xdeadbeef, first_chunk=(rank * nbuf + i) * B)
-            for i in range(nbuf)]
-    dev = [torch.from_numpy(h).cuda() for h in host]
-    tout = bc.network.layers[0].out_len(L) if hasattr(bc.network.layers[0], "out_len") else L
-    out_host = [torch.empty((B, tout), dtype=torch.int32).pin_memory() for _ in range(nslot)]
-    klen = 5
-    if args.with_bases:
-        bases_dev = [torch.empty((B, klen * tout), dtype=torch.uint8, device="cuda") for _ in range(nslot)]
-        nbases_dev = [torch.empty((B,), dtype=torch.int32, device="cuda") for _ in range(nslot)]
-        bases_host = [torch.empty((B, klen * tout), dtype=torch.uint8).pin_memory() for _ in range(nslot)]
-        nbases_host = [torch.empty((B,), dtype=torch.int32).pin_memory() for _ in range(nslot)]
-        acgt = int.from_bytes(b"ACGT".ljust(8, b"\0"), "little")
-
-    # The results leave for the host on a copy stream of their own: the next step's kernels do not queue behind a PCIe
-    # transfer.  `paths` is a fresh tensor every step (record_stream keeps the allocator from reusing it before the copy
-    # has run); the persistent base buffers are protected by the copy's event.
-    copy_stream = torch.cuda.Stream()
-    copied = [None] * nslot
-
-    def step(i, nact=nstream):
-        k = i % nact
-        with torch.cuda.stream(streams[k]):
-            scores, paths, lens = bcs[k].call_chunks(dev[i % nbuf])
-            paths.record_stream(copy_stream)
-            if args.with_bases:                                                 # base sequences, still on the device
-                if copied[k] is not None:
-                    streams[k].wait_event(copied[k])
-                with profiler.region("bases", 0.0, 5.0 * paths.numel()):
-                    _lib.check(_lib.lib().slk_paths_to_bases(paths.data_ptr(), paths.stride(0), lens.data_ptr(), B, klen, 4, 1,
-                                                             acgt, bases_dev[k].data_ptr(), klen * tout, nbases_dev[k].data_ptr(),
-                                                             streams[k].cuda_stream), "paths_to_bases")
-            done = torch.cuda.Event()
-            done.record(streams[k])
-        with torch.cuda.stream(copy_stream):
-            copy_stream.wait_event(done)
-            out_host[k][:, : paths.shape[1]].copy_(paths, non_blocking=True)     # paths end up on the host
-            if args.with_bases:                                                 # ... and so do the base sequences
-                bases_host[k].copy_(bases_dev[k], non_blocking=True)
-                nbases_host[k].copy_(nbases_dev[k], non_blocking=True)
-            copied[k] = torch.cuda.Event()
-            copied[k].record(copy_stream)
-        return scores, lens
+    nstream = max(1, args.streams)
+    extras = world == 1 and nstream == 1 and not args.quick        # the single-GPU legs behind the main region
+    nslot = max(nstream, 4 if (extras and args.overlap_steps > 0) else 1)
+    run = Runner(torch, args.model, B, L, nslot, rank=rank, with_bases=args.with_bases, main_stream=(nstream == 1))
+    run.set_in_flight(nstream)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def reduce_max(dt):
+        if dist is None:
+            return dt
+        tm = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return float(tm.item())
+
+    def timed(fn, n):
+        barrier()
+        t = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        barrier()
+        return reduce_max(time.perf_counter() - t)
+
+    # ---- the main region: W warm-up steps, then exactly K timed steps (no events inside) ----
     for i in range(args.warmup):
-        step(i)
-    barrier()
-    rec = None if args.no_stage_timing else profiler.start()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    if rec is not None:
+        run.step(i, nstream)
+    dt = timed(lambda i: run.step(i, nstream), args.steps)
+    value = world * B * L * args.steps / dt
+
+    # ---- the same steps once more with HIP events around every C-ABI call: per-stage times and the roofline ----
+    stages, roofline, ms_profiled = {}, None, None
+    if not args.no_stage_timing and args.stage_steps > 0:
+        rec = profiler.start()
+        dts = timed(lambda i: run.step(i, nstream), args.stage_steps)
         profiler.stop()
-    if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    samples = world * B * L * args.steps
-    value = samples / dt
+        stages = rec.summary()
+        ms_profiled = dts / args.stage_steps * 1e3
+        roofline = roofline_of(stages, pmc_traffic(args.model, B, L),
+                               "latency-bound serial scan; %d chunks per CU fill 4 of 16 MFMA columns" % max(1, B // 256)
+                               if args.model == "raw_0.98_rgrgr" and B <= 1024 else None)
+        if roofline is not None:
+            roofline["measured"] = "HIP events on the launch stream over %d steps issued right after the timed region " \
+                                   "(the timed region itself carries no events)" % args.stage_steps
 
-    # the same workload with every product in plain float32 MFMA (no fp16 splits anywhere): a few steps, same run
-    exact = None
-    if args.exact_steps > 0 and nstream == 1:
-        from sloika_amd import layers as _layers
-        keep = (_layers.SPLIT_F16, _layers.Softmax.split_f16)
-        _layers.SPLIT_F16, _layers.Softmax.split_f16 = False, False
-        try:
-            step(0)
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(args.exact_steps):
-                step(i)
-            barrier()
-            dte = time.perf_counter() - t1
-            if dist is not None:
-                tm = torch.tensor([dte], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                dte = float(tm.item())
-            exact = {"ms_per_step": dte / args.exact_steps * 1e3, "value": world * B * L * args.exact_steps / dte,
-                     "unit": "samples/s", "steps": args.exact_steps,
-                     "arithmetic": "float32 MFMA for every product (SLOIKA_AMD_EXACT_F32=1): two-kernel Gru, fp32 softmax projection"}
-        finally:
-            _layers.SPLIT_F16, _layers.Softmax.split_f16 = keep
+    line_extra = {}
+    if extras:
+        # ---- every product in plain float32 MFMA (no fp16 splits anywhere) ----
+        if args.exact_steps > 0:
+            keep = (_layers.SPLIT_F16, _layers.Softmax.split_f16)
+            _layers.SPLIT_F16, _layers.Softmax.split_f16 = False, False
+            try:
+                run.step(0)
+                dte = timed(lambda i: run.step(i), args.exact_steps)
+                line_extra["exact_f32"] = {
+                    "ms_per_step": dte / args.exact_steps * 1e3, "value": B * L * args.exact_steps / dte, "unit": "samples/s",
+                    "steps": args.exact_steps,
+                    "arithmetic": "float32 MFMA for every product (SLOIKA_AMD_EXACT_F32=1): two-kernel Gru, fp32 softmax "
+                                  "projection + decoder on the logits; a correctness fallback, not a performance path"}
+            finally:
+                _layers.SPLIT_F16, _layers.Softmax.split_f16 = keep
 
-    # the same workload with two batches in flight (two streams, Basecaller(in_flight=2)): batch i decodes while batch i+1 runs
-    # its recurrent layers, and two batches' recurrent layers share the chip on the eight-chunk plan
-    overlap = None
-    if args.overlap_steps > 0 and nstream == 1:
-        for bco in bcs:                       # every Basecaller is told that two batches are in flight (eight-chunk Gru plan)
-            bco.in_flight = 2
-        for i in range(4):                    # the second slot allocates its buffers on first use
-            step(i, 2)
-        barrier()
-        t2 = time.perf_counter()
-        for i in range(args.overlap_steps):
-            step(i, 2)
-        barrier()
-        dto = time.perf_counter() - t2
-        if dist is not None:
-            tm = torch.tensor([dto], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            dto = float(tm.item())
-        overlap = {"ms_per_step": dto / args.overlap_steps * 1e3, "value": world * B * L * args.overlap_steps / dto,
-                   "unit": "samples/s", "steps": args.overlap_steps, "streams_per_gpu": 2}
-        # ... four in flight on four streams: each batch's recurrent layers take a quarter of the chip on the sixteen-chunk plan
-        for bco in bcs:
-            bco.in_flight = 4
-        for i in range(8):
-            step(i, 4)
-        barrier()
-        t6 = time.perf_counter()
-        n4 = 2 * args.overlap_steps
-        for i in range(n4):
-            step(i, 4)
-        barrier()
-        dt4 = time.perf_counter() - t6
-        if dist is not None:
-            tm = torch.tensor([dt4], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            dt4 = float(tm.item())
-        overlap["four_in_flight"] = {"ms_per_step": dt4 / n4 * 1e3, "value": world * B * L * n4 / dt4, "unit": "samples/s",
-                                     "steps": n4, "streams_per_gpu": 4}
-        for bco in bcs:
-            bco.in_flight = nstream
-        # ... and with the two batches handed over as ONE call of 2B chunks: a recurrent layer then runs the eight-chunk plan
-        # (csrc/gru_bar16d.hip: one workgroup per CU takes a 4-chunk tile of EACH batch through the same MFMAs) instead of two
-        # rounds of four-chunk workgroups.  Only the paths of the first B chunks are copied out per B chunks of work, as above.
-        if not args.with_bases:
-            pair = torch.cat([dev[0], dev[1 % nbuf]], dim=0)
-            out2 = torch.empty((2 * B, tout), dtype=torch.int32).pin_memory()
-            def step_pair():
-                scores, paths, lens = bc.call_chunks(pair)
-                paths.record_stream(copy_stream)
-                done = torch.cuda.Event()
-                done.record(torch.cuda.current_stream())
-                with torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(done)
-                    out2[:, : paths.shape[1]].copy_(paths, non_blocking=True)
-            npair = max(1, args.overlap_steps // 2)
-            for _ in range(2):
-                step_pair()
-            barrier()
-            t3 = time.perf_counter()
-            for _ in range(npair):
-                step_pair()
-            barrier()
-            dtp = time.perf_counter() - t3
-            if dist is not None:
-                tm = torch.tensor([dtp], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                dtp = float(tm.item())
-            overlap["as_one_batch"] = {"ms_per_step": dtp / (2 * npair) * 1e3, "value": world * 2 * B * L * npair / dtp,
-                                       "unit": "samples/s", "steps": 2 * npair, "chunks_per_call": 2 * B,
-                                       "note": "ms_per_step is per %d chunks; one call carries two batches" % B}
-            del pair
-            # ... and four batches as one call of 4B chunks: the recurrent layers run sixteen chunks per workgroup
-            # (csrc/gru_bar16q.hip: every column of the recurrent MFMAs a different chunk)
-            quad = torch.cat([dev[i % nbuf] for i in range(4)], dim=0)
-            out4 = torch.empty((4 * B, tout), dtype=torch.int32).pin_memory()
-            def step_quad():
-                scores, paths, lens = bc.call_chunks(quad)
-                paths.record_stream(copy_stream)
-                done = torch.cuda.Event()
-                done.record(torch.cuda.current_stream())
-                with torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(done)
-                    out4[:, : paths.shape[1]].copy_(paths, non_blocking=True)
-            nquad = max(1, args.overlap_steps // 4)
-            step_quad()
-            barrier()
-            t5 = time.perf_counter()
-            for _ in range(nquad):
-                step_quad()
-            barrier()
-            dtq = time.perf_counter() - t5
-            if dist is not None:
-                tm = torch.tensor([dtq], dtype=torch.float64, device="cuda")
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                dtq = float(tm.item())
-            overlap["four_as_one_batch"] = {"ms_per_step": dtq / (4 * nquad) * 1e3, "value": world * 4 * B * L * nquad / dtq,
-                                            "unit": "samples/s", "steps": 4 * nquad, "chunks_per_call": 4 * B,
-                                            "note": "ms_per_step is per %d chunks; one call carries four batches" % B}
-            del quad
+        # ---- batches in flight ----
+        if args.overlap_steps > 0:
+            infl = {}
+            for nact, key in ((2, "two_in_flight"), (4, "four_in_flight")):
+                run.set_in_flight(nact)
+                for i in range(2 * nact):
+                    run.step(i, nact)
+                n = args.overlap_steps * (nact // 2)
+                d = timed(lambda i: run.step(i, nact), n)
+                infl[key] = {"ms_per_step": d / n * 1e3, "value": B * L * n / d, "unit": "samples/s", "steps": n,
+                             "streams_per_gpu": nact}
+            run.set_in_flight(1)
+            if not args.with_bases:
+                for mult, key in ((2, "two_as_one_batch"), (4, "four_as_one_batch")):
+                    big = torch.cat([run.dev[i % run.nbuf] for i in range(mult)], dim=0)
+                    outb = torch.empty((mult * B, run.tout), dtype=torch.int32).pin_memory()
 
-    # BASELINE.json configs[1] -- the batch north_star quotes (baseline_raw_gru, 256 chunks of 4000 samples): every stage is
-    # latency bound at that size (64 workgroups per recurrent launch, 256 decoder workgroups), so the device only fills up with
-    # several batches in flight
-    small = None
-    if (args.small_batch_steps > 0 and world == 1 and nstream == 1 and args.model == "raw_0.98_rgrgr" and args.batch == 1024
-            and not args.with_bases):
-        net1 = models.randomise_zero_layers(models.build_model("baseline_raw_gru", klen=5, sd=0.5, seed=11))
-        B1, nfl = 256, 8
-        bcs1 = [pipeline.Basecaller(net1, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0) for _ in range(nfl)]
-        st1 = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nfl - 1)]
-        dev1 = [torch.from_numpy(pipeline.synthetic_chunks(B1, chunk_len=L, seed=0xfeed, first_chunk=i * B1)).cuda() for i in range(nfl)]
-        tout1 = bcs1[0].network.layers[0].out_len(L)
-        host1 = [torch.empty((B1, tout1), dtype=torch.int32).pin_memory() for _ in range(nfl)]
+                    def step_big(_i, big=big, outb=outb):
+                        scores, paths, lens = run.bcs[0].call_chunks(big)
+                        paths.record_stream(run.copy_stream)
+                        done = torch.cuda.Event()
+                        done.record(torch.cuda.current_stream())
+                        with torch.cuda.stream(run.copy_stream):
+                            run.copy_stream.wait_event(done)
+                            outb[:, : paths.shape[1]].copy_(paths, non_blocking=True)
+                    step_big(0)
+                    n = max(1, args.overlap_steps // mult)
+                    d = timed(step_big, n)
+                    infl[key] = {"ms_per_step": d / (mult * n) * 1e3, "value": mult * B * L * n / d, "unit": "samples/s",
+                                 "steps": mult * n, "chunks_per_call": mult * B,
+                                 "note": "ms_per_step is per %d chunks; one call carries %d batches" % (B, mult)}
+                    del big, outb
+            line_extra["in_flight"] = infl
 
-        def step1(i, nact):
-            k = i % nact
-            with torch.cuda.stream(st1[k]):
-                scores, paths, lens = bcs1[k].call_chunks(dev1[k])
-                paths.record_stream(copy_stream)
-                done = torch.cuda.Event()
-                done.record(st1[k])
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(done)
-                host1[k][:, : paths.shape[1]].copy_(paths, non_blocking=True)
+        # ---- the step including the upload of the next batch's raw signal (pinned host memory -> HBM on the copy stream) ----
+        if args.upload_steps > 0 and not args.with_bases:
+            for i in range(3):
+                run.step_with_upload(i)
+            d = timed(run.step_with_upload, args.upload_steps)
+            line_extra["with_upload"] = {"ms_per_step": d / args.upload_steps * 1e3, "value": B * L * args.upload_steps / d,
+                                         "unit": "samples/s", "steps": args.upload_steps,
+                                         "upload_bytes_per_step": int(B * L * 4),
+                                         "note": "float32 raw signal of the NEXT batch uploaded from pinned host memory on the "
+                                                 "copy stream while this batch runs; `value` of the line excludes it"}
 
-        small = {"workload": "baseline_raw_gru inference, %d-sample chunks, batch %d (BASELINE.json configs[1])" % (L, B1)}
-        for nact, key in ((1, "one_at_a_time"), (nfl, "eight_in_flight")):
-            for bco in bcs1:
-                bco.in_flight = nact
-            for i in range(2 * nact):
-                step1(i, nact)
-            barrier()
-            t4 = time.perf_counter()
-            nst = args.small_batch_steps * nact
-            for i in range(nst):
-                step1(i, nact)
-            barrier()
-            d4 = time.perf_counter() - t4
-            small[key] = {"ms_per_step": d4 / nst * 1e3, "value": B1 * L * nst / d4, "unit": "samples/s", "steps": nst,
-                          "streams_per_gpu": nact}
-        del bcs1, dev1
+        # ---- the batch north_star quotes (256 chunks): configs[1] and the metric's own model, each with its roofline ----
+        if args.small_batch_steps > 0 and args.model == "raw_0.98_rgrgr" and B == 1024 and not args.with_bases:
+            small = {}
+            for mname in ("baseline_raw_gru", "raw_0.98_rgrgr"):
+                B1, nfl = 256, 8
+                r1 = Runner(torch, mname, B1, L, nfl)
+                ent = {"workload": "%s inference, %d-sample chunks, batch %d%s" % (
+                    mname, L, B1, " (BASELINE.json configs[1])" if mname == "baseline_raw_gru" else " (the metric's model at the "
+                    "north star's batch)")}
+                for nact, key in ((1, "one_at_a_time"), (nfl, "eight_in_flight")):
+                    r1.set_in_flight(nact)
+                    for i in range(2 * nact):
+                        r1.step(i, nact)
+                    n = args.small_batch_steps * nact
+                    d = timed(lambda i: r1.step(i, nact), n)
+                    ent[key] = {"ms_per_step": d / n * 1e3, "value": B1 * L * n / d, "unit": "samples/s", "steps": n,
+                                "streams_per_gpu": nact}
+                r1.set_in_flight(1)
+                rec1 = profiler.start()
+                timed(lambda i: r1.step(i, 1), args.small_batch_steps)
+                profiler.stop()
+                st1 = rec1.summary()
+                ent["stages_ms_per_step"] = {k: v["ms_total"] / args.small_batch_steps for k, v in sorted(st1.items())}
+                ent["roofline"] = roofline_of(st1, pmc_traffic(mname, B1, L),
+                                              "one batch at a time: %d workgroups of 4 chunks on 256 CUs" % (B1 // 4))
+                small[mname] = ent
+                del r1
+            line_extra["batch256"] = small
 
-    stages = rec.summary() if rec is not None else {}
-    roofline = None
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/collect_pmc.sh);
-    # only quoted when the file describes the configuration being run.
-    traffic_by_stage = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            pmc = json.load(fh)
-        if pmc.get("workload") == [args.model, args.batch, args.chunk_len]:
-            traffic_by_stage = pmc.get("stage_bytes_per_launch", {})
-    except (OSError, ValueError):
-        pass
-    if stages:
-        dom = max(stages, key=lambda k: stages[k]["ms_total"])
-        d = stages[dom]
-        if dom in MFMA_STAGES:
-            # The matrix roofline of this launch for ITS instruction mix: the fp32 part at the fp32 MFMA peak, the part
-            # evaluated as a 3-term fp16 split (three fp16 MFMAs per product) at the fp16 peak.  `peak` is the
-            # algorithmic FLOP/s the kernel would reach with both pipes saturated, so frac = t_roofline / t_measured.
-            flops = d["flops"] / d["calls"]
-            f16 = d.get("f16x3_flops", 0.0) / d["calls"]
-            t_min = (flops - f16) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + 3.0 * f16 / (F16_MFMA_PEAK_TFLOPS * 1e12)
-            ach = flops / (d["ms_avg"] * 1e-3) / 1e12
-            peak = flops / t_min / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak,
-                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic_by_stage.get(dom),
-                        "ms_per_launch": d["ms_avg"], "launches": d["calls"],
-                        "mix": {"fp32_mfma_flops": flops - f16, "f16x3_flops": f16,
-                                "fp32_peak": FP32_MFMA_PEAK_TFLOPS, "f16_peak": F16_MFMA_PEAK_TFLOPS},
-                        # SURVEY 8(d)'s yardstick for the NN stage (all flops at the fp32 MFMA peak), for comparison only
-                        "frac_vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
-                        # B = 1024 over 256 CUs leaves 4 chunks per workgroup: 4 of the 16 columns of a 16x16x32 MFMA tile
-                        "note": "latency-bound serial scan; 4 chunks per CU fill 4 of 16 MFMA columns"}
-        else:
-            ach = d["bytes"] / d["calls"] / (d["ms_avg"] * 1e-3) / 1e9
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic_by_stage.get(dom), "ms_per_launch": d["ms_avg"],
-                        "launches": d["calls"]}
+        # ---- whole reads (the reference's inference mode), bucketed by length, ragged batches in flight ----
+        if args.whole_reads > 0 and not args.with_bases:
+            reads = synthetic_reads(args.whole_reads)
+            kw = dict(kmer_len=5, skip=0.0)
+            lanes = pipeline.Basecaller.read_lanes(run.net, 8, **kw)          # kept across calls, as a serving process would
+            pipeline.Basecaller.call_reads_bucketed(run.net, reads, max_batch=256, max_waste=0.08, lanes=lanes, **kw)   # warm-up
+            torch.cuda.synchronize()
+            # (1) from host arrays: trimming, bucketing, packing, upload, network, decoder, paths back on the host
+            t0 = time.perf_counter()
+            scores, paths, nsamp, wst = pipeline.Basecaller.call_reads_bucketed(run.net, reads, max_batch=256, max_waste=0.08,
+                                                                                lanes=lanes, **kw)
+            torch.cuda.synchronize()
+            d_all = time.perf_counter() - t0
+            # (2) the prepared batches resident in HBM (as the chunks of the main region are): network + decoder + paths to host
+            batches, nsamp = pipeline.Basecaller.prepare_read_batches(run.net, reads, max_batch=256, max_waste=0.08, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            scores2, paths2 = pipeline.Basecaller.run_read_batches(run.net, batches, len(nsamp), lanes=lanes, **kw)
+            torch.cuda.synchronize()
+            d_dev = time.perf_counter() - t0
+            assert all(np.array_equal(a, b) for a, b in zip(paths, paths2))
+            line_extra["whole_reads"] = {
+                "workload": "%d synthetic whole reads of 50k-115k samples (test/unit/test_fast5.py:98-110), per-read normalisation, "
+                            "bucketed by length into ragged batches of <= 256 reads, all batches side by side on streams of their "
+                            "own" % len(reads),
+                "value": sum(nsamp) / d_dev, "unit": "samples/s", "seconds": d_dev, "reads_per_s": len(reads) / d_dev,
+                "note": "`value`: padded batches resident in HBM when the clock starts (like the chunks of the main region), paths "
+                        "on the host when it stops; `from_host_arrays` adds open-pore trimming, bucketing, packing and the upload",
+                "from_host_arrays": {"value": sum(nsamp) / d_all, "unit": "samples/s", "seconds": d_all},
+                "batches": wst["batches"], "padded_step_waste": wst["padded_step_waste"],
+                "bases_called": int(sum(len(p) for p in paths))}
+            del batches, paths2, lanes
+            del reads, paths
+
+        # ---- a few steps of the training step (BASELINE.json configs[4] on this GPU) ----
+        if args.train_steps > 0 and not args.with_bases:
+            line_extra["train"] = main_train(args, as_field=True, torch=torch, dist=None)
+
+
+        # ---- sustained load, LAST (the device throttles for a while after it: every other leg would pay): >= N seconds of
+        # back-to-back steps, the shader clock sampled between steps ----
+        if args.sustained_seconds > 0 and not args.with_bases:
+            sus = {}
+            for nact, key in ((1, "one_at_a_time"), (4, "four_in_flight")):
+                if nact > nslot:
+                    continue
+                run.set_in_flight(nact)
+                for i in range(2 * nact):
+                    run.step(i, nact)
+                probe = ClockProbe(torch)
+                barrier()
+                t0 = time.perf_counter()
+                n = 0
+                while True:
+                    for _ in range(16):
+                        run.step(n, nact)
+                        n += 1
+                    probe.sample()
+                    torch.cuda.current_stream().synchronize() if nact == 1 else run.streams[(n - 1) % nact].synchronize()
+                    if time.perf_counter() - t0 >= args.sustained_seconds:
+                        break
+                barrier()
+                d = time.perf_counter() - t0
+                sus[key] = {"seconds": d, "steps": n, "ms_per_step": d / n * 1e3, "value": B * L * n / d, "unit": "samples/s",
+                            "shader_clock_mhz": probe.result()}
+            run.set_in_flight(1)
+            line_extra["sustained"] = sus
+
+
     if rank == 0:
         cpu = None
         if world == 1 and args.cpu_chunks > 0:
             cpu = cpu_baseline(args.model, L, args.cpu_chunks)
-        gemm_flops = sum(stages[k]["flops"] for k in stages if k in MFMA_STAGES) / max(1, args.steps)
+        nst = max(1, args.stage_steps)
+        gemm_flops = sum(stages[k]["flops"] for k in stages if k in MFMA_STAGES) / nst
         line = {
             "metric": "raw-signal samples/sec basecalled", "value": value, "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -548,18 +681,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s inference, %d-sample chunks, batch %d per GPU, klen 5 (1025 states), "
                                    "normalise->conv->GRU->softmax->Viterbi->paths%s on host; matrix products as fp16x3 splits "
-                                   "(f32-grade, see exact_f32 for plain fp32 MFMA)"
-                                   % (args.model, L, B, " + base sequences" if args.with_bases else ""),
+                                   "(f32-grade, see exact_f32 for plain fp32 MFMA); softmax projection + decoder fused (logits "
+                                   "never written)" % (args.model, L, B, " + base sequences" if args.with_bases else ""),
                        "model": args.model, "chunk_len": L, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "chunks sharded over %d GPU(s), no collective" % world, "streams_per_gpu": nstream},
             "roofline": roofline,
             "cpu_baseline": cpu,
-            "exact_f32": exact,
-            "two_in_flight": overlap,
-            "batch256": small,
-            "stages_ms_per_step": {k: v["ms_total"] / args.steps for k, v in sorted(stages.items())},
+            "stages_ms_per_step": {k: v["ms_total"] / nst for k, v in sorted(stages.items())},
+            "ms_per_step_with_stage_events": ms_profiled,
             "e2e_algorithmic_tflops": (gemm_flops / (dt / args.steps) / 1e12) if stages else None,
         }
+        line.update(line_extra)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

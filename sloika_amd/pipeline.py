@@ -123,19 +123,26 @@ class Basecaller(object):
             raise ValueError("empty read after trimming")
         return sigs
 
-    def _call_trimmed(self, sigs):
-        """One padded batch of trimmed reads (host float32 arrays): pack, upload, per-read normalisation, network and decoder
-        with per-read lengths.  -> (scores, paths, lens) on the device."""
+    @staticmethod
+    def _pack_reads(sigs):
+        """Trimmed reads (host float32 arrays) -> zero-padded [B, Lmax] device tensor (through pinned memory when it is big)."""
         import torch
         from . import device as D
-        net = self.network
         nsamp = [len(s) for s in sigs]
         B, lmax = len(sigs), max(nsamp)
-        host = torch.zeros((B, lmax), dtype=torch.float32).pin_memory() if B * lmax >= (1 << 20) else torch.zeros((B, lmax))
+        host = torch.zeros((B, lmax), dtype=torch.float32)
+        if B * lmax >= (1 << 20):
+            host = host.pin_memory()
         hv = host.numpy()
         for b, sig in enumerate(sigs):
             hv[b, :nsamp[b]] = sig
-        padded = host.to(D.device(), non_blocking=True)
+        return host.to(D.device(), non_blocking=True), nsamp
+
+    def _call_padded(self, padded, nsamp):
+        """One padded batch of trimmed reads resident on the device ([B, Lmax], read b in its first nsamp[b] samples): per-read
+        normalisation, network and decoder with per-read lengths.  -> (scores, paths, lens) on the device."""
+        net = self.network
+        B = padded.shape[0]
         with layers.ragged(nsamp) as ctx:
             x = batch.normalise_reads_ragged(padded, ctx.lengths)      # per-read normalisation (basecall.py:117-118)
             hid = x
@@ -151,6 +158,10 @@ class Basecaller(object):
                                               min_prob=self.min_prob, workspace=self._ws, lengths=lengths.contiguous())
         return decode.viterbi_logits_batch(logits, stats, self.kmer_len, T, B, ld=ld, skip_pen=self.skip, nbase=self.nbase,
                                            min_prob=self.min_prob, workspace=self._ws, lengths=lengths.contiguous())
+
+    def _call_trimmed(self, sigs):
+        padded, nsamp = self._pack_reads(sigs)
+        return self._call_padded(padded, nsamp)
 
     def call_reads(self, signals, trim=(0, 0), open_pore_fraction=0.0):
         """Whole reads of different lengths in ONE batch (the reference calls them one at a time, basecall.py:88-121):
@@ -185,42 +196,72 @@ class Basecaller(object):
         return buckets
 
     @classmethod
-    def call_reads_bucketed(cls, network, signals, trim=(0, 0), open_pore_fraction=0.0, max_batch=256, max_waste=0.08, in_flight=2,
-                            **kwargs):
-        """Whole-read mode for MANY reads (what bin/basecall_network.py does with a pool of workers, basecall_network.py:100-104):
-        reads are bucketed by length (length_buckets), every bucket is one padded ragged batch, and the buckets alternate over
-        `in_flight` streams (one Basecaller each, sharing the network).  Each read gets bit for bit what call_reads([read])
-        gives.  -> (scores [N] float32, list of N int32 path arrays, sample counts [N], stats) all on the host; stats holds the
-        padded-step waste."""
-        import torch
-        bcs = [cls(network, in_flight=in_flight, **kwargs) for _ in range(max(1, in_flight))]
-        sigs = bcs[0]._trim_reads(signals, trim, open_pore_fraction)
+    def prepare_read_batches(cls, network, signals, trim=(0, 0), open_pore_fraction=0.0, max_batch=256, max_waste=0.08, **kwargs):
+        """Host side of the whole-read mode: trim every read (one device call for all their windows), bucket by length, pack each
+        bucket into a zero-padded batch and upload it.  -> (batches, nsamp): batches = [(read indices, padded device tensor
+        [B, Lmax], their sample counts)], nsamp = sample count of every read after trimming."""
+        bc = cls(network, **kwargs)
+        sigs = bc._trim_reads(signals, trim, open_pore_fraction)
         nsamp = [len(s) for s in sigs]
-        buckets = cls.length_buckets(nsamp, max_batch, max_waste)
-        streams = [torch.cuda.Stream() for _ in bcs]
+        batches = []
+        for idx in cls.length_buckets(nsamp, max_batch, max_waste):
+            padded, ns = cls._pack_reads([sigs[i] for i in idx])
+            batches.append((idx, padded, ns))
+        return batches, nsamp
+
+    @classmethod
+    def run_read_batches(cls, network, batches, nreads, in_flight=None, lanes=None, **kwargs):
+        """Device side: every prepared batch through normalisation, network and decoder, the batches spread over `in_flight`
+        streams (default: one per batch, at most 8 -- a batch of 200 long reads occupies 50 of the 256 CUs for tens of
+        milliseconds, so the chip only fills up with several of them side by side).  `lanes`: a list of (Basecaller, stream)
+        pairs to reuse (read_lanes(); torch's allocator caches device memory per stream, so a server that keeps its lanes does
+        not pay for gigabytes of fresh allocations on every call).  -> (scores [N] float32, list of N int32 path arrays) on the
+        host."""
+        import torch
+        if lanes is None:
+            lanes = cls.read_lanes(network, max(1, min(8, len(batches)) if in_flight is None else in_flight), **kwargs)
+        nfl = len(lanes)
         cur = torch.cuda.current_stream()
         pending = []
-        for k, idx in enumerate(buckets):
-            s = streams[k % len(bcs)]
+        for k, (idx, padded, ns) in enumerate(batches):
+            bc, s = lanes[k % nfl]
             s.wait_stream(cur)
             with torch.cuda.stream(s):
-                res = bcs[k % len(bcs)]._call_trimmed([sigs[i] for i in idx])
+                padded.record_stream(s)
+                res = bc._call_padded(padded, ns)
                 host = tuple(t.to("cpu", non_blocking=True) for t in res)
                 ev = torch.cuda.Event()
                 ev.record(s)
             pending.append((idx, host, ev, res))
-        scores = np.empty(len(sigs), dtype=np.float32)
-        paths = [None] * len(sigs)
-        used = padded = 0
+        scores = np.empty(nreads, dtype=np.float32)
+        paths = [None] * nreads
         for idx, host, ev, res in pending:
             ev.synchronize()
             sc, pa, le = (h.numpy() for h in host)
             for j, i in enumerate(idx):
                 scores[i] = sc[j]
                 paths[i] = pa[j, :le[j]].copy()
-            used += sum(nsamp[i] for i in idx)
-            padded += nsamp[idx[0]] * len(idx)
-        stats = {"reads": len(sigs), "batches": len(buckets), "samples": used, "padded_samples": padded,
+        return scores, paths
+
+    @classmethod
+    def read_lanes(cls, network, n, **kwargs):
+        """n (Basecaller, stream) pairs sharing one network, for run_read_batches / call_reads_bucketed."""
+        import torch
+        return [(cls(network, in_flight=n, **kwargs), torch.cuda.Stream()) for _ in range(max(1, n))]
+
+    @classmethod
+    def call_reads_bucketed(cls, network, signals, trim=(0, 0), open_pore_fraction=0.0, max_batch=256, max_waste=0.08, in_flight=None,
+                            lanes=None, **kwargs):
+        """Whole-read mode for MANY reads (what bin/basecall_network.py does with a pool of workers, basecall_network.py:100-104):
+        reads are bucketed by length (length_buckets), every bucket is one padded ragged batch, and the buckets run side by side
+        on streams of their own (one Basecaller each, sharing the network).  Each read gets bit for bit what call_reads([read])
+        gives.  -> (scores [N] float32, list of N int32 path arrays, sample counts [N], stats) all on the host; stats holds the
+        padded-step waste."""
+        batches, nsamp = cls.prepare_read_batches(network, signals, trim, open_pore_fraction, max_batch, max_waste, **kwargs)
+        scores, paths = cls.run_read_batches(network, batches, len(nsamp), in_flight, lanes, **kwargs)
+        used = sum(nsamp)
+        padded = sum(ns[0] * len(idx) for idx, _, ns in batches)
+        stats = {"reads": len(nsamp), "batches": len(batches), "samples": used, "padded_samples": padded,
                  "padded_step_waste": 1.0 - used / float(padded)}
         return scores, paths, nsamp, stats
 

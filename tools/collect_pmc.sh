@@ -6,5 +6,5 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 mkdir -p gpurun_out
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-chunks 0 --exact-steps 0 --overlap-steps 0 --small-batch-steps 0 --no-stage-timing "$@" > gpurun_out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-chunks 0 --exact-steps 0 --overlap-steps 0 --small-batch-steps 0 --no-stage-timing "$@" > gpurun_out/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --cpu-chunks 0 --quick --no-stage-timing "$@" > gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 2 --warmup 1 --cpu-chunks 0 --quick --no-stage-timing "$@" > gpurun_out/pmc_write.log 2>&1

@@ -6,5 +6,5 @@ cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 mkdir -p gpurun_out
 for c in MfmaUtil LdsUtil VALUBusy LDSBankConflict; do
   rm -rf gpurun_out/util_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/util_$c -- python3 bench.py --steps 2 --warmup 1 --cpu-chunks 0 --exact-steps 0 --overlap-steps 0 --small-batch-steps 0 --no-stage-timing "$@" > gpurun_out/util_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/util_$c -- python3 bench.py --steps 2 --warmup 1 --cpu-chunks 0 --quick --no-stage-timing "$@" > gpurun_out/util_$c.log 2>&1
 done

@@ -24,6 +24,8 @@ STAGES = {            # bench.py stage -> substrings of the kernels it launches 
     "gru_fused": ("gru_bar16_kernel", "gru_fused16_kernel", "gru_fused_kernel"),
     "softmax_gemm": ("gemm_rows_f16x3_kernel", "gemm_rows_kernel"),
     "viterbi": ("viterbi_forward", "viterbi_backtrace"),
+    "softmax_viterbi": ("softmax_viterbi_kernel", "viterbi_backtrace"),
+    "gemm_bias_act": ("gemm_bias_act_kernel", "gemm_rows_f16x3_kernel"),
     "conv1d": ("conv1d_",),
     "normalise": ("med_mad_",),
 }
@@ -69,7 +71,9 @@ def train_stage_file(summary_path, workload, steps_sampled=3):
 
 def main():
     if sys.argv[1] == "--stages":
-        return stage_file(sys.argv[2], ["raw_0.98_rgrgr", 1024, 4000])
+        # python tools/pmc_summary.py --stages summary.json [model batch chunk_len]
+        wl = [sys.argv[3], int(sys.argv[4]), int(sys.argv[5])] if len(sys.argv) >= 6 else ["raw_0.98_rgrgr", 1024, 4000]
+        return stage_file(sys.argv[2], wl)
     if sys.argv[1] == "--train-stages":
         return train_stage_file(sys.argv[2], ["raw_0.98_rgrgr", 1024, 4000])
     fetch, write = load(sys.argv[1]), load(sys.argv[2])
