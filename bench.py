@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--whole-reads", type=int, default=1024, help="synthetic whole reads of 50k-115k samples (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=5, help="training steps for the `train` field (0 = skip)")
     ap.add_argument("--quick", action="store_true", help="only the main region, the stage pass and the CPU baseline")
+    ap.add_argument("--only", default=None, choices=["batch256"],
+                    help="run ONE leg and print its JSON (bench.py starts itself with this as a child process)")
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (BASELINE.json configs[4]: forward + backward + ADAMski, "
                          "gradient all-reduce over RCCL when --gpus > 1); prints the same kind of JSON line")
@@ -322,6 +324,53 @@ def synthetic_reads(n, seed=0x5eed):
     return [np.ascontiguousarray(pool[rs.randint(0, len(pool))][rs.randint(0, 5000):][:ln]) for ln in lens]
 
 
+def leg_batch256(args, torch):
+    """The batch north_star quotes (256 chunks): BASELINE.json configs[1] and the metric's own model, one batch at a time and
+    eight in flight, each with the roofline of its dominant kernel (HIP events, one batch at a time)."""
+    from sloika_amd import profiler
+    L = args.chunk_len
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+
+    small = {}
+    for mname in (args.model,):                      # one model per child process (see the caller)
+        B1, nfl = 256, 8
+        r1 = Runner(torch, mname, B1, L, nfl)
+        ent = {"workload": "%s inference, %d-sample chunks, batch %d%s" % (
+            mname, L, B1, " (BASELINE.json configs[1])" if mname == "baseline_raw_gru" else " (the metric's model at the "
+            "north star's batch)")}
+        r1.set_in_flight(1)
+        for i in range(3):
+            r1.step(i, 1)
+        n = args.small_batch_steps
+        d = timed(lambda i: r1.step(i, 1), n)
+        ent["one_at_a_time"] = {"ms_per_step": d / n * 1e3, "value": B1 * L * n / d, "unit": "samples/s", "steps": n,
+                                "streams_per_gpu": 1}
+        rec1 = profiler.start()
+        timed(lambda i: r1.step(i, 1), n)
+        profiler.stop()
+        st1 = rec1.summary()
+        ent["stages_ms_per_step"] = {k: v["ms_total"] / n for k, v in sorted(st1.items())}
+        ent["roofline"] = roofline_of(st1, pmc_traffic(mname, B1, L),
+                                      "one batch at a time: %d workgroups of 4 chunks on 256 CUs" % (B1 // 4))
+        r1.set_in_flight(nfl)
+        for i in range(2 * nfl):
+            r1.step(i, nfl)
+        n8 = args.small_batch_steps * nfl
+        d = timed(lambda i: r1.step(i, nfl), n8)
+        ent["eight_in_flight"] = {"ms_per_step": d / n8 * 1e3, "value": B1 * L * n8 / d, "unit": "samples/s", "steps": n8,
+                                  "streams_per_gpu": nfl}
+        small[mname] = ent
+        del r1, rec1, st1
+    return small
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def main_train(args, as_field=False, torch=None, dist=None):
     """One step = wrap_network's fg(x, labels, weights, rate) on one batch per GPU (bin/train_network.py:308).  With `as_field`
@@ -451,6 +500,11 @@ def main():
     if args.train:
         return main_train(args)
     import torch
+    if args.only == "batch256":
+        from sloika_amd import _lib as _l
+        _l.require_gpu()
+        print(json.dumps(leg_batch256(args, torch)))
+        return
     from sloika_amd import _lib, layers as _layers, pipeline, profiler, shard
     rank, world, local_rank = shard.dist_info()
     _lib.require_gpu()
@@ -507,6 +561,15 @@ def main():
             roofline["measured"] = "HIP events on the launch stream over %d steps issued right after the timed region " \
                                    "(the timed region itself carries no events)" % args.stage_steps
 
+    def release():
+        """torch's allocator caches device memory per stream; a leg that ran on side streams leaves tens of gigabytes reserved for
+        streams that no longer exist, and the legs behind it then run into allocator garbage collection (measured: the training
+        step 50 instead of 23 ms, the whole-read leg 330 instead of 510 M samples/s).  Every leg hands its cache back."""
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
     line_extra = {}
     if extras:
         # ---- every product in plain float32 MFMA (no fp16 splits anywhere) ----
@@ -557,6 +620,7 @@ def main():
                                  "note": "ms_per_step is per %d chunks; one call carries %d batches" % (B, mult)}
                     del big, outb
             line_extra["in_flight"] = infl
+            release()
 
         # ---- the step including the upload of the next batch's raw signal (pinned host memory -> HBM on the copy stream) ----
         if args.upload_steps > 0 and not args.with_bases:
@@ -569,34 +633,22 @@ def main():
                                          "note": "float32 raw signal of the NEXT batch uploaded from pinned host memory on the "
                                                  "copy stream while this batch runs; `value` of the line excludes it"}
 
-        # ---- the batch north_star quotes (256 chunks): configs[1] and the metric's own model, each with its roofline ----
+        # ---- the batch north_star quotes (256 chunks), in a CHILD process: eight batches in flight, each with side streams for
+        # the directions of a birnn, create more HIP streams than the device has hardware queues, and from then on every queue
+        # of the process is time-sliced (measured: the legs behind this one ran at half speed).  A child gets queues of its own
+        # and gives them back when it exits; the parent's queues idle meanwhile. ----
         if args.small_batch_steps > 0 and args.model == "raw_0.98_rgrgr" and B == 1024 and not args.with_bases:
-            small = {}
+            import subprocess
+            torch.cuda.synchronize()
+            line_extra["batch256"] = {}
             for mname in ("baseline_raw_gru", "raw_0.98_rgrgr"):
-                B1, nfl = 256, 8
-                r1 = Runner(torch, mname, B1, L, nfl)
-                ent = {"workload": "%s inference, %d-sample chunks, batch %d%s" % (
-                    mname, L, B1, " (BASELINE.json configs[1])" if mname == "baseline_raw_gru" else " (the metric's model at the "
-                    "north star's batch)")}
-                for nact, key in ((1, "one_at_a_time"), (nfl, "eight_in_flight")):
-                    r1.set_in_flight(nact)
-                    for i in range(2 * nact):
-                        r1.step(i, nact)
-                    n = args.small_batch_steps * nact
-                    d = timed(lambda i: r1.step(i, nact), n)
-                    ent[key] = {"ms_per_step": d / n * 1e3, "value": B1 * L * n / d, "unit": "samples/s", "steps": n,
-                                "streams_per_gpu": nact}
-                r1.set_in_flight(1)
-                rec1 = profiler.start()
-                timed(lambda i: r1.step(i, 1), args.small_batch_steps)
-                profiler.stop()
-                st1 = rec1.summary()
-                ent["stages_ms_per_step"] = {k: v["ms_total"] / args.small_batch_steps for k, v in sorted(st1.items())}
-                ent["roofline"] = roofline_of(st1, pmc_traffic(mname, B1, L),
-                                              "one batch at a time: %d workgroups of 4 chunks on 256 CUs" % (B1 // 4))
-                small[mname] = ent
-                del r1
-            line_extra["batch256"] = small
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only", "batch256", "--model", mname,
+                                    "--small-batch-steps", str(args.small_batch_steps), "--chunk-len", str(L)],
+                                   stdout=subprocess.PIPE, text=True)
+                try:
+                    line_extra["batch256"].update(json.loads(r.stdout.strip().split("\n")[-1]))
+                except (ValueError, IndexError):
+                    line_extra["batch256"][mname] = {"error": "child process failed (exit code %d)" % r.returncode}
 
         # ---- whole reads (the reference's inference mode), bucketed by length, ragged batches in flight ----
         if args.whole_reads > 0 and not args.with_bases:
@@ -629,12 +681,15 @@ def main():
                 "from_host_arrays": {"value": sum(nsamp) / d_all, "unit": "samples/s", "seconds": d_all},
                 "batches": wst["batches"], "padded_step_waste": wst["padded_step_waste"],
                 "bases_called": int(sum(len(p) for p in paths))}
-            del batches, paths2, lanes
-            del reads, paths
+            del batches, paths2, lanes, scores, paths, scores2
+            release()
+            del reads
 
         # ---- a few steps of the training step (BASELINE.json configs[4] on this GPU) ----
         if args.train_steps > 0 and not args.with_bases:
+            release()
             line_extra["train"] = main_train(args, as_field=True, torch=torch, dist=None)
+            release()
 
 
         # ---- sustained load, LAST (the device throttles for a while after it: every other leg would pay): >= N seconds of
