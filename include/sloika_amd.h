@@ -364,6 +364,44 @@ SLK_API int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const in
                                   const double *prior_initial, const double *prior_final, void *workspace,
                                   const int64_t *ws_off, float *score_out, int32_t *path_out, slk_stream_t stream);
 
+/* f3, second half: the labels of raw_chunkify (sloika/tools/chunkify_raw.py:164-210), from the mapping table raw_remap
+ * (chunkify_raw.py:260-296) produces.  Integer work, bit-exact.  `alphabet` is a HOST string of `nbase` <= 8 letters
+ * (batch.init_chunk_identity_worker's alphabet, sloika/batch.py:17-27); every other pointer is device memory.
+ * `status` (device int, zeroed by the caller) gets bit 0 set for a letter outside the alphabet and bit 1 for a reference
+ * position outside the reference string -- the cases in which the reference's `batch.kmer_to_state[...]` raises KeyError.
+ *
+ * slk_kmer_labels_i32 = labels_from_mapping_table (chunkify_raw.py:117-136): kmers:[n][old_klen] bytes (the table's 'kmer'
+ *   column), labels_out[i] = state of the middle `klen` letters + index_from, or -1 for a foreign letter. */
+SLK_API int slk_kmer_labels_i32(const uint8_t *kmers, int64_t n, int old_klen, int klen, const char *alphabet, int nbase,
+                                int index_from, int32_t *labels_out, int *status, slk_stream_t stream);
+/* slk_raw_chunk_labels_i32 = the non-interpolated branch (chunkify_raw.py:194-204) for `nread` reads in one launch (the
+ * reference runs one read per worker call, chunkify_raw.py:299-337).  The tables are the TRIMMED ones (after
+ * trim_signal_and_mapping(signal, table, 0, nchunk*chunk_len), chunkify_raw.py:174), concatenated:
+ *   start, move:[sum nevent] int64 columns; event_label:[sum nevent] = slk_kmer_labels_i32 of the 'kmer' column;
+ *   ev_off:[nread+1]; nchunk:[nread] chunks of read b; lab_off:[nread] offset (in elements) of read b's
+ *   [nchunk_b][ceil(chunk_len / downsample)] int32 labels inside labels_out; max_nchunk = max(nchunk).
+ * workspace: slk_raw_chunk_labels_workspace_bytes(sum nevent) bytes. */
+SLK_API size_t slk_raw_chunk_labels_workspace_bytes(int64_t nevent);
+SLK_API int slk_raw_chunk_labels_i32(const int64_t *start, const int64_t *move, const int32_t *event_label,
+                                     const int64_t *ev_off, int nread, const int64_t *nchunk, const int64_t *lab_off,
+                                     int64_t max_nchunk, int chunk_len, int downsample, void *workspace,
+                                     size_t workspace_bytes, int32_t *labels_out, slk_stream_t stream);
+/* slk_raw_chunk_labels_interp_i32 = the interpolated branch (chunkify_raw.py:187-193 with interpolate_pos /
+ * interpolate_labels :86-114) for one read: label o belongs to sample o * downsample; position = np.interp over the block
+ * mid-times in float64, evaluated like numpy's C loop, then np.around(. - 0.5 * klen + 1e-10).
+ *   forward != 0: direction '+', ref_anchor = ref_start;  forward == 0: direction '-', ref_anchor = ref_stop.
+ *   map_klen = length of the table's k-mers; reference:[ref_len] bytes; pos_out (optional):[nlabel] int64 positions.
+ *   times (optional):[nlabel] float64 -- the caller's own times (the closures interpolate_pos / interpolate_labels return
+ *   take any), instead of o * downsample;  zero_repeats != 0 applies line :191 (raw_chunkify), 0 leaves every label.
+ * labels_out[o] = state + 1 of reference[pos:pos+klen], 0 where pos repeats the previous label's, -1 on a status error;
+ * labels_out may be NULL when only positions are wanted (then reference / alphabet are not read). */
+SLK_API int slk_raw_chunk_labels_interp_i32(const int64_t *start, const int64_t *length, const int64_t *seq_pos,
+                                            int64_t nevent, int map_klen, int forward, int64_t ref_anchor,
+                                            const uint8_t *reference, int64_t ref_len, int klen, const char *alphabet,
+                                            int nbase, int64_t nlabel, int downsample, const double *times,
+                                            int zero_repeats, int32_t *labels_out, int64_t *pos_out, int *status,
+                                            slk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * f2. The training step: bin/train_network.py:124-142 (`wrap_network`: loss, accuracy, th.grad, updates.adam) and
  * sloika/updates.py:9-103.  The reference crosses into Theano once per batch (`fg(indata, labels, weights, rate)`,

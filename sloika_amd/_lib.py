@@ -73,6 +73,11 @@ PROTOTYPES = {
     "slk_map_to_sequence_workspace_bytes": (_sz, [_i, _i]),
     "slk_map_to_sequence_f32": (_i, [_vp, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "slk_map_to_sequence_batch_f32": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "slk_kmer_labels_i32": (_i, [_vp, _l, _i, _i, C.c_char_p, _i, _i, _vp, _vp, _vp]),
+    "slk_raw_chunk_labels_workspace_bytes": (_sz, [_l]),
+    "slk_raw_chunk_labels_i32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp, _sz, _vp, _vp]),
+    "slk_raw_chunk_labels_interp_i32": (_i, [_vp, _vp, _vp, _l, _i, _i, _l, _vp, _l, _i, C.c_char_p, _i, _l, _i, _vp, _i, _vp, _vp,
+                                             _vp, _vp]),
     "slk_activation_f32": (_i, [_vp, _vp, _sz, _i, _vp]),
     "slk_train_pack_xh_f32": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp]),
     "slk_train_pack_xrh_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),

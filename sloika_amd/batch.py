@@ -152,3 +152,28 @@ def chunks_to_network_input(chunks):
     if isinstance(chunks, torch.Tensor):
         return chunks.t().contiguous()[:, :, None]
     return np.ascontiguousarray(np.asarray(chunks).T)[:, :, None]
+
+
+#: process-global set by init_chunk_identity_worker / init_chunk_remap_worker (sloika/batch.py:127-140)
+kmer_to_state = None
+kmer_alphabet = None
+calc_post = None
+
+
+def init_chunk_identity_worker(kmer_len, alphabet):
+    """sloika/batch.py:127-129: the k-mer -> state dictionary of this process (and the alphabet it was built from, which the
+    device-side label kernels take instead of a dictionary)."""
+    global kmer_to_state, kmer_alphabet
+    from . import bio
+    kmer_to_state = bio.kmer_mapping(kmer_len, alphabet=alphabet)
+    kmer_alphabet = alphabet if isinstance(alphabet, bytes) else alphabet.encode('ascii')
+
+
+def init_chunk_remap_worker(model, kmer_len, alphabet):
+    """sloika/batch.py:132-140: as above, plus the compiled model in the process-global `calc_post`.  `model` is a model file
+    name or a Layer."""
+    global calc_post
+    from . import helpers, layers
+    init_chunk_identity_worker(kmer_len, alphabet)
+    net = model if isinstance(model, layers.Layer) else helpers.load_model(model)
+    calc_post = net.compile()

@@ -29,4 +29,10 @@ def install(force=False):
         mod = importlib.import_module("sloika_amd." + name)
         sys.modules["sloika." + name] = mod
         setattr(pkg, name, mod)
+    tools = types.ModuleType("sloika.tools")                   # sloika/tools/chunkify_raw.py
+    tools.__path__ = []
+    tools.chunkify_raw = importlib.import_module("sloika_amd.chunkify_raw")
+    sys.modules["sloika.tools"] = tools
+    sys.modules["sloika.tools.chunkify_raw"] = tools.chunkify_raw
+    pkg.tools = tools
     return pkg
