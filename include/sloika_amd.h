@@ -357,7 +357,7 @@ SLK_API int slk_map_to_sequence_f32(const float *ltrans, int nev, int nst, const
  *   ev_off:[nread+1] int64 -- read b owns rows ev_off[b]..ev_off[b+1] of ltrans ([sum nev][nst]) and of path_out;
  *   pos_off:[nread+1] int64 -- ... and positions pos_off[b]..pos_off[b+1] of seq / prior_initial / prior_final;
  *   ws_off:[nread] int64 -- offset (in int32 elements) of read b's nev_b*npos_b traceback inside `workspace`;
- *   max_npos = the longest sequence (sizes the LDS request; npos <= 3276); score_out:[nread].
+ *   max_npos = the longest sequence (sizes the LDS request: 28 bytes per position of the 160 KB, npos <= 5851); score_out:[nread].
  * A read with fewer than 3 positions or no events gets score -inf and its path is left untouched. */
 SLK_API int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *ev_off, const int32_t *seq,
                                   const int64_t *pos_off, int nread, int max_npos, float slip,

@@ -1,5 +1,6 @@
 """GPU parity: slip_update and map_to_sequence through the C ABI, bit exact against reference goldens."""
 import hashlib
+import zlib
 
 import numpy as np
 import pytest
@@ -93,3 +94,44 @@ def test_map_to_sequence_batch_equals_goldens_and_single_calls(oracle, golden_ca
         assert np.array_equal(paths[b], p1) and float(scores[b]) == float(s1)
     with pytest.raises(ValueError):
         transducer.map_to_sequence_batch(trans, seqs[:2], 2.5)
+
+
+def _slip_inputs(rs, n, kind):
+    if kind == "noise":
+        return (rs.normal(size=n) * 8 - 200).astype(np.float32)
+    if kind == "falling":                      # every value below the decayed chain: one chain owns the whole array
+        return (-np.arange(n) * 7.0 - rs.uniform(0, 1, size=n)).astype(np.float32)
+    if kind == "rising":                       # every value beats the chain
+        return (np.arange(n) * 0.37 - 900 + rs.uniform(0, 0.1, size=n)).astype(np.float32)
+    if kind == "flat":
+        return np.full(n, -123.456, dtype=np.float32)
+    if kind == "ridge":                        # remap-like: a peak, slow decay to the right (about the slip rate), cliffs
+        peak = rs.randint(0, n)
+        x = -np.abs(np.arange(n) - peak) * rs.choice([1.0, 4.9, 5.0, 5.1]) - 300 + rs.normal(size=n) * 0.7
+        x[rs.randint(0, n, size=max(1, n // 40))] -= 400
+        return x.astype(np.float32)
+    if kind == "ties":                         # small integers: decayed values collide exactly all the time
+        return rs.randint(-12, 0, size=n).astype(np.float32) * 2.5
+    if kind == "neginf":
+        x = (rs.normal(size=n) * 3 - 50).astype(np.float32)
+        x[rs.uniform(size=n) < 0.3] = -np.inf
+        if rs.uniform() < 0.5:
+            x[0] = -np.inf
+        return x
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["noise", "falling", "rising", "flat", "ridge", "ties", "neginf"])
+def test_slip_update_wave_scan_is_the_sequential_recurrence(oracle, kind):
+    """The 64-lane evaluation (csrc/transducer.hip slip_scan_wave) against the sequential oracle, bit for bit, on inputs
+    built to exercise every branch: chains that die at once, chains that survive many segments, exact ties, -inf."""
+    need_gpu()
+    from sloika_amd import viterbi_helpers
+    rs = np.random.RandomState(zlib.crc32(kind.encode()) % 10000)
+    for n in [3, 4, 5, 6, 63, 64, 65, 66, 67, 129, 130, 131, 194, 257, 500, 1000, 2047, 4099, 20000]:
+        for slip in (5.0, 2.5, 0.1, 0.0, 37.25):
+            x = _slip_inputs(rs, n, kind)
+            fs, fp = viterbi_helpers.slip_update(x, slip)
+            wfs, wfp = oracle.slip_update(x, slip)
+            assert np.array_equal(fs.view(np.uint32), np.asarray(wfs, dtype=np.float32).view(np.uint32)), (kind, n, slip)
+            assert np.array_equal(fp, wfp), (kind, n, slip)
