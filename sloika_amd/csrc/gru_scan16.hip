@@ -8,6 +8,11 @@
 // two steps ahead -- and the weights of a wave (2 tiles x 3 gates x 4 K blocks x hi/lo = 192 registers) do not fit next to
 // its working set: the update gate's and the candidate's live in accumulation registers and their MFMAs are asm (bar16_common.h).
 // Sizes below 128 (a multiple of 16) run with zero weights for the missing neurons: their state stays exactly 0.
+//
+// n = 144 (the middle layer of models/pretrained.pkl; 142 padded, models/raw_1.00_rGr.py) is the N = 160 instantiation: five K
+// blocks, the same four chain waves for neurons 0..127, and a NINTH tile (neurons 128..143) that wave 3 carries on top of its two --
+// its weights (3 gates x 5 K blocks x hi/lo, 30 KB) live in LDS and are fetched as A operands when they are needed, every
+// other register of that wave being taken.  Wave 3's 135 MFMAs per step set the pace (the others issue 90).
 #include <limits.h>
 
 #include "bar16_common.h"
@@ -36,14 +41,18 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
                                                             const float *__restrict__ sW2, float *__restrict__ h_out, long ldh, int T,
                                                             int B, int n, int reverse, const int *__restrict__ lens)
 {
-    static_assert(N == 128, "four chain waves of 32 neurons");
+    static_assert(N == 128 || N == 160, "four chain waves of 32 neurons (+ a ninth tile on wave 3)");
     constexpr int KBS = N / 32;
+    constexpr bool T9 = N == 160;
+    constexpr int NV = T9 ? 3 : 2;                       // (neuron, chunk) pairs a lane requests per step
 
     __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * N], h_lo[2 * N], rh_hi[2 * N], rh_lo[2 * N];
+    // the ninth tile's A operands: [gate r, z, c][K block][hi, lo][lane] x 16 bytes
+    __shared__ __attribute__((aligned(16))) unsigned w9[T9 ? 3 * KBS * 2 * 64 * 4 : 4];
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
-    for (int i = tid; i < 2 * N; i += 256) { h_hi[i] = 0u; h_lo[i] = 0u; }             // h(-1) = 0
+    for (int i = tid; i < 2 * N; i += 256) { h_hi[i] = 0u; h_lo[i] = 0u; rh_hi[i] = 0u; rh_lo[i] = 0u; }      // h(-1) = 0
     auto ldH = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
 
     const int c = lane & 3, q = (lane >> 2) & 3, g = lane >> 4;
@@ -91,6 +100,50 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         for (int i = 0; i < KBS; i++) {
             wz_hi[p][i] = to_acc_regs(wz_hi[p][i]); wz_lo[p][i] = to_acc_regs(wz_lo[p][i]);
             wc_hi[p][i] = to_acc_regs(wc_hi[p][i]); wc_lo[p][i] = to_acc_regs(wc_lo[p][i]);
+            if constexpr (T9) {     // five K blocks: the reset gate's weights too (240 of the 256), or in-flight vI registers get spilled
+                wr_hi[p][i] = to_acc_regs(wr_hi[p][i]); wr_lo[p][i] = to_acc_regs(wr_lo[p][i]);
+            }
+        }
+    }
+    float inv9[3] = {1.0f, 1.0f, 1.0f};                  // r, z, c
+    const bool w3 = __builtin_amdgcn_readfirstlane(w) == 3;
+    auto w9at = [&](int gate, int i, int hl) { return reinterpret_cast<half8 *>(w9 + (((gate * KBS + i) * 2 + hl) * 64 + lane) * 4); };
+    if constexpr (T9) {
+        if (w3) {                                        // K blocks stored in wave 3's rotated order: slot i holds block (3 + i) % KBS
+            const int row = 128 + (lane & 15);
+            const bool rok = row < n;
+#pragma unroll
+            for (int gate = 0; gate < 3; gate++) {
+                const float *src = gate == 0 ? sW + (size_t)(n + row) * n : gate == 1 ? sW + (size_t)row * n : sW2 + (size_t)row * n;
+                float v[KBS][8];
+                float m = 0.0f;
+#pragma unroll
+                for (int i = 0; i < KBS; i++) {
+                    const int kb = (3 + i) % KBS;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int k = 32 * kb + 16 * (j & 1) + 4 * g + (j >> 1);
+                        v[i][j] = (rok && k < n) ? src[k] : 0.0f;
+                        m = fmaxf(m, fabsf(v[i][j]));
+                    }
+                }
+                float iv;
+                const float sc = pow2_scale(kgroup_max(m), iv);
+                inv9[gate] = __shfl(iv, 4 * g + q);
+#pragma unroll
+                for (int i = 0; i < KBS; i++) {
+                    half8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float a = v[i][j] * sc;
+                        const _Float16 h = (_Float16)a;
+                        hi[j] = h;
+                        lo[j] = (_Float16)(a - (float)h);
+                    }
+                    *w9at(gate, i, 0) = hi;
+                    *w9at(gate, i, 1) = lo;
+                }
+            }
         }
     }
     int boff[KBS];
@@ -99,6 +152,9 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
     const int wd = ((w * 4 + g) * 4 + c) * 4 + q;                                           // my packed pair, in dwords
     const int n0 = 32 * w + 4 * g + q;                                                      // my neuron of tile 2w (+16: 2w+1)
     const bool nok0 = n0 < n, nok1 = n0 + 16 < n;
+    const int n9 = 128 + 4 * g + q;                                                         // ninth tile: my neuron (wave 3)
+    const bool nok9 = T9 && n9 < n;
+    const int wd9 = ((4 * 4 + g) * 4 + c) * 4 + q;
     // my chunk's rows (ragged batch: chunk bc is Tc <= T steps long; a reversed scan starts at ITS last step)
     const int bc = b0 + c;
     const bool live = bc < B;
@@ -112,19 +168,21 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
     // flight.  The loads are asm (the compiler would wait for ALL outstanding memory operations at the first use -- the wave also has
     // stores in flight); loads complete in order among themselves, so once at most 18 operations are outstanding (the loads of the
     // three younger steps) those of the current step have arrived, whatever the stores do.
-    struct VI { float z[2], r[2], c[2]; };
+    struct VI { float z[NV], r[NV], c[NV]; };
     VI vs[4];
     // addresses: three wave-uniform bases (z | r | c block of row 0) + this lane's byte offset of the step being requested, which
     // advances by one time step per request until the chunk's last row (requests past it re-read that row); the caller refuses
     // projections of 4 GiB and more
     const float *sb_z = vI, *sb_r = vI + n, *sb_c = vI + 2 * n;
     const unsigned tile1 = nok1 ? 64u : 0u;                                       // bytes to my neuron of tile 2w+1
+    const unsigned tile9 = (nok9 && nok0) ? (unsigned)(128 - 32 * w) * 4u : 0u;  // ... of the ninth tile (every wave requests it: one count)
     unsigned voff = (unsigned)((((size_t)(reverse ? Tc - 1 : 0) * B + bcc) * ldv + (nok0 ? n0 : 0)) * sizeof(float));
     const unsigned vstep = (unsigned)((size_t)B * ldv * sizeof(float));
     int vnext = 0;                                                                // step the next request is for
     auto load_vi = [&](int, VI &v) {
         gload1_s(v.z[0], voff, sb_z); gload1_s(v.r[0], voff, sb_r); gload1_s(v.c[0], voff, sb_c);
         gload1_s(v.z[1], voff + tile1, sb_z); gload1_s(v.r[1], voff + tile1, sb_r); gload1_s(v.c[1], voff + tile1, sb_c);
+        if constexpr (T9) { gload1_s(v.z[2], voff + tile9, sb_z); gload1_s(v.r[2], voff + tile9, sb_r); gload1_s(v.c[2], voff + tile9, sb_c); }
         vnext++;
         if (vnext < Tc) voff = reverse ? voff - vstep : voff + vstep;
     };
@@ -134,6 +192,24 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
 
     __syncthreads();                                     // LDS initialised
     float hold[2] = {0.0f, 0.0f};
+    float hold9 = 0.0f;
+    // one gate of the ninth tile: sum over the K blocks of the 3-term split, A operands from LDS (slot i <-> my block order)
+    auto tile9_mfma = [&](int gate, const half8 *bhh, const half8 *bll) __attribute__((always_inline)) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        half8 ah = *w9at(gate, 0, 0), al = *w9at(gate, 0, 1);
+#pragma unroll
+        for (int i = 0; i < KBS; i++) {
+            half8 nh = ah, nl = al;
+            if (i + 1 < KBS) { nh = *w9at(gate, i + 1, 0); nl = *w9at(gate, i + 1, 1); }       // in flight under this block's MFMAs
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bll[i], acc, 0, 0, 0);
+            if (i == 0) asm volatile("" : "+v"(acc) : "v"(ah), "v"(al), "v"(bll[0]), "v"(bhh[0]));     // see gemm_rows_f16x3.hip
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bhh[i], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bhh[i], acc, 0, 0, 0);
+            ah = nh;
+            al = nl;
+        }
+        return acc;
+    };
     half8 oh = {0, 0, 0, 0, 0, 0, 0, 0}, ol = {0, 0, 0, 0, 0, 0, 0, 0};      // my own K block of h(s-1) as B operand
     auto step = [&](auto PHC, const int s) {
         constexpr int ph = decltype(PHC)::value;
@@ -148,7 +224,8 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         if constexpr (!(SCAN16_ABL & 4)) load_vi(s + 3, vs[(ph + 3) & 3]);                // three steps ahead
         __builtin_amdgcn_sched_barrier(0);
         f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2], accC[2];
-        mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
+        if constexpr (T9) z_block_mfma<true>(accR[0], accR[1], wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0]);
+        else mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
 #if SCAN16_Z0_EARLY
         z_block_mfma<true>(accZ[0], accZ[1], wz_hi[0][0], wz_lo[0][0], wz_hi[1][0], wz_lo[1][0], bh[0], bl[0]);
 #endif
@@ -158,8 +235,14 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 1; i < KBS; i++)
-            mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
+        for (int i = 1; i < KBS; i++) {
+            if constexpr (T9) z_block_mfma<false>(accR[0], accR[1], wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i]);
+            else mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
+        }
+        f32x4 acc9 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (T9) {
+            if (w3) acc9 = tile9_mfma(0, bh, bl);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // z products of blocks 0 .. KBS-2 under the r epilogue
 #if !SCAN16_Z0_EARLY
@@ -169,8 +252,13 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
             constexpr int i = decltype(IC)::value;
             z_block_mfma<false>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i]);
         });
-        if constexpr (!(SCAN16_ABL & 5)) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");                 // this step's vI (see above)
+        if constexpr (!(SCAN16_ABL & 5)) {                                                                  // this step's vI (see above)
+            if constexpr (T9) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        }
         pin_f(cur.z[0]); pin_f(cur.z[1]); pin_f(cur.r[0]); pin_f(cur.r[1]); pin_f(cur.c[0]); pin_f(cur.c[1]);
+        if constexpr (T9) { pin_f(cur.z[2]); pin_f(cur.r[2]); pin_f(cur.c[2]); }
+        if constexpr (T9) { mfma_drain(accR[0]); mfma_drain(accR[1]); }       // asm MFMAs: the compiler keeps no distance for them
         float rr[2];
         rr[0] = nok0 ? sigmoid4(fmaf(sel4(accR[0], q), inv_r[0], cur.r[0])) : 0.0f;
         rr[1] = nok1 ? sigmoid4(fmaf(sel4(accR[1], q), inv_r[1], cur.r[1])) : 0.0f;
@@ -180,6 +268,15 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
             lds_fence();
             rh_hi[wd] = hi;
             rh_lo[wd] = lo;
+        }
+        if constexpr (T9) {
+            if (w3) {
+                const float rr9 = nok9 ? sigmoid4(fmaf(sel4(acc9, q), inv9[0], cur.r[2])) : 0.0f;
+                unsigned hi, lo;
+                split2(rr9 * hold9, 0.0f, hi, lo);
+                rh_hi[wd9] = hi;
+                rh_lo[wd9] = lo;
+            }
         }
         half8 ch[KBS], cl[KBS];
         ch[0] = ldH(rh_hi, boff[0]);                     // my own block, straight back (LDS executes a wave's operations in order)
@@ -213,6 +310,13 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
             constexpr int i = decltype(IC)::value;
             z_block_mfma<false>(accC[0], accC[1], wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i]);
         });
+        f32x4 acc9z = {0.f, 0.f, 0.f, 0.f}, acc9c = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (T9) {
+            if (w3) {
+                acc9z = tile9_mfma(1, bh, bl);
+                acc9c = tile9_mfma(2, ch, cl);
+            }
+        }
         mfma_drain(accC[0]);
         mfma_drain(accC[1]);
         float hn[2];
@@ -228,16 +332,32 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
             h_hi[wd] = hi;
             h_lo[wd] = lo;
         }
+        float hn9 = 0.0f;
+        if constexpr (T9) {
+            if (w3) {
+                const float z9 = sigmoid4(fmaf(sel4(acc9z, q), inv9[1], cur.z[2]));
+                const float hb9 = tanh5(fmaf(sel4(acc9c, q), inv9[2], cur.c[2]));
+                hn9 = nok9 ? fmaf(1.0f - z9, hb9, z9 * hold9) : 0.0f;
+                unsigned hi, lo;
+                split2(hn9, 0.0f, hi, lo);
+                h_hi[wd9] = hi;
+                h_lo[wd9] = lo;
+            }
+        }
         oh = ldH(h_hi, boff[0]);
         ol = ldH(h_lo, boff[0]);
         lds_fence();
         if (live && s < Tc && !(SCAN16_ABL & 2)) {
             if (nok0) hp[0] = hn[0];
             if (nok1) hp[16] = hn[1];
+            if constexpr (T9) {
+                if (w3 && nok9) hp[32] = hn9;                 // neuron 128 + 4g + q = n0 + 32 for wave 3
+            }
         }
         hp += hstep;
         hold[0] = hn[0];
         hold[1] = hn[1];
+        hold9 = hn9;
     };
     for (int s = 0; s < T; s += 4) {
         step(ic<0>{}, s);
@@ -249,13 +369,14 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
 }
 
 // One workgroup per CU: ask for enough dynamic LDS that two cannot share a CU (each wave is compiled for a whole SIMD's registers).
+template <int N>
 static size_t scan16_exclusive_lds()
 {
     hipFuncAttributes attr;
-    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(gru_scan16_kernel<128>)) != hipSuccess) return 0;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(gru_scan16_kernel<N>)) != hipSuccess) return 0;
     const size_t half_cu = 80 * 1024 + 512;
     const size_t dyn = attr.sharedSizeBytes >= half_cu ? 0 : half_cu - attr.sharedSizeBytes;
-    if (dyn && hipFuncSetAttribute(reinterpret_cast<const void *>(gru_scan16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (dyn && hipFuncSetAttribute(reinterpret_cast<const void *>(gru_scan16_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)dyn) != hipSuccess)
         return 0;
     return dyn;
@@ -267,9 +388,15 @@ extern "C" int slk_gru_scan16_f32(const float *vI, long ldv, const float *sW, co
 {
     if (!vI || !sW || !sW2 || !y || T < 1 || B < 1 || n < 1 || ldv < 3L * n || ldy < n) return SLK_ERR_INVALID_ARG;
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
-    if (n % 16 || n <= 96 || n > 128) return SLK_ERR_UNSUPPORTED;
+    if (n % 16 || n <= 96 || n > 144) return SLK_ERR_UNSUPPORTED;
     if ((unsigned long long)T * B * ldv * sizeof(float) >= (1ull << 32)) return SLK_ERR_UNSUPPORTED;       // 32-bit lane offsets
-    const size_t dyn = SLK_PER_DEVICE(size_t, scan16_exclusive_lds());
+    if (n > 128) {
+        const size_t dyn = SLK_PER_DEVICE(size_t, scan16_exclusive_lds<160>());
+        hipLaunchKernelGGL((gru_scan16_kernel<160>), dim3((B + 3) / 4), dim3(256), dyn, slk_stream(stream), vI, ldv, sW, sW2, y, ldy, T, B,
+                           n, reverse & 1, lens);
+        return slk_launch_status();
+    }
+    const size_t dyn = SLK_PER_DEVICE(size_t, scan16_exclusive_lds<128>());
     hipLaunchKernelGGL((gru_scan16_kernel<128>), dim3((B + 3) / 4), dim3(256), dyn, slk_stream(stream), vI, ldv, sW, sW2, y, ldy, T, B, n,
                        reverse & 1, lens);
     return slk_launch_status();

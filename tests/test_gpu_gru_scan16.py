@@ -1,4 +1,4 @@
-"""csrc/gru_scan16.hip -- the Gru scan for layers too wide for the fused kernels (n = 112 / 128: models/pretrained.pkl,
+"""csrc/gru_scan16.hip -- the Gru scan for layers too wide for the fused kernels (n = 112 / 128 / 144: models/pretrained.pkl,
 raw_1.00_rGr zero-padded) on the barrier-stepped fp16-split plan -- through the C ABI, against the oracle (float32 C port,
 itself pinned to the reference's layers.py by tests/test_oracle_reference_layers.py)."""
 import numpy as np
@@ -22,7 +22,7 @@ def _scan(L, vI, ldv, sW, sW2, y, ldy, T, B, n, reverse, lens=None):
                                 None if lens is None else lens.data_ptr(), stream())
 
 
-@pytest.mark.parametrize("n", [112, 128])
+@pytest.mark.parametrize("n", [112, 128, 144])
 @pytest.mark.parametrize("T,B,reverse", [(23, 9, False), (8, 4, True), (3, 2, False), (1, 1, True), (41, 5, True), (100, 33, False)])
 def test_scan16_vs_oracle(oracle, n, T, B, reverse):
     torch = need_gpu()
@@ -45,7 +45,7 @@ def test_scan16_vs_oracle(oracle, n, T, B, reverse):
     assert err < 2e-5, err
 
 
-@pytest.mark.parametrize("n", [112, 128])
+@pytest.mark.parametrize("n", [112, 128, 144])
 def test_scan16_ragged(oracle, n):
     """Each chunk of a ragged batch must equal the call on the chunk alone at its own length, reversed scans included; rows past
     a chunk's end stay untouched."""
@@ -73,13 +73,14 @@ def test_scan16_ragged(oracle, n):
             assert np.isnan(out[tb:, bb]).all()
 
 
-def test_scan16_weights_as_trained_and_determinism(oracle):
+@pytest.mark.parametrize("n", [112, 144])
+def test_scan16_weights_as_trained_and_determinism(oracle, n):
     """|w| up to 6 with saturating gates, as in models/pretrained.pkl; and a kernel whose waves exchange data through LDS without
     enough ordering gives different bits from launch to launch: every launch must reproduce the first."""
     torch = need_gpu()
     from sloika_amd import _lib
     L = _lib.lib()
-    n, I, T, B = 112, 128, 40, 1021
+    I, T, B = 128, 40, 1021
     rs = np.random.RandomState(5)
     iW, sW, sW2, b = _params(rs, I, n, scale=2.0)
     sW2[rs.randint(0, n, 40), rs.randint(0, n, 40)] = rs.choice([-6.0, 6.0, 4.5], size=40)
@@ -105,7 +106,7 @@ def test_scan16_unsupported_shapes_are_refused():
     from sloika_amd import _lib
     L = _lib.lib()
     z = torch.zeros(4096, device="cuda")
-    for n, act, gate in [(144, 1, 2), (96, 1, 2), (120, 1, 2), (128, 2, 2)]:
+    for n, act, gate in [(160, 1, 2), (96, 1, 2), (120, 1, 2), (128, 2, 2), (144, 1, 1)]:
         assert L.slk_gru_scan16_f32(z.data_ptr(), 3 * n, z.data_ptr(), z.data_ptr(), z.data_ptr(), n, 1, 1, n, 0, act, gate, None,
                                     stream()) == _lib.SLK_ERR_UNSUPPORTED
     assert L.slk_gru_scan16_f32(None, 384, z.data_ptr(), z.data_ptr(), z.data_ptr(), 128, 1, 1, 128, 0, 1, 2, None, stream()) == _lib.SLK_ERR_INVALID_ARG

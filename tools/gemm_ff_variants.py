@@ -7,7 +7,10 @@ lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bui
 st = torch.cuda.current_stream().cuda_stream
 NV = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 vp, i_, l_ = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
-for M, K, N in [(2000 * 1024, 192, 128), (2000 * 256, 128, 64), (800 * 1024, 288, 96)]:
+SHAPES = [(2000 * 1024, 192, 128), (2000 * 256, 128, 64), (800 * 1024, 288, 96)]
+if os.environ.get("SHAPES"):          # e.g. SHAPES=819200:128:336,819200:112:432  (the Gru projections of models/pretrained.pkl)
+    SHAPES = [tuple(int(v) for v in t.split(":")) for t in os.environ["SHAPES"].split(",")]
+for M, K, N in SHAPES:
     x = torch.tanh(torch.randn(M, K, device="cuda")); W = torch.randn(N, K, device="cuda") * 0.5; b = torch.randn(N, device="cuda")
     KP = (K + 15) // 16 * 16
     hi = torch.empty(N, KP, dtype=torch.float16, device="cuda"); lo = torch.empty_like(hi); inv = torch.empty(N, device="cuda")
