@@ -10,9 +10,11 @@
 // Sizes below 128 (a multiple of 16) run with zero weights for the missing neurons: their state stays exactly 0.
 //
 // n = 144 (the middle layer of models/pretrained.pkl; 142 padded, models/raw_1.00_rGr.py) is the N = 160 instantiation: five K
-// blocks, the same four chain waves for neurons 0..127, and a NINTH tile (neurons 128..143) that wave 3 carries on top of its two --
-// its weights (3 gates x 5 K blocks x hi/lo, 30 KB) live in LDS and are fetched as A operands when they are needed, every
-// other register of that wave being taken.  Wave 3's 135 MFMAs per step set the pace (the others issue 90).
+// blocks, the same four chain waves for neurons 0..127, and a NINTH tile (neurons 128..143) whose three gates are spread over
+// three waves -- wave 0 the reset gate (it writes r*h of those neurons), wave 1 the update gate (its z goes to wave 3 through
+// LDS, in time because z only needs h(s-1)), wave 3 the candidate and the new state (which it hands back to wave 0 as float32).
+// The tile's weights (3 gates x 5 K blocks x hi/lo, 30 KB) live in LDS and are fetched as A operands when they are needed, every
+// register being taken.  105 MFMAs per step on the three waves with a share, 90 on wave 2.
 #include <limits.h>
 
 #include "bar16_common.h"
@@ -49,10 +51,12 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
     __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * N], h_lo[2 * N], rh_hi[2 * N], rh_lo[2 * N];
     // the ninth tile's A operands: [gate r, z, c][K block][hi, lo][lane] x 16 bytes
     __shared__ __attribute__((aligned(16))) unsigned w9[T9 ? 3 * KBS * 2 * 64 * 4 : 4];
+    __shared__ float h9f[64], z9f[64];                   // ninth tile: h(s-1) for the reset-gate wave, z(s) for the owner
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
     for (int i = tid; i < 2 * N; i += 256) { h_hi[i] = 0u; h_lo[i] = 0u; rh_hi[i] = 0u; rh_lo[i] = 0u; }      // h(-1) = 0
+    if (tid < 64) { h9f[tid] = 0.0f; z9f[tid] = 0.0f; }
     auto ldH = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
 
     const int c = lane & 3, q = (lane >> 2) & 3, g = lane >> 4;
@@ -105,44 +109,43 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
             }
         }
     }
-    float inv9[3] = {1.0f, 1.0f, 1.0f};                  // r, z, c
-    const bool w3 = __builtin_amdgcn_readfirstlane(w) == 3;
-    auto w9at = [&](int gate, int i, int hl) { return reinterpret_cast<half8 *>(w9 + (((gate * KBS + i) * 2 + hl) * 64 + lane) * 4); };
+    // duty of this wave for the ninth tile: gate 0 (r) on wave 0, 1 (z) on wave 1, 2 (c) on wave 3; -1: none
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    const int duty = !T9 ? -1 : wu == 0 ? 0 : wu == 1 ? 1 : wu == 3 ? 2 : -1;
+    const bool w3 = wu == 3;
+    float inv9 = 1.0f;
+    auto w9at = [&](int gate, int kb, int hl) { return reinterpret_cast<half8 *>(w9 + (((gate * KBS + kb) * 2 + hl) * 64 + lane) * 4); };
     if constexpr (T9) {
-        if (w3) {                                        // K blocks stored in wave 3's rotated order: slot i holds block (3 + i) % KBS
+        if (duty >= 0) {
             const int row = 128 + (lane & 15);
             const bool rok = row < n;
+            const float *src = duty == 0 ? sW + (size_t)(n + row) * n : duty == 1 ? sW + (size_t)row * n : sW2 + (size_t)row * n;
+            float v[KBS][8];
+            float m = 0.0f;
 #pragma unroll
-            for (int gate = 0; gate < 3; gate++) {
-                const float *src = gate == 0 ? sW + (size_t)(n + row) * n : gate == 1 ? sW + (size_t)row * n : sW2 + (size_t)row * n;
-                float v[KBS][8];
-                float m = 0.0f;
+            for (int kb = 0; kb < KBS; kb++) {
 #pragma unroll
-                for (int i = 0; i < KBS; i++) {
-                    const int kb = (3 + i) % KBS;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int k = 32 * kb + 16 * (j & 1) + 4 * g + (j >> 1);
-                        v[i][j] = (rok && k < n) ? src[k] : 0.0f;
-                        m = fmaxf(m, fabsf(v[i][j]));
-                    }
+                for (int j = 0; j < 8; j++) {
+                    const int k = 32 * kb + 16 * (j & 1) + 4 * g + (j >> 1);
+                    v[kb][j] = (rok && k < n) ? src[k] : 0.0f;
+                    m = fmaxf(m, fabsf(v[kb][j]));
                 }
-                float iv;
-                const float sc = pow2_scale(kgroup_max(m), iv);
-                inv9[gate] = __shfl(iv, 4 * g + q);
+            }
+            float iv;
+            const float sc = pow2_scale(kgroup_max(m), iv);
+            inv9 = __shfl(iv, 4 * g + q);
 #pragma unroll
-                for (int i = 0; i < KBS; i++) {
-                    half8 hi, lo;
+            for (int kb = 0; kb < KBS; kb++) {
+                half8 hi, lo;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const float a = v[i][j] * sc;
-                        const _Float16 h = (_Float16)a;
-                        hi[j] = h;
-                        lo[j] = (_Float16)(a - (float)h);
-                    }
-                    *w9at(gate, i, 0) = hi;
-                    *w9at(gate, i, 1) = lo;
+                for (int j = 0; j < 8; j++) {
+                    const float a = v[kb][j] * sc;
+                    const _Float16 h = (_Float16)a;
+                    hi[j] = h;
+                    lo[j] = (_Float16)(a - (float)h);
                 }
+                *w9at(duty, kb, 0) = hi;
+                *w9at(duty, kb, 1) = lo;
             }
         }
     }
@@ -196,11 +199,15 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
     // one gate of the ninth tile: sum over the K blocks of the 3-term split, A operands from LDS (slot i <-> my block order)
     auto tile9_mfma = [&](int gate, const half8 *bhh, const half8 *bll) __attribute__((always_inline)) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        half8 ah = *w9at(gate, 0, 0), al = *w9at(gate, 0, 1);
+        half8 ah = *w9at(gate, wu, 0), al = *w9at(gate, wu, 1);                     // my operand order starts at my own K block
 #pragma unroll
         for (int i = 0; i < KBS; i++) {
             half8 nh = ah, nl = al;
-            if (i + 1 < KBS) { nh = *w9at(gate, i + 1, 0); nl = *w9at(gate, i + 1, 1); }       // in flight under this block's MFMAs
+            if (i + 1 < KBS) {                                                      // in flight under this block's MFMAs
+                const int kb = (wu + i + 1) % KBS;
+                nh = *w9at(gate, kb, 0);
+                nl = *w9at(gate, kb, 1);
+            }
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bll[i], acc, 0, 0, 0);
             if (i == 0) asm volatile("" : "+v"(acc) : "v"(ah), "v"(al), "v"(bll[0]), "v"(bhh[0]));     // see gemm_rows_f16x3.hip
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bhh[i], acc, 0, 0, 0);
@@ -240,8 +247,10 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
             else mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
         }
         f32x4 acc9 = {0.f, 0.f, 0.f, 0.f};
+        float h9prev = 0.0f;
         if constexpr (T9) {
-            if (w3) acc9 = tile9_mfma(0, bh, bl);
+            if (duty == 0) h9prev = h9f[lane];                                     // written by wave 3 before the barrier that ended step s-1
+            if (duty == 0 || duty == 1) acc9 = tile9_mfma(duty, bh, bl);
         }
         __builtin_amdgcn_sched_barrier(0);
         // z products of blocks 0 .. KBS-2 under the r epilogue
@@ -270,12 +279,14 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
             rh_lo[wd] = lo;
         }
         if constexpr (T9) {
-            if (w3) {
-                const float rr9 = nok9 ? sigmoid4(fmaf(sel4(acc9, q), inv9[0], cur.r[2])) : 0.0f;
+            if (duty == 0) {
+                const float rr9 = nok9 ? sigmoid4(fmaf(sel4(acc9, q), inv9, cur.r[2])) : 0.0f;
                 unsigned hi, lo;
-                split2(rr9 * hold9, 0.0f, hi, lo);
+                split2(rr9 * h9prev, 0.0f, hi, lo);
                 rh_hi[wd9] = hi;
                 rh_lo[wd9] = lo;
+            } else if (duty == 1) {
+                z9f[lane] = sigmoid4(fmaf(sel4(acc9, q), inv9, cur.z[2]));
             }
         }
         half8 ch[KBS], cl[KBS];
@@ -310,10 +321,11 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
             constexpr int i = decltype(IC)::value;
             z_block_mfma<false>(accC[0], accC[1], wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i]);
         });
-        f32x4 acc9z = {0.f, 0.f, 0.f, 0.f}, acc9c = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc9c = {0.f, 0.f, 0.f, 0.f};
+        float z9 = 0.0f;
         if constexpr (T9) {
             if (w3) {
-                acc9z = tile9_mfma(1, bh, bl);
+                z9 = z9f[lane];                                                     // wave 1 wrote it before the barrier that opened this interval
                 acc9c = tile9_mfma(2, ch, cl);
             }
         }
@@ -335,9 +347,9 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         float hn9 = 0.0f;
         if constexpr (T9) {
             if (w3) {
-                const float z9 = sigmoid4(fmaf(sel4(acc9z, q), inv9[1], cur.z[2]));
-                const float hb9 = tanh5(fmaf(sel4(acc9c, q), inv9[2], cur.c[2]));
+                const float hb9 = tanh5(fmaf(sel4(acc9c, q), inv9, cur.c[2]));
                 hn9 = nok9 ? fmaf(1.0f - z9, hb9, z9 * hold9) : 0.0f;
+                h9f[lane] = hn9;
                 unsigned hi, lo;
                 split2(hn9, 0.0f, hi, lo);
                 h_hi[wd9] = hi;
