@@ -24,3 +24,17 @@ def test_no_mfma_destination_over_live_operands(tmp_path, src, flags):
     assert r.returncode == 0, r.stdout
     own, war = mfma_overlap_scan.scan(out)
     assert own == 0 and war == 0, "%s: %d MFMA destinations over their own operands, %d over the preceding MFMA's" % (src, own, war)
+
+
+def test_no_instruction_touches_a_register_an_asm_load_is_filling(tmp_path):
+    """csrc/gru_scan16.hip issues its projection loads as asm, three steps ahead, and counts them itself; the compiler must not move
+    such a destination (it once spilled one to an accumulation register right behind the load: tools/inflight_load_scan.py)."""
+    import inflight_load_scan
+    from sloika_amd import build
+    out = str(tmp_path / "gru_scan16.s")
+    cmd = [build.hipcc()] + build.FLAGS + ["--cuda-device-only", "-S", os.path.join(build.CSRC, "gru_scan16.hip"), "-o", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert open(out).read().count("global_load_dword") > 50            # both instantiations are in the file
+    bad = inflight_load_scan.scan(out)
+    assert not bad, bad[:3]
