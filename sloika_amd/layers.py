@@ -385,12 +385,12 @@ class Identity(Layer):
 class FeedForward(Layer):
     """  Basic feedforward layer:  out = f( inMat W + b )       (layers.py:114-158)
 
-    :param insize: Size of input to layer
-    :param size: Layer size
-    :param init: function to initialise tensors with
-    :param has_bias: Whether layer has bias
-    :param fun: The activation function.
-    :param name: Name for layer
+    :param insize: number of input features per step
+    :param size: number of units (output features per step)
+    :param init: callable(shape) drawing the initial weights
+    :param has_bias: False leaves out the bias vector `b`
+    :param fun: activation of the output (a function of sloika_amd.activation)
+    :param name: label that json() and pickles carry
     """
 
     _json_type = "feed-forward"
@@ -447,11 +447,11 @@ class FeedForward(Layer):
 class Softmax(Layer):
     """  Softmax layer: tmp = exp( inmat W + b ); out = row_normalise( tmp )     (layers.py:268-314)
 
-    :param insize: Size of input to layer
-    :param size: Layer size
-    :param init: function to initialise tensors with
-    :param has_bias: Whether layer has bias
-    :param name: Name for layer
+    :param insize: number of input features per step
+    :param size: number of units (output features per step)
+    :param init: callable(shape) drawing the initial weights
+    :param has_bias: False leaves out the bias vector `b`
+    :param name: label that json() and pickles carry
     """
 
     _json_type = "softmax_old"
@@ -572,8 +572,8 @@ class SoftmaxTheano(Softmax):
 class Window(Layer):
     """  Create a sliding window over input      (layers.py:317-351)
 
-    :param w: Size of window
-    :param name: Name for layer
+    :param w: width of the window in time steps (odd)
+    :param name: label that json() and pickles carry
     """
 
     def __init__(self, insize, w, name="Window"):
@@ -617,18 +617,17 @@ class Window(Layer):
 class Convolution(Layer):
     """1D convolution over the first dimension       (layers.py:354-419)
 
-    Takes input of shape [time, batch, features] and produces output of shape
-    [ceil((time + padding) / stride), batch, features]
+    [time, batch, insize] in, [ceil((time + total padding) / stride), batch, size] out.
 
-    :param insize: number of features on input
-    :param size: number of output features
-    :param winlen: size of window over input
-    :param stride: step size between successive windows
-    :param init: function to initialise tensors with
-    :param has_bias: whether layer has bias
-    :param fun: the activation function
+    :param insize: features per input step
+    :param size: features per output step
+    :param winlen: filter taps (input steps one output sees)
+    :param stride: input steps from one output to the next
+    :param init: callable(shape) drawing the initial weights
+    :param has_bias: False leaves out the bias vector `b`
+    :param fun: activation of the output (a function of sloika_amd.activation)
     :param padding_mode: str, int or (int, int); see conv.calculate_padding. Default: 'same'
-    :param name: Name for layer
+    :param name: label that json() and pickles carry
     """
 
     _json_type = "convolution"
@@ -698,13 +697,10 @@ class Convolution(Layer):
 
 class Lstm(RNN):
     """ LSTM layer with peepholes (layers.py:599-697).  Step (:677-691):
-        v = [ input_new, output_old ]
-        Pforget = gatefun( v W2 + b2 + state * p1)
-        Pupdate = gatefun( v W1 + b1 + state * p0)
-        Update  = fun( v W0 + b0 )
-        state_new = state_old * Pforget + Update * Pupdate
-        Poutput = gatefun( v W3 + b3 + state * p2)
-        output_new = fun(state) * Poutput
+        a = x iW^T + h sW^T + b, read per unit j as (a0, a1, a2, a3) = a[4j .. 4j+3];  c = cell state, p = peepholes
+        i = gatefun(a1 + c p0)        input gate          f = gatefun(a2 + c p1)        forget gate
+        c' = f c + i fun(a0)          new cell state      o = gatefun(a3 + c' p2)       output gate (peeps at the NEW state)
+        h' = o fun(c')                output
     Rows of iW / sW / b are interleaved as j*4 + gate (the layout `step` reads; `json`/`set_params` keep the
     reference's block reshapes verbatim).
     """
@@ -785,13 +781,13 @@ class Gru(RNN):
         vI = x iW^T + b ; vS = h sW^T ; z, r = gatefun(vI[:2n] + vS) ; y = (r*h) sW2^T
         hbar = fun(vI[2n:] + y) ; h = z*h + (1-z)*hbar
 
-    :param insize: Size of input to layer
-    :param size: Layer size
-    :param init: function to initialise tensors with
-    :param has_bias: Whether layer has bias
-    :param fun: The activation function.
-    :param gatefun: The activation function for gates.
-    :param name: Name for layer
+    :param insize: number of input features per step
+    :param size: number of units (output features per step)
+    :param init: callable(shape) drawing the initial weights
+    :param has_bias: False leaves out the bias vector `b`
+    :param fun: activation of the output (a function of sloika_amd.activation)
+    :param gatefun: activation of the gates
+    :param name: label that json() and pickles carry
     """
 
     _json_type = "GRU"
@@ -961,8 +957,8 @@ class Gru(RNN):
 class Reverse(Layer):
     """  Runs a recurrent layer in reverse time (backwards)       (layers.py:1420-1450)
 
-    :param layer: A :class:`layer` to reverse
-    :param name: Name for layer
+    :param layer: the wrapped layer; it sees the input back to front
+    :param name: label that json() and pickles carry
     """
 
     def __init__(self, layer, name='Reverse'):
@@ -997,8 +993,8 @@ class Reverse(Layer):
 class Parallel(Layer):
     """ Run multiple layers in parallel (all have same input and outputs are concatenated)   (layers.py:1453-1487)
 
-    :param layers: A list of :class:`layer` to run in parallel
-    :param name: Name for layer
+    :param layers: layers that all read the same input; their outputs are joined along the feature axis
+    :param name: label that json() and pickles carry
     """
 
     def __init__(self, layers, name='Parallel'):
@@ -1107,8 +1103,8 @@ class Parallel(Layer):
 class Serial(Layer):
     """ Run multiple layers serially: output of a layer is the input for the next layer  (layers.py:1524-1560)
 
-    :param layers: A list of :class:`layer` to run in series
-    :param name: Name for layer
+    :param layers: layers applied one after the other, first to last
+    :param name: label that json() and pickles carry
     """
 
     def __init__(self, layers, name='Serial'):
@@ -1159,9 +1155,9 @@ def _keeps_time(layer):
 def birnn(forward, backward, name='BiRNN'):
     """  Creates a bidirectional RNN from two RNNs      (layers.py:1622-1629)
 
-    :param forward: A :class:`layer` to run forwards
-    :param backward: A :class:`layer` to run backwards
-    :param name: Name for layer
+    :param forward: layer that reads the input in time order
+    :param backward: layer that reads it back to front (wrapped in Reverse)
+    :param name: label that json() and pickles carry
     """
     return Parallel([forward, Reverse(backward)], name=name)
 
