@@ -668,17 +668,35 @@ extern "C" int slk_reduce_sum_f32(const float *x, size_t n, int square, double *
 #define TN_BLK 96
 #define TN_UNROLL 4
 
+// Which block of C and which slice of rows this workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
+// b + 8 share one; observed, speed only), each with an L2 of its own, and the g1 * g2 column blocks of ONE slice read the same rows
+// of A and B: numbered along the launch order they would sit on 8 different XCDs and every operand row would cross the fabric up to
+// 8 times.  Launch index l -> work item (l % 8) * ceil(W / 8) + l / 8: consecutive work items (the blocks of a slice) run on the
+// same XCD one after the other and find each other's operand rows in its L2.
+__device__ __forceinline__ bool tn_block_of(int g1, int g2, int nslice, int &bx, int &by, int &bz)
+{
+    const long W = (long)g1 * g2 * nslice, per_xcd = (W + 7) / 8;
+    const long l = blockIdx.x;
+    const long work = (l & 7) * per_xcd + (l >> 3);
+    if (work >= W) return false;
+    bx = (int)(work % g1);
+    const long rest = work / g1;
+    bz = (int)(rest % g2);
+    by = (int)(rest / g2);
+    return true;
+}
+
 // CS: also produce the column sums of A (the bias gradient, da^T 1) from the operands already in registers
 template <bool CS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_tn_kernel(const float *__restrict__ A, long lda, const float *__restrict__ Bm,
                                                      long ldb, float *__restrict__ partial, long M, int N1, int N2,
-                                                     float *__restrict__ cs_partial, int slice_rows)
+                                                     float *__restrict__ cs_partial, int slice_rows, int g1, int g2, int nslice)
 {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-    // the column blocks of one slice are neighbours in launch order, so the operand rows they share are read from HBM once
-    // and from L2 by the others
-    const int n1_0 = blockIdx.x * TN_BLK, n2_0 = blockIdx.z * TN_BLK;
-    const long m_lo = (long)blockIdx.y * slice_rows, m_hi = min(m_lo + slice_rows, M);
+    int bx, by, bz;
+    if (!tn_block_of(g1, g2, nslice, bx, by, bz)) return;
+    const int n1_0 = bx * TN_BLK, n2_0 = bz * TN_BLK;
+    const long m_lo = (long)by * slice_rows, m_hi = min(m_lo + slice_rows, M);
     const int ta = min(3, (N1 - n1_0 + 31) / 32), tb = min(3, (N2 - n2_0 + 31) / 32);    // live 32-wide tiles (uniform)
     const float *pa[3], *pb[3];
 #pragma unroll
@@ -737,7 +755,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         mma(a1, b1, m0 + STEP);
     }
     // partial[slice][N1][N2]; D[row = (e&3) + 8*(e>>2) + 4*h][col = r]; columns clamped above are dropped here
-    float *out = partial + (size_t)blockIdx.y * N1 * N2;
+    float *out = partial + (size_t)by * N1 * N2;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -751,12 +769,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 }
             }
         }
-    if (CS && blockIdx.z == 0) {
+    if (CS && bz == 0) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const float tot = cs[i] + __shfl_xor(cs[i], 32);
             const int colc = n1_0 + 32 * i + r;
-            if (h == 0 && i < ta && colc < N1) cs_partial[(size_t)blockIdx.y * N1 + colc] = tot;
+            if (h == 0 && i < ta && colc < N1) cs_partial[(size_t)by * N1 + colc] = tot;
         }
     }
 }
@@ -794,11 +812,13 @@ __device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8 &p1, bf
 template <bool CS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm_tn_bf16_kernel(const float *__restrict__ A, long lda, const float *__restrict__ Bm,
                                                           long ldb, float *__restrict__ partial, long M, int N1, int N2,
-                                                          float *__restrict__ cs_partial, int slice_rows)
+                                                          float *__restrict__ cs_partial, int slice_rows, int g1, int g2, int nslice)
 {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-    const int n1_0 = blockIdx.x * TN_BLK, n2_0 = blockIdx.z * TN_BLK;
-    const long m_lo = (long)blockIdx.y * slice_rows, m_hi = min(m_lo + slice_rows, M);
+    int bx, by, bz;
+    if (!tn_block_of(g1, g2, nslice, bx, by, bz)) return;
+    const int n1_0 = bx * TN_BLK, n2_0 = bz * TN_BLK;
+    const long m_lo = (long)by * slice_rows, m_hi = min(m_lo + slice_rows, M);
     const int ta = min(3, (N1 - n1_0 + 31) / 32), tb = min(3, (N2 - n2_0 + 31) / 32);    // live 32-wide tiles (uniform)
     const float *pa[3], *pb[3];
 #pragma unroll
@@ -840,21 +860,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             split_bf16x3(av[i], pa1[i], pa2[i], pa3[i]);
             split_bf16x3(bv[i], pb1[i], pb2[i], pb3[i]);
         }
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-                if (i < ta && j < tb) {
-                    // small terms first so that they are not absorbed by the large one
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1[i], pb3[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa2[i], pb2[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa3[i], pb1[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1[i], pb2[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa2[i], pb1[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1[i], pb1[j], c, 0, 0, 0);
-                    acc[i][j] = c;
-                }
+        // small terms first so that they are not absorbed by the large one; term-major: consecutive MFMAs go to different
+        // accumulators, so none waits for the result of the one before it
+#define TN_TERM(PA, PB)                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 3; i++) _Pragma("unroll") for (int j = 0; j < 3; j++)            \
+            if (i < ta && j < tb) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[i], PB[j], acc[i][j], 0, 0, 0);
+        TN_TERM(pa1, pb3) TN_TERM(pa2, pb2) TN_TERM(pa3, pb1) TN_TERM(pa1, pb2) TN_TERM(pa2, pb1) TN_TERM(pa1, pb1)
+#undef TN_TERM
     };
     constexpr int STEP = 16;
     load(a0, b0, m_lo);
@@ -864,7 +876,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         load(a0, b0, m0 + 2 * STEP);
         mma(a1, b1, m0 + STEP);
     }
-    float *out = partial + (size_t)blockIdx.y * N1 * N2;
+    float *out = partial + (size_t)by * N1 * N2;
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -878,12 +890,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 }
             }
         }
-    if (CS && blockIdx.z == 0) {
+    if (CS && bz == 0) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const float tot = cs[i] + __shfl_xor(cs[i], 32);
             const int colc = n1_0 + 32 * i + r;
-            if (h == 0 && i < ta && colc < N1) cs_partial[(size_t)blockIdx.y * N1 + colc] = tot;
+            if (h == 0 && i < ta && colc < N1) cs_partial[(size_t)by * N1 + colc] = tot;
         }
     }
 }
@@ -941,11 +953,12 @@ static int gemm_tn_launch(bool bf16, const float *A, long lda, const float *B, l
     const int rows = tn_slice_rows(M, N1, N2);
     const long nslice = (M + rows - 1) / rows;
     const int g1 = (N1 + TN_BLK - 1) / TN_BLK, g2 = (N2 + TN_BLK - 1) / TN_BLK;
-    if (nslice > 65535 || g2 > 65535) return SLK_ERR_UNSUPPORTED;
+    const long W = (long)g1 * g2 * nslice;
+    if (W > 0x7ffffff0L) return SLK_ERR_UNSUPPORTED;
     hipStream_t s = slk_stream(stream);
     float *partial = (float *)workspace, *cs_partial = partial + (size_t)nslice * N1 * N2;
-    const dim3 grid(g1, (unsigned)nslice, g2);
-#define TN_LAUNCH(K) hipLaunchKernelGGL(K, grid, dim3(64), 0, s, A, lda, B, ldb, partial, M, N1, N2, cs_partial, rows)
+    const dim3 grid((unsigned)(8 * ((W + 7) / 8)));                       // tn_block_of: 8 XCDs x ceil(W / 8) work items
+#define TN_LAUNCH(K) hipLaunchKernelGGL(K, grid, dim3(64), 0, s, A, lda, B, ldb, partial, M, N1, N2, cs_partial, rows, g1, g2, (int)nslice)
     if (bf16) {
         if (colsum) TN_LAUNCH(gemm_tn_bf16_kernel<true>);
         else TN_LAUNCH(gemm_tn_bf16_kernel<false>);
