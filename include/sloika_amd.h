@@ -248,6 +248,11 @@ SLK_API int slk_lstm_recurrent_f32(const float *vW, const float *sW, const float
 SLK_API int slk_lstm_recurrent_ragged_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
                                   int n, int reverse, int act, int gate_act, const int32_t *lens /* see slk_gru_fused_ragged_f32 */,
                                   slk_stream_t stream);
+/* The same scan with the recurrent product as a 3-term fp16 split on the barrier-stepped plan (csrc/lstm_scan16.hip; n a multiple
+ * of 16 up to 64, tanh / sigmoid, vW 16-byte aligned and < 4 GiB; SLK_ERR_UNSUPPORTED otherwise -> slk_lstm_recurrent_f32).
+ * lens may be NULL (all chunks T steps long). */
+SLK_API int slk_lstm_scan16_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B, int n,
+                        int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream);
 SLK_API size_t slk_lstm_workspace_bytes(int T, int B, int n);
 SLK_API int slk_lstm_f32(const float *x, long ldx, const float *iW, const float *sW, const float *bias, const float *p,
                  float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
@@ -357,7 +362,7 @@ SLK_API int slk_map_to_sequence_f32(const float *ltrans, int nev, int nst, const
  *   ev_off:[nread+1] int64 -- read b owns rows ev_off[b]..ev_off[b+1] of ltrans ([sum nev][nst]) and of path_out;
  *   pos_off:[nread+1] int64 -- ... and positions pos_off[b]..pos_off[b+1] of seq / prior_initial / prior_final;
  *   ws_off:[nread] int64 -- offset (in int32 elements) of read b's nev_b*npos_b traceback inside `workspace`;
- *   max_npos = the longest sequence (sizes the LDS request: 28 bytes per position of the 160 KB, npos <= 5851); score_out:[nread].
+ *   max_npos = the longest sequence (sizes the LDS request: 28 bytes per position of the 160 KB, npos <= 5846); score_out:[nread].
  * A read with fewer than 3 positions or no events gets score -inf and its path is left untouched. */
 SLK_API int slk_map_to_sequence_batch_f32(const float *ltrans, int nst, const int64_t *ev_off, const int32_t *seq,
                                   const int64_t *pos_off, int nread, int max_npos, float slip,

@@ -758,7 +758,15 @@ class Lstm(RNN):
         # the two halves of slk_lstm_f32, timed separately: projection GEMM into the workspace, then the recurrence
         _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 4 * n, "lstm_input_gemm", "Lstm")
         with profiler.region("lstm_recurrent", 8.0 * rows * n * n, 4.0 * rows * 5 * n):
-            if lens is None:
+            rc = _lib.SLK_ERR_UNSUPPORTED
+            if SPLIT_F16 and RECURRENT_F16:
+                # the recurrent product as a 3-term fp16 split on the barrier-stepped plan (csrc/lstm_scan16.hip: n <= 64)
+                rc = L.slk_lstm_scan16_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(), y.data_ptr(),
+                                           _row_stride(y), T, B, n, int(reverse), activation.act_id(self.fun),
+                                           activation.act_id(self.gatefun), None if lens is None else lens.data_ptr(), _stream())
+            if rc != _lib.SLK_ERR_UNSUPPORTED:
+                pass
+            elif lens is None:
                 rc = L.slk_lstm_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(),
                                               y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
                                               activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())

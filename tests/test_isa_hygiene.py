@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 @pytest.mark.parametrize("src,flags", [("softmax_viterbi.hip", ["-DSV_ONLY_KS=4"]), ("softmax_viterbi.hip", ["-DSV_ONLY_KS=6"]),
-                                       ("gemm_rows_f16x3.hip", [])])
+                                       ("gemm_rows_f16x3.hip", []), ("lstm_scan16.hip", [])])
 def test_no_mfma_destination_over_live_operands(tmp_path, src, flags):
     import mfma_overlap_scan
     from sloika_amd import build
@@ -26,15 +26,17 @@ def test_no_mfma_destination_over_live_operands(tmp_path, src, flags):
     assert own == 0 and war == 0, "%s: %d MFMA destinations over their own operands, %d over the preceding MFMA's" % (src, own, war)
 
 
-def test_no_instruction_touches_a_register_an_asm_load_is_filling(tmp_path):
-    """csrc/gru_scan16.hip issues its projection loads as asm, three steps ahead, and counts them itself; the compiler must not move
-    such a destination (it once spilled one to an accumulation register right behind the load: tools/inflight_load_scan.py)."""
+@pytest.mark.parametrize("src,nloads", [("gru_scan16.hip", 50), ("lstm_scan16.hip", 8)])
+def test_no_instruction_touches_a_register_an_asm_load_is_filling(tmp_path, src, nloads):
+    """csrc/gru_scan16.hip and lstm_scan16.hip issue their projection loads as asm, three steps ahead, and count them themselves; the
+    compiler must not move such a destination (it once spilled one to an accumulation register right behind the load:
+    tools/inflight_load_scan.py)."""
     import inflight_load_scan
     from sloika_amd import build
-    out = str(tmp_path / "gru_scan16.s")
-    cmd = [build.hipcc()] + build.FLAGS + ["--cuda-device-only", "-S", os.path.join(build.CSRC, "gru_scan16.hip"), "-o", out]
+    out = str(tmp_path / (src + ".s"))
+    cmd = [build.hipcc()] + build.FLAGS + ["--cuda-device-only", "-S", os.path.join(build.CSRC, src), "-o", out]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
-    assert open(out).read().count("global_load_dword") > 50            # both instantiations are in the file
+    assert open(out).read().count("global_load_dword") > nloads         # the scan has something to look at
     bad = inflight_load_scan.scan(out)
     assert not bad, bad[:3]

@@ -7,7 +7,18 @@ NaN.  The loads in question use the `vaddr, s[base]` form, which the compiler's 
 import re
 import sys
 
-LOAD = re.compile(r'\s*global_load_dword (v\d+), v\d+, s\[')
+LOAD = re.compile(r'\s*global_load_dword(?:x[234])? (v\d+|v\[\d+:\d+\]), v\d+, s\[')
+REG = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
+
+
+def _regs(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
 
 
 def scan(path):
@@ -17,12 +28,14 @@ def scan(path):
         m = LOAD.match(l)
         if not m:
             continue
-        reg = re.compile(r'\b%s\b' % m.group(1))
+        dst = _regs(m.group(1))
         for j in range(i + 1, min(i + 600, len(lines))):
             t = lines[j]
             if 's_waitcnt' in t and 'vmcnt' in t:
                 break
-            if reg.search(t) and 'global_load' not in t:
+            if t.lstrip().startswith(';') or 'global_load' in t:
+                continue
+            if dst & _regs(t.split(';')[0]):
                 bad.append((i + 1, l.strip(), j + 1, t.strip()))
                 break
     return bad
