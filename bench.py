@@ -84,6 +84,10 @@ def parse():
 # ----------------------------------------------------------------------------------------------------------------------
 # CPU baselines (the oracle: test infrastructure, timed here as the reported CPU column)
 # ----------------------------------------------------------------------------------------------------------------------
+def feature_input(L, B, nfeature, seed):
+    return np.random.RandomState(1000 + seed).normal(size=(L, B, nfeature)).astype(np.float32)
+
+
 def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
     """The oracle (CPU port of the same pipeline: C + OpenMP over chunks) on the host cores of this box.
     Bounded sample: slabs of `slab` chunks of the same synthetic workload until ~budget_s seconds of CPU work."""
@@ -95,10 +99,11 @@ def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
     cores = orc.num_threads()
     done, spent = 0, 0.0
     for i in range(max_slabs):
-        chunks = pipeline.synthetic_chunks(slab, chunk_len=chunk_len, seed=123, first_chunk=i * slab)
+        feats = net.insize != 1
+        chunks = feature_input(chunk_len, slab, net.insize, 7000 + i) if feats else \
+            pipeline.synthetic_chunks(slab, chunk_len=chunk_len, seed=123, first_chunk=i * slab)
         t0 = time.perf_counter()
-        x = orc.med_mad_normalise(chunks)
-        post = orc.run_network(spec, np.ascontiguousarray(x.T)[:, :, None])
+        post = orc.run_network(spec, chunks if feats else np.ascontiguousarray(orc.med_mad_normalise(chunks).T)[:, :, None])
         lp = np.log(np.float32(1e-5) + np.float32(1.0 - 1e-5) * post + np.float32(1e-10))
         orc.viterbi_batch(lp, 5, skip_pen=0.0)
         spent += time.perf_counter() - t0
@@ -113,10 +118,10 @@ def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
     try:
         orc.set_num_threads(1)
         n1 = 12
-        chunks = pipeline.synthetic_chunks(n1, chunk_len=chunk_len, seed=123, first_chunk=0)
+        chunks = feature_input(chunk_len, n1, net.insize, 7000) if feats else \
+            pipeline.synthetic_chunks(n1, chunk_len=chunk_len, seed=123, first_chunk=0)
         t0 = time.perf_counter()
-        x = orc.med_mad_normalise(chunks)
-        post = orc.run_network(spec, np.ascontiguousarray(x.T)[:, :, None])
+        post = orc.run_network(spec, chunks if feats else np.ascontiguousarray(orc.med_mad_normalise(chunks).T)[:, :, None])
         lp = np.log(np.float32(1e-5) + np.float32(1.0 - 1e-5) * post + np.float32(1e-10))
         orc.viterbi_batch(lp, 5, skip_pen=0.0)
         t1 = time.perf_counter() - t0
@@ -212,8 +217,13 @@ class Runner(object):
         self.streams = ([torch.cuda.current_stream()] if main_stream else []) + \
             [torch.cuda.Stream() for _ in range(nslot - (1 if main_stream else 0))]
         self.nbuf = 2
-        self.host_in = [pipeline.synthetic_chunks(B, chunk_len=L, seed=0xdeadbeef, first_chunk=(rank * self.nbuf + i) * B)
-                        for i in range(self.nbuf)]
+        if self.net.insize == 1:
+            self.host_in = [pipeline.synthetic_chunks(B, chunk_len=L, seed=0xdeadbeef, first_chunk=(rank * self.nbuf + i) * B)
+                            for i in range(self.nbuf)]
+        else:
+            # event-feature models (baseline_gru / baseline_lstm / tiny_gru: a Window over 4 features per event): the input is the
+            # [T, B, features] tensor calc_post takes; synthetic standard-normal features, L events per chunk
+            self.host_in = [feature_input(L, B, self.net.insize, rank * self.nbuf + i) for i in range(self.nbuf)]
         self.dev = [torch.from_numpy(h).cuda() for h in self.host_in]
         first = self.net.layers[0]
         self.tout = first.out_len(L) if hasattr(first, "out_len") else L

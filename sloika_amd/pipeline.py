@@ -48,7 +48,16 @@ class Basecaller(object):
         net = self.network
         seq = net.layers if isinstance(net, layers.Serial) else [net]
         first = seq[0]
-        if (self.normalisation == 'per-chunk' and isinstance(first, layers.Convolution) and first.insize == 1
+        if cd.dim() == 3:
+            # event-feature models (models/baseline_lstm.py, baseline_gru.py: Window over 4 features per event): the input is the
+            # [T, B, features] tensor itself, as `calc_post` takes it (basecall.py:73-75); nothing to normalise
+            if cd.shape[2] != first.insize:
+                raise ValueError("feature input has %d features per step, the network takes %d" % (cd.shape[2], first.insize))
+            x, rest = cd, seq[:upto]
+        elif first.insize != 1:
+            raise ValueError("this network takes %d features per step: hand over a [T, B, %d] feature tensor, not raw chunks"
+                             % (first.insize, first.insize))
+        elif (self.normalisation == 'per-chunk' and isinstance(first, layers.Convolution) and first.insize == 1
                 and len(seq) > 1):
             # the conv front end reads the chunk-major normalised signal directly: no [T,B,1] transpose
             norm = batch.normalise_chunks(cd, 'per-chunk', out_layout='chunk')

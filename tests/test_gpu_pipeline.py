@@ -252,3 +252,23 @@ def test_first_calls_on_two_streams_without_warm_up():
         torch.cuda.synchronize()
         for got in outs:
             assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]) and torch.equal(got[0], ref[0]), name
+
+
+def test_event_model_through_the_basecaller(oracle):
+    """Event-feature models take the [T, B, features] tensor itself (basecall.py:73-75); raw chunks are refused instead of being
+    read with the wrong feature count."""
+    torch = need_gpu()
+    from sloika_amd import decode, models, pipeline
+    net = models.randomise_zero_layers(models.build_model("baseline_lstm", klen=5, sd=0.5, seed=5))
+    x = np.random.RandomState(4).normal(size=(90, 3, 4)).astype(np.float32)
+    bc = pipeline.Basecaller(net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0)
+    scores, paths, lens = bc.call_chunks(torch.from_numpy(x).cuda())
+    post = net.compile()(x)
+    s2, p2, l2 = decode.viterbi_batch(post, 5, skip_pen=0.0, nbase=4, min_prob=1e-5)
+    assert torch.equal(lens.cpu(), l2.cpu())
+    agree = (paths.cpu() == p2.cpu()).float().mean().item()
+    assert agree > 0.98, agree                       # the fused decoder's log-posteriors differ from the posterior path's in the last bits
+    with pytest.raises(ValueError):
+        bc.call_chunks(pipeline.synthetic_chunks(2, chunk_len=200, seed=1))
+    with pytest.raises(ValueError):
+        bc.call_chunks(torch.zeros((10, 2, 3), device="cuda"))
