@@ -164,6 +164,58 @@ __device__ __forceinline__ void z_block_mfma_hooked(f32x4 &a0, f32x4 &a1, const 
     hook(ic<BASE + 5>{});
 }
 
+// ---- two MFMAs per product instead of three: the state's hi and lo halves in DIFFERENT column groups --------------------------
+// With four chunks per workgroup the 16 columns of the recurrent MFMAs hold four copies of every chunk (lane (g, q, c) reads
+// column 4q + c, the copies differ in q).  Let the copies q = 0, 1 carry the hi half of the state and q = 2, 3 the lo half (one
+// operand fetch per K block instead of two: the lane picks its image by q): then W_lo.B and W_hi.B give, in a hi column,
+// lo.hi + hi.hi and, in a lo column, lo.lo + hi.lo -- all four terms of (W_hi + W_lo)(h_hi + h_lo) from TWO instructions -- and the
+// product for row 4g+j of chunk c is the sum of register j over the columns (c, q) and (c, q ^ 2).  pick_mix does that sum and the
+// row selection at once: four v_add_f32 whose first source comes from the lane eight columns away (row_ror:8) and whose bank mask
+// lets only the lane quartet q = j write register j's sum -- one instruction more than sel4's three selects.
+__device__ __forceinline__ void mfma2x2(const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi, const half8 &w1_lo, const half8 &bm,
+                                        f32x4 &acc0, f32x4 &acc1)
+{
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0_lo, bm, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1_lo, bm, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0_hi, bm, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1_hi, bm, acc1, 0, 0, 0);
+}
+// the same with the weights in accumulation registers (asm: see z_block_mfma)
+template <bool FIRST>
+__device__ __forceinline__ void z_block_mfma2(f32x4 &a0, f32x4 &a1, const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi,
+                                              const half8 &w1_lo, const half8 &bm)
+{
+    if constexpr (FIRST) {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a0) : "a"(w0_lo), "v"(bm));
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a1) : "a"(w1_lo), "v"(bm));
+    } else {
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_lo), "v"(bm));
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_lo), "v"(bm));
+    }
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_hi), "v"(bm));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bm));
+}
+__device__ __forceinline__ float pick_mix(const f32x4 &a)
+{
+    float r;
+    // s_nop: a DPP source written by a VALU instruction just before needs two wait states, and the compiler does not look into asm
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x1\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x2\n\t"
+                 "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x4\n\t"
+                 "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x8"
+                 : "=&v"(r)
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+    return r;
+}
+// barrier for a wave whose youngest LDS operation is a read of its own data (lds_bar_2reads with one operand image)
+template <bool REAL = true>
+__device__ __forceinline__ void lds_bar_1read()
+{
+    if constexpr (REAL) asm volatile("s_waitcnt lgkmcnt(1)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+}
+
 // One projection tile for both sets, weights in accumulation registers: the two accumulation chains alternate (consecutive
 // MFMAs never depend on each other) and hook(ic<i>) runs after MFMA i = 0 .. 6 KBLK - 1 -- the matrix pipe keeps the wave's issue
 // port for 4 cycles of every 16, the leader's split of x is cut into pieces that fill the rest.

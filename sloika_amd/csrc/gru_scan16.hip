@@ -28,6 +28,11 @@
 #ifndef SCAN16_Z0_EARLY
 #define SCAN16_Z0_EARLY 1
 #endif
+// 1: two MFMAs per recurrent product, the state's hi and lo halves in different column groups (bar16_common.h, mfma2x2 / pick_mix);
+// 0: the three-term sequence of round 2 (every column group a copy of the hi half, the lo half a second operand)
+#ifndef SCAN16_MIX
+#define SCAN16_MIX 1
+#endif
 // one float per lane from HBM, not tracked by the compiler: the caller counts (s_waitcnt vmcnt(n), then pin_f)
 __device__ __forceinline__ void gload1(float &dst, const float *src) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(src) : "memory"); }
 // the same with the row's base address in scalar registers and the lane's part as an unsigned 32-bit byte offset: nothing but one
@@ -48,7 +53,9 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
     constexpr bool T9 = N == 160;
     constexpr int NV = T9 ? 3 : 2;                       // (neuron, chunk) pairs a lane requests per step
 
-    __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * N], h_lo[2 * N], rh_hi[2 * N], rh_lo[2 * N];
+    constexpr bool MIX = SCAN16_MIX != 0;
+    __shared__ __attribute__((aligned(16))) unsigned h_img[2 * 2 * N], rh_img[2 * 2 * N];        // hi image, then lo image
+    unsigned *const h_hi = h_img, *const h_lo = h_img + 2 * N, *const rh_hi = rh_img, *const rh_lo = rh_img + 2 * N;
     // the ninth tile's A operands: [gate r, z, c][K block][hi, lo][lane] x 16 bytes
     __shared__ __attribute__((aligned(16))) unsigned w9[T9 ? 3 * KBS * 2 * 64 * 4 : 4];
     __shared__ float h9f[64], z9f[64];                   // ninth tile: h(s-1) for the reset-gate wave, z(s) for the owner
@@ -152,6 +159,10 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
     int boff[KBS];
 #pragma unroll
     for (int i = 0; i < KBS; i++) boff[i] = ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
+    int moff[KBS];                                       // MIX: my column group's image (q = 0, 1: hi; q = 2, 3: lo)
+#pragma unroll
+    for (int i = 0; i < KBS; i++) moff[i] = (q >> 1) * 2 * N + boff[i];
+    auto pick = [&](const f32x4 &a) { if constexpr (MIX) return pick_mix(a); else return sel4(a, q); };
     const int wd = ((w * 4 + g) * 4 + c) * 4 + q;                                           // my packed pair, in dwords
     const int n0 = 32 * w + 4 * g + q;                                                      // my neuron of tile 2w (+16: 2w+1)
     const bool nok0 = n0 < n, nok1 = n0 + 16 < n;
@@ -208,6 +219,14 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
                 nh = *w9at(gate, kb, 0);
                 nl = *w9at(gate, kb, 1);
             }
+            if constexpr (MIX) {                                                    // bhh = the mixed operands, bll unused
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bhh[i], acc, 0, 0, 0);
+                if (i == 0) asm volatile("" : "+v"(acc) : "v"(ah), "v"(al), "v"(bhh[0]));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bhh[i], acc, 0, 0, 0);
+                ah = nh;
+                al = nl;
+                continue;
+            }
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bll[i], acc, 0, 0, 0);
             if (i == 0) asm volatile("" : "+v"(acc) : "v"(ah), "v"(al), "v"(bll[0]), "v"(bhh[0]));     // see gemm_rows_f16x3.hip
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bhh[i], acc, 0, 0, 0);
@@ -222,29 +241,43 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         constexpr int ph = decltype(PHC)::value;
         VI &cur = vs[ph];
         // ------------------------------ interval A ------------------------------
-        lds_bar_2reads();
-        half8 bh[KBS], bl[KBS];
+        if constexpr (MIX) lds_bar_1read(); else lds_bar_2reads();
+        half8 bh[KBS], bl[KBS];                          // MIX: bh = the mixed operands, bl unused
         bh[0] = oh;
         bl[0] = ol;
 #pragma unroll
-        for (int i = 1; i < KBS; i++) { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+        for (int i = 1; i < KBS; i++) {
+            if constexpr (MIX) bh[i] = ldH(h_img, moff[i]);
+            else { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+        }
         if constexpr (!(SCAN16_ABL & 4)) load_vi(s + 3, vs[(ph + 3) & 3]);                // three steps ahead
         __builtin_amdgcn_sched_barrier(0);
         f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2], accC[2];
-        if constexpr (T9) z_block_mfma<true>(accR[0], accR[1], wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0]);
-        else mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
+        if constexpr (MIX) {
+            if constexpr (T9) z_block_mfma2<true>(accR[0], accR[1], wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0]);
+            else mfma2x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], accR[0], accR[1]);
+        } else {
+            if constexpr (T9) z_block_mfma<true>(accR[0], accR[1], wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0]);
+            else mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
+        }
 #if SCAN16_Z0_EARLY
-        z_block_mfma<true>(accZ[0], accZ[1], wz_hi[0][0], wz_lo[0][0], wz_hi[1][0], wz_lo[1][0], bh[0], bl[0]);
+        if constexpr (MIX) z_block_mfma2<true>(accZ[0], accZ[1], wz_hi[0][0], wz_lo[0][0], wz_hi[1][0], wz_lo[1][0], bh[0]);
+        else z_block_mfma<true>(accZ[0], accZ[1], wz_hi[0][0], wz_lo[0][0], wz_hi[1][0], wz_lo[1][0], bh[0], bl[0]);
 #endif
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
+        for (int i = 1; i < KBS; i++) { keep(bh[i]); if constexpr (!MIX) keep(bl[i]); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 1; i < KBS; i++) {
-            if constexpr (T9) z_block_mfma<false>(accR[0], accR[1], wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i]);
-            else mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
+            if constexpr (MIX) {
+                if constexpr (T9) z_block_mfma2<false>(accR[0], accR[1], wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i]);
+                else mfma2x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], accR[0], accR[1]);
+            } else {
+                if constexpr (T9) z_block_mfma<false>(accR[0], accR[1], wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i]);
+                else mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
+            }
         }
         f32x4 acc9 = {0.f, 0.f, 0.f, 0.f};
         float h9prev = 0.0f;
@@ -255,11 +288,13 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         __builtin_amdgcn_sched_barrier(0);
         // z products of blocks 0 .. KBS-2 under the r epilogue
 #if !SCAN16_Z0_EARLY
-        z_block_mfma<true>(accZ[0], accZ[1], wz_hi[0][0], wz_lo[0][0], wz_hi[1][0], wz_lo[1][0], bh[0], bl[0]);
+        if constexpr (MIX) z_block_mfma2<true>(accZ[0], accZ[1], wz_hi[0][0], wz_lo[0][0], wz_hi[1][0], wz_lo[1][0], bh[0]);
+        else z_block_mfma<true>(accZ[0], accZ[1], wz_hi[0][0], wz_lo[0][0], wz_hi[1][0], wz_lo[1][0], bh[0], bl[0]);
 #endif
         static_for<1, KBS - 1>([&](auto IC) {
             constexpr int i = decltype(IC)::value;
-            z_block_mfma<false>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i]);
+            if constexpr (MIX) z_block_mfma2<false>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i]);
+            else z_block_mfma<false>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i]);
         });
         if constexpr (!(SCAN16_ABL & 5)) {                                                                  // this step's vI (see above)
             if constexpr (T9) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
@@ -269,8 +304,8 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         if constexpr (T9) { pin_f(cur.z[2]); pin_f(cur.r[2]); pin_f(cur.c[2]); }
         if constexpr (T9) { mfma_drain(accR[0]); mfma_drain(accR[1]); }       // asm MFMAs: the compiler keeps no distance for them
         float rr[2];
-        rr[0] = nok0 ? sigmoid4(fmaf(sel4(accR[0], q), inv_r[0], cur.r[0])) : 0.0f;
-        rr[1] = nok1 ? sigmoid4(fmaf(sel4(accR[1], q), inv_r[1], cur.r[1])) : 0.0f;
+        rr[0] = nok0 ? sigmoid4(fmaf(pick(accR[0]), inv_r[0], cur.r[0])) : 0.0f;
+        rr[1] = nok1 ? sigmoid4(fmaf(pick(accR[1]), inv_r[1], cur.r[1])) : 0.0f;
         {
             unsigned hi, lo;
             split2(rr[0] * hold[0], rr[1] * hold[1], hi, lo);
@@ -280,46 +315,61 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         }
         if constexpr (T9) {
             if (duty == 0) {
-                const float rr9 = nok9 ? sigmoid4(fmaf(sel4(acc9, q), inv9, cur.r[2])) : 0.0f;
+                const float rr9 = nok9 ? sigmoid4(fmaf(pick(acc9), inv9, cur.r[2])) : 0.0f;
                 unsigned hi, lo;
                 split2(rr9 * h9prev, 0.0f, hi, lo);
                 rh_hi[wd9] = hi;
                 rh_lo[wd9] = lo;
             } else if (duty == 1) {
-                z9f[lane] = sigmoid4(fmaf(sel4(acc9, q), inv9, cur.z[2]));
+                z9f[lane] = sigmoid4(fmaf(pick(acc9), inv9, cur.z[2]));
             }
         }
-        half8 ch[KBS], cl[KBS];
-        ch[0] = ldH(rh_hi, boff[0]);                     // my own block, straight back (LDS executes a wave's operations in order)
-        cl[0] = ldH(rh_lo, boff[0]);
+        half8 ch[KBS], cl[KBS];                          // MIX: ch = the mixed operands, cl unused
+        if constexpr (MIX) {
+            ch[0] = ldH(rh_img, moff[0]);                // my own block, straight back (LDS executes a wave's operations in order)
+            cl[0] = ch[0];
+        } else {
+            ch[0] = ldH(rh_hi, boff[0]);
+            cl[0] = ldH(rh_lo, boff[0]);
+        }
         lds_fence();
         // ------------------------------ interval B ------------------------------
-        lds_bar_2reads();
+        if constexpr (MIX) lds_bar_1read(); else lds_bar_2reads();
 #pragma unroll
-        for (int i = 1; i < KBS; i++) { ch[i] = ldH(rh_hi, boff[i]); cl[i] = ldH(rh_lo, boff[i]); }
+        for (int i = 1; i < KBS; i++) {
+            if constexpr (MIX) ch[i] = ldH(rh_img, moff[i]);
+            else { ch[i] = ldH(rh_hi, boff[i]); cl[i] = ldH(rh_lo, boff[i]); }
+        }
         __builtin_amdgcn_sched_barrier(0);
-        z_block_mfma<false>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1],
-                            bl[KBS - 1]);
-        z_block_mfma<true>(accC[0], accC[1], wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0]);
+        if constexpr (MIX) {
+            z_block_mfma2<false>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1]);
+            z_block_mfma2<true>(accC[0], accC[1], wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0]);
+        } else {
+            z_block_mfma<false>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1],
+                                bl[KBS - 1]);
+            z_block_mfma<true>(accC[0], accC[1], wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int i = 1; i < KBS; i++) { keep(ch[i]); keep(cl[i]); }
+        for (int i = 1; i < KBS; i++) { keep(ch[i]); if constexpr (!MIX) keep(cl[i]); }
         __builtin_amdgcn_sched_barrier(0);
-        z_block_mfma<false>(accC[0], accC[1], wc_hi[0][1], wc_lo[0][1], wc_hi[1][1], wc_lo[1][1], ch[1], cl[1]);
-        // the z accumulators: twelve MFMAs have been issued since their last one
+        if constexpr (MIX) z_block_mfma2<false>(accC[0], accC[1], wc_hi[0][1], wc_lo[0][1], wc_hi[1][1], wc_lo[1][1], ch[1]);
+        else z_block_mfma<false>(accC[0], accC[1], wc_hi[0][1], wc_lo[0][1], wc_hi[1][1], wc_lo[1][1], ch[1], cl[1]);
+        // the z accumulators: twelve (MIX: eight) MFMAs have been issued since their last one
         asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]));
         float zz[2], omz[2], zh[2];
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            zz[p] = sigmoid4(fmaf(sel4(accZ[p], q), inv_z[p], cur.z[p]));
+            zz[p] = sigmoid4(fmaf(pick(accZ[p]), inv_z[p], cur.z[p]));
             omz[p] = 1.0f - zz[p];
             zh[p] = zz[p] * hold[p];
             asm volatile("" : "+v"(zh[p]), "+v"(omz[p]));                 // pinned here: not sunk to the blend below
         }
         static_for<2, KBS>([&](auto IC) {
             constexpr int i = decltype(IC)::value;
-            z_block_mfma<false>(accC[0], accC[1], wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i]);
+            if constexpr (MIX) z_block_mfma2<false>(accC[0], accC[1], wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i]);
+            else z_block_mfma<false>(accC[0], accC[1], wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i]);
         });
         f32x4 acc9c = {0.f, 0.f, 0.f, 0.f};
         float z9 = 0.0f;
@@ -333,7 +383,7 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         mfma_drain(accC[1]);
         float hn[2];
         {
-            const float hb0 = tanh5(fmaf(sel4(accC[0], q), inv_c[0], cur.c[0])), hb1 = tanh5(fmaf(sel4(accC[1], q), inv_c[1], cur.c[1]));
+            const float hb0 = tanh5(fmaf(pick(accC[0]), inv_c[0], cur.c[0])), hb1 = tanh5(fmaf(pick(accC[1]), inv_c[1], cur.c[1]));
             hn[0] = nok0 ? fmaf(omz[0], hb0, zh[0]) : 0.0f;               // layers.py:1020
             hn[1] = nok1 ? fmaf(omz[1], hb1, zh[1]) : 0.0f;
         }
@@ -347,7 +397,7 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         float hn9 = 0.0f;
         if constexpr (T9) {
             if (w3) {
-                const float hb9 = tanh5(fmaf(sel4(acc9c, q), inv9, cur.c[2]));
+                const float hb9 = tanh5(fmaf(pick(acc9c), inv9, cur.c[2]));
                 hn9 = nok9 ? fmaf(1.0f - z9, hb9, z9 * hold9) : 0.0f;
                 h9f[lane] = hn9;
                 unsigned hi, lo;
@@ -356,8 +406,13 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
                 h_lo[wd9] = lo;
             }
         }
-        oh = ldH(h_hi, boff[0]);
-        ol = ldH(h_lo, boff[0]);
+        if constexpr (MIX) {
+            oh = ldH(h_img, moff[0]);
+            ol = oh;
+        } else {
+            oh = ldH(h_hi, boff[0]);
+            ol = ldH(h_lo, boff[0]);
+        }
         lds_fence();
         if (live && s < Tc && !(SCAN16_ABL & 2)) {
             if (nok0) hp[0] = hn[0];
