@@ -109,6 +109,7 @@ __device__ __forceinline__ f32x4 tile_mfma_acc(const half8 *w_hi, const half8 *w
     return acc;
 }
 __device__ __forceinline__ void mfma_drain(f32x4 &a) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a)); }
+__device__ __forceinline__ void mfma_drain2(f32x4 &a, f32x4 &b) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b)); }
 // one K block of one tile, accumulator kept across steps (chain waves); FIRST: start from zero
 template <bool FIRST>
 __device__ __forceinline__ void block_mfma_acc(f32x4 &acc, const half8 &w_hi, const half8 &w_lo, const half8 &x_hi, const half8 &x_lo)
@@ -206,6 +207,26 @@ __device__ __forceinline__ float pick_mix(const f32x4 &a)
                  "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x8"
                  : "=&v"(r)
                  : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+    return r;
+}
+// The same for gru_bar16d.hip's layout (eight chunks per workgroup: the two copies of a chunk sit FOUR columns apart, copy q&1 = 0 carries
+// the hi half and owns rows 4g + {0, 1}, copy 1 the lo half and rows 4g + {2, 3}): value j of the lane = register 2(q&1) + j summed over
+// both copies.  Two instructions: the even quartets take their partner four lanes up, the odd ones four lanes down.
+__device__ __forceinline__ float pick_mix_d(const f32x4 &a, int j)
+{
+    float r;
+    if (j == 0)
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                     "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+                     : "=&v"(r)
+                     : "v"(a[0]), "v"(a[2]));
+    else
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                     "v_add_f32_dpp %0, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
+                     : "=&v"(r)
+                     : "v"(a[1]), "v"(a[3]));
     return r;
 }
 // barrier for a wave whose youngest LDS operation is a read of its own data (lds_bar_2reads with one operand image)

@@ -22,6 +22,12 @@
 
 #include "bar16_common.h"
 
+// 1: two MFMAs per recurrent product, the state's hi and lo halves in different column groups (bar16_common.h: mfma2x2, pick_mix);
+// 0: round 2's three-term sequence (every column group a copy of the hi half, the lo half a second operand)
+#ifndef BAR16_MIX
+#define BAR16_MIX 1
+#endif
+
 // Diagnostic instantiation: shader-clock cycles the waves of workgroup 0 spend in each section of a step, summed over the scan
 // (tools/bar16_check.py reads them).  The production instantiation carries none of this.
 // (Diagnostic launches and the readers of these tables exist only in builds with -DSLK_DIAG: tools/build_diag_lib.sh.)
@@ -101,13 +107,16 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
     __shared__ __attribute__((aligned(16))) float xinv_lds[2 * 16];
     __shared__ __attribute__((aligned(16))) float vbuf[R * VSTEP];
     // + 4: sixteen zero bytes behind each image, the operand of the lanes whose columns stay empty (ZC below)
-    __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * N + 4], h_lo[2 * N + 4], rh_hi[2 * N + 4], rh_lo[2 * N + 4];
+    constexpr int IMG = 2 * N + 4;
+    __shared__ __attribute__((aligned(16))) unsigned h_img[2 * IMG], rh_img[2 * IMG];             // hi image, then lo image
+    unsigned *const h_hi = h_img, *const h_lo = h_img + IMG, *const rh_hi = rh_img, *const rh_lo = rh_img + IMG;
     // ZC (ABL & 64, an experiment kept for the record): the state enters the recurrent MFMAs in column group 0 only (lanes
     // q = 0 read it, the others read zeros; gather4 instead of sel4).  When the kernel fills the chip its clock is set by the
     // power limit (tools/bar16_wg_times.py: 1.83-2.39 GHz at B = 1024 depending on the device and the moment, 2.38-2.41 GHz
     // at B = 256, always the same 1880 cycles per step), and a matrix pipe multiplying zeros draws less -- but alternating
     // launches on one device give it +1-2 % of clock for +1.8 % of cycles (the DPP moves), in the pipeline nothing.
     constexpr bool ZC = (ABL & 64) != 0;
+    constexpr bool MIX = BAR16_MIX != 0 && !ZC;
     __shared__ __attribute__((aligned(16))) float bias_lds[3 * N], invw_lds[3 * N];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -241,6 +250,9 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         int boff[KBS];
 #pragma unroll
         for (int i = 0; i < KBS; i++) boff[i] = (ZC && q != 0) ? 2 * N : ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
+        int moff[KBS];                                   // MIX: my column group's image (q = 0, 1: hi; q = 2, 3: lo)
+#pragma unroll
+        for (int i = 0; i < KBS; i++) moff[i] = (q >> 1) * IMG + boff[i];
         const int wd = ((w * 4 + g) * 4 + c) * 4 + q;                                           // my packed pair, in dwords
         const int n0 = 32 * w + 4 * g + q;                                                      // my neuron of tile 2w (+16: 2w+1)
         const int voff = (g * 4 + c) * 4 + q;                                                   // my element of a vI tile
@@ -295,18 +307,34 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 ::mfma3x2(w0_hi, w0_lo, w1_hi, w1_lo, h_hi_, h_lo_, acc0, acc1);
             }
         };
-        auto pick = [&](const f32x4 &a) { if constexpr (ZC) return gather4(a); else return sel4(a, q); };
+        auto mfma2x2 = [](const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi, const half8 &w1_lo, const half8 &bm, f32x4 &acc0,
+                          f32x4 &acc1) {
+            if constexpr (ABL & 2) {
+                half8 a = w0_hi, b = bm;
+                asm volatile("" : "+v"(a), "+v"(b), "+v"(acc0), "+v"(acc1));
+            } else {
+                ::mfma2x2(w0_hi, w0_lo, w1_hi, w1_lo, bm, acc0, acc1);
+            }
+        };
+        auto pick = [&](const f32x4 &a) {
+            if constexpr (ZC) return gather4(a);
+            else if constexpr (MIX) return pick_mix(a);
+            else return sel4(a, q);
+        };
         auto step = [&](auto PHC, const int s, const int G) {
             constexpr int ph = decltype(PHC)::value;
             constexpr bool PROJ = CT > 0 && ph < KBLK;
             // ------------------------------ interval A ------------------------------
-            if constexpr (DIAG) lds_bar(); else lds_bar_2reads<!(ABL & 1)>();
+            if constexpr (DIAG) lds_bar(); else if constexpr (MIX) lds_bar_1read<!(ABL & 1)>(); else lds_bar_2reads<!(ABL & 1)>();
             BSTAMP(0)
-            half8 bh[KBS], bl[KBS];
+            half8 bh[KBS], bl[KBS];                      // MIX: bh = the mixed operands, bl unused
             bh[0] = oh;
             bl[0] = ol;
 #pragma unroll
-            for (int i = 1; i < KBS; i++) { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+            for (int i = 1; i < KBS; i++) {
+                if constexpr (MIX) bh[i] = ldH(h_img, moff[i]);
+                else { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+            }
             // vI(s): complete since the previous barrier at the latest (the service waves use every interval)
             const float *vcur = vbuf + (s % R) * VSTEP + voff;
             float vz[2], vr[2], vc[2];
@@ -318,7 +346,8 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             }
             __builtin_amdgcn_sched_barrier(0);
             f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
+            if constexpr (MIX) mfma2x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], accR[0], accR[1]);
+            else mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
             if constexpr (PROJ) {                        // my tile of the projection, K block ph: inside the LDS round trip
                 if constexpr (!(ABL & 2)) {
 #pragma unroll
@@ -336,25 +365,33 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             if constexpr (KBS > 1) {
                 asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");       // the six vI words may still be on their way
 #pragma unroll
-                for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
+                for (int i = 1; i < KBS; i++) { keep(bh[i]); if constexpr (!MIX) keep(bl[i]); }
                 __builtin_amdgcn_sched_barrier(0);
                 BSTAMP(1)
 #pragma unroll
-                for (int i = 1; i < KBS; i++)
-                    mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
+                for (int i = 1; i < KBS; i++) {
+                    if constexpr (MIX) mfma2x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], accR[0], accR[1]);
+                    else mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             BSTAMP(2)
             if constexpr (ZACC && !(ABL & 2)) {
                 static_for<0, KBS - 1>([&](auto IC) {
                     constexpr int i = decltype(IC)::value;
-                    z_block_mfma<i == 0>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i]);
+                    if constexpr (MIX) z_block_mfma2<i == 0>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i]);
+                    else z_block_mfma<i == 0>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i]);
                 });
             } else {
 #pragma unroll
-                for (int i = 0; i < KBS - 1; i++)
-                    mfma3x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i], accZ[0], accZ[1]);
+                for (int i = 0; i < KBS - 1; i++) {
+                    if constexpr (MIX) mfma2x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], accZ[0], accZ[1]);
+                    else mfma3x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i], accZ[0], accZ[1]);
+                }
             }
+            // pick_mix reads the accumulators from asm, where the compiler keeps no distance to the MFMAs that wrote them: with more
+            // than one K block the z products above lie in between, otherwise let the pipe drain
+            if constexpr (MIX && KBS == 1) mfma_drain2(accR[0], accR[1]);
             float rr[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) rr[p] = (ABL & 4) ? fmaf(pick(accR[p]), inv_r[p], vr[p]) * 0.01f : sigmoid4(fmaf(pick(accR[p]), inv_r[p], vr[p]));
@@ -365,9 +402,14 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 rh_hi[wd] = hi;
                 rh_lo[wd] = lo;
             }
-            half8 ch[KBS], cl[KBS];
-            ch[0] = ldH(rh_hi, boff[0]);                 // my own block, straight back (LDS executes a wave's operations in order)
-            cl[0] = ldH(rh_lo, boff[0]);
+            half8 ch[KBS], cl[KBS];                      // MIX: ch = the mixed operands, cl unused
+            if constexpr (MIX) {
+                ch[0] = ldH(rh_img, moff[0]);            // my own block, straight back (LDS executes a wave's operations in order)
+                cl[0] = ch[0];
+            } else {
+                ch[0] = ldH(rh_hi, boff[0]);
+                cl[0] = ldH(rh_lo, boff[0]);
+            }
             lds_fence();
             // one MFMA, then up to three VALU instructions, for as long as both last
 #pragma unroll
@@ -380,10 +422,13 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 if (store) { zp[N] = rr[0]; zp[N + 16] = rr[1]; }
             }
             // ------------------------------ interval B ------------------------------
-            if constexpr (DIAG) { BSTAMP(3) lds_bar(); } else lds_bar_2reads<!(ABL & 1)>();
+            if constexpr (DIAG) { BSTAMP(3) lds_bar(); } else if constexpr (MIX) lds_bar_1read<!(ABL & 1)>(); else lds_bar_2reads<!(ABL & 1)>();
             BSTAMP(4)
 #pragma unroll
-            for (int i = 1; i < KBS; i++) { ch[i] = ldH(rh_hi, boff[i]); cl[i] = ldH(rh_lo, boff[i]); }
+            for (int i = 1; i < KBS; i++) {
+                if constexpr (MIX) ch[i] = ldH(rh_img, moff[i]);
+                else { ch[i] = ldH(rh_hi, boff[i]); cl[i] = ldH(rh_lo, boff[i]); }
+            }
             constexpr int nph = (ph + 1) & 3;            // the next step projects K block nph of the group after ITS group
             constexpr bool NPROJ = CT > 0 && nph < KBLK;
             half8 xh, xl;
@@ -393,24 +438,33 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 xl = ldH(xop_lo, ob);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ZACC && !(ABL & 2))
+            if constexpr (MIX) {
+                if constexpr (ZACC && !(ABL & 2))
+                    z_block_mfma2<KBS == 1>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1],
+                                            bh[KBS - 1]);
+                else
+                    mfma2x2(wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1], accZ[0], accZ[1]);
+            } else if constexpr (ZACC && !(ABL & 2))
                 z_block_mfma<KBS == 1>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1],
                                        bl[KBS - 1]);
             else
                 mfma3x2(wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1], bl[KBS - 1], accZ[0],
                         accZ[1]);
             f32x4 accC[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            mfma3x2(wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0], accC[0], accC[1]);
+            if constexpr (MIX) mfma2x2(wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], accC[0], accC[1]);
+            else mfma3x2(wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0], accC[0], accC[1]);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 1; i < KBS; i++) { keep(ch[i]); keep(cl[i]); }
+            for (int i = 1; i < KBS; i++) { keep(ch[i]); if constexpr (!MIX) keep(cl[i]); }
             if constexpr (NPROJ) { keep(xh); keep(xl); pxh = xh; pxl = xl; }
             __builtin_amdgcn_sched_barrier(0);
             BSTAMP(5)
 #pragma unroll
-            for (int i = 1; i < KBS; i++)
-                mfma3x2(wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i], accC[0], accC[1]);
+            for (int i = 1; i < KBS; i++) {
+                if constexpr (MIX) mfma2x2(wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], accC[0], accC[1]);
+                else mfma3x2(wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i], accC[0], accC[1]);
+            }
             // asm MFMAs wrote the z accumulators: six candidate MFMAs (or the drain) have been issued since the last of them
             if constexpr (ZACC && !(ABL & 2)) {
                 if constexpr (KBS == 1) { mfma_drain(accZ[0]); mfma_drain(accZ[1]); }
@@ -431,6 +485,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             }
             __builtin_amdgcn_sched_barrier(0);
             BSTAMP(6)
+            if constexpr (MIX) mfma_drain2(accC[0], accC[1]);                  // the candidate's last MFMAs were issued just above
             float hn[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
@@ -444,8 +499,13 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 h_hi[wd] = hi;
                 h_lo[wd] = lo;
             }
-            oh = ldH(h_hi, boff[0]);
-            ol = ldH(h_lo, boff[0]);
+            if constexpr (MIX) {
+                oh = ldH(h_img, moff[0]);
+                ol = oh;
+            } else {
+                oh = ldH(h_hi, boff[0]);
+                ol = ldH(h_lo, boff[0]);
+            }
             lds_fence();
             if (store) {
                 hp[0] = hn[0];

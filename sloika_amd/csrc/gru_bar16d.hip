@@ -40,6 +40,11 @@ typedef float f32x2d __attribute__((ext_vector_type(2)));
 // which gate's weights live in accumulation registers (its MFMAs are asm, placed where the source puts them): 0 = the update gate,
 // 1 = the candidate (its MFMAs come in one run in front of its epilogue anyway; the update gate's stay the compiler's to interleave):
 // measured 2912 against 2782 cycles per step
+// 1: two MFMAs per recurrent product, the two copies of a chunk carrying the hi and the lo half of the state (bar16_common.h: mfma2x2,
+// pick_mix_d) -- the same arithmetic as gru_bar16.hip's, bit for bit; 0: round 2's three-term sequence
+#ifndef BAR16D_MIX
+#define BAR16D_MIX 1
+#endif
 #ifndef BAR16D_CACC
 #define BAR16D_CACC 0
 #endif
@@ -110,7 +115,10 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
     __shared__ __attribute__((aligned(16))) unsigned xop_hi[2 * 2 * OPIMG], xop_lo[2 * 2 * OPIMG];      // [group & 1][set]
     __shared__ __attribute__((aligned(16))) float xinv_lds[2 * 2 * 16];
     __shared__ __attribute__((aligned(16))) float vbuf[R * 2 * VSTEP];                                   // [step % R][set]
-    __shared__ __attribute__((aligned(16))) unsigned h_hi[2 * 2 * N], h_lo[2 * 2 * N], rh_hi[2 * 2 * N], rh_lo[2 * 2 * N];   // [set]
+    constexpr bool MIX = BAR16D_MIX != 0;
+    static_assert(!MIX || (!BAR16D_ZHOOK && !BAR16D_CACC), "the two-term products are written for the default schedule only");
+    __shared__ __attribute__((aligned(16))) unsigned h_img[2 * 4 * N], rh_img[2 * 4 * N];          // hi image [set], then lo image [set]
+    unsigned *const h_hi = h_img, *const h_lo = h_img + 4 * N, *const rh_hi = rh_img, *const rh_lo = rh_img + 4 * N;
     __shared__ __attribute__((aligned(16))) float bias_lds[3 * N], invw_lds[3 * N];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -241,6 +249,9 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
         int boff[KBS];
 #pragma unroll
         for (int i = 0; i < KBS; i++) boff[i] = set * 2 * N + ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
+        int moff[KBS];                                   // MIX: my copy's image (q & 1 = 0: hi, 1: lo)
+#pragma unroll
+        for (int i = 0; i < KBS; i++) moff[i] = qh * 4 * N + boff[i];
         const int wd = set * 2 * N + ((w * 4 + g) * 4 + c) * 4 + 2 * qh;                         // my two packed pairs, in dwords
         const int n0 = 32 * w + 4 * g + 2 * qh;                                                  // my neurons n0, n0+1 of tile 2w (+16: 2w+1)
         const int voff = (g * 4 + c) * 4 + 2 * qh;                                               // my two elements of a vI tile
@@ -281,9 +292,18 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
         // carried from step to step: my own K block of h(s-1) as B operand (read back right after I wrote it)
         half8 oh = hzero, ol = hzero;
         // rows 4g + 2qh + j of a tile's accumulator
-        auto pick = [&](const f32x4 &a, int j) { return qh ? a[2 + j] : a[j]; };
+        auto pick = [&](const f32x4 &a, int j) {
+            if constexpr (MIX) return pick_mix_d(a, j);
+            else return qh ? a[2 + j] : a[j];
+        };
         auto mfma_z = [&](auto FIRSTC, int i, const half8 &bh_, const half8 &bl_, f32x4 &a0, f32x4 &a1) {
-            z_block_mfma<decltype(FIRSTC)::value != 0>(a0, a1, wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh_, bl_);
+            if constexpr (MIX) z_block_mfma2<decltype(FIRSTC)::value != 0>(a0, a1, wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh_);
+            else z_block_mfma<decltype(FIRSTC)::value != 0>(a0, a1, wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh_, bl_);
+        };
+        // r / c products of one K block (MIX: bh_ = the mixed operand, bl_ unused)
+        auto mfma_rc = [&](const half8 (&wh)[2][KBS], const half8 (&wl)[2][KBS], int i, const half8 &bh_, const half8 &bl_, f32x4 &a0, f32x4 &a1) {
+            if constexpr (MIX) mfma2x2(wh[0][i], wl[0][i], wh[1][i], wl[1][i], bh_, a0, a1);
+            else mfma3x2(wh[0][i], wl[0][i], wh[1][i], wl[1][i], bh_, bl_, a0, a1);
         };
         // One step = two intervals, each opened by a barrier (see gru_bar16.hip for the plan of a step)
         auto step = [&](auto PHC, const int s, const int G) {
@@ -291,13 +311,16 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
             constexpr bool PROJ = CT > 0 && ph < KBLK && !(BAR16D_ABL & 4);
             // ------------------------------ interval A ------------------------------
             DSTAMP_IN(2 * ph)
-            if constexpr (BAR16D_ABL & 16) lds_bar(); else lds_bar_2reads();
+            if constexpr (BAR16D_ABL & 16) lds_bar(); else if constexpr (MIX) lds_bar_1read(); else lds_bar_2reads();
             DSTAMP_OUT(2 * ph)
-            half8 bh[KBS], bl[KBS];
+            half8 bh[KBS], bl[KBS];                      // MIX: bh = the mixed operands, bl unused
             bh[0] = oh;
             bl[0] = ol;
 #pragma unroll
-            for (int i = 1; i < KBS; i++) { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+            for (int i = 1; i < KBS; i++) {
+                if constexpr (MIX) bh[i] = ldH(h_img, moff[i]);
+                else { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+            }
             // vI(s): complete since the previous barrier at the latest (the service waves use every interval)
             const float *vcur = vbuf + ((s % R) * 2 + set) * VSTEP + voff;
             f32x2d vz[2], vr[2], vc[2];
@@ -309,7 +332,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
             }
             __builtin_amdgcn_sched_barrier(0);
             f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2];
-            mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
+            mfma_rc(wr_hi, wr_lo, 0, bh[0], bl[0], accR[0], accR[1]);
             if constexpr (PROJ) {                        // my tiles of the projection, K block ph, both sets: inside the LDS round trip
 #pragma unroll
                 for (int sset = 0; sset < 2; sset++) {
@@ -331,11 +354,10 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
             if constexpr (KBS > 1) {
                 asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");       // the six vI reads may still be on their way
 #pragma unroll
-                for (int i = 1; i < KBS; i++) { keep(bh[i]); keep(bl[i]); }
+                for (int i = 1; i < KBS; i++) { keep(bh[i]); if constexpr (!MIX) keep(bl[i]); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 1; i < KBS; i++)
-                    mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
+                for (int i = 1; i < KBS; i++) mfma_rc(wr_hi, wr_lo, i, bh[i], bl[i], accR[0], accR[1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // z products of all blocks but the last INSIDE the r epilogue: the asm MFMAs are not the compiler's to place (it put
@@ -373,6 +395,9 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
 #pragma unroll
                     for (int i = 1; i < KBS - 1; i++) mfma_z(ic<0>{}, i, bh[i], bl[i], accZ[0], accZ[1]);
                 }
+                // pick_mix_d reads the accumulators from asm, where the compiler keeps no distance to the MFMAs that wrote them: with
+                // more than one K block the z products lie in between, otherwise let the pipe drain
+                if constexpr (MIX && KBS == 1) mfma_drain2(accR[0], accR[1]);
 #pragma unroll
                 for (int p = 0; p < 2; p++) {
 #pragma unroll
@@ -391,9 +416,14 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
             lds_fence();
             *reinterpret_cast<uint2 *>(&rh_hi[wd]) = rhi;
             *reinterpret_cast<uint2 *>(&rh_lo[wd]) = rlo;
-            half8 ch[KBS], cl[KBS];
-            ch[0] = ldH(rh_hi, boff[0]);                 // my own block, straight back (LDS executes a wave's operations in order)
-            cl[0] = ldH(rh_lo, boff[0]);
+            half8 ch[KBS], cl[KBS];                      // MIX: ch = the mixed operands, cl unused
+            if constexpr (MIX) {
+                ch[0] = ldH(rh_img, moff[0]);            // my own block, straight back (LDS executes a wave's operations in order)
+                cl[0] = ch[0];
+            } else {
+                ch[0] = ldH(rh_hi, boff[0]);
+                cl[0] = ldH(rh_lo, boff[0]);
+            }
             lds_fence();
             const bool store = live && s < Tc && !(BAR16D_ABL & 8);
             if constexpr (SAVE) {
@@ -404,10 +434,13 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
             }
             // ------------------------------ interval B ------------------------------
             DSTAMP_IN(2 * ph + 1)
-            if constexpr (BAR16D_ABL & 16) lds_bar(); else lds_bar_2reads();
+            if constexpr (BAR16D_ABL & 16) lds_bar(); else if constexpr (MIX) lds_bar_1read(); else lds_bar_2reads();
             DSTAMP_OUT(2 * ph + 1)
 #pragma unroll
-            for (int i = 1; i < KBS; i++) { ch[i] = ldH(rh_hi, boff[i]); cl[i] = ldH(rh_lo, boff[i]); }
+            for (int i = 1; i < KBS; i++) {
+                if constexpr (MIX) ch[i] = ldH(rh_img, moff[i]);
+                else { ch[i] = ldH(rh_hi, boff[i]); cl[i] = ldH(rh_lo, boff[i]); }
+            }
             constexpr int nph = (ph + 1) & 3;            // the next step projects K block nph of the group after ITS group
             constexpr bool NPROJ = CT > 0 && nph < KBLK;
             half8 xh[2], xl[2];
@@ -430,12 +463,12 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 else mfma_z(ic<1>{}, 0, bh[0], bl[0], accZ[0], accZ[1]);
                 accC[0] = f32x4{0.f, 0.f, 0.f, 0.f};
                 accC[1] = accC[0];
-                mfma3x2(wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0], accC[0], accC[1]);
+                mfma_rc(wc_hi, wc_lo, 0, ch[0], cl[0], accC[0], accC[1]);
             }
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int i = 1; i < KBS; i++) { keep(ch[i]); keep(cl[i]); }
+            for (int i = 1; i < KBS; i++) { keep(ch[i]); if constexpr (!MIX) keep(cl[i]); }
             if constexpr (NPROJ) {
 #pragma unroll
                 for (int sset = 0; sset < 2; sset++) { keep(xh[sset]); keep(xl[sset]); pxh[sset] = xh[sset]; pxl[sset] = xl[sset]; }
@@ -449,7 +482,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 });
             } else {
                 if constexpr (KBS > 1) {
-                    mfma3x2(wc_hi[0][1], wc_lo[0][1], wc_hi[1][1], wc_lo[1][1], ch[1], cl[1], accC[0], accC[1]);
+                    mfma_rc(wc_hi, wc_lo, 1, ch[1], cl[1], accC[0], accC[1]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // the z accumulators came from asm MFMAs the compiler does not know as such: twelve MFMAs (or the drain) have been
@@ -457,8 +490,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 if constexpr (KBS == 1) { mfma_drain(accZ[0]); mfma_drain(accZ[1]); }
                 else asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]));
 #pragma unroll
-                for (int i = 2; i < KBS; i++)
-                    mfma3x2(wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i], accC[0], accC[1]);
+                for (int i = 2; i < KBS; i++) mfma_rc(wc_hi, wc_lo, i, ch[i], cl[i], accC[0], accC[1]);
             }
             float zz[2][2], omz[2][2], zh[2][2];
 #pragma unroll
@@ -483,6 +515,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MIX) mfma_drain2(accC[0], accC[1]);                  // the candidate's last MFMAs were issued just above
             float hn[2][2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
@@ -500,8 +533,13 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 *reinterpret_cast<uint2 *>(&h_hi[wd]) = hi;
                 *reinterpret_cast<uint2 *>(&h_lo[wd]) = lo;
             }
-            oh = ldH(h_hi, boff[0]);
-            ol = ldH(h_lo, boff[0]);
+            if constexpr (MIX) {
+                oh = ldH(h_img, moff[0]);
+                ol = oh;
+            } else {
+                oh = ldH(h_hi, boff[0]);
+                ol = ldH(h_lo, boff[0]);
+            }
             lds_fence();
             if (store) {
                 *reinterpret_cast<f32x2d *>(hp) = f32x2d{hn[0][0], hn[0][1]};

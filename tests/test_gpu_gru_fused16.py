@@ -263,9 +263,9 @@ def test_fused16_launches_are_deterministic(I, n):
 
 @pytest.mark.parametrize("I,n", [(96, 96), (64, 64), (32, 96), (48, 32)])
 def test_eight_chunk_plan_is_bit_identical(I, n):
-    """gru_bar16d.hip (eight chunks per workgroup) and gru_bar16q.hip (sixteen) compute every (neuron, chunk) pair with the same
-    instructions in the same order as gru_bar16.hip: the plans must agree bit for bit -- states and saved gates, ragged and
-    reversed, batch sizes around the multiples of eight and sixteen and batches (2048 + 3, 4096 + 4 chunks) that take the eight-
+    """gru_bar16d.hip (eight chunks per workgroup) computes every (neuron, chunk) pair with the same instructions in the same order as
+    gru_bar16.hip: the two plans must agree bit for bit; gru_bar16q.hip (sixteen) within float32 rounding -- states and saved gates,
+    ragged and reversed, batch sizes around the multiples of eight and sixteen and batches (2048 + 3, 4096 + 4 chunks) that take the eight-
     and the sixteen-chunk plan by themselves."""
     torch = need_gpu()
     from sloika_amd import _lib
@@ -288,5 +288,11 @@ def test_eight_chunk_plan_is_bit_identical(I, n):
                                              I, n, reverse | (plan << 8), 1, 2, None if lp is None else lp.data_ptr(), zr.data_ptr(), stream())
                     assert rc == 0
                     got.append((torch.nan_to_num(y, nan=9.0), torch.nan_to_num(zr, nan=9.0)))
-                for other in got[1:]:
-                    assert torch.equal(got[0][0], other[0]) and torch.equal(got[0][1], other[1]), (T, B, reverse, lp is not None)
+                # four and eight chunks per workgroup: the same two-MFMA products (hi and lo halves of the state in different column
+                # groups) in the same order -> the same bits
+                assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1]), (T, B, reverse, lp is not None)
+                # sixteen chunks leave no column group to spare: the three-term products agree to float32 rounding (states and gates
+                # are in [-1, 1])
+                for other in got[2:]:
+                    assert (got[0][0] - other[0]).abs().max().item() < 3e-6 and (got[0][1] - other[1]).abs().max().item() < 3e-6, \
+                        (T, B, reverse, lp is not None)
