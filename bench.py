@@ -165,7 +165,8 @@ def cpu_baseline_train(model_name, chunk_len, nchunk=48):
 def roofline_of(stages, traffic_by_stage, note=None):
     """The dominant stage (by device time) of a pass timed with HIP events: algorithmic work per launch / average launch
     duration, against the peak of the pipe it runs on (matrix stages: the fp32 part at the fp32 MFMA peak, the part evaluated
-    as a 3-term fp16 split at three fp16 MFMAs per product; the others against HBM)."""
+    as a 3-term fp16 split at three fp16 MFMAs per product, the part whose lo half rides in spare MFMA columns at two; the others
+    against HBM)."""
     if not stages:
         return None
     dom = max(stages, key=lambda k: stages[k]["ms_total"])
@@ -173,13 +174,14 @@ def roofline_of(stages, traffic_by_stage, note=None):
     if dom in MFMA_STAGES and d["flops"] > 0:
         flops = d["flops"] / d["calls"]
         f16 = d.get("f16x3_flops", 0.0) / d["calls"]
-        t_min = (flops - f16) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + 3.0 * f16 / (F16_MFMA_PEAK_TFLOPS * 1e12)
+        f16x2 = d.get("f16x2_flops", 0.0) / d["calls"]
+        t_min = (flops - f16 - f16x2) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + (3.0 * f16 + 2.0 * f16x2) / (F16_MFMA_PEAK_TFLOPS * 1e12)
         ach = flops / (d["ms_avg"] * 1e-3) / 1e12
         peak = flops / t_min / 1e12
         out = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                "traffic": traffic_by_stage.get(dom), "ms_per_launch": d["ms_avg"], "launches": d["calls"],
-               "mix": {"fp32_mfma_flops": flops - f16, "f16x3_flops": f16, "fp32_peak": FP32_MFMA_PEAK_TFLOPS,
-                       "f16_peak": F16_MFMA_PEAK_TFLOPS},
+               "mix": {"fp32_mfma_flops": flops - f16 - f16x2, "f16x3_flops": f16, "f16x2_flops": f16x2,
+                       "fp32_peak": FP32_MFMA_PEAK_TFLOPS, "f16_peak": F16_MFMA_PEAK_TFLOPS},
                # SURVEY 8(d)'s yardstick for the NN stage (all flops at the fp32 MFMA peak), for comparison only
                "frac_vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS}
     else:

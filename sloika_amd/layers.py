@@ -901,12 +901,18 @@ class Gru(RNN):
             rc = _lib.SLK_ERR_UNSUPPORTED
             if RECURRENT_F16:
                 # projection AND recurrence as 3-term fp16 splits (csrc/gru_bar16.hip / gru_fused16.hip)
+                # (roofline bookkeeping: up to eight chunks per workgroup the recurrent products take two MFMAs each, the
+                #  projection three; the sixteen-chunk plan three everywhere -- csrc/gru_bar16.hip bar16_auto_plan)
+                bits = self._plan_bits(x, B) if GRU_PLAN == "bar" else 3
+                ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+                two_term = GRU_PLAN == "bar" and (bits in (1, 2) or (bits == 0 and (B + 7) // 8 <= ncu))
                 with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
-                                     f16x3_flops=6.0 * rows * n * (n + self.insize)) as reg:
+                                     f16x3_flops=6.0 * rows * n * (self.insize if two_term else n + self.insize),
+                                     f16x2_flops=6.0 * rows * n * n if two_term else 0.0) as reg:
                     rc = gru_f16_entry()(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
                                          self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
                                          y.data_ptr(), _row_stride(y), T, B, self.insize, n,
-                                         int(reverse) | ((self._plan_bits(x, B) << 8) if GRU_PLAN == "bar" else 0),
+                                         int(reverse) | ((bits << 8) if GRU_PLAN == "bar" else 0),
                                          activation.act_id(self.fun), activation.act_id(self.gatefun),
                                          None if lens is None else lens.data_ptr(), None, _stream())
                     if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:

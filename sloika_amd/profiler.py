@@ -11,18 +11,19 @@ _active = None
 
 class Recorder(object):
     def __init__(self):
-        self.records = []          # (name, start_event, end_event, flops, bytes, flops executed as 3-term fp16 split)
+        self.records = []          # (name, start_event, end_event, flops, bytes, flops as 3-term fp16 split, flops as 2-MFMA split)
 
     def summary(self):
-        """name -> dict(calls, ms_total, ms_avg, flops, f16x3_flops, bytes) ; call after torch.cuda.synchronize()."""
+        """name -> dict(calls, ms_total, ms_avg, flops, f16x3_flops, f16x2_flops, bytes) ; call after torch.cuda.synchronize()."""
         out = {}
-        for name, e0, e1, flops, nbytes, f16 in self.records:
-            d = out.setdefault(name, {"calls": 0, "ms_total": 0.0, "flops": 0.0, "bytes": 0.0, "f16x3_flops": 0.0})
+        for name, e0, e1, flops, nbytes, f16, f16x2 in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms_total": 0.0, "flops": 0.0, "bytes": 0.0, "f16x3_flops": 0.0, "f16x2_flops": 0.0})
             d["calls"] += 1
             d["ms_total"] += e0.elapsed_time(e1)
             d["flops"] += flops
             d["bytes"] += nbytes
             d["f16x3_flops"] += f16
+            d["f16x2_flops"] += f16x2
         for d in out.values():
             d["ms_avg"] = d["ms_total"] / d["calls"]
         return out
@@ -50,9 +51,11 @@ class _Region(object):
 
 
 @contextlib.contextmanager
-def region(name, flops=0.0, nbytes=0.0, f16x3_flops=0.0):
+def region(name, flops=0.0, nbytes=0.0, f16x3_flops=0.0, f16x2_flops=0.0):
     """`f16x3_flops`: the part of `flops` that the kernel evaluates as three fp16 MFMAs per product (fp32-grade split
-    arithmetic on the fp16 pipe) -- bench.py prices that part against the fp16 matrix peak, the rest against the fp32 one."""
+    arithmetic on the fp16 pipe) -- bench.py prices that part against the fp16 matrix peak, the rest against the fp32 one.
+    `f16x2_flops`: the part evaluated with TWO fp16 MFMAs per product (the recurrent products of the Gru kernels whose spare
+    MFMA columns carry the lo half of the state, csrc/bar16_common.h) -- not included in `f16x3_flops`."""
     if _active is None:
         yield None
         return
@@ -66,4 +69,4 @@ def region(name, flops=0.0, nbytes=0.0, f16x3_flops=0.0):
     finally:
         e1.record()
         if not reg.cancelled:
-            _active.records.append((name, e0, e1, float(flops), float(nbytes), float(f16x3_flops)))
+            _active.records.append((name, e0, e1, float(flops), float(nbytes), float(f16x3_flops), float(f16x2_flops)))
