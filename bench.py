@@ -567,7 +567,7 @@ def main():
         stages = rec.summary()
         ms_profiled = dts / args.stage_steps * 1e3
         roofline = roofline_of(stages, pmc_traffic(args.model, B, L),
-                               "latency-bound serial scan; %d chunks per CU fill 4 of 16 MFMA columns" % max(1, B // 256)
+                               "latency-bound serial scan; %d chunks per CU, whose hi and lo state halves fill 8 of the 16 MFMA columns (twice over)" % max(1, B // 256)
                                if args.model == "raw_0.98_rgrgr" and B <= 1024 else None)
         if roofline is not None:
             roofline["measured"] = "HIP events on the launch stream over %d steps issued right after the timed region " \
