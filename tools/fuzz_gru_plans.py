@@ -1,5 +1,6 @@
 """Differential fuzz of the three Gru plans (four / eight / sixteen chunks per workgroup): random T, B, direction, ragged lengths,
-saved gates and input strides for every fused size -- the plans must agree bit for bit."""
+saved gates and input strides for every fused size -- four and eight chunks must agree bit for bit (the same two-MFMA products in the
+same order), sixteen (three-term products) within float32 rounding."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -31,7 +32,11 @@ for case in range(ncase):
         assert rc == 0, rc
         outs.append((torch.nan_to_num(y, nan=9.0), None if zr is None else torch.nan_to_num(zr, nan=9.0)))
     for k in (1, 2):
-        same = torch.equal(outs[0][0], outs[k][0]) and (outs[0][1] is None or torch.equal(outs[0][1], outs[k][1]))
+        if k == 1:
+            same = torch.equal(outs[0][0], outs[k][0]) and (outs[0][1] is None or torch.equal(outs[0][1], outs[k][1]))
+        else:
+            same = (outs[0][0] - outs[k][0]).abs().max().item() < 3e-6 and \
+                (outs[0][1] is None or (outs[0][1] - outs[k][1]).abs().max().item() < 3e-6)
         if not same:
             bad += 1
             print("MISMATCH plan", k + 1, "I=%d n=%d T=%d B=%d rev=%d ragged=%s save=%s ldx=%d ldy=%d" % (I, n, T, B, rev, ragged, save, ldx, ldy), flush=True)
