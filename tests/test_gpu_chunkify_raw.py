@@ -188,3 +188,48 @@ def test_errors_are_loud(gold):
             cr.raw_remap(c["ref"], c["signal"], 1e-5, 5, (None, None), 5.0)           # no compiled model anywhere
     finally:
         batch.calc_post = saved
+
+
+def test_remap_of_a_real_read_with_the_trained_model(oracle):
+    """`chunkify raw_remap` end to end on one of the reference's example reads (fixture reads.npz) with the trained pretrained.pkl
+    weights: the read is remapped to the basecall stored in its fast5 file, then cut into labelled chunks.  The oracle runs the
+    same chain on the posterior the device network produced."""
+    import os
+    need = pytest.importorskip("torch")
+    from tests.gpu_util import need_gpu
+    need_gpu()
+    from sloika_amd import batch, chunkify_raw as cr, models, util
+    batch.init_chunk_identity_worker(5, b"ACGT")
+    g = np.load(os.path.join(GOLD, "reads.npz"))
+    dig, off, rng, _rate = g["meta_5"]
+    signal = ((g["adc_5"].astype(np.float64) + off) * (rng / dig)).astype(np.float32)
+    signal = util.trim_array(signal, 200, 10)                                         # chunkify_raw.py:317-318
+    ref = g["called_5"].tobytes()
+    calc_post = models.from_weights_npz(os.path.join(GOLD, "pretrained_weights.npz")).compile()
+    prior, slip = (25.0, 25.0), 5.0
+    score, table, path, seq = cr.raw_remap(ref, signal, 1e-5, 5, prior, slip, calc_post=calc_post)
+    nstep = len(path)
+    assert nstep == -(-len(signal) // 5) and len(seq) == len(ref) - 4 and cr.mapping_table_is_registered(signal, table)
+    # the mapping walks through (nearly) the whole reference, mostly staying or stepping by one
+    assert path[0] < 0.05 * len(seq) and path[-1] > 0.95 * len(seq)
+    steps = np.diff(path)
+    assert ((steps >= 0) & (steps <= 2)).mean() > 0.97
+    # the oracle on the same posterior
+    post = calc_post(batch.normalise_chunks(signal.reshape(1, -1), "per-chunk", out_layout="network"))[:, 0, :]
+    want = oracle_remap.raw_remap(ref, signal, post, 1e-5, 5, prior, slip)
+    assert float(score) == pytest.approx(float(want[0]), rel=2e-6)
+    assert (path == want[2]).mean() > 0.999                                          # np.log's last bit may move a tie
+    if np.array_equal(path, want[2]):
+        for f in ("start", "length", "seq_pos", "move"):
+            assert np.array_equal(table[f], want[1][f]), f
+    # labelled chunks from the device's own table: labels equal the oracle's on that table
+    chunk_len, ds = 2000, 5
+    chunks, labels, bad = cr.raw_chunkify(signal, table, chunk_len, 5, "per-read", ds, False)
+    ml = len(signal) // chunk_len
+    cols = {f: table[f].astype(np.int64) for f in ("start", "length", "seq_pos", "move")}
+    trimmed = oracle_remap.trim_table(cols, len(signal), 0, ml * chunk_len)
+    states = oracle_remap.states_of_reference(ref, 5)[trimmed["seq_pos"]]
+    assert np.array_equal(labels, oracle_remap.chunk_labels(trimmed, states, ml, chunk_len, ds))
+    assert chunks.shape == (ml, chunk_len, 1) and not bad.any()
+    moved = (labels > 0).mean()
+    assert 0.2 < moved < 0.7, moved                                                  # ~3600 bases over ~6600 blocks of five samples
