@@ -249,7 +249,7 @@ SLK_API int slk_lstm_recurrent_ragged_f32(const float *vW, const float *sW, cons
                                   int n, int reverse, int act, int gate_act, const int32_t *lens /* see slk_gru_fused_ragged_f32 */,
                                   slk_stream_t stream);
 /* The same scan with the recurrent product as a 3-term fp16 split on the barrier-stepped plan (csrc/lstm_scan16.hip; n a multiple
- * of 16 up to 64, tanh / sigmoid, vW 16-byte aligned and < 4 GiB; SLK_ERR_UNSUPPORTED otherwise -> slk_lstm_recurrent_f32).
+ * of 16 up to 128, tanh / sigmoid, vW 16-byte aligned and < 4 GiB; SLK_ERR_UNSUPPORTED otherwise -> slk_lstm_recurrent_f32).
  * lens may be NULL (all chunks T steps long). */
 SLK_API int slk_lstm_scan16_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B, int n,
                         int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream);

@@ -760,7 +760,7 @@ class Lstm(RNN):
         with profiler.region("lstm_recurrent", 8.0 * rows * n * n, 4.0 * rows * 5 * n):
             rc = _lib.SLK_ERR_UNSUPPORTED
             if SPLIT_F16 and RECURRENT_F16:
-                # the recurrent product as a 3-term fp16 split on the barrier-stepped plan (csrc/lstm_scan16.hip: n <= 64)
+                # the recurrent product as a 3-term fp16 split on the barrier-stepped plan (csrc/lstm_scan16.hip: n <= 128)
                 rc = L.slk_lstm_scan16_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(), y.data_ptr(),
                                            _row_stride(y), T, B, n, int(reverse), activation.act_id(self.fun),
                                            activation.act_id(self.gatefun), None if lens is None else lens.data_ptr(), _stream())

@@ -21,7 +21,7 @@ def _scan(L, vW, sW, p, y, ldy, T, B, n, reverse, lens=None, act=1, gate=2):
                                  int(reverse), act, gate, None if lens is None else lens.data_ptr(), stream())
 
 
-@pytest.mark.parametrize("n", [16, 32, 48, 64])
+@pytest.mark.parametrize("n", [16, 32, 48, 64, 80, 96, 128])
 @pytest.mark.parametrize("T,B,reverse,peep", [(23, 9, False, True), (8, 4, True, True), (3, 2, False, False), (1, 1, True, True),
                                               (41, 5, True, False), (100, 33, False, True)])
 def test_lstm_scan16_vs_oracle(oracle, n, T, B, reverse, peep):
@@ -44,7 +44,7 @@ def test_lstm_scan16_vs_oracle(oracle, n, T, B, reverse, peep):
     assert err < 2e-5, err
 
 
-@pytest.mark.parametrize("n", [32, 64])
+@pytest.mark.parametrize("n", [32, 64, 96, 128])
 def test_lstm_scan16_ragged(oracle, n):
     """Each chunk of a ragged batch equals the call on the chunk alone at its own length, reversed scans included; rows past a
     chunk's end stay untouched."""
@@ -71,12 +71,13 @@ def test_lstm_scan16_ragged(oracle, n):
             assert np.isnan(out[tb:, bb]).all()
 
 
-def test_lstm_scan16_large_weights_and_determinism(oracle):
+@pytest.mark.parametrize("n", [64, 128])
+def test_lstm_scan16_large_weights_and_determinism(oracle, n):
     """|w| up to 6 with saturating gates; every launch must reproduce the first bit for bit (waves exchange the state through LDS)."""
     torch = need_gpu()
     from sloika_amd import _lib
     L = _lib.lib()
-    n, I, T, B = 64, 12, 60, 1021
+    I, T, B = 12, 60, 1021
     rs = np.random.RandomState(5)
     iW, sW, b, p = _params(rs, I, n, scale=2.0)
     sW[rs.randint(0, 4 * n, 60), rs.randint(0, n, 60)] = rs.choice([-6.0, 6.0, 4.5], size=60)
@@ -101,6 +102,6 @@ def test_lstm_scan16_unsupported_shapes_are_refused():
     from sloika_amd import _lib
     L = _lib.lib()
     z = torch.zeros(4096, device="cuda")
-    for n, act, gate in [(96, 1, 2), (128, 1, 2), (24, 1, 2), (64, 2, 2), (64, 1, 1)]:
+    for n, act, gate in [(144, 1, 2), (24, 1, 2), (64, 2, 2), (64, 1, 1)]:
         assert _scan(L, z, z, z, z, n, 1, 1, n, 0, act=act, gate=gate) == _lib.SLK_ERR_UNSUPPORTED
     assert L.slk_lstm_scan16_f32(None, z.data_ptr(), z.data_ptr(), z.data_ptr(), 64, 1, 1, 64, 0, 1, 2, None, stream()) == _lib.SLK_ERR_INVALID_ARG

@@ -93,7 +93,7 @@ def test_gru_strided_output_slice(oracle):
                                                (9, 48, False, True, 1, 1), (64, 64, True, False, 2, 4)])
 @pytest.mark.parametrize("reverse", [False, True])
 def test_lstm_vs_oracle(oracle, I, n, bias, peep, T, B, reverse):
-    """Sizes 16/32/48/64 take the MFMA kernel (csrc/lstm_mfma.hip), the others the portable one."""
+    """Multiples of 16 up to 128 take the fp16-split scan (csrc/lstm_scan16.hip), the others the portable kernel."""
     need_gpu()
     from sloika_amd import layers
     rs = np.random.RandomState(I * 10 + n)
