@@ -481,26 +481,34 @@ class Softmax(Layer):
         d = dict(self.__dict__)
         d.pop("_w16", None)          # device caches: never pickled
         d.pop("_svpack", None)
+        d.pop("_svpack_p", None)
         return d
 
-    def viterbi_pack(self, nbase, klen):
+    def viterbi_pack(self, nbase, klen, kpad=None):
         """The weights as csrc/softmax_viterbi.hip wants them (MFMA fragment order, fp16 hi/lo, column scales) for decoding
         straight from this layer's INPUT (decode.viterbi_fused_batch), or None where that kernel does not apply (state count
-        other than 4^5 + 1, insize not a multiple of 16 up to 128, all-fp32 arithmetic requested)."""
+        other than 4^5 + 1, insize not a multiple of 16 up to 128, all-fp32 arithmetic requested).  `kpad` > insize: the input
+        rows carry zero columns up to `kpad` (the output of a zero-padded Gru twin, models/raw_1.00_rGr.py: 110 -> 112); the
+        weights get zero columns to match."""
         import torch
         L = _lib.lib()
-        nbytes = L.slk_softmax_viterbi_pack_bytes(self.insize, nbase, klen) if self.split_f16 else 0
+        K = self.insize if kpad is None else int(kpad)
+        nbytes = L.slk_softmax_viterbi_pack_bytes(K, nbase, klen) if (self.split_f16 and K >= self.insize) else 0
         if nbytes == 0 or self.size != nbase ** klen + 1:
             return None
 
         def build():
             wd, bd = self.W.dev(), self.b.dev()
+            if K != self.insize:
+                wp = torch.zeros((self.size, K), dtype=torch.float32, device=wd.device)
+                wp[:, :self.insize] = wd.reshape(self.size, self.insize)
+                wd = wp
             pack = torch.empty(nbytes, dtype=torch.uint8, device=wd.device)
-            _lib.check(L.slk_softmax_viterbi_pack_f32(wd.data_ptr(), bd.data_ptr(), self.insize, nbase, klen, pack.data_ptr(),
+            _lib.check(L.slk_softmax_viterbi_pack_f32(wd.data_ptr(), bd.data_ptr(), K, nbase, klen, pack.data_ptr(),
                                                       _stream()), "softmax_viterbi_pack")
             return pack
 
-        return _derived_cache(self, "_svpack", (self.W, self.b), build)
+        return _derived_cache(self, "_svpack" if K == self.insize else "_svpack_p", (self.W, self.b), build)
 
     def _logits(self, x, ld):
         """tmp = x.W^T + b (layers.py:310) with rows `ld` floats apart, and per-row (max, 1/sum exp) [T*B,2]."""
@@ -887,6 +895,7 @@ class Gru(RNN):
             if out is not None:
                 out.copy_(y)
                 return out
+            y._slk_zero_padded = twin.size                # the columns behind `n` exist and are exactly zero (pipeline._fused_pack)
             return y
         y = _alloc_out(x, T, B, self.size, out)
         L = _lib.lib()

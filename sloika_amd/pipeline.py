@@ -83,12 +83,19 @@ class Basecaller(object):
         return self._hidden(chunks, n)
 
     def _fused_pack(self, last, hid):
-        """The Softmax layer's weights packed for csrc/softmax_viterbi.hip, or None when that kernel does not apply."""
+        """(the Softmax layer's weights packed for csrc/softmax_viterbi.hip, the row width the kernel reads), or None when that
+        kernel does not apply."""
         if not self.fused_decode or hid.stride(1) % 4 or hid.data_ptr() % 16:
             return None
         if hid.stride(2) != 1 or hid.stride(0) != hid.shape[1] * hid.stride(1):
             return None
-        return last.viterbi_pack(self.nbase, self.kmer_len)
+        if last.insize % 16:
+            # an odd width straight out of a zero-padded Gru twin (layers.Gru._forward): decode the padded rows
+            kp = (last.insize + 15) // 16 * 16
+            if getattr(hid, "_slk_zero_padded", 0) < kp or hid.stride(1) < kp:
+                return None
+            return last.viterbi_pack(self.nbase, self.kmer_len, kpad=kp), kp
+        return last.viterbi_pack(self.nbase, self.kmer_len), last.insize
 
     def call_chunks(self, chunks, lp_dump=None):
         """-> device tensors (scores float32 [B], paths int32 [B, T'] (-1 padded), lens int32 [B]).
@@ -102,8 +109,11 @@ class Basecaller(object):
         last = net.layers[-1] if isinstance(net, layers.Serial) else None
         if type(last) is layers.Softmax and len(net.layers) > 1:
             hid = self._hidden(chunks, len(net.layers) - 1)
-            pack = self._fused_pack(last, hid)
+            packed = self._fused_pack(last, hid)
+            pack = packed[0] if packed is not None else None
             if pack is not None:
+                if packed[1] != hid.shape[2]:
+                    hid = hid.as_strided((hid.shape[0], hid.shape[1], packed[1]), hid.stride())
                 return decode.viterbi_fused_batch(hid, pack, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
                                                   min_prob=self.min_prob, workspace=self._ws, lp_dump=lp_dump)
             if lp_dump is not None:
@@ -158,9 +168,12 @@ class Basecaller(object):
             for layer in net.layers[:-1]:
                 hid = layer._forward(hid, None, False)
             lengths = layers.ragged.current
-            pack = self._fused_pack(net.layers[-1], hid)
+            packed = self._fused_pack(net.layers[-1], hid)
+            pack = packed[0] if packed is not None else None
             if pack is None:
                 logits, stats, ld = net.layers[-1].logits_and_stats(hid)
+            elif packed[1] != hid.shape[2]:
+                hid = hid.as_strided((hid.shape[0], hid.shape[1], packed[1]), hid.stride())
         T = hid.shape[0]
         if pack is not None:
             return decode.viterbi_fused_batch(hid, pack, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,

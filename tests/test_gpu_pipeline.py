@@ -69,7 +69,8 @@ def _check_fused_decode(oracle, net, cd, lp_two_kernel, klen=5, skip=0.0, pick=N
     from sloika_amd import pipeline
     bcf = pipeline.Basecaller(net, kmer_len=klen, skip=skip)
     last = net.layers[-1]
-    if last.viterbi_pack(4, klen) is None:
+    kp = (last.insize + 15) // 16 * 16                               # an odd width (raw_1.00_rGr: 110) is decoded from the zero-padded rows
+    if last.viterbi_pack(4, klen, kpad=None if kp == last.insize else kp) is None:
         return                                                       # shape outside the fused kernel: nothing more to check
     T, B = lp_two_kernel.shape[0], cd.shape[0]
     dump = torch.empty((T, B, last.size), dtype=torch.float32, device="cuda")

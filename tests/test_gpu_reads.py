@@ -89,7 +89,9 @@ def _check_against_single_reads(bc, calc_post, reads, scores, paths, lens, nsamp
     csrc/softmax_viterbi.hip (its log-posteriors differ from the posterior path's in the last bits)."""
     from sloika_amd import basecall, layers
     last = bc.network.layers[-1]
-    fused = bc.fused_decode and type(last) is layers.Softmax and last.viterbi_pack(bc.nbase, bc.kmer_len) is not None
+    kp = (last.insize + 15) // 16 * 16                               # odd widths are decoded from the zero-padded rows of a Gru twin
+    fused = bc.fused_decode and type(last) is layers.Softmax and \
+        last.viterbi_pack(bc.nbase, bc.kmer_len, kpad=None if kp == last.insize else kp) is not None
     for b, r in enumerate(reads):
         s1, p1, l1, n1 = bc.call_reads([r])
         assert n1[0] == nsamp[b]
