@@ -4,6 +4,8 @@
     normalise_chunks(chunks, 'per-chunk'|...)      median/MAD normalisation (chunkify_raw.py:178-185)
     chunks_to_network_input(chunks)                [ml, chunk_len] -> [chunk_len, ml, 1] (bin/train_network.py:304)
 """
+import threading
+
 import numpy as np
 
 from . import _lib, profiler
@@ -128,6 +130,67 @@ def trim_open_pore_many(signals, max_op_fraction=0.3, var_method='mad', window_s
         lo += n
         lively = np.flatnonzero(sp > np.percentile(sp, 100 * max_op_fraction))
         out.append(s[int(lively[0]) * window_size: (int(lively[-1]) + 1) * window_size])
+    return out
+
+
+class _Staging(threading.local):
+    """Pinned host staging buffer of upload_reads_windowed, one per host thread, kept between calls."""
+    buf = None
+    event = None
+
+
+_staging = _Staging()
+
+
+def upload_reads_windowed(signals, window_size=100):
+    """All reads of a set in ONE upload (through pinned memory): read r occupies `dev[off[r] : off[r] + len[r]]`, every read padded
+    with zeros to whole windows, so that `dev.view(-1, window_size)` is the window matrix of all reads.  -> (dev, off, lengths)."""
+    import torch
+    from . import device as D
+    lens = [len(s) for s in signals]
+    strides = [-(-n // window_size) * window_size for n in lens]
+    off = np.concatenate([[0], np.cumsum(strides)]).astype(np.int64)
+    total = int(off[-1])
+    st = _staging
+    if getattr(st, "buf", None) is None or st.buf.numel() < total:
+        st.buf = torch.empty(max(total, 1 << 20), dtype=torch.float32).pin_memory()      # grow-only: pinning is the expensive part
+        st.event = None
+    if st.event is not None:
+        st.event.synchronize()                           # the previous upload out of this buffer has left the host
+    hv = st.buf.numpy()
+    for r, sig in enumerate(signals):
+        hv[off[r]: off[r] + lens[r]] = sig
+        hv[off[r] + lens[r]: off[r + 1]] = 0.0
+    dev = st.buf[:total].to(D.device(), non_blocking=True)
+    st.event = torch.cuda.Event()
+    st.event.record()
+    return dev, off, lens
+
+
+def open_pore_bounds_many(dev, off, lens, max_op_fraction=0.3, var_method='mad', window_size=100):
+    """trim_open_pore (sloika/batch.py:194-220) for reads resident on the device as upload_reads_windowed leaves them: the
+    spreads of ALL windows in one launch, the percentile threshold per read on the host (a few hundred numbers each).
+    -> list of (first sample, one past the last sample) relative to each read's start."""
+    import torch
+    from . import device as D
+    assert var_method in TRIM_OPEN_PORE_LOCAL_VAR_METHODS, "var_method not understood: {}".format(var_method)
+    nwin = [n // window_size for n in lens]
+    if min(nwin) < 1:
+        raise ValueError("a read is shorter than one window of %d samples" % window_size)
+    wd = dev.view(-1, window_size)
+    if var_method == 'mad':
+        _, _, spread = normalise_chunks(wd, 'per-chunk', return_stats=True)
+    else:
+        spread = torch.empty((wd.shape[0],), dtype=torch.float32, device=wd.device)
+        _lib.check(_lib.lib().slk_window_std_f32(wd.data_ptr(), wd.shape[0], window_size, spread.data_ptr(), D.stream_ptr()),
+                   "window_std")
+    spread = spread.cpu().numpy()
+    out = []
+    for r, n in enumerate(nwin):
+        w0 = int(off[r]) // window_size
+        sp = spread[w0: w0 + n]                          # whole windows only, as the reference's reshape leaves them
+        lively = np.flatnonzero(sp > np.percentile(sp, 100 * max_op_fraction))
+        out.append((int(lively[0]) * window_size, (int(lively[-1]) + 1) * window_size))
     return out
 
 

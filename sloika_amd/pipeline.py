@@ -219,15 +219,27 @@ class Basecaller(object):
 
     @classmethod
     def prepare_read_batches(cls, network, signals, trim=(0, 0), open_pore_fraction=0.0, max_batch=256, max_waste=0.08, **kwargs):
-        """Host side of the whole-read mode: trim every read (one device call for all their windows), bucket by length, pack each
-        bucket into a zero-padded batch and upload it.  -> (batches, nsamp): batches = [(read indices, padded device tensor
+        """Preparation of the whole-read mode: the read set goes to the device in one upload, trimming bounds come from one launch over
+        all windows (basecall.py:111-112), reads are bucketed by length and every bucket becomes a zero-padded device batch.
+        -> (batches, nsamp): batches = [(read indices, padded device tensor
         [B, Lmax], their sample counts)], nsamp = sample count of every read after trimming."""
-        bc = cls(network, **kwargs)
-        sigs = bc._trim_reads(signals, trim, open_pore_fraction)
-        nsamp = [len(s) for s in sigs]
+        import torch
+        # ONE upload of the whole read set; trimming bounds from the device's window spreads; the padded batches are then built on
+        # the device (a copy per read) -- the host touches every sample once
+        dev, off, lens = batch.upload_reads_windowed(signals)
+        bounds = batch.open_pore_bounds_many(dev, off, lens, open_pore_fraction)
+        assert trim[0] >= 0 and trim[1] >= 0
+        spans = [(lo + trim[0], hi - trim[1]) for lo, hi in bounds]                       # util.trim_array
+        nsamp = [max(0, hi - lo) for lo, hi in spans]
+        if min(nsamp) < 1:
+            raise ValueError("empty read after trimming")
         batches = []
         for idx in cls.length_buckets(nsamp, max_batch, max_waste):
-            padded, ns = cls._pack_reads([sigs[i] for i in idx])
+            ns = [nsamp[i] for i in idx]
+            padded = torch.zeros((len(idx), max(ns)), dtype=torch.float32, device=dev.device)
+            for b, i in enumerate(idx):
+                lo = int(off[i]) + spans[i][0]
+                padded[b, :ns[b]].copy_(dev[lo: lo + ns[b]])
             batches.append((idx, padded, ns))
         return batches, nsamp
 
