@@ -249,7 +249,9 @@ __device__ __forceinline__ void tile2_mfma_acc(f32x4 &a0, f32x4 &a1, const half8
         if constexpr (kb == 0) {
             asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a0) : "a"(w_hi[0]), "v"(x0_lo[0]));
             hook(ic<0>{});
-            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a1) : "a"(w_hi[0]), "v"(x1_lo[0]));
+            // (x0_lo[0] is listed so that the fresh destination does not take over the registers the MFMA just issued still reads:
+            //  tests/test_isa_hygiene.py)
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a1) : "a"(w_hi[0]), "v"(x1_lo[0]), "v"(x0_lo[0]));
             hook(ic<1>{});
         } else {
             asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w_hi[kb]), "v"(x0_lo[kb]));

@@ -344,6 +344,9 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
             fetch_slot(ic<nk>{}, G + (ph == 0 ? 1 : 2), xhB, xlB);
             __builtin_amdgcn_sched_barrier(0);
             z_block_mfma<true>(accC[0], accC[1], wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0]);
+            // (the fresh accumulators must not take over the operands the update gate's MFMAs just issued still read)
+#pragma unroll
+            for (int i = 0; i < KBS; i++) asm volatile("" ::"v"(bh[i]), "v"(bl[i]));
             proj_slot(ic<2 * ph + 1>{});
             // the update gate's epilogue while the other waves' r*h is on its way
             float zz[2][4];

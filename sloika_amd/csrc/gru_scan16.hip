@@ -344,10 +344,12 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         if constexpr (MIX) {
             z_block_mfma2<false>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1]);
             z_block_mfma2<true>(accC[0], accC[1], wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0]);
+            asm volatile("" ::"v"(bh[KBS - 1]));         // the fresh accumulators must not take over the operand the z MFMAs still read
         } else {
             z_block_mfma<false>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1],
                                 bl[KBS - 1]);
             z_block_mfma<true>(accC[0], accC[1], wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0]);
+            asm volatile("" ::"v"(bh[KBS - 1]), "v"(bl[KBS - 1]));
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -1,6 +1,6 @@
-"""ISA-level screen of the kernels built on v_mfma_f32_32x32x16_f16: hipcc (ROCm 7.2) may give a freshly defined MFMA
-destination (C = 0) the registers of an operand that dies at that instruction or at the MFMA just before it; on MI355X that
-corrupted rows under matrix-pipe contention (csrc/softmax_viterbi.hip, mma_pair).  The sources keep the operands alive with
+"""ISA-level screen of the MFMA kernels: hipcc (ROCm 7.2) may give a freshly defined MFMA destination (C = 0) the registers of an
+operand that dies at that instruction or at the MFMA just before it; on MI355X that corrupted rows of v_mfma_f32_32x32x16_f16 under
+matrix-pipe contention (csrc/softmax_viterbi.hip, mma_pair).  The 16x16x32 kernels never showed it, but carry the same guards.  The sources keep the operands alive with
 empty asm statements; this test compiles them to ISA (hipcc cross-compiles without a GPU) and checks that no such overlap is
 left."""
 import os
@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 @pytest.mark.parametrize("src,flags", [("softmax_viterbi.hip", ["-DSV_ONLY_KS=4"]), ("softmax_viterbi.hip", ["-DSV_ONLY_KS=6"]),
-                                       ("gemm_rows_f16x3.hip", []), ("lstm_scan16.hip", [])])
+                                       ("gemm_rows_f16x3.hip", []), ("lstm_scan16.hip", []), ("gru_bar16.hip", []),
+                                       ("gru_bar16d.hip", []), ("gru_bar16q.hip", []), ("gru_scan16.hip", [])])
 def test_no_mfma_destination_over_live_operands(tmp_path, src, flags):
     import mfma_overlap_scan
     from sloika_amd import build
