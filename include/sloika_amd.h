@@ -460,6 +460,11 @@ SLK_API int slk_lstm_gates_f32(const float *sum, const float *peep, float *gates
 SLK_API int slk_lstm_backward_f32(const float *dy, long lddy, const float *gates, const float *cell, const float *sW, const float *peep,
                           float *dsum, float *dpeep, int T, int B, int n, int reverse, int act, int gate_act,
                           slk_stream_t stream);
+/* The same reverse scan on the barrier-stepped fp16-split plan of csrc/lstm_scan16.hip (csrc/lstm_bwd16.hip: n a multiple of 16 up to
+ * 64, tanh / sigmoid, gates / dsum 16-byte aligned, operands < 4 GiB; SLK_ERR_UNSUPPORTED otherwise -> slk_lstm_backward_f32). */
+SLK_API int slk_lstm_backward16_f32(const float *dy, long lddy, const float *gates, const float *cell, const float *sW, const float *peep,
+                          float *dsum, float *dpeep, int T, int B, int n, int reverse, int act, int gate_act,
+                          slk_stream_t stream);
 SLK_API int slk_softmax_xent_grad_f32(float *logits, long ld, const float *stats, const int32_t *labels, const float *weights, int T,
                               int B, int nstate, int drop, float min_prob, float *loss_rows, float *correct_rows,
                               slk_stream_t stream);

@@ -632,8 +632,15 @@ class TrainingStep(object):
         dsum = summed                                                            # reuse: the sums are not needed again
         dpeep = torch.empty((B, 3 * n), dtype=torch.float32, device=dev)
         with profiler.region("train_lstm_scan", 8.0 * M * n * n, 4.0 * M * 10 * n):
-            rc = L.slk_lstm_backward_f32(dy.data_ptr(), layers._row_stride(dy), gates.data_ptr(), cell.data_ptr(), sW.data_ptr(),
-                                         peep, dsum.data_ptr(), dpeep.data_ptr(), T, B, n, int(rev), act, gact, st())
+            rc = _lib.SLK_ERR_UNSUPPORTED
+            if layers.SPLIT_F16 and layers.RECURRENT_F16:     # the product of a step as an fp16 split (csrc/lstm_bwd16.hip: n <= 64)
+                rc = L.slk_lstm_backward16_f32(dy.data_ptr(), layers._row_stride(dy), gates.data_ptr(), cell.data_ptr(),
+                                               sW.data_ptr(), peep, dsum.data_ptr(), dpeep.data_ptr(), T, B, n, int(rev), act, gact,
+                                               st())
+            if rc == _lib.SLK_ERR_UNSUPPORTED:
+                rc = L.slk_lstm_backward_f32(dy.data_ptr(), layers._row_stride(dy), gates.data_ptr(), cell.data_ptr(),
+                                             sW.data_ptr(), peep, dsum.data_ptr(), dpeep.data_ptr(), T, B, n, int(rev), act, gact,
+                                             st())
         if rc == _lib.SLK_ERR_UNSUPPORTED:
             raise NotImplementedError("training: no reverse-scan kernel for an Lstm of size %d" % n)
         _lib.check(rc, "lstm_backward")
