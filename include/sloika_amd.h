@@ -253,6 +253,13 @@ SLK_API int slk_lstm_recurrent_ragged_f32(const float *vW, const float *sW, cons
  * lens may be NULL (all chunks T steps long). */
 SLK_API int slk_lstm_scan16_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B, int n,
                         int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream);
+/* A whole Lstm layer of up to 64 units and up to 64 inputs in one kernel (csrc/lstm_fused16.hip): the scan of slk_lstm_scan16_f32 with
+ * the projection vW = x.iW^T + b computed inside, four steps at a time, from x:[T][B][insize] (rows ldx floats apart) -- vW is never
+ * written.  insize a multiple of 4 up to 64, n a multiple of 16 up to 64, tanh / sigmoid, x 16-byte aligned, ldx a multiple of 4;
+ * SLK_ERR_UNSUPPORTED otherwise (-> projection GEMM + slk_lstm_scan16_f32).  bias, p and lens may be NULL. */
+SLK_API int slk_lstm_fused16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *bias, const float *p, float *y,
+                         long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act, const int32_t *lens,
+                         slk_stream_t stream);
 SLK_API size_t slk_lstm_workspace_bytes(int T, int B, int n);
 SLK_API int slk_lstm_f32(const float *x, long ldx, const float *iW, const float *sW, const float *bias, const float *p,
                  float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,

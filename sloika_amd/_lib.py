@@ -78,6 +78,7 @@ PROTOTYPES = {
     "slk_raw_chunk_labels_i32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _l, _i, _i, _vp, _sz, _vp, _vp]),
     "slk_raw_chunk_labels_interp_i32": (_i, [_vp, _vp, _vp, _l, _i, _i, _l, _vp, _l, _i, C.c_char_p, _i, _l, _i, _vp, _i, _vp, _vp,
                                              _vp, _vp]),
+    "slk_lstm_fused16_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slk_lstm_scan16_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slk_activation_f32": (_i, [_vp, _vp, _sz, _i, _vp]),
     "slk_train_pack_xh_f32": (_i, [_vp, _l, _vp, _l, _vp, _i, _i, _i, _i, _i, _vp]),

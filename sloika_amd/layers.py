@@ -111,6 +111,9 @@ RECURRENT_F16 = os.environ.get("SLOIKA_AMD_RECURRENT_F32", "0") != "1"
 #: Execution plan of that kernel: "bar" = four waves stepping through barriers (csrc/gru_bar16.hip, the faster one),
 #: "flags" = eight waves coupled by LDS progress counters (csrc/gru_fused16.hip).  Same arithmetic, same contract.
 GRU_PLAN = os.environ.get("SLOIKA_AMD_GRU_PLAN", "bar")
+#: An Lstm layer of up to 64 units and 64 inputs runs as ONE kernel that computes its input projection inside the scan
+#: (csrc/lstm_fused16.hip); SLOIKA_AMD_LSTM_FUSED=0 keeps projection GEMM + scan (csrc/lstm_scan16.hip) for comparison.
+LSTM_FUSED = os.environ.get("SLOIKA_AMD_LSTM_FUSED", "1") != "0"
 
 
 class _PlanHints(__import__("threading").local):
@@ -754,6 +757,11 @@ class Lstm(RNN):
         d.pop("_iw16", None)         # device cache: never pickled
         return d
 
+    def takes_fused_kernel(self):
+        """Whether csrc/lstm_fused16.hip (projection inside the scan) applies to this layer's shape."""
+        return (SPLIT_F16 and RECURRENT_F16 and LSTM_FUSED and self.size <= 64 and self.size % 16 == 0 and self.insize <= 64
+                and self.insize % 4 == 0 and self.fun is activation.tanh and self.gatefun is activation.sigmoid)
+
     def _forward(self, x, out, reverse):
         import torch
         T, B, _ = x.shape
@@ -761,6 +769,19 @@ class Lstm(RNN):
         L = _lib.lib()
         n, rows = self.size, T * B
         lens = ragged.current if reverse else None       # a reversed scan starts every chunk at its own last step
+        if self.takes_fused_kernel():
+            # the whole layer in one kernel (csrc/lstm_fused16.hip): the projection is computed inside the scan and never written
+            with profiler.region("lstm_fused", 8.0 * rows * n * (self.insize + n), 4.0 * rows * (self.insize + n),
+                                 f16x3_flops=8.0 * rows * n * self.insize, f16x2_flops=8.0 * rows * n * n) as reg:
+                rc = L.slk_lstm_fused16_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(), self.sW.dev().data_ptr(),
+                                            self.b.dev().data_ptr(), self.p.dev().data_ptr(), y.data_ptr(), _row_stride(y), T, B,
+                                            self.insize, n, int(reverse), activation.act_id(self.fun),
+                                            activation.act_id(self.gatefun), None if lens is None else lens.data_ptr(), _stream())
+                if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
+                    reg.cancel()
+            if rc != _lib.SLK_ERR_UNSUPPORTED:
+                _lib.check(rc, "Lstm")
+                return y
         nbytes = L.slk_lstm_workspace_bytes(T, B, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         # the two halves of slk_lstm_f32, timed separately: projection GEMM into the workspace, then the recurrence
@@ -1103,6 +1124,9 @@ class Parallel(Layer):
         ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
         self._side_plan = 0
         share = len(self.layers) * max(1, _HINTS.in_flight)
+        inners = [l.layer if isinstance(l, Reverse) else l for l in self.layers]
+        if all(isinstance(l, Lstm) and l.takes_fused_kernel() for l in inners):
+            ncu *= 2                   # csrc/lstm_fused16.hip fits two workgroups on a CU: the directions fill each other's waits
         if ((B + 3) // 4) * share > ncu:
             # too many four-chunk workgroups to run together; eight chunks per workgroup (csrc/gru_bar16d.hip: 1.4 x the step
             # time for twice the chunks) may still let the directions share the chip: B = 1024, two directions -> 2 x 128
