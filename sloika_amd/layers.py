@@ -133,14 +133,17 @@ class _PlanHints(__import__("threading").local):
 _HINTS = _PlanHints()
 
 
-def _gru_plan_for(B, share, ncu):
+def _gru_plan_for(B, share, ncu, per_cu=1):
     """Plan bits for `share` Gru launches of batch B that are meant to run at the same time: 0 when their four-chunk
-    workgroups fit the CUs together (or nothing helps), 2 when only the eight-chunk ones do, 3 when only the sixteen-chunk ones."""
+    workgroups fit the CUs together (or nothing helps), 2 when only the eight-chunk ones do, 3 when only the sixteen-chunk ones.
+    per_cu = 2 for layers up to 64 wide: their eight- and sixteen-chunk kernels (csrc/gru_bar16d.hip, gru_bar16q.hip: < 256
+    registers, < 80 KB of LDS) run two workgroups per CU, and two eight-chunk workgroups on a CU beat one of sixteen
+    (baseline_raw_gru, eight batches of 256 in flight: 520 -> 545 M samples/s).  The four-chunk kernel keeps a CU to itself."""
     if ((B + 3) // 4) * share <= ncu:
         return 0
-    if ((B + 7) // 8) * share <= ncu:
+    if ((B + 7) // 8) * share <= ncu * per_cu:
         return 2
-    return 3 if ((B + 15) // 16) * share <= ncu else 0
+    return 3 if ((B + 15) // 16) * share <= ncu * per_cu else 0
 
 
 def gru_f16_entry():
@@ -858,14 +861,14 @@ class Gru(RNN):
             params += [self.b]
         return params
 
-    @staticmethod
-    def _plan_bits(x, B):
+    def _plan_bits(self, x, B):
         """Bits 8-9 of `reverse` for slk_gru_bar16_f32: what Parallel decided for its side-by-side sub-layers, else eight chunks
         per workgroup when that is what lets the batches in flight share the chip."""
         if _HINTS.gru_plan_bits or _HINTS.in_flight <= 1:
             return _HINTS.gru_plan_bits
         import torch
-        return _gru_plan_for(B, _HINTS.in_flight, torch.cuda.get_device_properties(x.device).multi_processor_count)
+        return _gru_plan_for(B, _HINTS.in_flight, torch.cuda.get_device_properties(x.device).multi_processor_count,
+                             2 if max(self.size, self.insize) <= 64 else 1)
 
     def _padded(self):
         """Zero-padded copy of this layer with input and output sizes rounded up to multiples of 16 (what the MFMA
@@ -1131,7 +1134,7 @@ class Parallel(Layer):
             # too many four-chunk workgroups to run together; eight chunks per workgroup (csrc/gru_bar16d.hip: 1.4 x the step
             # time for twice the chunks) may still let the directions share the chip: B = 1024, two directions -> 2 x 128
             grus = all(isinstance(l.layer if isinstance(l, Reverse) else l, Gru) for l in self.layers)
-            plan = _gru_plan_for(B, share, ncu)
+            plan = _gru_plan_for(B, share, ncu, 2 if grus and all(max(l.size, l.insize) <= 64 for l in inners) else 1)
             if not (grus and SPLIT_F16 and RECURRENT_F16 and GRU_PLAN == "bar" and plan):
                 return None
             self._side_plan = plan
