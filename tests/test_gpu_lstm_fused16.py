@@ -137,3 +137,36 @@ def test_lstm_fused16_unsupported_shapes_are_refused():
     assert _layer(L, z[1:], 12, z, z, z, z, z, 64, 1, 1, 12, 64, 0) == _lib.SLK_ERR_UNSUPPORTED          # x not 16-byte aligned
     assert L.slk_lstm_fused16_f32(None, 12, z.data_ptr(), z.data_ptr(), None, None, z.data_ptr(), 64, 1, 1, 12, 64, 0, 1, 2, None,
                                   stream()) == _lib.SLK_ERR_INVALID_ARG
+
+
+def test_bilstm_directions_side_by_side(oracle):
+    """The two directions of a birnn of fused Lstm layers run on two streams as long as two workgroups per CU hold them
+    (B = 600: 2 x 150 workgroups on 256 CUs); the result is that of the layers one after the other."""
+    torch = need_gpu()
+    from sloika_amd import layers
+    rs = np.random.RandomState(11)
+    T, B, I, n = 40, 600, 12, 64
+    init = lambda shape: rs.normal(size=shape).astype(np.float32)
+    fwd = layers.Lstm(I, n, init=init, has_bias=True, has_peep=True)
+    bwd = layers.Lstm(I, n, init=init, has_bias=True, has_peep=True)
+    net = layers.birnn(fwd, bwd)
+    x = rs.normal(size=(T, B, I)).astype(np.float32)
+    xd = dev(x)
+    assert net._side_streams(xd, B) is not None
+    got = net.run(xd)
+    torch.cuda.synchronize()
+    again = net.run(xd)
+    assert torch.equal(got, again)
+    got = got.cpu().numpy()
+    pick = [0, 1, 299, 598, 599]
+    for layer, sl, reverse in ((fwd, slice(0, n), False), (bwd, slice(n, 2 * n), True)):
+        ref = oracle.lstm(x[:, pick], layer.iW.get_value(), layer.sW.get_value(), layer.b.get_value(), layer.p.get_value(),
+                          reverse=reverse)
+        assert np.abs(got[:, pick, sl] - ref).max() < 2e-5
+    saved, layers.LSTM_FUSED = layers.LSTM_FUSED, False
+    try:
+        assert net._side_streams(xd, B) is None          # 2 x 150 four-chunk workgroups of the scan kernel do not fit 256 CUs
+        two = net.run(xd).cpu().numpy()
+    finally:
+        layers.LSTM_FUSED = saved
+    assert np.abs(got - two).max() < 1e-5
