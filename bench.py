@@ -42,7 +42,7 @@ F16_MFMA_PEAK_TFLOPS = 2516.6     # dense fp16/bf16 MFMA = 16 x the fp32 rate (t
 HBM_PEAK_GBS = 8000.0              # spec; ~6300 achievable
 
 # stages whose work is matrix products (priced against the MFMA peaks); the others against HBM
-MFMA_STAGES = ("gru_fused", "gru_recurrent", "gru_input_gemm", "lstm_recurrent", "lstm_input_gemm", "softmax_gemm",
+MFMA_STAGES = ("gru_fused", "gru_recurrent", "gru_input_gemm", "lstm_fused", "lstm_recurrent", "lstm_input_gemm", "softmax_gemm",
                "gemm_bias_act", "conv1d", "softmax_viterbi")
 
 
