@@ -842,9 +842,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
         for (int j = 0; j < 8; j++) {
             const long mc = min(m0 + 8 * h + j, M - 1);
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
-                av[i][j] = i < ta ? pa[i][mc * lda] : 0.0f;
-                bv[i][j] = i < tb ? pb[i][mc * ldb] : 0.0f;
+            for (int i = 0; i < 3; i++) {                // (unconditional, from clamped columns: a load inside a branch -- even a
+                av[i][j] = pa[i][mc * lda];              // wave-uniform one -- makes the compiler wait for EVERYTHING in flight
+                bv[i][j] = pb[i][mc * ldb];              // before the next use, the prefetch of the next block included)
             }
         }
     };
@@ -872,9 +872,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     load(a0, b0, m_lo);
     for (long m0 = m_lo; m0 < m_hi; m0 += 2 * STEP) {
         load(a1, b1, m0 + STEP);
+        __builtin_amdgcn_sched_barrier(0);               // (keeps the cutting of a block from being pulled up to its loads)
         mma(a0, b0, m0);
+        __builtin_amdgcn_sched_barrier(0);
         load(a0, b0, m0 + 2 * STEP);
+        __builtin_amdgcn_sched_barrier(0);
         mma(a1, b1, m0 + STEP);
+        __builtin_amdgcn_sched_barrier(0);
     }
     float *out = partial + (size_t)by * N1 * N2;
 #pragma unroll
