@@ -724,8 +724,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const long mc = min(m0 + 2 * u + h, M - 1);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                av[u][i] = i < ta ? pa[i][mc * lda] : 0.0f;
-                bv[u][i] = i < tb ? pb[i][mc * ldb] : 0.0f;
+                av[u][i] = pa[i][mc * lda];               // (unconditional: see gemm_tn_bf16_kernel)
+                bv[u][i] = pb[i][mc * ldb];
             }
         }
     };
@@ -750,9 +750,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     load(a0, b0, m_lo);
     for (long m0 = m_lo; m0 < m_hi; m0 += 2 * STEP) {
         load(a1, b1, m0 + STEP);
+        __builtin_amdgcn_sched_barrier(0);
         mma(a0, b0, m0);
+        __builtin_amdgcn_sched_barrier(0);
         load(a0, b0, m0 + 2 * STEP);
+        __builtin_amdgcn_sched_barrier(0);
         mma(a1, b1, m0 + STEP);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // partial[slice][N1][N2]; D[row = (e&3) + 8*(e>>2) + 4*h][col = r]; columns clamped above are dropped here
     float *out = partial + (size_t)by * N1 * N2;
