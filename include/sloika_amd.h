@@ -456,6 +456,13 @@ SLK_API int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *xrh,
 SLK_API int slk_gru_backward_f32(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h, long ldh,
                          const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n, int reverse,
                          int act, int gate_act, slk_stream_t stream);
+/* The same reverse scan with its two products as fp16 splits on the barrier-stepped plan of the forward kernels (csrc/gru_bwd16.hip:
+ * one wave per 16 units, two MFMAs per product, operand images scaled per chunk and step by a power of two from a bound -- gradients
+ * have no natural range).  Same arguments; n a multiple of 16 up to 128, tanh / sigmoid, fewer than 4 GiB per operand;
+ * SLK_ERR_UNSUPPORTED otherwise (-> slk_gru_backward_f32).  Results agree with it to float32 rounding of the products. */
+SLK_API int slk_gru_backward16_f32(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h, long ldh,
+                         const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n, int reverse,
+                         int act, int gate_act, slk_stream_t stream);
 /* Lstm (layers.py:677-697) in the reverse pass.  sum:[M][4n] = [x_t | out_{t-1}] . [iW | sW]^T + b (a GEMM over
  * slk_train_pack_xh_f32 rows), gate rows interleaved j*4 + gate as the reference stores them.
  *   slk_lstm_gates_f32: the element-wise cell recursion -> gates:[M][4n] = (candidate, input, forget, output) activated,

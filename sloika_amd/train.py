@@ -536,9 +536,15 @@ class TrainingStep(object):
         da = torch.empty((M, 3 * n), dtype=torch.float32, device=dev)
         rh = torch.empty((M, n), dtype=torch.float32, device=dev)
         with profiler.region("train_gru_scan", 6.0 * M * n * n, 4.0 * M * 9 * n):
-            rc = L.slk_gru_backward_f32(dy.data_ptr(), layers._row_stride(dy), hp_ptr, ldhp, zr.data_ptr(),
-                                        h.data_ptr(), layers._row_stride(h), sW.data_ptr(), sW2.data_ptr(), da.data_ptr(),
-                                        rh.data_ptr(), T, B, n, int(rev), act, gact, st())
+            rc = _lib.SLK_ERR_UNSUPPORTED
+            if layers.SPLIT_F16 and layers.RECURRENT_F16:     # the two products of a step as fp16 splits (csrc/gru_bwd16.hip: n <= 128)
+                rc = L.slk_gru_backward16_f32(dy.data_ptr(), layers._row_stride(dy), hp_ptr, ldhp, zr.data_ptr(),
+                                              h.data_ptr(), layers._row_stride(h), sW.data_ptr(), sW2.data_ptr(), da.data_ptr(),
+                                              rh.data_ptr(), T, B, n, int(rev), act, gact, st())
+            if rc == _lib.SLK_ERR_UNSUPPORTED:
+                rc = L.slk_gru_backward_f32(dy.data_ptr(), layers._row_stride(dy), hp_ptr, ldhp, zr.data_ptr(),
+                                            h.data_ptr(), layers._row_stride(h), sW.data_ptr(), sW2.data_ptr(), da.data_ptr(),
+                                            rh.data_ptr(), T, B, n, int(rev), act, gact, st())
         if rc == _lib.SLK_ERR_UNSUPPORTED:
             raise NotImplementedError("training: no reverse-scan kernel for a Gru of size %d" % n)
         _lib.check(rc, "gru_backward")
