@@ -160,6 +160,16 @@ SLK_API int slk_linear_rowstats_f16x3(const float *x, long ldx, const void *W_hi
  * relu / elu, otherwise SLK_ERR_UNSUPPORTED (use slk_gemm_bias_act_f32).  Both: K <= 192, N <= 2048.                  */
 SLK_API int slk_gemm_bias_act_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
                             const float *bias, float *y, long ldy, long M, int K, int N, int act, slk_stream_t stream);
+/* The same product for rows longer than that kernel takes (csrc/gemm_bf16x6.hip: any K that is a multiple of 4; the dL/dx
+ * products of the training step -- th.grad through T.dot in layers.py:157-158, :310-313, :1010-1021 -- whose K = 3n / 4n / nstate
+ * exceeds 192): every float32 operand as three bf16 pieces, six bf16 MFMA terms per product in float32 accumulators (float32-grade,
+ * float32's exponent range: gradients need no scaling).  W:[N][K] is cut once by slk_pack_bf16x3_f32 into
+ * slk_pack_bf16x3_bytes(N, K) bytes.  act: linear / tanh / sigmoid; bias may be NULL.  SLK_ERR_UNSUPPORTED (->
+ * slk_gemm_bias_act_f32) for other activations, K or ldx not multiples of 4, x or packed not 16-byte aligned. */
+SLK_API size_t slk_pack_bf16x3_bytes(int N, int K);
+SLK_API int slk_pack_bf16x3_f32(const float *W, int N, int K, void *packed, slk_stream_t stream);
+SLK_API int slk_gemm_bias_act_bf16x6(const float *x, long ldx, const void *packed, const float *bias, float *y, long ldy, long M,
+                             int K, int N, int act, slk_stream_t stream);
 /* In-place row softmax of y:[M][N] (the second half of the above, exposed for testing).                     */
 SLK_API int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream);
 /* Row statistics only: stats[r] = (max_j logits[r][j], 1 / sum_j exp(logits[r][j] - max)); the posterior

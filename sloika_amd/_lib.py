@@ -39,6 +39,9 @@ PROTOTYPES = {
     "slk_linear_rowstats_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _l, _i, _i, _vp, _vp]),
     "slk_split_f16x2_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "slk_linear_rowstats_f16x3": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _vp, _vp]),
+    "slk_pack_bf16x3_bytes": (_sz, [_i, _i]),
+    "slk_pack_bf16x3_f32": (_i, [_vp, _i, _i, _vp, _vp]),
+    "slk_gemm_bias_act_bf16x6": (_i, [_vp, _l, _vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
     "slk_gemm_bias_act_f16x3": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
     "slk_softmax_from_stats_f32": (_i, [_vp, _l, _vp, _vp, _l, _l, _i, _vp]),
     "slk_softmax_rows_f32": (_i, [_vp, _l, _i, _vp]),

@@ -1,0 +1,213 @@
+// gemm_bf16x6.hip -- y[M][N] = act(x[M][K] . W[N][K]^T + b) on the bf16 matrix pipe with float32-grade products, for the shapes
+// gemm_rows_f16x3.hip does not take (K > 192): the dL/dx products of the training step (train.py: Softmax dx K = the padded logits
+// row, N = 96; Gru dx K = 3n; Lstm dx K = 4n), which ran on the fp32 matrix pipe (gemm.hip, 108 TFLOP/s = 0.69 of its peak).
+//
+// Arithmetic: train.hip's bf16 scheme -- every float32 operand is cut into three bf16 pieces (8 significand bits each, float32's
+// exponent range: gradients need no scaling) and a product is six v_mfma_f32_32x32x16_bf16 terms in float32 accumulators; what is
+// dropped is below 2^-24 of the product.  Six bf16 MFMAs do the work of sixteen fp32 ones.
+//
+// Plan: gemm.hip's -- 128 rows x (32 NT) columns per 256-thread workgroup, each wave 32 rows x all columns, K staged through LDS in
+// slabs of 32, several workgroups per CU hiding each other's loads (a one-wave-per-SIMD kernel with register prefetch reached
+// 1.35 ms on the 1040-wide product against 1.50 here before: it issued its loads, cuts and MFMAs one after the other).  x goes
+// through LDS as float32 and is cut by the wave that multiplies it (16 values per lane and slab); W arrives pre-cut
+// (slk_pack_bf16x3_f32: [piece][N][K rounded up to 32] bf16, zero padded) so that nobody cuts it four times.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define GB_BM 128
+#ifndef GB_BK
+#define GB_BK 32                                         // (64: 256-byte runs per row and half the barriers, two workgroups per CU -- measured below)
+#endif
+#define GB_XLD (GB_BK + 4)                               // floats per x row in LDS (gemm.hip)
+#define GB_WLD (GB_BK + 8)                               // bf16 per W row in LDS: the 16-byte reads of 16 rows hit 64 banks
+
+// v = p1 + p2 + p3, each piece the top 16 bits of what is left (train.hip: split_bf16x3)
+__device__ __forceinline__ void gb_split(const float (&v)[8], bf16x8 &p1, bf16x8 &p2, bf16x8 &p3)
+{
+    union { bf16x8 v; unsigned u[4]; } o1, o2, o3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        unsigned t1[2], t2[2], t3[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float x = v[2 * j + e];
+            t1[e] = __float_as_uint(x) & 0xffff0000u;
+            const float r1 = x - __uint_as_float(t1[e]);
+            t2[e] = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(t2[e]);
+            t3[e] = __float_as_uint(r2) & 0xffff0000u;
+        }
+        o1.u[j] = (t1[0] >> 16) | t1[1];
+        o2.u[j] = (t2[0] >> 16) | t2[1];
+        o3.u[j] = (t3[0] >> 16) | t3[1];
+    }
+    p1 = o1.v; p2 = o2.v; p3 = o3.v;
+}
+
+// packed[piece][n][KP] (bf16), KP = K rounded up to a whole slab: one thread per 8 consecutive k of one row
+__global__ void __launch_bounds__(256) pack_bf16x3_kernel(const float *__restrict__ W, int N, int K, int KP, uint4 *__restrict__ packed)
+{
+    const long total = (long)N * (KP / 8);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int n = (int)(e / (KP / 8)), k0 = (int)(e % (KP / 8)) * 8;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = k0 + j < K ? W[(size_t)n * K + k0 + j] : 0.0f;
+        union { bf16x8 v; uint4 q; } p1, p2, p3;
+        gb_split(v, p1.v, p2.v, p3.v);
+        const size_t piece = (size_t)N * (KP / 8);
+        packed[e] = p1.q;
+        packed[piece + e] = p2.q;
+        packed[2 * piece + e] = p3.q;
+    }
+}
+
+template <int NT, int ACT>
+__global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const float *__restrict__ x, long ldx, const uint4 *__restrict__ wp,
+                                                          const float *__restrict__ bias, float *__restrict__ y, long ldy, long M, int K,
+                                                          int KP, int N, int ntile_n)
+{
+    constexpr int BN = 32 * NT;
+    __shared__ __attribute__((aligned(16))) float xs[GB_BM * GB_XLD];
+    __shared__ __attribute__((aligned(16))) unsigned short ws[3 * BN * GB_WLD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const long bid = blockIdx.x;
+    const long m0 = (bid / ntile_n) * GB_BM;
+    const int n0 = (int)(bid % ntile_n) * BN;
+    const size_t piece = (size_t)N * (KP / 8);           // uint4 per piece
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
+
+    constexpr int XL = (GB_BM * GB_BK / 4) / 256;        // float4 loads per thread for x: 4
+    constexpr int CPR = GB_BK / 8;                       // 16-byte chunks per row of a slab (x: twice as many)
+    constexpr int WCH = 3 * BN * CPR;                    // 16-byte chunks of the W slab: [piece][row][CPR]
+    constexpr int WL = (WCH + 255) / 256;
+    for (int k0 = 0; k0 < K; k0 += GB_BK) {
+        // all loads back to back from clamped (always valid) addresses, masked when they are stored (gemm.hip)
+        float4 xv[XL];
+        uint4 wv[WL];
+#pragma unroll
+        for (int i = 0; i < XL; i++) {
+            const int idx = tid + 256 * i, row = idx / (2 * CPR), c4 = (idx % (2 * CPR)) * 4;
+            const long gr = m0 + row;
+            const int gk = k0 + c4;
+            xv[i] = *reinterpret_cast<const float4 *>(x + (gr < M ? gr : M - 1) * ldx + (gk < K ? gk : 0));
+        }
+#pragma unroll
+        for (int i = 0; i < WL; i++) {
+            const int idx = min(tid + 256 * i, WCH - 1), p = idx / (BN * CPR), rem = idx % (BN * CPR), row = rem / CPR, ch = rem % CPR;
+            const int gn = min(n0 + row, N - 1);
+            wv[i] = wp[p * piece + (size_t)gn * (KP / 8) + (k0 >> 3) + ch];
+        }
+#pragma unroll
+        for (int i = 0; i < XL; i++) {
+            const int idx = tid + 256 * i, row = idx / (2 * CPR), c4 = (idx % (2 * CPR)) * 4;
+            const bool in = m0 + row < M && k0 + c4 < K;                              // K is a multiple of 4
+            *reinterpret_cast<float4 *>(&xs[row * GB_XLD + c4]) = in ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < WL; i++) {
+            const int idx = tid + 256 * i, p = idx / (BN * CPR), rem = idx % (BN * CPR), row = rem / CPR, ch = rem % CPR;
+            if (idx < WCH) *reinterpret_cast<uint4 *>(&ws[(p * BN + row) * GB_WLD + 8 * ch]) = wv[i];   // (columns past N: never stored)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GB_BK / 16; ks++) {
+            float v[8];
+            const float *ap = &xs[(32 * wave + r) * GB_XLD + 16 * ks + 8 * h];
+            const float4 lo4 = *reinterpret_cast<const float4 *>(ap), hi4 = *reinterpret_cast<const float4 *>(ap + 4);
+            v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+            bf16x8 a1, a2, a3;
+            gb_split(v, a1, a2, a3);
+            bf16x8 b[NT][3];
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int p = 0; p < 3; p++)
+                    b[t][p] = *reinterpret_cast<const bf16x8 *>(&ws[(p * BN + 32 * t + r) * GB_WLD + 16 * ks + 8 * h]);
+            // small terms first; term-major: consecutive MFMAs go to different accumulators
+#define GB_TERM(PA, PB) \
+            _Pragma("unroll") for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA, b[t][PB], acc[t], 0, 0, 0);
+            GB_TERM(a1, 2) GB_TERM(a2, 1) GB_TERM(a3, 0) GB_TERM(a1, 1) GB_TERM(a2, 0) GB_TERM(a1, 0)
+#undef GB_TERM
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*h][col = lane&31] ----
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int col = n0 + 32 * nt + r;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const long row = m0 + 32 * wave + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (row < M) y[row * ldy + col] = slk_act_t<ACT>(acc[nt][reg] + bv);
+        }
+    }
+}
+
+// include/sloika_amd.h
+extern "C" size_t slk_pack_bf16x3_bytes(int N, int K)
+{
+    if (N < 1 || K < 1) return 0;
+    return (size_t)3 * N * ((K + GB_BK - 1) / GB_BK * GB_BK) * 2;
+}
+
+extern "C" int slk_pack_bf16x3_f32(const float *W, int N, int K, void *packed, slk_stream_t stream)
+{
+    if (!W || !packed || N < 1 || K < 1) return SLK_ERR_INVALID_ARG;
+    const int KP = (K + GB_BK - 1) / GB_BK * GB_BK;
+    long blocks = ((long)N * (KP / 8) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, slk_stream(stream), W, N, K, KP,
+                       static_cast<uint4 *>(packed));
+    return slk_launch_status();
+}
+
+template <int NT>
+static int gb_launch(const float *x, long ldx, const uint4 *wp, const float *bias, float *y, long ldy, long M, int K, int N, int act,
+                     hipStream_t s)
+{
+    const int ntile_n = (N + 32 * NT - 1) / (32 * NT), KP = (K + GB_BK - 1) / GB_BK * GB_BK;
+    const long blocks = ((M + GB_BM - 1) / GB_BM) * ntile_n;
+    if (blocks > 0x7fffffffL) return SLK_ERR_UNSUPPORTED;
+#define GB_LAUNCH(AC)                                                                                                            \
+    hipLaunchKernelGGL((gemm_bf16x6_kernel<NT, AC>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, wp, bias, y, ldy, M, K, KP, N, \
+                       ntile_n)
+    switch (act) {
+    case SLK_ACT_LINEAR: GB_LAUNCH(SLK_ACT_LINEAR); break;
+    case SLK_ACT_TANH: GB_LAUNCH(SLK_ACT_TANH); break;
+    case SLK_ACT_SIGMOID: GB_LAUNCH(SLK_ACT_SIGMOID); break;
+    default: return SLK_ERR_UNSUPPORTED;
+    }
+#undef GB_LAUNCH
+    return slk_launch_status();
+}
+
+extern "C" int slk_gemm_bias_act_bf16x6(const float *x, long ldx, const void *packed, const float *bias, float *y, long ldy, long M,
+                                        int K, int N, int act, slk_stream_t stream)
+{
+    if (!x || !packed || !y || M < 0 || K < 1 || N < 1 || ldx < K || ldy < N || !slk_act_valid(act)) return SLK_ERR_INVALID_ARG;
+    if (M == 0) return SLK_OK;
+    if ((K & 3) || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15))
+        return SLK_ERR_UNSUPPORTED;
+    // the column-tile count that wastes the fewest MFMA columns (ties -> wider tile), as gemm.hip
+    int best = 3, best_cost = 1 << 30;
+    for (int nt = 3; nt >= 1; nt--) {
+        const int cost = ((N + 32 * nt - 1) / (32 * nt)) * nt;
+        if (cost < best_cost) { best_cost = cost; best = nt; }
+    }
+    hipStream_t s = slk_stream(stream);
+    const uint4 *wp = static_cast<const uint4 *>(packed);
+    switch (best) {
+    case 1: return gb_launch<1>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
+    case 2: return gb_launch<2>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
+    default: return gb_launch<3>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
+    }
+}

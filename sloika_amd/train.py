@@ -100,6 +100,22 @@ def broadcast_from_rank0_(tensor):
     return tensor
 
 
+def _dx_gemm(a_ptr, lda, wt, out_ptr, ldo, M, what):
+    """out[M][N] = a[M][K] . wt[N][K]^T, the dL/dx product of a layer (wt = its transposed weight, contiguous): six bf16 MFMA terms
+    per product (csrc/gemm_bf16x6.hip) unless SLOIKA_AMD_EXACT_F32=1 or the shape is not covered, then the fp32 matrix pipe."""
+    import torch
+    L = _lib.lib()
+    N, K = int(wt.shape[0]), int(wt.shape[1])
+    rc = _lib.SLK_ERR_UNSUPPORTED
+    if layers.SPLIT_F16 and K % 4 == 0 and lda % 4 == 0 and K >= 32:
+        packed = torch.empty(L.slk_pack_bf16x3_bytes(N, K), dtype=torch.uint8, device=wt.device)
+        _lib.check(L.slk_pack_bf16x3_f32(wt.data_ptr(), N, K, packed.data_ptr(), layers._stream()), what)
+        rc = L.slk_gemm_bias_act_bf16x6(a_ptr, lda, packed.data_ptr(), None, out_ptr, ldo, M, K, N, 0, layers._stream())
+    if rc == _lib.SLK_ERR_UNSUPPORTED:
+        rc = L.slk_gemm_bias_act_f32(a_ptr, lda, wt.data_ptr(), None, out_ptr, ldo, M, K, N, 0, layers._stream())
+    _lib.check(rc, what)
+
+
 def _unwrap(layer, rev=False):
     while isinstance(layer, layers.Reverse):
         layer, rev = layer.layer, not rev
@@ -321,8 +337,7 @@ class TrainingStep(object):
             wt[:, :sm.size] = sm.W.dev().t()
             dy = torch.empty((To, B, n_in), dtype=torch.float32, device=x.device)
             with profiler.region("train_dx", 2.0 * M * sm.size * n_in, 4.0 * M * (ld + n_in)):
-                _lib.check(L.slk_gemm_bias_act_f32(logits.data_ptr(), ld, wt.data_ptr(), None, dy.data_ptr(), n_in, M, ld,
-                                                   n_in, 0, st()), "softmax dx")
+                _dx_gemm(logits.data_ptr(), ld, wt, dy.data_ptr(), n_in, M, "softmax dx")
         del logits
         # ---- the layers in front of it, top down ----------------------------------------------------------------------
         for k in range(len(tapes) - 1, -1, -1):
@@ -425,8 +440,7 @@ class TrainingStep(object):
             return None
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dy.device)
         with profiler.region("train_dx", 2.0 * M * n * i_sz, 4.0 * M * (n + i_sz)):
-            _lib.check(L.slk_gemm_bias_act_f32(dpre.data_ptr(), n, layer.W.dev().t().contiguous().data_ptr(), None,
-                                               dx.data_ptr(), i_sz, M, n, i_sz, 0, st()), "ff dx")
+            _dx_gemm(dpre.data_ptr(), n, layer.W.dev().t().contiguous(), dx.data_ptr(), i_sz, M, "ff dx")
         return dx
 
     def _gru_forward_saving(self, layer, x, rev):
@@ -558,8 +572,7 @@ class TrainingStep(object):
             return None
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
         with profiler.region("train_dx", 6.0 * M * n * i_sz, 4.0 * M * (3 * n + i_sz)):
-            _lib.check(L.slk_gemm_bias_act_f32(da.data_ptr(), 3 * n, iW.t().contiguous().data_ptr(), None, dx.data_ptr(), i_sz,
-                                               M, 3 * n, i_sz, 0, st()), "gru dx")
+            _dx_gemm(da.data_ptr(), 3 * n, iW.t().contiguous(), dx.data_ptr(), i_sz, M, "gru dx")
         return dx
 
     #: Lstm widths the reverse-scan kernels are instantiated for (csrc/train.hip); others run zero-padded to the next one
@@ -662,8 +675,7 @@ class TrainingStep(object):
             return None
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
         with profiler.region("train_dx", 8.0 * M * n * i_sz, 4.0 * M * (4 * n + i_sz)):
-            _lib.check(L.slk_gemm_bias_act_f32(dsum.data_ptr(), 4 * n, iW.reshape(4 * n, i_sz).t().contiguous().data_ptr(), None,
-                                               dx.data_ptr(), i_sz, M, 4 * n, i_sz, 0, st()), "lstm dx")
+            _dx_gemm(dsum.data_ptr(), 4 * n, iW.reshape(4 * n, i_sz).t().contiguous(), dx.data_ptr(), i_sz, M, "lstm dx")
         return dx
 
     def _conv_backward(self, layer, xin, y, dy, need_dx=False):
