@@ -16,6 +16,7 @@
 // The tile's weights (3 gates x 5 K blocks x hi/lo, 30 KB) live in LDS and are fetched as A operands when they are needed, every
 // register being taken.  105 MFMAs per step on the three waves with a share, 90 on wave 2.
 #include <limits.h>
+#include <stdlib.h>
 
 #include "bar16_common.h"
 
@@ -451,6 +452,9 @@ static size_t scan16_exclusive_lds()
     return dyn;
 }
 
+extern "C" int slk_gru_scan1t_launch(const float *vI, long ldv, const float *sW, const float *sW2, float *y, long ldy, int T, int B, int n,
+                                     int reverse, const int32_t *lens, hipStream_t s);             // gru_scan1t.hip
+
 // include/sloika_amd.h
 extern "C" int slk_gru_scan16_f32(const float *vI, long ldv, const float *sW, const float *sW2, float *y, long ldy, int T, int B, int n,
                                   int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream)
@@ -459,6 +463,14 @@ extern "C" int slk_gru_scan16_f32(const float *vI, long ldv, const float *sW, co
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
     if (n % 16 || n <= 96 || n > 144) return SLK_ERR_UNSUPPORTED;
     if ((unsigned long long)T * B * ldv * sizeof(float) >= (1ull << 32)) return SLK_ERR_UNSUPPORTED;       // 32-bit lane offsets
+    // one tile per wave (gru_scan1t.hip) where it is the faster plan: up to n = 128 (a layer of 112 at B = 1024, T' = 800: 1.11-1.19 ms
+    // against 1.21-1.28 with its projection, 128: 1.19-1.22 against 1.23-1.26; 144 needs nine waves of 168 registers, spills, and is
+    // slower: 2.09 against 1.93).  SLOIKA_AMD_SCAN1T=0 / 1: never / always, for comparisons.
+    static const int plan1t = getenv("SLOIKA_AMD_SCAN1T") ? atoi(getenv("SLOIKA_AMD_SCAN1T")) : -1;
+    if (plan1t == 1 || (plan1t < 0 && n <= 128)) {
+        const int rc = slk_gru_scan1t_launch(vI, ldv, sW, sW2, y, ldy, T, B, n, reverse, lens, slk_stream(stream));
+        if (rc != SLK_ERR_UNSUPPORTED) return rc;
+    }
     if (n > 128) {
         const size_t dyn = SLK_PER_DEVICE(size_t, scan16_exclusive_lds<160>());
         hipLaunchKernelGGL((gru_scan16_kernel<160>), dim3((B + 3) / 4), dim3(256), dyn, slk_stream(stream), vI, ldv, sW, sW2, y, ldy, T, B,

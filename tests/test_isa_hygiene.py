@@ -16,7 +16,8 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 @pytest.mark.parametrize("src,flags", [("softmax_viterbi.hip", ["-DSV_ONLY_KS=4"]), ("softmax_viterbi.hip", ["-DSV_ONLY_KS=6"]),
                                        ("gemm_rows_f16x3.hip", []), ("lstm_scan16.hip", []), ("gru_bar16.hip", []),
                                        ("gru_bar16d.hip", []), ("gru_bar16q.hip", []), ("gru_scan16.hip", []), ("lstm_bwd16.hip", []),
-                                       ("lstm_fused16.hip", []), ("gru_bwd16.hip", [])])
+                                       ("lstm_fused16.hip", []), ("gru_bwd16.hip", []),
+                                       ("gru_scan1t.hip", [])])
 def test_no_mfma_destination_over_live_operands(tmp_path, src, flags):
     import mfma_overlap_scan
     from sloika_amd import build
@@ -29,7 +30,8 @@ def test_no_mfma_destination_over_live_operands(tmp_path, src, flags):
 
 
 @pytest.mark.parametrize("src,nloads", [("gru_scan16.hip", 50), ("lstm_scan16.hip", 8), ("lstm_bwd16.hip", 8),
-                                        ("lstm_fused16.hip", 4), ("gru_bwd16.hip", 8)])
+                                        ("lstm_fused16.hip", 4), ("gru_bwd16.hip", 8),
+                                        ("gru_scan1t.hip", 6)])
 def test_no_instruction_touches_a_register_an_asm_load_is_filling(tmp_path, src, nloads):
     """csrc/gru_scan16.hip and lstm_scan16.hip issue their projection loads as asm, three steps ahead, and count them themselves; the
     compiler must not move such a destination (it once spilled one to an accumulation register right behind the load:
