@@ -796,19 +796,18 @@ __device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8 &p1, bf
     union { bf16x8 v; unsigned u[4]; } o1, o2, o3;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        unsigned t1[2], t2[2], t3[2];
+        // a piece = the top 16 bits of what is left; v_perm_b32 packs the top halves of a pair of values in one instruction (no
+        // masking, shifting and or-ing of the pieces themselves: 11 instructions per pair instead of 16)
+        float r1[2], r2[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const float x = v[2 * j + e];
-            t1[e] = __float_as_uint(x) & 0xffff0000u;
-            const float r1 = x - __uint_as_float(t1[e]);
-            t2[e] = __float_as_uint(r1) & 0xffff0000u;
-            const float r2 = r1 - __uint_as_float(t2[e]);
-            t3[e] = __float_as_uint(r2) & 0xffff0000u;
+            r1[e] = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u);
+            r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);
         }
-        o1.u[j] = (t1[0] >> 16) | t1[1];
-        o2.u[j] = (t2[0] >> 16) | t2[1];
-        o3.u[j] = (t3[0] >> 16) | t3[1];
+        o1.u[j] = __builtin_amdgcn_perm(__float_as_uint(v[2 * j + 1]), __float_as_uint(v[2 * j]), 0x07060302u);
+        o2.u[j] = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u);
+        o3.u[j] = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u);
     }
     p1 = o1.v; p2 = o2.v; p3 = o3.v;
 }
