@@ -221,7 +221,9 @@ SLK_API int slk_gru_fused16_f32(const float *x, long ldx, const float *iW, const
  * A workgroup takes four chunks; a batch with more such workgroups than the device has CUs runs the eight-chunk plan of
  * csrc/gru_bar16d.hip instead (two four-chunk tiles through the same MFMAs), one with more eight-chunk workgroups than CUs
  * the sixteen-chunk plan of csrc/gru_bar16q.hip (four and eight chunks: bit-identical results; sixteen: to float32 rounding).  Bits 8-9 of `reverse` force a plan: 0 = by batch
- * size, 1 / 2 / 3 = four / eight / sixteen chunks per workgroup (environment: SLOIKA_AMD_GRU_DUAL=0|1|2).               */
+ * size, 1 / 2 / 3 = four / eight / sixteen chunks per workgroup (environment: SLOIKA_AMD_GRU_DUAL=0|1|2).  Bit 10: the
+ * four-chunk workgroups of a layer up to 64 wide may share a CU (no exclusive LDS request): for callers that run two such
+ * launches side by side -- the directions of a birnn -- with more workgroups in all than the device has CUs.            */
 SLK_API int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                       float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                       const int32_t *lens, float *zr_out, slk_stream_t stream);

@@ -749,9 +749,11 @@ static size_t exclusive_cu_lds_bar(K kernel)
     return dyn;
 }
 
+// share_cu: the caller runs more four-chunk workgroups at a time than there are CUs and the instantiation fits two per CU (<= 256
+// registers, <= 80 KB of LDS: the 64-wide ones): no dynamic LDS, so that two of them -- the directions of a birnn -- share a CU
 template <int I, int N>
 static int launch_bar16(const float *x, long ldx, const float *iW, const float *bias, const float *sW, const float *sW2,
-                        float *y, long ldy, int T, int B, int reverse, const int *lens, float *zr_out, hipStream_t s)
+                        float *y, long ldy, int T, int B, int reverse, const int *lens, float *zr_out, hipStream_t s, bool share_cu)
 {
 #ifdef SLK_DIAG
     if constexpr (I == 96 && N == 96) {
@@ -773,12 +775,13 @@ static int launch_bar16(const float *x, long ldx, const float *iW, const float *
 #undef DIAG_LAUNCH
     }
 #endif
+    const bool shared = share_cu && N <= 64;
     if (zr_out) {
-        const size_t dyn = SLK_PER_DEVICE(size_t, exclusive_cu_lds_bar(gru_bar16_kernel<I, N, true>));
+        const size_t dyn = shared ? 0 : SLK_PER_DEVICE(size_t, exclusive_cu_lds_bar(gru_bar16_kernel<I, N, true>));
         hipLaunchKernelGGL((gru_bar16_kernel<I, N, true>), dim3((B + 3) / 4), dim3(256), dyn, s, x, ldx, iW, bias, sW, sW2, y,
                            ldy, T, B, reverse & 1, lens, zr_out);
     } else {
-        const size_t dyn = SLK_PER_DEVICE(size_t, exclusive_cu_lds_bar(gru_bar16_kernel<I, N, false>));
+        const size_t dyn = shared ? 0 : SLK_PER_DEVICE(size_t, exclusive_cu_lds_bar(gru_bar16_kernel<I, N, false>));
         hipLaunchKernelGGL((gru_bar16_kernel<I, N, false>), dim3((B + 3) / 4), dim3(256), dyn, s, x, ldx, iW, bias, sW, sW2, y,
                            ldy, T, B, reverse & 1, lens, zr_out);
     }
@@ -820,6 +823,7 @@ extern "C" int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, cons
     if ((ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;   // 16-byte DMA pieces
     hipStream_t s = slk_stream(stream);
     const int plan = (reverse >> 8) & 3;                 // include/sloika_amd.h: 0 = by batch size, 1 / 2 / 3 = four / eight / sixteen chunks
+    const bool share_cu = (reverse >> 10) & 1;           // ... bit 10: four-chunk workgroups of a 64-wide layer may share a CU
     reverse &= 0xff;
     const int per4 = plan == 1 ? 1 : plan == 2 ? 2 : plan == 3 ? 4 : ((reverse >> 1) == 0 ? bar16_auto_plan(B) : 1);
     if (per4 == 4) {
@@ -831,7 +835,7 @@ extern "C" int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, cons
         if (rc != SLK_ERR_UNSUPPORTED) return rc;
     }
 #define BAR16(II, NN) \
-    if (insize == II && n == NN) return launch_bar16<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s);
+    if (insize == II && n == NN) return launch_bar16<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s, share_cu);
     BAR16(96, 96) BAR16(64, 64) BAR16(32, 96) BAR16(128, 96) BAR16(64, 96) BAR16(48, 32) BAR16(16, 64)
 #undef BAR16
     return SLK_ERR_UNSUPPORTED;

@@ -111,6 +111,10 @@ RECURRENT_F16 = os.environ.get("SLOIKA_AMD_RECURRENT_F32", "0") != "1"
 #: Execution plan of that kernel: "bar" = four waves stepping through barriers (csrc/gru_bar16.hip, the faster one),
 #: "flags" = eight waves coupled by LDS progress counters (csrc/gru_fused16.hip).  Same arithmetic, same contract.
 GRU_PLAN = os.environ.get("SLOIKA_AMD_GRU_PLAN", "bar")
+#: Gru layers up to 64 wide run their four-chunk workgroups two per CU where one per CU does not hold what is meant to run together (the
+#: directions of a birnn at B = 1024: `baseline_gru` 16.9 -> 14.9 ms per step against the eight-chunk plan on half the chip each);
+#: SLOIKA_AMD_GRU64_SHARE=0 switches it off for comparisons.
+GRU64_SHARE = os.environ.get("SLOIKA_AMD_GRU64_SHARE", "1") != "0"
 #: An Lstm layer of up to 64 units and 64 inputs runs as ONE kernel that computes its input projection inside the scan
 #: (csrc/lstm_fused16.hip); SLOIKA_AMD_LSTM_FUSED=0 keeps projection GEMM + scan (csrc/lstm_scan16.hip) for comparison.
 LSTM_FUSED = os.environ.get("SLOIKA_AMD_LSTM_FUSED", "1") != "0"
@@ -141,6 +145,8 @@ def _gru_plan_for(B, share, ncu, per_cu=1):
     (baseline_raw_gru, eight batches of 256 in flight: 520 -> 545 M samples/s).  The four-chunk kernel keeps a CU to itself."""
     if ((B + 3) // 4) * share <= ncu:
         return 0
+    if per_cu == 2 and GRU64_SHARE and ((B + 3) // 4) * share <= 2 * ncu:
+        return 5                   # four chunks per workgroup, two workgroups per CU (bit 2 = bit 10 of `reverse`: may share a CU)
     if ((B + 7) // 8) * share <= ncu * per_cu:
         return 2
     return 3 if ((B + 15) // 16) * share <= ncu * per_cu else 0
@@ -938,7 +944,7 @@ class Gru(RNN):
                 #  projection three; the sixteen-chunk plan three everywhere -- csrc/gru_bar16.hip bar16_auto_plan)
                 bits = self._plan_bits(x, B) if GRU_PLAN == "bar" else 3
                 ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
-                two_term = GRU_PLAN == "bar" and (bits in (1, 2) or (bits == 0 and (B + 7) // 8 <= ncu))
+                two_term = GRU_PLAN == "bar" and (bits in (1, 2, 5) or (bits == 0 and (B + 7) // 8 <= ncu))
                 with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
                                      f16x3_flops=6.0 * rows * n * (self.insize if two_term else n + self.insize),
                                      f16x2_flops=6.0 * rows * n * n if two_term else 0.0) as reg:
