@@ -198,6 +198,20 @@ def _split_f16_cached(owner, attr, param, rows, k):
     return _derived_cache(owner, attr, (param,), build)
 
 
+def _pack_bf16_cached(owner, attr, param, rows, k):
+    """The [rows][k] weight `param` cut into three bf16 pieces (csrc/gemm_bf16x6.hip), on the device, re-made whenever the
+    parameter changes."""
+    import torch
+
+    def build():
+        wd = param.dev()
+        packed = torch.empty(_lib.lib().slk_pack_bf16x3_bytes(rows, k), dtype=torch.uint8, device=wd.device)
+        _lib.check(_lib.lib().slk_pack_bf16x3_f32(wd.data_ptr(), rows, k, packed.data_ptr(), _stream()), "pack_bf16")
+        return (packed,)
+
+    return _derived_cache(owner, attr, (param,), build)[0]
+
+
 def _projection(owner, x, W, b, ws_ptr, rows, k, n_out, stage, name):
     """ws[rows][n_out] = x.W^T + b for a recurrent layer's input projection: fp16x3 kernel where it applies
     (k <= 192, n_out <= 2048), else the fp32 MFMA GEMM."""
@@ -425,7 +439,8 @@ class FeedForward(Layer):
 
     def __getstate__(self):
         d = dict(self.__dict__)
-        d.pop("_w16", None)          # device cache: never pickled
+        d.pop("_w16", None)          # device caches: never pickled
+        d.pop("_wbf16", None)
         return d
 
     def _forward(self, x, out, reverse):
@@ -435,11 +450,18 @@ class FeedForward(Layer):
         L = _lib.lib()
         act = activation.act_id(self.fun)
         use_f16 = SPLIT_F16 and self.insize <= 192 and self.size <= 2048
+        # up to 96 output columns (one column block) the LDS-staged kernel with six bf16 terms per product is the faster one:
+        # 128 -> 64 at 4.1 M rows 0.78 ms against 1.10, 192 -> 96 0.29 against 0.39 (csrc/gemm_bf16x6.hip; float32-grade like the split)
+        use_bf16 = SPLIT_F16 and self.size <= 96 and self.insize % 4 == 0 and self.insize >= 32 and act in (0, 1, 2)
         with profiler.region("gemm_bias_act", 2.0 * rows * self.insize * self.size,
                              4.0 * rows * (self.insize + self.size),
                              f16x3_flops=2.0 * rows * self.insize * self.size if use_f16 else 0.0) as reg:
             rc = _lib.SLK_ERR_UNSUPPORTED
-            if use_f16:
+            if use_bf16:
+                packed = _pack_bf16_cached(self, "_wbf16", self.W, self.size, self.insize)
+                rc = L.slk_gemm_bias_act_bf16x6(x.data_ptr(), _row_stride(x), packed.data_ptr(), self.b.dev().data_ptr(),
+                                                y.data_ptr(), _row_stride(y), rows, self.insize, self.size, act, _stream())
+            if rc == _lib.SLK_ERR_UNSUPPORTED and use_f16:
                 hi, lo, inv = _split_f16_cached(self, "_w16", self.W, self.size, self.insize)
                 rc = L.slk_gemm_bias_act_f16x3(x.data_ptr(), _row_stride(x), hi.data_ptr(), lo.data_ptr(), inv.data_ptr(),
                                                self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), rows, self.insize,

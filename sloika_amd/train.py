@@ -236,7 +236,7 @@ class TrainingStep(object):
         for p in self.shared:                            # every cache keys on (device tensor, version): a new version ...
             p._version = getattr(p, "_version", 0) + 1
         for layer in [leaf for sub in self.body for leaf in _leaves(sub)] + [self.softmax]:
-            for attr in ("_w16", "_iw16", "_pad_cache", "_svpack", "_svpack_p"):    # ... and the old tensors are released right away
+            for attr in ("_w16", "_wbf16", "_iw16", "_pad_cache", "_svpack", "_svpack_p"):    # ... and the old tensors are released right away
                 layer.__dict__.pop(attr, None)
             # (a Gru whose forward pass runs a zero-padded twin rebuilds it from get_value(), which reads the device copy)
 
