@@ -197,8 +197,8 @@ extern "C" int slk_gemm_bias_act_bf16x6(const float *x, long ldx, const void *pa
     if ((K & 3) || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15))
         return SLK_ERR_UNSUPPORTED;
     // the column-tile count that wastes the fewest MFMA columns (ties -> wider tile), as gemm.hip
-    int best = 3, best_cost = 1 << 30;
-    for (int nt = 3; nt >= 1; nt--) {
+    int best = 4, best_cost = 1 << 30;
+    for (int nt = 4; nt >= 1; nt--) {                    // (four tiles: 128 columns in one block, x read once)
         const int cost = ((N + 32 * nt - 1) / (32 * nt)) * nt;
         if (cost < best_cost) { best_cost = cost; best = nt; }
     }
@@ -207,6 +207,7 @@ extern "C" int slk_gemm_bias_act_bf16x6(const float *x, long ldx, const void *pa
     switch (best) {
     case 1: return gb_launch<1>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
     case 2: return gb_launch<2>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
-    default: return gb_launch<3>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
+    case 3: return gb_launch<3>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
+    default: return gb_launch<4>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
     }
 }

@@ -111,6 +111,9 @@ RECURRENT_F16 = os.environ.get("SLOIKA_AMD_RECURRENT_F32", "0") != "1"
 #: Execution plan of that kernel: "bar" = four waves stepping through barriers (csrc/gru_bar16.hip, the faster one),
 #: "flags" = eight waves coupled by LDS progress counters (csrc/gru_fused16.hip).  Same arithmetic, same contract.
 GRU_PLAN = os.environ.get("SLOIKA_AMD_GRU_PLAN", "bar")
+#: widest FeedForward output that takes csrc/gemm_bf16x6.hip (128 -> 64: 0.78 against 1.10 ms, 192 -> 96: 0.29 against 0.39; 192 -> 128
+#: as one 128-column block: 1.69 against 1.72 ms, i.e. no gain, so it stays with the row kernel); SLOIKA_AMD_BF16_FF_MAX for comparisons
+BF16_FF_MAX = int(os.environ.get("SLOIKA_AMD_BF16_FF_MAX", "96"))
 #: Gru layers up to 64 wide run their four-chunk workgroups two per CU where one per CU does not hold what is meant to run together (the
 #: directions of a birnn at B = 1024: `baseline_gru` 16.9 -> 14.9 ms per step against the eight-chunk plan on half the chip each);
 #: SLOIKA_AMD_GRU64_SHARE=0 switches it off for comparisons.
@@ -452,7 +455,7 @@ class FeedForward(Layer):
         use_f16 = SPLIT_F16 and self.insize <= 192 and self.size <= 2048
         # up to 96 output columns (one column block) the LDS-staged kernel with six bf16 terms per product is the faster one:
         # 128 -> 64 at 4.1 M rows 0.78 ms against 1.10, 192 -> 96 0.29 against 0.39 (csrc/gemm_bf16x6.hip; float32-grade like the split)
-        use_bf16 = SPLIT_F16 and self.size <= 96 and self.insize % 4 == 0 and self.insize >= 32 and act in (0, 1, 2)
+        use_bf16 = SPLIT_F16 and self.size <= BF16_FF_MAX and self.insize % 4 == 0 and self.insize >= 32 and act in (0, 1, 2)
         with profiler.region("gemm_bias_act", 2.0 * rows * self.insize * self.size,
                              4.0 * rows * (self.insize + self.size),
                              f16x3_flops=2.0 * rows * self.insize * self.size if use_f16 else 0.0) as reg:
