@@ -195,33 +195,20 @@ SLK_API size_t slk_gru_workspace_bytes(int T, int B, int n);
 SLK_API int slk_gru_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
                 float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
                 void *workspace, size_t workspace_bytes, slk_stream_t stream);
-/* Whole layer in one persistent kernel (projection waves + recurrent waves, csrc/gru_fused.hip): no workspace, the
- * projection never touches HBM.  The recurrence is exact float32 MFMA; the input projection is evaluated as a 3-term
- * fp16 split with float32 accumulation (error a few float32 ulps, as slk_linear_rowstats_f16x3) -- callers that need
- * plain fp32 arithmetic throughout use slk_gemm_bias_act_f32 + slk_gru_recurrent_f32.  Returns SLK_ERR_UNSUPPORTED
- * when (insize, n, activations, alignment) has no fused instantiation; slk_gru_f32 tries it first and falls back to
- * projection GEMM + slk_gru_recurrent_f32.                                                                          */
-SLK_API int slk_gru_fused_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
-                      float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
-                      slk_stream_t stream);
-/* The same layer with the RECURRENCE on the fp16 matrix pipe as well (csrc/gru_fused16.hip): every float32 operand of
- * h.sW^T and (r*h).sW2^T is split v = hi + lo into two fp16 halves and each product evaluated as hi.lo + lo.hi + hi.hi in
- * float32 accumulators (v_mfma_f32_16x16x32_f16) -- 22 significand bits per operand.  |h| <= 1 by construction; every
- * row of x and of the three weight matrices is scaled by a power of two to a maximum in [1, 2) before its split and the
- * accumulators are scaled back, so inputs and weights of any finite float32 magnitude are safe.  lens: NULL, or ragged lengths as slk_gru_fused_ragged_f32; zr_out: NULL, or [T*B][2n] = [z | r] of every
- * step as slk_gru_fused_train_f32.  n in {32, 64, 96}; SLK_ERR_UNSUPPORTED for shapes without an instantiation.     */
-SLK_API int slk_gru_fused16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
-                        float *y, long ldy, int T, int B, int insize, int n, int reverse, int act, int gate_act,
-                        const int32_t *lens, float *zr_out, slk_stream_t stream);
-/* The same arithmetic and contract as slk_gru_fused16_f32 on a different execution plan (csrc/gru_bar16.hip): four waves
- * per workgroup, one per SIMD with 512 registers each, stepping in lock step through two s_barrier per time step instead of
- * LDS progress counters; projection weights live in accumulation registers.  Results agree with slk_gru_fused16_f32 to a
- * few 1e-7 (the three split terms are summed in a different order).  This is the plan sloika_amd.layers.Gru runs;
- * SLK_ERR_UNSUPPORTED for shapes without an instantiation (the same list as slk_gru_fused16_f32).
+/* The whole layer with the RECURRENCE on the fp16 matrix pipe as well (csrc/gru_bar16.hip): every float32 operand of
+ * h.sW^T and (r*h).sW2^T is split v = hi + lo into two fp16 halves and each product evaluated in float32 accumulators
+ * (v_mfma_f32_16x16x32_f16) -- 22 significand bits per operand.  |h| <= 1 by construction; every row of x and of the
+ * three weight matrices is scaled by a power of two to a maximum in [1, 2) before its split and the accumulators are
+ * scaled back, so inputs and weights of any finite float32 magnitude are safe.  lens: NULL, or ragged lengths as
+ * slk_gru_recurrent_ragged_f32; zr_out: NULL, or [T*B][2n] = [z | r] of every step (the training forward pass).
+ * Execution plan: four waves per workgroup, one per SIMD with 512 registers each, stepping in lock step through two
+ * s_barrier per time step; projection weights live in accumulation registers.  This is the plan sloika_amd.layers.Gru runs;
+ * SLK_ERR_UNSUPPORTED for shapes without an instantiation ((insize, n) in {(96,96), (64,64), (32,96), (128,96), (64,96),
+ * (48,32), (16,64)}, tanh / sigmoid).
  * A workgroup takes four chunks; a batch with more such workgroups than the device has CUs runs the eight-chunk plan of
  * csrc/gru_bar16d.hip instead (two four-chunk tiles through the same MFMAs), one with more eight-chunk workgroups than CUs
- * the sixteen-chunk plan of csrc/gru_bar16q.hip (four and eight chunks: bit-identical results; sixteen: to float32 rounding).  Bits 8-9 of `reverse` force a plan: 0 = by batch
- * size, 1 / 2 / 3 = four / eight / sixteen chunks per workgroup (environment: SLOIKA_AMD_GRU_DUAL=0|1|2).  Bit 10: the
+ * the sixteen-chunk plan of csrc/gru_bar16q.hip (four and eight chunks: bit-identical results; sixteen: to float32 rounding).
+ * Bits 8-9 of `reverse` force a plan: 0 = by batch size, 1 / 2 / 3 = four / eight / sixteen chunks per workgroup.  Bit 10: the
  * four-chunk workgroups of a layer up to 64 wide may share a CU (no exclusive LDS request): for callers that run two such
  * launches side by side -- the directions of a birnn -- with more workgroups in all than the device has CUs.            */
 SLK_API int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
@@ -231,9 +218,6 @@ SLK_API int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, const f
  * sloika/basecall.py:88-121): lens[b] in [1, T] (int32, device) is the number of valid steps of chunk b.  Steps
  * t >= lens[b] of y / h_out are left untouched, and with reverse = 1 the scan of chunk b starts at ITS last step,
  * i.e. each chunk gets exactly what a call on the unpadded chunk alone would produce.                                */
-SLK_API int slk_gru_fused_ragged_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2,
-                             const float *bias, float *y, long ldy, int T, int B, int insize, int n, int reverse, int act,
-                             int gate_act, const int32_t *lens, slk_stream_t stream);
 SLK_API int slk_gru_recurrent_ragged_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh, int T, int B,
                                  int n, int reverse, int act, int gate_act, const int32_t *lens, slk_stream_t stream);
 /* The same scan (Gru.step over a projection vI [T*B][ldv >= 3n] = x.iW^T + b in HBM; sloika/layers.py:1010-1021) for layers
@@ -258,7 +242,7 @@ SLK_API int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const flo
 SLK_API int slk_lstm_recurrent_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
                            int n, int reverse, int act, int gate_act, slk_stream_t stream);
 SLK_API int slk_lstm_recurrent_ragged_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T, int B,
-                                  int n, int reverse, int act, int gate_act, const int32_t *lens /* see slk_gru_fused_ragged_f32 */,
+                                  int n, int reverse, int act, int gate_act, const int32_t *lens /* see slk_gru_recurrent_ragged_f32 */,
                                   slk_stream_t stream);
 /* The same scan with the recurrent product as a 3-term fp16 split on the barrier-stepped plan (csrc/lstm_scan16.hip; n a multiple
  * of 16 up to 128, tanh / sigmoid, vW 16-byte aligned and < 4 GiB; SLK_ERR_UNSUPPORTED otherwise -> slk_lstm_recurrent_f32).
@@ -312,7 +296,7 @@ SLK_API int slk_viterbi_kmer_logits_f32(const float *logits, long ld /* floats b
                                 int T, int B, int nbase, int klen, float skip_pen, float min_prob, void *workspace,
                                 size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out,
                                 slk_stream_t stream);
-/* Ragged form (see slk_gru_fused_ragged_f32): chunk b is decoded over its first lens[b] steps only; path_out rows keep
+/* Ragged form (see slk_gru_recurrent_ragged_f32): chunk b is decoded over its first lens[b] steps only; path_out rows keep
  * the padded length T.                                                                                               */
 SLK_API int slk_viterbi_kmer_logits_ragged_f32(const float *logits, long ld, const float *stats, int T, int B, int nbase, int klen,
                                        float skip_pen, float min_prob, const int32_t *lens, void *workspace,
@@ -441,7 +425,7 @@ SLK_API int slk_raw_chunk_labels_interp_i32(const int64_t *start, const int64_t 
  * slk_gru_backward_f32: the reverse scan.  dy:[T][B] rows lddy apart = dL/dh from the layer above; hprev: h at the
  *   previous scan step per row (rows ldhp apart: the h half of the packed xh rows, or a view of the layer output shifted
  *   by one step over a zero row); zr:[M][2n] the activated gates (recomputed as above, or saved by
- *   slk_gru_fused_train_f32); h: the layer's own forward output (rows ldh apart), from which the candidate of every step is recovered as (h_t - z h_prev) / (1 - z);
+ *   slk_gru_bar16_f32 with zr_out); h: the layer's own forward output (rows ldh apart), from which the candidate of every step is recovered as (h_t - z h_prev) / (1 - z);
  *   writes da:[M][3n] = dL/dvI = [daz | dar | dac] and rh:[M][n] = r * h_prev.  n in {16,32,48,64,96,112,128,144},
  *   tanh / sigmoid, else SLK_ERR_UNSUPPORTED.
  *   Weight gradients follow as contractions over m (slk_gemm_tn_f32): diW = da^T x, dsW = da[:, :2n]^T h_prev,
@@ -458,10 +442,6 @@ SLK_API int slk_raw_chunk_labels_interp_i32(const int64_t *start, const int64_t 
  * slk_adamski_update_f32: updates.py:77-87 over flat buffers with this step's lr_t / momentum_decay (updates.py:73-76);
  *   g = clip(grad * gscale + 2 l2 param).   slk_sgd_update_f32: updates.py:9-33.
  * ------------------------------------------------------------------------------------------------------- */
-/* Forward pass that also saves the gates: slk_gru_fused_f32 + zr_out:[T*B][2n] = [z | r] of every step. */
-SLK_API int slk_gru_fused_train_f32(const float *x, long ldx, const float *iW, const float *sW, const float *sW2, const float *bias,
-                            float *y, long ldy, float *zr_out, int T, int B, int insize, int n, int reverse, int act,
-                            int gate_act, slk_stream_t stream);
 SLK_API int slk_train_pack_xh_f32(const float *x, long ldx, const float *h, long ldh, float *xh, int T, int B, int insize, int n,
                           int reverse, slk_stream_t stream);
 SLK_API int slk_train_pack_xrh_f32(const float *xh, const float *zr, float *xrh, long M, int insize, int n, slk_stream_t stream);

@@ -51,7 +51,6 @@ PROTOTYPES = {
     "slk_softmax_viterbi_pack_bytes": (_sz, [_i, _i, _i]),
     "slk_softmax_viterbi_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "slk_softmax_viterbi_f32": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
-    "slk_gru_fused_ragged_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slk_gru_recurrent_ragged_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slk_gru_scan16_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slk_log_post_logits_f32": (_i, [_vp, _l, _vp, _vp, _sz, _i, _f, _vp]),
@@ -60,9 +59,7 @@ PROTOTYPES = {
     "slk_gru_workspace_bytes": (_sz, [_i, _i, _i]),
     "slk_gru_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "slk_paths_to_bases": (_i, [_vp, _l, _vp, _i, _i, _i, _i, C.c_ulonglong, _vp, _l, _vp, _vp]),
-    "slk_gru_fused16_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "slk_gru_bar16_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "slk_gru_fused_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_lstm_recurrent_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_lstm_recurrent_ragged_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "slk_lstm_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -88,7 +85,6 @@ PROTOTYPES = {
     "slk_train_pack_xrh_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "slk_gru_backward_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_gru_backward16_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "slk_gru_fused_train_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_lstm_gates_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "slk_lstm_backward_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_lstm_backward16_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -25,6 +25,19 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-
 # must round exactly like numpy's float32 evaluation.  Kernels that want fused multiply-adds call fmaf / MFMA.
 
 
+# -amdgpu-mfma-vgpr-form: compiler-generated MFMAs keep their accumulators in ordinary registers.  Without it a kernel that
+# names accumulation registers in inline asm (weights as "a" operands) gets ALL its MFMA results in accumulation registers and
+# pays four v_accvgpr_read per tile before the gate arithmetic can touch them (gru_bar16_kernel<96,96>: 112 of them, 28 per
+# step on the serial chain).  Only for the files written for it: their asm reads of accumulators keep the eight wait states
+# behind an MFMA themselves (the compiler pads in front of its own v_accvgpr_read, never inside asm).
+VGPR_FORM = ("gru_bar16.hip",)
+
+
+def flags_for(src):
+    """Compile flags of one source file of csrc/."""
+    return FLAGS + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.path.basename(src) in VGPR_FORM else [])
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -50,7 +63,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OUT, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([cc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([cc] + flags_for(src) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -108,8 +108,10 @@ __device__ __forceinline__ f32x4 tile_mfma_acc(const half8 *w_hi, const half8 *w
     }
     return acc;
 }
-__device__ __forceinline__ void mfma_drain(f32x4 &a) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a)); }
-__device__ __forceinline__ void mfma_drain2(f32x4 &a, f32x4 &b) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b)); }
+// (Eight wait states: what hipcc itself puts between a v_mfma_f32_16x16x32_f16 and a vector instruction that reads its result; the
+//  hardware does not interlock that read, and seven is where every register arrives -- tools/probes/mfma_read_hazard_probe.hip.)
+__device__ __forceinline__ void mfma_drain(f32x4 &a) { asm volatile("s_nop 7" : "+v"(a)); }
+__device__ __forceinline__ void mfma_drain2(f32x4 &a, f32x4 &b) { asm volatile("s_nop 7" : "+v"(a), "+v"(b)); }
 // one K block of one tile, accumulator kept across steps (chain waves); FIRST: start from zero
 template <bool FIRST>
 __device__ __forceinline__ void block_mfma_acc(f32x4 &acc, const half8 &w_hi, const half8 &w_lo, const half8 &x_hi, const half8 &x_lo)
@@ -196,18 +198,43 @@ __device__ __forceinline__ void z_block_mfma2(f32x4 &a0, f32x4 &a1, const half8 
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a0) : "a"(w0_hi), "v"(bm));
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bm));
 }
+// one tile's product with one K block of the mixed operand
+__device__ __forceinline__ void mfma2(const half8 &w_hi, const half8 &w_lo, const half8 &bm, f32x4 &acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi, bm, acc, 0, 0, 0);
+}
+// WS: wait states in front of the first read.  The compiler does not look into asm: a DPP source written by a VALU instruction just
+// before needs two, an accumulator written by an MFMA eight counted from that MFMA (mfma_drain) -- callers that have pinned other
+// instructions in between pass what is left of the eight.
+template <int WS = 2>
 __device__ __forceinline__ float pick_mix(const f32x4 &a)
 {
+    static_assert(WS >= 2 && WS <= 8, "wait states");
     float r;
-    // s_nop: a DPP source written by a VALU instruction just before needs two wait states, and the compiler does not look into asm
-    asm volatile("s_nop 1\n\t"
+    asm volatile("s_nop %c5\n\t"
                  "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x1\n\t"
                  "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x2\n\t"
                  "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x4\n\t"
                  "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x8"
                  : "=&v"(r)
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(WS - 1));
     return r;
+}
+// ... into a register the caller keeps from step to step (see split2_kept).  Not volatile: the scheduler may move it among the MFMAs
+// of another gate; `after` is an operand the statement only waits for -- the value whose producer must lie in front of it (the
+// accumulator of the tile whose MFMAs supply the wait states, or the result of the pick that does).
+template <int WS = 2>
+__device__ __forceinline__ void pick_mix_kept(const f32x4 &a, float &r, float after)
+{
+    static_assert(WS >= 2 && WS <= 8, "wait states");
+    asm("s_nop %c5\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x1\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x2\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x4\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x8"
+        : "+v"(r)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "n"(WS - 1), "v"(after));
 }
 // The same for gru_bar16d.hip's layout (eight chunks per workgroup: the two copies of a chunk sit FOUR columns apart, copy q&1 = 0 carries
 // the hi half and owns rows 4g + {0, 1}, copy 1 the lo half and rows 4g + {2, 3}): value j of the lane = register 2(q&1) + j summed over

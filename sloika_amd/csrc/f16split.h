@@ -17,19 +17,31 @@ __device__ __forceinline__ float sel4(const f32x4 &a, int q)
     return (q & 2) ? hi : lo;
 }
 
-// two float32 -> one dword of fp16 "hi" parts and one of fp16 "lo" parts (v = hi + lo)
-// (the inputs are made opaque first: hipcc otherwise folds the multiply or add that produced them into the conversion --
-// v_fma_mixlo_f16, ONE rounding -- for the value it subtracts, while the stored hi part is the conversion of the rounded
-// float32: the two disagree whenever the float32 value is an exact fp16 tie, 1 in 8192, and hi + lo is then off by an
-// fp16 ulp.  Found by tools/f16_error_probe4.py.)
+// two float32 -> one dword of fp16 "hi" parts and one of fp16 "lo" parts (v = hi + lo): the hi pair is one packed conversion, each
+// lo = v - float(hi) one v_fma_mix_f32 that reads its half of the hi pair as fp16 ((-1) * hi + v: exact, the difference of a float32
+// and its own 11-bit rounding is representable), the lo pair another packed conversion -- four instructions where the plain C form
+// compiles to eight.  (It is asm for a second reason: from C hipcc folded the multiply or add that PRODUCED a value into the
+// conversion of the value it subtracts -- v_fma_mixlo_f16, ONE rounding -- while the stored hi part was the conversion of the rounded
+// float32; on an exact fp16 tie, 1 value in 8192, hi + lo was then off by an fp16 ulp.  Found by tools/experiments/f16_error_probe4.py.)
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
 {
-    asm volatile("" : "+v"(a), "+v"(b));
-    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-    const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
-    half2_t h = {ha, hb}, l = {la, lb};
-    hi = __builtin_bit_cast(unsigned, h);
-    lo = __builtin_bit_cast(unsigned, l);
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %1, %2, %3"
+        : "=&v"(hi), "=&v"(lo), "+v"(a), "+v"(b));
+}
+// The same into registers the caller keeps for it from step to step (`hi` and `lo` go in as well as out, so they never share a
+// register with anything else): behind an asm statement hipcc pads for every MFMA that wrote the registers of the statement's
+// outputs in the last few instructions -- it counts the statement as ONE wait state -- and fresh outputs tend to land in the
+// registers of accumulators that have just died.
+__device__ __forceinline__ void split2_kept(float a, float b, unsigned &hi, unsigned &lo)
+{
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %0, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_cvt_pk_f16_f32 %1, %2, %3"
+        : "+v"(hi), "+v"(lo), "+v"(a), "+v"(b));
 }
 
 // Power-of-two scale that brings a row whose largest magnitude is `amax` into [1, 2): scale = 2^(127 - e), inv = 2^(e - 127),

@@ -22,32 +22,25 @@
 
 #include "bar16_common.h"
 
-// 1: two MFMAs per recurrent product, the state's hi and lo halves in different column groups (bar16_common.h: mfma2x2, pick_mix);
-// 0: round 2's three-term sequence (every column group a copy of the hi half, the lo half a second operand)
-#ifndef BAR16_MIX
-#define BAR16_MIX 1
-#endif
-
-// Diagnostic instantiation: shader-clock cycles the waves of workgroup 0 spend in each section of a step, summed over the scan
-// (tools/bar16_check.py reads them).  The production instantiation carries none of this.
-// (Diagnostic launches and the readers of these tables exist only in builds with -DSLK_DIAG: tools/build_diag_lib.sh.)
-__device__ unsigned long long slk_dbg_bar16[4][16];
+// Recurrent products take TWO MFMAs each: the state's hi and lo halves ride in different column groups (bar16_common.h: pick_mix).
+//
+// Diagnostics (per-section shader-clock stamps, ablation launches, workgroup clocks) exist only in builds with -DSLK_DIAG
+// (tools/build_diag_lib.sh; readers: tools/bar16_check.py, tools/bar16_wg_times.py).  ABL bits (results are then garbage):
+// 1 = no s_barrier, 2 = chain waves issue no MFMAs, 4 = cheap activations, 8 = service waves only keep the barriers,
+// 16 = no stores to h_out, 32 = every workgroup records where it ran and for how long.
 #ifdef SLK_DIAG
+__device__ unsigned long long slk_dbg_bar16[4][16];
 extern "C" SLK_API int slk_debug_read_bar16(unsigned long long *host_out)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_bar16), sizeof(unsigned long long) * 64) == hipSuccess ? SLK_OK
                                                                                                                 : SLK_ERR_LAUNCH;
 }
-#endif
-// ABL & 32: every workgroup records where it ran and for how long (shader clock and the 100 MHz wall clock)
 __device__ unsigned long long slk_dbg_bar16_wg[1024][4];
-#ifdef SLK_DIAG
 extern "C" SLK_API int slk_debug_read_bar16_wg(unsigned long long *host_out)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(slk_dbg_bar16_wg), sizeof(unsigned long long) * 4096) == hipSuccess ? SLK_OK
                                                                                                                     : SLK_ERR_LAUNCH;
 }
-#endif
 #define BSTAMP(i)                                                                     \
     if constexpr (DIAG) {                                                             \
         unsigned long long tnow;                                                      \
@@ -57,9 +50,10 @@ extern "C" SLK_API int slk_debug_read_bar16_wg(unsigned long long *host_out)
         sacc[i] += tnow - tprev;                                                      \
         tprev = tnow;                                                                 \
     }
+#else
+#define BSTAMP(i)
+#endif
 
-// ABL (timing experiments of tools/bar16_check.py only; results are garbage): 1 = no s_barrier, 2 = chain waves issue no MFMAs,
-// 4 = cheap activations, 8 = service waves only keep the barriers, 16 = no stores to h_out
 // first tile of interval k when a service wave has st tiles per group (k = 8: st)
 __host__ __device__ constexpr int tile_first(int st, int k)
 {
@@ -106,30 +100,21 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
     __shared__ __attribute__((aligned(16))) unsigned xop_hi[2 * OPIMG], xop_lo[2 * OPIMG];
     __shared__ __attribute__((aligned(16))) float xinv_lds[2 * 16];
     __shared__ __attribute__((aligned(16))) float vbuf[R * VSTEP];
-    // + 4: sixteen zero bytes behind each image, the operand of the lanes whose columns stay empty (ZC below)
-    constexpr int IMG = 2 * N + 4;
+    // The lo image lies 32 banks behind the hi image: a ds_read_b128 of the mixed operand serves lane quartets of both in one pass
+    // (2N + 4 put the two on the same banks: SQ_LDS_BANK_CONFLICT was 37 % of the kernel's LDS cycles)
+    constexpr int IMG = 2 * N + (2 * N % 64 == 0 ? 32 : 2 * N % 64 == 32 ? 0 : 4);
     __shared__ __attribute__((aligned(16))) unsigned h_img[2 * IMG], rh_img[2 * IMG];             // hi image, then lo image
     unsigned *const h_hi = h_img, *const h_lo = h_img + IMG, *const rh_hi = rh_img, *const rh_lo = rh_img + IMG;
-    // ZC (ABL & 64, an experiment kept for the record): the state enters the recurrent MFMAs in column group 0 only (lanes
-    // q = 0 read it, the others read zeros; gather4 instead of sel4).  When the kernel fills the chip its clock is set by the
-    // power limit (tools/bar16_wg_times.py: 1.83-2.39 GHz at B = 1024 depending on the device and the moment, 2.38-2.41 GHz
-    // at B = 256, always the same 1880 cycles per step), and a matrix pipe multiplying zeros draws less -- but alternating
-    // launches on one device give it +1-2 % of clock for +1.8 % of cycles (the DPP moves), in the pipeline nothing.
-    constexpr bool ZC = (ABL & 64) != 0;
-    constexpr bool MIX = BAR16_MIX != 0 && !ZC;
     __shared__ __attribute__((aligned(16))) float bias_lds[3 * N], invw_lds[3 * N];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
+#ifdef SLK_DIAG
     unsigned long long wg_t0 = 0, wg_r0 = 0;
     if constexpr (ABL & 32) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(wg_t0), "=s"(wg_r0)::"memory");
+#endif
 
-    if constexpr (ABL & 256) {                           // experiment: workgroups out of phase (do 256 CUs bursting in step cost clock?)
-        const int ph = (blockIdx.x * 7) & 15;
-        for (int i = 0; i < ph; i++) __builtin_amdgcn_s_sleep(2);               // 16 x 64 x 2 cycles: up to ~one step
-    }
-    for (int i = tid; i < 2 * N + 4; i += 256) { h_hi[i] = 0u; h_lo[i] = 0u; }         // h(-1) = 0
-    if (tid < 4) { rh_hi[2 * N + tid] = 0u; rh_lo[2 * N + tid] = 0u; }
+    for (int i = tid; i < 2 * N; i += 256) { h_hi[i] = 0u; h_lo[i] = 0u; }             // h(-1) = 0
     for (int i = tid; i < 3 * N; i += 256) bias_lds[i] = bias ? bias[i] : 0.0f;
 
     // ---------------- projection pieces shared by both kinds of wave ----------------
@@ -225,17 +210,6 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 }
             }
         }
-        // ZACC (ABL & 128, an experiment kept for the record): the update gate's weights in accumulation registers, its MFMAs as
-        // asm -- what gru_bar16d.hip needs to make room for its second value per gate.  Here it frees 48 registers the wave
-        // does not need: 1898 instead of 1880 cycles per step (alternating launches, tools/bar16_wg_times.py --ab).
-        constexpr bool ZACC = (ABL & 128) != 0;
-        if constexpr (ZACC) {
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-#pragma unroll
-                for (int i = 0; i < KBS; i++) { wz_hi[p][i] = to_acc_regs(wz_hi[p][i]); wz_lo[p][i] = to_acc_regs(wz_lo[p][i]); }
-            }
-        }
         constexpr int CTA = CT > 0 ? CT : 1;
         half8 pw_hi[CTA][KBLK], pw_lo[CTA][KBLK];
         f32x4 pacc[CTA];
@@ -247,12 +221,10 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 for (int kb = 0; kb < KBLK; kb++) { pw_hi[t][kb] = to_acc_regs(pw_hi[t][kb]); pw_lo[t][kb] = to_acc_regs(pw_lo[t][kb]); }
             }
         }
-        int boff[KBS];
+        // my 16 bytes of K block (w + i) % KBS in MY column group's image (q = 0, 1: hi; q = 2, 3: lo), in dwords
+        int moff[KBS];
 #pragma unroll
-        for (int i = 0; i < KBS; i++) boff[i] = (ZC && q != 0) ? 2 * N : ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
-        int moff[KBS];                                   // MIX: my column group's image (q = 0, 1: hi; q = 2, 3: lo)
-#pragma unroll
-        for (int i = 0; i < KBS; i++) moff[i] = (q >> 1) * IMG + boff[i];
+        for (int i = 0; i < KBS; i++) moff[i] = (q >> 1) * IMG + ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;
         const int wd = ((w * 4 + g) * 4 + c) * 4 + q;                                           // my packed pair, in dwords
         const int n0 = 32 * w + 4 * g + q;                                                      // my neuron of tile 2w (+16: 2w+1)
         const int voff = (g * 4 + c) * 4 + q;                                                   // my element of a vI tile
@@ -283,58 +255,50 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         }
         lds_bar();                                       // vI of group 0 complete
 
-        unsigned long long sacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+        [[maybe_unused]] unsigned long long sacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
         if constexpr (DIAG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
         float hold[2] = {0.0f, 0.0f};
-        // carried from step to step: my own K block of h(s-1) as B operand (read back right after I wrote it) and vI(s)
-        half8 oh = {0, 0, 0, 0, 0, 0, 0, 0}, ol = {0, 0, 0, 0, 0, 0, 0, 0};
+        // carried from step to step: my own K block of h(s-1) as B operand, read back right after I wrote it
+        half8 oh = {0, 0, 0, 0, 0, 0, 0, 0};
+        // registers the asm statements of a step write, kept from step to step (bar16_common.h: pick_mix_kept)
+        float pk0 = 0.0f, pk1 = 0.0f;
+        unsigned sp_hi = 0u, sp_lo = 0u;
         // One step = two intervals, each opened by a barrier; MFMAs are issued in an order that keeps the matrix pipe busy
         // through every LDS round trip and every stretch of gate arithmetic (an MFMA occupies the pipe for 16 cycles and
         // the issuing wave for 4):
-        //   A  [others' h(s-1) visible]  request the other K blocks; r products with my own block (already in registers);
-        //      r products with the others; z products (all but the last block) with sigmoid(r), r*h, split, write, own
-        //      block read back in their shadow
-        //   B  [others' r*h visible]     request the other K blocks, vI(s+1) and the x operands of this step's share of the
+        //   A  [others' h(s-1) visible]  request the other K blocks, then vI(s); r products with my own block (already in
+        //      registers) and this step's share of the projection while they fly; r products with the others, tile 0 first;
+        //      z products (all but the last block) under sigmoid(r), r*h, split, write, own block read back
+        //   B  [others' r*h visible]     request the other K blocks, then the x operands of the next step's share of the
         //      projection; last z block and candidate products with my own block while they fly; candidate products with
-        //      the others, sigmoid(z) in their shadow; projection MFMAs (vI of the NEXT group of four steps, K block `ph`)
-        //      under tanh, blend, split, write, own block read back, store to h_out
-        auto mfma3x2 = [](const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi, const half8 &w1_lo, const half8 &h_hi_, const half8 &h_lo_,
-                          f32x4 &acc0, f32x4 &acc1) {
+        //      the others (tile 0 first), sigmoid(z) in their shadow; tanh, blend, split, write, own block read back, store
+        // The gate arithmetic reads the accumulators from inline asm (pick_mix), where hipcc inserts no wait states, and the
+        // hardware does not interlock a vector read of an MFMA result: seven wait states must lie between a
+        // v_mfma_f32_16x16x32_f16 and the read (tools/probes/mfma_read_hazard_probe.hip).  Every tile's last MFMA is therefore
+        // pinned (sched_barrier) in front of at least eight wait states of other instructions: tile 1's MFMAs for tile 0 --
+        // which also hides their latency behind tile 0's arithmetic -- and tile 0's pick for tile 1.
+        auto mfma2 = [](const half8 &w_hi, const half8 &w_lo, const half8 &bm, f32x4 &acc) {
             if constexpr (ABL & 2) {
-                half8 a = w0_hi, b = h_hi_;
-                asm volatile("" : "+v"(a), "+v"(b), "+v"(acc0), "+v"(acc1));
+                half8 a = w_hi, b = bm;
+                asm volatile("" : "+v"(a), "+v"(b), "+v"(acc));
             } else {
-                ::mfma3x2(w0_hi, w0_lo, w1_hi, w1_lo, h_hi_, h_lo_, acc0, acc1);
+                ::mfma2(w_hi, w_lo, bm, acc);
             }
         };
-        auto mfma2x2 = [](const half8 &w0_hi, const half8 &w0_lo, const half8 &w1_hi, const half8 &w1_lo, const half8 &bm, f32x4 &acc0,
-                          f32x4 &acc1) {
-            if constexpr (ABL & 2) {
-                half8 a = w0_hi, b = bm;
-                asm volatile("" : "+v"(a), "+v"(b), "+v"(acc0), "+v"(acc1));
-            } else {
-                ::mfma2x2(w0_hi, w0_lo, w1_hi, w1_lo, bm, acc0, acc1);
-            }
-        };
-        auto pick = [&](const f32x4 &a) {
-            if constexpr (ZC) return gather4(a);
-            else if constexpr (MIX) return pick_mix(a);
-            else return sel4(a, q);
-        };
+        // wait states in front of tile 0's pick when 2 (KBS - 1) MFMAs of tile 1 (at least two: its own block) follow tile 0's last
+        constexpr int WS0 = KBS > 1 ? (8 - 2 * (KBS - 1) > 2 ? 8 - 2 * (KBS - 1) : 2) : 6;
+        constexpr int WS1 = (8 - WS0 - 4) > 2 ? (8 - WS0 - 4) : 2;         // ... of tile 1's, behind tile 0's pick (WS0 + four reads)
         auto step = [&](auto PHC, const int s, const int G) {
             constexpr int ph = decltype(PHC)::value;
             constexpr bool PROJ = CT > 0 && ph < KBLK;
             // ------------------------------ interval A ------------------------------
-            if constexpr (DIAG) lds_bar(); else if constexpr (MIX) lds_bar_1read<!(ABL & 1)>(); else lds_bar_2reads<!(ABL & 1)>();
+            if constexpr (DIAG) lds_bar(); else lds_bar_1read<!(ABL & 1)>();
             BSTAMP(0)
-            half8 bh[KBS], bl[KBS];                      // MIX: bh = the mixed operands, bl unused
+            half8 bh[KBS];
             bh[0] = oh;
-            bl[0] = ol;
 #pragma unroll
-            for (int i = 1; i < KBS; i++) {
-                if constexpr (MIX) bh[i] = ldH(h_img, moff[i]);
-                else { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
-            }
+            for (int i = 1; i < KBS; i++) bh[i] = ldH(h_img, moff[i]);       // what the step waits for is requested first
+            __builtin_amdgcn_sched_barrier(0);
             // vI(s): complete since the previous barrier at the latest (the service waves use every interval)
             const float *vcur = vbuf + (s % R) * VSTEP + voff;
             float vz[2], vr[2], vc[2];
@@ -346,8 +310,8 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             }
             __builtin_amdgcn_sched_barrier(0);
             f32x4 accR[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accZ[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            if constexpr (MIX) mfma2x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], accR[0], accR[1]);
-            else mfma3x2(wr_hi[0][0], wr_lo[0][0], wr_hi[1][0], wr_lo[1][0], bh[0], bl[0], accR[0], accR[1]);
+            mfma2(wr_hi[0][0], wr_lo[0][0], bh[0], accR[0]);
+            mfma2(wr_hi[1][0], wr_lo[1][0], bh[0], accR[1]);
             if constexpr (PROJ) {                        // my tile of the projection, K block ph: inside the LDS round trip
                 if constexpr (!(ABL & 2)) {
 #pragma unroll
@@ -362,58 +326,43 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (KBS > 1) {
-                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");       // the six vI words may still be on their way
+            BSTAMP(1)
 #pragma unroll
-                for (int i = 1; i < KBS; i++) { keep(bh[i]); if constexpr (!MIX) keep(bl[i]); }
-                __builtin_amdgcn_sched_barrier(0);
-                BSTAMP(1)
+            for (int i = 1; i < KBS; i++) mfma2(wr_hi[0][i], wr_lo[0][i], bh[i], accR[0]);
+            // tile 0 complete BEFORE tile 1's remaining MFMAs are issued (WS0 counts on them).  Instruction selection places an MFMA
+            // anywhere its operands allow, sched_barrier or not; these statements (volatile: they keep their order) hand the
+            // accumulators on, so the MFMAs in front of one and behind the next cannot change sides.
+            asm volatile("" : "+v"(accR[0]));
+            asm volatile("" : "+v"(accR[1]));
 #pragma unroll
-                for (int i = 1; i < KBS; i++) {
-                    if constexpr (MIX) mfma2x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], accR[0], accR[1]);
-                    else mfma3x2(wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i], accR[0], accR[1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int i = 1; i < KBS; i++) mfma2(wr_hi[1][i], wr_lo[1][i], bh[i], accR[1]);
+            asm volatile("" : "+v"(accR[1]));
+            asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]));                 // the z products: behind the r products
+            __builtin_amdgcn_sched_barrier(0);
             BSTAMP(2)
-            if constexpr (ZACC && !(ABL & 2)) {
-                static_for<0, KBS - 1>([&](auto IC) {
-                    constexpr int i = decltype(IC)::value;
-                    if constexpr (MIX) z_block_mfma2<i == 0>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i]);
-                    else z_block_mfma<i == 0>(accZ[0], accZ[1], wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i]);
-                });
-            } else {
 #pragma unroll
-                for (int i = 0; i < KBS - 1; i++) {
-                    if constexpr (MIX) mfma2x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], accZ[0], accZ[1]);
-                    else mfma3x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i], accZ[0], accZ[1]);
-                }
+            for (int i = 0; i < KBS - 1; i++) {
+                mfma2(wz_hi[0][i], wz_lo[0][i], bh[i], accZ[0]);
+                mfma2(wz_hi[1][i], wz_lo[1][i], bh[i], accZ[1]);
             }
-            // pick_mix reads the accumulators from asm, where the compiler keeps no distance to the MFMAs that wrote them: with more
-            // than one K block the z products above lie in between, otherwise let the pipe drain
-            if constexpr (MIX && KBS == 1) mfma_drain2(accR[0], accR[1]);
             float rr[2];
-#pragma unroll
-            for (int p = 0; p < 2; p++) rr[p] = (ABL & 4) ? fmaf(pick(accR[p]), inv_r[p], vr[p]) * 0.01f : sigmoid4(fmaf(pick(accR[p]), inv_r[p], vr[p]));
-            {
-                unsigned hi, lo;
-                split2(rr[0] * hold[0], rr[1] * hold[1], hi, lo);
-                lds_fence();
-                rh_hi[wd] = hi;
-                rh_lo[wd] = lo;
-            }
-            half8 ch[KBS], cl[KBS];                      // MIX: ch = the mixed operands, cl unused
-            if constexpr (MIX) {
-                ch[0] = ldH(rh_img, moff[0]);            // my own block, straight back (LDS executes a wave's operations in order)
-                cl[0] = ch[0];
-            } else {
-                ch[0] = ldH(rh_hi, boff[0]);
-                cl[0] = ldH(rh_lo, boff[0]);
-            }
+            pick_mix_kept<WS0>(accR[0], pk0, accR[1][0]);                     // behind tile 1's MFMAs
+            pick_mix_kept<WS1>(accR[1], pk1, pk0);                            // behind tile 0's pick
+            rr[0] = (ABL & 4) ? fmaf(pk0, inv_r[0], vr[0]) * 0.01f : sigmoid4(fmaf(pk0, inv_r[0], vr[0]));
+            rr[1] = (ABL & 4) ? fmaf(pk1, inv_r[1], vr[1]) * 0.01f : sigmoid4(fmaf(pk1, inv_r[1], vr[1]));
+            split2_kept(rr[0] * hold[0], rr[1] * hold[1], sp_hi, sp_lo);
+            lds_fence();
+            rh_hi[wd] = sp_hi;
+            rh_lo[wd] = sp_lo;
+            // the accumulators stay allocated until here: a value that moved into their registers right behind the picks would
+            // make the compiler pad for the MFMAs it knows wrote them (it counts an asm statement as one wait state)
+            asm volatile("" ::"v"(accR[0]), "v"(accR[1]));
+            half8 ch[KBS];
+            ch[0] = ldH(rh_img, moff[0]);                // my own block, straight back (LDS executes a wave's operations in order)
             lds_fence();
             // one MFMA, then up to three VALU instructions, for as long as both last
 #pragma unroll
-            for (int i = 0; i < 6 * (KBS - 1); i++) {
+            for (int i = 0; i < 4 * (KBS - 1); i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
@@ -422,90 +371,68 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 if (store) { zp[N] = rr[0]; zp[N + 16] = rr[1]; }
             }
             // ------------------------------ interval B ------------------------------
-            if constexpr (DIAG) { BSTAMP(3) lds_bar(); } else if constexpr (MIX) lds_bar_1read<!(ABL & 1)>(); else lds_bar_2reads<!(ABL & 1)>();
+            if constexpr (DIAG) { BSTAMP(3) lds_bar(); } else lds_bar_1read<!(ABL & 1)>();
             BSTAMP(4)
 #pragma unroll
-            for (int i = 1; i < KBS; i++) {
-                if constexpr (MIX) ch[i] = ldH(rh_img, moff[i]);
-                else { ch[i] = ldH(rh_hi, boff[i]); cl[i] = ldH(rh_lo, boff[i]); }
-            }
+            for (int i = 1; i < KBS; i++) ch[i] = ldH(rh_img, moff[i]);
+            __builtin_amdgcn_sched_barrier(0);
             constexpr int nph = (ph + 1) & 3;            // the next step projects K block nph of the group after ITS group
             constexpr bool NPROJ = CT > 0 && nph < KBLK;
-            half8 xh, xl;
             if constexpr (NPROJ) {
                 const int ob = ((G + (ph == 3 ? 2 : 1)) & 1) * OPIMG + poff + 64 * nph;
-                xh = ldH(xop_hi, ob);
-                xl = ldH(xop_lo, ob);
+                pxh = ldH(xop_hi, ob);
+                pxl = ldH(xop_lo, ob);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MIX) {
-                if constexpr (ZACC && !(ABL & 2))
-                    z_block_mfma2<KBS == 1>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1],
-                                            bh[KBS - 1]);
-                else
-                    mfma2x2(wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1], accZ[0], accZ[1]);
-            } else if constexpr (ZACC && !(ABL & 2))
-                z_block_mfma<KBS == 1>(accZ[0], accZ[1], wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1],
-                                       bl[KBS - 1]);
-            else
-                mfma3x2(wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1], bl[KBS - 1], accZ[0],
-                        accZ[1]);
+            mfma2(wz_hi[0][KBS - 1], wz_lo[0][KBS - 1], bh[KBS - 1], accZ[0]);
+            mfma2(wz_hi[1][KBS - 1], wz_lo[1][KBS - 1], bh[KBS - 1], accZ[1]);
             f32x4 accC[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            if constexpr (MIX) mfma2x2(wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], accC[0], accC[1]);
-            else mfma3x2(wc_hi[0][0], wc_lo[0][0], wc_hi[1][0], wc_lo[1][0], ch[0], cl[0], accC[0], accC[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 1; i < KBS; i++) { keep(ch[i]); if constexpr (!MIX) keep(cl[i]); }
-            if constexpr (NPROJ) { keep(xh); keep(xl); pxh = xh; pxl = xl; }
+            mfma2(wc_hi[0][0], wc_lo[0][0], ch[0], accC[0]);
+            mfma2(wc_hi[1][0], wc_lo[1][0], ch[0], accC[1]);
+            // everything below -- sigmoid(z) and the other blocks' candidate products -- behind these eight MFMAs
+            asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]), "+v"(accC[0]), "+v"(accC[1]));
             __builtin_amdgcn_sched_barrier(0);
             BSTAMP(5)
 #pragma unroll
-            for (int i = 1; i < KBS; i++) {
-                if constexpr (MIX) mfma2x2(wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], accC[0], accC[1]);
-                else mfma3x2(wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i], accC[0], accC[1]);
-            }
-            // asm MFMAs wrote the z accumulators: six candidate MFMAs (or the drain) have been issued since the last of them
-            if constexpr (ZACC && !(ABL & 2)) {
-                if constexpr (KBS == 1) { mfma_drain(accZ[0]); mfma_drain(accZ[1]); }
-                else asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]));
-            }
+            for (int i = 1; i < KBS; i++) mfma2(wc_hi[0][i], wc_lo[0][i], ch[i], accC[0]);
+            asm volatile("" : "+v"(accC[0]));                                // as above: tile 0's sum before tile 1's
+            asm volatile("" : "+v"(accC[1]));
+#pragma unroll
+            for (int i = 1; i < KBS; i++) mfma2(wc_hi[1][i], wc_lo[1][i], ch[i], accC[1]);
+            asm volatile("" : "+v"(accC[1]));
+            // sigmoid(z): its last MFMAs were issued in front of the candidate's own-block products (four MFMAs ago at least)
             float zz[2], omz[2], zh[2];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                zz[p] = (ABL & 4) ? fmaf(pick(accZ[p]), inv_z[p], vz[p]) * 0.01f : sigmoid4(fmaf(pick(accZ[p]), inv_z[p], vz[p]));
+                float &pz = p ? pk1 : pk0;
+                pick_mix_kept<4>(accZ[p], pz, accZ[1][0]);
+                zz[p] = (ABL & 4) ? fmaf(pz, inv_z[p], vz[p]) * 0.01f : sigmoid4(fmaf(pz, inv_z[p], vz[p]));
                 omz[p] = 1.0f - zz[p];
                 zh[p] = zz[p] * hold[p];
                 asm volatile("" : "+v"(zh[p]), "+v"(omz[p]));                 // pinned here: not sunk to the blend below
             }
 #pragma unroll
-            for (int i = 0; i < 6 * (KBS - 1); i++) {
+            for (int i = 0; i < 4 * (KBS - 1); i++) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             BSTAMP(6)
-            if constexpr (MIX) mfma_drain2(accC[0], accC[1]);                  // the candidate's last MFMAs were issued just above
             float hn[2];
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                const float hbar = (ABL & 4) ? fmaf(pick(accC[p]), inv_c[p], vc[p]) * 0.01f : tanh5(fmaf(pick(accC[p]), inv_c[p], vc[p]));
-                hn[p] = fmaf(omz[p], hbar, zh[p]);                            // layers.py:1020
-            }
             {
-                unsigned hi, lo;
-                split2(hn[0], hn[1], hi, lo);
-                lds_fence();
-                h_hi[wd] = hi;
-                h_lo[wd] = lo;
+                pick_mix_kept<WS0>(accC[0], pk0, accC[1][0]);
+                pick_mix_kept<WS1>(accC[1], pk1, pk0);
+                const float h0 = (ABL & 4) ? fmaf(pk0, inv_c[0], vc[0]) * 0.01f : tanh5(fmaf(pk0, inv_c[0], vc[0]));
+                const float h1 = (ABL & 4) ? fmaf(pk1, inv_c[1], vc[1]) * 0.01f : tanh5(fmaf(pk1, inv_c[1], vc[1]));
+                hn[0] = fmaf(omz[0], h0, zh[0]);                              // layers.py:1020
+                hn[1] = fmaf(omz[1], h1, zh[1]);
             }
-            if constexpr (MIX) {
-                oh = ldH(h_img, moff[0]);
-                ol = oh;
-            } else {
-                oh = ldH(h_hi, boff[0]);
-                ol = ldH(h_lo, boff[0]);
-            }
+            split2_kept(hn[0], hn[1], sp_hi, sp_lo);
+            lds_fence();
+            h_hi[wd] = sp_hi;
+            h_lo[wd] = sp_lo;
+            asm volatile("" ::"v"(accC[0]), "v"(accC[1]), "v"(accZ[0]), "v"(accZ[1]));
+            oh = ldH(h_img, moff[0]);
             lds_fence();
             if (store) {
                 hp[0] = hn[0];
@@ -525,6 +452,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             if (s + 2 < T) step(ic<2>{}, s + 2, G);
             if (s + 3 < T) step(ic<3>{}, s + 3, G);
         }
+#ifdef SLK_DIAG
         if constexpr (DIAG) {
             if (blockIdx.x == 0 && lane == 0)
                 for (int i = 0; i < 16; i++) slk_dbg_bar16[wave][i] = sacc[i];
@@ -541,6 +469,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 slk_dbg_bar16_wg[blockIdx.x][3] = wg_r0;
             }
         }
+#endif
     } else {
         // =================================================================================================
         // service waves: the rest of the projection; the leader (first of them) also runs the x DMA and splits x
@@ -667,7 +596,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             }
             f32x4 a0 = tile_acc(T0), a1 = {0.f, 0.f, 0.f, 0.f};
             if constexpr (t1 < ST) a1 = tile_acc(ic<t1 < ST ? t1 : 0>{});
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a0), "+v"(a1));
+            mfma_drain2(a0, a1);
             const int st = GS * G1 + pstep;
             float *dst = &vbuf[(st % R) * VSTEP + (kg * 4 + pc) * 4];
             f32x4 o;
@@ -694,7 +623,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         lds_bar();                                       // vI of group 0 complete
 
         // interval k = 0..7 of group G (two per step, each opened by the barrier the chain waves open theirs with)
-        unsigned long long sacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+        [[maybe_unused]] unsigned long long sacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
         if constexpr (DIAG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
         auto interval = [&](auto KC, const int G) {
             constexpr int k = decltype(KC)::value;
@@ -728,10 +657,12 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             if (s + 2 < T) { interval(ic<4>{}, G); interval(ic<5>{}, G); }
             if (s + 3 < T) { interval(ic<6>{}, G); interval(ic<7>{}, G); }
         }
+#ifdef SLK_DIAG
         if constexpr (DIAG) {
             if (blockIdx.x == 0 && lane == 0)
                 for (int i = 0; i < 16; i++) slk_dbg_bar16[wave][i] = sacc[i];
         }
+#endif
     }
 }
 

@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) lstm_mfma_kernel(const float *__restrict_
             const int idx = (j * 4 + wave) * 64 + lane;          // float4 index inside the block image
             const int kk = idx / (4 * ROWF4), r = idx % (4 * ROWF4), c = r / ROWF4, f4 = r % ROWF4;
             const int bc = min(b0 + c, B - 1);
-            const int Tc = lens ? min(max(lens[bc], 1), T) : T;          // ragged batch: see gru_fused.hip
+            const int Tc = lens ? min(max(lens[bc], 1), T) : T;          // ragged batch: include/sloika_amd.h
             const int ss = min(s0 + kk, Tc - 1);
             const int tt = reverse ? Tc - 1 - ss : ss;
             const float *src = vW + ((size_t)tt * B + bc) * (4 * N) + 4 * f4;

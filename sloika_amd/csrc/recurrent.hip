@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(64 * NWAVES, (NWAVES + 3) / 4) gru_mfma_kernel
                 const int idx = piece * 64 + lane;
                 const int kk = idx / (4 * ROWF4), r = idx % (4 * ROWF4), c = r / ROWF4, f4 = r % ROWF4;
                 const int bc = min(b0 + c, B - 1);
-                const int Tc = lens ? min(max(lens[bc], 1), T) : T;      // ragged batch: see gru_fused.hip
+                const int Tc = lens ? min(max(lens[bc], 1), T) : T;      // ragged batch: include/sloika_amd.h
                 const int ss = min(s0 + kk, Tc - 1);
                 const int tt = reverse ? Tc - 1 - ss : ss;
                 const float *src = vI + ((size_t)tt * B + bc) * (3 * N) + 4 * f4;
@@ -351,7 +351,7 @@ extern "C" int slk_gru_recurrent_f32_ex(const float *vI, const float *sW, const 
     return gru_recurrent_entry(vI, sW, sW2, h_out, ldh, T, B, n, reverse, act, gate_act, force_generic, nullptr, stream);
 }
 
-// Ragged batch: lens[b] in [1, T] valid steps of chunk b (see slk_gru_fused_ragged_f32).
+// Ragged batch: lens[b] in [1, T] valid steps of chunk b (include/sloika_amd.h).
 extern "C" int slk_gru_recurrent_ragged_f32(const float *vI, const float *sW, const float *sW2, float *h_out, long ldh,
                                             int T, int B, int n, int reverse, int act, int gate_act, const int32_t *lens,
                                             slk_stream_t stream)
@@ -377,7 +377,8 @@ extern "C" int slk_gru_f32(const float *x, long ldx, const float *iW, const floa
                            int gate_act, void *workspace, size_t workspace_bytes, slk_stream_t stream)
 {
     if (T < 1 || B < 1 || n < 1 || insize < 1) return SLK_ERR_INVALID_ARG;
-    int rc = slk_gru_fused_f32(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse, act, gate_act, stream);
+    // the whole layer in one kernel where an instantiation exists (fp16-split products: float32-grade, not bit-equal to the pair below)
+    int rc = slk_gru_bar16_f32(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse & 1, act, gate_act, nullptr, nullptr, stream);
     if (rc != SLK_ERR_UNSUPPORTED) return rc;
     if (!workspace || workspace_bytes < slk_gru_workspace_bytes(T, B, n)) return SLK_ERR_WORKSPACE;
     float *vI = static_cast<float *>(workspace);
@@ -411,7 +412,7 @@ extern "C" int slk_lstm_recurrent_f32(const float *vW, const float *sW, const fl
     return lstm_recurrent_entry(vW, sW, p, out, ldo, T, B, n, reverse, act, gate_act, nullptr, stream);
 }
 
-// Ragged batch: lens[b] in [1, T] valid steps of chunk b (see slk_gru_fused_ragged_f32).
+// Ragged batch: lens[b] in [1, T] valid steps of chunk b (include/sloika_amd.h).
 extern "C" int slk_lstm_recurrent_ragged_f32(const float *vW, const float *sW, const float *p, float *out, long ldo, int T,
                                              int B, int n, int reverse, int act, int gate_act, const int32_t *lens,
                                              slk_stream_t stream)

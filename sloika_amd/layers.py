@@ -99,28 +99,31 @@ def _stream():
     return D.stream_ptr()
 
 
+#: The package has two switches (set in the shell, read once at import):
+#:   SLOIKA_AMD_EXACT_F32=1    every product in plain float32 MFMA, no fp16 / bf16 splits anywhere: the correctness fallback
+#:                             (two-kernel Gru / Lstm, fp32 softmax projection + decoder on the logits)
+#:   SLOIKA_AMD_DEBUG=a,b,...  comparison runs of one plan against another, never needed for results:
+#:                             recurrent_f32    split projections, but the recurrences in float32 MFMA (csrc/recurrent.hip, lstm_mfma.hip)
+#:                             no_lstm_fused    Lstm as projection GEMM + csrc/lstm_scan16.hip instead of csrc/lstm_fused16.hip
+#:                             no_gru64_share   64-wide Gru layers never two workgroups per CU
+#:                             no_fused_decode  Softmax writes the logits, csrc/decode.hip reads them (pipeline.FUSED_DECODE)
+#:                             bf16_ff_max=N    widest FeedForward output on csrc/gemm_bf16x6.hip
+_DEBUG = dict((t.partition("=")[0], t.partition("=")[2]) for t in os.environ.get("SLOIKA_AMD_DEBUG", "").split(",") if t)
 #: Time-parallel projections (softmax, and the input projections of recurrent layers that have no fused kernel) run on the
 #: FP16 matrix pipe as a 3-term split of every float32 operand (csrc/gemm_rows_f16x3.hip: float32 accumulation, error a few
-#: float32 ulps, ~5x the fp32-MFMA rate).  SLOIKA_AMD_EXACT_F32=1 selects plain fp32 MFMA everywhere.
+#: float32 ulps, ~5x the fp32-MFMA rate) unless SLOIKA_AMD_EXACT_F32=1.
 SPLIT_F16 = os.environ.get("SLOIKA_AMD_EXACT_F32", "0") != "1"
-
-
-#: The recurrent products of a fused Gru layer also run as 3-term fp16 splits unless SLOIKA_AMD_RECURRENT_F32=1 asks for the
-#: exact-fp32 recurrence of csrc/gru_fused.hip (SLOIKA_AMD_EXACT_F32=1 implies it).
-RECURRENT_F16 = os.environ.get("SLOIKA_AMD_RECURRENT_F32", "0") != "1"
-#: Execution plan of that kernel: "bar" = four waves stepping through barriers (csrc/gru_bar16.hip, the faster one),
-#: "flags" = eight waves coupled by LDS progress counters (csrc/gru_fused16.hip).  Same arithmetic, same contract.
-GRU_PLAN = os.environ.get("SLOIKA_AMD_GRU_PLAN", "bar")
+#: ... and so do the recurrent products (csrc/gru_bar16*.hip, gru_scan16.hip, lstm_fused16.hip, lstm_scan16.hip).
+RECURRENT_F16 = "recurrent_f32" not in _DEBUG
 #: widest FeedForward output that takes csrc/gemm_bf16x6.hip (128 -> 64: 0.78 against 1.10 ms, 192 -> 96: 0.29 against 0.39; 192 -> 128
-#: as one 128-column block: 1.69 against 1.72 ms, i.e. no gain, so it stays with the row kernel); SLOIKA_AMD_BF16_FF_MAX for comparisons
-BF16_FF_MAX = int(os.environ.get("SLOIKA_AMD_BF16_FF_MAX", "96"))
+#: as one 128-column block: 1.69 against 1.72 ms, i.e. no gain, so it stays with the row kernel)
+BF16_FF_MAX = int(_DEBUG.get("bf16_ff_max") or 96)
 #: Gru layers up to 64 wide run their four-chunk workgroups two per CU where one per CU does not hold what is meant to run together (the
-#: directions of a birnn at B = 1024: `baseline_gru` 16.9 -> 14.9 ms per step against the eight-chunk plan on half the chip each);
-#: SLOIKA_AMD_GRU64_SHARE=0 switches it off for comparisons.
-GRU64_SHARE = os.environ.get("SLOIKA_AMD_GRU64_SHARE", "1") != "0"
+#: directions of a birnn at B = 1024: `baseline_gru` 16.9 -> 14.9 ms per step against the eight-chunk plan on half the chip each)
+GRU64_SHARE = "no_gru64_share" not in _DEBUG
 #: An Lstm layer of up to 64 units and 64 inputs runs as ONE kernel that computes its input projection inside the scan
-#: (csrc/lstm_fused16.hip); SLOIKA_AMD_LSTM_FUSED=0 keeps projection GEMM + scan (csrc/lstm_scan16.hip) for comparison.
-LSTM_FUSED = os.environ.get("SLOIKA_AMD_LSTM_FUSED", "1") != "0"
+#: (csrc/lstm_fused16.hip)
+LSTM_FUSED = "no_lstm_fused" not in _DEBUG
 
 
 class _PlanHints(__import__("threading").local):
@@ -155,12 +158,50 @@ def _gru_plan_for(B, share, ncu, per_cu=1):
     return 3 if ((B + 15) // 16) * share <= ncu * per_cu else 0
 
 
+#: (insize, size) of the Gru layers that run as ONE kernel, projection included (the instantiations of csrc/gru_bar16.hip,
+#: gru_bar16d.hip, gru_bar16q.hip: every Gru of models/ up to 96 wide)
+GRU_LAYER_SHAPES = frozenset([(96, 96), (64, 64), (32, 96), (128, 96), (64, 96), (48, 32), (16, 64)])
+#: sizes of the fp16-split scan behind a projection GEMM (csrc/gru_scan1t.hip: 112, 128; gru_scan16.hip: 144)
+GRU_SCAN16_SIZES = frozenset([112, 128, 144])
+
+
+def gru_plan(insize, size, fun, gatefun):
+    """THE plan table of a Gru layer: which kernels run it.  (How many chunks a workgroup of the "layer" plan takes is a matter
+    of batch size and batches in flight: _gru_plan_for.)
+
+      "layer"   one persistent kernel for the whole layer           slk_gru_bar16_f32
+      "scan16"  projection GEMM + scan on the fp16 split             slk_gru_scan16_f32
+      "scan"    projection GEMM + float32-MFMA / portable scan       slk_gru_recurrent_f32, slk_gru_recurrent_ragged_f32
+    """
+    tanh_sigmoid = fun is activation.tanh and gatefun is activation.sigmoid
+    if SPLIT_F16 and RECURRENT_F16 and tanh_sigmoid:
+        if (insize, size) in GRU_LAYER_SHAPES:
+            return "layer"
+        if size in GRU_SCAN16_SIZES:
+            return "scan16"
+    return "scan"
+
+
+#: widest Lstm on the fp16-split scan (csrc/lstm_scan16.hip: every multiple of 16 up to this, zero-padded to the next instantiation)
+LSTM_SCAN16_MAX = 128
+
+
+def lstm_plan(insize, size, fun, gatefun):
+    """The plan table of an Lstm layer, as gru_plan: "layer" = slk_lstm_fused16_f32 (size and insize up to 64: every Lstm of
+    models/), "scan16" = projection GEMM + slk_lstm_scan16_f32, "scan" = projection GEMM + slk_lstm_recurrent*_f32."""
+    tanh_sigmoid = fun is activation.tanh and gatefun is activation.sigmoid
+    if SPLIT_F16 and RECURRENT_F16 and tanh_sigmoid and size % 16 == 0:
+        if LSTM_FUSED and size <= 64 and insize <= 64 and insize % 4 == 0:
+            return "layer"
+        if size <= LSTM_SCAN16_MAX:
+            return "scan16"
+    return "scan"
+
+
 def gru_f16_entry():
-    """The C-ABI entry of the fp16-split fused Gru kernel selected by GRU_PLAN."""
-    if GRU_PLAN not in ("bar", "flags"):
-        raise ValueError("SLOIKA_AMD_GRU_PLAN must be 'bar' or 'flags'")
-    L = _lib.lib()
-    return L.slk_gru_bar16_f32 if GRU_PLAN == "bar" else L.slk_gru_fused16_f32
+    """The C-ABI entry of the whole-layer Gru kernel (projection and recurrence as fp16 splits: csrc/gru_bar16.hip)."""
+    return _lib.lib().slk_gru_bar16_f32
+
 
 def _derived_cache(owner, attr, params, build):
     """Device tensors derived from the Shared leaves `params` (fp16 splits, re-laid-out weights, zero-padded twins), kept on
@@ -508,7 +549,7 @@ class Softmax(Layer):
 
     #: evaluate the projection on the FP16 matrix pipe with operands split in two halves (x.w = hi.hi + hi.lo + lo.hi,
     #: float32 accumulation; error a few float32 ulps, ~5x the fp32-MFMA rate).  Set False for plain fp32 MFMA.
-    split_f16 = os.environ.get("SLOIKA_AMD_EXACT_F32", "0") != "1"
+    split_f16 = SPLIT_F16
 
     def _split_weights(self):
         """fp16 hi/lo parts of W and the inverse row scales on the device, re-made whenever W changes."""
@@ -793,8 +834,7 @@ class Lstm(RNN):
 
     def takes_fused_kernel(self):
         """Whether csrc/lstm_fused16.hip (projection inside the scan) applies to this layer's shape."""
-        return (SPLIT_F16 and RECURRENT_F16 and LSTM_FUSED and self.size <= 64 and self.size % 16 == 0 and self.insize <= 64
-                and self.insize % 4 == 0 and self.fun is activation.tanh and self.gatefun is activation.sigmoid)
+        return lstm_plan(self.insize, self.size, self.fun, self.gatefun) == "layer"
 
     def _forward(self, x, out, reverse):
         import torch
@@ -803,41 +843,42 @@ class Lstm(RNN):
         L = _lib.lib()
         n, rows = self.size, T * B
         lens = ragged.current if reverse else None       # a reversed scan starts every chunk at its own last step
-        if self.takes_fused_kernel():
+        lens_p = None if lens is None else lens.data_ptr()
+        act, gact = activation.act_id(self.fun), activation.act_id(self.gatefun)
+        plan = lstm_plan(self.insize, n, self.fun, self.gatefun)
+        if plan == "layer":
             # the whole layer in one kernel (csrc/lstm_fused16.hip): the projection is computed inside the scan and never written
             with profiler.region("lstm_fused", 8.0 * rows * n * (self.insize + n), 4.0 * rows * (self.insize + n),
                                  f16x3_flops=8.0 * rows * n * self.insize, f16x2_flops=8.0 * rows * n * n) as reg:
                 rc = L.slk_lstm_fused16_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(), self.sW.dev().data_ptr(),
                                             self.b.dev().data_ptr(), self.p.dev().data_ptr(), y.data_ptr(), _row_stride(y), T, B,
-                                            self.insize, n, int(reverse), activation.act_id(self.fun),
-                                            activation.act_id(self.gatefun), None if lens is None else lens.data_ptr(), _stream())
+                                            self.insize, n, int(reverse), act, gact, lens_p, _stream())
                 if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
                     reg.cancel()
-            if rc != _lib.SLK_ERR_UNSUPPORTED:
+            if rc != _lib.SLK_ERR_UNSUPPORTED:                 # (unsupported: rows of x that are not 16-byte aligned)
                 _lib.check(rc, "Lstm")
                 return y
+            plan = "scan16"
         nbytes = L.slk_lstm_workspace_bytes(T, B, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         # the two halves of slk_lstm_f32, timed separately: projection GEMM into the workspace, then the recurrence
         _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 4 * n, "lstm_input_gemm", "Lstm")
         with profiler.region("lstm_recurrent", 8.0 * rows * n * n, 4.0 * rows * 5 * n):
             rc = _lib.SLK_ERR_UNSUPPORTED
-            if SPLIT_F16 and RECURRENT_F16:
-                # the recurrent product as a 3-term fp16 split on the barrier-stepped plan (csrc/lstm_scan16.hip: n <= 128)
+            if plan == "scan16":
+                # the recurrent product as an fp16 split on the barrier-stepped plan (csrc/lstm_scan16.hip; unsupported: a
+                # projection of 4 GiB or more, its lanes keep 32-bit offsets)
                 rc = L.slk_lstm_scan16_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(), y.data_ptr(),
-                                           _row_stride(y), T, B, n, int(reverse), activation.act_id(self.fun),
-                                           activation.act_id(self.gatefun), None if lens is None else lens.data_ptr(), _stream())
+                                           _row_stride(y), T, B, n, int(reverse), act, gact, lens_p, _stream())
             if rc != _lib.SLK_ERR_UNSUPPORTED:
                 pass
-            elif lens is None:
+            elif lens is None:                             # float32 MFMA (csrc/lstm_mfma.hip), portable kernel beyond its sizes
                 rc = L.slk_lstm_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(),
-                                              y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
-                                              activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
+                                              y.data_ptr(), _row_stride(y), T, B, n, int(reverse), act, gact, _stream())
             else:
                 rc = L.slk_lstm_recurrent_ragged_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.p.dev().data_ptr(),
-                                                     y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
-                                                     activation.act_id(self.fun), activation.act_id(self.gatefun),
-                                                     lens.data_ptr(), _stream())
+                                                     y.data_ptr(), _row_stride(y), T, B, n, int(reverse), act, gact,
+                                                     lens_p, _stream())
         _lib.check(rc, "Lstm")
         return y
 
@@ -959,70 +1000,48 @@ class Gru(RNN):
         lens = ragged.current if reverse else None
         if lens is not None and (lens.numel() != B or lens.device != x.device):
             raise ValueError("ragged lengths do not match the batch")
-        # one persistent kernel (projection waves + recurrent waves) where an instantiation exists (its projection half
-        # runs as an fp16 3-term split, so SLOIKA_AMD_EXACT_F32=1 takes the two-kernel all-fp32 path instead) ...
-        if SPLIT_F16:
-            rc = _lib.SLK_ERR_UNSUPPORTED
-            if RECURRENT_F16:
-                # projection AND recurrence as 3-term fp16 splits (csrc/gru_bar16.hip / gru_fused16.hip)
-                # (roofline bookkeeping: up to eight chunks per workgroup the recurrent products take two MFMAs each, the
-                #  projection three; the sixteen-chunk plan three everywhere -- csrc/gru_bar16.hip bar16_auto_plan)
-                bits = self._plan_bits(x, B) if GRU_PLAN == "bar" else 3
-                ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
-                two_term = GRU_PLAN == "bar" and (bits in (1, 2, 5) or (bits == 0 and (B + 7) // 8 <= ncu))
-                with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
-                                     f16x3_flops=6.0 * rows * n * (self.insize if two_term else n + self.insize),
-                                     f16x2_flops=6.0 * rows * n * n if two_term else 0.0) as reg:
-                    rc = gru_f16_entry()(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
-                                         self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
-                                         y.data_ptr(), _row_stride(y), T, B, self.insize, n,
-                                         int(reverse) | ((bits << 8) if GRU_PLAN == "bar" else 0),
-                                         activation.act_id(self.fun), activation.act_id(self.gatefun),
-                                         None if lens is None else lens.data_ptr(), None, _stream())
-                    if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
-                        reg.cancel()
-            if rc == _lib.SLK_ERR_UNSUPPORTED:
-                # fp32 recurrence (v_mfma_f32_4x4x1), projection as a 3-term fp16 split (csrc/gru_fused.hip)
-                with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
-                                     f16x3_flops=6.0 * rows * n * self.insize) as reg:
-                    if lens is None:
-                        rc = L.slk_gru_fused_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
-                                                 self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), self.b.dev().data_ptr(),
-                                                 y.data_ptr(), _row_stride(y), T, B, self.insize, n, int(reverse),
-                                                 activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
-                    else:
-                        rc = L.slk_gru_fused_ragged_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(),
-                                                        self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
-                                                        self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), T, B,
-                                                        self.insize, n, int(reverse), activation.act_id(self.fun),
-                                                        activation.act_id(self.gatefun), lens.data_ptr(), _stream())
-                    if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
-                        reg.cancel()
-            if rc != _lib.SLK_ERR_UNSUPPORTED:
+        lens_p = None if lens is None else lens.data_ptr()
+        act, gact = activation.act_id(self.fun), activation.act_id(self.gatefun)
+        plan = gru_plan(self.insize, n, self.fun, self.gatefun)
+        if plan == "layer":
+            # projection AND recurrence in one persistent kernel (csrc/gru_bar16.hip; eight / sixteen chunks per workgroup:
+            # gru_bar16d.hip / gru_bar16q.hip).  Roofline bookkeeping: up to eight chunks per workgroup the recurrent products
+            # take two MFMAs each, the projection three; the sixteen-chunk plan three everywhere (bar16_auto_plan)
+            bits = self._plan_bits(x, B)
+            ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+            two_term = bits in (1, 2, 5) or (bits == 0 and (B + 7) // 8 <= ncu)
+            with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
+                                 f16x3_flops=6.0 * rows * n * (self.insize if two_term else n + self.insize),
+                                 f16x2_flops=6.0 * rows * n * n if two_term else 0.0) as reg:
+                rc = L.slk_gru_bar16_f32(x.data_ptr(), _row_stride(x), self.iW.dev().data_ptr(), self.sW.dev().data_ptr(),
+                                         self.sW2.dev().data_ptr(), self.b.dev().data_ptr(), y.data_ptr(), _row_stride(y), T, B,
+                                         self.insize, n, int(reverse) | (bits << 8), act, gact, lens_p, None, _stream())
+                if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
+                    reg.cancel()
+            if rc != _lib.SLK_ERR_UNSUPPORTED:                 # (unsupported: rows of x that are not 16-byte aligned)
                 _lib.check(rc, "Gru")
                 return y
-        # ... otherwise projection GEMM into a workspace, then the recurrence kernel
+            plan = "scan"
+        # projection GEMM into a workspace, then the scan
         nbytes = L.slk_gru_workspace_bytes(T, B, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 3 * n, "gru_input_gemm", "Gru")
         with profiler.region("gru_recurrent", 6.0 * rows * n * n, 4.0 * rows * 4 * n):
             rc = _lib.SLK_ERR_UNSUPPORTED
-            if SPLIT_F16 and RECURRENT_F16:
-                # n = 112 / 128: the barrier-stepped scan on the fp16 split (csrc/gru_scan16.hip)
+            if plan == "scan16":
+                # n = 112 / 128 / 144: the barrier-stepped scan on the fp16 split (csrc/gru_scan16.hip, gru_scan1t.hip; unsupported:
+                # a projection of 4 GiB or more, its lanes keep 32-bit offsets)
                 rc = L.slk_gru_scan16_f32(ws.data_ptr(), 3 * n, self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(), y.data_ptr(),
-                                          _row_stride(y), T, B, n, int(reverse), activation.act_id(self.fun),
-                                          activation.act_id(self.gatefun), None if lens is None else lens.data_ptr(), _stream())
+                                          _row_stride(y), T, B, n, int(reverse), act, gact, lens_p, _stream())
             if rc != _lib.SLK_ERR_UNSUPPORTED:
                 pass
-            elif lens is None:
+            elif lens is None:                             # float32 MFMA (csrc/recurrent.hip), portable kernel beyond n = 144
                 rc = L.slk_gru_recurrent_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
-                                             y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
-                                             activation.act_id(self.fun), activation.act_id(self.gatefun), _stream())
+                                             y.data_ptr(), _row_stride(y), T, B, n, int(reverse), act, gact, _stream())
             else:
                 rc = L.slk_gru_recurrent_ragged_f32(ws.data_ptr(), self.sW.dev().data_ptr(), self.sW2.dev().data_ptr(),
-                                                    y.data_ptr(), _row_stride(y), T, B, n, int(reverse),
-                                                    activation.act_id(self.fun), activation.act_id(self.gatefun),
-                                                    lens.data_ptr(), _stream())
+                                                    y.data_ptr(), _row_stride(y), T, B, n, int(reverse), act, gact,
+                                                    lens_p, _stream())
         _lib.check(rc, "Gru")
         return y
 
@@ -1166,7 +1185,7 @@ class Parallel(Layer):
             # time for twice the chunks) may still let the directions share the chip: B = 1024, two directions -> 2 x 128
             grus = all(isinstance(l.layer if isinstance(l, Reverse) else l, Gru) for l in self.layers)
             plan = _gru_plan_for(B, share, ncu, 2 if grus and all(max(l.size, l.insize) <= 64 for l in inners) else 1)
-            if not (grus and SPLIT_F16 and RECURRENT_F16 and GRU_PLAN == "bar" and plan):
+            if not (grus and SPLIT_F16 and RECURRENT_F16 and plan):
                 return None
             self._side_plan = plan
         # side streams belong to the stream the caller runs on: batches in flight on different streams must not meet on one

@@ -16,7 +16,7 @@ from . import _lib, batch, decode, layers
 #: decode straight from the Softmax layer's input (csrc/softmax_viterbi.hip: projection, softmax, prepare_post, log and the
 #: Viterbi forward pass in one kernel, the logits never written) where that kernel applies; SLOIKA_AMD_FUSED_DECODE=0 keeps the
 #: projection kernel + decoder pair
-FUSED_DECODE = os.environ.get("SLOIKA_AMD_FUSED_DECODE", "1") != "0"
+FUSED_DECODE = "no_fused_decode" not in layers._DEBUG
 
 
 class Basecaller(object):

@@ -460,7 +460,7 @@ class TrainingStep(object):
         zr = torch.empty((T * B, 2 * n), dtype=torch.float32, device=x.device)
         M = T * B
         rc = _lib.SLK_ERR_UNSUPPORTED
-        if layers.RECURRENT_F16:            # projection and recurrence as fp16 splits (csrc/gru_bar16.hip / gru_fused16.hip)
+        if layers.RECURRENT_F16:            # projection and recurrence as fp16 splits (csrc/gru_bar16.hip)
             with profiler.region("gru_fused", 6.0 * M * n * (n + layer.insize), 4.0 * M * (layer.insize + 3 * n),
                                  f16x3_flops=6.0 * M * n * (n + layer.insize)) as reg:
                 rc = layers.gru_f16_entry()(x.data_ptr(), layers._row_stride(x), layer.iW.dev().data_ptr(),
@@ -468,16 +468,6 @@ class TrainingStep(object):
                                             layer.b.dev().data_ptr(), y.data_ptr(), n, T, B, layer.insize, n, int(rev),
                                             activation.act_id(layer.fun), activation.act_id(layer.gatefun), None,
                                             zr.data_ptr(), layers._stream())
-                if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
-                    reg.cancel()
-        if rc == _lib.SLK_ERR_UNSUPPORTED:
-            with profiler.region("gru_fused", 6.0 * M * n * (n + layer.insize), 4.0 * M * (layer.insize + 3 * n),
-                                 f16x3_flops=6.0 * M * n * layer.insize) as reg:
-                rc = _lib.lib().slk_gru_fused_train_f32(x.data_ptr(), layers._row_stride(x), layer.iW.dev().data_ptr(),
-                                                        layer.sW.dev().data_ptr(), layer.sW2.dev().data_ptr(),
-                                                        layer.b.dev().data_ptr(), y.data_ptr(), n, zr.data_ptr(), T, B,
-                                                        layer.insize, n, int(rev), activation.act_id(layer.fun),
-                                                        activation.act_id(layer.gatefun), layers._stream())
                 if rc == _lib.SLK_ERR_UNSUPPORTED and reg is not None:
                     reg.cancel()
         if rc == _lib.SLK_ERR_UNSUPPORTED:

@@ -1,4 +1,4 @@
-"""csrc/gru_fused16.hip -- whole Gru layer with projection AND recurrence as 3-term fp16 splits -- through the C ABI, against
+"""csrc/gru_bar16.hip, gru_bar16d.hip, gru_bar16q.hip -- whole Gru layer with projection AND recurrence as fp16 splits -- through the C ABI, against
 the oracle (float32 C port, itself pinned to the reference's layers.py by tests/test_oracle_reference_layers.py)."""
 import numpy as np
 import pytest
@@ -18,14 +18,14 @@ def _params(rs, I, n, bias=True, scale=1.0):
     return iW, sW, sW2, b
 
 
-#: the execution plans of the same arithmetic: LDS progress counters (gru_fused16.hip), barrier-stepped with four chunks per
+#: the execution plans of the same arithmetic: barrier-stepped with four chunks per
 #: workgroup (gru_bar16.hip) and with eight (gru_bar16d.hip, what batches beyond one workgroup per CU run: forced here through
 #: bits 8-9 of `reverse` so that the small cases exercise it too) and with sixteen (gru_bar16q.hip, batches beyond eight chunks per CU)
 ENTRY = "slk_gru_bar16_f32"
 PLAN = 0
 
 
-@pytest.fixture(autouse=True, params=["slk_gru_bar16_f32", "slk_gru_fused16_f32", "slk_gru_bar16_f32:8", "slk_gru_bar16_f32:16"])
+@pytest.fixture(autouse=True, params=["slk_gru_bar16_f32", "slk_gru_bar16_f32:8", "slk_gru_bar16_f32:16"])
 def _entry(request):
     global ENTRY, PLAN
     ENTRY, _, chunks = request.param.partition(":")
@@ -41,7 +41,7 @@ def _call(L, x, ldx, iW, sW, sW2, b, y, ldy, T, B, I, n, reverse, lens=None, zr=
 
 @pytest.mark.parametrize("I,n", SHAPES)
 @pytest.mark.parametrize("T,B,reverse", [(23, 9, False), (8, 4, True), (3, 2, False), (1, 1, True), (41, 5, True)])
-def test_fused16_vs_oracle(oracle, I, n, T, B, reverse):
+def test_bar16_vs_oracle(oracle, I, n, T, B, reverse):
     torch = need_gpu()
     from sloika_amd import _lib
     L = _lib.lib()
@@ -65,7 +65,7 @@ def test_fused16_vs_oracle(oracle, I, n, T, B, reverse):
 
 
 @pytest.mark.parametrize("xmag", [1e-7, 1e-3, 1e3, 1e5, 3e7])
-def test_fused16_input_magnitudes(oracle, xmag):
+def test_bar16_input_magnitudes(oracle, xmag):
     """The fp16 halves of x AND of every weight row are taken AFTER a per-row power-of-two scaling: inputs and weights far
     outside fp16's range (65504) or below its normal range (6e-5) keep float32-grade accuracy.  iW is scaled inversely to x
     (up to 7e5, down to 2e-9) so that the gates are exercised, not saturated."""
@@ -87,7 +87,7 @@ def test_fused16_input_magnitudes(oracle, xmag):
     assert np.abs(out - ref).max() < 5e-5, np.abs(out - ref).max()
 
 
-def test_fused16_recurrent_weight_rows_of_any_magnitude(oracle):
+def test_bar16_recurrent_weight_rows_of_any_magnitude(oracle):
     """Rows of sW / sW2 whose magnitudes differ by many orders (one neuron's incoming weights ~1e4, another's ~1e-6)."""
     torch = need_gpu()
     from sloika_amd import _lib
@@ -107,7 +107,7 @@ def test_fused16_recurrent_weight_rows_of_any_magnitude(oracle):
     assert np.abs(out - ref).max() < TOL
 
 
-def test_fused16_trained_weight_magnitudes(oracle):
+def test_bar16_trained_weight_magnitudes(oracle):
     """|w| up to 6 with saturating gates, as in models/pretrained.pkl.  Few steps: recurrent weights this large make the
     map chaotic, and over dozens of steps ANY two float32 evaluations (the oracle's C port and numpy included) drift apart
     by more than the layer tolerance, which would test the dynamics, not the kernel."""
@@ -133,7 +133,7 @@ def test_fused16_trained_weight_magnitudes(oracle):
 
 
 @pytest.mark.parametrize("I,n", [(96, 96), (64, 64)])
-def test_fused16_ragged_and_saved_gates(oracle, I, n):
+def test_bar16_ragged_and_saved_gates(oracle, I, n):
     """Ragged batch (each chunk must equal the call on the chunk alone at its own length, reversed scans included) and the
     training variant that also stores the activated gates z | r."""
     torch = need_gpu()
@@ -177,7 +177,7 @@ def test_fused16_ragged_and_saved_gates(oracle, I, n):
 
 
 @pytest.mark.parametrize("I,n", [(96, 96), (128, 96), (64, 64)])
-def test_fused16_agrees_with_exact_kernels_under_load(I, n):
+def test_bar16_agrees_with_exact_kernels_under_load(I, n):
     """Race screen: every CU busy, hundreds of steps (dozens of LDS ring turnovers), repeated: any operand image or ring
     slot reused too early shows up as a large error in some chunk."""
     torch = need_gpu()
@@ -204,7 +204,7 @@ def test_fused16_agrees_with_exact_kernels_under_load(I, n):
             assert err < 5e-5, "reverse=%d rep=%d: %g" % (reverse, rep, err)
 
 
-def test_fused16_unsupported_shapes():
+def test_bar16_unsupported_shapes():
     need_gpu()
     from sloika_amd import _lib
     L = _lib.lib()
@@ -232,7 +232,7 @@ def test_layer_with_weights_outside_fp16_range(oracle):
 
 
 @pytest.mark.parametrize("I,n", [(96, 96), (128, 96), (16, 64)])
-def test_fused16_launches_are_deterministic(I, n):
+def test_bar16_launches_are_deterministic(I, n):
     """Race screen of a different kind: a kernel whose waves exchange data through LDS without enough ordering gives different
     bits from launch to launch.  Every launch of the same inputs -- full-size batch, ragged lengths, both directions, with the
     saved gates -- must reproduce the first one exactly."""

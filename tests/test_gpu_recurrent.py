@@ -149,32 +149,34 @@ def test_layer_input_validation():
 
 @pytest.mark.parametrize("I,n", [(96, 96), (64, 64), (32, 96), (64, 96), (16, 16), (48, 32), (16, 64)])
 @pytest.mark.parametrize("T,B,reverse", [(23, 9, False), (8, 4, True), (3, 2, False), (1, 1, True), (41, 5, True)])
-def test_gru_fused_layer_kernel(oracle, I, n, T, B, reverse):
-    """Projection + recurrence in one persistent kernel (csrc/gru_fused.hip) vs the oracle."""
+def test_gru_layer_entry(oracle, I, n, T, B, reverse):
+    """slk_gru_f32 -- the whole layer in one persistent kernel where an instantiation exists (csrc/gru_bar16.hip), projection
+    GEMM + scan otherwise (16 -> 16) -- vs the oracle."""
     torch = need_gpu()
     from sloika_amd import _lib
+    L = _lib.lib()
+    ws = torch.empty(L.slk_gru_workspace_bytes(T, B, n), dtype=torch.uint8, device="cuda")
     rs = np.random.RandomState(I + n + T)
     iW, sW, sW2, b = _gru_params(rs, I, n, scale=2.0)
     x = rs.normal(size=(T, B, I)).astype(np.float32)
     ref = oracle.gru(x, iW, sW, sW2, b, reverse=reverse)
     xd, iWd, sWd, sW2d, bd = dev(x), dev(iW), dev(sW), dev(sW2), dev(b)
     y = torch.full((T, B, n), np.nan, dtype=torch.float32, device="cuda")
-    rc = _lib.lib().slk_gru_fused_f32(xd.data_ptr(), I, iWd.data_ptr(), sWd.data_ptr(), sW2d.data_ptr(), bd.data_ptr(),
-                                      y.data_ptr(), n, T, B, I, n, int(reverse), 1, 2, stream())
+    rc = L.slk_gru_f32(xd.data_ptr(), I, iWd.data_ptr(), sWd.data_ptr(), sW2d.data_ptr(), bd.data_ptr(),
+                       y.data_ptr(), n, T, B, I, n, int(reverse), 1, 2, ws.data_ptr(), ws.numel(), stream())
     assert rc == 0
     np.testing.assert_allclose(y.cpu().numpy(), ref, atol=TOL)
     # no bias + strided input/output rows (slices of wider tensors)
     xw = torch.zeros((T, B, I + 16), device="cuda")
     xw[:, :, 8:8 + I] = xd
     yw = torch.full((T, B, n + 8), -5.0, device="cuda")
-    rc = _lib.lib().slk_gru_fused_f32(xw.data_ptr() + 8 * 4, I + 16, iWd.data_ptr(), sWd.data_ptr(), sW2d.data_ptr(), None,
-                                      yw.data_ptr() + 4 * 4, n + 8, T, B, I, n, int(reverse), 1, 2, stream())
-    assert rc in (0, _lib.SLK_ERR_UNSUPPORTED)
-    if rc == 0:
-        ref_nb = oracle.gru(x, iW, sW, sW2, None, reverse=reverse)
-        out = yw.cpu().numpy()
-        np.testing.assert_allclose(out[:, :, 4:4 + n], ref_nb, atol=TOL)
-        assert (out[:, :, :4] == -5.0).all() and (out[:, :, 4 + n:] == -5.0).all()
+    rc = L.slk_gru_f32(xw.data_ptr() + 8 * 4, I + 16, iWd.data_ptr(), sWd.data_ptr(), sW2d.data_ptr(), None,
+                       yw.data_ptr() + 4 * 4, n + 8, T, B, I, n, int(reverse), 1, 2, ws.data_ptr(), ws.numel(), stream())
+    assert rc == 0
+    ref_nb = oracle.gru(x, iW, sW, sW2, None, reverse=reverse)
+    out = yw.cpu().numpy()
+    np.testing.assert_allclose(out[:, :, 4:4 + n], ref_nb, atol=TOL)
+    assert (out[:, :, :4] == -5.0).all() and (out[:, :, 4 + n:] == -5.0).all()
 
 
 @pytest.mark.parametrize("I,n", [(96, 96), (128, 96), (112, 112), (64, 64), (112, 144), (128, 128)])
@@ -206,21 +208,21 @@ def test_gru_kernels_agree_under_load(I, n):
             err = (y - ref).abs().max().item()
             assert err < TOL, "recurrent kernel, reverse=%d rep=%d: %g" % (reverse, rep, err)
             y.fill_(float("nan"))
-            rc = L.slk_gru_fused_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), b.data_ptr(),
-                                     y.data_ptr(), n, T, B, I, n, reverse, 1, 2, stream())
+            rc = L.slk_gru_bar16_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), b.data_ptr(),
+                                     y.data_ptr(), n, T, B, I, n, reverse, 1, 2, None, None, stream())
             assert rc in (0, _lib.SLK_ERR_UNSUPPORTED)
             if rc == 0:
                 err = (y - ref).abs().max().item()
                 assert err < TOL, "fused kernel, reverse=%d rep=%d: %g" % (reverse, rep, err)
 
 
-def test_gru_fused_unsupported_falls_back(oracle):
+def test_gru_layer_kernel_unsupported_shapes(oracle):
     need_gpu()
     from sloika_amd import _lib
     L = _lib.lib()
     z = dev(np.zeros((4, 4), dtype=np.float32))
-    # sizes with no fused instantiation report UNSUPPORTED (slk_gru_f32 then takes the two-kernel path)
-    assert L.slk_gru_fused_f32(z.data_ptr(), 7, z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), 5, 1, 1, 7, 5,
-                               0, 1, 2, stream()) == _lib.SLK_ERR_UNSUPPORTED
-    assert L.slk_gru_fused_f32(z.data_ptr(), 96, z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), 96, 1, 1, 96,
-                               96, 0, 3, 2, stream()) == _lib.SLK_ERR_UNSUPPORTED
+    # sizes and activations with no instantiation report UNSUPPORTED (slk_gru_f32 then takes the two-kernel path)
+    assert L.slk_gru_bar16_f32(z.data_ptr(), 7, z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), 5, 1, 1, 7, 5,
+                               0, 1, 2, None, None, stream()) == _lib.SLK_ERR_UNSUPPORTED
+    assert L.slk_gru_bar16_f32(z.data_ptr(), 96, z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), 96, 1, 1, 96,
+                               96, 0, 3, 2, None, None, stream()) == _lib.SLK_ERR_UNSUPPORTED

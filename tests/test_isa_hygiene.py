@@ -17,12 +17,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
                                        ("gemm_rows_f16x3.hip", []), ("lstm_scan16.hip", []), ("gru_bar16.hip", []),
                                        ("gru_bar16d.hip", []), ("gru_bar16q.hip", []), ("gru_scan16.hip", []), ("lstm_bwd16.hip", []),
                                        ("lstm_fused16.hip", []), ("gru_bwd16.hip", []),
-                                       ("gru_scan1t.hip", [])])
+                                       ("gru_scan1t.hip", []), ("gemm_bf16x6.hip", []), ("train.hip", []),
+                                       ("softmax_viterbi.hip", ["-DSV_ONLY_KS=7"]), ("softmax_viterbi.hip", ["-DSV_ONLY_KS=8"])])
 def test_no_mfma_destination_over_live_operands(tmp_path, src, flags):
     import mfma_overlap_scan
     from sloika_amd import build
     out = str(tmp_path / (src + ".s"))
-    cmd = [build.hipcc()] + build.FLAGS + flags + ["--cuda-device-only", "-S", os.path.join(build.CSRC, src), "-o", out]
+    cmd = [build.hipcc()] + build.flags_for(src) + flags + ["--cuda-device-only", "-S", os.path.join(build.CSRC, src), "-o", out]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     own, war = mfma_overlap_scan.scan(out)
@@ -39,7 +40,7 @@ def test_no_instruction_touches_a_register_an_asm_load_is_filling(tmp_path, src,
     import inflight_load_scan
     from sloika_amd import build
     out = str(tmp_path / (src + ".s"))
-    cmd = [build.hipcc()] + build.FLAGS + ["--cuda-device-only", "-S", os.path.join(build.CSRC, src), "-o", out]
+    cmd = [build.hipcc()] + build.flags_for(src) + ["--cuda-device-only", "-S", os.path.join(build.CSRC, src), "-o", out]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     assert open(out).read().count("global_load_dword") > nloads         # the scan has something to look at

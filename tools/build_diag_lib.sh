@@ -8,7 +8,7 @@ V=tools/_build/diag; mkdir -p $V
 objs=()
 for src in sloika_amd/csrc/*.hip; do
   o=$V/$(basename ${src%.hip}).o
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=off -fvisibility=hidden -DSLK_DIAG -c $src -o $o &
+  /opt/rocm/bin/hipcc $(python3 -c "import sys; sys.path.insert(0, '.'); from sloika_amd import build; print(' '.join(f for f in build.flags_for('$src') if f != '-Wall'))") -DSLK_DIAG -c $src -o $o &
   objs+=($o)
   if (( ${#objs[@]} % 4 == 0 )); then wait; fi
 done

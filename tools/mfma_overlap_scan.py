@@ -1,7 +1,11 @@
 """Scan gfx950 ISA (hipcc --cuda-device-only -S) for MFMA destinations that overlap operand registers:
    (1) of the same instruction, (2) of the MFMA issued just before it (within 12 lines).
 hipcc (ROCm 7.2) emits both for v_mfma_f32_32x32x16_f16 when the destination is freshly defined (C = 0); on MI355X they
-produced wrong rows under matrix-pipe contention (csrc/softmax_viterbi.hip, mma_pair).
+produced wrong rows under matrix-pipe contention (csrc/softmax_viterbi.hip, mma_pair): a 32x32 tile is sixteen registers that
+the instruction writes back in groups while later passes still read A and B.  A 16x16 tile is four registers written once, after
+the last pass has read its operands: there the overlap is the compiler's normal register reuse (every kernel built with
+-amdgpu-mfma-vgpr-form has it), counted separately (`scan(path, wide_only=False)`) and screened on the device instead
+(tests/test_gpu_gru_bar16.py: repeated full-size launches bit for bit, agreement with the float32 kernels under load).
     python tools/mfma_overlap_scan.py file.s ..."""
 import re
 import sys
@@ -9,7 +13,8 @@ import sys
 PAT = re.compile(r'\s*(v_mfma_\S+)\s+([av])\[(\d+):(\d+)\],\s*([av])\[(\d+):(\d+)\],\s*([av])\[(\d+):(\d+)\],\s*(\S+)')
 
 
-def scan(path):
+def scan(path, wide_only=True):
+    """(own, war) over the MFMAs with 32x32 tiles (wide_only) or over all of them."""
     own, war, prev = 0, 0, []
     for ln, line in enumerate(open(path)):
         m = PAT.match(line)
@@ -18,6 +23,9 @@ def scan(path):
         op, dt, d0, d1, at, a0, a1, bt, b0, b1, c = m.groups()
         d0, d1, a0, a1, b0, b1 = map(int, (d0, d1, a0, a1, b0, b1))
         srcs = [(at, a0, a1), (bt, b0, b1)]
+        if wide_only and "32x32" not in op:
+            prev.append((ln, [], (d0, d1)))
+            continue
         for (t, lo, hi) in srcs:
             if t == dt and not (hi < d0 or lo > d1):
                 own += 1
@@ -35,6 +43,7 @@ if __name__ == "__main__":
     bad = 0
     for f in sys.argv[1:]:
         own, war = scan(f)
-        print("%s: destination overlaps its own operands %d times, operands of a preceding MFMA %d times" % (f, own, war))
+        print("%s: 32x32 destinations over their own operands %d times, over operands of the preceding MFMA %d times; all tile "
+              "shapes: %s" % (f, own, war, scan(f, wide_only=False)))
         bad += own + war
     sys.exit(1 if bad else 0)
