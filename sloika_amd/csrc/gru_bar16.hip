@@ -57,8 +57,8 @@ extern "C" SLK_API int slk_debug_read_bar16_wg(unsigned long long *host_out)
 // first tile of interval k when a service wave has st tiles per group (k = 8: st)
 __host__ __device__ constexpr int tile_first(int st, int k)
 {
-    // share per interval in sixteenths: light where the leader also splits x (intervals 1..4) and fetches operands (0)
-    constexpr int w[8] = {1, 0, 1, 1, 2, 2, 2, 3};
+    // share per interval: lighter where the leader also splits x (intervals 1..4) and fetches operands (0)
+    constexpr int w[8] = {1, 1, 1, 1, 2, 2, 2, 2};
     int tot = 0, acc = 0;
     for (int i = 0; i < 8; i++) tot += w[i];
     for (int i = 0; i < k && i < 8; i++) acc += w[i];
@@ -80,7 +80,6 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
     constexpr int NT16 = 3 * NT;                         // tiles of vI rows (z | r | c)
     constexpr int KBLK = (I + 31) / 32;
     constexpr int GS = 4;                                // steps per projection group (16 MFMA columns = 4 steps x 4 chunks)
-    constexpr int KB = 8;                                // steps per x block
     constexpr int R = 2 * GS;                            // vI ring: group G+1 is written while group G is consumed
     constexpr int CT = NCW == 3 ? 2 : 0;                                // projection tiles of a chain wave (weights in accumulation registers)
     constexpr int ST = (NT16 - NCW * CT) / NSW;                         // ... of a service wave
@@ -88,15 +87,14 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
     constexpr int NA = ST < NACAP ? ST : NACAP;                               // of which this many keep their weights in accumulation registers
     static_assert(NCW * CT + NSW * ST == NT16, "tile assignment");
     static_assert(KBLK <= 4 && ST <= 21, "interval plan");
-    constexpr int XIMG = 4 * I;                          // floats of one step's x image: [k/4][chunk][k%4]
-    constexpr int XPIECES = KB * I;                      // 16-byte pieces per x block
-    constexpr int XSLOTS = 4;
-    constexpr int NREQ = XPIECES / 64;                   // 1 KiB DMA requests per block, one per interval
-    static_assert(XPIECES % 64 == 0 && NREQ <= 16, "x block requests");
-    constexpr int OPIMG = GS * KBLK * 64;                // dwords of one operand image: [step][k block][k group][chunk][8 halves]
-    constexpr int VSTEP = NT16 * 64;                     // floats of one step's vI: [tile][g][chunk][r], row = 16 tile + 4g + r
+    // dwords of one operand image: [step][k block][k group][chunk][8 halves]; the steps lie 32 banks apart so that the 16-lane
+    // groups of a ds_read_b128 (lanes of two k groups and two steps each) find their pieces on different banks
+    constexpr int OPSTEP = KBLK * 64 + 32;
+    constexpr int OPIMG = GS * OPSTEP;
+    // floats of one step's vI: [tile][g][chunk][r], row = 16 tile + 4g + r; + 16: the steps of a projection tile (one per lane
+    // quartet of its 16-byte writes) on different banks
+    constexpr int VSTEP = NT16 * 64 + 16;
 
-    __shared__ __attribute__((aligned(16))) float xraw[XSLOTS * KB * XIMG];
     __shared__ __attribute__((aligned(16))) unsigned xop_hi[2 * OPIMG], xop_lo[2 * OPIMG];
     __shared__ __attribute__((aligned(16))) float xinv_lds[2 * 16];
     __shared__ __attribute__((aligned(16))) float vbuf[R * VSTEP];
@@ -120,7 +118,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
     // ---------------- projection pieces shared by both kinds of wave ----------------
     const int pcol = lane & 15, kg = lane >> 4;          // operand row / column and k group of this lane
     const int pstep = pcol >> 2, pc = pcol & 3;          // as a B column: (step in group, chunk)
-    const int poff = pstep * (KBLK * 64) + kg * 16 + pc * 4;            // + 64 kb: my 16 bytes of an operand image, in dwords
+    const int poff = pstep * OPSTEP + kg * 16 + pc * 4;                 // + 64 kb: my 16 bytes of an operand image, in dwords
     auto ldH = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
     // iW tile -> A operands (lane: row pcol of the tile, k = 32 kb + 8 kg + 0..7), row scale remembered in invw_lds
     auto load_tile = [&](int tile, half8 *hi, half8 *lo) {
@@ -166,7 +164,6 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         *reinterpret_cast<f32x4 *>(&vbuf[(st % R) * VSTEP + ((tile * 4 + kg) * 4 + pc) * 4]) = o;
     };
     const int NG = (T + GS - 1) / GS;
-    const int NBLK = (T + KB - 1) / KB;
 
     if (wave < NCW) {
         // =================================================================================================
@@ -489,42 +486,39 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
 #pragma unroll
         for (int t = NA; t < ST; t++) load_tile(tile0 + t, pw_hi[t - NA], pw_lo[t - NA]);
 
-        // x DMA: request j of a block moves pieces 64 j .. 64 j + 63; piece p = (step kk, 16-byte column qq, chunk cc)
-        // (p % I) & 3 = lane & 3: a lane always serves the same chunk
-        const int dcc = lane & 3;
-        const int dbc = min(b0 + dcc, B - 1);
-        const int dTc = lens ? min(max(lens[dbc], 1), T) : T;
-        auto dma_request = [&](int blk, int j) {
-            const int p = 64 * j + lane;
-            const int kk = p / I, qq = (p % I) >> 2;
+        // x of a group: the leader's lane (row pcol = (step, chunk), k group kg) loads ITS eight floats of every K block straight
+        // into registers (the four lanes of a row and K block cover one 128-byte line) a group ahead of the split -- no staging
+        // in LDS, no LDS-DMA (a 1-KiB request kept the issuing wave ~150 cycles, twelve of sixteen intervals carried one).
+        // Ordinary loads: the compiler waits for them where the split first uses them, a group later.
+        const int xbc = min(b0 + pc, B - 1);
+        const int xTc = lens ? min(max(lens[xbc], 1), T) : T;
+        f32x4 xr[KBLK][2];
+        auto load_x = [&](int G2) {
             // steps past the chunk's end re-read its last valid row (their results are never stored)
-            const int ss = min(blk * KB + kk, dTc - 1);
-            const int tt = reverse ? dTc - 1 - ss : ss;
-            const float *src = x + ((size_t)tt * B + dbc) * ldx + 4 * qq;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)&xraw[(blk % XSLOTS) * (KB * XIMG) + 256 * j],
-                                             16, 0, 0);
+            const int ss = min(G2 * GS + pstep, xTc - 1);
+            const int tt = reverse ? xTc - 1 - ss : ss;
+            const float *row = x + ((size_t)tt * B + xbc) * ldx;
+#pragma unroll
+            for (int kb = 0; kb < KBLK; kb++) {
+                const int k0 = 32 * kb + 8 * kg;
+                const bool kok = (I % 32 == 0) || k0 < I;
+                const float *src = row + (kok ? k0 : 0);
+                xr[kb][0] = *reinterpret_cast<const f32x4 *>(src);
+                xr[kb][1] = *reinterpret_cast<const f32x4 *>(src + 4);
+            }
         };
-        // split of group G2's x rows: lane = (row pcol = (step, chunk), k group kg); element x[chunk][k] of a step's image
-        // sits at 16 (k>>2) + 4 chunk + (k&3)
         float xs = 1.0f;
-        auto split_img = [&](int G2) {
-            return xraw + ((G2 >> 1) % XSLOTS) * (KB * XIMG) + (GS * (G2 & 1) + pstep) * XIMG + 4 * pc;
-        };
         float raw[KBLK][8];                              // the group's rows as read for the scale, kept for the split
         auto split_scale = [&](int G2) {                 // pass 1: the row's power-of-two scale
-            const float *img = split_img(G2);
             float amax = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < KBLK; kb++) {
                 const int k0 = 32 * kb + 8 * kg;
                 const bool kok = (I % 32 == 0) || k0 < I;
-                const float *src = img + 4 * (kok ? k0 : 0);
-                const f32x4 u0 = *reinterpret_cast<const f32x4 *>(src), u1 = *reinterpret_cast<const f32x4 *>(src + 16);
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    raw[kb][j] = kok ? u0[j] : 0.0f;
-                    raw[kb][4 + j] = kok ? u1[j] : 0.0f;
+                    raw[kb][j] = kok ? xr[kb][0][j] : 0.0f;
+                    raw[kb][4 + j] = kok ? xr[kb][1][j] : 0.0f;
                     amax = fmaxf(amax, fmaxf(fabsf(raw[kb][j]), fabsf(raw[kb][4 + j])));
                 }
             }
@@ -533,32 +527,23 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             if (kg == 0) xinv_lds[(G2 & 1) * 16 + pcol] = xinv;
         };
         auto split_block = [&](int G2, int kb) {         // pass 2: K block kb -> operand images
-            half8 ahi, alo;
+            unsigned ahi[4], alo[4];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float v = raw[kb][j] * xs;
-                const _Float16 h = (_Float16)v;
-                ahi[j] = h;
-                alo[j] = (_Float16)(v - (float)h);
-            }
+            for (int j = 0; j < 4; j++) split2(raw[kb][2 * j] * xs, raw[kb][2 * j + 1] * xs, ahi[j], alo[j]);
             const int ob = (G2 & 1) * OPIMG + poff + 64 * kb;
-            *reinterpret_cast<half8 *>(xop_hi + ob) = ahi;
-            *reinterpret_cast<half8 *>(xop_lo + ob) = alo;
+            *reinterpret_cast<uint4 *>(xop_hi + ob) = make_uint4(ahi[0], ahi[1], ahi[2], ahi[3]);
+            *reinterpret_cast<uint4 *>(xop_lo + ob) = make_uint4(alo[0], alo[1], alo[2], alo[3]);
         };
 
         __syncthreads();
         if (leader) {
-            const int nb0 = min(XSLOTS - 1, NBLK);
-            for (int blk = 0; blk < nb0; blk++)
-                for (int j = 0; j < NREQ; j++) dma_request(blk, j);
-            if (nb0 >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NREQ) : "memory");
-            else if (nb0 == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NREQ) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             for (int G2 = 0; G2 < 2; G2++) {
+                load_x(G2);
                 split_scale(G2);
 #pragma unroll
                 for (int kb = 0; kb < KBLK; kb++) split_block(G2, kb);
             }
+            load_x(2);                                   // group 2: split during group 0
         }
         lds_bar();
         half8 xh[KBLK], xl[KBLK];
@@ -630,23 +615,12 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             lds_bar<!(ABL & 1)>();
             BSTAMP(8 + k)
             if constexpr (ABL & 8) return;
-            if (leader) {
-                const int blk = G >> 1;                  // block the chain is in; j counts its 16 intervals
-                const int j = (G & 1) * 8 + k;
-                if constexpr (k == 0) {
-                    if ((G & 1) == 0 && blk + 1 < NBLK) {
-                        // block blk+1 (split from here on) has landed once only block blk+2's requests are outstanding
-                        if (blk + 2 < NBLK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NREQ) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                }
-                if (j < NREQ && blk + XSLOTS - 1 < NBLK) dma_request(blk + XSLOTS - 1, j);
-            }
             if constexpr (k == 0) load_operands(G + 1);
             project_interval(KC, G + 1);
             if (leader) {
                 if constexpr (k == 1) split_scale(G + 2);
                 if constexpr (k >= 2 && k < 2 + KBLK) split_block(G + 2, k - 2);
+                if constexpr (k == 1 + KBLK) load_x(G + 3);
             }
             BSTAMP(k)
         };
@@ -702,7 +676,6 @@ static int launch_bar16(const float *x, long ldx, const float *iW, const float *
         DIAG_LAUNCH(1, true, 0) DIAG_LAUNCH(2, false, 1) DIAG_LAUNCH(3, false, 2) DIAG_LAUNCH(4, false, 4) DIAG_LAUNCH(5, false, 8)
         DIAG_LAUNCH(6, false, 16) DIAG_LAUNCH(7, false, 9) DIAG_LAUNCH(8, false, 3) DIAG_LAUNCH(9, false, 11) DIAG_LAUNCH(10, false, 31)
         DIAG_LAUNCH(11, false, 32) DIAG_LAUNCH(12, false, 34) DIAG_LAUNCH(13, false, 40) DIAG_LAUNCH(14, false, 42) DIAG_LAUNCH(15, false, 36)
-        DIAG_LAUNCH(16, false, 96) DIAG_LAUNCH(17, false, 128) DIAG_LAUNCH(18, false, 160) DIAG_LAUNCH(19, false, 288)
 #undef DIAG_LAUNCH
     }
 #endif

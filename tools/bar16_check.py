@@ -1,4 +1,5 @@
-"""csrc/gru_bar16.hip against gru_fused16 (same arithmetic, differences of a few 1e-7 from the order of the split terms) and in-process timing of both, plus the experiment's ablations and section stamps."""
+"""csrc/gru_bar16.hip: in-process timing, the ablation launches and the per-section stamps of the diagnostic build
+    tools/build_diag_lib.sh && SLOIKA_AMD_LIB=$PWD/tools/_build/libsloika_amd_diag.so python tools/bar16_check.py [IxN ...]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes
@@ -21,18 +22,6 @@ for I, n in shapes:
     bb = torch.randn(3 * n, device='cuda', generator=g)
     sW = torch.randn(2 * n, n, device='cuda', generator=g) / np.sqrt(2 * n) * 2
     sW2 = torch.randn(n, n, device='cuda', generator=g) / np.sqrt(2 * n) * 2
-    for T, B, rev in [(1, 1, 0), (3, 2, 0), (4, 4, 1), (5, 4, 0), (8, 4, 1), (9, 3, 0), (17, 9, 1), (23, 9, 0), (41, 5, 1), (100, 33, 0), (333, 1021, 1)]:
-        x = torch.randn(T, B, I, device='cuda', generator=g)
-        for ragged in (False, True):
-            lens = torch.randint(1, T + 1, (B,), device='cuda', dtype=torch.int32) if ragged else None
-            zr_a = torch.full((T * B, 2 * n), float('nan'), device='cuda'); zr_b = zr_a.clone()
-            rc_a, ya = run('slk_gru_fused16_f32', x, iW, sW, sW2, bb, T, B, I, n, rev, lens, zr_a)
-            rc_b, yb = run('slk_gru_bar16_f32', x, iW, sW, sW2, bb, T, B, I, n, rev, lens, zr_b)
-            assert rc_a == 0 and rc_b == 0, (rc_a, rc_b)
-            same = torch.equal(torch.nan_to_num(ya, nan=7.0), torch.nan_to_num(yb, nan=7.0))
-            samez = torch.equal(torch.nan_to_num(zr_a, nan=7.0), torch.nan_to_num(zr_b, nan=7.0))
-            d = (torch.nan_to_num(ya, nan=7.0) - torch.nan_to_num(yb, nan=7.0)).abs().max().item()
-            print("I=%d n=%d T=%d B=%d rev=%d ragged=%d: y identical %s (max diff %.3g), gates identical %s" % (I, n, T, B, rev, ragged, same, d, samez), flush=True)
     T, B = 800, 1024
     x = torch.randn(T, B, I, device='cuda', generator=g)
     y = torch.empty(T, B, n, device='cuda')
@@ -45,8 +34,8 @@ for I, n in shapes:
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
     for rnd in range(3):
-        a, b = timeit('slk_gru_fused16_f32'), timeit('slk_gru_bar16_f32')
-        print("I=%d n=%d T=800 B=1024: fused16 %.3f ms   bar16 %.3f ms  (%.0f cycles/step at 2.4 GHz)" % (I, n, a, b, b * 1e6 / T * 2.4), flush=True)
+        b = timeit('slk_gru_bar16_f32')
+        print("I=%d n=%d T=800 B=1024: bar16 %.3f ms  (%.0f cycles/step at 2.4 GHz)" % (I, n, b, b * 1e6 / T * 2.4), flush=True)
 
     def timeit_code(code, reps=10):
         f = lambda: L.slk_gru_bar16_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B, I, n, 2 * code, 1, 2, None, None, st)
