@@ -30,7 +30,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-
 # pays four v_accvgpr_read per tile before the gate arithmetic can touch them (gru_bar16_kernel<96,96>: 112 of them, 28 per
 # step on the serial chain).  Only for the files written for it: their asm reads of accumulators keep the eight wait states
 # behind an MFMA themselves (the compiler pads in front of its own v_accvgpr_read, never inside asm).
-VGPR_FORM = ("gru_bar16.hip",)
+VGPR_FORM = ("gru_bar16.hip", "gru_bar16d.hip", "gru_bar16q.hip")
 
 
 def flags_for(src):

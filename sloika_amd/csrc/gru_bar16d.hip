@@ -358,6 +358,10 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 1; i < KBS; i++) mfma_rc(wr_hi, wr_lo, i, bh[i], bl[i], accR[0], accR[1]);
+                // the r products in FRONT of the update gate's asm MFMAs, which supply the wait states between them and the asm reads of
+                // pick_mix_d (instruction selection places an MFMA anywhere its operands allow, sched_barrier or not; volatile
+                // statements keep their order, and this one hands the accumulators on)
+                asm volatile("" : "+v"(accR[0]), "+v"(accR[1]));
                 __builtin_amdgcn_sched_barrier(0);
             }
             // z products of all blocks but the last INSIDE the r epilogue: the asm MFMAs are not the compiler's to place (it put
@@ -487,8 +491,9 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 }
                 // the z accumulators came from asm MFMAs the compiler does not know as such: twelve MFMAs (or the drain) have been
                 // issued since the last of them, and nothing that reads them may move above this point
-                if constexpr (KBS == 1) { mfma_drain(accZ[0]); mfma_drain(accZ[1]); }
-                else asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]));
+                // (... and the candidate's MFMAs issued so far lie between them and those reads: the statement hands their accumulators on too)
+                if constexpr (KBS == 1) mfma_drain2(accZ[0], accZ[1]);
+                else asm volatile("" : "+v"(accZ[0]), "+v"(accZ[1]), "+v"(accC[0]), "+v"(accC[1]));
 #pragma unroll
                 for (int i = 2; i < KBS; i++) mfma_rc(wc_hi, wc_lo, i, ch[i], cl[i], accC[0], accC[1]);
             }
@@ -707,7 +712,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 }
                 static_for<0, 6 * KBLK>([&](auto HC) { hook(HC); });
             }
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a0), "+v"(a1));
+            mfma_drain2(a0, a1);
             const int st = GS * G1 + pstep;
             float *dst = &vbuf[(st % R) * 2 * VSTEP + 64 * (tile0 + t0) + (kg * 4 + pc) * 4];
             f32x4 o;

@@ -292,8 +292,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
                 constexpr int i = decltype(IC)::value;
                 z_block_mfma<false>(accR[0], accR[1], wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i]);
             });
-            mfma_drain(accR[0]);
-            mfma_drain(accR[1]);
+            mfma_drain2(accR[0], accR[1]);
             __builtin_amdgcn_sched_barrier(0);
             // ALL z products under the r epilogue (they only need h(s-1), like r)
 #pragma unroll
@@ -379,8 +378,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
                     }
                 }
             }
-            mfma_drain(accC[0]);
-            mfma_drain(accC[1]);
+            mfma_drain2(accC[0], accC[1]);
             __builtin_amdgcn_sched_barrier(0);
             float hn[2][4];
 #pragma unroll
@@ -546,7 +544,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
                     a1 = mfma3(pw_hi[t0 - NA][kb], pw_lo[t0 - NA][kb], xh[1][kb], xl[1][kb], a1);
                 }
             }
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a0), "+v"(a1));
+            mfma_drain2(a0, a1);
             const int st = GS * G1 + pstep;
             float *dst = &vbuf[(st % R) * 2 * VSTEP + 128 * (tile0 + t0) + (kg * 8 + pc) * 4];
             f32x4 o;

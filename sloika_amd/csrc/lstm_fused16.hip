@@ -274,13 +274,13 @@ __global__ void __launch_bounds__(256, LF_OCC) lstm_fused16_kernel(const float *
         // pick_mix reads the accumulators from asm; the state operands stay live until the sums exist (see project_term)
         // (and the projection operand last read just before these MFMAs until they have their destinations)
         if constexpr (ph == 1)
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+            asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
                          : "v"(bm[0]), "v"(bm[KBS - 1]), "v"(xl[0]), "v"(xl[KBLK - 1]));
         else if constexpr (ph == 3)
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+            asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
                          : "v"(bm[0]), "v"(bm[KBS - 1]), "v"(xh[0]), "v"(xh[KBLK - 1]));
         else
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(bm[0]), "v"(bm[KBS - 1]));
+            asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : "v"(bm[0]), "v"(bm[KBS - 1]));
         // layers.py:686-691
         const float a0 = fmaf(pick_mix(acc[0]), inv[0], cur[0]), a1 = fmaf(pick_mix(acc[1]), inv[1], cur[1]);
         const float a2 = fmaf(pick_mix(acc[2]), inv[2], cur[2]), a3 = fmaf(pick_mix(acc[3]), inv[3], cur[3]);
