@@ -649,9 +649,12 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
             *reinterpret_cast<half8 *>(xop_lo + ob) = alo;
         };
         auto split_block = [&](int G2, int sset, int kb) {         // pass 2: K block kb -> operand images
+            unsigned bhi[4], blo[4];
 #pragma unroll
-            for (int j = 0; j < 8; j++) split_piece(kb, j);
-            split_store(G2, sset, kb);
+            for (int j = 0; j < 4; j++) split2(raw[kb][2 * j] * xs, raw[kb][2 * j + 1] * xs, bhi[j], blo[j]);
+            const int ob = opimg(G2, sset) + 64 * kb;
+            *reinterpret_cast<uint4 *>(xop_hi + ob) = make_uint4(bhi[0], bhi[1], bhi[2], bhi[3]);
+            *reinterpret_cast<uint4 *>(xop_lo + ob) = make_uint4(blo[0], blo[1], blo[2], blo[3]);
         };
 
         __syncthreads();

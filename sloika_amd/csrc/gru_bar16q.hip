@@ -28,7 +28,7 @@
 __host__ __device__ constexpr int tile_first_q(int st, int k)
 {
 #ifndef BAR16Q_W
-#define BAR16Q_W 2, 3, 2, 3
+#define BAR16Q_W 2, 2, 2, 3
 #endif
     constexpr int w[4] = {BAR16Q_W};
     int tot = 0, acc = 0;
@@ -467,9 +467,11 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
                 xr[sset][kb][1] = *reinterpret_cast<const f32x4 *>(src + 4);
             }
         };
-        auto split_set = [&](int G2, auto SC) {          // the row's power-of-two scale, then its K blocks -> operand images
+        // the split of a set's rows is spread over two intervals (the scale and the first K block, then the others): done in one, it
+        // made that interval the longest of the group and the chain waves waited for it at the barrier
+        float raw[KBLK][8], xs = 1.0f;
+        auto split_scale = [&](int G2, auto SC) {        // the row's power-of-two scale
             constexpr int sset = decltype(SC)::value;
-            float raw[KBLK][8];
             float amax = 0.0f;
 #pragma unroll
             for (int kb = 0; kb < KBLK; kb++) {
@@ -483,22 +485,21 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
                 }
             }
             float xinv;
-            const float xs = pow2_scale(kgroup_max(amax), xinv);
+            xs = pow2_scale(kgroup_max(amax), xinv);
             if (kg == 0) xinv_lds[((G2 & 1) * 2 + sset) * 16 + pcol] = xinv;
+        };
+        auto split_block = [&](int G2, int sset, int kb) {         // K block kb -> operand images
+            unsigned ahi[4], alo[4];
 #pragma unroll
-            for (int kb = 0; kb < KBLK; kb++) {
-                half8 ahi, alo;
+            for (int j = 0; j < 4; j++) split2(raw[kb][2 * j] * xs, raw[kb][2 * j + 1] * xs, ahi[j], alo[j]);
+            const int ob = opimg(G2, sset) + 128 * kb;
+            *reinterpret_cast<uint4 *>(xop_hi + ob) = make_uint4(ahi[0], ahi[1], ahi[2], ahi[3]);
+            *reinterpret_cast<uint4 *>(xop_lo + ob) = make_uint4(alo[0], alo[1], alo[2], alo[3]);
+        };
+        auto split_set = [&](int G2, auto SC) {
+            split_scale(G2, SC);
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float v = raw[kb][j] * xs;
-                    const _Float16 h = (_Float16)v;
-                    ahi[j] = h;
-                    alo[j] = (_Float16)(v - (float)h);
-                }
-                const int ob = opimg(G2, sset) + 128 * kb;
-                *reinterpret_cast<half8 *>(xop_hi + ob) = ahi;
-                *reinterpret_cast<half8 *>(xop_lo + ob) = alo;
-            }
+            for (int kb = 0; kb < KBLK; kb++) split_block(G2, decltype(SC)::value, kb);
         };
 
         __syncthreads();
@@ -555,16 +556,21 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
             for (int r = 0; r < 4; r++) o[r] = fmaf(a1[r] * xin1, iw0[r], bs0[r]);
             *reinterpret_cast<f32x4 *>(dst + VSTEP) = o;
         };
-        // interval k of group G: the tiles of group G1 = G + 1; the leader splits set 0 of group G + 2 in interval 0 and set 1 in
-        // interval 2, and requests the same set of group G + 3 right behind
+        // interval k of group G: the tiles of group G1 = G + 1; the leader splits set 0 of group G + 2 in intervals 0 and 1, set 1 in
+        // intervals 2 and 3, and requests the same set of group G + 3 right behind
         auto project_interval = [&](auto KC, int G1) {
             constexpr int k = decltype(KC)::value;
             constexpr int lo = tile_first_q(ST, k), hi = tile_first_q(ST, k + 1);
             static_for<lo, hi>([&](auto TC) { project_tile(TC, G1); });
-            if constexpr (k == 0 || k == 2) {
-                if (leader && G1 > 0) {
-                    split_set(G1 + 1, ic<k / 2>{});
-                    load_x(G1 + 2, ic<k / 2>{});
+            if (leader && G1 > 0) {
+                constexpr int sset = k / 2;
+                if constexpr ((k & 1) == 0) {
+                    split_scale(G1 + 1, ic<sset>{});
+                    split_block(G1 + 1, sset, 0);
+                } else {
+#pragma unroll
+                    for (int kb = 1; kb < KBLK; kb++) split_block(G1 + 1, sset, kb);
+                    load_x(G1 + 2, ic<sset>{});
                 }
             }
         };

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 V=tools/_build/variants; mkdir -p $V
 objs=(); i=0
 for flags in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=off $flags \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form $flags \
       -Dslk_gru_bar16d_launch=slk_d_v$i -Dgru_bar16d_kernel=gru_d_k$i -Dslk_dbg_bar16d=slk_dbg_d$i -Dslk_debug_read_bar16d=slk_debug_read_d$i -c sloika_amd/csrc/gru_bar16d.hip -o $V/d_$i.o &
   objs+=($V/d_$i.o); i=$((i+1))
 done

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 V=tools/_build/variants; mkdir -p $V
 objs=(); i=0
 for flags in "$@"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=off $flags \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form $flags \
       -Dslk_gru_bar16q_launch=slk_q_v$i -Dgru_bar16q_kernel=gru_q_k$i -c sloika_amd/csrc/gru_bar16q.hip -o $V/q_$i.o &
   objs+=($V/q_$i.o); i=$((i+1))
 done
