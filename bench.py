@@ -74,6 +74,12 @@ def parse():
     ap.add_argument("--upload-steps", type=int, default=10, help="steps of the leg that uploads the next batch (0 = skip)")
     ap.add_argument("--whole-reads", type=int, default=1024, help="synthetic whole reads of 50k-115k samples (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=5, help="training steps for the `train` field (0 = skip)")
+    ap.add_argument("--host-feed-steps", type=int, default=10,
+                    help="steps of the leg that uploads EIGHT ranks' raw signal per step from pinned host memory (0 = skip)")
+    ap.add_argument("--stub-device", action="store_true",
+                    help="tests only (tests/test_bench_launcher.py): the rank plumbing of this script -- device binding by LOCAL_RANK, "
+                         "barriers, max over ranks, one line from rank 0 -- on the gloo backend with a Runner that sleeps; no GPU, "
+                         "no kernel, and the line says so")
     ap.add_argument("--quick", action="store_true", help="only the main region, the stage pass and the CPU baseline")
     ap.add_argument("--only", default=None, choices=["batch256"],
                     help="run ONE leg and print its JSON (bench.py starts itself with this as a child process)")
@@ -192,7 +198,34 @@ def roofline_of(stages, traffic_by_stage, note=None):
                "traffic": traffic_by_stage.get(dom), "ms_per_launch": d["ms_avg"], "launches": d["calls"]}
     if note:
         out["note"] = note
+    # north_star: "rocprof HBM GB/s + MFMA utilisation reported against chip peak"
+    tr = traffic_by_stage.get(dom)
+    out["hbm_gbs"] = (tr / (d["ms_avg"] * 1e-3) / 1e9) if tr else None          # PMC bytes per launch / HIP-event duration
+    out["hbm_frac_of_peak"] = (out["hbm_gbs"] / HBM_PEAK_GBS) if tr else None
     return out
+
+
+def unit_utilisation(model, batch, chunk_len, kernel_substr, streams=1):
+    """MfmaUtil / VALUBusy / LdsUtil / LDSBankConflict (percent of the kernel's duration, rocprofv3 derived counters, one pass per
+    counter: tools/r04_measure.sh) of the kernel whose name contains `kernel_substr`, from the committed passes of this same workload;
+    None when no file describes the configuration being run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "unit_utilisation.json")) as fh:
+            table = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    for ent in table.get("workloads", []):
+        if ent.get("workload") == [model, batch, chunk_len, streams]:
+            for name, c in ent.get("kernels", {}).items():
+                if kernel_substr in name:
+                    return {"kernel": name, "source": ent.get("source"),
+                            **{k: c[k] for k in ("MfmaUtil", "VALUBusy", "LdsUtil", "LDSBankConflict") if k in c}}
+    return None
+
+
+#: the kernel a stage's time is spent in (for the utilisation lookup)
+STAGE_KERNEL = {"gru_fused": "gru_bar16", "softmax_viterbi": "softmax_viterbi_kernel", "lstm_fused": "lstm_fused16_kernel",
+                "gru_recurrent": "gru_scan", "train_wgrad": "gemm_tn", "train_gru_backward": "gru_bwd16_kernel"}
 
 
 def pmc_traffic(model, batch, chunk_len):
@@ -303,6 +336,20 @@ class Runner(object):
         self.consumed[cur].record(main)
 
 
+class StubRunner(object):
+    """--stub-device: what Runner offers to the rank plumbing, with a step that sleeps (longer on higher ranks, so that the
+    maximum over ranks and `per_rank_ms` have something to show)."""
+
+    def __init__(self, rank):
+        self.rank = rank
+
+    def set_in_flight(self, n):
+        pass
+
+    def step(self, i, nact=1, src=None):
+        time.sleep(0.002 * (1.0 + 0.25 * self.rank))
+
+
 class ClockProbe(object):
     """The shader clock under load: slk_clock_probe launched on a high-priority stream of its own between steps."""
 
@@ -373,6 +420,10 @@ def leg_batch256(args, torch):
         ent["stages_ms_per_step"] = {k: v["ms_total"] / n for k, v in sorted(st1.items())}
         ent["roofline"] = roofline_of(st1, pmc_traffic(mname, B1, L),
                                       "one batch at a time: %d workgroups of 4 chunks on 256 CUs" % (B1 // 4))
+        if ent["roofline"] is not None:
+            k = ent["roofline"]["kernel"]
+            ent["roofline"]["unit_utilisation"] = unit_utilisation(mname, B1, L, STAGE_KERNEL.get(k, k))
+            ent["roofline"]["mfma_util"] = (ent["roofline"]["unit_utilisation"] or {}).get("MfmaUtil")
         r1.set_in_flight(nfl)
         for i in range(2 * nfl):
             r1.step(i, nfl)
@@ -440,11 +491,6 @@ def main_train(args, as_field=False, torch=None, dist=None):
         stages = rec.summary()
         for v in stages.values():
             v["per_step"] = v["ms_total"] / ns
-    if as_field:
-        return {"workload": "%s training step (forward, backward, ADAMski), %d-sample chunks, batch %d" % (args.model, L, B),
-                "ms_per_step": dt / steps * 1e3, "value": world * B * L * steps / dt, "unit": "samples/s", "steps": steps,
-                "final_loss": float(loss),
-                "stages_ms_per_step": {k: v["per_step"] for k, v in sorted(stages.items())}}
     roofline = None
     # HBM bytes per step of every stage from the committed PMC passes of this same workload (tools/collect_pmc.sh --train)
     stage_traffic = {}
@@ -465,7 +511,18 @@ def main_train(args, as_field=False, torch=None, dist=None):
         per_launch = stage_traffic[dom] * ns / d["calls"] if dom in stage_traffic else None
         roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": flops / t_min / 1e12, "unit": "TFLOP/s",
                     "frac": ach / (flops / t_min / 1e12), "traffic": per_launch, "ms_per_launch": d["ms_avg"],
-                    "launches": d["calls"]}
+                    "launches": d["calls"],
+                    "hbm_gbs": (per_launch / (d["ms_avg"] * 1e-3) / 1e9) if per_launch else None,
+                    "unit_utilisation": unit_utilisation(args.model + ":train", B, L, STAGE_KERNEL.get(dom, dom))}
+        roofline["mfma_util"] = (roofline["unit_utilisation"] or {}).get("MfmaUtil")
+    hbm_per_step = {k: stage_traffic[k] for k in sorted(stages) if k in stage_traffic} or None
+    if as_field:
+        return {"workload": "%s training step (forward, backward, ADAMski), %d-sample chunks, batch %d" % (args.model, L, B),
+                "ms_per_step": dt / steps * 1e3, "value": world * B * L * steps / dt, "unit": "samples/s", "steps": steps,
+                "final_loss": float(loss), "roofline": roofline,
+                "stages_ms_per_step": {k: v["per_step"] for k, v in sorted(stages.items())},
+                "stages_hbm_bytes_per_step": hbm_per_step,
+                "hbm_bytes_per_step": sum(hbm_per_step.values()) if hbm_per_step else None}
     if rank == 0:
         print(json.dumps({
             "metric": "raw-signal samples/sec trained", "value": world * B * L * steps / dt, "unit": "samples/s",
@@ -481,7 +538,7 @@ def main_train(args, as_field=False, torch=None, dist=None):
             "cpu_baseline": cpu_baseline_train(args.model, L) if (world == 1 and args.cpu_chunks > 0) else None,
             "final_loss": loss,
             "stages_ms_per_step": {k: v["per_step"] for k, v in sorted(stages.items())},
-            "stages_hbm_bytes_per_step": {k: stage_traffic[k] for k in sorted(stages) if k in stage_traffic} or None}))
+            "stages_hbm_bytes_per_step": hbm_per_step}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -519,50 +576,88 @@ def main():
         _l.require_gpu()
         print(json.dumps(leg_batch256(args, torch)))
         return
-    from sloika_amd import _lib, layers as _layers, pipeline, profiler, shard
+    from sloika_amd import shard
     rank, world, local_rank = shard.dist_info()
-    _lib.require_gpu()
-    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    stub = args.stub_device
+    if stub:
+        # the rank plumbing alone (tests): gloo, host tensors, a Runner that sleeps; `device` records what a real run would bind
+        ndev = int(os.environ.get("SLOIKA_AMD_STUB_DEVICES", "8"))
+        bound = local_rank % max(1, ndev)
+        dev = "cpu"
+        sync = lambda: None
+    else:
+        from sloika_amd import _lib, layers as _layers, pipeline, profiler
+        _lib.require_gpu()
+        bound = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(bound)
+        dev = "cuda"
+        sync = torch.cuda.synchronize
     dist = None
     if "WORLD_SIZE" in os.environ:          # under a launcher (also with one rank: the RCCL path is the path that runs)
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", torch.cuda.current_device()))
     B, L = args.batch, args.chunk_len
     nstream = max(1, args.streams)
-    extras = world == 1 and nstream == 1 and not args.quick        # the single-GPU legs behind the main region
+    extras = world == 1 and nstream == 1 and not args.quick and not stub        # the single-GPU legs behind the main region
     nslot = max(nstream, 4 if (extras and args.overlap_steps > 0) else 1)
-    run = Runner(torch, args.model, B, L, nslot, rank=rank, with_bases=args.with_bases, main_stream=(nstream == 1))
+    if stub:
+        if os.environ.get("SLOIKA_AMD_STUB_FAIL_RANK") == str(rank):      # tests: a rank that dies must fail the whole launch
+            sys.stderr.write("bench.py: rank %d fails on request\n" % rank)
+            sys.exit(3)
+        run = StubRunner(rank)
+    else:
+        run = Runner(torch, args.model, B, L, nslot, rank=rank, with_bases=args.with_bases, main_stream=(nstream == 1))
     run.set_in_flight(nstream)
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def reduce_max(dt):
         if dist is None:
             return dt
-        tm = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tm = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         return float(tm.item())
+
+    local_dt = [0.0]
 
     def timed(fn, n):
         barrier()
         t = time.perf_counter()
         for i in range(n):
             fn(i)
+        sync()
+        local_dt[0] = time.perf_counter() - t          # this rank's own work (per_rank_ms) ...
         barrier()
-        return reduce_max(time.perf_counter() - t)
+        return reduce_max(time.perf_counter() - t)     # ... and the job's: until the last rank is through
 
     # ---- the main region: W warm-up steps, then exactly K timed steps (no events inside) ----
     for i in range(args.warmup):
         run.step(i, nstream)
+    probe = None if stub else ClockProbe(torch, nmax=4)
+    if probe is not None:
+        sync()
+        probe.sample()                       # the shader clock right in front of the timed region (a launch of its own, waited for) ...
+        sync()
     dt = timed(lambda i: run.step(i, nstream), args.steps)
+    if probe is not None:
+        probe.sample()                       # ... and right behind it
     value = world * B * L * args.steps / dt
+    # every rank's own time for the K steps (a straggler shows here; `ms_per_step` is the maximum)
+    per_rank_ms = [local_dt[0] / args.steps * 1e3]
+    if dist is not None:
+        tl = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([per_rank_ms[0]], dtype=torch.float64, device=dev))
+        per_rank_ms = [float(t.item()) for t in tl]
 
     # ---- the same steps once more with HIP events around every C-ABI call: per-stage times and the roofline ----
     stages, roofline, ms_profiled = {}, None, None
-    if not args.no_stage_timing and args.stage_steps > 0:
+    if not args.no_stage_timing and args.stage_steps > 0 and not stub:
         rec = profiler.start()
         dts = timed(lambda i: run.step(i, nstream), args.stage_steps)
         profiler.stop()
@@ -574,6 +669,9 @@ def main():
         if roofline is not None:
             roofline["measured"] = "HIP events on the launch stream over %d steps issued right after the timed region " \
                                    "(the timed region itself carries no events)" % args.stage_steps
+            roofline["unit_utilisation"] = unit_utilisation(args.model, B, L, STAGE_KERNEL.get(roofline["kernel"], roofline["kernel"]),
+                                                            nstream)
+            roofline["mfma_util"] = (roofline["unit_utilisation"] or {}).get("MfmaUtil")
 
     def release():
         """torch's allocator caches device memory per stream; a leg that ran on side streams leaves tens of gigabytes reserved for
@@ -646,6 +744,47 @@ def main():
                                          "upload_bytes_per_step": int(B * L * 4),
                                          "note": "float32 raw signal of the NEXT batch uploaded from pinned host memory on the "
                                                  "copy stream while this batch runs; `value` of the line excludes it"}
+
+        # ---- what ONE host has to feed EIGHT ranks with: eight batches of raw signal per step (8 x B x L float32) from pinned memory
+        # into HBM on the copy stream while the step runs.  (On an 8-GPU node every GPU has a link of its own; here all eight
+        # uploads share this GPU's, so the leg bounds the host side -- pinned-memory reads, the copy engine's descriptors -- from above.)
+        if args.host_feed_steps > 0 and not args.with_bases:
+            nrank = 8
+            pinned = [torch.from_numpy(run.host_in[j % run.nbuf]).pin_memory() for j in range(2)]
+            land = [torch.empty_like(run.dev[0]) for _ in range(nrank)]
+            feed_stream = torch.cuda.Stream()
+            fed = [None]
+
+            def step_fed(i):
+                with torch.cuda.stream(feed_stream):
+                    if fed[0] is not None:
+                        feed_stream.wait_event(fed[0])
+                    for r in range(nrank):
+                        land[r].copy_(pinned[(i + r) % 2], non_blocking=True)
+                run.step(i)
+                fed[0] = torch.cuda.Event()
+                fed[0].record(torch.cuda.current_stream())
+            for i in range(2):
+                step_fed(i)
+            feed_stream.synchronize()
+            t0 = time.perf_counter()
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.host_feed_steps):
+                step_fed(i)
+            sync()
+            feed_stream.synchronize()
+            d = time.perf_counter() - t0
+            nbytes = nrank * B * L * 4
+            line_extra["host_feed"] = {"ranks_emulated": nrank, "bytes_per_step": int(nbytes), "steps": args.host_feed_steps,
+                                       "ms_per_step": d / args.host_feed_steps * 1e3, "value": B * L * args.host_feed_steps / d,
+                                       "unit": "samples/s (of the ONE batch that is computed)",
+                                       "upload_gb_per_s": nbytes * args.host_feed_steps / d / 1e9,
+                                       "demand_gb_per_s_at_value": nbytes / (dt / args.steps) / 1e9,
+                                       "note": "eight ranks' uploads (pinned host memory -> HBM, copy stream) beside one rank's step; "
+                                               "demand = what eight ranks at `value` each would ask of the host"}
+            del pinned, land
+            release()
 
         # ---- the batch north_star quotes (256 chunks), in a CHILD process: eight batches in flight, each with side streams for
         # the directions of a birnn, create more HIP streams than the device has hardware queues, and from then on every queue
@@ -738,7 +877,7 @@ def main():
 
     if rank == 0:
         cpu = None
-        if world == 1 and args.cpu_chunks > 0:
+        if world == 1 and args.cpu_chunks > 0 and not stub:
             cpu = cpu_baseline(args.model, L, args.cpu_chunks)
         nst = max(1, args.stage_steps)
         gemm_flops = sum(stages[k]["flops"] for k in stages if k in MFMA_STAGES) / nst
@@ -755,13 +894,21 @@ def main():
                        "model": args.model, "chunk_len": L, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "chunks sharded over %d GPU(s), no collective" % world, "streams_per_gpu": nstream},
             "roofline": roofline,
+            "per_rank_ms": per_rank_ms,
+            "device_of_rank0": bound,
+            "shader_clock_mhz_before_after": None if probe is None else probe.result(),
             "cpu_baseline": cpu,
             "stages_ms_per_step": {k: v["ms_total"] / nst for k, v in sorted(stages.items())},
             "ms_per_step_with_stage_events": ms_profiled,
             "e2e_algorithmic_tflops": (gemm_flops / (dt / args.steps) / 1e12) if stages else None,
         }
         line.update(line_extra)
+        if stub:
+            line["data"] = "none: --stub-device (rank plumbing only, no GPU, no kernel)"
+            line["value"] = None
         print(json.dumps(line))
+    elif stub:
+        sys.stderr.write("bench.py: rank %d bound to device %d\n" % (rank, bound))
     if dist is not None:
         dist.destroy_process_group()
 

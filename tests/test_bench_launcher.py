@@ -1,6 +1,7 @@
 """`bench.py --gpus N` is the multi-GPU entry point (one process per GPU, reference fan-out: sloika/iterators.py:343-351,
 bin/basecall_network.py:100-101).  On this CPU-only box it must really create N ranks, and each must fail loudly at
 require_gpu() -- never fall back to one rank or to a CPU path."""
+import json
 import os
 import subprocess
 import sys
@@ -31,3 +32,49 @@ def test_gpus_must_match_the_launcher_world_size():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
+
+
+def _stub(*extra, **env_extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub-device", "--steps", "5", "--warmup", "1"] + list(extra),
+                          env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_eight_ranks_rank_plumbing_on_gloo():
+    """The N > 1 code path of bench.py end to end without a GPU: `--gpus 8` starts eight ranks under torch.distributed.run, every
+    rank binds the device LOCAL_RANK names, the barriers and the max over ranks run on a real (gloo) process group, rank 0 alone
+    prints ONE line whose time is the slowest rank's, and `per_rank_ms` shows every rank's own."""
+    r = _stub("--gpus", "8")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 5 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["value"] is None and "stub" in d["data"]                   # no throughput is claimed from a stub
+    assert len(d["per_rank_ms"]) == 8
+    assert d["per_rank_ms"][7] > d["per_rank_ms"][0] * 1.5              # StubRunner sleeps 1 + r / 4 units: the straggler is visible
+    assert d["ms_per_step"] >= max(d["per_rank_ms"]) * 0.9              # ... and the line's time is the maximum over ranks
+    assert d["config"]["global_batch"] == 8 * d["config"]["batch_per_gpu"]
+    for rank in range(8):
+        assert "rank %d of 8 starting" % rank in r.stderr
+        if rank:
+            assert "rank %d bound to device %d" % (rank, rank) in r.stderr
+    assert d["device_of_rank0"] == 0
+
+
+def test_a_failing_rank_fails_the_launch():
+    r = _stub("--gpus", "4", SLOIKA_AMD_STUB_FAIL_RANK="2")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_stub_single_process_and_ranks_wrap_onto_devices():
+    """One process, no launcher: no process group, the same line.  With more ranks than devices the binding wraps (LOCAL_RANK % devices)."""
+    r = _stub()
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["per_rank_ms"] and len(d["per_rank_ms"]) == 1
+    r = _stub("--gpus", "4", SLOIKA_AMD_STUB_DEVICES="2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rank 3 bound to device 1" in r.stderr and "rank 2 bound to device 0" in r.stderr
