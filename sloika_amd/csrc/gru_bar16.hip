@@ -81,7 +81,9 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
     constexpr int KBLK = (I + 31) / 32;
     constexpr int GS = 4;                                // steps per projection group (16 MFMA columns = 4 steps x 4 chunks)
     constexpr int R = 2 * GS;                            // vI ring: group G+1 is written while group G is consumed
-    constexpr int CT = NCW == 3 ? 2 : 0;                                // projection tiles of a chain wave (weights in accumulation registers)
+    // projection tiles of a chain wave (weights in accumulation registers); three where four K blocks of the input would not leave
+    // the service wave room for the tiles it keeps in ordinary registers next to the x rows it loads (128 -> 96 spilled)
+    constexpr int CT = NCW == 3 ? (KBLK == 4 ? 3 : 2) : 0;
     constexpr int ST = (NT16 - NCW * CT) / NSW;                         // ... of a service wave
     constexpr int NACAP = 240 / (8 * KBLK);                              // 256 accumulation registers, 2 * KBLK * 4 per tile
     constexpr int NA = ST < NACAP ? ST : NACAP;                               // of which this many keep their weights in accumulation registers

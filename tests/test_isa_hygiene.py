@@ -46,3 +46,18 @@ def test_no_instruction_touches_a_register_an_asm_load_is_filling(tmp_path, src,
     assert open(out).read().count("global_load_dword") > nloads         # the scan has something to look at
     bad = inflight_load_scan.scan(out)
     assert not bad, bad[:3]
+
+
+@pytest.mark.parametrize("src", ["gru_bar16.hip", "gru_bar16d.hip", "gru_bar16q.hip", "gru_scan16.hip", "gru_scan1t.hip", "lstm_fused16.hip",
+                                 "gru_bwd16.hip", "lstm_bwd16.hip"])
+def test_recurrent_kernels_keep_everything_in_registers(tmp_path, src):
+    """The persistent scan kernels are sized against the register file by hand (weights in registers for the whole scan); a spill puts
+    scratch traffic on the serial chain.  (gru_bar16_kernel<128, 96> once spilled 36 registers unnoticed when its service wave gained
+    the x rows it now loads itself.)"""
+    from sloika_amd import build
+    out = str(tmp_path / (src + ".s"))
+    cmd = [build.hipcc()] + build.flags_for(src) + ["--cuda-device-only", "-S", os.path.join(build.CSRC, src), "-o", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    sizes = [int(ln.split()[-1]) for ln in open(out) if ".amdhsa_private_segment_fixed_size" in ln]
+    assert sizes and max(sizes) == 0, sizes
