@@ -72,7 +72,9 @@ def parse():
     ap.add_argument("--small-batch-steps", type=int, default=6, help="steps of the batch-256 legs (0 = skip)")
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of each sustained leg (0 = skip)")
     ap.add_argument("--upload-steps", type=int, default=10, help="steps of the leg that uploads the next batch (0 = skip)")
-    ap.add_argument("--whole-reads", type=int, default=1024, help="synthetic whole reads of 50k-115k samples (0 = skip)")
+    # 4096: with 1024 reads the longest read's own chain (115 000 samples through five sequential layers) takes longer than the whole
+    # set would at the chunk-mode rate -- no schedule can do better than 0.68 x -- so a set that small measures the read, not the path
+    ap.add_argument("--whole-reads", type=int, default=4096, help="synthetic whole reads of 50k-115k samples (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=5, help="training steps for the `train` field (0 = skip)")
     ap.add_argument("--host-feed-steps", type=int, default=10,
                     help="steps of the leg that uploads EIGHT ranks' raw signal per step from pinned host memory (0 = skip)")

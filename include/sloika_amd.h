@@ -106,6 +106,16 @@ SLK_API int slk_med_mad_normalise_f32(const float *signal, int nchunk, int chunk
 SLK_API int slk_med_mad_normalise_ragged_f32(const float *signal, int nread, long in_stride, const int32_t *lens, float *out,
                                              long out_chunk_stride, long out_sample_stride, float *med_out, float *mad_out,
                                              slk_stream_t stream);
+/* Whole-read mode (sloika/basecall.py:88-121 calls reads one at a time; the build batches reads of similar length): the read set lies
+ * in one device buffer, read r in src[start[r] .. start[r] + len[r]).
+ *   slk_pack_reads_f32       dst:[nread][ld] (ld >= max len) <- the reads, zero-padded to ld samples each
+ *   slk_reads_nonfinite_f32  flags[r] |= 1 when read r holds a NaN or an infinity (flags zeroed by the caller; max_len >= max len):
+ *                            such a read is skipped and reported, as raw_worker skips a read that fails (basecall.py:103-115),
+ *                            instead of poisoning the batch it would have shared.                                               */
+SLK_API int slk_pack_reads_f32(const float *src, const int64_t *start, const int32_t *len, int nread, float *dst, long ld,
+                       slk_stream_t stream);
+SLK_API int slk_reads_nonfinite_f32(const float *src, const int64_t *start, const int32_t *len, int nread, int max_len, int32_t *flags,
+                            slk_stream_t stream);
 /* Standard deviation of each of nwin consecutive windows of `win` samples (population form, numpy's .std()):
  * batch.trim_open_pore(var_method='std'), sloika/batch.py:210-211.  out:[nwin].                                    */
 SLK_API int slk_window_std_f32(const float *signal, int nwin, int win, float *out, slk_stream_t stream);

@@ -4,6 +4,7 @@
     normalise_chunks(chunks, 'per-chunk'|...)      median/MAD normalisation (chunkify_raw.py:178-185)
     chunks_to_network_input(chunks)                [ml, chunk_len] -> [chunk_len, ml, 1] (bin/train_network.py:304)
 """
+import os
 import threading
 
 import numpy as np
@@ -158,9 +159,23 @@ def upload_reads_windowed(signals, window_size=100):
     if st.event is not None:
         st.event.synchronize()                           # the previous upload out of this buffer has left the host
     hv = st.buf.numpy()
-    for r, sig in enumerate(signals):
-        hv[off[r]: off[r] + lens[r]] = sig
-        hv[off[r] + lens[r]: off[r + 1]] = 0.0
+
+    def pack(lo, hi):
+        for r in range(lo, hi):
+            hv[off[r]: off[r] + lens[r]] = signals[r]
+            hv[off[r] + lens[r]: off[r + 1]] = 0.0
+
+    n = len(signals)
+    if total >= (1 << 24) and n >= 16:
+        # a gigabyte of samples is a tenth of a second of memcpy on one core; numpy's copies release the interpreter lock
+        import concurrent.futures
+        nthr = min(8, os.cpu_count() or 1)
+        cuts = np.searchsorted(off, np.linspace(0, total, nthr + 1)[1:-1]).tolist()
+        edges = [0] + [min(max(c, 0), n) for c in cuts] + [n]
+        with concurrent.futures.ThreadPoolExecutor(nthr) as ex:
+            list(ex.map(lambda a: pack(*a), [(edges[k], edges[k + 1]) for k in range(nthr) if edges[k + 1] > edges[k]]))
+    else:
+        pack(0, n)
     dev = st.buf[:total].to(D.device(), non_blocking=True)
     st.event = torch.cuda.Event()
     st.event.record()
@@ -170,13 +185,12 @@ def upload_reads_windowed(signals, window_size=100):
 def open_pore_bounds_many(dev, off, lens, max_op_fraction=0.3, var_method='mad', window_size=100):
     """trim_open_pore (sloika/batch.py:194-220) for reads resident on the device as upload_reads_windowed leaves them: the
     spreads of ALL windows in one launch, the percentile threshold per read on the host (a few hundred numbers each).
-    -> list of (first sample, one past the last sample) relative to each read's start."""
+    -> list of (first sample, one past the last sample) relative to each read's start; None for a read the reference's function
+    would fail on (shorter than one window, or no window livelier than the threshold)."""
     import torch
     from . import device as D
     assert var_method in TRIM_OPEN_PORE_LOCAL_VAR_METHODS, "var_method not understood: {}".format(var_method)
-    nwin = [n // window_size for n in lens]
-    if min(nwin) < 1:
-        raise ValueError("a read is shorter than one window of %d samples" % window_size)
+    nwin = np.asarray([n // window_size for n in lens], dtype=np.int64)
     wd = dev.view(-1, window_size)
     if var_method == 'mad':
         _, _, spread = normalise_chunks(wd, 'per-chunk', return_stats=True)
@@ -185,13 +199,48 @@ def open_pore_bounds_many(dev, off, lens, max_op_fraction=0.3, var_method='mad',
         _lib.check(_lib.lib().slk_window_std_f32(wd.data_ptr(), wd.shape[0], window_size, spread.data_ptr(), D.stream_ptr()),
                    "window_std")
     spread = spread.cpu().numpy()
-    out = []
+    w0 = np.asarray(off[:-1] if len(off) == len(lens) + 1 else off, dtype=np.int64) // window_size
+    out = [None] * len(lens)
+    if max_op_fraction == 0 and len(lens):
+        # np.percentile(., 0) is the minimum: all reads at once (whole windows only, as the reference's reshape leaves them)
+        live = np.flatnonzero(nwin > 0)
+        if len(live):
+            cnt = nwin[live]
+            seg0 = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+            pos = np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(seg0, cnt)          # window index inside its read
+            vals = spread[np.repeat(w0[live], cnt) + pos]
+            lively = vals > np.repeat(np.minimum.reduceat(vals, seg0), cnt)
+            first = np.minimum.reduceat(np.where(lively, pos, np.iinfo(np.int64).max), seg0)
+            last = np.maximum.reduceat(np.where(lively, pos, -1), seg0)
+            for k, r in enumerate(live):
+                if last[k] >= 0:
+                    out[r] = (int(first[k]) * window_size, (int(last[k]) + 1) * window_size)
+        return out
     for r, n in enumerate(nwin):
-        w0 = int(off[r]) // window_size
-        sp = spread[w0: w0 + n]                          # whole windows only, as the reference's reshape leaves them
+        if n < 1:
+            continue
+        sp = spread[w0[r]: w0[r] + n]                    # whole windows only, as the reference's reshape leaves them
         lively = np.flatnonzero(sp > np.percentile(sp, 100 * max_op_fraction))
-        out.append((int(lively[0]) * window_size, (int(lively[-1]) + 1) * window_size))
+        if len(lively):
+            out[r] = (int(lively[0]) * window_size, (int(lively[-1]) + 1) * window_size)
     return out
+
+
+def reads_nonfinite(dev, off, lens):
+    """Which reads of an uploaded read set (upload_reads_windowed) hold a NaN or an infinity: bool array [nread]."""
+    import torch
+    from . import device as D
+    n = len(lens)
+    if n == 0:
+        return np.zeros(0, dtype=bool)
+    start = torch.as_tensor(np.ascontiguousarray(off[:n], dtype=np.int64)).to(dev.device)
+    ln = torch.as_tensor(np.ascontiguousarray(lens, dtype=np.int32)).to(dev.device)
+    flags = torch.zeros((n,), dtype=torch.int32, device=dev.device)
+    for lo in range(0, n, 65535):
+        hi = min(n, lo + 65535)
+        _lib.check(_lib.lib().slk_reads_nonfinite_f32(dev.data_ptr(), start[lo:].data_ptr(), ln[lo:].data_ptr(), hi - lo,
+                                                      int(max(lens[lo:hi])), flags[lo:].data_ptr(), D.stream_ptr()), "reads_nonfinite")
+    return flags.cpu().numpy() != 0
 
 
 def normalise_reads_ragged(padded, lengths):

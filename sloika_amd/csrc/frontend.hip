@@ -365,6 +365,62 @@ __global__ void __launch_bounds__(256) window_std_kernel(const float *__restrict
     if (lane == 0) out[w] = (float)sqrt(q / win);
 }
 
+// ---- whole reads: the read set lies in one device buffer (batch.upload_reads_windowed); a batch of reads of similar length becomes
+// ---- a zero-padded [B][ld] matrix (what 4096 device-to-device copies did before), and reads with samples that are not finite are
+// ---- found before they can poison a batch (basecall.py:103-115: the reference's worker skips a read that fails and goes on)
+__global__ void __launch_bounds__(256) pack_reads_kernel(const float *__restrict__ src, const long long *__restrict__ start,
+                                                         const int *__restrict__ len, float *__restrict__ dst, long ld)
+{
+    const int b = blockIdx.y;
+    const long j0 = (long)blockIdx.x * 1024 + threadIdx.x;
+    const int n = len[b];
+    const float *s = src + start[b];
+    float *d = dst + (size_t)b * ld;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const long j = j0 + 256 * k;
+        if (j < ld) d[j] = j < n ? s[j] : 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256) reads_nonfinite_kernel(const float *__restrict__ src, const long long *__restrict__ start,
+                                                              const int *__restrict__ len, int *__restrict__ flags)
+{
+    const int b = blockIdx.y;
+    const long j0 = (long)blockIdx.x * 4096 + threadIdx.x;
+    const int n = len[b];
+    const float *s = src + start[b];
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const long j = j0 + 256 * k;
+        if (j < n) bad |= (__float_as_uint(s[j]) & 0x7f800000u) == 0x7f800000u;      // exponent all ones: infinity or NaN
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&flags[b], 1);
+}
+
+extern "C" int slk_pack_reads_f32(const float *src, const int64_t *start, const int32_t *len, int nread, float *dst, long ld,
+                                  slk_stream_t stream)
+{
+    if (!src || !start || !len || !dst || nread < 0 || ld < 1) return SLK_ERR_INVALID_ARG;
+    if (nread == 0) return SLK_OK;
+    if (nread > 65535) return SLK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(pack_reads_kernel, dim3((unsigned)((ld + 1023) / 1024), nread), dim3(256), 0, slk_stream(stream), src,
+                       reinterpret_cast<const long long *>(start), len, dst, ld);
+    return slk_launch_status();
+}
+
+extern "C" int slk_reads_nonfinite_f32(const float *src, const int64_t *start, const int32_t *len, int nread, int max_len,
+                                       int32_t *flags, slk_stream_t stream)
+{
+    if (!src || !start || !len || !flags || nread < 0 || max_len < 0) return SLK_ERR_INVALID_ARG;
+    if (nread == 0 || max_len == 0) return SLK_OK;
+    if (nread > 65535) return SLK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(reads_nonfinite_kernel, dim3((max_len + 4095) / 4096, nread), dim3(256), 0, slk_stream(stream), src,
+                       reinterpret_cast<const long long *>(start), len, flags);
+    return slk_launch_status();
+}
+
 extern "C" int slk_window_std_f32(const float *signal, int nwin, int win, float *out, slk_stream_t stream)
 {
     if (!signal || !out || nwin < 0 || win < 1) return SLK_ERR_INVALID_ARG;

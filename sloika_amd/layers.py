@@ -274,13 +274,27 @@ def _projection(owner, x, W, b, ws_ptr, rows, k, n_out, stage, name):
     _lib.check(rc, name)
 
 
-class ragged(object):
+class _RaggedMeta(type):
+    """`ragged.current` per host thread (one forward pass per thread at a time, like _PlanHints): two threads that run ragged batches
+    side by side must not see each other's lengths."""
+    _tls = __import__("threading").local()
+
+    @property
+    def current(cls):
+        return getattr(_RaggedMeta._tls, "current", None)
+
+    @current.setter
+    def current(cls, value):
+        _RaggedMeta._tls.current = value
+
+
+class ragged(object, metaclass=_RaggedMeta):
     """Context for a ragged batch: `with ragged(lengths): net.run(x)` runs a zero-padded batch [T, B, F] whose chunk b is
     only lengths[b] steps long (whole reads of different lengths).  Time-local layers are unaffected (they compute the
     padding too), Convolution maps the lengths through its stride, and recurrent layers in reverse time start every chunk
     at ITS last step -- so each chunk gets exactly what a run on the unpadded chunk alone would produce; rows beyond a
-    chunk's length hold unspecified values."""
-    current = None               # int32 device tensor [B] of the tensor currently flowing through the network, or None
+    chunk's length hold unspecified values.  `ragged.current`: the int32 device tensor [B] of the tensor currently flowing through
+    the network on this host thread, or None."""
 
     def __init__(self, lengths):
         import torch

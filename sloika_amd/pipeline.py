@@ -162,18 +162,25 @@ class Basecaller(object):
         normalisation, network and decoder with per-read lengths.  -> (scores, paths, lens) on the device."""
         net = self.network
         B = padded.shape[0]
-        with layers.ragged(nsamp) as ctx:
-            x = batch.normalise_reads_ragged(padded, ctx.lengths)      # per-read normalisation (basecall.py:117-118)
-            hid = x
-            for layer in net.layers[:-1]:
-                hid = layer._forward(hid, None, False)
-            lengths = layers.ragged.current
-            packed = self._fused_pack(net.layers[-1], hid)
-            pack = packed[0] if packed is not None else None
-            if pack is None:
-                logits, stats, ld = net.layers[-1].logits_and_stats(hid)
-            elif packed[1] != hid.shape[2]:
-                hid = hid.as_strided((hid.shape[0], hid.shape[1], packed[1]), hid.stride())
+        keep = layers._HINTS.in_flight
+        # ragged batches side by side keep the four-chunk plan: their workgroups queue for the CUs and a batch of short reads hands its
+        # CUs on early, which a plan that packs more chunks into fewer, slower workgroups would not let it do
+        layers._HINTS.in_flight = 1
+        try:
+            with layers.ragged(nsamp) as ctx:
+                x = batch.normalise_reads_ragged(padded, ctx.lengths)      # per-read normalisation (basecall.py:117-118)
+                hid = x
+                for layer in net.layers[:-1]:
+                    hid = layer._forward(hid, None, False)
+                lengths = layers.ragged.current
+                packed = self._fused_pack(net.layers[-1], hid)
+                pack = packed[0] if packed is not None else None
+                if pack is None:
+                    logits, stats, ld = net.layers[-1].logits_and_stats(hid)
+                elif packed[1] != hid.shape[2]:
+                    hid = hid.as_strided((hid.shape[0], hid.shape[1], packed[1]), hid.stride())
+        finally:
+            layers._HINTS.in_flight = keep
         T = hid.shape[0]
         if pack is not None:
             return decode.viterbi_fused_batch(hid, pack, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
@@ -220,28 +227,50 @@ class Basecaller(object):
     @classmethod
     def prepare_read_batches(cls, network, signals, trim=(0, 0), open_pore_fraction=0.0, max_batch=256, max_waste=0.08, **kwargs):
         """Preparation of the whole-read mode: the read set goes to the device in one upload, trimming bounds come from one launch over
-        all windows (basecall.py:111-112), reads are bucketed by length and every bucket becomes a zero-padded device batch.
-        -> (batches, nsamp): batches = [(read indices, padded device tensor
-        [B, Lmax], their sample counts)], nsamp = sample count of every read after trimming."""
+        all windows (basecall.py:111-112), reads are bucketed by length and every bucket becomes a zero-padded device batch (one launch
+        per bucket).  -> (batches, nsamp): batches = [(read indices, padded device tensor [B, Lmax], their sample counts)], nsamp =
+        sample count of every read after trimming.
+
+        A read that cannot be called -- no sample left after trimming, shorter than one open-pore window, no window livelier than
+        the threshold, or a sample that is not finite -- is left out of every batch and gets nsamp 0; `failed_reads(nsamp)` lists
+        them.  The reference's worker does the same one read at a time: it reports the read on stderr, returns None and the pool goes
+        on (basecall.py:103-115).  The other reads of the set are unaffected."""
+        import sys
         import torch
+        from . import device as D
         # ONE upload of the whole read set; trimming bounds from the device's window spreads; the padded batches are then built on
-        # the device (a copy per read) -- the host touches every sample once
+        # the device (a launch per bucket) -- the host touches every sample once
         dev, off, lens = batch.upload_reads_windowed(signals)
+        bad = batch.reads_nonfinite(dev, off, lens)
         bounds = batch.open_pore_bounds_many(dev, off, lens, open_pore_fraction)
         assert trim[0] >= 0 and trim[1] >= 0
-        spans = [(lo + trim[0], hi - trim[1]) for lo, hi in bounds]                       # util.trim_array
-        nsamp = [max(0, hi - lo) for lo, hi in spans]
-        if min(nsamp) < 1:
-            raise ValueError("empty read after trimming")
+        spans, nsamp = [], []
+        for r, bd in enumerate(bounds):
+            lo, hi = (0, 0) if (bd is None or bad[r]) else (bd[0] + trim[0], bd[1] - trim[1])               # util.trim_array
+            spans.append((lo, hi))
+            nsamp.append(max(0, hi - lo))
+            if nsamp[-1] < 1:
+                why = "samples that are not finite" if bad[r] else ("too short to trim the open pore" if bd is None else
+                                                                    "nothing left after trimming")
+                sys.stderr.write("Failure calling read {}: {}\n".format(r, why))
+        good = [r for r in range(len(nsamp)) if nsamp[r] > 0]
         batches = []
-        for idx in cls.length_buckets(nsamp, max_batch, max_waste):
+        L = _lib.lib()
+        for sub in cls.length_buckets([nsamp[r] for r in good], max_batch, max_waste):
+            idx = [good[j] for j in sub]
             ns = [nsamp[i] for i in idx]
-            padded = torch.zeros((len(idx), max(ns)), dtype=torch.float32, device=dev.device)
-            for b, i in enumerate(idx):
-                lo = int(off[i]) + spans[i][0]
-                padded[b, :ns[b]].copy_(dev[lo: lo + ns[b]])
+            padded = torch.empty((len(idx), max(ns)), dtype=torch.float32, device=dev.device)
+            start = torch.as_tensor(np.asarray([int(off[i]) + spans[i][0] for i in idx], dtype=np.int64)).to(dev.device)
+            ln = torch.as_tensor(np.asarray(ns, dtype=np.int32)).to(dev.device)
+            _lib.check(L.slk_pack_reads_f32(dev.data_ptr(), start.data_ptr(), ln.data_ptr(), len(idx), padded.data_ptr(),
+                                            padded.shape[1], D.stream_ptr()), "pack_reads")
             batches.append((idx, padded, ns))
         return batches, nsamp
+
+    @staticmethod
+    def failed_reads(nsamp):
+        """Indices of the reads prepare_read_batches left out (their sample count after trimming is 0)."""
+        return [i for i, n in enumerate(nsamp) if n < 1]
 
     @classmethod
     def run_read_batches(cls, network, batches, nreads, in_flight=None, lanes=None, **kwargs):
@@ -250,7 +279,7 @@ class Basecaller(object):
         milliseconds, so the chip only fills up with several of them side by side).  `lanes`: a list of (Basecaller, stream)
         pairs to reuse (read_lanes(); torch's allocator caches device memory per stream, so a server that keeps its lanes does
         not pay for gigabytes of fresh allocations on every call).  -> (scores [N] float32, list of N int32 path arrays) on the
-        host."""
+        host; a read that is in no batch (failed_reads) has score NaN and path None."""
         import torch
         if lanes is None:
             lanes = cls.read_lanes(network, max(1, min(8, len(batches)) if in_flight is None else in_flight), **kwargs)
@@ -267,7 +296,7 @@ class Basecaller(object):
                 ev = torch.cuda.Event()
                 ev.record(s)
             pending.append((idx, host, ev, res))
-        scores = np.empty(nreads, dtype=np.float32)
+        scores = np.full(nreads, np.nan, dtype=np.float32)
         paths = [None] * nreads
         for idx, host, ev, res in pending:
             ev.synchronize()
@@ -290,13 +319,14 @@ class Basecaller(object):
         reads are bucketed by length (length_buckets), every bucket is one padded ragged batch, and the buckets run side by side
         on streams of their own (one Basecaller each, sharing the network).  Each read gets bit for bit what call_reads([read])
         gives.  -> (scores [N] float32, list of N int32 path arrays, sample counts [N], stats) all on the host; stats holds the
-        padded-step waste."""
+        padded-step waste and the indices of the reads that could not be called (`failed`: score NaN, path None, sample count 0 --
+        each reported on stderr as the reference's worker reports a read it skips, basecall.py:103-115)."""
         batches, nsamp = cls.prepare_read_batches(network, signals, trim, open_pore_fraction, max_batch, max_waste, **kwargs)
         scores, paths = cls.run_read_batches(network, batches, len(nsamp), in_flight, lanes, **kwargs)
         used = sum(nsamp)
         padded = sum(ns[0] * len(idx) for idx, _, ns in batches)
         stats = {"reads": len(nsamp), "batches": len(batches), "samples": used, "padded_samples": padded,
-                 "padded_step_waste": 1.0 - used / float(padded)}
+                 "padded_step_waste": 1.0 - used / float(max(padded, 1)), "failed": cls.failed_reads(nsamp)}
         return scores, paths, nsamp, stats
 
     def call_chunks_host(self, chunks):

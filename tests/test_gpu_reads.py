@@ -172,3 +172,41 @@ def test_bucketed_whole_read_mode_equals_single_reads():
         assert n1[0] == nsamp[i]
         assert p1.cpu().numpy()[0, :int(l1[0])].tolist() == paths[i].tolist(), i
         assert float(s1[0]) == float(scores[i]), i
+
+
+@pytest.mark.parametrize("fraction", [0.0, 0.3])
+def test_a_read_that_fails_is_skipped_and_the_others_are_unaffected(fraction, capsys):
+    """sloika/basecall.py:103-115: the reference's worker reports a read it cannot call and returns None; the pool goes on.  Here
+    such a read (a NaN or an infinity among its samples, fewer samples than one open-pore window) must not poison the ragged batch it
+    would have shared: it is left out, reported, and every other read gets bit for bit what it gets without it."""
+    need_gpu()
+    from sloika_amd import batch, models, pipeline
+    net = models.randomise_zero_layers(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=17))
+    rs = np.random.RandomState(9)
+    base = pipeline.synthetic_chunks(4, chunk_len=7000, seed=31)
+    good = [np.ascontiguousarray(base[i % 4][rs.randint(0, 500):][:n]) for i, n in enumerate(rs.randint(1500, 5000, size=9))]
+    nan_read = good[2].copy()
+    nan_read[1234] = np.nan
+    inf_read = good[5].copy()
+    inf_read[7] = np.inf
+    reads = good[:3] + [nan_read] + good[3:6] + [good[0][:60]] + good[6:] + [inf_read]
+    bad_idx = [3, 7, len(reads) - 1]
+    kw = dict(max_batch=4, max_waste=0.2, in_flight=2, kmer_len=5, skip=0.0, open_pore_fraction=fraction)
+    scores, paths, nsamp, stats = pipeline.Basecaller.call_reads_bucketed(net, reads, **kw)
+    assert stats["failed"] == bad_idx and pipeline.Basecaller.failed_reads(nsamp) == bad_idx
+    err = capsys.readouterr().err
+    for i in bad_idx:
+        assert paths[i] is None and np.isnan(scores[i]) and nsamp[i] == 0
+        assert "Failure calling read %d" % i in err
+    s2, p2, n2, st2 = pipeline.Basecaller.call_reads_bucketed(net, good, **kw)
+    assert st2["failed"] == []
+    keep = [i for i in range(len(reads)) if i not in bad_idx]
+    assert [nsamp[i] for i in keep] == list(n2)
+    for j, i in enumerate(keep):
+        assert paths[i].tolist() == p2[j].tolist() and float(scores[i]) == float(s2[j])
+    # the vectorised bounds of fraction 0 are the reference's np.percentile(., 0) bounds
+    if fraction == 0.0:
+        dev, off, lens = batch.upload_reads_windowed(good)
+        fast = batch.open_pore_bounds_many(dev, off, lens, 0.0)
+        slow = batch.open_pore_bounds_many(dev, off, lens, 1e-12)          # the general path; same threshold for all practical purposes
+        assert fast == slow
