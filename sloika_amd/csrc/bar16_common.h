@@ -122,6 +122,15 @@ __device__ __forceinline__ void block_mfma_acc(f32x4 &acc, const half8 &w_hi, co
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w_hi), "v"(x_hi));
 }
 
+// one tile's product with one K block, three terms (per accumulator the order of mfma3), weights in accumulation registers
+template <bool FIRST>
+__device__ __forceinline__ void tile_block_mfma(f32x4 &a, const half8 &w_hi, const half8 &w_lo, const half8 &bh, const half8 &bl)
+{
+    if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(a) : "a"(w_hi), "v"(bl));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a) : "a"(w_hi), "v"(bl));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a) : "a"(w_lo), "v"(bh));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a) : "a"(w_hi), "v"(bh));
+}
 // z products of one K block for the wave's two tiles, weights in accumulation registers, the two accumulation chains interleaved
 // (per accumulator the order of the terms is that of mfma3)
 template <bool FIRST>

@@ -288,11 +288,29 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
                 for (int sset = 0; sset < 2; sset++) { keep(xhA[sset]); keep(xlA[sset]); pxh[sset] = xhA[sset]; pxl[sset] = xlA[sset]; }
             }
             __builtin_amdgcn_sched_barrier(0);
-            static_for<1, KBS>([&](auto IC) {
-                constexpr int i = decltype(IC)::value;
-                z_block_mfma<false>(accR[0], accR[1], wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i]);
-            });
-            mfma_drain2(accR[0], accR[1]);
+            // tile 0 first, then tile 1: tile 1's MFMAs are the wait states between tile 0's last MFMA and the arithmetic that reads its
+            // sum (the hardware does not interlock that read: tools/probes/mfma_read_hazard_probe.hip), and they run while that
+            // arithmetic does; tile 1's own sum is handed on behind tile 0's sigmoids (below)
+            // (narrower layers -- two workgroups per CU, three MFMAs per tile -- keep the interleaved order and the drain: measured
+            //  0.81 against 0.91 ms for 64 -> 64 at B = 4096)
+            if constexpr (KBS >= 3) {
+                static_for<1, KBS>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    tile_block_mfma<false>(accR[0], wr_hi[0][i], wr_lo[0][i], bh[i], bl[i]);
+                });
+                static_for<1, KBS>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    tile_block_mfma<false>(accR[1], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i]);
+                });
+                // tile 0's sum is handed on BEHIND tile 1's MFMAs: the arithmetic that reads it must not be placed in front of them
+                asm volatile("" : "+v"(accR[0]), "+v"(accR[1]));
+            } else {
+                static_for<1, KBS>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    z_block_mfma<false>(accR[0], accR[1], wr_hi[0][i], wr_lo[0][i], wr_hi[1][i], wr_lo[1][i], bh[i], bl[i]);
+                });
+                mfma_drain2(accR[0], accR[1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ALL z products under the r epilogue (they only need h(s-1), like r)
 #pragma unroll
@@ -300,10 +318,11 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
                 mfma3x2(wz_hi[0][i], wz_lo[0][i], wz_hi[1][i], wz_lo[1][i], bh[i], bl[i], accZ[0], accZ[1]);
             float rr[2][4];
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
+            for (int j = 0; j < 4; j++) rr[0][j] = sigmoid4(fmaf(accR[0][j], inv_r[0][j], vr[0][j]));
+            // (twenty instructions of tile 0's gate lie in front of the first read of tile 1's sum)
+            asm volatile("" : "+v"(accR[1]) : "v"(rr[0][0]), "v"(rr[0][1]), "v"(rr[0][2]), "v"(rr[0][3]));
 #pragma unroll
-                for (int j = 0; j < 4; j++) rr[p][j] = sigmoid4(fmaf(accR[p][j], inv_r[p][j], vr[p][j]));
-            }
+            for (int j = 0; j < 4; j++) rr[1][j] = sigmoid4(fmaf(accR[1][j], inv_r[1][j], vr[1][j]));
             {
                 uint4 hi, lo;
                 split2(rr[0][0] * hold[0][0], rr[1][0] * hold[1][0], hi.x, lo.x);
@@ -363,10 +382,21 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
                 for (int sset = 0; sset < 2; sset++) { keep(xhB[sset]); keep(xlB[sset]); pxh[sset] = xhB[sset]; pxl[sset] = xlB[sset]; }
             }
             __builtin_amdgcn_sched_barrier(0);
-            static_for<1, KBS>([&](auto IC) {
-                constexpr int i = decltype(IC)::value;
-                z_block_mfma<false>(accC[0], accC[1], wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i]);
-            });
+            if constexpr (KBS >= 3) {
+                static_for<1, KBS>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    tile_block_mfma<false>(accC[0], wc_hi[0][i], wc_lo[0][i], ch[i], cl[i]);
+                });
+                static_for<1, KBS>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    tile_block_mfma<false>(accC[1], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i]);
+                });
+            } else {
+                static_for<1, KBS>([&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    z_block_mfma<false>(accC[0], accC[1], wc_hi[0][i], wc_lo[0][i], wc_hi[1][i], wc_lo[1][i], ch[i], cl[i]);
+                });
+            }
             if constexpr (CT > 0 && ph == 1) {           // vI of group G+1: its last MFMAs are at least a candidate block old, or drained
 #pragma unroll
                 for (int sset = 0; sset < 2; sset++) {
@@ -378,11 +408,14 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
                     }
                 }
             }
-            mfma_drain2(accC[0], accC[1]);
+            if constexpr (KBS >= 3) asm volatile("" : "+v"(accC[0]), "+v"(accC[1]));
+            else mfma_drain2(accC[0], accC[1]);
             __builtin_amdgcn_sched_barrier(0);
             float hn[2][4];
 #pragma unroll
             for (int p = 0; p < 2; p++) {
+                // tile 1's sum behind tile 0's candidate (see interval A)
+                if (p == 1) asm volatile("" : "+v"(accC[1]) : "v"(hn[0][0]), "v"(hn[0][1]), "v"(hn[0][2]), "v"(hn[0][3]));
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const float hbar = tanh5(fmaf(accC[p][j], inv_c[p][j], vc[p][j]));
@@ -564,7 +597,12 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
             static_for<lo, hi>([&](auto TC) { project_tile(TC, G1); });
             if (leader && G1 > 0) {
                 constexpr int sset = k / 2;
-                if constexpr ((k & 1) == 0) {
+                if constexpr (NCW < 3) {                 // narrow layers (two workgroups per CU): the whole set in one interval, as measured
+                    if constexpr ((k & 1) == 0) {
+                        split_set(G1 + 1, ic<sset>{});
+                        load_x(G1 + 2, ic<sset>{});
+                    }
+                } else if constexpr ((k & 1) == 0) {
                     split_scale(G1 + 1, ic<sset>{});
                     split_block(G1 + 1, sset, 0);
                 } else {
