@@ -49,10 +49,11 @@ MFMA_STAGES = ("gru_fused", "gru_recurrent", "gru_input_gemm", "lstm_fused", "ls
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 0.4 s of timed steps behind 40 ms of warm-up -- a fresh box takes a few dozen steps to reach its clock under load
-    # (20 steps behind 3 read 4.45 ms per step on a device whose next 10 steps, the stage pass, took 3.98)
+    # defaults: 0.4 s of timed steps behind 0.6 s of warm-up.  A fresh process needs about a hundred steps to reach its steady state
+    # (torch's caching allocator still grows while result tensors wait for their copies; measured on one box, same clock both times:
+    # 100 steps behind 10 of warm-up 4.14-4.21 ms per step, behind 200 3.91-3.92 -- the figure the 10-second `sustained` leg confirms)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=150)
     ap.add_argument("--model", default="raw_0.98_rgrgr")
     ap.add_argument("--batch", type=int, default=1024, help="chunks per GPU per step")
     ap.add_argument("--chunk-len", type=int, default=4000)

@@ -284,7 +284,10 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     half8 wfh[SV_D], wfl[SV_D];
     f32x16 acc[4];
     float val[4][16];                                          // logits -> exponentials of the block in the making
-    float lp[4][16];                                           // log-posteriors of the block being decoded
+    // log-posteriors of the block being decoded, [row][to-state]: the four to-states of a step lie in neighbouring registers, so the
+    // packed adds of the dynamic programme take them as they are (laid out [to-state][row] like the accumulators they needed two
+    // register moves per pair and step)
+    float lp[16][4];
     float4 xr0, xr1;                                           // this lane's eight x values of a coming block
     // operand preparation: wave w, 16-lane row r4 handles MFMA row rho = 4 w + r4 = lane half (w & 1), row i of that half
     const int kb = lane & 15, r4 = lane >> 4;
@@ -506,20 +509,34 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         if constexpr (n0 < n1 && i0 < i1) {
             float fac[16];
             load16p(my_fac, fac);
+            // tiles in pairs (n, n + 1): the fused multiply-adds run on row pairs (neighbouring accumulator registers), the logarithms
+            // are scalar instructions that write where the dynamic programme wants them, the final scaling runs on to-state pairs
+            static_assert((n1 - n0) % 2 == 0, "tiles in pairs");
 #pragma unroll
-            for (int n = n0; n < n1; n++)
+            for (int n = n0; n < n1; n += 2)
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
                     const bool in0 = i % BS >= i0 && i % BS < i1, in1 = (i + 1) % BS >= i0 && (i + 1) % BS < i1;
                     if (in0 && in1) {
                         const f32x2 a = __builtin_elementwise_fma(f32x2{val[n][i], val[n][i + 1]}, f32x2{fac[i], fac[i + 1]},
                                                                   f32x2{mp_eta, mp_eta});
-                        const f32x2 l = f32x2{__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(a.y)} * SV_LN2;
-                        lp[n][i] = (SV_ABL & 8) ? a.x : l.x;
-                        lp[n][i + 1] = (SV_ABL & 8) ? a.y : l.y;
+                        const f32x2 b = __builtin_elementwise_fma(f32x2{val[n + 1][i], val[n + 1][i + 1]}, f32x2{fac[i], fac[i + 1]},
+                                                                  f32x2{mp_eta, mp_eta});
+                        const f32x2 l0 = f32x2{__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(b.x)} * SV_LN2;
+                        const f32x2 l1 = f32x2{__builtin_amdgcn_logf(a.y), __builtin_amdgcn_logf(b.y)} * SV_LN2;
+                        lp[i][n] = (SV_ABL & 8) ? a.x : l0.x;
+                        lp[i][n + 1] = (SV_ABL & 8) ? b.x : l0.y;
+                        lp[i + 1][n] = (SV_ABL & 8) ? a.y : l1.x;
+                        lp[i + 1][n + 1] = (SV_ABL & 8) ? b.y : l1.y;
                     } else {
-                        if (in0) lp[n][i] = sv_log(fmaf(val[n][i], fac[i], mp_eta));
-                        if (in1) lp[n][i + 1] = sv_log(fmaf(val[n][i + 1], fac[i + 1], mp_eta));
+                        if (in0) {
+                            lp[i][n] = sv_log(fmaf(val[n][i], fac[i], mp_eta));
+                            lp[i][n + 1] = sv_log(fmaf(val[n + 1][i], fac[i], mp_eta));
+                        }
+                        if (in1) {
+                            lp[i + 1][n] = sv_log(fmaf(val[n][i + 1], fac[i + 1], mp_eta));
+                            lp[i + 1][n + 1] = sv_log(fmaf(val[n + 1][i + 1], fac[i + 1], mp_eta));
+                        }
                     }
                 }
             // the values are first used a period later: without this the compiler sinks the whole transform to the loop's end,
@@ -528,7 +545,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             for (int n = n0; n < n1; n++)
 #pragma unroll
                 for (int i = 0; i < 16; i++)
-                    if (i % BS >= i0 && i % BS < i1) keepf(lp[n][i]);
+                    if (i % BS >= i0 && i % BS < i1) keepf(lp[i][n]);
         }
     };
     auto dump_block = [&](int nb) __attribute__((always_inline)) {
@@ -541,7 +558,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
                 const int t = BS * nb + i % BS, bb = b0 + hch + 2 * (i / BS);
                 if (t < T && bb < B) {
                     float *dst = lp_dump + ((size_t)t * B + bb) * (SV_NK + 1) + 1 + 4 * j;
-                    dst[0] = lp[0][i]; dst[1] = lp[1][i]; dst[2] = lp[2][i]; dst[3] = lp[3][i];
+                    dst[0] = lp[i][0]; dst[1] = lp[i][1]; dst[2] = lp[i][2]; dst[3] = lp[i][3];
                 }
             }
         }
@@ -576,7 +593,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         dump_block(nb);
     };
 
-    // ---- the dynamic programme: step t0 + k of block cb, log-posteriors lp[n][p BS + k] (viterbi_forward4_kernel::step) ----
+    // ---- the dynamic programme: step t0 + k of block cb, log-posteriors lp[p BS + k][n] (viterbi_forward4_kernel::step) ----
     float own[NPL][4];                                         // this thread's four scores of the previous step, per chunk
 #pragma unroll
     for (int p = 0; p < NPL; p++)
@@ -621,12 +638,12 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         uint32_t moves = 0;                                         // bit 2n: to-state n moves
 #pragma unroll
         for (int n = 0; n < 4; n++) {
-            const float nv = lp[n][p * BS + k] + mx;                // decode.py:75
+            const float nv = lp[p * BS + k][n] + mx;                // decode.py:75
             const float stay = own[p][n] + lp0;                     // decode.py:80
             const bool move = nv > stay;                            // decode.py:81 (tie -> stay)
             moves |= move ? (1u << (2 * n)) : 0u;
             float r = move ? nv : stay;
-            if constexpr (k == 0) r = t0 == 0 ? lp[n][p * BS] : r;  // t = 0: v = lpost[0][1:] (decode.py:57)
+            if constexpr (k == 0) r = t0 == 0 ? lp[p * BS][n] : r;  // t = 0: v = lpost[0][1:] (decode.py:57)
             nw[n] = r;
         }
         // two bits per to-state: 0 stay, 1 step, 2 skip (viterbi_forward4_kernel's traceback word)
