@@ -226,6 +226,8 @@ def unit_utilisation(model, batch, chunk_len, kernel_substr, streams=1):
     return None
 
 
+#: stages of the training step that stream their operands once (priced against HBM)
+TRAIN_HBM_STAGES = ("train_wgrad", "train_dx", "train_xent")
 #: the kernel a stage's time is spent in (for the utilisation lookup)
 STAGE_KERNEL = {"gru_fused": "gru_bar16", "softmax_viterbi": "softmax_viterbi_kernel", "lstm_fused": "lstm_fused16_kernel",
                 "gru_recurrent": "gru_scan", "train_wgrad": "gemm_tn", "train_gru_backward": "gru_bwd16_kernel"}
@@ -507,16 +509,26 @@ def main_train(args, as_field=False, torch=None, dist=None):
     if stages:
         dom = max(stages, key=lambda k: stages[k]["ms_total"])
         d = stages[dom]
-        flops = d["flops"] / d["calls"]
-        f16 = d.get("f16x3_flops", 0.0) / d["calls"]
-        t_min = (flops - f16) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + 3.0 * f16 / (F16_MFMA_PEAK_TFLOPS * 1e12)
-        ach = flops / (d["ms_avg"] * 1e-3) / 1e12
         per_launch = stage_traffic[dom] * ns / d["calls"] if dom in stage_traffic else None
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": flops / t_min / 1e12, "unit": "TFLOP/s",
-                    "frac": ach / (flops / t_min / 1e12), "traffic": per_launch, "ms_per_launch": d["ms_avg"],
-                    "launches": d["calls"],
-                    "hbm_gbs": (per_launch / (d["ms_avg"] * 1e-3) / 1e9) if per_launch else None,
-                    "unit_utilisation": unit_utilisation(args.model + ":train", B, L, STAGE_KERNEL.get(dom, dom))}
+        if dom in TRAIN_HBM_STAGES:
+            # the contractions of the backward pass stream their operands once and are bound by those loads (six bf16 MFMA terms per
+            # product would take a quarter of the time at the matrix peak): priced against HBM on their ALGORITHMIC bytes
+            ach = d["bytes"] / d["calls"] / (d["ms_avg"] * 1e-3) / 1e9
+            flops = d["flops"] / d["calls"]
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": per_launch, "ms_per_launch": d["ms_avg"], "launches": d["calls"],
+                        "matrix_side": {"tflops": flops / (d["ms_avg"] * 1e-3) / 1e12,
+                                        "frac_of_bf16_peak_at_six_terms": 6.0 * flops / (d["ms_avg"] * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS}}
+        else:
+            flops = d["flops"] / d["calls"]
+            f16 = d.get("f16x3_flops", 0.0) / d["calls"]
+            t_min = (flops - f16) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + 3.0 * f16 / (F16_MFMA_PEAK_TFLOPS * 1e12)
+            ach = flops / (d["ms_avg"] * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": flops / t_min / 1e12, "unit": "TFLOP/s",
+                        "frac": ach / (flops / t_min / 1e12), "traffic": per_launch, "ms_per_launch": d["ms_avg"],
+                        "launches": d["calls"]}
+        roofline["hbm_gbs"] = (per_launch / (d["ms_avg"] * 1e-3) / 1e9) if per_launch else None
+        roofline["unit_utilisation"] = unit_utilisation(args.model + ":train", B, L, STAGE_KERNEL.get(dom, dom))
         roofline["mfma_util"] = (roofline["unit_utilisation"] or {}).get("MfmaUtil")
     hbm_per_step = {k: stage_traffic[k] for k in sorted(stages) if k in stage_traffic} or None
     if as_field:
@@ -642,14 +654,14 @@ def main():
     # ---- the main region: W warm-up steps, then exactly K timed steps (no events inside) ----
     for i in range(args.warmup):
         run.step(i, nstream)
-    probe = None if stub else ClockProbe(torch, nmax=4)
-    if probe is not None:
+    edge_probe = None if stub else ClockProbe(torch, nmax=4)
+    if edge_probe is not None:
         sync()
-        probe.sample()                       # the shader clock right in front of the timed region (a launch of its own, waited for) ...
+        edge_probe.sample()                  # the shader clock right in front of the timed region (a launch of its own, waited for) ...
         sync()
     dt = timed(lambda i: run.step(i, nstream), args.steps)
-    if probe is not None:
-        probe.sample()                       # ... and right behind it
+    if edge_probe is not None:
+        edge_probe.sample()                  # ... and right behind it
     value = world * B * L * args.steps / dt
     # every rank's own time for the K steps (a straggler shows here; `ms_per_step` is the maximum)
     per_rank_ms = [local_dt[0] / args.steps * 1e3]
@@ -899,7 +911,7 @@ def main():
             "roofline": roofline,
             "per_rank_ms": per_rank_ms,
             "device_of_rank0": bound,
-            "shader_clock_mhz_before_after": None if probe is None else probe.result(),
+            "shader_clock_mhz_before_after": None if edge_probe is None else edge_probe.result(),
             "cpu_baseline": cpu,
             "stages_ms_per_step": {k: v["ms_total"] / nst for k, v in sorted(stages.items())},
             "ms_per_step_with_stage_events": ms_profiled,

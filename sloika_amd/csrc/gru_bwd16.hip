@@ -71,8 +71,11 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
 
     // operand images: [hi image | lo image], each K x 4 chunks halves; element (k block kb, k group g, chunk c, r) = dword
     // ((kb*4+g)*4+c)*4 + r holds k = 32kb+4g+r (low half) and 32kb+16+4g+r (high half) of chunk c
-    __shared__ __attribute__((aligned(16))) unsigned c_img[2 * 2 * N];             // dac, K = N
-    __shared__ __attribute__((aligned(16))) unsigned z_img[2 * 4 * N];             // [daz | dar], K = 2N
+    // (the lo image 32 banks behind the hi image, as in gru_bar16.hip: back to back they shared their banks and the mixed-operand reads
+    //  conflicted two ways -- LDSBankConflict 21 % of the kernel's time, profiles/r04m_train_unit_utilisation.json)
+    constexpr int CI = 2 * N + 32, ZI = 4 * N + 32;       // dwords from the hi to the lo image
+    __shared__ __attribute__((aligned(16))) unsigned c_img[CI + 2 * N];            // dac, K = N
+    __shared__ __attribute__((aligned(16))) unsigned z_img[ZI + 4 * N];            // [daz | dar], K = 2N
     // [step parity][chunk]: max |dy + keep|, max |dzr|, max |g| over ALL units of a chunk, as the bits of non-negative floats (which
     // order like unsigned integers): every lane adds its value with one LDS atomic maximum.  (Reducing inside the wave first -- two
     // lane swaps and two DPP steps per quantity -- and reading one number per wave back cost 800-960 of a step's 2100-2850 cycles.)
@@ -81,8 +84,8 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
-    for (int i = tid; i < 2 * 2 * N; i += NTH) c_img[i] = 0u;
-    for (int i = tid; i < 2 * 4 * N; i += NTH) z_img[i] = 0u;
+    for (int i = tid; i < CI + 2 * N; i += NTH) c_img[i] = 0u;
+    for (int i = tid; i < ZI + 4 * N; i += NTH) z_img[i] = 0u;
     auto ldH = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
     if (tid < 8) { s_m[tid >> 2][tid & 3] = 0u; s_z[tid >> 2][tid & 3] = 0u; s_g[tid >> 2][tid & 3] = 0u; }
     auto amax = [](unsigned *slot, float v) { atomicMax(slot, __float_as_uint(fabsf(v))); };
@@ -145,9 +148,9 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
     const float D2 = fmaxf(0.5f, 0.25f * C2);            // max |dzr| <= D2 max |g|
     int moff1[KB1], moff2[KB2];
 #pragma unroll
-    for (int kb = 0; kb < KB1; kb++) moff1[kb] = (q >> 1) * 2 * N + ((kb * 4 + g) * 4 + c) * 4;   // in dwords, my column group's image
+    for (int kb = 0; kb < KB1; kb++) moff1[kb] = (q >> 1) * CI + ((kb * 4 + g) * 4 + c) * 4;   // in dwords, my column group's image
 #pragma unroll
-    for (int kb = 0; kb < KB2; kb++) moff2[kb] = (q >> 1) * 4 * N + ((kb * 4 + g) * 4 + c) * 4;
+    for (int kb = 0; kb < KB2; kb++) moff2[kb] = (q >> 1) * ZI + ((kb * 4 + g) * 4 + c) * 4;
 
     const int bc = b0 + c;
     const bool live = bc < B;
@@ -246,7 +249,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
             const _Float16 h16 = (_Float16)hv;
             const _Float16 l16 = (_Float16)(hv - (float)h16);
             reinterpret_cast<unsigned short *>(&c_img[0])[wpos] = __builtin_bit_cast(unsigned short, h16);
-            reinterpret_cast<unsigned short *>(&c_img[2 * N])[wpos] = __builtin_bit_cast(unsigned short, l16);
+            reinterpret_cast<unsigned short *>(&c_img[CI])[wpos] = __builtin_bit_cast(unsigned short, l16);
         }
         // ---- barrier Y: the dac image and max |g| are there ----
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -288,7 +291,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
             asm volatile("" : "+v"(v0), "+v"(v1));
             const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
             const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
-            unsigned short *ih = reinterpret_cast<unsigned short *>(&z_img[0]), *il = reinterpret_cast<unsigned short *>(&z_img[4 * N]);
+            unsigned short *ih = reinterpret_cast<unsigned short *>(&z_img[0]), *il = reinterpret_cast<unsigned short *>(&z_img[ZI]);
             ih[wpos] = __builtin_bit_cast(unsigned short, h0);                         // k = u
             il[wpos] = __builtin_bit_cast(unsigned short, l0);
             ih[wpos + KB1 * 128] = __builtin_bit_cast(unsigned short, h1);              // k = N + u: KB1 K blocks further

@@ -55,8 +55,10 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
     constexpr int NV = T9 ? 3 : 2;                       // (neuron, chunk) pairs a lane requests per step
 
     constexpr bool MIX = SCAN16_MIX != 0;
-    __shared__ __attribute__((aligned(16))) unsigned h_img[2 * 2 * N], rh_img[2 * 2 * N];        // hi image, then lo image
-    unsigned *const h_hi = h_img, *const h_lo = h_img + 2 * N, *const rh_hi = rh_img, *const rh_lo = rh_img + 2 * N;
+    // hi image, then lo image 32 banks behind it (gru_bar16.hip)
+    constexpr int LO = 2 * N + (2 * N % 64 == 32 ? 0 : 32);
+    __shared__ __attribute__((aligned(16))) unsigned h_img[LO + 2 * N], rh_img[LO + 2 * N];
+    unsigned *const h_hi = h_img, *const h_lo = h_img + LO, *const rh_hi = rh_img, *const rh_lo = rh_img + LO;
     // the ninth tile's A operands: [gate r, z, c][K block][hi, lo][lane] x 16 bytes
     __shared__ __attribute__((aligned(16))) unsigned w9[T9 ? 3 * KBS * 2 * 64 * 4 : 4];
     __shared__ float h9f[64], z9f[64];                   // ninth tile: h(s-1) for the reset-gate wave, z(s) for the owner
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
     for (int i = 0; i < KBS; i++) boff[i] = ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
     int moff[KBS];                                       // MIX: my column group's image (q = 0, 1: hi; q = 2, 3: lo)
 #pragma unroll
-    for (int i = 0; i < KBS; i++) moff[i] = (q >> 1) * 2 * N + boff[i];
+    for (int i = 0; i < KBS; i++) moff[i] = (q >> 1) * LO + boff[i];
     auto pick = [&](const f32x4 &a) { if constexpr (MIX) return pick_mix(a); else return sel4(a, q); };
     const int wd = ((w * 4 + g) * 4 + c) * 4 + q;                                           // my packed pair, in dwords
     const int n0 = 32 * w + 4 * g + q;                                                      // my neuron of tile 2w (+16: 2w+1)

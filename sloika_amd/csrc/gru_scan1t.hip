@@ -35,11 +35,13 @@ __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__res
 
     // state images: [hi image | lo image], each KP x 4 chunks halves; element (k block kb, k group g, chunk c, r) = dword
     // ((kb*4+g)*4+c)*4 + r holds neuron 32kb+4g+r (low half) and 32kb+16+4g+r (high half) of chunk c
-    __shared__ __attribute__((aligned(16))) unsigned h_img[2 * 2 * KP], rh_img[2 * 2 * KP];
+    // the lo image 32 banks behind the hi image (back to back on the same banks the mixed-operand reads conflict two ways: gru_bar16.hip)
+    constexpr int LO = 2 * KP + (2 * KP % 64 == 32 ? 0 : 32);
+    __shared__ __attribute__((aligned(16))) unsigned h_img[LO + 2 * KP], rh_img[LO + 2 * KP];
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
-    for (int i = tid; i < 2 * 2 * KP; i += NTH) { h_img[i] = 0u; rh_img[i] = 0u; }                // h(-1) = 0
+    for (int i = tid; i < LO + 2 * KP; i += NTH) { h_img[i] = 0u; rh_img[i] = 0u; }                // h(-1) = 0
     auto ldH = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
 
     const int c = lane & 3, q = (lane >> 2) & 3, g = lane >> 4;
@@ -84,7 +86,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__res
     }
     int moff[KBS];
 #pragma unroll
-    for (int kb = 0; kb < KBS; kb++) moff[kb] = (q >> 1) * 2 * KP + ((kb * 4 + g) * 4 + c) * 4;      // my column group's image, in dwords
+    for (int kb = 0; kb < KBS; kb++) moff[kb] = (q >> 1) * LO + ((kb * 4 + g) * 4 + c) * 4;      // my column group's image, in dwords
     // my neuron u = 16w + 4g + q -> K block w >> 1, half w & 1, k group g, r = q
     const int u0 = 16 * w + 4 * g + q;
     const bool uok = u0 < n;
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__res
             const _Float16 h16 = (_Float16)hv;
             const _Float16 l16 = (_Float16)(hv - (float)h16);
             reinterpret_cast<unsigned short *>(&rh_img[0])[wpos] = __builtin_bit_cast(unsigned short, h16);
-            reinterpret_cast<unsigned short *>(&rh_img[2 * KP])[wpos] = __builtin_bit_cast(unsigned short, l16);
+            reinterpret_cast<unsigned short *>(&rh_img[LO])[wpos] = __builtin_bit_cast(unsigned short, l16);
         }
         const float zg = sigmoid4(fmaf(pick_mix(accZ), inv_z, cur.z));
         // ---- barrier B: r * h(s-1) is in its image ----
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__res
             const _Float16 h16 = (_Float16)hv;
             const _Float16 l16 = (_Float16)(hv - (float)h16);
             reinterpret_cast<unsigned short *>(&h_img[0])[wpos] = __builtin_bit_cast(unsigned short, h16);
-            reinterpret_cast<unsigned short *>(&h_img[2 * KP])[wpos] = __builtin_bit_cast(unsigned short, l16);
+            reinterpret_cast<unsigned short *>(&h_img[LO])[wpos] = __builtin_bit_cast(unsigned short, l16);
         }
         if (live && s < Tc && uok) hp[0] = hn;
         hp += hstep;

@@ -42,7 +42,9 @@ __global__ void __launch_bounds__(256, LF_OCC) lstm_fused16_kernel(const float *
     constexpr int N = 64, KBS = N / 32;
     constexpr int XIMG = KBLK * 4 * 16 * 4;              // dwords of one x operand image: [k block][k group][column = 4 step + chunk][4 dwords]
 
-    __shared__ __attribute__((aligned(16))) unsigned h_img[2][2 * 2 * N];          // lstm_scan16.hip
+    // (the lo image 32 banks behind the hi image: gru_bar16.hip)
+    constexpr int LO = 2 * N + (2 * N % 64 == 32 ? 0 : 32);
+    __shared__ __attribute__((aligned(16))) unsigned h_img[2][LO + 2 * N];         // lstm_scan16.hip
     __shared__ __attribute__((aligned(16))) unsigned xop[2][2 * XIMG];              // [group parity][hi image | lo image]
     __shared__ __attribute__((aligned(16))) float xinv[2][16];                      // inverse row scales of the staged x rows
     __shared__ __attribute__((aligned(16))) float vbuf[2][4 * 4 * N * 4];           // [group parity][step][chunk][unit][gate]
@@ -50,7 +52,7 @@ __global__ void __launch_bounds__(256, LF_OCC) lstm_fused16_kernel(const float *
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * 4;
-    for (int i = tid; i < 2 * 2 * N; i += 256) { h_img[0][i] = 0u; h_img[1][i] = 0u; }
+    for (int i = tid; i < LO + 2 * N; i += 256) { h_img[0][i] = 0u; h_img[1][i] = 0u; }
     for (int i = tid; i < 2 * XIMG; i += 256) { xop[0][i] = 0u; xop[1][i] = 0u; }
     auto ldH = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
 
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(256, LF_OCC) lstm_fused16_kernel(const float *
     }
     int moff[KBS];
 #pragma unroll
-    for (int kb = 0; kb < KBS; kb++) moff[kb] = (q >> 1) * 2 * N + ((kb * 4 + g) * 4 + c) * 4;
+    for (int kb = 0; kb < KBS; kb++) moff[kb] = (q >> 1) * LO + ((kb * 4 + g) * 4 + c) * 4;
     const int u0 = 16 * w + 4 * g + q;
     const bool uok = u0 < n;
     const float p0 = (peep && uok) ? peep[u0] : 0.0f, p1 = (peep && uok) ? peep[n + u0] : 0.0f, p2 = (peep && uok) ? peep[2 * n + u0] : 0.0f;
@@ -296,7 +298,7 @@ __global__ void __launch_bounds__(256, LF_OCC) lstm_fused16_kernel(const float *
             const _Float16 hh = (_Float16)hv;
             const _Float16 hl = (_Float16)(hv - (float)hh);
             reinterpret_cast<unsigned short *>(&h_img[par ^ 1][wdw])[w & 1] = __builtin_bit_cast(unsigned short, hh);
-            reinterpret_cast<unsigned short *>(&h_img[par ^ 1][2 * N + wdw])[w & 1] = __builtin_bit_cast(unsigned short, hl);
+            reinterpret_cast<unsigned short *>(&h_img[par ^ 1][LO + wdw])[w & 1] = __builtin_bit_cast(unsigned short, hl);
         }
         if constexpr (ph == 3) {
             project_out(gp ^ 1);                         // vW of group G+1: visible to everybody behind the next barrier
