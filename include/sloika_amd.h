@@ -484,6 +484,16 @@ SLK_API int slk_lstm_backward16_f32(const float *dy, long lddy, const float *gat
 SLK_API int slk_softmax_xent_grad_f32(float *logits, long ld, const float *stats, const int32_t *labels, const float *weights, int T,
                               int B, int nstate, int drop, float min_prob, float *loss_rows, float *correct_rows,
                               slk_stream_t stream);
+/* The softmax layer of a training step WITHOUT a logits tensor: the layer's products (pre-split weights, as for
+ * slk_linear_rowstats_f16x3) are computed twice -- a statistics pass that stores nothing but, per row, the loss term, the accuracy
+ * term and four floats in xrow:[M][4], and a gradient pass that stores grad:[M][ld] = dL/dlogits (columns N..ld-1 zero) -- instead
+ * of written, read, overwritten and read again.  Same values bit for bit as slk_linear_rowstats_f16x3 followed by
+ * slk_softmax_xent_grad_f32.  M = T * B; K in 49..64 or 81..128, N <= 2048, ld <= N rounded up to 64, xrow 16-byte aligned;
+ * SLK_ERR_UNSUPPORTED otherwise (-> the two calls above). */
+SLK_API int slk_linear_xent_grad_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
+                               const float *bias, float *grad, long ld, int K, int N, const int32_t *labels, const float *weights,
+                               int T, int B, int drop, float min_prob, float *loss_rows, float *correct_rows, float *xrow,
+                               slk_stream_t stream);
 SLK_API int slk_reduce_sum_f32(const float *x, size_t n, int square, double *out, slk_stream_t stream);
 SLK_API size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2);
 SLK_API int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,

@@ -91,6 +91,7 @@ PROTOTYPES = {
     "slk_lstm_backward_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_lstm_backward16_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_softmax_xent_grad_f32": (_i, [_vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "slk_linear_xent_grad_f16x3": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "slk_reduce_sum_f32": (_i, [_vp, _sz, _i, _vp, _vp]),
     "slk_gemm_tn_workspace_bytes": (_sz, [_l, _i, _i]),
     "slk_gemm_tn_f32": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _vp, _vp, _sz, _vp]),

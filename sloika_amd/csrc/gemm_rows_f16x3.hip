@@ -98,15 +98,32 @@ extern "C" int slk_split_f16x2_f32(const float *w, int rows, int K, void *hi, vo
 #ifndef GH_TRSTORE
 #define GH_TRSTORE true
 #endif
-template <int KS, bool STATS, int ACT, bool TRSTORE = GH_TRSTORE>
+// XM (the softmax layer of the training step, train_network.py:128-136, as two passes over the SAME products instead of a logits
+// tensor that is written, read, overwritten with its gradient and read again):
+//   1  statistics pass: no logits are stored.  Per row: maximum, 1 / sum of exp(l - maximum), the first column that attains the
+//      maximum (T.argmax's rule) and the logit of the row's label, and from them the row's loss term, its accuracy term and
+//      the coefficient of its gradient -- the arithmetic of softmax_xent_grad_kernel (train.hip), which this pair replaces --
+//      leaving xrow[row] = {maximum, 1 / sum, coefficient, label}
+//   2  gradient pass: the element stored is coefficient * (p - [column == label]), p = exp(l - maximum) / sum, with l the
+//      same product bit for bit; columns N .. ldy - 1 are written as zeros (the gradient is contracted with a padded row length)
+struct XentArgs {
+    float4 *xrow;                  // [M] pass 1 writes, pass 2 reads
+    const int32_t *labels;         // [M] = [T][B]
+    const float *weights;          // [M]
+    float *loss_rows, *correct_rows;
+    int T, B, drop;
+    float min_prob;
+};
+template <int KS, bool STATS, int ACT, bool TRSTORE = GH_TRSTORE, int XM = 0>
 __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float *__restrict__ x, long ldx,
                                                               const _Float16 *__restrict__ Whi,
                                                               const _Float16 *__restrict__ Wlo,
                                                               const float *__restrict__ winv,
                                                               const float *__restrict__ bias, float *__restrict__ y,
                                                               long ldy, long M, int K, int N,
-                                                              float2 *__restrict__ stats)
+                                                              float2 *__restrict__ stats, XentArgs xa)
 {
+    static_assert(XM == 0 || (ACT == SLK_ACT_LINEAR && (XM == 1) == STATS), "cross-entropy passes: linear logits, statistics in pass 1");
     constexpr int KP = 16 * KS;                    // padded K (halves per weight row in Whi/Wlo)
     constexpr int LD = KP + 8;                     // LDS row stride in halves: (KP+8)*2 B = odd multiple of 16 B
     constexpr int RING = (KS <= 9 && GH_RINGMAX >= 3) ? 3 : 2;          // weight-tile slots (a tile is 64 x (KP+8) halves, twice): LDS budget
@@ -115,10 +132,12 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
     __shared__ __attribute__((aligned(16))) _Float16 wsh[RING][GH_BN * LD];
     __shared__ __attribute__((aligned(16))) _Float16 wsl[RING][GH_BN * LD];
     __shared__ float2 red[2][GH_BM];
+    __shared__ int redarg[XM == 1 ? 2 : 1][XM == 1 ? GH_BM : 1];
+    __shared__ float redlab[XM == 1 ? GH_BM : 1];
     __shared__ __attribute__((aligned(16))) float bias_lds[BIAS_MAX];   // zero padded to whole tiles
     __shared__ __attribute__((aligned(16))) float winv_lds[BIAS_MAX];   // inverse scales of the weight rows (= columns here)
     constexpr int TP = 36;                          // floats per row of a wave's 32 x 32 store patch (144 B: no bank clash)
-    constexpr bool TR = TRSTORE && KS <= (GH_NWM > 4 ? 6 : 8);         // (K > 128: the weight ring leaves no room for the patches)
+    constexpr bool TR = TRSTORE && XM != 1 && KS <= (GH_NWM > 4 ? 6 : 8);         // (K > 128: the weight ring leaves no room for the patches)
     __shared__ __attribute__((aligned(16))) float patch[TR ? 2 * GH_NWM * 32 * TP : 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -224,6 +243,26 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
     float *const yrow = y + (rowok ? row : 0) * ldy + 32 * wn + 4 * h;
     const bool vec_ok = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
     float rmax = -INFINITY, rsum = 0.0f;           // online softmax statistics of this lane's share of the row
+    int rarg = 0x7fffffff;                         // XM 1: first column of this lane's share that attains rmax
+    float xmx = 0.0f, xinvs = 0.0f, xcoef = 0.0f;  // XM 2: the row's maximum, 1 / sum, coefficient
+    int xlabel = -1;
+    float llab = 0.0f;                             // XM 1: the label's logit, in the one lane of the row's four that meets it
+    bool lfound = false;
+    if constexpr (XM == 1) xlabel = xa.labels[rowok ? row : M - 1];
+    if constexpr (XM == 2) {
+        const float4 rc = xa.xrow[rowok ? row : M - 1];
+        xmx = rc.x; xinvs = rc.y; xcoef = rc.z; xlabel = __float_as_int(rc.w);
+    }
+    auto note_label = [&](const f32x16 &acc, int cbase) {
+#pragma unroll
+        for (int reg = 0; reg < 16; reg++) {
+            const bool hit = cbase + 8 * (reg >> 2) + (reg & 3) == xlabel;
+            llab = hit ? acc[reg] : llab;
+            lfound |= hit;
+        }
+    };
+    // XM 2: logit -> gradient element
+    auto xgrad = [&](float l, int col) { return xcoef * (__expf(l - xmx) * xinvs - (col == xlabel ? 1.0f : 0.0f)); };
 
     tile_barrier();                                                // (P)
     // Software pipeline: the epilogue of tile nt-1 (stores, statistics) is in the same straight-line block as the MFMA
@@ -279,7 +318,13 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) o[reg] = slk_act_t<ACT>(acc[reg]);
         }
-        if (tile_full && vec_ok) {
+        if constexpr (XM == 2) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) o[reg] = xgrad(acc[reg], cbase + 8 * (reg >> 2) + (reg & 3));
+        }
+        if constexpr (XM == 1) {
+            // nothing is stored
+        } else if (tile_full && vec_ok) {
             if (rowok) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
@@ -291,8 +336,11 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
             for (int q = 0; q < 4; q++) {
                 float *dst = yrow + nt * GH_BN + 8 * q;
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (cbase + 8 * q + i < N) dst[i] = o[4 * q + i];
+                for (int i = 0; i < 4; i++) {
+                    const int col = cbase + 8 * q + i;
+                    if (col < N) dst[i] = o[4 * q + i];
+                    else if (XM == 2 && col < ldy) dst[i] = 0.0f;
+                }
             }
         }
         if (STATS) {
@@ -304,6 +352,19 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
                 tm = fmaxf(tm, ok ? acc[reg] : -INFINITY);
             }
             const float mn = fmaxf(rmax, tm);
+            if constexpr (XM == 1) {
+                // first column of the tile that attains its maximum (columns rise with reg; scanned downwards, the smallest wins);
+                // a tile only takes over from the earlier ones -- whose columns are all smaller -- when it is strictly larger
+                int ti = 0x7fffffff;
+#pragma unroll
+                for (int reg = 15; reg >= 0; reg--) {
+                    const int col = cbase + 8 * (reg >> 2) + (reg & 3);
+                    const bool ok = full || col < N;
+                    ti = (ok && acc[reg] == tm) ? col : ti;
+                }
+                rarg = tm > rmax ? ti : rarg;
+                note_label(acc, cbase);
+            }
             if (mn > -INFINITY) {
                 float sum = (rmax == -INFINITY) ? 0.0f : rsum * __expf(rmax - mn);
 #pragma unroll
@@ -325,7 +386,14 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) o[reg] = slk_act_t<ACT>(acc[reg]);
         }
-        if constexpr (TR) {
+        if constexpr (XM == 2) {
+            const int cbase = nt * GH_BN + 32 * wn + 4 * h;
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) o[reg] = xgrad(acc[reg], cbase + 8 * (reg >> 2) + (reg & 3));
+        }
+        if constexpr (XM == 1) {
+            // nothing is stored
+        } else if constexpr (TR) {
             // my 16 values -> patch[row r][column 8q + 4h + i]; then lane l takes 16 bytes of row 8i + (l >> 3), so that
             // eight lanes cover the 128 bytes of a row and one instruction writes eight whole lines
             float *pw = patch + wave * (32 * TP);
@@ -348,6 +416,14 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
             float tm = acc[0];
 #pragma unroll
             for (int reg = 1; reg < 16; reg++) tm = fmaxf(tm, acc[reg]);
+            if constexpr (XM == 1) {
+                const int cbase = nt * GH_BN + 32 * wn + 4 * h;
+                int ti = 0x7fffffff;
+#pragma unroll
+                for (int reg = 15; reg >= 0; reg--) ti = acc[reg] == tm ? cbase + 8 * (reg >> 2) + (reg & 3) : ti;
+                rarg = tm > rmax ? ti : rarg;
+                note_label(acc, cbase);
+            }
             const float mn = fmaxf(rmax, tm);
             const float ms = fmaxf(mn, -3.0e38f);                  // all -inf so far: exp(-inf - ms) = 0, no NaN
             float sum = rsum * __expf(fmaxf(rmax, -3.0e38f) - ms);  // rsum = 0 while rmax = -inf
@@ -362,8 +438,8 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
 #pragma unroll
         for (int i = 0; i < 3 * KS; i++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, STATS ? 5 : 1, 0);   // VALU
-            if (STATS) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);    // one transcendental
+            __builtin_amdgcn_sched_group_barrier(0x002, (STATS || XM == 2) ? 5 : 1, 0);   // VALU
+            if (STATS || XM == 2) __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);    // one transcendental
         }
     };
     // two accumulator sets swap roles statically (loop unrolled by two): no register copies between tiles
@@ -426,20 +502,45 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
         // combine the two column halves (lanes l and l^32 hold the same row), then the two column waves
         {
             const float om = __shfl_xor(rmax, 32), os = __shfl_xor(rsum, 32);
+            const int oa = __shfl_xor(rarg, 32);
             const float mn = fmaxf(rmax, om);
             const float sa = (rmax == -INFINITY) ? 0.0f : rsum * __expf(rmax - mn);
             const float sb = (om == -INFINITY) ? 0.0f : os * __expf(om - mn);
+            rarg = om > rmax ? oa : (om == rmax ? min(rarg, oa) : rarg);
             rsum = sa + sb;
             rmax = mn;
         }
-        if (h == 0) red[wn][32 * wm + r] = make_float2(rmax, rsum);
+        if (h == 0) {
+            red[wn][32 * wm + r] = make_float2(rmax, rsum);
+            if constexpr (XM == 1) redarg[wn][32 * wm + r] = rarg;
+        }
+        if constexpr (XM == 1) {
+            if (lfound) redlab[32 * wm + r] = llab;
+        }
         tile_barrier();
         if (tid < GH_BM && m0 + tid < M) {
             const float2 p0 = red[0][tid], p1 = red[1][tid];
             const float mn = fmaxf(p0.x, p1.x);
             const float s = ((p0.x == -INFINITY) ? 0.0f : p0.y * __expf(p0.x - mn)) +
                             ((p1.x == -INFINITY) ? 0.0f : p1.y * __expf(p1.x - mn));
-            stats[m0 + tid] = make_float2(mn, 1.0f / s);
+            if constexpr (XM == 1) {
+                const int a0 = redarg[0][tid], a1 = redarg[1][tid];
+                const int arg = p1.x > p0.x ? a1 : (p1.x == p0.x ? min(a0, a1) : a0);
+                // the row's terms of train_network.py:128-136 (as softmax_xent_grad_kernel computes them)
+                const long m = m0 + tid;
+                const int t = (int)(m / xa.B), label = xa.labels[m];
+                const bool counted = t >= xa.drop && t < xa.T - xa.drop;
+                const float count = (float)(xa.T - 2 * xa.drop) * (float)xa.B, inv = 1.0f / s;
+                const float p_lab = __expf(redlab[tid] - mn) * inv;
+                const float post_lab = xa.min_prob + (1.0f - xa.min_prob) * p_lab;
+                const float w = counted ? xa.weights[m] / count : 0.0f;
+                const float coef = w * (1.0f - xa.min_prob) * p_lab / post_lab;
+                xa.loss_rows[m] = counted ? -w * logf(post_lab) : 0.0f;
+                xa.correct_rows[m] = (counted && arg == label) ? 1.0f / count : 0.0f;
+                xa.xrow[m] = make_float4(mn, inv, coef, __int_as_float(label));
+            } else {
+                stats[m0 + tid] = make_float2(mn, 1.0f / s);
+            }
         }
     }
 }
@@ -450,7 +551,7 @@ static int launch_f16x3(const float *x, long ldx, const _Float16 *hi, const _Flo
 {
     dim3 grid((unsigned)((M + GH_BM - 1) / GH_BM)), block(GH_THREADS);
 #define F16X3_LAUNCH(ST, A) \
-    hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, ST, A>), grid, block, 0, s, x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, stats)
+    hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, ST, A>), grid, block, 0, s, x, ldx, hi, lo, winv, bias, y, ldy, M, K, N, stats, XentArgs{})
     if (stats) F16X3_LAUNCH(true, SLK_ACT_LINEAR);
     else if (act == SLK_ACT_LINEAR) F16X3_LAUNCH(false, SLK_ACT_LINEAR);
     else if (act == SLK_ACT_TANH) F16X3_LAUNCH(false, SLK_ACT_TANH);
@@ -505,4 +606,44 @@ extern "C" int slk_gemm_bias_act_f16x3(const float *x, long ldx, const void *W_h
                                        const float *bias, float *y, long ldy, long M, int K, int N, int act, slk_stream_t stream)
 {
     return dispatch_f16x3(x, ldx, W_hi, W_lo, W_inv_scale, bias, y, ldy, M, K, N, nullptr, act, stream);
+}
+
+// The softmax layer of a training step without a logits tensor (train_network.py:128-136): pass 1 computes the products and keeps
+// only the rows' statistics, loss and accuracy terms; pass 2 computes them again and stores d loss / d logits [M][ld] (columns
+// N .. ld - 1 zero).  Against logits -> statistics -> gradient in place (slk_linear_rowstats_f16x3 + slk_softmax_xent_grad_f32) the
+// logits are neither written nor read back: 4 M ld bytes of traffic instead of 12 M ld, for 6 M N K more fp16 products.
+// xrow: scratch of 4 M floats (16-byte aligned).  The usual layer widths only (K in 49..128): SLK_ERR_UNSUPPORTED otherwise.
+template <int KS>
+static int launch_xent(const float *x, long ldx, const _Float16 *hi, const _Float16 *lo, const float *winv, const float *bias, float *grad,
+                       long ld, long M, int K, int N, const XentArgs &xa, hipStream_t s)
+{
+    dim3 grid((unsigned)((M + GH_BM - 1) / GH_BM)), block(GH_THREADS);
+    hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, true, SLK_ACT_LINEAR, GH_TRSTORE, 1>), grid, block, 0, s, x, ldx, hi, lo, winv, bias, grad, ld,
+                       M, K, N, (float2 *)nullptr, xa);
+    hipLaunchKernelGGL((gemm_rows_f16x3_kernel<KS, false, SLK_ACT_LINEAR, GH_TRSTORE, 2>), grid, block, 0, s, x, ldx, hi, lo, winv, bias, grad, ld,
+                       M, K, N, (float2 *)nullptr, xa);
+    return slk_launch_status();
+}
+
+extern "C" int slk_linear_xent_grad_f16x3(const float *x, long ldx, const void *W_hi, const void *W_lo, const float *W_inv_scale,
+                                          const float *bias, float *grad, long ld, int K, int N, const int32_t *labels,
+                                          const float *weights, int T, int B, int drop, float min_prob, float *loss_rows,
+                                          float *correct_rows, float *xrow, slk_stream_t stream)
+{
+    if (!x || !W_hi || !W_lo || !W_inv_scale || !grad || !labels || !weights || !loss_rows || !correct_rows || !xrow || T < 1 || B < 1 ||
+        K < 1 || N < 1 || ldx < K || ld < N || drop < 0 || 2 * drop >= T || !(min_prob >= 0.0f && min_prob < 1.0f) ||
+        (reinterpret_cast<uintptr_t>(xrow) & 15) != 0)
+        return SLK_ERR_INVALID_ARG;
+    const long M = (long)T * B;
+    if ((M + GH_BM - 1) / GH_BM > 0x7fffffffL || N > GH_BIASMAX || ld > ((long)(N + GH_BN - 1) / GH_BN) * GH_BN) return SLK_ERR_UNSUPPORTED;
+    const _Float16 *hi = static_cast<const _Float16 *>(W_hi), *lo = static_cast<const _Float16 *>(W_lo);
+    XentArgs xa{reinterpret_cast<float4 *>(xrow), labels, weights, loss_rows, correct_rows, T, B, drop, min_prob};
+    hipStream_t s = slk_stream(stream);
+    switch ((K + 15) / 16) {
+    case 4: return launch_xent<4>(x, ldx, hi, lo, W_inv_scale, bias, grad, ld, M, K, N, xa, s);
+    case 6: return launch_xent<6>(x, ldx, hi, lo, W_inv_scale, bias, grad, ld, M, K, N, xa, s);
+    case 7: return launch_xent<7>(x, ldx, hi, lo, W_inv_scale, bias, grad, ld, M, K, N, xa, s);
+    case 8: return launch_xent<8>(x, ldx, hi, lo, W_inv_scale, bias, grad, ld, M, K, N, xa, s);
+    default: return SLK_ERR_UNSUPPORTED;
+    }
 }

@@ -108,6 +108,8 @@ def _stream():
 #:                             no_gru64_share   64-wide Gru layers never two workgroups per CU
 #:                             no_fused_decode  Softmax writes the logits, csrc/decode.hip reads them (pipeline.FUSED_DECODE)
 #:                             bf16_ff_max=N    widest FeedForward output on csrc/gemm_bf16x6.hip
+#:                             xent_in_place    training: logits written, then the loss gradient in place over them (train.hip)
+#:                                              instead of the two passes that never store logits (train.XENT_TWO_PASS)
 _DEBUG = dict((t.partition("=")[0], t.partition("=")[2]) for t in os.environ.get("SLOIKA_AMD_DEBUG", "").split(",") if t)
 #: Time-parallel projections (softmax, and the input projections of recurrent layers that have no fused kernel) run on the
 #: FP16 matrix pipe as a 3-term split of every float32 operand (csrc/gemm_rows_f16x3.hip: float32 accumulation, error a few

@@ -122,6 +122,8 @@ def _unwrap(layer, rev=False):
     return layer, rev
 
 
+#: the softmax layer's loss gradient from two passes over its products, no logits in memory (csrc/gemm_rows_f16x3.hip)
+XENT_TWO_PASS = "xent_in_place" not in layers._DEBUG
 _FF_ACTS = ("linear", "tanh", "sigmoid", "relu", "elu")     # activations whose derivative is a function of the output
 
 
@@ -306,7 +308,6 @@ class TrainingStep(object):
         sm = self.softmax
         To = int(h_top.shape[0])
         M = To * B
-        logits, stats, ld = sm.logits_and_stats(h_top)
         labels = D.to_dev(np.ascontiguousarray(labels) if not isinstance(labels, torch.Tensor) else labels, torch.int32)
         weights = D.to_dev(weights)
         if tuple(labels.shape) != (To, B) or tuple(weights.shape) != (To, B):
@@ -318,10 +319,14 @@ class TrainingStep(object):
         # ---- loss, accuracy, d loss / d logits (in place) -------------------------------------------------------------
         rows = torch.empty((2, M), dtype=torch.float32, device=x.device)
         sc = self._scalars
-        with profiler.region("train_xent", 0.0, 8.0 * M * ld):
-            _lib.check(L.slk_softmax_xent_grad_f32(logits.data_ptr(), ld, stats.data_ptr(), labels.data_ptr(),
-                                                   weights.data_ptr(), To, B, sm.size, self.drop, self.min_prob,
-                                                   rows[0].data_ptr(), rows[1].data_ptr(), st()), "softmax_xent")
+        logits, ld = self._softmax_grad_two_pass(h_top, labels, weights, rows)
+        if logits is None:
+            logits, stats, ld = sm.logits_and_stats(h_top)
+            with profiler.region("train_xent", 0.0, 8.0 * M * ld):
+                _lib.check(L.slk_softmax_xent_grad_f32(logits.data_ptr(), ld, stats.data_ptr(), labels.data_ptr(),
+                                                       weights.data_ptr(), To, B, sm.size, self.drop, self.min_prob,
+                                                       rows[0].data_ptr(), rows[1].data_ptr(), st()), "softmax_xent")
+        with profiler.region("train_xent_sums", 0.0, 8.0 * M):
             _lib.check(L.slk_reduce_sum_f32(rows[0].data_ptr(), M, 0, sc[0:].data_ptr(), st()), "reduce")
             _lib.check(L.slk_reduce_sum_f32(rows[1].data_ptr(), M, 0, sc[1:].data_ptr(), st()), "reduce")
             if self.l2 != 0.0:
@@ -350,6 +355,31 @@ class TrainingStep(object):
         s = sc.cpu().numpy()
         loss = float(s[0]) * self.gscale + (self.l2 * float(s[2]) if self.l2 != 0.0 else 0.0)
         return loss, float(s[1]) * self.gscale
+
+    def _softmax_grad_two_pass(self, h_top, labels, weights, rows):
+        """(d loss / d logits [M][ld], ld) with the rows' loss and accuracy terms in rows[0], rows[1] -- or (None, None) where the
+        two-pass kernel does not apply (csrc/gemm_rows_f16x3.hip: the layer's products are computed twice and the logits never
+        exist in memory; 4 M ld bytes of traffic where logits -> gradient in place -> two readers move 12 M ld)."""
+        import torch
+        sm = self.softmax
+        if not (sm.split_f16 and sm.insize <= 128 and sm.size <= 2048) or not XENT_TWO_PASS:
+            return None, None
+        To, B = int(h_top.shape[0]), int(h_top.shape[1])
+        M, L = To * B, _lib.lib()
+        ld = ((sm.size + 31) // 32) * 32
+        grad = torch.empty((M, ld), dtype=torch.float32, device=h_top.device)
+        xrow = torch.empty((M, 4), dtype=torch.float32, device=h_top.device)
+        hi, lo, inv = sm._split_weights()
+        flops = 2.0 * M * sm.insize * sm.size
+        with profiler.region("train_softmax_xent", 2.0 * flops, 4.0 * M * (2 * sm.insize + ld), f16x3_flops=2.0 * flops):
+            rc = L.slk_linear_xent_grad_f16x3(h_top.data_ptr(), layers._row_stride(h_top), hi.data_ptr(), lo.data_ptr(), inv.data_ptr(),
+                                              sm.b.dev().data_ptr(), grad.data_ptr(), ld, sm.insize, sm.size, labels.data_ptr(),
+                                              weights.data_ptr(), To, B, self.drop, self.min_prob, rows[0].data_ptr(),
+                                              rows[1].data_ptr(), xrow.data_ptr(), layers._stream())
+        if rc == _lib.SLK_ERR_UNSUPPORTED:
+            return None, None
+        _lib.check(rc, "softmax_xent (two passes)")
+        return grad, ld
 
     def _forward(self, layer, x, rev):
         """(output, tape): run `layer` on the inference kernels and keep what its reverse pass needs."""

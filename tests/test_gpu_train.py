@@ -453,3 +453,80 @@ def test_training_edge_cases():
         after = [p.get_value() for p in net.params()]
         assert np.isfinite(last) and last < first
         assert all(np.isfinite(a).all() for a in after) and any(np.abs(a - b).max() > 0 for a, b in zip(after, before))
+
+
+@pytest.mark.parametrize("K,N,T,B,drop,min_prob", [
+    (96, 1025, 83, 7, 2, 1e-30),       # the headline layer; 581 rows: ragged last workgroup, partial last column tile
+    (64, 1025, 40, 16, 0, 1e-5),       # 640 rows: whole workgroups (the branch-free epilogue)
+    (112, 260, 33, 5, 3, 0.0),
+    (128, 17, 50, 4, 1, 1e-3),         # one partial tile only
+    (96, 1024, 16, 8, 0, 1e-30),       # exactly sixteen full tiles, ld == N
+])
+def test_softmax_loss_gradient_two_passes_equal_in_place(K, N, T, B, drop, min_prob):
+    """slk_linear_xent_grad_f16x3 (two passes over the products, no logits in memory) against the pair it replaces
+    (slk_linear_rowstats_f16x3, then slk_softmax_xent_grad_f32 in place): the same bits, including the first-maximum rule of
+    T.argmax on rows with ties and the zeroed padding columns."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(K + N)
+    M, ld, kp = T * B, (N + 31) // 32 * 32, (K + 15) // 16 * 16
+    x = rs.normal(size=(M, K)).astype(np.float32)
+    W = (rs.normal(size=(N, K)) * 0.4).astype(np.float32)
+    b = rs.normal(size=N).astype(np.float32)
+    W[N - 3] = W[2]; b[N - 3] = b[2]                           # two columns with identical logits in every row ...
+    labels = rs.randint(0, N, size=M).astype(np.int32)
+    r0 = M // 2                                                # (a counted row: drop <= t < T - drop)
+    x[r0] = 0.0; b[2] = b[N - 3] = b.max() + 1.0              # ... and they hold the maximum of many rows (always of row r0)
+    labels[r0], labels[r0 + 1], labels[r0 + 2] = 2, N - 3, N - 1
+    weights = rs.uniform(0.5, 1.5, size=M).astype(np.float32)
+    xd, Wd, bd, ld_, wd = dev(x), dev(W), dev(b), dev(labels), dev(weights)
+    hi = torch.empty((N, kp), dtype=torch.float16, device="cuda"); lo = torch.empty_like(hi)
+    inv = torch.empty(N, dtype=torch.float32, device="cuda")
+    _lib.check(L.slk_split_f16x2_f32(Wd.data_ptr(), N, K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), stream()), "split")
+    # the pair
+    logits = torch.full((M, ld), 7.0, dtype=torch.float32, device="cuda")
+    stats = torch.empty((M, 2), dtype=torch.float32, device="cuda")
+    rows_a = torch.empty((2, M), dtype=torch.float32, device="cuda")
+    _lib.check(L.slk_linear_rowstats_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), bd.data_ptr(),
+                                           logits.data_ptr(), ld, M, K, N, stats.data_ptr(), stream()), "rowstats")
+    _lib.check(L.slk_softmax_xent_grad_f32(logits.data_ptr(), ld, stats.data_ptr(), ld_.data_ptr(), wd.data_ptr(), T, B, N, drop,
+                                           min_prob, rows_a[0].data_ptr(), rows_a[1].data_ptr(), stream()), "xent")
+    # the two passes
+    grad = torch.full((M, ld), 7.0, dtype=torch.float32, device="cuda")
+    rows_b = torch.empty((2, M), dtype=torch.float32, device="cuda")
+    xrow = torch.empty((M, 4), dtype=torch.float32, device="cuda")
+    _lib.check(L.slk_linear_xent_grad_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), bd.data_ptr(),
+                                            grad.data_ptr(), ld, K, N, ld_.data_ptr(), wd.data_ptr(), T, B, drop, min_prob,
+                                            rows_b[0].data_ptr(), rows_b[1].data_ptr(), xrow.data_ptr(), stream()), "two passes")
+    torch.cuda.synchronize()
+    assert torch.equal(rows_a, rows_b)
+    assert torch.equal(grad, logits)
+    assert float(rows_b[1][r0]) > 0.0                          # the FIRST of the tied maxima is the label: counted correct
+    assert not bool((grad[:, N:] != 0).any())
+    # K outside the instantiated widths is refused, not computed some other way
+    rc = L.slk_linear_xent_grad_f16x3(xd.data_ptr(), K, hi.data_ptr(), lo.data_ptr(), inv.data_ptr(), bd.data_ptr(), grad.data_ptr(), ld,
+                                      32, N, ld_.data_ptr(), wd.data_ptr(), T, B, drop, min_prob, rows_b[0].data_ptr(),
+                                      rows_b[1].data_ptr(), xrow.data_ptr(), stream())
+    assert rc == _lib.SLK_ERR_UNSUPPORTED
+
+
+def test_training_step_two_pass_softmax_equals_in_place():
+    """TrainingStep.forward_backward with and without train.XENT_TWO_PASS: same loss, accuracy and gradients bit for bit."""
+    need_gpu()
+    from sloika_amd import train
+    rs = np.random.RandomState(11)
+    net = _build(rs, n=96, nstate=1025, stride=5, winlen=11, nlayer=2)
+    x, labels, weights = _batch(rs, net, 200, 6)
+    step = train.TrainingStep(net, min_prob=1e-30, drop=2)
+    res = []
+    for flag in (True, False):
+        train.XENT_TWO_PASS = flag
+        try:
+            la = step.forward_backward(x, labels, weights)
+        finally:
+            train.XENT_TWO_PASS = True
+        res.append((la, [g.copy() for g in step.gradients()]))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1], res[1][1]):
+        np.testing.assert_array_equal(a, b)
