@@ -14,10 +14,12 @@
 //
 // Gradients have no natural range (the forward state lives in [-1, 1]; these may be 1e-9 or 1e+3), so every image is scaled by a
 // power of two per chunk and step.  lstm_bwd16.hip spends a barrier on the exact maximum; with two products that would be four
-// barriers per step, so here the scale comes from a BOUND that every wave can form from numbers exchanged at the two barriers the
-// step has anyway -- |dac|, 2 |daz| <= |g| <= max|dy_t + keep| + C1 max|dzr_{t+1}| and 4 |dar| <= |drh| <= C2 max|g| with
-// C1, C2 the largest column sums of |sW|, |sW2| -- and maps the bound to 2^14 (fp16 reaches 2^16): rigorous against overflow, and
-// loose by a few bits at most, which the 22 bits of the hi/lo pair absorb.
+// barriers per step, so here the scale comes from a BOUND that every wave can form from ONE number per chunk exchanged at a barrier
+// the step has anyway -- |dac|, 2 |daz| <= |g| <= Gb := 2 max_u (|dy_t + keep| + C1 |dzr_{t+1}|) and 4 |dar| <= |drh| <= C2 Gb with
+// C1, C2 the largest column sums of |sW|, |sW2| -- and maps the bound to 2^14 (fp16 reaches 2^16): rigorous against overflow.  It is
+// loose by a handful of bits (worst-case column sums where the products average out); what that costs is the range over which the
+// lo half stays a normal number, i.e. an absolute error of 2^-25 of the BOUND on the smallest entries -- 2^-39+L relative to the
+// largest entry for a bound L bits loose: float32-grade up to L = 15.
 //
 // Per step a lane reads dy, z, r, h_t, h_prev of its unit: asm loads the kernel counts itself (gru_scan16.hip), four steps ahead.
 #include <limits.h>
@@ -79,7 +81,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
     // [step parity][chunk]: max |dy + keep|, max |dzr|, max |g| over ALL units of a chunk, as the bits of non-negative floats (which
     // order like unsigned integers): every lane adds its value with one LDS atomic maximum.  (Reducing inside the wave first -- two
     // lane swaps and two DPP steps per quantity -- and reading one number per wave back cost 800-960 of a step's 2100-2850 cycles.)
-    __shared__ unsigned s_m[2][4], s_z[2][4], s_g[2][4];
+    __shared__ unsigned s_m[2][4];
     __shared__ float s_c[2][NW];                         // weight column sums, per wave
 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -87,7 +89,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
     for (int i = tid; i < CI + 2 * N; i += NTH) c_img[i] = 0u;
     for (int i = tid; i < ZI + 4 * N; i += NTH) z_img[i] = 0u;
     auto ldH = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
-    if (tid < 8) { s_m[tid >> 2][tid & 3] = 0u; s_z[tid >> 2][tid & 3] = 0u; s_g[tid >> 2][tid & 3] = 0u; }
+    if (tid < 8) s_m[tid >> 2][tid & 3] = 0u;
     auto amax = [](unsigned *slot, float v) { atomicMax(slot, __float_as_uint(fabsf(v))); };
 
     const int c = lane & 3, q = (lane >> 2) & 3, g = lane >> 4;
@@ -192,7 +194,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
     // before the first step: max |dy| of the first request (keep = 0, no image yet)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
     asm volatile("" : "+v"(vs[0].dy));
-    amax(&s_m[0][c], uok ? vs[0].dy : 0.0f);
+    amax(&s_m[0][c], uok ? 2.0f * vs[0].dy : 0.0f);
 
     auto step = [&](auto PHC, const int par) {           // one step of the pass; the i-th one (par = i & 1) handles scan step s = T-1-i
         constexpr int ph = decltype(PHC)::value;
@@ -204,12 +206,11 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
 #pragma unroll
         for (int kb = 0; kb < KB2; kb++) bz[kb] = ldH(z_img, moff2[kb]);
 #if GW_ABL & 4
-        const float M1 = 1.0f, Zm = 1.0f;
+        const float Gb = 1.0f;
 #else
-        const float M1 = __uint_as_float(s_m[par][c]), Zm = __uint_as_float(s_z[par][c]);
-        // the other parity's slots are empty again before they are filled: max |g| behind the next barrier X, the other two behind
-        // this step's barrier Y (all were read last a whole barrier ago)
-        if (tid < 4) { s_g[par ^ 1][tid] = 0u; s_m[par ^ 1][tid] = 0u; s_z[par ^ 1][tid] = 0u; }
+        const float Gb = __uint_as_float(s_m[par][c]);   // >= max |g| of this step over the chunk's units (see below)
+        // the other parity's slot is empty again before it is filled behind this step's barrier Y (it was read last a whole barrier ago)
+        if (tid < 4) s_m[par ^ 1][tid] = 0u;
 #endif
 #if !(GW_ABL & 2)
         load_v(vs[(ph + 4) % 5]);
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
         asm volatile("" : "+v"(cur.dy), "+v"(cur.z), "+v"(cur.r), "+v"(cur.ht), "+v"(cur.hp), "+v"(nxt.dy));
         mfma_drain(a2);                                  // pick_mix reads the accumulator from asm
         float invs1;
-        const float sc1 = gw_pow2_top(fmaf(C1, Zm, M1), invs1);
+        const float sc1 = gw_pow2_top(Gb, invs1);
         // csrc/train.hip, gru_backward_kernel
         const float p2 = pick_mix(a2) * inv2 * invs2;
         const float z = cur.z, r = cur.r, h = cur.hp;
@@ -241,9 +242,6 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
         }
 #endif
         {
-#if !(GW_ABL & 4)
-            amax(&s_g[par][c], gg);
-#endif
             float hv = dac * sc1;
             asm volatile("" : "+v"(hv));                 // split2's note on v_fma_mixlo_f16 applies
             const _Float16 h16 = (_Float16)hv;
@@ -256,11 +254,6 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
         half8 bm[KB1];
 #pragma unroll
         for (int kb = 0; kb < KB1; kb++) bm[kb] = ldH(c_img, moff1[kb]);
-#if GW_ABL & 4
-        const float Gm = 1.0f;
-#else
-        const float Gm = __uint_as_float(s_g[par][c]);
-#endif
         f32x4 a1;
         static_for<0, KB1>([&](auto KC) {
             constexpr int kb = decltype(KC)::value;
@@ -268,7 +261,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
             gw_mma<false>(a1, w1h[kb], bm[kb]);
         });
         mfma_drain(a1);
-        const float sc2 = gw_pow2_top(Gm * D2, invs2);
+        const float sc2 = gw_pow2_top(Gb * D2, invs2);
         const float drh = uok ? pick_mix(a1) * inv1 * invs1 : 0.0f;
         const float dar = drh * h * r * (1.0f - r);
         keep = gg * z + drh * r;
@@ -284,8 +277,11 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
         rhp += rhstep;
         {
 #if !(GW_ABL & 4)
-            amax(&s_z[par ^ 1][c], fmaxf(fabsf(daz), fabsf(dar)));
-            amax(&s_m[par ^ 1][c], uok ? nxt.dy + keep : 0.0f);
+            // |g| of the next step <= max_u |dy + keep| + C1 max_u |dzr| <= 2 max_u (|dy + keep| + C1 |dzr|): ONE number per chunk and
+            // step.  (Round 3 exchanged the two maxima and the exact max |g| as well: three atomics, 2260 cycles per step; one: 1950;
+            // none -- fixed scales, a timing experiment -- 1640.  Issuing it behind a barrier instead of in front of one, or from 16
+            // lanes after a reduction over the k groups, changes nothing or costs: tools/bwd16_variants.py.)
+            amax(&s_m[par ^ 1][c], uok ? 2.0f * fmaf(C1, fmaxf(fabsf(daz), fabsf(dar)), fabsf(nxt.dy + keep)) : 0.0f);
 #endif
             float v0 = daz * sc2, v1 = dar * sc2;
             asm volatile("" : "+v"(v0), "+v"(v1));
