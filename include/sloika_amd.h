@@ -496,6 +496,14 @@ SLK_API int slk_linear_xent_grad_f16x3(const float *x, long ldx, const void *W_h
                                slk_stream_t stream);
 SLK_API int slk_reduce_sum_f32(const float *x, size_t n, int square, double *out, slk_stream_t stream);
 SLK_API size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2);
+/* 1..4 contractions over the same M rows in ONE launch (the weight gradients of a recurrent layer all contract the same dL/d(pre-
+ * activation) matrix: launched together its rows cross the memory bus once): C[q] = A[q]^T B[q], colsum[q] (the array or an entry may be
+ * NULL) = A[q]^T 1.  The arrays have nprob entries and live in host memory.  Six bf16 terms per product as slk_gemm_tn_bf16x6_f32.
+ * SLK_ERR_UNSUPPORTED: rows longer than 4 M floats or slices beyond 32-bit byte offsets (-> one slk_gemm_tn_f32 per problem). */
+SLK_API size_t slk_gemm_tn_multi_workspace_bytes(long M, int nprob, const int *N1, const int *N2);
+SLK_API int slk_gemm_tn_multi_bf16x6_f32(int nprob, const float *const *A, const long *lda, const float *const *B, const long *ldb,
+                                 float *const *C, const long *ldc, long M, const int *N1, const int *N2, float *const *colsum,
+                                 void *workspace, size_t workspace_bytes, slk_stream_t stream);
 SLK_API int slk_gemm_tn_f32(const float *A, long lda, const float *B, long ldb, float *C, long ldc, long M, int N1, int N2,
                     float *colsum /* [N1] or NULL */, void *workspace, size_t workspace_bytes, slk_stream_t stream);
 /* The same contraction with every float32 operand cut into three bf16 pieces and each product evaluated as six bf16 MFMA terms

@@ -96,6 +96,8 @@ PROTOTYPES = {
     "slk_gemm_tn_workspace_bytes": (_sz, [_l, _i, _i]),
     "slk_gemm_tn_f32": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _vp, _vp, _sz, _vp]),
     "slk_gemm_tn_bf16x6_f32": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _vp, _vp, _sz, _vp]),
+    "slk_gemm_tn_multi_workspace_bytes": (_sz, [_l, _i, _vp, _vp]),
+    "slk_gemm_tn_multi_bf16x6_f32": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _vp, _sz, _vp]),
     "slk_act_backward_f32": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "slk_add_inplace_f32": (_i, [_vp, _vp, _sz, _vp]),
     "slk_train_im2col_cin1_f32": (_i, [_vp, _l, _l, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -19,6 +19,8 @@
 //   * softmax + weighted cross-entropy + its gradient is one pass over the logits (softmax_xent_grad_kernel), in place;
 //   * ADAMski (updates.py:36-89) is one element-wise kernel over the flat parameter / gradient / moment buffers; the
 //     data-parallel all-reduce of the flat gradient (RCCL) happens on the host side between the two.
+#include <type_traits>
+
 #include "common.h"
 #include "mfma4.h"
 
@@ -667,6 +669,9 @@ extern "C" int slk_reduce_sum_f32(const float *x, size_t n, int square, double *
 #define TN_WAVES 2048          /* waves wanted per launch: 256 CUs x 4 SIMDs x 2 */
 #define TN_BLK 96
 #define TN_UNROLL 4
+#ifndef TN_DEAL
+#define TN_DEAL 6              /* vector instructions asked for behind every MFMA of gemm_tn_bf16_kernel */
+#endif
 
 // Which block of C and which slice of rows this workgroup takes.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and
 // b + 8 share one; observed, speed only), each with an L2 of its own, and the g1 * g2 column blocks of ONE slice read the same rows
@@ -812,22 +817,26 @@ __device__ __forceinline__ void split_bf16x3(const float (&v)[8], bf16x8 &p1, bf
     p1 = o1.v; p2 = o2.v; p3 = o3.v;
 }
 
+// one 96 x 96 block (bx, bz) of C for slice `by` of the rows; CS: the column sums of A as well (cs_partial may still be null)
 template <bool CS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm_tn_bf16_kernel(const float *__restrict__ A, long lda, const float *__restrict__ Bm,
-                                                          long ldb, float *__restrict__ partial, long M, int N1, int N2,
-                                                          float *__restrict__ cs_partial, int slice_rows, int g1, int g2, int nslice)
+__device__ __forceinline__ void tn_bf16_block(const float *__restrict__ A, long lda, const float *__restrict__ Bm, long ldb,
+                                              float *__restrict__ partial, long M, int N1, int N2, float *__restrict__ cs_partial,
+                                              int slice_rows, int bx, int by, int bz)
 {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
-    int bx, by, bz;
-    if (!tn_block_of(g1, g2, nslice, bx, by, bz)) return;
     const int n1_0 = bx * TN_BLK, n2_0 = bz * TN_BLK;
     const long m_lo = (long)by * slice_rows, m_hi = min(m_lo + slice_rows, M);
     const int ta = min(3, (N1 - n1_0 + 31) / 32), tb = min(3, (N2 - n2_0 + 31) / 32);    // live 32-wide tiles (uniform)
-    const float *pa[3], *pb[3];
+    // Addresses: the slice's first row as a uniform base, the rest as a 32-bit byte offset per lane -- row within the slice (clamped
+    // to the last row of the matrix) times the row length (v_mad_u32_u24) plus the lane's column: 64 vector instructions per block
+    // where 64-bit row * length + column arithmetic took ~190 (the launcher checks that the offsets fit).
+    const char *const Abase = reinterpret_cast<const char *>(A + m_lo * lda), *const Bbase = reinterpret_cast<const char *>(Bm + m_lo * ldb);
+    const unsigned lastrel = (unsigned)(M - 1 - m_lo), lda4 = (unsigned)lda * 4u, ldb4 = (unsigned)ldb * 4u;
+    unsigned ca[3], cb[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        pa[i] = A + min(n1_0 + 32 * i + r, N1 - 1);
-        pb[i] = Bm + min(n2_0 + 32 * i + r, N2 - 1);
+        ca[i] = (unsigned)min(n1_0 + 32 * i + r, N1 - 1) * 4u;
+        cb[i] = (unsigned)min(n2_0 + 32 * i + r, N2 - 1) * 4u;
     }
     f32x16 acc[3][3];
 #pragma unroll
@@ -840,19 +849,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     // one K block = 16 rows: this lane holds rows m0 + 8h + (0..7) of its column in each of the six operand tiles.  Two
     // register buffers: the loads of the next block are in flight while the matrix pipe works through the current one.
     float a0[3][8], b0[3][8], a1[3][8], b1[3][8];
-    auto load = [&](float (&av)[3][8], float (&bv)[3][8], long m0) {
+    auto load = [&](float (&av)[3][8], float (&bv)[3][8], long m0) __attribute__((always_inline)) {
+        const unsigned rel0 = (unsigned)(m0 - m_lo) + 8u * h;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            const long mc = min(m0 + 8 * h + j, M - 1);
+            const unsigned rel = min(rel0 + j, lastrel);
 #pragma unroll
-            for (int i = 0; i < 3; i++) {                // (unconditional, from clamped columns: a load inside a branch -- even a
-                av[i][j] = pa[i][mc * lda];              // wave-uniform one -- makes the compiler wait for EVERYTHING in flight
-                bv[i][j] = pb[i][mc * ldb];              // before the next use, the prefetch of the next block included)
+            for (int i = 0; i < 3; i++) {                // (unconditional, from clamped rows and columns: a load inside a branch --
+                // even a wave-uniform one -- makes the compiler wait for EVERYTHING in flight before the next use, the prefetch included)
+                av[i][j] = *reinterpret_cast<const float *>(Abase + (__umul24(rel, lda4) + ca[i]));
+                bv[i][j] = *reinterpret_cast<const float *>(Bbase + (__umul24(rel, ldb4) + cb[i]));
             }
         }
     };
-    auto mma = [&](float (&av)[3][8], float (&bv)[3][8], long m0) {
-        bf16x8 pa1[3], pa2[3], pa3[3], pb1[3], pb2[3], pb3[3];
+    // A block is cut into pieces by ~310 vector instructions.  Round 3 cut a block completely and then multiplied it, smallest terms
+    // first -- the first product needs the LAST piece -- so the matrix pipe idled through the cutting (MfmaUtil 33 %); and the test on
+    // the live tile counts, uniform as it is, put every MFMA into a basic block of its own with nothing schedulable in between.
+    // Now the terms run largest first, each level of pieces is cut under the MFMAs of the level before, and the first level of the
+    // NEXT block (one v_perm per pair of values) under the last MFMAs of this one:
+    //     9 MFMAs  a1.b1             | v -= top(v): second level          (the raw values are peeled in place)
+    //    18 MFMAs  a1.b2, a2.b1      | v -= top(v): third level
+    //              -- the raw registers are free: request the block after next into them --
+    //    27 MFMAs  a2.b2, a1.b3, a3.b1 | rows past the slice -> 0, column sums, first level of the next block
+    // (The running sums already hold the blocks before: which term of a block is added first no longer decides what is absorbed.)
+    struct Pieces { bf16x8 a1[3], a2[3], a3[3], b1[3], b2[3], b3[3]; };
+    auto top = [](const float (&v)[8]) __attribute__((always_inline)) {                 // the top 16 bits of eight values: one v_perm_b32 per pair
+        union { bf16x8 v; unsigned u[4]; } o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o.u[j] = __builtin_amdgcn_perm(__float_as_uint(v[2 * j + 1]), __float_as_uint(v[2 * j]), 0x07060302u);
+        return o.v;
+    };
+    auto peel = [](float (&v)[8]) __attribute__((always_inline)) {                      // what is left below the top 16 bits (exact)
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = v[j] - __uint_as_float(__float_as_uint(v[j]) & 0xffff0000u);
+    };
+    auto prep = [&](float (&av)[3][8], float (&bv)[3][8], long m0, Pieces &P) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
 #pragma unroll
@@ -860,29 +891,79 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 av[i][j] = (m0 + 8 * h + j) < m_hi ? av[i][j] : 0.0f;       // rows past the slice (read from a clamped address)
                 if (CS) cs[i] += av[i][j];
             }
-            split_bf16x3(av[i], pa1[i], pa2[i], pa3[i]);
-            split_bf16x3(bv[i], pb1[i], pb2[i], pb3[i]);
+            P.a1[i] = top(av[i]);
+            P.b1[i] = top(bv[i]);
         }
-        // small terms first so that they are not absorbed by the large one; term-major: consecutive MFMAs go to different
-        // accumulators, so none waits for the result of the one before it
+    };
+    auto level = [&](float (&av)[3][8], float (&bv)[3][8], bf16x8 (&pa)[3], bf16x8 (&pb)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            peel(av[i]);
+            peel(bv[i]);
+            pa[i] = top(av[i]);
+            pb[i] = top(bv[i]);
+        }
+    };
 #define TN_TERM(PA, PB)                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 3; i++) _Pragma("unroll") for (int j = 0; j < 3; j++)            \
-            if (i < ta && j < tb) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[i], PB[j], acc[i][j], 0, 0, 0);
-        TN_TERM(pa1, pb3) TN_TERM(pa2, pb2) TN_TERM(pa3, pb1) TN_TERM(pa1, pb2) TN_TERM(pa2, pb1) TN_TERM(pa1, pb1)
-#undef TN_TERM
+    _Pragma("unroll") for (int i = 0; i < 3; i++) _Pragma("unroll") for (int j = 0; j < 3; j++)                \
+        if (FULL || (i < ta && j < tb)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(P.PA[i], P.PB[j], acc[i][j], 0, 0, 0);
+    // one block: its values in (av, bv), its first-level pieces in P; the next block's values in (an, bn) have arrived by the third
+    // phase and get their first-level pieces into Q; (av, bv) are requested again for the block at m_next
+    auto block = [&](float (&av)[3][8], float (&bv)[3][8], Pieces &P, float (&an)[3][8], float (&bn)[3][8], Pieces &Q, long m_this,
+                     auto fullc) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(fullc)::value;
+        TN_TERM(a1, b1)
+        level(av, bv, P.a2, P.b2);
+        if constexpr (FULL) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+            }
+        }
+        TN_TERM(a1, b2) TN_TERM(a2, b1)
+        level(av, bv, P.a3, P.b3);
+        if constexpr (FULL) {
+#pragma unroll
+            for (int i = 0; i < 18; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);               // (the requests must not rise above the last use of the registers they fill)
+        TN_TERM(a2, b2) TN_TERM(a1, b3) TN_TERM(a3, b1)
+        load(av, bv, m_this + 2 * 16);
+        prep(an, bn, m_this + 16, Q);
+        if constexpr (FULL) {
+#pragma unroll
+            for (int i = 0; i < 24; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // two of the 48 requests
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     };
     constexpr int STEP = 16;
+    Pieces P0, P1;
     load(a0, b0, m_lo);
-    for (long m0 = m_lo; m0 < m_hi; m0 += 2 * STEP) {
-        load(a1, b1, m0 + STEP);
-        __builtin_amdgcn_sched_barrier(0);               // (keeps the cutting of a block from being pulled up to its loads)
-        mma(a0, b0, m0);
-        __builtin_amdgcn_sched_barrier(0);
-        load(a0, b0, m0 + 2 * STEP);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(a1, b1, m0 + STEP);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    load(a1, b1, m_lo + STEP);
+    prep(a0, b0, m_lo, P0);
+    auto run = [&](auto fullc) __attribute__((always_inline)) {
+        for (long m0 = m_lo; m0 < m_hi; m0 += 2 * STEP) {
+            block(a0, b0, P0, a1, b1, P1, m0, fullc);
+            block(a1, b1, P1, a0, b0, P0, m0 + STEP, fullc);
+        }
+    };
+    if (ta == 3 && tb == 3) run(std::true_type{});
+    else run(std::false_type{});
+#undef TN_TERM
     float *out = partial + (size_t)by * N1 * N2;
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -897,7 +978,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 }
             }
         }
-    if (CS && bz == 0) {
+    if (CS && bz == 0 && cs_partial) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const float tot = cs[i] + __shfl_xor(cs[i], 32);
@@ -905,6 +986,42 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             if (h == 0 && i < ta && colc < N1) cs_partial[(size_t)by * N1 + colc] = tot;
         }
     }
+}
+
+template <bool CS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm_tn_bf16_kernel(const float *__restrict__ A, long lda, const float *__restrict__ Bm,
+                                                          long ldb, float *__restrict__ partial, long M, int N1, int N2,
+                                                          float *__restrict__ cs_partial, int slice_rows, int g1, int g2, int nslice)
+{
+    int bx, by, bz;
+    if (!tn_block_of(g1, g2, nslice, bx, by, bz)) return;
+    tn_bf16_block<CS>(A, lda, Bm, ldb, partial, M, N1, N2, cs_partial, slice_rows, bx, by, bz);
+}
+
+// Several contractions over the SAME rows in one launch (the three weight gradients of a Gru layer all contract da -- with x, with
+// h(t-1), with r * h(t-1) -- and as three launches da crossed the memory bus twice): the blocks of all problems for one slice of rows are
+// consecutive work items, so they run at the same time on one XCD and whichever reads a row of an operand first brings it into that
+// XCD's L2 for the others.
+#define TN_MAXPROB 4
+struct TnProblems {
+    const float *A[TN_MAXPROB], *B[TN_MAXPROB];
+    float *partial[TN_MAXPROB], *cs_partial[TN_MAXPROB];
+    long lda[TN_MAXPROB], ldb[TN_MAXPROB];
+    int N1[TN_MAXPROB], N2[TN_MAXPROB], g1[TN_MAXPROB], first[TN_MAXPROB + 1];      // first[q]: work item of problem q's first block within a slice
+    int nprob;
+};
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm_tn_bf16_multi_kernel(TnProblems pr, long M, int slice_rows, int nslice)
+{
+    const int per_slice = pr.first[pr.nprob];
+    const long W = (long)per_slice * nslice, per_xcd = (W + 7) / 8;
+    const long l = blockIdx.x, work = (l & 7) * per_xcd + (l >> 3);         // tn_block_of's dealing over the XCDs
+    if (work >= W) return;
+    const int by = (int)(work / per_slice), rem = (int)(work % per_slice);
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < TN_MAXPROB; k++) q = (k < pr.nprob && rem >= pr.first[k]) ? k : q;
+    const int local = rem - pr.first[q], bx = local % pr.g1[q], bz = local / pr.g1[q];
+    tn_bf16_block<true>(pr.A[q], pr.lda[q], pr.B[q], pr.ldb[q], pr.partial[q], M, pr.N1[q], pr.N2[q], pr.cs_partial[q], slice_rows, bx, by, bz);
 }
 
 // C = sum over slices of partial, in a fixed order: 64 outputs x 16 slice groups per workgroup; group sg adds slices
@@ -966,6 +1083,9 @@ static int gemm_tn_launch(bool bf16, const float *A, long lda, const float *B, l
     float *partial = (float *)workspace, *cs_partial = partial + (size_t)nslice * N1 * N2;
     const dim3 grid((unsigned)(8 * ((W + 7) / 8)));                       // tn_block_of: 8 XCDs x ceil(W / 8) work items
 #define TN_LAUNCH(K) hipLaunchKernelGGL(K, grid, dim3(64), 0, s, A, lda, B, ldb, partial, M, N1, N2, cs_partial, rows, g1, g2, (int)nslice)
+    // the bf16 kernel's 32-bit byte offsets within a slice (24-bit row length): rows too long for them take the float32 kernel
+    const unsigned long long ldmax = (unsigned long long)(lda > ldb ? lda : ldb) * 4ull;
+    if (ldmax >= (1ull << 24) || ((unsigned long long)rows + 64ull) * ldmax + ldmax >= (1ull << 32)) bf16 = false;
     if (bf16) {
         if (colsum) TN_LAUNCH(gemm_tn_bf16_kernel<true>);
         else TN_LAUNCH(gemm_tn_bf16_kernel<false>);
@@ -994,6 +1114,80 @@ extern "C" int slk_gemm_tn_bf16x6_f32(const float *A, long lda, const float *B, 
                                       int N2, float *colsum, void *workspace, size_t workspace_bytes, slk_stream_t stream)
 {
     return gemm_tn_launch(true, A, lda, B, ldb, C, ldc, M, N1, N2, colsum, workspace, workspace_bytes, stream);
+}
+
+// nprob (1..4) contractions over the same M rows in one launch: C[q] = A[q]^T B[q], colsum[q] (or NULL) = A[q]^T 1 (arrays of nprob
+// entries in HOST memory).  Six bf16 terms per product as slk_gemm_tn_bf16x6_f32, same results.
+static long tn_multi_blocks(int nprob, const int *N1, const int *N2)
+{
+    long blocks = 0;
+    for (int q = 0; q < nprob; q++) blocks += (long)((N1[q] + TN_BLK - 1) / TN_BLK) * ((N2[q] + TN_BLK - 1) / TN_BLK);
+    return blocks;
+}
+static int tn_multi_slice_rows(long M, long blocks)
+{
+    long rows = M * blocks / TN_WAVES;
+    rows = (rows + 31) / 32 * 32;
+    return (int)(rows < TN_MIN_ROWS ? TN_MIN_ROWS : (rows > TN_ROWS ? TN_ROWS : rows));
+}
+
+extern "C" size_t slk_gemm_tn_multi_workspace_bytes(long M, int nprob, const int *N1, const int *N2)
+{
+    if (M < 1 || nprob < 1 || nprob > TN_MAXPROB || !N1 || !N2) return 0;
+    for (int q = 0; q < nprob; q++)
+        if (N1[q] < 1 || N2[q] < 1) return 0;
+    const int rows = tn_multi_slice_rows(M, tn_multi_blocks(nprob, N1, N2));
+    const size_t nslice = (size_t)((M + rows - 1) / rows);
+    size_t floats = 0;
+    for (int q = 0; q < nprob; q++) floats += nslice * N1[q] * ((size_t)N2[q] + 1);
+    return floats * sizeof(float);
+}
+
+extern "C" int slk_gemm_tn_multi_bf16x6_f32(int nprob, const float *const *A, const long *lda, const float *const *B, const long *ldb,
+                                            float *const *C, const long *ldc, long M, const int *N1, const int *N2, float *const *colsum,
+                                            void *workspace, size_t workspace_bytes, slk_stream_t stream)
+{
+    if (nprob < 1 || nprob > TN_MAXPROB || !A || !lda || !B || !ldb || !C || !ldc || !N1 || !N2 || M < 1) return SLK_ERR_INVALID_ARG;
+    for (int q = 0; q < nprob; q++)
+        if (!A[q] || !B[q] || !C[q] || N1[q] < 1 || N2[q] < 1 || lda[q] < N1[q] || ldb[q] < N2[q] || ldc[q] < N2[q]) return SLK_ERR_INVALID_ARG;
+    if (!workspace || workspace_bytes < slk_gemm_tn_multi_workspace_bytes(M, nprob, N1, N2)) return SLK_ERR_WORKSPACE;
+    const long blocks = tn_multi_blocks(nprob, N1, N2);
+    const int rows = tn_multi_slice_rows(M, blocks);
+    const long nslice = (M + rows - 1) / rows, W = blocks * nslice;
+    if (W > 0x7ffffff0L) return SLK_ERR_UNSUPPORTED;
+    TnProblems pr;
+    float *ws = (float *)workspace;
+    pr.nprob = nprob;
+    pr.first[0] = 0;
+    for (int q = 0; q < TN_MAXPROB; q++) {
+        const int k = q < nprob ? q : 0;
+        const unsigned long long ldmax = (unsigned long long)(lda[k] > ldb[k] ? lda[k] : ldb[k]) * 4ull;
+        if (ldmax >= (1ull << 24) || ((unsigned long long)rows + 64ull) * ldmax + ldmax >= (1ull << 32)) return SLK_ERR_UNSUPPORTED;   // 32-bit offsets
+        pr.A[q] = A[k]; pr.B[q] = B[k]; pr.lda[q] = lda[k]; pr.ldb[q] = ldb[k]; pr.N1[q] = N1[k]; pr.N2[q] = N2[k];
+        pr.g1[q] = (N1[k] + TN_BLK - 1) / TN_BLK;
+        if (q < nprob) {
+            pr.partial[q] = ws;
+            ws += (size_t)nslice * N1[q] * N2[q];
+            pr.cs_partial[q] = (colsum && colsum[q]) ? ws : nullptr;
+            ws += (size_t)nslice * N1[q];
+            pr.first[q + 1] = pr.first[q] + pr.g1[q] * ((N2[q] + TN_BLK - 1) / TN_BLK);
+        } else {
+            pr.partial[q] = nullptr; pr.cs_partial[q] = nullptr;
+            pr.first[q + 1] = pr.first[q];
+        }
+    }
+    pr.first[TN_MAXPROB] = pr.first[nprob];
+    hipStream_t s = slk_stream(stream);
+    hipLaunchKernelGGL(gemm_tn_bf16_multi_kernel, dim3((unsigned)(8 * ((W + 7) / 8))), dim3(64), 0, s, pr, M, rows, (int)nslice);
+    for (int q = 0; q < nprob; q++) {
+        const size_t total = (size_t)N1[q] * N2[q];
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, s, (const float *)pr.partial[q], (int)nslice,
+                           N1[q], N2[q], C[q], ldc[q]);
+        if (pr.cs_partial[q])
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((N1[q] + 63) / 64)), dim3(1024), 0, s, (const float *)pr.cs_partial[q],
+                               (int)nslice, N1[q], 1, colsum[q], 1L);
+    }
+    return slk_launch_status();
 }
 
 // ---------------------------------------------------------------------------------------------------------------

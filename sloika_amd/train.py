@@ -265,6 +265,27 @@ class TrainingStep(object):
         fn = L.slk_gemm_tn_bf16x6_f32 if (layers.SPLIT_F16 and n2 >= 32) else L.slk_gemm_tn_f32
         _lib.check(fn(A, lda, Bm, ldb, C, ldc, M, n1, n2, colsum, ws.data_ptr(), nbytes, layers._stream()), "gemm_tn")
 
+    def _tn_many(self, problems, M):
+        """Several contractions over the same M rows -- problems = [(A, lda, B, ldb, C, ldc, n1, n2, colsum or None), ...] with device
+        addresses -- in one launch where the bf16 kernel applies (slk_gemm_tn_multi_bf16x6_f32: a matrix that several problems
+        share is read from memory once), else one by one."""
+        import ctypes
+        L = _lib.lib()
+        n = len(problems)
+        if layers.SPLIT_F16 and 1 < n <= 4 and all(p[7] >= 32 for p in problems):
+            vps, longs, ints = (ctypes.c_void_p * n), (ctypes.c_long * n), (ctypes.c_int * n)
+            A, lda, Bm, ldb = vps(*[p[0] for p in problems]), longs(*[p[1] for p in problems]), vps(*[p[2] for p in problems]), longs(*[p[3] for p in problems])
+            C, ldc = vps(*[p[4] for p in problems]), longs(*[p[5] for p in problems])
+            n1, n2, cs = ints(*[p[6] for p in problems]), ints(*[p[7] for p in problems]), vps(*[p[8] for p in problems])
+            nbytes = L.slk_gemm_tn_multi_workspace_bytes(M, n, n1, n2)
+            ws = self._workspace(nbytes)
+            rc = L.slk_gemm_tn_multi_bf16x6_f32(n, A, lda, Bm, ldb, C, ldc, M, n1, n2, cs, ws.data_ptr(), nbytes, layers._stream())
+            if rc != _lib.SLK_ERR_UNSUPPORTED:
+                _lib.check(rc, "gemm_tn (several)")
+                return
+        for A, lda, Bm, ldb, C, ldc, n1, n2, cs in problems:
+            self._tn(A, lda, Bm, ldb, C, ldc, M, n1, n2, colsum=cs)
+
     def _gemm(self, x, ldx, W, bias, y, ldy, M, K, N, act):
         """y = act(x . W^T + b), W:[N][K] -- fp16 3-term split where it applies, else float32 MFMA."""
         import torch
@@ -584,10 +605,9 @@ class TrainingStep(object):
         _lib.check(rc, "gru_backward")
         f4 = 4                                                                       # bytes per float, for column offsets
         with profiler.region("train_wgrad", 2.0 * M * (3 * n * i_sz + 3 * n * n), 4.0 * M * (3 * n + 2 * K)):
-            self._tn(da.data_ptr(), 3 * n, x_ptr, ldx, giW.data_ptr(), i_sz, M, 3 * n, i_sz,
-                     colsum=gb.data_ptr() if gb is not None else None)
-            self._tn(da.data_ptr(), 3 * n, hp_ptr, ldhp, gsW.data_ptr(), n, M, 2 * n, n)
-            self._tn(da.data_ptr() + f4 * 2 * n, 3 * n, rh.data_ptr(), n, gsW2.data_ptr(), n, M, n, n)
+            self._tn_many([(da.data_ptr(), 3 * n, x_ptr, ldx, giW.data_ptr(), i_sz, 3 * n, i_sz, gb.data_ptr() if gb is not None else None),
+                           (da.data_ptr(), 3 * n, hp_ptr, ldhp, gsW.data_ptr(), n, 2 * n, n, None),
+                           (da.data_ptr() + f4 * 2 * n, 3 * n, rh.data_ptr(), n, gsW2.data_ptr(), n, n, n, None)], M)
         if not need_dx:
             return None
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
@@ -684,9 +704,8 @@ class TrainingStep(object):
             raise NotImplementedError("training: no reverse-scan kernel for an Lstm of size %d" % n)
         _lib.check(rc, "lstm_backward")
         with profiler.region("train_wgrad", 8.0 * M * n * K, 4.0 * M * (4 * n + K)):
-            self._tn(dsum.data_ptr(), 4 * n, xh.data_ptr(), K, giW.data_ptr(), i_sz, M, 4 * n, i_sz,
-                     colsum=gb.data_ptr() if gb is not None else None)
-            self._tn(dsum.data_ptr(), 4 * n, xh.data_ptr() + 4 * i_sz, K, gsW.data_ptr(), n, M, 4 * n, n)
+            self._tn_many([(dsum.data_ptr(), 4 * n, xh.data_ptr(), K, giW.data_ptr(), i_sz, 4 * n, i_sz, gb.data_ptr() if gb is not None else None),
+                           (dsum.data_ptr(), 4 * n, xh.data_ptr() + 4 * i_sz, K, gsW.data_ptr(), n, 4 * n, n, None)], M)
             if gp is not None:                        # sum of the per-chunk peephole gradients: the column sums of dpeep
                 scratch = torch.empty(3 * n, dtype=torch.float32, device=dev)
                 self._tn(dpeep.data_ptr(), 3 * n, dpeep.data_ptr(), 3 * n, scratch.data_ptr(), 1, B, 3 * n, 1,

@@ -530,3 +530,43 @@ def test_training_step_two_pass_softmax_equals_in_place():
     assert res[0][0] == res[1][0]
     for a, b in zip(res[0][1], res[1][1]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("M,n,i_sz", [(4111, 96, 96), (900, 64, 33), (2049, 128, 40)])
+def test_gemm_tn_multi_equals_single_launches(M, n, i_sz):
+    """slk_gemm_tn_multi_bf16x6_f32 (the three weight gradients of a Gru layer in one launch, sharing dL/d(pre-activation)) gives what three
+    slk_gemm_tn_bf16x6_f32 launches give (to the rounding of float32 sums grouped differently) and leaves the padding of its outputs alone."""
+    import ctypes
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(M + n)
+    da = dev((rs.normal(size=(M, 3 * n)) * 1e-3).astype(np.float32))
+    xs = [dev(rs.normal(size=(M, w + 2)).astype(np.float32)) for w in (i_sz, n, n)]
+    shapes = [(3 * n, i_sz, 0), (2 * n, n, 0), (n, n, 2 * n)]            # (N1, N2, first column of da)
+    single, multi, cs_single, cs_multi = [], [], torch.full((3 * n,), -7.0, device="cuda"), torch.full((3 * n,), -7.0, device="cuda")
+    for (n1, n2, c0), xb in zip(shapes, xs):
+        C = torch.full((n1, n2 + 1), -7.0, dtype=torch.float32, device="cuda")
+        nbytes = L.slk_gemm_tn_workspace_bytes(M, n1, n2)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        assert L.slk_gemm_tn_bf16x6_f32(da.data_ptr() + 4 * c0, 3 * n, xb.data_ptr(), n2 + 2, C.data_ptr(), n2 + 1, M, n1, n2,
+                                        cs_single.data_ptr() if c0 == 0 and n1 == 3 * n else None, ws.data_ptr(), nbytes, stream()) == 0
+        single.append(C)
+        multi.append(torch.full((n1, n2 + 1), -7.0, dtype=torch.float32, device="cuda"))
+    vps, longs, ints = ctypes.c_void_p * 3, ctypes.c_long * 3, ctypes.c_int * 3
+    n1s, n2s = ints(*[s[0] for s in shapes]), ints(*[s[1] for s in shapes])
+    nbytes = L.slk_gemm_tn_multi_workspace_bytes(M, 3, n1s, n2s)
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    args = (3, vps(*[da.data_ptr() + 4 * s[2] for s in shapes]), longs(3 * n, 3 * n, 3 * n), vps(*[x.data_ptr() for x in xs]),
+            longs(*[s[1] + 2 for s in shapes]), vps(*[c.data_ptr() for c in multi]), longs(*[s[1] + 1 for s in shapes]), M, n1s, n2s,
+            vps(cs_multi.data_ptr(), None, None), ws.data_ptr())
+    assert L.slk_gemm_tn_multi_bf16x6_f32(*args, nbytes, stream()) == 0
+    torch.cuda.synchronize()
+    for a, b, (n1, n2, c0) in zip(single, multi, shapes):           # (the slices of the rows differ: float32 sums in another grouping)
+        scale = float(a[:, :n2].abs().max())
+        assert float((a[:, :n2] - b[:, :n2]).abs().max()) <= 2e-6 * scale
+        assert bool((b[:, n2:] == -7.0).all())
+    assert float((cs_single - cs_multi).abs().max()) <= 2e-6 * float(cs_single.abs().max())
+    assert L.slk_gemm_tn_multi_bf16x6_f32(*args, nbytes - 1, stream()) == _lib.SLK_ERR_WORKSPACE
+    assert L.slk_gemm_tn_multi_bf16x6_f32(5, *args[1:], nbytes, stream()) == _lib.SLK_ERR_INVALID_ARG
