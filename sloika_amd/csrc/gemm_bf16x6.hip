@@ -15,9 +15,12 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define GB_BM 128
+#define GB_BM 128                                        // rows per workgroup and row tile of its waves (WR row tiles: WR times as many)
 #ifndef GB_BK
 #define GB_BK 32                                         // (64: 256-byte runs per row and half the barriers, two workgroups per CU -- measured below)
+#endif
+#ifndef GB_WR
+#define GB_WR 2                                          // row tiles per wave of the wide variant
 #endif
 #define GB_XLD (GB_BK + 4)                               // floats per x row in LDS (gemm.hip)
 #define GB_WLD (GB_BK + 8)                               // bf16 per W row in LDS: the 16-byte reads of 16 rows hit 64 banks
@@ -62,34 +65,46 @@ __global__ void __launch_bounds__(256) pack_bf16x3_kernel(const float *__restric
     }
 }
 
-template <int NT, int ACT>
+// WR: 32-row tiles per wave.  A wave reads the W fragments of a slab from LDS once per row tile group, and with one row tile the LDS
+// moved 112 bytes per cycle of its 128 (4 waves x (2 KiB of x + 9 KiB of W fragments) per 16 k, plus the staging writes, against 18
+// MFMAs of 32 cycles): the kernel was bound by the LDS port, not by the matrix pipe (0.28 of its peak).  With two row tiles the W
+// fragments serve twice the MFMAs.
+// With two row tiles the slab after the one being multiplied is requested before the multiplication and staged behind the barrier that
+// ends it (the one-tile form requests a slab, waits, stages and multiplies it, and three workgroups per CU fill each other's waits:
+// pipelined as well it needs 24 registers more than three waves per SIMD leave and was slower, 1.86 against 1.37 ms).
+// 819200 x 1056 -> 96: 1.37 ms one tile, 1.43 two tiles unpipelined, 1.12 two tiles pipelined.
+template <int NT, int ACT, int WR>
 __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const float *__restrict__ x, long ldx, const uint4 *__restrict__ wp,
                                                           const float *__restrict__ bias, float *__restrict__ y, long ldy, long M, int K,
                                                           int KP, int N, int ntile_n)
 {
     constexpr int BN = 32 * NT;
-    __shared__ __attribute__((aligned(16))) float xs[GB_BM * GB_XLD];
+    constexpr int BM = GB_BM * WR;
+    __shared__ __attribute__((aligned(16))) float xs[BM * GB_XLD];
     __shared__ __attribute__((aligned(16))) unsigned short ws[3 * BN * GB_WLD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const long bid = blockIdx.x;
-    const long m0 = (bid / ntile_n) * GB_BM;
+    const long m0 = (bid / ntile_n) * BM;
     const int n0 = (int)(bid % ntile_n) * BN;
     const size_t piece = (size_t)N * (KP / 8);           // uint4 per piece
 
-    f32x16 acc[NT];
+    f32x16 acc[WR][NT];
 #pragma unroll
-    for (int i = 0; i < NT; i++)
+    for (int w = 0; w < WR; w++)
 #pragma unroll
-        for (int j = 0; j < 16; j++) acc[i][j] = 0.0f;
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[w][i][j] = 0.0f;
 
-    constexpr int XL = (GB_BM * GB_BK / 4) / 256;        // float4 loads per thread for x: 4
+    constexpr int XL = (BM * GB_BK / 4) / 256;           // float4 loads per thread for x: 4 per row tile
     constexpr int CPR = GB_BK / 8;                       // 16-byte chunks per row of a slab (x: twice as many)
     constexpr int WCH = 3 * BN * CPR;                    // 16-byte chunks of the W slab: [piece][row][CPR]
     constexpr int WL = (WCH + 255) / 256;
-    for (int k0 = 0; k0 < K; k0 += GB_BK) {
-        // all loads back to back from clamped (always valid) addresses, masked when they are stored (gemm.hip)
-        float4 xv[XL];
-        uint4 wv[WL];
+    constexpr bool PIPE = WR > 1;
+    // (LDS counter only: __syncthreads() would also wait for the slab that has just been requested)
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    // all loads back to back from clamped (always valid) addresses, masked when they are stored (gemm.hip)
+    auto request = [&](int k0, float4 (&xv)[XL], uint4 (&wv)[WL]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < XL; i++) {
             const int idx = tid + 256 * i, row = idx / (2 * CPR), c4 = (idx % (2 * CPR)) * 4;
@@ -101,8 +116,10 @@ __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const float *__restric
         for (int i = 0; i < WL; i++) {
             const int idx = min(tid + 256 * i, WCH - 1), p = idx / (BN * CPR), rem = idx % (BN * CPR), row = rem / CPR, ch = rem % CPR;
             const int gn = min(n0 + row, N - 1);
-            wv[i] = wp[p * piece + (size_t)gn * (KP / 8) + (k0 >> 3) + ch];
+            wv[i] = wp[p * piece + (size_t)gn * (KP / 8) + min(k0 >> 3, KP / 8 - CPR) + ch];
         }
+    };
+    auto stage = [&](int k0, const float4 (&xv)[XL], const uint4 (&wv)[WL]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < XL; i++) {
             const int idx = tid + 256 * i, row = idx / (2 * CPR), c4 = (idx % (2 * CPR)) * 4;
@@ -114,15 +131,19 @@ __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const float *__restric
             const int idx = tid + 256 * i, p = idx / (BN * CPR), rem = idx % (BN * CPR), row = rem / CPR, ch = rem % CPR;
             if (idx < WCH) *reinterpret_cast<uint4 *>(&ws[(p * BN + row) * GB_WLD + 8 * ch]) = wv[i];   // (columns past N: never stored)
         }
-        __syncthreads();
+    };
+    auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < GB_BK / 16; ks++) {
-            float v[8];
-            const float *ap = &xs[(32 * wave + r) * GB_XLD + 16 * ks + 8 * h];
-            const float4 lo4 = *reinterpret_cast<const float4 *>(ap), hi4 = *reinterpret_cast<const float4 *>(ap + 4);
-            v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
-            bf16x8 a1, a2, a3;
-            gb_split(v, a1, a2, a3);
+            bf16x8 a1[WR], a2[WR], a3[WR];
+#pragma unroll
+            for (int w = 0; w < WR; w++) {
+                float v[8];
+                const float *ap = &xs[(32 * (WR * wave + w) + r) * GB_XLD + 16 * ks + 8 * h];
+                const float4 lo4 = *reinterpret_cast<const float4 *>(ap), hi4 = *reinterpret_cast<const float4 *>(ap + 4);
+                v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+                gb_split(v, a1[w], a2[w], a3[w]);
+            }
             bf16x8 b[NT][3];
 #pragma unroll
             for (int t = 0; t < NT; t++)
@@ -130,12 +151,57 @@ __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const float *__restric
                 for (int p = 0; p < 3; p++)
                     b[t][p] = *reinterpret_cast<const bf16x8 *>(&ws[(p * BN + 32 * t + r) * GB_WLD + 16 * ks + 8 * h]);
             // small terms first; term-major: consecutive MFMAs go to different accumulators
-#define GB_TERM(PA, PB) \
-            _Pragma("unroll") for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA, b[t][PB], acc[t], 0, 0, 0);
+#define GB_TERM(PA, PB)                                                              \
+            _Pragma("unroll") for (int w = 0; w < WR; w++) _Pragma("unroll") for (int t = 0; t < NT; t++) \
+                acc[w][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PA[w], b[t][PB], acc[w][t], 0, 0, 0);
             GB_TERM(a1, 2) GB_TERM(a2, 1) GB_TERM(a3, 0) GB_TERM(a1, 1) GB_TERM(a2, 0) GB_TERM(a1, 0)
 #undef GB_TERM
         }
-        __syncthreads();
+    };
+    if constexpr (PIPE) {
+        float4 xv[XL];
+        uint4 wv[WL];
+        request(0, xv, wv);
+        for (int k0 = 0; k0 < K; k0 += GB_BK) {
+            stage(k0, xv, wv);
+            lds_barrier();
+            request(k0 + GB_BK, xv, wv);                 // (past the last slab: clamped addresses, never stored)
+            multiply();
+            lds_barrier();
+        }
+    } else {
+        for (int k0 = 0; k0 < K; k0 += GB_BK) {
+            // (written out, not through request() / stage(): as arguments of those the arrays of this branch stayed in scratch memory)
+            float4 xv[XL];
+            uint4 wv[WL];
+#pragma unroll
+            for (int i = 0; i < XL; i++) {
+                const int idx = tid + 256 * i, row = idx / (2 * CPR), c4 = (idx % (2 * CPR)) * 4;
+                const long gr = m0 + row;
+                const int gk = k0 + c4;
+                xv[i] = *reinterpret_cast<const float4 *>(x + (gr < M ? gr : M - 1) * ldx + (gk < K ? gk : 0));
+            }
+#pragma unroll
+            for (int i = 0; i < WL; i++) {
+                const int idx = min(tid + 256 * i, WCH - 1), p = idx / (BN * CPR), rem = idx % (BN * CPR), row = rem / CPR, ch = rem % CPR;
+                const int gn = min(n0 + row, N - 1);
+                wv[i] = wp[p * piece + (size_t)gn * (KP / 8) + (k0 >> 3) + ch];
+            }
+#pragma unroll
+            for (int i = 0; i < XL; i++) {
+                const int idx = tid + 256 * i, row = idx / (2 * CPR), c4 = (idx % (2 * CPR)) * 4;
+                const bool in = m0 + row < M && k0 + c4 < K;                              // K is a multiple of 4
+                *reinterpret_cast<float4 *>(&xs[row * GB_XLD + c4]) = in ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < WL; i++) {
+                const int idx = tid + 256 * i, p = idx / (BN * CPR), rem = idx % (BN * CPR), row = rem / CPR, ch = rem % CPR;
+                if (idx < WCH) *reinterpret_cast<uint4 *>(&ws[(p * BN + row) * GB_WLD + 8 * ch]) = wv[i];   // (columns past N: never stored)
+            }
+            __syncthreads();
+            multiply();
+            __syncthreads();
+        }
     }
     // ---- epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*h][col = lane&31] ----
 #pragma unroll
@@ -144,10 +210,12 @@ __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const float *__restric
         if (col >= N) continue;
         const float bv = bias ? bias[col] : 0.0f;
 #pragma unroll
-        for (int reg = 0; reg < 16; reg++) {
-            const long row = m0 + 32 * wave + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            if (row < M) y[row * ldy + col] = slk_act_t<ACT>(acc[nt][reg] + bv);
-        }
+        for (int w = 0; w < WR; w++)
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) {
+                const long row = m0 + 32 * (WR * wave + w) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (row < M) y[row * ldy + col] = slk_act_t<ACT>(acc[w][nt][reg] + bv);
+            }
     }
 }
 
@@ -173,11 +241,17 @@ template <int NT>
 static int gb_launch(const float *x, long ldx, const uint4 *wp, const float *bias, float *y, long ldy, long M, int K, int N, int act,
                      hipStream_t s)
 {
-    const int ntile_n = (N + 32 * NT - 1) / (32 * NT), KP = (K + GB_BK - 1) / GB_BK * GB_BK;
-    const long blocks = ((M + GB_BM - 1) / GB_BM) * ntile_n;
+    // two row tiles per wave for the 96-column products of a large batch (measured: 819200 x 1056 -> 96 1.37 -> 1.12 ms, x 288 -> 96
+    // 0.39 -> 0.38; 64 columns 0.26 -> 0.34, so those and everything small stay with one tile)
+    constexpr int WRMAX = NT == 3 ? GB_WR : 1;
+    const bool wide = WRMAX > 1 && M >= (long)GB_BM * WRMAX * 1024 && K >= 512;    // (short rows: 0.38-0.44 against 0.39-0.40 ms, no gain)
+    const int ntile_n = (N + 32 * NT - 1) / (32 * NT), KP = (K + GB_BK - 1) / GB_BK * GB_BK, bm = GB_BM * (wide ? WRMAX : 1);
+    const long blocks = ((M + bm - 1) / bm) * ntile_n;
     if (blocks > 0x7fffffffL) return SLK_ERR_UNSUPPORTED;
 #define GB_LAUNCH(AC)                                                                                                            \
-    hipLaunchKernelGGL((gemm_bf16x6_kernel<NT, AC>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, wp, bias, y, ldy, M, K, KP, N, \
+    if (wide) hipLaunchKernelGGL((gemm_bf16x6_kernel<NT, AC, WRMAX>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, wp, bias, y, ldy, M, K, KP, N, \
+                       ntile_n);                                                                                                 \
+    else hipLaunchKernelGGL((gemm_bf16x6_kernel<NT, AC, 1>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, wp, bias, y, ldy, M, K, KP, N, \
                        ntile_n)
     switch (act) {
     case SLK_ACT_LINEAR: GB_LAUNCH(SLK_ACT_LINEAR); break;
