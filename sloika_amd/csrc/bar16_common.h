@@ -208,6 +208,13 @@ __device__ __forceinline__ void z_block_mfma2(f32x4 &a0, f32x4 &a1, const half8 
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(a1) : "a"(w1_hi), "v"(bm));
 }
 // one tile's product with one K block of the mixed operand
+// An operand of an asm MFMA must not have been written by a vector instruction in the instruction slot or two before it: the hardware
+// does not interlock that (the MFMA reads what the register held before), and hipcc counts no wait states for what is inside asm.
+// Operands normally arrive from LDS behind an s_waitcnt; the exception is a CONSTANT -- the zero state of step 0 -- which hipcc
+// materialises with v_mov right in front of its first use (found when a rescheduled step 0 of gru_bar16q_kernel<64,64,true> computed
+// its first r gate from whatever the registers held: tests/test_gpu_gru_bar16.py, saved gates).  settle() makes the value opaque (no
+// rematerialisation later) and puts the wait states behind its definition, once.
+__device__ __forceinline__ void settle(half8 &v) { asm volatile("s_nop 1" : "+v"(v)); }
 __device__ __forceinline__ void mfma2(const half8 &w_hi, const half8 &w_lo, const half8 &bm, f32x4 &acc)
 {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo, bm, acc, 0, 0, 0);

@@ -239,6 +239,8 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         __syncthreads();                                 // LDS initialised, every wave's invw_lds rows written
         lds_bar();                                       // x operand images of groups 0 and 1 (service leader)
         half8 pxh = {0, 0, 0, 0, 0, 0, 0, 0}, pxl = pxh;    // x operands of the coming step's share of the projection
+        settle(pxh);
+        settle(pxl);
         if constexpr (CT > 0) {                          // vI of group 0
             half8 xh0[KBLK], xl0[KBLK];
 #pragma unroll
@@ -257,8 +259,10 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
         [[maybe_unused]] unsigned long long sacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
         if constexpr (DIAG) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory"); }
         float hold[2] = {0.0f, 0.0f};
+        [[maybe_unused]] float zkeep[2] = {0.0f, 0.0f};  // SAVE: the update gate of the step before, stored with its h
         // carried from step to step: my own K block of h(s-1) as B operand, read back right after I wrote it
         half8 oh = {0, 0, 0, 0, 0, 0, 0, 0};
+        settle(oh);
         // registers the asm statements of a step write, kept from step to step (bar16_common.h: pick_mix_kept)
         float pk0 = 0.0f, pk1 = 0.0f;
         unsigned sp_hi = 0u, sp_lo = 0u;
@@ -297,6 +301,16 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             bh[0] = oh;
 #pragma unroll
             for (int i = 1; i < KBS; i++) bh[i] = ldH(h_img, moff[i]);       // what the step waits for is requested first
+            __builtin_amdgcn_sched_barrier(0);
+            if (s > 0) {                                 // h(s-1): still in `hold`
+                if (live && s - 1 < Tc && !(ABL & 16)) {
+                    hp[0] = hold[0];
+                    hp[16] = hold[1];
+                    if constexpr (SAVE) { zp[0] = zkeep[0]; zp[16] = zkeep[1]; }
+                }
+                hp += hstep;
+                if constexpr (SAVE) zp += zstep;
+            }
             __builtin_amdgcn_sched_barrier(0);
             // vI(s): complete since the previous barrier at the latest (the service waves use every interval)
             const float *vcur = vbuf + (s % R) * VSTEP + voff;
@@ -366,15 +380,16 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
             const bool store = live && s < Tc && !(ABL & 16);
-            if constexpr (SAVE) {
-                if (store) { zp[N] = rr[0]; zp[N + 16] = rr[1]; }
-            }
             // ------------------------------ interval B ------------------------------
             if constexpr (DIAG) { BSTAMP(3) lds_bar(); } else lds_bar_1read<!(ABL & 1)>();
             BSTAMP(4)
 #pragma unroll
             for (int i = 1; i < KBS; i++) ch[i] = ldH(rh_img, moff[i]);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SAVE) {                        // (behind the barrier, like h: while the requested operands are on their way)
+                if (store) { zp[N] = rr[0]; zp[N + 16] = rr[1]; }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             constexpr int nph = (ph + 1) & 3;            // the next step projects K block nph of the group after ITS group
             constexpr bool NPROJ = CT > 0 && nph < KBLK;
             if constexpr (NPROJ) {
@@ -433,13 +448,12 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             asm volatile("" ::"v"(accC[0]), "v"(accC[1]), "v"(accZ[0]), "v"(accZ[1]));
             oh = ldH(h_img, moff[0]);
             lds_fence();
-            if (store) {
-                hp[0] = hn[0];
-                hp[16] = hn[1];
-                if constexpr (SAVE) { zp[0] = zz[0]; zp[16] = zz[1]; }
+            // (h(s) is stored by the NEXT step, behind its first barrier, while that step waits for the state it has requested from LDS;
+            //  here the stores were two more instructions between the last write of the state and the barrier everybody waits at)
+            if constexpr (SAVE) {
+                zkeep[0] = zz[0];
+                zkeep[1] = zz[1];
             }
-            hp += hstep;
-            if constexpr (SAVE) zp += zstep;
 #pragma unroll
             for (int p = 0; p < 2; p++) hold[p] = hn[p];
             BSTAMP(7)
@@ -450,6 +464,11 @@ __global__ void __launch_bounds__(256, 1) gru_bar16_kernel(const float *__restri
             if (s + 1 < T) step(ic<1>{}, s + 1, G);
             if (s + 2 < T) step(ic<2>{}, s + 2, G);
             if (s + 3 < T) step(ic<3>{}, s + 3, G);
+        }
+        if (live && T - 1 < Tc && !(ABL & 16)) {         // h (and z) of the last step
+            hp[0] = hold[0];
+            hp[16] = hold[1];
+            if constexpr (SAVE) { zp[0] = zkeep[0]; zp[16] = zkeep[1]; }
         }
 #ifdef SLK_DIAG
         if constexpr (DIAG) {

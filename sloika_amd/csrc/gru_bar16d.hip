@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
         lds_bar();                                       // x operand images of groups 0 and 1 (service leader)
         const half8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
         half8 pxh[2] = {hzero, hzero}, pxl[2] = {hzero, hzero};      // x operands of the coming step's share of the projection
+        settle(pxh[0]); settle(pxh[1]); settle(pxl[0]); settle(pxl[1]);
         if constexpr (CT > 0) {                          // vI of group 0
 #pragma unroll
             for (int sset = 0; sset < 2; sset++) {
@@ -289,8 +290,11 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
         unsigned long long dwork[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dwait[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
         if constexpr (BAR16D_ABL & 16) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
         float hold[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+        [[maybe_unused]] float zkeep[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};      // SAVE: the update gates of the step before
         // carried from step to step: my own K block of h(s-1) as B operand (read back right after I wrote it)
         half8 oh = hzero, ol = hzero;
+        settle(oh);
+        settle(ol);
         // rows 4g + 2qh + j of a tile's accumulator
         auto pick = [&](const f32x4 &a, int j) {
             if constexpr (MIX) return pick_mix_d(a, j);
@@ -320,6 +324,18 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
             for (int i = 1; i < KBS; i++) {
                 if constexpr (MIX) bh[i] = ldH(h_img, moff[i]);
                 else { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+            }
+            if (s > 0) {                                 // h(s-1), still in `hold` (gru_bar16.hip: stored behind the barrier, not in front of it)
+                if (live && s - 1 < Tc && !(BAR16D_ABL & 8)) {
+                    *reinterpret_cast<f32x2d *>(hp) = f32x2d{hold[0][0], hold[0][1]};
+                    *reinterpret_cast<f32x2d *>(hp + 16) = f32x2d{hold[1][0], hold[1][1]};
+                    if constexpr (SAVE) {
+                        *reinterpret_cast<f32x2d *>(zp) = f32x2d{zkeep[0][0], zkeep[0][1]};
+                        *reinterpret_cast<f32x2d *>(zp + 16) = f32x2d{zkeep[1][0], zkeep[1][1]};
+                    }
+                }
+                hp += hstep;
+                if constexpr (SAVE) zp += zstep;
             }
             // vI(s): complete since the previous barrier at the latest (the service waves use every interval)
             const float *vcur = vbuf + ((s % R) * 2 + set) * VSTEP + voff;
@@ -546,16 +562,10 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 ol = ldH(h_lo, boff[0]);
             }
             lds_fence();
-            if (store) {
-                *reinterpret_cast<f32x2d *>(hp) = f32x2d{hn[0][0], hn[0][1]};
-                *reinterpret_cast<f32x2d *>(hp + 16) = f32x2d{hn[1][0], hn[1][1]};
-                if constexpr (SAVE) {
-                    *reinterpret_cast<f32x2d *>(zp) = f32x2d{zz[0][0], zz[0][1]};
-                    *reinterpret_cast<f32x2d *>(zp + 16) = f32x2d{zz[1][0], zz[1][1]};
-                }
+            if constexpr (SAVE) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) { zkeep[p][0] = zz[p][0]; zkeep[p][1] = zz[p][1]; }
             }
-            hp += hstep;
-            if constexpr (SAVE) zp += zstep;
 #pragma unroll
             for (int p = 0; p < 2; p++) { hold[p][0] = hn[p][0]; hold[p][1] = hn[p][1]; }
         };
@@ -565,6 +575,14 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
             if (s + 1 < T) step(ic<1>{}, s + 1, G);
             if (s + 2 < T) step(ic<2>{}, s + 2, G);
             if (s + 3 < T) step(ic<3>{}, s + 3, G);
+        }
+        if (live && T - 1 < Tc && !(BAR16D_ABL & 8)) {   // h (and z) of the last step
+            *reinterpret_cast<f32x2d *>(hp) = f32x2d{hold[0][0], hold[0][1]};
+            *reinterpret_cast<f32x2d *>(hp + 16) = f32x2d{hold[1][0], hold[1][1]};
+            if constexpr (SAVE) {
+                *reinterpret_cast<f32x2d *>(zp) = f32x2d{zkeep[0][0], zkeep[0][1]};
+                *reinterpret_cast<f32x2d *>(zp + 16) = f32x2d{zkeep[1][0], zkeep[1][1]};
+            }
         }
         if constexpr (BAR16D_ABL & 16) {
             if (blockIdx.x == 0 && lane == 0)

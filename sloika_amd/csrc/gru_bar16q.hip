@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
         lds_bar();                                       // x operand images of groups 0 and 1 (service leader)
         const half8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
         half8 pxh[2] = {hzero, hzero}, pxl[2] = {hzero, hzero};      // x operands of the coming slot of the projection share
+        settle(pxh[0]); settle(pxh[1]); settle(pxl[0]); settle(pxl[1]);
         if constexpr (CT > 0) {                          // vI of group 0
 #pragma unroll
             for (int sset = 0; sset < 2; sset++) {
@@ -233,6 +234,8 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
 
         float hold[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         half8 oh = hzero, ol = hzero;                    // my own K block of h(s-1) as B operand (read back right after I wrote it)
+        settle(oh);
+        settle(ol);
         // The chain waves' share of the projection: a group is two steps = four slots (ph, interval), slot k = 2 ph + interval
         // projects K block k of the NEXT group (when k < KBLK); the operands of a slot are fetched one slot earlier
         auto proj_slot = [&](auto KC) {
@@ -264,6 +267,13 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
             bl[0] = ol;
 #pragma unroll
             for (int i = 1; i < KBS; i++) { bh[i] = ldH(h_hi, boff[i]); bl[i] = ldH(h_lo, boff[i]); }
+            if (s > 0) {                                 // h(s-1), still in `hold` (gru_bar16.hip: stored behind the barrier, not in front of it)
+                if (live && s - 1 < Tc && !(BAR16Q_ABL & 4)) {
+                    *reinterpret_cast<f32x4 *>(hp) = f32x4{hold[0][0], hold[0][1], hold[0][2], hold[0][3]};
+                    *reinterpret_cast<f32x4 *>(hp + 16) = f32x4{hold[1][0], hold[1][1], hold[1][2], hold[1][3]};
+                }
+                hp += hstep;
+            }
             // vI(s): complete since the previous barrier at the latest
             const float *vcur = vbuf + ((s % R) * 2 + set) * VSTEP + voff;
             f32x4 vz[2], vr[2], vc[2];
@@ -436,16 +446,13 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
             oh = ldH(h_hi, boff[0]);
             ol = ldH(h_lo, boff[0]);
             lds_fence();
-            if (store) {
-                *reinterpret_cast<f32x4 *>(hp) = f32x4{hn[0][0], hn[0][1], hn[0][2], hn[0][3]};
-                *reinterpret_cast<f32x4 *>(hp + 16) = f32x4{hn[1][0], hn[1][1], hn[1][2], hn[1][3]};
-                if constexpr (SAVE) {
+            if constexpr (SAVE) {
+                if (store) {
                     *reinterpret_cast<f32x4 *>(zp) = f32x4{zz[0][0], zz[0][1], zz[0][2], zz[0][3]};
                     *reinterpret_cast<f32x4 *>(zp + 16) = f32x4{zz[1][0], zz[1][1], zz[1][2], zz[1][3]};
                 }
+                zp += zstep;
             }
-            hp += hstep;
-            if constexpr (SAVE) zp += zstep;
 #pragma unroll
             for (int p = 0; p < 2; p++) {
 #pragma unroll
@@ -456,6 +463,10 @@ __global__ void __launch_bounds__(256, 1) gru_bar16q_kernel(const float *__restr
             const int s = GS * G;
             step(ic<0>{}, s, G);
             if (s + 1 < T) step(ic<1>{}, s + 1, G);
+        }
+        if (live && T - 1 < Tc && !(BAR16Q_ABL & 4)) {   // h of the last step
+            *reinterpret_cast<f32x4 *>(hp) = f32x4{hold[0][0], hold[0][1], hold[0][2], hold[0][3]};
+            *reinterpret_cast<f32x4 *>(hp + 16) = f32x4{hold[1][0], hold[1][1], hold[1][2], hold[1][3]};
         }
     } else {
         // =================================================================================================

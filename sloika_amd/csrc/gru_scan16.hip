@@ -240,6 +240,8 @@ __global__ void __launch_bounds__(256, 1) gru_scan16_kernel(const float *__restr
         return acc;
     };
     half8 oh = {0, 0, 0, 0, 0, 0, 0, 0}, ol = {0, 0, 0, 0, 0, 0, 0, 0};      // my own K block of h(s-1) as B operand
+    settle(oh);
+    settle(ol);
     auto step = [&](auto PHC, const int s) {
         constexpr int ph = decltype(PHC)::value;
         VI &cur = vs[ph];

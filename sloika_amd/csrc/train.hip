@@ -1054,6 +1054,46 @@ __global__ void __launch_bounds__(1024) tn_reduce_kernel(const float *__restrict
     }
 }
 
+// several of those sums in one launch (slk_gemm_tn_multi_bf16x6_f32: up to four products and their column sums)
+struct TnReduceJobs {
+    const float *partial[2 * TN_MAXPROB];
+    float *C[2 * TN_MAXPROB];
+    long ldc[2 * TN_MAXPROB];
+    int N1[2 * TN_MAXPROB], N2[2 * TN_MAXPROB], first[2 * TN_MAXPROB + 1];      // first[k]: first workgroup of job k
+    int njob;
+};
+__global__ void __launch_bounds__(1024) tn_reduce_jobs_kernel(TnReduceJobs jobs, int nslice)
+{
+    __shared__ double part[16][64];
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < 2 * TN_MAXPROB; q++) k = (q < jobs.njob && (int)blockIdx.x >= jobs.first[q]) ? q : k;
+    const float *partial = jobs.partial[k];
+    const int N2 = jobs.N2[k];
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const size_t e = (size_t)((int)blockIdx.x - jobs.first[k]) * 64 + o, total = (size_t)jobs.N1[k] * N2;
+    double acc = 0.0;
+    if (e < total) {                                     // (the order of tn_reduce_kernel)
+        int s = sg;
+        for (; s + 7 * 16 < nslice; s += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = partial[(size_t)(s + 16 * j) * total + e];
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc += v[j];
+        }
+        for (; s < nslice; s += 16) acc += partial[(size_t)s * total + e];
+    }
+    part[sg][o] = acc;
+    __syncthreads();
+    if (sg == 0 && e < total) {
+        double tot = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) tot += part[j][o];
+        jobs.C[k][(e / N2) * jobs.ldc[k] + (e % N2)] = (float)tot;
+    }
+}
+
 static int tn_slice_rows(long M, int N1, int N2)
 {
     const long blocks = (long)((N1 + TN_BLK - 1) / TN_BLK) * ((N2 + TN_BLK - 1) / TN_BLK);
@@ -1179,14 +1219,26 @@ extern "C" int slk_gemm_tn_multi_bf16x6_f32(int nprob, const float *const *A, co
     pr.first[TN_MAXPROB] = pr.first[nprob];
     hipStream_t s = slk_stream(stream);
     hipLaunchKernelGGL(gemm_tn_bf16_multi_kernel, dim3((unsigned)(8 * ((W + 7) / 8))), dim3(64), 0, s, pr, M, rows, (int)nslice);
+    // the sums over the slices of every problem (and of its column sums) in one launch
+    TnReduceJobs jobs;
+    int nj = 0, blk = 0;
     for (int q = 0; q < nprob; q++) {
-        const size_t total = (size_t)N1[q] * N2[q];
-        hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, s, (const float *)pr.partial[q], (int)nslice,
-                           N1[q], N2[q], C[q], ldc[q]);
-        if (pr.cs_partial[q])
-            hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((N1[q] + 63) / 64)), dim3(1024), 0, s, (const float *)pr.cs_partial[q],
-                               (int)nslice, N1[q], 1, colsum[q], 1L);
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1 && !pr.cs_partial[q]) continue;
+            jobs.partial[nj] = pass ? pr.cs_partial[q] : pr.partial[q];
+            jobs.C[nj] = pass ? colsum[q] : C[q];
+            jobs.N1[nj] = N1[q];
+            jobs.N2[nj] = pass ? 1 : N2[q];
+            jobs.ldc[nj] = pass ? 1L : ldc[q];
+            jobs.first[nj] = blk;
+            blk += (int)(((size_t)N1[q] * (pass ? 1 : N2[q]) + 63) / 64);
+            nj++;
+        }
     }
+    for (int k = nj; k < 2 * TN_MAXPROB; k++) { jobs.partial[k] = nullptr; jobs.C[k] = nullptr; jobs.N1[k] = jobs.N2[k] = 0; jobs.ldc[k] = 0; jobs.first[k] = blk; }
+    jobs.first[2 * TN_MAXPROB] = blk;
+    jobs.njob = nj;
+    hipLaunchKernelGGL(tn_reduce_jobs_kernel, dim3((unsigned)blk), dim3(1024), 0, s, jobs, (int)nslice);
     return slk_launch_status();
 }
 

@@ -28,6 +28,11 @@ def test_no_mfma_destination_over_live_operands(tmp_path, src, flags):
     assert r.returncode == 0, r.stdout
     own, war = mfma_overlap_scan.scan(out)
     assert own == 0 and war == 0, "%s: %d MFMA destinations over their own operands, %d over the preceding MFMA's" % (src, own, war)
+    # ... and no MFMA reads a register the vector instruction right in front of it wrote: not interlocked either
+    # (tools/probes/valu_to_mfma_hazard_probe.hip), and hipcc counts no wait states for the MFMAs inside inline asm
+    import mfma_operand_hazard_scan
+    bad = mfma_operand_hazard_scan.scan(out)
+    assert not bad, "%s: %s" % (src, bad[:3])
 
 
 @pytest.mark.parametrize("src,nloads", [("gru_scan16.hip", 50), ("lstm_scan16.hip", 8), ("lstm_bwd16.hip", 8),
