@@ -230,7 +230,8 @@ def unit_utilisation(model, batch, chunk_len, kernel_substr, streams=1):
 TRAIN_HBM_STAGES = ("train_wgrad", "train_dx", "train_xent")
 #: the kernel a stage's time is spent in (for the utilisation lookup)
 STAGE_KERNEL = {"gru_fused": "gru_bar16", "softmax_viterbi": "softmax_viterbi_kernel", "lstm_fused": "lstm_fused16_kernel",
-                "gru_recurrent": "gru_scan", "train_wgrad": "gemm_tn", "train_gru_backward": "gru_bwd16_kernel"}
+                "gru_recurrent": "gru_scan", "train_wgrad": "gemm_tn_bf16_multi", "train_gru_scan": "gru_bwd16_kernel",
+                "train_dx": "gemm_bf16x6_kernel", "train_softmax_xent": "gemm_rows_f16x3_kernel"}
 
 
 def pmc_traffic(model, batch, chunk_len):

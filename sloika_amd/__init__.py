@@ -13,4 +13,18 @@ import os as _os
 # side streams for the directions of a birnn and one for copies) then serialise on them: baseline_raw_gru, 256 chunks, eight in
 # flight ran 191 M samples/s on 4 queues and 417 M on 32.  The runtime reads the variable once, when it starts, so it is set
 # here, at import, unless the user has chosen a value; device.want_hw_queues() warns when that came too late.
+def _hip_already_running():
+    """True when this process initialised the GPU runtime before importing sloika_amd (the value set below is then not read)."""
+    import sys
+    torch = sys.modules.get("torch")
+    try:
+        return bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+#: GPU_MAX_HW_QUEUES as the HIP runtime of this process saw (or will see) it: the user's value, else 32 if the runtime had not started
+#: when this module was imported, else the runtime's default of 4
+HW_QUEUES_IN_EFFECT = int(_os.environ["GPU_MAX_HW_QUEUES"]) if _os.environ.get("GPU_MAX_HW_QUEUES", "").isdigit() else (
+    4 if _hip_already_running() else 32)
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")

@@ -266,8 +266,44 @@ def raw_chunkify(signal, mapping_table, chunk_len, kmer_len, normalisation, down
     chunks = batch.normalise_chunks(D.to_dev(signal).reshape(ml, chunk_len), normalisation)
     nlabel = len(range(0, ml * chunk_len, downsample_factor))
     _, labels = _interp_call(mapping_table, mapping_attrs, None, kmer_len, True, True, downsample_factor, nlabel)
-    labels = labels.cpu().numpy().reshape((ml, -1))                       # chunkify_raw.py:192
+    labels = labels.cpu().numpy().astype(np.int64).reshape((ml, -1))      # chunkify_raw.py:189-192 (int64 there: np.array(...) + 1)
     return chunks[:, :, None].cpu().numpy(), labels, np.zeros((ml, chunk_len), dtype=bool)
+
+
+def raw_chunk_worker(fn, chunk_len, kmer_len, min_length, trim, normalisation, downsample_factor, interpolation=False):
+    """Worker of `chunkify raw_identity` for one single-read fast5 file with a stored mapping (chunkify_raw.py:213-257): same
+    arguments, the same tuple (chunks, labels, bad) or None with the reference's message on stderr.  `fn` may also be an object
+    that offers what the reference reads through untangled.fast5 -- `get_any_mapping_data('template')`, `get_read(raw=True)`,
+    `sample_rate`, `start_time` -- since that package is a dependency of the reference, not part of it: sloika_amd.fast5.Fast5
+    reads signal and stored basecalls only, so for a plain path the mapping data is reported as unavailable the way the reference
+    reports a file without it."""
+    try:
+        f5 = fn if hasattr(fn, 'get_any_mapping_data') else None
+        if f5 is None:
+            from . import fast5
+            f5 = fast5.Fast5(fn)
+        mapping_table, att = f5.get_any_mapping_data('template')
+        sig = f5.get_read(raw=True)
+        sample_rate = f5.sample_rate
+        start_sample = f5.start_time
+    except Exception as e:
+        sys.stderr.write('Failed to get mapping data from {}.\n{}\n'.format(fn, repr(e)))
+        return None
+    mapping_table = convert_mapping_times_to_samples(mapping_table, start_sample, sample_rate)
+    map_start = mapping_table['start'][0] + trim[0]
+    map_end = mapping_table['start'][-1] + mapping_table['length'][-1] - trim[1]
+    mapped_signal, mapping_table = trim_signal_and_mapping(sig, mapping_table, map_start, map_end)
+    try:
+        assert mapping_table_is_registered(mapped_signal, mapping_table)
+    except Exception as e:
+        sys.stderr.write('Failed to properly register raw signal and mapping table in {}.\n{}\n'.format(fn, repr(e)))
+        return None
+    if len(mapped_signal) < max(chunk_len, min_length):
+        sys.stderr.write('{} is too short.\n'.format(fn))
+        return None
+    chunks, labels, bad = raw_chunkify(mapped_signal, mapping_table, chunk_len, kmer_len, normalisation, downsample_factor,
+                                       interpolation, att)
+    return np.ascontiguousarray(chunks), np.ascontiguousarray(labels), np.ascontiguousarray(bad)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

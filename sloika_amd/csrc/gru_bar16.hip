@@ -675,6 +675,14 @@ static size_t exclusive_cu_lds_bar(K kernel)
     return dyn;
 }
 
+template <typename K>
+static int bar16_blocks_per_cu(K kernel)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), 256, 0) != hipSuccess) return 0;
+    return nb;
+}
+
 // share_cu: the caller runs more four-chunk workgroups at a time than there are CUs and the instantiation fits two per CU (<= 256
 // registers, <= 80 KB of LDS: the 64-wide ones): no dynamic LDS, so that two of them -- the directions of a birnn -- share a CU
 template <int I, int N>
@@ -701,6 +709,13 @@ static int launch_bar16(const float *x, long ldx, const float *iW, const float *
     }
 #endif
     const bool shared = share_cu && N <= 64;
+    if (shared) {
+        // the caller's plan counts on two of these workgroups per CU: ask the runtime whether they fit (a compiler that takes more
+        // than 256 registers or 80 KB of LDS for the instantiation would otherwise halve the plan's speed silently)
+        const int fit = zr_out ? SLK_PER_DEVICE(int, bar16_blocks_per_cu(gru_bar16_kernel<I, N, true>))
+                               : SLK_PER_DEVICE(int, bar16_blocks_per_cu(gru_bar16_kernel<I, N, false>));
+        if (fit < 2) return SLK_ERR_UNSUPPORTED;         // -> slk_gru_bar16_f32 takes the eight-chunk plan
+    }
     if (zr_out) {
         const size_t dyn = shared ? 0 : SLK_PER_DEVICE(size_t, exclusive_cu_lds_bar(gru_bar16_kernel<I, N, true>));
         hipLaunchKernelGGL((gru_bar16_kernel<I, N, true>), dim3((B + 3) / 4), dim3(256), dyn, s, x, ldx, iW, bias, sW, sW2, y,
@@ -759,8 +774,15 @@ extern "C" int slk_gru_bar16_f32(const float *x, long ldx, const float *iW, cons
         const int rc = slk_gru_bar16d_launch(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse, lens, zr_out, s);
         if (rc != SLK_ERR_UNSUPPORTED) return rc;
     }
-#define BAR16(II, NN) \
-    if (insize == II && n == NN) return launch_bar16<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s, share_cu);
+#define BAR16(II, NN)                                                                                                              \
+    if (insize == II && n == NN) {                                                                                                 \
+        int rc = launch_bar16<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s, share_cu);                 \
+        if (rc == SLK_ERR_UNSUPPORTED && share_cu) {     /* two workgroups per CU do not fit: eight chunks, else one per CU */     \
+            rc = slk_gru_bar16d_launch(x, ldx, iW, sW, sW2, bias, y, ldy, T, B, insize, n, reverse, lens, zr_out, s);              \
+            if (rc == SLK_ERR_UNSUPPORTED) rc = launch_bar16<II, NN>(x, ldx, iW, bias, sW, sW2, y, ldy, T, B, reverse, lens, zr_out, s, false); \
+        }                                                                                                                          \
+        return rc;                                                                                                                 \
+    }
     BAR16(96, 96) BAR16(64, 64) BAR16(32, 96) BAR16(128, 96) BAR16(64, 96) BAR16(48, 32) BAR16(16, 64)
 #undef BAR16
     return SLK_ERR_UNSUPPORTED;

@@ -1094,12 +1094,11 @@ __global__ void __launch_bounds__(1024) tn_reduce_jobs_kernel(TnReduceJobs jobs,
     }
 }
 
+static int tn_multi_slice_rows(long M, long blocks);
 static int tn_slice_rows(long M, int N1, int N2)
 {
     const long blocks = (long)((N1 + TN_BLK - 1) / TN_BLK) * ((N2 + TN_BLK - 1) / TN_BLK);
-    long rows = M * blocks / TN_WAVES;
-    rows = (rows + 31) / 32 * 32;                              // the kernel walks 32 rows per double-buffered iteration
-    return (int)(rows < TN_MIN_ROWS ? TN_MIN_ROWS : (rows > TN_ROWS ? TN_ROWS : rows));
+    return tn_multi_slice_rows(M, blocks);
 }
 
 extern "C" size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2)
@@ -1168,7 +1167,11 @@ static int tn_multi_slice_rows(long M, long blocks)
 {
     long rows = M * blocks / TN_WAVES;
     rows = (rows + 31) / 32 * 32;
-    return (int)(rows < TN_MIN_ROWS ? TN_MIN_ROWS : (rows > TN_ROWS ? TN_ROWS : rows));
+    rows = rows < TN_MIN_ROWS ? TN_MIN_ROWS : (rows > TN_ROWS ? TN_ROWS : rows);
+    // not one work item more than the waves wanted: 2052 items on 1024 wave slots are THREE rounds, the last one of four waves (the six
+    // blocks of a Gru layer at M = 819200 had exactly that: train_wgrad 4.1 -> 3.4 ms per step)
+    while (rows < TN_ROWS && blocks * ((M + rows - 1) / rows) > TN_WAVES) rows += 32;
+    return (int)rows;
 }
 
 extern "C" size_t slk_gemm_tn_multi_workspace_bytes(long M, int nprob, const int *N1, const int *N2)

@@ -44,12 +44,9 @@ def want_hw_queues(n):
     """Called by users of several streams (pipeline.Basecaller(in_flight > 2)): warn when the HIP runtime was started with fewer
     hardware queues than streams that are meant to run side by side (GPU_MAX_HW_QUEUES, default 4, is read once at start-up:
     sloika_amd sets 32 at import unless the environment says otherwise)."""
-    import os
     import warnings
-    try:
-        have = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
-    except ValueError:
-        have = 4
+    import sloika_amd
+    have = sloika_amd.HW_QUEUES_IN_EFFECT            # (not os.environ: the import sets the variable even when it comes too late)
     if have < min(n, 32):
         warnings.warn("sloika_amd: GPU_MAX_HW_QUEUES=%d but %d streams are meant to run side by side; batches in flight will "
                       "serialise on the hardware queues (set GPU_MAX_HW_QUEUES=32 before the process touches the GPU)" % (have, n))

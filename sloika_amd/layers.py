@@ -220,7 +220,10 @@ def _derived_cache(owner, attr, params, build):
         tensors = build()
         ev = torch.cuda.Event()
         ev.record(cur)
-        owner.__dict__[attr] = cache = (key, tensors, ev, cur)
+        # The generation this one replaces stays referenced until the NEXT replacement: kernels queued on other streams may still be
+        # reading it, and torch's per-stream allocator would hand its memory to the next allocation on the building stream the
+        # moment the last reference goes (weights replaced while inference is in flight; one extra copy of the derived tensors).
+        owner.__dict__[attr] = cache = (key, tensors, ev, cur, None if cache is None else cache[1])
     elif cache[3] != cur and not cache[2].query():
         cur.wait_event(cache[2])
     return cache[1]
@@ -981,7 +984,7 @@ class Gru(RNN):
         b = np.zeros((3, n16), dtype=sloika_dtype)
         b[:, :n] = self.b.get_value().reshape(3, n)
         twin.set_params({"iW": iW, "sW": sW, "sW2": sW2, "b": b})
-        self._pad_cache = (key, twin)
+        self._pad_cache = (key, twin, None if cache is None else cache[1])      # (the twin it replaces: kept one generation, as in _derived_cache)
         return twin
 
     def __getstate__(self):

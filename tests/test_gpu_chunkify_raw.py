@@ -71,10 +71,54 @@ def test_raw_chunkify_matches_reference(gold, ci, interp):
     attrs = {"reference": c["ref"], "direction": "+", "ref_start": 0}
     chunks, labels, bad = cr.raw_chunkify(c["signal"], _table(gold, tag), c["chunk_len"], 5, c["norm"], c["ds"], interp, attrs)
     k = tag + ("interp_" if interp else "plain_")
-    assert labels.dtype == np.int32 and np.array_equal(labels, gold[k + "labels"])
+    # (the reference's interpolated labels are int64 -- np.array(...) + 1, chunkify_raw.py:113 -- the others 'i4', :205)
+    assert labels.dtype == (np.int64 if interp else np.int32) and np.array_equal(labels, gold[k + "labels"])
     assert bad.dtype == bool and np.array_equal(bad, gold[k + "bad"])
     assert chunks.dtype == np.float32 and chunks.shape == gold[k + "chunks"].shape + (1,)
     assert np.array_equal(chunks[:, :, 0], gold[k + "chunks"])
+
+
+def test_raw_chunk_worker_with_a_stored_mapping(gold, capsys):
+    """chunkify_raw.py:213-257 (`chunkify raw_identity`): mapping times in seconds -> samples, trim, register, chunk.  The reference
+    reads the stored mapping through untangled.fast5 (a dependency, not in its tree); here a stand-in object offers the same four
+    things, built from a golden table shifted by a start time and expressed in seconds."""
+    from sloika_amd import batch, chunkify_raw as cr
+    batch.init_chunk_identity_worker(5, b"ACGT")
+    c = case(gold, 0)
+    tag = c["tag"]
+    table = _table(gold, tag)
+    rate, start_time, lead = 4000.0, 12000, 37                      # 37 unmapped samples in front of the mapped part
+    secs = np.zeros(len(table), dtype=[(n, "<f8" if n in ("start", "length") else k) for n, k in table.dtype.descr])
+    for n in table.dtype.names:
+        secs[n] = table[n]
+    secs["start"] = (table["start"] + lead + start_time) / rate
+    secs["length"] = table["length"] / rate
+    signal = np.concatenate([np.full(lead, 50.0, dtype=np.float32), c["signal"], np.full(11, 50.0, dtype=np.float32)])
+    attrs = {"reference": c["ref"], "direction": "+", "ref_start": 0}
+
+    class Stored(object):
+        sample_rate = rate
+
+        def __init__(self):
+            self.start_time = start_time
+
+        def get_any_mapping_data(self, section):
+            assert section == "template"
+            return secs, attrs
+
+        def get_read(self, raw=True):
+            return signal
+
+    got = cr.raw_chunk_worker(Stored(), c["chunk_len"], 5, 0, (0, 0), c["norm"], c["ds"])
+    want = cr.raw_chunkify(c["signal"], table, c["chunk_len"], 5, c["norm"], c["ds"], False)
+    for a, b in zip(got, want):
+        assert a.flags["C_CONTIGUOUS"] and a.dtype == b.dtype and np.array_equal(a, b)
+    assert np.array_equal(got[1], gold[tag + "plain_labels"])
+    # too short for min_length, and a file without a stored mapping: None and the reference's messages
+    assert cr.raw_chunk_worker(Stored(), c["chunk_len"], 5, 10 ** 9, (0, 0), c["norm"], c["ds"]) is None
+    assert "is too short" in capsys.readouterr().err
+    assert cr.raw_chunk_worker("/nonexistent/read.fast5", 500, 5, 0, (0, 0), "per-read", 5) is None
+    assert "Failed to get mapping data from /nonexistent/read.fast5" in capsys.readouterr().err
 
 
 def test_remap_then_chunkify_end_to_end(gold):

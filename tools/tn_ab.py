@@ -47,3 +47,37 @@ for n1, n2, lda, cs in ((288, 96, 288, True), (192, 96, 288, False), (96, 96, 28
     if len(out) == 2:
         msg += "   colsum diff %.2e" % float((out[0][2] - out[1][2]).abs().max())
     print(msg, flush=True)
+
+# the three weight gradients of a Gru layer in one launch (slk_gemm_tn_multi_bf16x6_f32), where the builds have it
+n = 96
+da = torch.randn(M, 3 * n, device="cuda") * 1e-3
+xs = [torch.randn(M, n, device="cuda") for _ in range(3)]
+shapes = [(3 * n, n, 0), (2 * n, n, 0), (n, n, 2 * n)]
+msg = "Gru layer, three problems in one launch:"
+for k, lib in enumerate(libs):
+    if not hasattr(lib, "slk_gemm_tn_multi_bf16x6_f32"):
+        continue
+    vps, longs, ints = ctypes.c_void_p * 3, ctypes.c_long * 3, ctypes.c_int * 3
+    n1s, n2s = ints(*[s_[0] for s_ in shapes]), ints(*[s_[1] for s_ in shapes])
+    lib.slk_gemm_tn_multi_workspace_bytes.restype = ctypes.c_size_t
+    lib.slk_gemm_tn_multi_workspace_bytes.argtypes = [L, I, vp, vp]
+    lib.slk_gemm_tn_multi_bf16x6_f32.argtypes = [I, vp, vp, vp, vp, vp, vp, L, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    nb = lib.slk_gemm_tn_multi_workspace_bytes(M, 3, n1s, n2s)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    Cs = [torch.zeros(a, b, device="cuda") for a, b, _ in shapes]
+    col = torch.zeros(3 * n, device="cuda")
+    args = (3, vps(*[da.data_ptr() + 4 * s_[2] for s_ in shapes]), longs(3 * n, 3 * n, 3 * n), vps(*[x.data_ptr() for x in xs]), longs(n, n, n),
+            vps(*[c.data_ptr() for c in Cs]), longs(n, n, n), M, n1s, n2s, vps(col.data_ptr(), None, None), ws.data_ptr(), nb, st)
+    assert lib.slk_gemm_tn_multi_bf16x6_f32(*args) == 0
+    torch.cuda.synchronize()
+    ts = []
+    for rnd in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            lib.slk_gemm_tn_multi_bf16x6_f32(*args)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 10)
+    msg += "   %s %.3f ms" % (os.path.basename(paths[k])[:16], min(ts))
+print(msg, flush=True)
