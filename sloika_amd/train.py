@@ -306,6 +306,8 @@ class TrainingStep(object):
 
     # ---- the step ---------------------------------------------------------------------------------------------------
     def __call__(self, x, labels, weights, rate):
+        """One training step.  (Loss and accuracy are read back BEFORE the update is queued, although that leaves the device idle for
+        60-85 us: a batch whose labels are out of range must raise without having changed a parameter.)"""
         loss, acc = self.forward_backward(x, labels, weights)
         self.update(rate)
         return loss, acc
@@ -313,6 +315,19 @@ class TrainingStep(object):
     def forward_backward(self, x, labels, weights):
         """Loss and accuracy of the (global) batch; leaves d loss / d params (without the l2 term, which the update adds) in
         self.grad, summed over the ranks, and the factor that turns the sum into the mean in self.gscale."""
+        self._queue_forward_backward(x, labels, weights)
+        return self._read_loss()
+
+    def _read_loss(self):
+        """(loss, accuracy) of the step that _queue_forward_backward queued; raises if its labels were out of range (checked on the
+        device beside the step -- a host-side check was two more synchronisations in the middle of it)."""
+        s = self._scalars.cpu().numpy()
+        if self._bad_labels is not None and bool(self._bad_labels.item()):
+            raise ValueError("labels must lie in [0, %d)" % self.softmax.size)
+        loss = float(s[0]) * self.gscale + (self.l2 * float(s[2]) if self.l2 != 0.0 else 0.0)
+        return loss, float(s[1]) * self.gscale
+
+    def _queue_forward_backward(self, x, labels, weights):
         import torch
         from . import device as D
         L = _lib.lib()
@@ -335,13 +350,18 @@ class TrainingStep(object):
             raise ValueError("labels and weights must be [%d, %d] (the network's output length x batch)" % (To, B))
         if 2 * self.drop >= To:
             raise ValueError("drop=%d leaves nothing of %d output steps" % (self.drop, To))
-        if int(labels.min()) < 0 or int(labels.max()) >= sm.size:
-            raise ValueError("labels must lie in [0, %d)" % sm.size)
         # ---- loss, accuracy, d loss / d logits (in place) -------------------------------------------------------------
         rows = torch.empty((2, M), dtype=torch.float32, device=x.device)
         sc = self._scalars
+        # labels outside [0, size): the two-pass kernel only compares columns with the label (a row without a match gets garbage, no
+        # access outside its buffers), so the check runs on the device and is read with the loss; the in-place kernel indexes the
+        # logits row with the label and needs the answer first
+        self._bad_labels = ((labels < 0) | (labels >= sm.size)).any()
         logits, ld = self._softmax_grad_two_pass(h_top, labels, weights, rows)
         if logits is None:
+            if bool(self._bad_labels.item()):
+                raise ValueError("labels must lie in [0, %d)" % sm.size)
+            self._bad_labels = None
             logits, stats, ld = sm.logits_and_stats(h_top)
             with profiler.region("train_xent", 0.0, 8.0 * M * ld):
                 _lib.check(L.slk_softmax_xent_grad_f32(logits.data_ptr(), ld, stats.data_ptr(), labels.data_ptr(),
@@ -373,9 +393,6 @@ class TrainingStep(object):
         self.gscale = allreduce_mean_(self.grad)
         if self.gscale != 1.0:
             allreduce_mean_(sc[:2])
-        s = sc.cpu().numpy()
-        loss = float(s[0]) * self.gscale + (self.l2 * float(s[2]) if self.l2 != 0.0 else 0.0)
-        return loss, float(s[1]) * self.gscale
 
     def _softmax_grad_two_pass(self, h_top, labels, weights, rows):
         """(d loss / d logits [M][ld], ld) with the rows' loss and accuracy terms in rows[0], rows[1] -- or (None, None) where the

@@ -570,3 +570,26 @@ def test_gemm_tn_multi_equals_single_launches(M, n, i_sz):
     assert float((cs_single - cs_multi).abs().max()) <= 2e-6 * float(cs_single.abs().max())
     assert L.slk_gemm_tn_multi_bf16x6_f32(*args, nbytes - 1, stream()) == _lib.SLK_ERR_WORKSPACE
     assert L.slk_gemm_tn_multi_bf16x6_f32(5, *args[1:], nbytes, stream()) == _lib.SLK_ERR_INVALID_ARG
+
+
+def test_out_of_range_labels_raise_and_leave_the_parameters_alone():
+    """The two-pass softmax path checks the labels on the device, beside the step (no host synchronisation in the middle of it): the
+    step still raises, and it raises before the optimiser has touched a parameter."""
+    need_gpu()
+    from sloika_amd import train
+    rs = np.random.RandomState(3)
+    net = _build(rs, n=64, nstate=260, nlayer=1)
+    step = train.TrainingStep(net, drop=1)
+    x, labels, weights = _batch(rs, net, 40, 3)
+    before = [p.get_value().copy() for p in net.params()]
+    bad = labels.copy()
+    bad[7, 1] = 260
+    with pytest.raises(ValueError):
+        step(x, bad, weights, 1e-3)
+    bad[7, 1] = -1
+    with pytest.raises(ValueError):
+        step.forward_backward(x, bad, weights)
+    for a, p in zip(before, net.params()):
+        np.testing.assert_array_equal(a, p.get_value())
+    loss, acc = step(x, labels, weights, 1e-3)                     # ... and the step object is still usable
+    assert np.isfinite(loss) and any((a != p.get_value()).any() for a, p in zip(before, net.params()))
