@@ -495,6 +495,9 @@ SLK_API int slk_linear_xent_grad_f16x3(const float *x, long ldx, const void *W_h
                                int T, int B, int drop, float min_prob, float *loss_rows, float *correct_rows, float *xrow,
                                slk_stream_t stream);
 SLK_API int slk_reduce_sum_f32(const float *x, size_t n, int square, double *out, slk_stream_t stream);
+/* out[r] = sum of x[r][0..n) for r < nrow (<= 16) contiguous arrays, float64, fixed order, 256 workgroups per array (the loss and
+ * accuracy terms of a step: two launches of ~5 us where two slk_reduce_sum_f32 take 2 x 74 us).  scratch: nrow * 256 doubles. */
+SLK_API int slk_reduce_rows_sum_f32(const float *x, int nrow, size_t n, double *out, double *scratch, slk_stream_t stream);
 SLK_API size_t slk_gemm_tn_workspace_bytes(long M, int N1, int N2);
 /* 1..4 contractions over the same M rows in ONE launch (the weight gradients of a recurrent layer all contract the same dL/d(pre-
  * activation) matrix: launched together its rows cross the memory bus once): C[q] = A[q]^T B[q], colsum[q] (the array or an entry may be

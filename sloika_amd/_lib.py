@@ -93,6 +93,7 @@ PROTOTYPES = {
     "slk_softmax_xent_grad_f32": (_i, [_vp, _l, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "slk_linear_xent_grad_f16x3": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "slk_reduce_sum_f32": (_i, [_vp, _sz, _i, _vp, _vp]),
+    "slk_reduce_rows_sum_f32": (_i, [_vp, _i, _sz, _vp, _vp, _vp]),
     "slk_gemm_tn_workspace_bytes": (_sz, [_l, _i, _i]),
     "slk_gemm_tn_f32": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _vp, _vp, _sz, _vp]),
     "slk_gemm_tn_bf16x6_f32": (_i, [_vp, _l, _vp, _l, _vp, _l, _l, _i, _i, _vp, _vp, _sz, _vp]),

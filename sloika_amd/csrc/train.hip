@@ -656,6 +656,55 @@ extern "C" int slk_reduce_sum_f32(const float *x, size_t n, int square, double *
     return slk_launch_status();
 }
 
+// The sums of nrow arrays x[r][0..n) in two launches: 256 workgroups per array each add a contiguous piece (thread-strided, eight loads
+// in flight, float64, then the tree of reduce_sum_kernel), one workgroup per array adds the 256 pieces in a fixed tree.  Deterministic
+// like reduce_sum_kernel -- whose single workgroup needs 74 us for the 819200 loss terms of a training step, twice per step.
+#define RS_PIECES 256
+__global__ void __launch_bounds__(256) reduce_rows_partial_kernel(const float *__restrict__ x, size_t n, double *__restrict__ scratch)
+{
+    __shared__ double part[256];
+    const float *row = x + (size_t)blockIdx.y * n;
+    const size_t per = (n + RS_PIECES - 1) / RS_PIECES, lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    double acc = 0.0;
+    size_t e = lo + threadIdx.x;
+    for (; e + 7 * 256 < hi; e += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = row[e + (size_t)k * 256];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc += (double)v[k];
+    }
+    for (; e < hi; e += 256) acc += (double)row[e];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scratch[(size_t)blockIdx.y * RS_PIECES + blockIdx.x] = part[0];
+}
+__global__ void __launch_bounds__(RS_PIECES) reduce_rows_final_kernel(const double *__restrict__ scratch, double *__restrict__ out)
+{
+    __shared__ double part[RS_PIECES];
+    part[threadIdx.x] = scratch[(size_t)blockIdx.x * RS_PIECES + threadIdx.x];
+    __syncthreads();
+    for (int s = RS_PIECES / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+
+// out[r] = sum of x[r][0..n), r < nrow <= 16; scratch: nrow * 256 doubles
+extern "C" int slk_reduce_rows_sum_f32(const float *x, int nrow, size_t n, double *out, double *scratch, slk_stream_t stream)
+{
+    if (!x || !out || !scratch || nrow < 1 || nrow > 16 || n < 1) return SLK_ERR_INVALID_ARG;
+    hipStream_t s = slk_stream(stream);
+    hipLaunchKernelGGL(reduce_rows_partial_kernel, dim3(RS_PIECES, nrow), dim3(256), 0, s, x, n, scratch);
+    hipLaunchKernelGGL(reduce_rows_final_kernel, dim3(nrow), dim3(RS_PIECES), 0, s, (const double *)scratch, out);
+    return slk_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // C[N1][N2] = A^T B over M rows (A:[M][N1], B:[M][N2], row-major): every weight gradient of the reverse pass.
 // v_mfma_f32_32x32x2_f32 contracts over k = the ROW index m, and both operands want "32 consecutive columns of one row

@@ -225,6 +225,7 @@ class TrainingStep(object):
         self._index = {id(p): i for i, p in enumerate(self.shared)}
         self._ws = None
         self._scalars = torch.zeros(3, dtype=torch.float64, device=dev)
+        self._sum_scratch = torch.empty(2 * 256, dtype=torch.float64, device=dev)
         self._drop_caches()
 
     # ---- plumbing -------------------------------------------------------------------------------------------------
@@ -368,8 +369,7 @@ class TrainingStep(object):
                                                        weights.data_ptr(), To, B, sm.size, self.drop, self.min_prob,
                                                        rows[0].data_ptr(), rows[1].data_ptr(), st()), "softmax_xent")
         with profiler.region("train_xent_sums", 0.0, 8.0 * M):
-            _lib.check(L.slk_reduce_sum_f32(rows[0].data_ptr(), M, 0, sc[0:].data_ptr(), st()), "reduce")
-            _lib.check(L.slk_reduce_sum_f32(rows[1].data_ptr(), M, 0, sc[1:].data_ptr(), st()), "reduce")
+            _lib.check(L.slk_reduce_rows_sum_f32(rows.data_ptr(), 2, M, sc.data_ptr(), self._sum_scratch.data_ptr(), st()), "reduce")
             if self.l2 != 0.0:
                 _lib.check(L.slk_reduce_sum_f32(self.flat.data_ptr(), self.flat.numel(), 1, sc[2:].data_ptr(), st()), "reduce")
         # ---- softmax layer ---------------------------------------------------------------------------------------------

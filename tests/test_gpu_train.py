@@ -593,3 +593,21 @@ def test_out_of_range_labels_raise_and_leave_the_parameters_alone():
         np.testing.assert_array_equal(a, p.get_value())
     loss, acc = step(x, labels, weights, 1e-3)                     # ... and the step object is still usable
     assert np.isfinite(loss) and any((a != p.get_value()).any() for a, p in zip(before, net.params()))
+
+
+@pytest.mark.parametrize("n", [1, 255, 819200, 70001])
+def test_reduce_rows_sum(n):
+    torch = need_gpu()
+    from sloika_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(n % 97)
+    x = (rs.normal(size=(3, n)) * 10.0 ** rs.uniform(-3, 3, size=(3, 1))).astype(np.float32)
+    xd = dev(x)
+    out = torch.zeros(3, dtype=torch.float64, device="cuda")
+    scratch = torch.empty(3 * 256, dtype=torch.float64, device="cuda")
+    assert L.slk_reduce_rows_sum_f32(xd.data_ptr(), 3, n, out.data_ptr(), scratch.data_ptr(), stream()) == 0
+    want = x.astype(np.float64).sum(axis=1)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-12, atol=1e-9 * np.abs(x).max())
+    again = torch.zeros(3, dtype=torch.float64, device="cuda")
+    assert L.slk_reduce_rows_sum_f32(xd.data_ptr(), 3, n, again.data_ptr(), scratch.data_ptr(), stream()) == 0
+    assert torch.equal(out, again)                                 # fixed order: the same bits every time
