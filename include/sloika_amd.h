@@ -180,6 +180,11 @@ SLK_API size_t slk_pack_bf16x3_bytes(int N, int K);
 SLK_API int slk_pack_bf16x3_f32(const float *W, int N, int K, void *packed, slk_stream_t stream);
 SLK_API int slk_gemm_bias_act_bf16x6(const float *x, long ldx, const void *packed, const float *bias, float *y, long ldy, long M,
                              int K, int N, int act, slk_stream_t stream);
+/* out = (x . W^T) * fun'(.), fun' in terms of the OUTPUT yref:[M][N] (rows ldyref apart) of the activation `dact` of the layer below
+ * (tanh, sigmoid, relu, elu, linear): the dL/dx product of a layer and slk_act_backward_f32 of the layer below it in one pass.
+ * Same shapes and packed weights as slk_gemm_bias_act_bf16x6; SLK_ERR_UNSUPPORTED likewise (-> the two calls). */
+SLK_API int slk_gemm_dact_bf16x6(const float *x, long ldx, const void *packed, const float *yref, long ldyref, int dact, float *out,
+                         long ldo, long M, int K, int N, slk_stream_t stream);
 /* In-place row softmax of y:[M][N] (the second half of the above, exposed for testing).                     */
 SLK_API int slk_softmax_rows_f32(float *y, long M, int N, slk_stream_t stream);
 /* Row statistics only: stats[r] = (max_j logits[r][j], 1 / sum_j exp(logits[r][j] - max)); the posterior

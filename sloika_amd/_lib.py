@@ -44,6 +44,7 @@ PROTOTYPES = {
     "slk_pack_bf16x3_bytes": (_sz, [_i, _i]),
     "slk_pack_bf16x3_f32": (_i, [_vp, _i, _i, _vp, _vp]),
     "slk_gemm_bias_act_bf16x6": (_i, [_vp, _l, _vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
+    "slk_gemm_dact_bf16x6": (_i, [_vp, _l, _vp, _vp, _l, _i, _vp, _l, _l, _i, _i, _vp]),
     "slk_gemm_bias_act_f16x3": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
     "slk_softmax_from_stats_f32": (_i, [_vp, _l, _vp, _vp, _l, _l, _i, _vp]),
     "slk_softmax_rows_f32": (_i, [_vp, _l, _i, _vp]),

@@ -73,10 +73,21 @@ __global__ void __launch_bounds__(256) pack_bf16x3_kernel(const float *__restric
 // ends it (the one-tile form requests a slab, waits, stages and multiplies it, and three workgroups per CU fill each other's waits:
 // pipelined as well it needs 24 registers more than three waves per SIMD leave and was slower, 1.86 against 1.37 ms).
 // 819200 x 1056 -> 96: 1.37 ms one tile, 1.43 two tiles unpipelined, 1.12 two tiles pipelined.
+__device__ __forceinline__ float gb_dact(float v, int act)
+{
+    switch (act) {                                       // activation.py:8-57, as act_backward_kernel
+    case SLK_ACT_TANH: return 1.0f - v * v;
+    case SLK_ACT_SIGMOID: return v * (1.0f - v);
+    case SLK_ACT_RELU: return v > 0.0f ? 1.0f : 0.0f;
+    case SLK_ACT_ELU: return v > 0.0f ? 1.0f : v + 1.0f;
+    default: return 1.0f;
+    }
+}
+
 template <int NT, int ACT, int WR>
 __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const float *__restrict__ x, long ldx, const uint4 *__restrict__ wp,
                                                           const float *__restrict__ bias, float *__restrict__ y, long ldy, long M, int K,
-                                                          int KP, int N, int ntile_n)
+                                                          int KP, int N, int ntile_n, const float *__restrict__ dref, long lddref, int dact)
 {
     constexpr int BN = 32 * NT;
     constexpr int BM = GB_BM * WR;
@@ -209,12 +220,27 @@ __global__ void __launch_bounds__(256) gemm_bf16x6_kernel(const float *__restric
         const int col = n0 + 32 * nt + r;
         if (col >= N) continue;
         const float bv = bias ? bias[col] : 0.0f;
+        // dL/dx of a layer whose input is the output `dref` of an element-wise activation: times fun'(.) written in terms of that
+        // output (csrc/train.hip act_backward_kernel), so that the layer below receives dL/d(pre-activation).  All of a tile's
+        // reference values are requested before the first store (from clamped rows: no branch around the loads).
+        float dv[WR][16];
+        if (dref) {
+#pragma unroll
+            for (int w = 0; w < WR; w++)
+#pragma unroll
+                for (int reg = 0; reg < 16; reg++) {
+                    const long row = m0 + 32 * (WR * wave + w) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                    dv[w][reg] = dref[(row < M ? row : M - 1) * lddref + col];
+                }
+        }
 #pragma unroll
         for (int w = 0; w < WR; w++)
 #pragma unroll
             for (int reg = 0; reg < 16; reg++) {
                 const long row = m0 + 32 * (WR * wave + w) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (row < M) y[row * ldy + col] = slk_act_t<ACT>(acc[w][nt][reg] + bv);
+                float v = slk_act_t<ACT>(acc[w][nt][reg] + bv);
+                if (dref) v *= gb_dact(dv[w][reg], dact);
+                if (row < M) y[row * ldy + col] = v;
             }
     }
 }
@@ -239,7 +265,7 @@ extern "C" int slk_pack_bf16x3_f32(const float *W, int N, int K, void *packed, s
 
 template <int NT>
 static int gb_launch(const float *x, long ldx, const uint4 *wp, const float *bias, float *y, long ldy, long M, int K, int N, int act,
-                     hipStream_t s)
+                     hipStream_t s, const float *dref = nullptr, long lddref = 0, int dact = 0)
 {
     // two row tiles per wave for the 96-column products of a large batch (measured: 819200 x 1056 -> 96 1.37 -> 1.12 ms, x 288 -> 96
     // 0.39 -> 0.38; 64 columns 0.26 -> 0.34, so those and everything small stay with one tile)
@@ -250,9 +276,9 @@ static int gb_launch(const float *x, long ldx, const uint4 *wp, const float *bia
     if (blocks > 0x7fffffffL) return SLK_ERR_UNSUPPORTED;
 #define GB_LAUNCH(AC)                                                                                                            \
     if (wide) hipLaunchKernelGGL((gemm_bf16x6_kernel<NT, AC, WRMAX>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, wp, bias, y, ldy, M, K, KP, N, \
-                       ntile_n);                                                                                                 \
+                       ntile_n, dref, lddref, dact);                                                                             \
     else hipLaunchKernelGGL((gemm_bf16x6_kernel<NT, AC, 1>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, wp, bias, y, ldy, M, K, KP, N, \
-                       ntile_n)
+                       ntile_n, dref, lddref, dact)
     switch (act) {
     case SLK_ACT_LINEAR: GB_LAUNCH(SLK_ACT_LINEAR); break;
     case SLK_ACT_TANH: GB_LAUNCH(SLK_ACT_TANH); break;
@@ -263,10 +289,11 @@ static int gb_launch(const float *x, long ldx, const uint4 *wp, const float *bia
     return slk_launch_status();
 }
 
-extern "C" int slk_gemm_bias_act_bf16x6(const float *x, long ldx, const void *packed, const float *bias, float *y, long ldy, long M,
-                                        int K, int N, int act, slk_stream_t stream)
+static int gb_entry(const float *x, long ldx, const void *packed, const float *bias, float *y, long ldy, long M, int K, int N, int act,
+                    const float *dref, long lddref, int dact, slk_stream_t stream)
 {
     if (!x || !packed || !y || M < 0 || K < 1 || N < 1 || ldx < K || ldy < N || !slk_act_valid(act)) return SLK_ERR_INVALID_ARG;
+    if (dref && (lddref < N || !slk_act_valid(dact))) return SLK_ERR_INVALID_ARG;
     if (M == 0) return SLK_OK;
     if ((K & 3) || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15))
         return SLK_ERR_UNSUPPORTED;
@@ -279,9 +306,27 @@ extern "C" int slk_gemm_bias_act_bf16x6(const float *x, long ldx, const void *pa
     hipStream_t s = slk_stream(stream);
     const uint4 *wp = static_cast<const uint4 *>(packed);
     switch (best) {
-    case 1: return gb_launch<1>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
-    case 2: return gb_launch<2>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
-    case 3: return gb_launch<3>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
-    default: return gb_launch<4>(x, ldx, wp, bias, y, ldy, M, K, N, act, s);
+    case 1: return gb_launch<1>(x, ldx, wp, bias, y, ldy, M, K, N, act, s, dref, lddref, dact);
+    case 2: return gb_launch<2>(x, ldx, wp, bias, y, ldy, M, K, N, act, s, dref, lddref, dact);
+    case 3: return gb_launch<3>(x, ldx, wp, bias, y, ldy, M, K, N, act, s, dref, lddref, dact);
+    default: return gb_launch<4>(x, ldx, wp, bias, y, ldy, M, K, N, act, s, dref, lddref, dact);
     }
+}
+
+extern "C" int slk_gemm_bias_act_bf16x6(const float *x, long ldx, const void *packed, const float *bias, float *y, long ldy, long M,
+                                        int K, int N, int act, slk_stream_t stream)
+{
+    return gb_entry(x, ldx, packed, bias, y, ldy, M, K, N, act, nullptr, 0, 0, stream);
+}
+
+// out = (x . W^T) * fun'(.) with fun' written in terms of the OUTPUT `yref` of the activation below (tanh 1 - y^2, sigmoid y (1 - y),
+// relu [y > 0], elu y > 0 ? 1 : y + 1, linear 1): dL/dx of a layer and slk_act_backward_f32 of the layer below it in one pass
+// (the training step's Gru-over-Convolution boundary: one write and one read of [M][N] less).
+extern "C" int slk_gemm_dact_bf16x6(const float *x, long ldx, const void *packed, const float *yref, long ldyref, int dact, float *out,
+                                    long ldo, long M, int K, int N, slk_stream_t stream)
+{
+    if (!yref) return SLK_ERR_INVALID_ARG;
+    if (dact != SLK_ACT_TANH && dact != SLK_ACT_SIGMOID && dact != SLK_ACT_RELU && dact != SLK_ACT_ELU && dact != SLK_ACT_LINEAR)
+        return SLK_ERR_UNSUPPORTED;
+    return gb_entry(x, ldx, packed, nullptr, out, ldo, M, K, N, SLK_ACT_LINEAR, yref, ldyref, dact, stream);
 }

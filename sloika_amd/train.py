@@ -100,20 +100,30 @@ def broadcast_from_rank0_(tensor):
     return tensor
 
 
-def _dx_gemm(a_ptr, lda, wt, out_ptr, ldo, M, what):
+def _dx_gemm(a_ptr, lda, wt, out_ptr, ldo, M, what, below=None):
     """out[M][N] = a[M][K] . wt[N][K]^T, the dL/dx product of a layer (wt = its transposed weight, contiguous): six bf16 MFMA terms
-    per product (csrc/gemm_bf16x6.hip) unless SLOIKA_AMD_EXACT_F32=1 or the shape is not covered, then the fp32 matrix pipe."""
+    per product (csrc/gemm_bf16x6.hip) unless SLOIKA_AMD_EXACT_F32=1 or the shape is not covered, then the fp32 matrix pipe.
+    `below` = (y, activation id) of an element-wise activation whose output is this layer's input: the product then leaves multiplied
+    by fun'(.) -- it IS dL/d(pre-activation) of the layer below (slk_gemm_dact_bf16x6) -- and True is returned; False when that
+    fusion did not happen (the caller applies slk_act_backward_f32 as before)."""
     import torch
     L = _lib.lib()
     N, K = int(wt.shape[0]), int(wt.shape[1])
-    rc = _lib.SLK_ERR_UNSUPPORTED
+    rc, fused = _lib.SLK_ERR_UNSUPPORTED, False
     if layers.SPLIT_F16 and K % 4 == 0 and lda % 4 == 0 and K >= 32:
         packed = torch.empty(L.slk_pack_bf16x3_bytes(N, K), dtype=torch.uint8, device=wt.device)
         _lib.check(L.slk_pack_bf16x3_f32(wt.data_ptr(), N, K, packed.data_ptr(), layers._stream()), what)
-        rc = L.slk_gemm_bias_act_bf16x6(a_ptr, lda, packed.data_ptr(), None, out_ptr, ldo, M, K, N, 0, layers._stream())
+        if below is not None:
+            yb, act = below
+            rc = L.slk_gemm_dact_bf16x6(a_ptr, lda, packed.data_ptr(), yb.data_ptr(), layers._row_stride(yb), act, out_ptr, ldo, M, K, N,
+                                        layers._stream())
+            fused = rc == _lib.SLK_OK
+        if not fused:
+            rc = L.slk_gemm_bias_act_bf16x6(a_ptr, lda, packed.data_ptr(), None, out_ptr, ldo, M, K, N, 0, layers._stream())
     if rc == _lib.SLK_ERR_UNSUPPORTED:
         rc = L.slk_gemm_bias_act_f32(a_ptr, lda, wt.data_ptr(), None, out_ptr, ldo, M, K, N, 0, layers._stream())
     _lib.check(rc, what)
+    return fused
 
 
 def _unwrap(layer, rev=False):
@@ -226,6 +236,7 @@ class TrainingStep(object):
         self._ws = None
         self._scalars = torch.zeros(3, dtype=torch.float64, device=dev)
         self._sum_scratch = torch.empty(2 * 256, dtype=torch.float64, device=dev)
+        self._below, self._dpre_ready, self._dy_is_dpre = None, False, False
         self._drop_caches()
 
     # ---- plumbing -------------------------------------------------------------------------------------------------
@@ -387,7 +398,20 @@ class TrainingStep(object):
         del logits
         # ---- the layers in front of it, top down ----------------------------------------------------------------------
         for k in range(len(tapes) - 1, -1, -1):
+            # a Gru layer directly above a Convolution / FeedForward layer: its dL/dx product takes the derivative of that layer's
+            # activation along (csrc/gemm_bf16x6.hip, slk_gemm_dact_bf16x6) and hands down dL/d(pre-activation)
+            self._below, self._dpre_ready = None, False
+            if k > 0 and tapes[k][0] == "gru" and tapes[k - 1][0] in ("conv", "ff"):
+                lb = tapes[k - 1][1]
+                try:
+                    if activation.act_name(lb.fun) in _FF_ACTS:
+                        self._below = (tapes[k - 1][4], activation.act_id(lb.fun))
+                except (KeyError, ValueError, AttributeError):
+                    pass
             dy = self._backward(tapes[k], dy, need_dx=k > 0)
+            if self._dpre_ready and k > 0:
+                tapes[k - 1] = tapes[k - 1] + ("dpre",)             # the layer below skips its slk_act_backward_f32
+            self._below = None
             tapes[k] = None
         # ---- data-parallel average --------------------------------------------------------------------------------------
         self.gscale = allreduce_mean_(self.grad)
@@ -479,6 +503,7 @@ class TrainingStep(object):
                                    "add")
             return dx
         layer, rev, xin, y = tape[1:5]
+        self._dy_is_dpre = isinstance(tape[-1], str) and tape[-1] == "dpre"
         if kind == "gru":
             return self._gru_backward(layer, rev, xin, y, dy, need_dx, saved=tape[5] if len(tape) > 5 else None)
         if kind == "lstm":
@@ -498,9 +523,12 @@ class TrainingStep(object):
         T, B, n = int(dy.shape[0]), int(dy.shape[1]), layer.size
         M, i_sz = T * B, layer.insize
         y, dy = y.contiguous(), dy.contiguous()
-        dpre = torch.empty((M, n), dtype=torch.float32, device=dy.device)
-        _lib.check(L.slk_act_backward_f32(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), dpre.numel(),
-                                          activation.act_id(layer.fun), st()), "act_backward")
+        if self._dy_is_dpre:                             # the layer above has applied fun'(.) already (_dx_gemm, below=...)
+            dpre = dy.reshape(M, n)
+        else:
+            dpre = torch.empty((M, n), dtype=torch.float32, device=dy.device)
+            _lib.check(L.slk_act_backward_f32(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), dpre.numel(),
+                                              activation.act_id(layer.fun), st()), "act_backward")
         with profiler.region("train_wgrad", 2.0 * M * n * i_sz, 4.0 * M * (n + i_sz)):
             self._tn(dpre.data_ptr(), n, xin.data_ptr(), layers._row_stride(xin), self._grad_of(layer.W).data_ptr(), i_sz, M, n,
                      i_sz, colsum=self._grad_of(layer.b).data_ptr() if layer.has_bias else None)
@@ -629,7 +657,10 @@ class TrainingStep(object):
             return None
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
         with profiler.region("train_dx", 6.0 * M * n * i_sz, 4.0 * M * (3 * n + i_sz)):
-            _dx_gemm(da.data_ptr(), 3 * n, iW.t().contiguous(), dx.data_ptr(), i_sz, M, "gru dx")
+            below, self._below = self._below, None
+            if below is not None and (tuple(below[0].shape) != (T, B, i_sz) or below[0].stride(2) != 1):
+                below = None
+            self._dpre_ready = _dx_gemm(da.data_ptr(), 3 * n, iW.t().contiguous(), dx.data_ptr(), i_sz, M, "gru dx", below=below)
         return dx
 
     #: Lstm widths the reverse-scan kernels are instantiated for (csrc/train.hip); others run zero-padded to the next one
@@ -745,11 +776,14 @@ class TrainingStep(object):
         To, n, cin, w = int(y.shape[0]), layer.size, layer.insize, layer.winlen
         M, K = To * B, layer.insize * layer.winlen
         y, dy = y.contiguous(), dy.contiguous()
-        dpre = torch.empty_like(y)
-        rc = L.slk_act_backward_f32(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), y.numel(), activation.act_id(layer.fun), st())
-        if rc == _lib.SLK_ERR_UNSUPPORTED:
-            raise NotImplementedError("training: Convolution activation %s has no derivative kernel" % layer.fun.__name__)
-        _lib.check(rc, "act_backward")
+        if self._dy_is_dpre:                             # the layer above has applied fun'(.) already (_dx_gemm, below=...)
+            dpre = dy
+        else:
+            dpre = torch.empty_like(y)
+            rc = L.slk_act_backward_f32(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), y.numel(), activation.act_id(layer.fun), st())
+            if rc == _lib.SLK_ERR_UNSUPPORTED:
+                raise NotImplementedError("training: Convolution activation %s has no derivative kernel" % layer.fun.__name__)
+            _lib.check(rc, "act_backward")
         cols = torch.empty((M, K), dtype=torch.float32, device=y.device)
         xc = xin.contiguous()
         if cin == 1:

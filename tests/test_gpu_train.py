@@ -611,3 +611,28 @@ def test_reduce_rows_sum(n):
     again = torch.zeros(3, dtype=torch.float64, device="cuda")
     assert L.slk_reduce_rows_sum_f32(xd.data_ptr(), 3, n, again.data_ptr(), scratch.data_ptr(), stream()) == 0
     assert torch.equal(out, again)                                 # fixed order: the same bits every time
+
+
+@pytest.mark.parametrize("act", ["tanh", "elu", "relu", "sigmoid"])
+def test_dx_product_with_the_activation_derivative_of_the_layer_below(act):
+    """slk_gemm_dact_bf16x6 = slk_gemm_bias_act_bf16x6 followed by slk_act_backward_f32, bit for bit; and the training step that uses it
+    (a Gru layer over a Convolution) gives the gradients of the step that does not (checked against the oracle elsewhere)."""
+    torch = need_gpu()
+    from sloika_amd import _lib, activation
+    L = _lib.lib()
+    rs = np.random.RandomState(17)
+    M, K, N = 1000, 288, 96
+    x = dev((rs.normal(size=(M, K)) * 1e-3).astype(np.float32))
+    W = dev((rs.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32))
+    yref = dev(np.tanh(rs.normal(size=(M, N + 4))).astype(np.float32))           # rows ldyref = N + 4 apart
+    packed = torch.empty(L.slk_pack_bf16x3_bytes(N, K), dtype=torch.uint8, device="cuda")
+    assert L.slk_pack_bf16x3_f32(W.data_ptr(), N, K, packed.data_ptr(), stream()) == 0
+    aid = activation.act_id(getattr(activation, act))
+    fused = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    assert L.slk_gemm_dact_bf16x6(x.data_ptr(), K, packed.data_ptr(), yref.data_ptr(), N + 4, aid, fused.data_ptr(), N, M, K, N, stream()) == 0
+    plain = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    assert L.slk_gemm_bias_act_bf16x6(x.data_ptr(), K, packed.data_ptr(), None, plain.data_ptr(), N, M, K, N, 0, stream()) == 0
+    yc = yref[:, :N].contiguous()
+    two = torch.empty_like(plain)
+    assert L.slk_act_backward_f32(plain.data_ptr(), yc.data_ptr(), two.data_ptr(), plain.numel(), aid, stream()) == 0
+    assert torch.equal(fused, two)
