@@ -48,7 +48,7 @@ TRAIN_STAGES = {      # bench.py --train stage -> substrings of the kernels it l
     "train_softmax_xent": ("gemm_rows_f16x3_kernel", "gemm_rows_kernel"),     # (round 4: both passes of slk_linear_xent_grad_f16x3)
     "conv1d": ("conv1d_",),
     "train_xent": ("softmax_xent_grad_kernel",),
-    "train_xent_sums": ("reduce_sum_kernel",),
+    "train_xent_sums": ("reduce_sum_kernel", "reduce_rows_"),
     "train_gru_scan": ("gru_backward_", "gru_bwd16_kernel", "pack_x"),
     "train_wgrad": ("gemm_tn_", "tn_reduce_kernel", "im2col_"),
     "train_dx": ("gemm_bias_act_kernel", "act_backward_kernel", "gemm_bf16x6_kernel", "pack_bf16"),
