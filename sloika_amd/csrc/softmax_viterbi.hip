@@ -159,6 +159,63 @@ template <bool SUM> __device__ __forceinline__ float sv_half_reduce16(const floa
     const float d = sv_op<SUM>(keepv, sv_dpp<0x4E>(send));          // partner l ^ 2 (quad_perm [2,3,0,1])
     return sv_op<SUM>(d, sv_dpp<0xB1>(d));                          // partner l ^ 1: both lanes end with the same value
 }
+// The same as ONE hand-scheduled sequence (round 5): hipcc's schedule of sv_half_reduce16 is ~90 instructions -- fmaxf canonicalises
+// its operands (v_max x, x, x), every select pair costs two v_cndmask and a mask, every DPP move waits two states for its source --
+// ~880 cycles per reduction in the per-step stamps.  Here the selects of the 8- and 4-lane stages are bank-masked DPP instructions
+// (a lane's selector bit = its bank of four lanes: the instruction that serves lanes with the bit clear writes banks 0/1 or 0/2,
+// the other the rest, in place), the stages are interleaved so that every DPP source is at least two instructions old: 35 issue
+// slots.  Data movement and operand pairing are those of sv_half_reduce16 (the sums come out bit for bit the same).  The values
+// must not be NaN-signalling (v_max_f32 / v_add_f32 as the hardware executes them).  m2 = 0xCCCC...: lanes with bit 1 set.
+#define SV_RED_STAGES(OP)                                                                                        \
+    "s_nop 1\n\t"                                                                                                \
+    "v_permlane16_swap_b32 %0, %8\n\t"                                                                           \
+    "v_permlane16_swap_b32 %1, %9\n\t"                                                                           \
+    "v_permlane16_swap_b32 %2, %10\n\t"                                                                          \
+    "v_permlane16_swap_b32 %3, %11\n\t"                                                                          \
+    "v_permlane16_swap_b32 %4, %12\n\t"                                                                          \
+    "v_permlane16_swap_b32 %5, %13\n\t"                                                                          \
+    "v_permlane16_swap_b32 %6, %14\n\t"                                                                          \
+    "v_permlane16_swap_b32 %7, %15\n\t"                                                                          \
+    OP " %0, %0, %8\n\t"                                                                                         \
+    OP " %1, %1, %9\n\t"                                                                                         \
+    OP " %2, %2, %10\n\t"                                                                                        \
+    OP " %3, %3, %11\n\t"                                                                                        \
+    OP " %4, %4, %12\n\t"                                                                                        \
+    OP " %5, %5, %13\n\t"                                                                                        \
+    OP " %6, %6, %14\n\t"                                                                                        \
+    OP " %7, %7, %15\n\t"                                                                                        \
+    OP "_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"                                                \
+    OP "_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                                                \
+    OP "_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"                                                \
+    OP "_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                                                \
+    OP "_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"                                                \
+    OP "_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                                                \
+    OP "_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"                                                \
+    OP "_dpp %3, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"                                                \
+    OP "_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"                                          \
+    OP "_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"                                          \
+    OP "_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"                                          \
+    OP "_dpp %1, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"                                          \
+    "v_cndmask_b32 %2, %1, %0, %16\n\t"                                                                          \
+    "v_cndmask_b32 %0, %0, %1, %16\n\t"                                                                          \
+    "s_nop 0\n\t"                                                                                                \
+    OP "_dpp %0, %2, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                                      \
+    "s_nop 1\n\t"                                                                                                \
+    OP "_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+template <bool SUM> __device__ __forceinline__ float sv_half_reduce16_asm(float (&v)[16], unsigned long long m2)
+{
+    if constexpr (SUM)
+        asm volatile(SV_RED_STAGES("v_add_f32")
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                       "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                     : "s"(m2));
+    else
+        asm volatile(SV_RED_STAGES("v_max_f32")
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                       "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                     : "s"(m2));
+    return v[0];
+}
 // all 16 lanes of a DPP row receive the row's maximum / sum
 template <bool SUM> __device__ __forceinline__ float sv_row_allreduce(float v)
 {
@@ -201,18 +258,49 @@ __device__ __forceinline__ float sv_logpost(float p, float min_prob, float one_m
     return sv_log(__fadd_rn(__fadd_rn(min_prob, __fmul_rn(one_m, p)), SV_ETA));
 }
 
-// Schedule of a period (the BS steps of the block being decoded, during which the next block is produced); k = step:
-//   k = 0 .. MMA_LAST   the MFMAs (weight fragments three pairs ahead)         k = 1   operand images of the block after next
-//   k = FIN_K           accumulators -> logits, the wave's maxima              k = EXP_K  exponentials, the wave's sums, x request
-//   k = ROW_K           row statistics (needs every wave's sums: one barrier after EXP_K)
-//   k = LOG_K ..        exponentials -> log-posteriors (needs the factors: one barrier after ROW_K)
-template <int BS> struct SvSched;
-template <> struct SvSched<16> { static constexpr int MMA_LAST = 10, FIN_K = 11, EXP_K = 12, ROW_K = 13, LOG_K = 14; };
-template <> struct SvSched<8> { static constexpr int MMA_LAST = 4, FIN_K = 5, EXP_K = 5, ROW_K = 6, LOG_K = 7; };
+// Schedule of a period = the 16 steps of the block being decoded (cb), during which block nb = cb + 1 is produced.  Round 5: the
+// production work is spread over ALL sixteen steps instead of sitting in five of them (the per-step stamps of round 4's kernel read
+// 1040 cycles for a step that carries only MFMAs and 2500-2850 for the steps with the scaling / exponentials / logarithms of a whole
+// block: both waves of a SIMD were in those at the same time, and a SIMD issues one vector instruction per four cycles whoever it
+// comes from).  k = step:
+//   every k             log-posteriors of row k of the block being decoded, made from its exponentials just before they are used
+//                       (eight vector instructions in the shadow of the dynamic programme's LDS reads)
+//   k = 0 .. MMA_LAST   the MFMAs of block nb, tile after tile (weight fragments SV_D pairs ahead)
+//   k = FIN(n)          tile n's accumulators -> logits (in place), running row maxima         [the step after the tile's last MFMA]
+//   k = FIN(3)          ... and the wave's maxima (butterfly, own LDS row)
+//   k = E0 + n          tile n: exponentials (in place), running row sums                      [E0 = FIN(3) + 1]
+//   k = E0 + 3          ... and the wave's sums
+//   k = ROW_K           row statistics (waves 0-3; needs every wave's sums: the barrier of step E0 + 3) | operand images of block
+//                       nb + 1 (waves 4-7)
+//   k = ROW_K + 1       operand images of block nb + 1 (waves 0-3)
+//   after step 15       the finished exponentials move to the registers the next period decodes from
+template <int KS> struct SvSched {
+    static constexpr int NP = 4 * KS;                           // weight fragment pairs per wave and block
+    static constexpr int NMF = 3 * NP;                          // MFMAs per wave and block
+#ifdef SV_MMA_LAST
+    static constexpr int MMA_LAST = SV_MMA_LAST;
+#else
+    static constexpr int MMA_LAST = 8;
+#endif
+    static constexpr int NM = MMA_LAST + 1;
+    static constexpr int MPS = (NMF + NM - 1) / NM;             // MFMAs per step
+    // positions of a step that take MFMAs: two right behind the programme's LDS requests (their A images were requested at the end of the
+    // step before), one in front of each of its eight chunks, two behind its writes -- where the wave would otherwise only wait for LDS and
+    // for the barrier, and so that the two waves of a SIMD, which run the same program in lock step, do not ask the matrix pipe for
+    // sixteen MFMAs within the 250 cycles of the chunks; position q takes MFMAs [q MPS / NPOS, (q + 1) MPS / NPOS) of the step
+    static constexpr int NPOS = 12;
+    static constexpr int mf_step(int m) { return m / MPS; }
+    static constexpr int fin_step(int n) { return mf_step(3 * KS * (n + 1) - 1) + 1; }
+    static constexpr int E0 = fin_step(3) + 1, SUM_K = E0 + 3, ROW_K = SUM_K + 1, LOADX_K = MMA_LAST + 2;
+    // the traceback stores of the previous block: behind the last weight fragment (vmcnt counts in order: a wait for a fragment issued
+    // after them would wait for the stores to reach memory)
+    static constexpr int FLUSH_K = MMA_LAST + 1;
+    static constexpr int WFIRST_K = SUM_K;                      // the first weight fragments of the NEXT block are requested here
+    static_assert(ROW_K + 1 <= 15, "the production of a block must fit its period");
+};
 
-// NCH chunks per workgroup (2 or 4): lane half h decodes chunks h and, with four, h + 2 -- two independent score chains per
-// lane, twice the work between two barriers.  A block is BS = 32 / NCH steps of every chunk (the 32 rows of an MFMA tile).
-template <int KS, int NCH, bool DUMP>
+// One 512-thread workgroup decodes TWO chunks: lane half h (lanes 32h .. 32h+31) owns chunk h.
+template <int KS, bool DUMP>
 __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float *__restrict__ x, long ldx, int T, int B,
                                                                      const uint8_t *__restrict__ pack, float skip_pen,
                                                                      float min_prob, float one_m, uint8_t *__restrict__ tb,
@@ -221,10 +309,9 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
                                                                      const int *__restrict__ lens,
                                                                      float *__restrict__ lp_dump)
 {
-    constexpr int BS = 32 / NCH;                                // steps per block
-    constexpr int NPL = NCH / 2;                                // chunks per lane
-    using Sched = SvSched<BS>;
-    constexpr int NP = 4 * KS;                                  // weight fragment pairs per wave and block
+    constexpr int NCH = 2, BS = 16;                             // chunks per workgroup, steps per block
+    using Sched = SvSched<KS>;
+    constexpr int NP = Sched::NP;
     constexpr int OFF_V = 0;                                    // [chunk NCH][parity 2][SV_VP] float
     constexpr int OFF_TBS = OFF_V + NCH * 2 * SV_VP * 4;        // [parity 2][chunk NCH][step BS][256] uint16
     constexpr int OFF_A = OFF_TBS + 2 * 16 * 1024;              // [parity 2][KS][hi, lo][64 lanes][16 B]
@@ -235,16 +322,19 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     constexpr int OFF_L0 = OFF_XINV + 256;                      // [parity 2][2][16] blank logits
     constexpr int OFF_REDA = OFF_L0 + 256;                      // [half 2][wave 8][16] maxima over a wave's 128 columns
     constexpr int OFF_REDB = OFF_REDA + 1024;                   // [2][8][16] sums of exp(logit - wave maximum)
-    constexpr int OFF_FAC = OFF_REDB + 1024;                    // [2][8][16] exp(wave maximum - row maximum) / row sum
-    constexpr int OFF_LP0 = OFF_FAC + 1024;                     // [parity 2][2][16] blank log-posteriors
+    constexpr int OFF_FAC = OFF_REDB + 1024;                    // [parity 2][2][8][16] exp(wave maximum - row maximum) / row sum
+    constexpr int OFF_LP0 = OFF_FAC + 2048;                     // [parity 2][2][16] blank log-posteriors
     constexpr int OFF_REDV = OFF_LP0 + 256;                     // [chunk NCH][8]
     constexpr int OFF_REDI = OFF_REDV + 128;                    // [chunk NCH][8]
     constexpr int SMEM = OFF_REDI + 128;
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM];
-    // the 16 rows of a lane half: row i is step i % BS of chunk h + 2 * (i / BS)
+    // the 16 rows of a lane half: row i is step i of chunk h
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SV_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(SV_PRIO);
+#endif
     const int c = lane & 31, hch = lane >> 5;
     const int j = 32 * wave + c, q = j >> 2, cc = j & 3;
     const int b0 = NCH * blockIdx.x;
@@ -264,7 +354,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     const float *const lp0b = reinterpret_cast<const float *>(smem + OFF_LP0) + hch * 16;
     const int o_step = j + 8 * (j >> 6), o_skip = cc * 72 + q;
     const int o_own = (j >> 6) * SV_AS + 4 * (j & 63) + 8 * ((j & 63) >> 4);     // states 4j .. 4j+3: block a = j >> 6
-    auto vbase = [&](int p) __attribute__((always_inline)) { return reinterpret_cast<float *>(smem + OFF_V) + (hch + 2 * p) * 2 * SV_VP; };
+    float *const vb = reinterpret_cast<float *>(smem + OFF_V) + hch * 2 * SV_VP;
     auto bar = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     // ---- constants of the whole kernel into LDS ----
@@ -282,17 +372,16 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     const int wwave = wave * 4 * KS * 2048;
     const int wlane = lane * 16;
     half8 wfh[SV_D], wfl[SV_D];
+    // acc: accumulators -> logits -> exponentials of the block in the making, in place ([tile n][row i]); ecur: the exponentials of
+    // the block being decoded.  Their log-posteriors exist one row at a time (lpk), made in the step that consumes them.
     f32x16 acc[4];
-    float val[4][16];                                          // logits -> exponentials of the block in the making
-    // log-posteriors of the block being decoded, [row][to-state]: the four to-states of a step lie in neighbouring registers, so the
-    // packed adds of the dynamic programme take them as they are (laid out [to-state][row] like the accumulators they needed two
-    // register moves per pair and step)
-    float lp[16][4];
+    float ecur[4][16];
+    float rst[16];                                             // running row maxima, then running row sums, of the block in the making
     float4 xr0, xr1;                                           // this lane's eight x values of a coming block
     // operand preparation: wave w, 16-lane row r4 handles MFMA row rho = 4 w + r4 = lane half (w & 1), row i of that half
     const int kb = lane & 15, r4 = lane >> 4;
     const int pa_half = wave & 1, pa_i = r4 + 4 * (wave >> 1), rho = 4 * wave + r4;
-    const int pa_chunk = pa_half + 2 * (pa_i / BS), pa_step = pa_i % BS;
+    const int pa_chunk = pa_half, pa_step = pa_i;
     const bool pa_act = kb < 2 * KS;
     const int pa_b = min(b0 + pa_chunk, B - 1);
 
@@ -354,54 +443,72 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             wfl[p % SV_D] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, wwave + p * 2048 + 1024, 0));
         }
     };
-    // fragment pair p = (tile n, K block s): three MFMAs, small terms first (gemm_rows_f16x3.hip).
-    //
-    // Register hygiene around v_mfma_f32_32x32x16_f16 (hipcc of ROCm 7.2, gfx950).  The first MFMA of a tile has C = 0 and a
-    // destination that is defined right there, so the allocator may place it on registers that have just died: the
-    // instruction's own `alo` operand, or the operands of the MFMAs issued just before it (v_mfma v[34:49], v[34:37], ..., 0
-    // two lines behind an MFMA that reads v[34:37]).  The compiler considers both safe; the hardware does not execute them
-    // safely: whenever the matrix pipe was contended, row 30 of a tile came out computed from overwritten operand registers --
-    // one register of sixteen lanes, in some waves, in some runs (found by repeating tests/test_gpu_fused_decode.py's K = 64
-    // cases and by tools/mfma_overlap_scan.py on the ISA).  So the operands of a pair (and of the pair before it) are kept
-    // alive until the NEXT pair's first MFMA has been issued: an empty asm takes that MFMA's result together with them.
-    half8 pahi = {}, palo = {}, pwfh = {}, pwfl = {};           // the previous pair's operands
-    auto mma_pair = [&](auto pc, int apar) __attribute__((always_inline)) {
+    // MFMA m of a block = term m % 3 of fragment pair p = m / 3 = (tile n = p / KS, K block s = p % KS): three fp16 terms per product,
+    // small terms first (gemm_rows_f16x3.hip): a_lo.w_hi, a_hi.w_lo, a_hi.w_hi.  The MFMAs are asm statements of their own, placed
+    // BETWEEN the chunks of the hand-scheduled dynamic programme (asm volatile statements keep their order): round 4's kernel issued a
+    // step's MFMAs and its programme one after the other, and the ablation builds showed their times adding up -- a wave issues in order,
+    // the matrix pipe idled while the programme's fifty vector instructions went by and the vector unit while the wave waited for the pipe.
+    // The accumulators are read-write operands even where C = 0: a freshly defined destination may be given registers that operands of
+    // MFMAs still in the pipe have just vacated (round 3: rows computed from overwritten operands whenever the pipe was contended).
+    half8 ah[NP], al[NP];                                      // A operand images of a pair: live from their LDS read to the pair's last MFMA
+    auto aload = [&](auto pc, int apar) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
-        constexpr int n = p / KS, s = p % KS;
-        const uint8_t *ab = smem + OFF_A + apar * KS * 2048 + s * 2048 + lane * 16;
-        const half8 ahi = *reinterpret_cast<const half8 *>(ab);
-        const half8 alo = *reinterpret_cast<const half8 *>(ab + 1024);
-        const half8 wh = wfh[p % SV_D], wl = wfl[p % SV_D];
-        if constexpr (s == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[n][i] = 0.0f;
+        if constexpr (p < NP) {
+            const uint8_t *ab = smem + OFF_A + apar * KS * 2048 + (p % KS) * 2048 + lane * 16;
+            ah[p] = *reinterpret_cast<const half8 *>(ab);
+            al[p] = *reinterpret_cast<const half8 *>(ab + 1024);
         }
-        if constexpr (!(SV_ABL & 1)) {
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, wh, acc[n], 0, 0, 0);
-            asm volatile("" : "+v"(acc[n]) : "v"(alo), "v"(pahi), "v"(palo), "v"(pwfh), "v"(pwfl));
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wl, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wh, acc[n], 0, 0, 0);
-        } else {
-            acc[n][0] += (float)ahi[0] + (float)alo[1] + (float)wh[0] + (float)wl[1];
+    };
+    auto mfma_m = [&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (m < Sched::NMF && !(SV_ABL & 1)) {
+            constexpr int p = m / 3, term = m % 3, n = p / KS;
+            constexpr bool zero = (p % KS == 0) && term == 0;
+            const half8 a = term == 0 ? al[p] : ah[p];
+            const half8 w = term == 1 ? wfl[p % SV_D] : wfh[p % SV_D];
+            // ("+&v": the accumulator is written while later passes still read A and B -- no operand may share its registers, which
+            //  hipcc would otherwise allow where the accumulator's incoming value is undefined: tools/mfma_overlap_scan.py)
+            if constexpr (zero) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "+&v"(acc[n]) : "v"(a), "v"(w));
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+&v"(acc[n]) : "v"(a), "v"(w));
+            if constexpr (term == 2) wload(ic<p + SV_D>{});
         }
-        pahi = ahi;
-        palo = alo;
-        pwfh = wh;
-        pwfl = wl;
-        wload(ic<p + SV_D>{});
+    };
+    // the MFMAs of step k at position c8: a step's MPS MFMAs in their order
+    auto mfma_run = [&](auto lo_c, auto hi_c, auto &&self) __attribute__((always_inline)) {
+        constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+        if constexpr (lo < hi) {
+            mfma_m(ic<lo>{});
+            self(ic<lo + 1>{}, hi_c, self);
+        }
+    };
+    auto mfma_slot = [&](auto kc, auto cc_, int apar) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value, c8 = decltype(cc_)::value;
+        if constexpr (k <= Sched::MMA_LAST) {
+            constexpr int base = k * Sched::MPS;
+            mfma_run(ic<base + (c8 * Sched::MPS) / Sched::NPOS>{}, ic<base + ((c8 + 1) * Sched::MPS) / Sched::NPOS>{}, mfma_run);
+        }
+    };
+    // the pairs whose first MFMA lies in chunk c8 of step k: their A images are requested a chunk earlier (at the top of the step for
+    // chunks 0 and 1; a pair that straddles the top of a step was requested in the step before)
+    auto aload_run = [&](auto lo_c, auto hi_c, int apar, auto &&self) __attribute__((always_inline)) {
+        constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+        if constexpr (lo < hi) {
+            if constexpr (lo < Sched::NMF && lo % 3 == 0) aload(ic<lo / 3>{}, apar);
+            self(ic<lo + 1>{}, hi_c, apar, self);
+        }
+    };
+    auto aload_for = [&](auto kc, auto cc_, int apar) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value, c8 = decltype(cc_)::value;
+        if constexpr (k <= Sched::MMA_LAST && c8 < Sched::NPOS) {
+            constexpr int base = k * Sched::MPS;
+            aload_run(ic<base + (c8 * Sched::MPS) / Sched::NPOS>{}, ic<base + ((c8 + 1) * Sched::MPS) / Sched::NPOS>{}, apar, aload_run);
+        }
     };
     auto wload_first = [&](auto pc, auto &&self) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
         if constexpr (p < SV_D) {
             wload(pc);
             self(ic<p + 1>{}, self);
-        }
-    };
-    auto mma_range = [&](auto lo_c, auto hi_c, int apar, auto &&self) __attribute__((always_inline)) {
-        constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
-        if constexpr (lo < hi) {
-            mma_pair(ic<lo>{}, apar);
-            self(ic<lo + 1>{}, hi_c, apar, self);
         }
     };
     auto load16p = [&](const float *p, float (&out)[16]) {
@@ -418,56 +525,67 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     // Logits are kept in units of log 2 (column scales and biases arrive multiplied by log2 e): exp is a bare v_exp_f32.
     float *const my_max = reinterpret_cast<float *>(smem + OFF_REDA) + (hch * 8 + wave) * 16;
     float *const my_sum = reinterpret_cast<float *>(smem + OFF_REDB) + (hch * 8 + wave) * 16;
-    const float *const my_fac = reinterpret_cast<const float *>(smem + OFF_FAC) + (hch * 8 + wave) * 16;
-    // scaled accumulators -> logits (gemm_rows_f16x3.hip's finish), the wave's maxima
-    auto finish_max = [&](int nb) __attribute__((always_inline)) {
+    const float *const my_fac = reinterpret_cast<const float *>(smem + OFF_FAC) + (hch * 8 + wave) * 16;      // + 256 * parity
+    // scaled accumulators of tile n -> logits in place (gemm_rows_f16x3.hip's finish), running row maxima
+    auto fin_tile = [&](auto nc, int nb) __attribute__((always_inline)) {
+        constexpr int n = decltype(nc)::value;
         float xinv[16];
         load16p(reinterpret_cast<const float *>(smem + OFF_XINV) + (nb & 1) * 32 + hch * 16, xinv);
-        const float4 ci = reinterpret_cast<const float4 *>(smem + OFF_CINV)[j];
-        const float4 cb = reinterpret_cast<const float4 *>(smem + OFF_CBIAS)[j];
-        const float civ[4] = {ci.x, ci.y, ci.z, ci.w}, cbv[4] = {cb.x, cb.y, cb.z, cb.w};
+        const float civ = reinterpret_cast<const float *>(smem + OFF_CINV)[4 * j + n];
+        const float cbv = reinterpret_cast<const float *>(smem + OFF_CBIAS)[4 * j + n];
 #pragma unroll
-        for (int n = 0; n < 4; n++)
+        for (int i = 0; i < 16; i += 2) {
+            const f32x2 a = {acc[n][i], acc[n][i + 1]}, xi = {xinv[i], xinv[i + 1]};
+            const f32x2 v = __builtin_elementwise_fma(a * xi, f32x2{civ, civ}, f32x2{cbv, cbv});
+            acc[n][i] = v.x;
+            acc[n][i + 1] = v.y;
+        }
+        // (sv_max: fmaxf would canonicalise both operands first -- three instructions per maximum; its only reader is reduce_max's asm)
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const f32x2 a = {acc[n][i], acc[n][i + 1]}, xi = {xinv[i], xinv[i + 1]};
-                const f32x2 v = __builtin_elementwise_fma(a * xi, f32x2{civ[n], civ[n]}, f32x2{cbv[n], cbv[n]});
-                val[n][i] = v.x;
-                val[n][i + 1] = v.y;
-            }
-        float m[16];
+        for (int i = 0; i < 16; i++) rst[i] = n == 0 ? acc[0][i] : sv_max(rst[i], acc[n][i]);
+        // pinned to this step: the values are first needed steps later, and the compiler would sink the whole tile there
+        asm volatile("" : "+v"(acc[n]));
 #pragma unroll
-        for (int i = 0; i < 16; i++) m[i] = fmaxf(fmaxf(val[0][i], val[1][i]), fmaxf(val[2][i], val[3][i]));
-        const float r = (SV_ABL & 16) ? m[0] + m[15] : sv_half_reduce16<false>(m, lane);
+        for (int i = 0; i < 16; i++) keepf(rst[i]);
+    };
+    auto reduce_max = [&]() __attribute__((always_inline)) {
+        const float r = (SV_ABL & 16) ? rst[0] + rst[15] : sv_half_reduce16_asm<false>(rst, 0xCCCCCCCCCCCCCCCCull);
         if (!(c & 1)) my_max[c >> 1] = r;
     };
-    auto exp_sum = [&]() __attribute__((always_inline)) {
-        asm volatile("" ::: "memory");                         // the wave's own LDS writes above, read back in order
+    // tile n: exponentials in place, running row sums (the order of round 4's sum: ((t0 + t1) + t2) + t3)
+    auto exp_tile = [&](auto nc) __attribute__((always_inline)) {
+        constexpr int n = decltype(nc)::value;
+        asm volatile("" ::: "memory");                         // the wave's own LDS writes (reduce_max), read back in order
         float m[16];
         load16p(my_max, m);
 #pragma unroll
-        for (int n = 0; n < 4; n++)
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const f32x2 d = f32x2{val[n][i], val[n][i + 1]} - f32x2{m[i], m[i + 1]};
-                val[n][i] = (SV_ABL & 8) ? d.x : __builtin_amdgcn_exp2f(d.x);
-                val[n][i + 1] = (SV_ABL & 8) ? d.y : __builtin_amdgcn_exp2f(d.y);
-            }
-        float s[16];
+        for (int i = 0; i < 16; i += 2) {
+            const f32x2 d = f32x2{acc[n][i], acc[n][i + 1]} - f32x2{m[i], m[i + 1]};
+            acc[n][i] = (SV_ABL & 8) ? d.x : __builtin_amdgcn_exp2f(d.x);
+            acc[n][i + 1] = (SV_ABL & 8) ? d.y : __builtin_amdgcn_exp2f(d.y);
+        }
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {
-            const f32x2 t = ((f32x2{val[0][i], val[0][i + 1]} + f32x2{val[1][i], val[1][i + 1]}) + f32x2{val[2][i], val[2][i + 1]}) +
-                            f32x2{val[3][i], val[3][i + 1]};
-            s[i] = t.x;
-            s[i + 1] = t.y;
+            if constexpr (n == 0) {
+                rst[i] = acc[0][i];
+                rst[i + 1] = acc[0][i + 1];
+            } else {
+                const f32x2 t = f32x2{rst[i], rst[i + 1]} + f32x2{acc[n][i], acc[n][i + 1]};
+                rst[i] = t.x;
+                rst[i + 1] = t.y;
+            }
         }
-        const float r = (SV_ABL & 16) ? s[0] + s[15] : sv_half_reduce16<true>(s, lane);
+        asm volatile("" : "+v"(acc[n]));                       // pinned to this step (see fin_tile)
+#pragma unroll
+        for (int i = 0; i < 16; i++) keepf(rst[i]);
+    };
+    auto reduce_sum = [&]() __attribute__((always_inline)) {
+        const float r = (SV_ABL & 16) ? rst[0] + rst[15] : sv_half_reduce16_asm<true>(rst, 0xCCCCCCCCCCCCCCCCull);
         if (!(c & 1)) my_sum[c >> 1] = r;
     };
     auto row_stats = [&](int nb) __attribute__((always_inline)) {                             // 256 lanes: (half, row) x the eight waves' shares
         if (tid < 256) {
             const int hh = tid >> 7, ri = (tid >> 3) & 15, w = tid & 7, row = hh * 16 + ri;
-            const int ch = hh + 2 * (ri / BS), st = ri % BS;
             const float l0 = reinterpret_cast<const float *>(smem + OFF_L0)[(nb & 1) * 32 + row];
             const float mw = reinterpret_cast<const float *>(smem + OFF_REDA)[(hh * 8 + w) * 16 + ri];
             const float sw = reinterpret_cast<const float *>(smem + OFF_REDB)[(hh * 8 + w) * 16 + ri];
@@ -484,174 +602,245 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             ssum += e0;
             // Ragged batch: a chunk past its own end keeps its scores.  Its steps get NaN log-posteriors and a zero blank one, so
             // that "move" (a > comparison) is false and "stay" adds nothing -- no per-state guard in the dynamic programme.
-            int tc = Tcs[0];
-#pragma unroll
-            for (int k2 = 1; k2 < NCH; k2++) tc = ch == k2 ? Tcs[k2] : tc;
-            const bool dead = BS * nb + st >= tc;
+            const int tc = hh ? Tcs[1] : Tcs[0];
+            const bool dead = BS * nb + ri >= tc;
             const float inv = dead ? __builtin_nanf("") : 1.0f / ssum;
-            reinterpret_cast<float *>(smem + OFF_FAC)[(hh * 8 + w) * 16 + ri] = ew * (inv * one_m);
+            reinterpret_cast<float *>(smem + OFF_FAC)[(nb & 1) * 256 + (hh * 8 + w) * 16 + ri] = ew * (inv * one_m);
             if (w == 0) {
                 const float lb = dead ? 0.0f : sv_log(fmaf(e0, inv * one_m, mp_eta));
                 reinterpret_cast<float *>(smem + OFF_LP0)[(nb & 1) * 32 + row] = lb;
 #ifndef SV_DIAG
                 if constexpr (DUMP) {
-                    const int t = BS * nb + st, bb = b0 + ch;
+                    const int t = BS * nb + ri, bb = b0 + hh;
                     if (t < T && bb < B) lp_dump[((size_t)t * B + bb) * (SV_NK + 1)] = lb;
                 }
 #endif
             }
         }
     };
-    // exponentials -> log-posteriors, written over the log-posteriors the dynamic programme has already consumed: row i of the
-    // block being decoded is dead once step i % BS has run.  Rows with i0 <= i % BS < i1 of tiles n0 .. n1-1.
-    auto to_logpost = [&](auto n0c, auto n1c, auto i0c, auto i1c) __attribute__((always_inline)) {
-        constexpr int n0 = decltype(n0c)::value, n1 = decltype(n1c)::value, i0 = decltype(i0c)::value, i1 = decltype(i1c)::value;
-        if constexpr (n0 < n1 && i0 < i1) {
-            float fac[16];
-            load16p(my_fac, fac);
-            // tiles in pairs (n, n + 1): the fused multiply-adds run on row pairs (neighbouring accumulator registers), the logarithms
-            // are scalar instructions that write where the dynamic programme wants them, the final scaling runs on to-state pairs
-            static_assert((n1 - n0) % 2 == 0, "tiles in pairs");
-#pragma unroll
-            for (int n = n0; n < n1; n += 2)
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    const bool in0 = i % BS >= i0 && i % BS < i1, in1 = (i + 1) % BS >= i0 && (i + 1) % BS < i1;
-                    if (in0 && in1) {
-                        const f32x2 a = __builtin_elementwise_fma(f32x2{val[n][i], val[n][i + 1]}, f32x2{fac[i], fac[i + 1]},
-                                                                  f32x2{mp_eta, mp_eta});
-                        const f32x2 b = __builtin_elementwise_fma(f32x2{val[n + 1][i], val[n + 1][i + 1]}, f32x2{fac[i], fac[i + 1]},
-                                                                  f32x2{mp_eta, mp_eta});
-                        const f32x2 l0 = f32x2{__builtin_amdgcn_logf(a.x), __builtin_amdgcn_logf(b.x)} * SV_LN2;
-                        const f32x2 l1 = f32x2{__builtin_amdgcn_logf(a.y), __builtin_amdgcn_logf(b.y)} * SV_LN2;
-                        lp[i][n] = (SV_ABL & 8) ? a.x : l0.x;
-                        lp[i][n + 1] = (SV_ABL & 8) ? b.x : l0.y;
-                        lp[i + 1][n] = (SV_ABL & 8) ? a.y : l1.x;
-                        lp[i + 1][n + 1] = (SV_ABL & 8) ? b.y : l1.y;
-                    } else {
-                        if (in0) {
-                            lp[i][n] = sv_log(fmaf(val[n][i], fac[i], mp_eta));
-                            lp[i][n + 1] = sv_log(fmaf(val[n + 1][i], fac[i], mp_eta));
-                        }
-                        if (in1) {
-                            lp[i + 1][n] = sv_log(fmaf(val[n][i + 1], fac[i + 1], mp_eta));
-                            lp[i + 1][n + 1] = sv_log(fmaf(val[n + 1][i + 1], fac[i + 1], mp_eta));
-                        }
-                    }
-                }
-            // the values are first used a period later: without this the compiler sinks the whole transform to the loop's end,
-            // out of the steps whose waiting time it is meant to fill
-#pragma unroll
-            for (int n = n0; n < n1; n++)
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                    if (i % BS >= i0 && i % BS < i1) keepf(lp[i][n]);
-        }
-    };
-    auto dump_block = [&](int nb) __attribute__((always_inline)) {
-#ifdef SV_DIAG
-        return;
-#endif
-        if constexpr (DUMP) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int t = BS * nb + i % BS, bb = b0 + hch + 2 * (i / BS);
-                if (t < T && bb < B) {
-                    float *dst = lp_dump + ((size_t)t * B + bb) * (SV_NK + 1) + 1 + 4 * j;
-                    dst[0] = lp[i][0]; dst[1] = lp[i][1]; dst[2] = lp[i][2]; dst[3] = lp[i][3];
-                }
-            }
-        }
-    };
-    // side work of step k of a period: the production of block nb (and the operand images of block nb + 1)
+    // vector side work of step k of a period: the production of block nb (and the operand images of block nb + 1)
     auto side = [&](auto kc, int nb) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        constexpr int NM = Sched::MMA_LAST + 1;
-        if constexpr (k == 0) wload_first(ic<0>{}, wload_first);
-        if constexpr (k <= Sched::MMA_LAST) mma_range(ic<(k * NP) / NM>{}, ic<((k + 1) * NP) / NM>{}, nb & 1, mma_range);
-        if constexpr (k == 1 && !(SV_ABL & 32)) prepare_a(nb + 1);
-        if constexpr (k == Sched::FIN_K) finish_max(nb);
-        if constexpr (k == Sched::EXP_K) {
-            load_x(nb + 2);                                    // its operand images are made in step 1 of the next period
-            exp_sum();
+        if constexpr (k == Sched::LOADX_K) load_x(nb + 1);
+        if constexpr (k == Sched::fin_step(0)) fin_tile(ic<0>{}, nb);
+        if constexpr (k == Sched::fin_step(1)) fin_tile(ic<1>{}, nb);
+        if constexpr (k == Sched::fin_step(2)) fin_tile(ic<2>{}, nb);
+        if constexpr (k == Sched::fin_step(3)) {
+            fin_tile(ic<3>{}, nb);
+            reduce_max();
         }
-        if constexpr (k == Sched::ROW_K) row_stats(nb);
-        if constexpr (BS == 16) {
-            if constexpr (k == 14) to_logpost(ic<0>{}, ic<2>{}, ic<0>{}, ic<14>{});
-            if constexpr (k == 15) to_logpost(ic<2>{}, ic<4>{}, ic<0>{}, ic<15>{});
+        if constexpr (k == Sched::E0) exp_tile(ic<0>{});
+        if constexpr (k == Sched::E0 + 1) exp_tile(ic<1>{});
+        if constexpr (k == Sched::E0 + 2) exp_tile(ic<2>{});
+        if constexpr (k == Sched::E0 + 3) {
+            exp_tile(ic<3>{});
+            reduce_sum();
+        }
+        if constexpr (k == Sched::WFIRST_K) wload_first(ic<0>{}, wload_first);
+        if constexpr (!(SV_ABL & 32)) {
+            if constexpr (k == Sched::ROW_K) {
+                if (wave < 4) row_stats(nb);
+                else prepare_a(nb + 1);
+            }
+            if constexpr (k == Sched::ROW_K + 1) {
+                if (wave < 4) prepare_a(nb + 1);
+            }
         } else {
-            if constexpr (k == 7) to_logpost(ic<0>{}, ic<4>{}, ic<0>{}, ic<7>{});
+            if constexpr (k == Sched::ROW_K) row_stats(nb);
         }
-    };
-    auto side_tail = [&](int nb) __attribute__((always_inline)) {                             // after the last step of the block being decoded
-        if constexpr (BS == 16) {
-            to_logpost(ic<0>{}, ic<2>{}, ic<14>{}, ic<16>{});
-            to_logpost(ic<2>{}, ic<4>{}, ic<15>{}, ic<16>{});
-        } else {
-            to_logpost(ic<0>{}, ic<4>{}, ic<7>{}, ic<8>{});
-        }
-        dump_block(nb);
     };
 
-    // ---- the dynamic programme: step t0 + k of block cb, log-posteriors lp[p BS + k][n] (viterbi_forward4_kernel::step) ----
-    float own[NPL][4];                                         // this thread's four scores of the previous step, per chunk
-#pragma unroll
-    for (int p = 0; p < NPL; p++)
-#pragma unroll
-        for (int n = 0; n < 4; n++) own[p][n] = 0.0f;
-    struct DpIn { float vs0, vs1, vs2, vs3, vk0, vk1, vk2, vk3, lp0; };
-    auto dp_read = [&](auto kc, int par, int p) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        const float *vold = vbase(p) + ((k & 1) ^ 1) * SV_VP;
-        DpIn d;
-        d.vs0 = vold[o_step]; d.vs1 = vold[SV_AS + o_step]; d.vs2 = vold[2 * SV_AS + o_step]; d.vs3 = vold[3 * SV_AS + o_step];
-        d.vk0 = vold[o_skip]; d.vk1 = vold[SV_AS + o_skip]; d.vk2 = vold[2 * SV_AS + o_skip]; d.vk3 = vold[3 * SV_AS + o_skip];
-        d.lp0 = lp0b[par * 32 + p * BS + k];
-        return d;
-    };
-    auto dp_compute = [&](auto kc, int t0, int par, int p, const DpIn &d) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        float *vnew = vbase(p) + (k & 1) * SV_VP;
-        // Values first, arguments beside them: the score chain is max, max, two quad maxima, one subtraction, one maximum, one
-        // addition, one compare, one select; which predecessor attained a maximum only feeds the traceback word.
-        const float vs0 = d.vs0, vs1 = d.vs1, vs2 = d.vs2, vs3 = d.vs3, vk0 = d.vk0, vk1 = d.vk1, vk2 = d.vk2, vk3 = d.vk3;
-        const float lp0 = d.lp0;
-        // step maximum over a; the first a that attains it (np.argmax, decode.py:67-68)
-        const float sstep = sv_max(sv_max3(vs0, vs1, vs2), vs3);
-        int sarg = vs2 == sstep ? 2 : 3;
-        sarg = vs1 == sstep ? 1 : sarg;
-        sarg = vs0 == sstep ? 0 : sarg;
-        // skip maximum over ab = a*4 + b (decode.py:72-73): this thread's share is b = cc, the quad holds the other three; the
-        // first ab that attains the maximum = the smallest key among the lanes whose share attains it
-        const float kpart = sv_max(sv_max3(vk0, vk1, vk2), vk3);
-        int kl = vk2 == kpart ? 8 + cc : 12 + cc;
-        kl = vk1 == kpart ? 4 + cc : kl;
-        kl = vk0 == kpart ? cc : kl;
-        const float kbest = sv_quad_max(kpart);
-        int karg = kpart == kbest ? kl : 16;
-        karg = min(karg, __builtin_amdgcn_update_dpp(0, karg, 0xB1, 0xf, 0xf, false));
-        karg = min(karg, __builtin_amdgcn_update_dpp(0, karg, 0x4E, 0xf, 0xf, false));
-        const float sskip = kbest - skip_pen;                       // decode.py:72
-        const float mx = sv_max(sstep, sskip);
-        const bool bystep = sstep > sskip;                          // decode.py:76 (tie -> skip)
-        float nw[4];
-        uint32_t moves = 0;                                         // bit 2n: to-state n moves
-#pragma unroll
-        for (int n = 0; n < 4; n++) {
-            const float nv = lp[p * BS + k][n] + mx;                // decode.py:75
-            const float stay = own[p][n] + lp0;                     // decode.py:80
-            const bool move = nv > stay;                            // decode.py:81 (tie -> stay)
-            moves |= move ? (1u << (2 * n)) : 0u;
-            float r = move ? nv : stay;
-            if constexpr (k == 0) r = t0 == 0 ? lp[p * BS][n] : r;  // t = 0: v = lpost[0][1:] (decode.py:57)
-            nw[n] = r;
+    // ---- the dynamic programme: step t0 + k of block cb (viterbi_forward4_kernel::step, decode.hip) ----
+    // The arithmetic of one step for this lane's four to-states, written out as hand-scheduled instruction sequences (chunks J, D1 .. D8;
+    // the step's MFMAs go between them): hipcc's own schedule of the same instructions carried ~20 wait states per step (a v_cndmask two
+    // instructions behind the v_cmp that made its mask, a DPP instruction behind the write of its source: 21 cycles per compare-select
+    // pair in tools/probes/coissue_probe.hip against 9.5 for two independent instructions) plus the waits of a dependent chain.  Here every
+    // consumer sits at least two instructions behind its producer (three behind a mask or a DPP source), across chunk boundaries too.
+    //   step maximum over a and the first a that attains it (np.argmax, decode.py:67-68); skip maximum over ab = a*4 + b
+    //   (decode.py:72-73: this lane's share is b = cc, the quad holds the other three; the first ab that attains the maximum is the
+    //   smallest key among the lanes whose share attains it); score = lp + max(step, skip - pen) against stay = own + lp0, a tie
+    //   stays (decode.py:75-81); "move ? nv : stay" is v_max_f32(nv, stay): the same value whether nv > stay or not, and a NaN nv (a
+    //   chunk past its end) returns stay like the compare does.  Traceback word: two bits per to-state (0 stay, 1 step, 2 skip), the
+    //   step argument at bit 8, the skip argument at bit 10.
+    float o0 = 0.0f, o1 = 0.0f, o2 = 0.0f, o3 = 0.0f;          // this thread's four scores of the previous step
+    const float mp_eta_s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp_eta)));
+    const float ln2_s = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(SV_LN2)));
+    // J: exponentials of a row -> log-posteriors (decode.py:36 and :56), made at the END of the step before the one that consumes them,
+    // behind that step's LDS writes: the wave would otherwise only wait for them and for the barrier.  t = the row's time step.
+    float ln0 = 0.0f, ln1 = 0.0f, ln2 = 0.0f, ln3 = 0.0f;
+    auto jit_log = [&](float e0, float e1, float e2, float e3, float fac, int t) __attribute__((always_inline)) {
+        asm volatile("v_fma_f32 %[l0], %[e0], %[fac], %[mpe]\n\t"
+                     "v_fma_f32 %[l1], %[e1], %[fac], %[mpe]\n\t"
+                     "v_fma_f32 %[l2], %[e2], %[fac], %[mpe]\n\t"
+                     "v_fma_f32 %[l3], %[e3], %[fac], %[mpe]\n\t"
+                     "v_log_f32 %[l0], %[l0]\n\t"
+                     "v_log_f32 %[l1], %[l1]\n\t"
+                     "v_log_f32 %[l2], %[l2]\n\t"
+                     "v_log_f32 %[l3], %[l3]\n\t"
+                     "v_mul_f32 %[l0], %[ln2], %[l0]\n\t"
+                     "v_mul_f32 %[l1], %[ln2], %[l1]\n\t"
+                     "v_mul_f32 %[l2], %[ln2], %[l2]\n\t"
+                     "v_mul_f32 %[l3], %[ln2], %[l3]"
+                     : [l0] "=&v"(ln0), [l1] "=&v"(ln1), [l2] "=&v"(ln2), [l3] "=&v"(ln3)
+                     : [e0] "v"(e0), [e1] "v"(e1), [e2] "v"(e2), [e3] "v"(e3), [fac] "v"(fac), [mpe] "s"(mp_eta_s), [ln2] "s"(ln2_s));
+#ifndef SV_DIAG
+        if constexpr (DUMP) {
+            const int bb = b0 + hch;
+            if (t < T && bb < B) {
+                float *dst = lp_dump + ((size_t)t * B + bb) * (SV_NK + 1) + 1 + 4 * j;
+                dst[0] = ln0; dst[1] = ln1; dst[2] = ln2; dst[3] = ln3;
+            }
         }
-        // two bits per to-state: 0 stay, 1 step, 2 skip (viterbi_forward4_kernel's traceback word)
-        const uint32_t packed = (moves << (bystep ? 0 : 1)) | ((uint32_t)sarg << 8) | ((uint32_t)karg << 10);
-#pragma unroll
-        for (int n = 0; n < 4; n++) own[p][n] = nw[n];
-        *reinterpret_cast<float4 *>(&vnew[o_own]) = make_float4(nw[0], nw[1], nw[2], nw[3]);
-        tbs[((par * NCH + hch + 2 * p) * BS + k) * 256 + j] = (uint16_t)packed;
+#endif
+    };
+    // one whole step: reads, the step's vector side work, the chunks with the MFMAs between them, writes
+    auto step = [&](auto kc, auto dpc, auto prodc, int t0, int par, int nb) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        constexpr bool DP = decltype(dpc)::value && !(SV_ABL & 4), PROD = decltype(prodc)::value;
+        const int apar = nb & 1;
+        [[maybe_unused]] float vs0, vs1, vs2, vs3, vk0, vk1, vk2, vk3, lp0, l0, l1, l2, l3, t0r, t1r, t2r, fac;
+        [[maybe_unused]] float ls0, ls1, ls2, ls3;
+        [[maybe_unused]] unsigned long long sA, sB, sC, sD, sE, sF, sG;
+        if constexpr (DP) {
+            const float *vold = vb + ((k & 1) ^ 1) * SV_VP;
+            vs0 = vold[o_step]; vs1 = vold[SV_AS + o_step]; vs2 = vold[2 * SV_AS + o_step]; vs3 = vold[3 * SV_AS + o_step];
+            vk0 = vold[o_skip]; vk1 = vold[SV_AS + o_skip]; vk2 = vold[2 * SV_AS + o_skip]; vk3 = vold[3 * SV_AS + o_skip];
+            lp0 = lp0b[par * 32 + k];
+            // the factor of the next row (for J at the end of this step): of this block, or (last step) of the block the next period decodes
+            fac = k < 15 ? my_fac[par * 256 + k + 1] : my_fac[(par ^ 1) * 256];
+        }
+        if constexpr (PROD) {
+            if constexpr (k == 0) {                             // (the images of a block are made in the last steps of the period before)
+                aload_for(kc, ic<0>{}, apar);
+                aload_for(kc, ic<1>{}, apar);
+                aload_for(kc, ic<2>{}, apar);
+            }
+            mfma_slot(kc, ic<0>{}, apar);
+            mfma_slot(kc, ic<1>{}, apar);
+            aload_for(kc, ic<3>{}, apar);
+        }
+        if constexpr (DP) {
+            l0 = ln0; l1 = ln1; l2 = ln2; l3 = ln3;             // made at the end of the step before (J)
+            if constexpr (k == 0) { ls0 = l0; ls1 = l1; ls2 = l2; ls3 = l3; }
+        }
+        if constexpr (PROD) side(kc, nb);
+        // ---- D1 ----
+        if constexpr (PROD) { mfma_slot(kc, ic<2>{}, apar); aload_for(kc, ic<4>{}, apar); }
+        if constexpr (DP)
+            asm volatile("v_max3_f32 %[t0], %[vs0], %[vs1], %[vs2]\n\t"
+                         "v_max3_f32 %[t1], %[vk0], %[vk1], %[vk2]\n\t"
+                         "v_add_f32 %[o0], %[o0], %[lp0]\n\t"
+                         "v_max_f32 %[t0], %[t0], %[vs3]\n\t"                                                   // sstep
+                         "v_max_f32 %[t1], %[t1], %[vk3]\n\t"                                                   // kpart
+                         "v_add_f32 %[o1], %[o1], %[lp0]\n\t"
+                         "v_add_f32 %[o2], %[o2], %[lp0]"
+                         : [t0] "=&v"(t0r), [t1] "=&v"(t1r), [o0] "+v"(o0), [o1] "+v"(o1), [o2] "+v"(o2)
+                         : [vs0] "v"(vs0), [vs1] "v"(vs1), [vs2] "v"(vs2), [vs3] "v"(vs3), [vk0] "v"(vk0), [vk1] "v"(vk1), [vk2] "v"(vk2),
+                           [vk3] "v"(vk3), [lp0] "v"(lp0));
+        // ---- D2 ----
+        if constexpr (PROD) { mfma_slot(kc, ic<3>{}, apar); aload_for(kc, ic<5>{}, apar); }
+        if constexpr (DP)
+            asm volatile("v_cmp_eq_f32 %[sA], %[vs2], %[t0]\n\t"
+                         "v_max_f32_dpp %[t2], %[t1], %[t1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_cmp_eq_f32 %[sB], %[vs1], %[t0]\n\t"
+                         "v_cmp_eq_f32 %[sC], %[vs0], %[t0]\n\t"
+                         "v_add_f32 %[o3], %[o3], %[lp0]\n\t"
+                         "v_max_f32_dpp %[t2], %[t2], %[t2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"       // kbest
+                         : [sA] "=&s"(sA), [sB] "=&s"(sB), [sC] "=&s"(sC), [t2] "=&v"(t2r), [o3] "+v"(o3)
+                         : [vs0] "v"(vs0), [vs1] "v"(vs1), [vs2] "v"(vs2), [t0] "v"(t0r), [t1] "v"(t1r), [lp0] "v"(lp0));
+        // ---- D3 ----  (vs2 becomes the step argument, vs3 the skip score)
+        if constexpr (PROD) { mfma_slot(kc, ic<4>{}, apar); aload_for(kc, ic<6>{}, apar); }
+        if constexpr (DP)
+            asm volatile("v_cmp_eq_f32 %[sD], %[vk2], %[t1]\n\t"
+                         "v_cmp_eq_f32 %[sE], %[vk1], %[t1]\n\t"
+                         "v_cmp_eq_f32 %[sF], %[vk0], %[t1]\n\t"
+                         "v_cndmask_b32 %[vs2], 3, 2, %[sA]\n\t"
+                         "v_subrev_f32 %[vs3], %[pen], %[t2]\n\t"                                               // sskip = kbest - skip_pen
+                         "v_cmp_eq_f32 %[sG], %[t1], %[t2]\n\t"                                                 // my share attains the quad's maximum
+                         "v_cndmask_b32 %[vs2], %[vs2], 1, %[sB]"
+                         : [sD] "=&s"(sD), [sE] "=&s"(sE), [sF] "=&s"(sF), [sG] "=&s"(sG), [vs2] "=&v"(vs2), [vs3] "=&v"(vs3)
+                         : [vk0] "v"(vk0), [vk1] "v"(vk1), [vk2] "v"(vk2), [t1] "v"(t1r), [t2] "v"(t2r), [sA] "s"(sA), [sB] "s"(sB),
+                           [pen] "s"(skip_pen));
+        // ---- D4 ----  (t2 becomes mx, vk2 my first skip maximum's a*4, sA "by step")
+        if constexpr (PROD) { mfma_slot(kc, ic<5>{}, apar); aload_for(kc, ic<7>{}, apar); }
+        if constexpr (DP)
+            asm volatile("v_max_f32 %[t2], %[t0], %[vs3]\n\t"                                                   // mx
+                         "v_cndmask_b32 %[vk2], 12, 8, %[sD]\n\t"
+                         "v_cmp_gt_f32 %[sA], %[t0], %[vs3]\n\t"                                                // by step (a tie skips)
+                         "v_cndmask_b32 %[vs2], %[vs2], 0, %[sC]\n\t"                                           // step argument
+                         "v_cndmask_b32 %[vk2], %[vk2], 4, %[sE]\n\t"
+                         "v_add_f32 %[l0], %[l0], %[t2]\n\t"
+                         "v_cndmask_b32 %[vk2], %[vk2], 0, %[sF]"
+                         : [t2] "=&v"(t2r), [vk2] "=&v"(vk2), [sA] "=&s"(sA), [vs2] "+v"(vs2), [l0] "+v"(l0)
+                         : [t0] "v"(t0r), [vs3] "v"(vs3), [sC] "s"(sC), [sD] "s"(sD), [sE] "s"(sE), [sF] "s"(sF));
+        // ---- D5 ----
+        if constexpr (PROD) { mfma_slot(kc, ic<6>{}, apar); aload_for(kc, ic<8>{}, apar); }
+        if constexpr (DP)
+            asm volatile("v_add_f32 %[l1], %[l1], %[t2]\n\t"
+                         "v_or_b32 %[vk2], %[vk2], %[cc]\n\t"                                                   // a*4 + b of my first maximum
+                         "v_add_f32 %[l2], %[l2], %[t2]\n\t"
+                         "v_cndmask_b32 %[vk2], 16, %[vk2], %[sG]\n\t"
+                         "v_add_f32 %[l3], %[l3], %[t2]\n\t"
+                         "v_cmp_gt_f32 %[sB], %[l0], %[o0]\n\t"                                                 // move (a tie stays)
+                         "v_cmp_gt_f32 %[sC], %[l1], %[o1]"
+                         : [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [vk2] "+v"(vk2), [sB] "=&s"(sB), [sC] "=&s"(sC)
+                         : [t2] "v"(t2r), [cc] "v"(cc), [sG] "s"(sG), [l0] "v"(l0), [o0] "v"(o0), [o1] "v"(o1));
+        // ---- D6 ----
+        if constexpr (PROD) { mfma_slot(kc, ic<7>{}, apar); aload_for(kc, ic<9>{}, apar); }
+        if constexpr (DP)
+            asm volatile("v_min_i32_dpp %[vk2], %[vk2], %[vk2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_cmp_gt_f32 %[sD], %[l2], %[o2]\n\t"
+                         "v_cmp_gt_f32 %[sE], %[l3], %[o3]\n\t"
+                         "v_max_f32 %[o0], %[l0], %[o0]\n\t"
+                         "v_min_i32_dpp %[vk2], %[vk2], %[vk2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"   // skip argument
+                         "v_max_f32 %[o1], %[l1], %[o1]"
+                         : [vk2] "+v"(vk2), [sD] "=&s"(sD), [sE] "=&s"(sE), [o0] "+v"(o0), [o1] "+v"(o1)
+                         : [l0] "v"(l0), [l1] "v"(l1), [l2] "v"(l2), [l3] "v"(l3), [o2] "v"(o2), [o3] "v"(o3));
+        // ---- D7 ----  (l0 .. l3 become the move bits)
+        if constexpr (PROD) { mfma_slot(kc, ic<8>{}, apar); aload_for(kc, ic<10>{}, apar); }
+        if constexpr (DP) {
+            asm volatile("v_cndmask_b32 %[l0], 0, 1, %[sB]\n\t"
+                         "v_cndmask_b32 %[l1], 0, 4, %[sC]\n\t"
+                         "v_max_f32 %[o2], %[l2], %[o2]\n\t"
+                         "v_max_f32 %[o3], %[l3], %[o3]\n\t"
+                         "v_cndmask_b32 %[l2], 0, 16, %[sD]\n\t"
+                         "v_cndmask_b32 %[l3], 0, 64, %[sE]\n\t"
+                         "v_cndmask_b32 %[t0], 1, 0, %[sA]"                                                     // by skip: the move bits one place up
+                         : [l0] "=&v"(l0), [l1] "=&v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [o2] "+v"(o2), [o3] "+v"(o3), [t0] "=&v"(t0r)
+                         : [sA] "s"(sA), [sB] "s"(sB), [sC] "s"(sC), [sD] "s"(sD), [sE] "s"(sE));
+            if constexpr (k == 0) {                                 // t = 0: v = lpost[0][1:] (decode.py:57)
+                if (t0 == 0) { o0 = ls0; o1 = ls1; o2 = ls2; o3 = ls3; }
+            }
+            float *vnew = vb + (k & 1) * SV_VP + o_own;
+            vnew[0] = o0; vnew[1] = o1; vnew[2] = o2; vnew[3] = o3;
+        }
+        // ---- D8 ----
+        if constexpr (PROD) { mfma_slot(kc, ic<9>{}, apar); aload_for(kc, ic<11>{}, apar); }
+        if constexpr (DP) {
+            asm volatile("v_or3_b32 %[l0], %[l0], %[l1], %[l2]\n\t"
+                         "v_lshlrev_b32 %[vk2], 10, %[vk2]\n\t"
+                         "v_or_b32 %[l0], %[l0], %[l3]\n\t"
+                         "v_lshl_or_b32 %[vk2], %[vs2], 8, %[vk2]\n\t"
+                         "v_lshlrev_b32 %[l0], %[t0], %[l0]\n\t"
+                         "v_or_b32 %[l0], %[l0], %[vk2]"
+                         : [l0] "+v"(l0), [vk2] "+v"(vk2)
+                         : [l1] "v"(l1), [l2] "v"(l2), [l3] "v"(l3), [vs2] "v"(vs2), [t0] "v"(t0r)
+                         : "memory");
+            tbs[((par * NCH + hch) * BS + k) * 256 + j] = (uint16_t)__float_as_uint(l0);
+        }
+        if constexpr (DP) {                                     // J for the next step's row
+            if constexpr (k < 15) jit_log(ecur[0][k + 1], ecur[1][k + 1], ecur[2][k + 1], ecur[3][k + 1], fac, t0 + k + 1);
+            else if constexpr (PROD) jit_log(acc[0][0], acc[1][0], acc[2][0], acc[3][0], fac, t0 + 16);    // row 0 of the block just finished
+        }
+        if constexpr (PROD) {                                   // behind the writes: the wave would only wait for them and the barrier
+            mfma_slot(kc, ic<10>{}, apar);
+            mfma_slot(kc, ic<11>{}, apar);
+            if constexpr (k + 1 <= Sched::MMA_LAST) {           // the A images the next step's first positions open (same block: same parity)
+                aload_for(ic<k + 1>{}, ic<0>{}, apar);
+                aload_for(ic<k + 1>{}, ic<1>{}, apar);
+                aload_for(ic<k + 1>{}, ic<2>{}, apar);
+            }
+        }
     };
     // rows of block blk (staged with parity par) -> HBM: per chunk BS rows of 512 bytes, contiguous on both sides
     auto flush_tb = [&](int blk, int par) __attribute__((always_inline)) {
@@ -660,58 +849,23 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             constexpr int PER_CHUNK = BS * 512;                     // bytes
             const int off = pass * 8192 + tid * 16;
             const int ch = off / PER_CHUNK, rest = off % PER_CHUNK, t = BS * blk + rest / 512;
-            int tc = Tcs[0];
-#pragma unroll
-            for (int k2 = 1; k2 < NCH; k2++) tc = ch == k2 ? Tcs[k2] : tc;
+            const int tc = ch ? Tcs[1] : Tcs[0];
             uint8_t *dst = tb + ((size_t)(b0 + ch) * Tpad + BS * blk) * (SV_NK / 2) + rest;
             if (t >= 1 && t < tc)
                 *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(smem + OFF_TBS + par * 16384 + off);
         }
     };
 
-    // MFMA steps: one MFMA, then a group of the programme's vector instructions (the wave issues in order: MFMAs back to back
-    // would keep it from its vector work for 32 cycles each, vector work first would leave the matrix pipe idle)
-    auto mix_hint = [&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        constexpr int NM = Sched::MMA_LAST + 1;
-        if constexpr (k <= Sched::MMA_LAST) {
-            constexpr int npairs = ((k + 1) * NP) / NM - (k * NP) / NM;
-#pragma unroll
-            for (int i = 0; i < npairs; i++) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the pair's A operands
-#pragma unroll
-                for (int m = 0; m < 3; m++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, SV_MIX, 0);   // vector instructions
-                }
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // the fragment loads three pairs ahead
-            }
-        }
-    };
     auto period = [&](auto dpc, auto prodc, int cb) __attribute__((always_inline)) {
         constexpr bool DP = decltype(dpc)::value, PROD = decltype(prodc)::value;
         const int t0 = BS * cb, par = cb & 1, nb = cb + 1;
-        // Order inside a step: the programme's LDS reads are requested first, the production work of the step runs while they
-        // are on their way, then the programme's arithmetic and its writes.
 #define SV_STEP(K)                                                                         \
     do {                                                                                   \
-        if constexpr ((K) < BS) {                                                          \
-            if constexpr (DP && !(SV_ABL & 4)) {                                           \
-                DpIn d[NPL];                                                               \
-                _Pragma("unroll") for (int p = 0; p < NPL; p++) d[p] = dp_read(ic<K>{}, par, p); \
-                if constexpr (SV_ORDER >= 1) __builtin_amdgcn_sched_barrier(0);            \
-                if constexpr (PROD) side(ic<K>{}, nb);                                     \
-                if constexpr (SV_ORDER == 1) __builtin_amdgcn_sched_barrier(0);            \
-                _Pragma("unroll") for (int p = 0; p < NPL; p++) dp_compute(ic<K>{}, t0, par, p, d[p]); \
-                if constexpr (PROD && SV_ORDER == 2) mix_hint(ic<K>{});                    \
-            } else {                                                                       \
-                if constexpr (PROD) side(ic<K>{}, nb);                                     \
-            }                                                                              \
-            bar();                                                                         \
-            SV_STAMP(K);                                                                   \
-            if constexpr ((K) == Sched::FIN_K - 1) {                                       \
-                if (DP && cb >= 1) flush_tb(cb - 1, par ^ 1);                              \
-            }                                                                              \
+        step(ic<K>{}, dpc, prodc, t0, par, nb);                                            \
+        bar();                                                                             \
+        SV_STAMP(K);                                                                       \
+        if constexpr ((K) == Sched::FLUSH_K) {                                             \
+            if (DP && cb >= 1) flush_tb(cb - 1, par ^ 1);                                  \
         }                                                                                  \
     } while (0)
         SV_STEP(0);
@@ -731,19 +885,27 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         SV_STEP(14);
         SV_STEP(15);
 #undef SV_STEP
-        if constexpr (PROD) side_tail(nb);
+        if constexpr (PROD) {                                   // the block just finished becomes the block being decoded
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) ecur[n][i] = acc[n][i];
+            if constexpr (!DP) jit_log(acc[0][0], acc[1][0], acc[2][0], acc[3][0], my_fac[0], 0);    // (prologue) row 0 of block 0
+        }
     };
 
+    // the accumulators exist (as defined values) from here on: an accumulator that first comes into being at its first MFMA may be given
+    // registers that operands of the MFMAs just issued have vacated (tools/mfma_overlap_scan.py, the hazard of round 3)
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[n][i] = 0.0f;
+        asm volatile("" : "+v"(acc[n]));
+    }
     load_x(0);
     bar();                                                      // constants staged
     prepare_a(0);
-#ifdef SV_DBG_A
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-    load_x(1);
-#ifdef SV_DBG_B
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
+    wload_first(ic<0>{}, wload_first);
     bar();
     period(std::false_type{}, std::true_type{}, -1);
     for (int cb = 0; cb + 1 < nblk; cb++) period(std::true_type{}, std::true_type{}, cb);
@@ -751,10 +913,9 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     flush_tb(nblk - 1, (nblk - 1) & 1);
 
     // ---- first argmax of the final scores (np.argmax, decode.py:85); the last step of a block writes parity 1 ----
-#pragma unroll
-    for (int p = 0; p < NPL; p++) {
-        const int ch = hch + 2 * p;
-        const float4 fv = *reinterpret_cast<const float4 *>(&vbase(p)[SV_VP + o_own]);
+    {
+        const int ch = hch;
+        const float4 fv = *reinterpret_cast<const float4 *>(&vb[SV_VP + o_own]);
         const float f[4] = {fv.x, fv.y, fv.z, fv.w};
         float bv = f[0];
         int bi = 4 * j;
@@ -808,7 +969,7 @@ extern "C" int slk_softmax_viterbi_pack_f32(const float *W, const float *bias, i
     return slk_launch_status();
 }
 
-template <int KS, int NCH>
+template <int KS>
 static int sv_launch(const float *x, long ldx, int T, int B, const uint8_t *pack, float skip_pen, float min_prob, uint8_t *tb,
                      int32_t *best, float *score_out, const int *lens, float *lp_dump, hipStream_t s)
 {
@@ -818,11 +979,11 @@ static int sv_launch(const float *x, long ldx, int T, int B, const uint8_t *pack
     constexpr bool diag = false;
 #endif
     if (lp_dump && !diag)
-        hipLaunchKernelGGL((softmax_viterbi_kernel<KS, NCH, true>), dim3((B + NCH - 1) / NCH), dim3(SV_THREADS), 0, s, x, ldx, T, B,
-                           pack, skip_pen, min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
+        hipLaunchKernelGGL((softmax_viterbi_kernel<KS, true>), dim3((B + 1) / 2), dim3(SV_THREADS), 0, s, x, ldx, T, B, pack,
+                           skip_pen, min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
     else
-        hipLaunchKernelGGL((softmax_viterbi_kernel<KS, NCH, false>), dim3((B + NCH - 1) / NCH), dim3(SV_THREADS), 0, s, x, ldx, T,
-                           B, pack, skip_pen, min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
+        hipLaunchKernelGGL((softmax_viterbi_kernel<KS, false>), dim3((B + 1) / 2), dim3(SV_THREADS), 0, s, x, ldx, T, B, pack,
+                           skip_pen, min_prob, (float)(1.0 - (double)min_prob), tb, best, score_out, lens, lp_dump);
     return slk_launch_status();
 }
 
@@ -834,10 +995,9 @@ extern "C" int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pac
     if (!x || !pack || !score_out || !path_out || !len_out || T < 1 || B < 1 || K < 1 || ldx < K || nbase < 2 || klen < 3 ||
         (plan != 0 && plan != 2 && plan != 4))
         return SLK_ERR_INVALID_ARG;
-#ifndef SV_WITH_NCH4
-    if (plan == 4) return SLK_ERR_UNSUPPORTED;    // four chunks per workgroup: measured equal to two (a vector instruction
-                                                  // costs its SIMD four cycles either way), so production builds leave it out
-#endif
+    // four chunks per workgroup (rounds 3-4, -DSV_WITH_NCH4) measured equal to two -- a SIMD issues one vector instruction per four
+    // cycles whichever of its waves it comes from, and that plan only moved instructions from one wave to the other -- and was removed
+    if (plan == 4) return SLK_ERR_UNSUPPORTED;
     if (!sv_shape_ok(K, nbase, klen) || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;
     const size_t need = slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen);
     if (!workspace || workspace_bytes < need) return SLK_ERR_WORKSPACE;
@@ -847,20 +1007,9 @@ extern "C" int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pac
     const uint8_t *pk = static_cast<const uint8_t *>(pack);
     hipStream_t s = slk_stream(stream);
     int rc;
-#ifdef SV_WITH_NCH4
-    const bool four = plan == 4;
-#endif
     switch (K / 16) {
-#ifdef SV_WITH_NCH4
 #define SV_CASE(KS)                                                                                                              \
-    case KS:                                                                                                                     \
-        rc = four ? sv_launch<KS, 4>(x, ldx, T, B, pk, skip_pen, min_prob, tb, best, score_out, lens, lp_dump, s)                \
-                  : sv_launch<KS, 2>(x, ldx, T, B, pk, skip_pen, min_prob, tb, best, score_out, lens, lp_dump, s);               \
-        break;
-#else
-#define SV_CASE(KS)                                                                                                              \
-    case KS: rc = sv_launch<KS, 2>(x, ldx, T, B, pk, skip_pen, min_prob, tb, best, score_out, lens, lp_dump, s); break;
-#endif
+    case KS: rc = sv_launch<KS>(x, ldx, T, B, pk, skip_pen, min_prob, tb, best, score_out, lens, lp_dump, s); break;
 #ifdef SV_ONLY_KS          /* development builds: one instantiation */
     SV_CASE(SV_ONLY_KS)
 #else

@@ -30,7 +30,9 @@ def main():
     le = torch.empty(B, dtype=torch.int32, device="cuda")
     vp = C.c_void_p
     fns = []
+    plans = {}
     for i, name in enumerate(names):
+        plans[name] = int(name.split("@")[1]) if "@" in name else PLAN          # "label@4": this variant runs plan 4
         pb = getattr(lib, "slk_svpb_v%d" % i)
         pb.restype = C.c_size_t
         n = pb(K, 4, 5)
@@ -47,8 +49,8 @@ def main():
     for rnd in range(5):
         for name, f, pack in fns:
             def call():
-                rc = f(x.data_ptr(), K, pack.data_ptr(), K, T, B, 4, 5, 0.0, 1e-5, None, PLAN, ws.data_ptr(), nws, sc.data_ptr(),
-                       pa.data_ptr(), le.data_ptr(), None, None)
+                rc = f(x.data_ptr(), K, pack.data_ptr(), K, T, B, 4, 5, 0.0, 1e-5, None, plans[name], ws.data_ptr(), nws,
+                       sc.data_ptr(), pa.data_ptr(), le.data_ptr(), None, None)
                 assert rc == 0, rc
             call()
             torch.cuda.synchronize()
@@ -67,12 +69,13 @@ def main():
                 continue
             dbg.zero_()
             for _ in range(3):
-                rc = f(x.data_ptr(), K, pack.data_ptr(), K, T, B, 4, 5, 0.0, 1e-5, None, PLAN, ws.data_ptr(), nws, sc.data_ptr(),
-                       pa.data_ptr(), le.data_ptr(), dbg.data_ptr(), None)
+                rc = f(x.data_ptr(), K, pack.data_ptr(), K, T, B, 4, 5, 0.0, 1e-5, None, plans[name], ws.data_ptr(), nws,
+                       sc.data_ptr(), pa.data_ptr(), le.data_ptr(), dbg.data_ptr(), None)
                 assert rc == 0
             torch.cuda.synchronize()
             st = dbg.cpu().numpy().reshape(-1, 16)
-            nper = (T + BS - 1) // BS + 1
+            bs = 8 if plans[name] == 4 else 16
+            nper = (T + bs - 1) // bs + 1
             flat = st[:nper].reshape(-1).astype(np.int64)
             d = np.diff(flat)
             per = d[16 * 5:16 * (nper - 3)].reshape(-1, 16)      # main-loop periods; column k = duration of step k+1 (k = 15: next step 0)
