@@ -23,8 +23,21 @@ def _hip_already_running():
         return False
 
 
+def _user_hw_queues():
+    """The user's GPU_MAX_HW_QUEUES as an int (' 32', '+32' count), None when unset or not a number."""
+    try:
+        return int(_os.environ["GPU_MAX_HW_QUEUES"])
+    except (KeyError, ValueError):
+        return None
+
+
+#: True when the user had set GPU_MAX_HW_QUEUES before this module was imported (recorded apart from the guess below)
+HW_QUEUES_SET_BY_USER = _user_hw_queues() is not None
 #: GPU_MAX_HW_QUEUES as the HIP runtime of this process saw (or will see) it: the user's value, else 32 if the runtime had not started
-#: when this module was imported, else the runtime's default of 4
-HW_QUEUES_IN_EFFECT = int(_os.environ["GPU_MAX_HW_QUEUES"]) if _os.environ.get("GPU_MAX_HW_QUEUES", "").isdigit() else (
-    4 if _hip_already_running() else 32)
+#: when this module was imported, else the runtime's default of 4.  Only torch's own initialisation is visible from here: a process that
+#: started HIP by other means (a ctypes load, another framework, the rocprofv3 preload) is a case this guess gets wrong, which is why
+#: device.want_hw_queues() words its warning for "unknown" rather than trusting 32 when torch is absent.
+HW_QUEUES_IN_EFFECT = _user_hw_queues() if HW_QUEUES_SET_BY_USER else (4 if _hip_already_running() else 32)
+#: False when the value above is a guess that could be wrong (no torch in the process to ask whether the runtime had started)
+HW_QUEUES_KNOWN = HW_QUEUES_SET_BY_USER or ("torch" in __import__("sys").modules)
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")

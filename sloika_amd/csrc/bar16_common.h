@@ -110,6 +110,8 @@ __device__ __forceinline__ f32x4 tile_mfma_acc(const half8 *w_hi, const half8 *w
 }
 // (Eight wait states: what hipcc itself puts between a v_mfma_f32_16x16x32_f16 and a vector instruction that reads its result; the
 //  hardware does not interlock that read, and seven is where every register arrives -- tools/probes/mfma_read_hazard_probe.hip.)
+// ONLY behind v_mfma_f32_16x16x32_f16 (a four-pass MFMA: the figure is that instruction's); a 32x32 tile (eight or sixteen passes) needs
+// more -- f32x4 in the signature is the guard: a sixteen-register accumulator does not convert.
 __device__ __forceinline__ void mfma_drain(f32x4 &a) { asm volatile("s_nop 7" : "+v"(a)); }
 __device__ __forceinline__ void mfma_drain2(f32x4 &a, f32x4 &b) { asm volatile("s_nop 7" : "+v"(a), "+v"(b)); }
 // one K block of one tile, accumulator kept across steps (chain waves); FIRST: start from zero

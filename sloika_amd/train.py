@@ -84,6 +84,22 @@ def allreduce_mean_(tensor):
     return 1.0 / dist.get_world_size()
 
 
+def allreduce_step_scalars_(sc):
+    """The scalars a rank reads after a training step, [loss sum, accuracy sum, sum of squared parameters, bad-label flag]: the two
+    sums and the FLAG are summed over the ranks in one collective (the parameter term is the same on every rank and stays), so that a
+    batch with a label out of range on ANY rank makes EVERY rank raise before its update -- the rank with the bad label has sent a
+    garbage gradient into the all-reduce, and a flag kept per rank would let the others apply it.  A no-op with one rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return sc
+    idx = torch.tensor([0, 1, 3], device=sc.device)
+    part = sc.index_select(0, idx)
+    dist.all_reduce(part, op=dist.ReduceOp.SUM)
+    sc.index_copy_(0, idx, part)
+    return sc
+
+
 def rank_and_world():
     """(rank, world size) of the initialised process group, (0, 1) without one."""
     import torch.distributed as dist
@@ -234,7 +250,7 @@ class TrainingStep(object):
         self.variance = torch.zeros(total, dtype=torch.float32, device=dev) if optimiser == "adam" else None
         self._index = {id(p): i for i, p in enumerate(self.shared)}
         self._ws = None
-        self._scalars = torch.zeros(3, dtype=torch.float64, device=dev)
+        self._scalars = torch.zeros(4, dtype=torch.float64, device=dev)     # loss sum, accuracy sum, sum of squared parameters, bad-label flag
         self._sum_scratch = torch.empty(2 * 256, dtype=torch.float64, device=dev)
         self._below, self._dpre_ready, self._dy_is_dpre = None, False, False
         self._drop_caches()
@@ -334,7 +350,7 @@ class TrainingStep(object):
         """(loss, accuracy) of the step that _queue_forward_backward queued; raises if its labels were out of range (checked on the
         device beside the step -- a host-side check was two more synchronisations in the middle of it)."""
         s = self._scalars.cpu().numpy()
-        if self._bad_labels is not None and bool(self._bad_labels.item()):
+        if s[3] != 0.0:                                  # (summed over the ranks: every rank raises, none updates)
             raise ValueError("labels must lie in [0, %d)" % self.softmax.size)
         loss = float(s[0]) * self.gscale + (self.l2 * float(s[2]) if self.l2 != 0.0 else 0.0)
         return loss, float(s[1]) * self.gscale
@@ -368,12 +384,15 @@ class TrainingStep(object):
         # labels outside [0, size): the two-pass kernel only compares columns with the label (a row without a match gets garbage, no
         # access outside its buffers), so the check runs on the device and is read with the loss; the in-place kernel indexes the
         # logits row with the label and needs the answer first
-        self._bad_labels = ((labels < 0) | (labels >= sm.size)).any()
+        bad = ((labels < 0) | (labels >= sm.size)).any()
+        sc[3] = bad                                      # travels with the sums: allreduce_step_scalars_ below, _read_loss
         logits, ld = self._softmax_grad_two_pass(h_top, labels, weights, rows)
         if logits is None:
-            if bool(self._bad_labels.item()):
+            # (with several ranks the others learn of it through the flag: this rank must not leave the step's collectives to them)
+            if rank_and_world()[1] == 1 and bool(bad.item()):
                 raise ValueError("labels must lie in [0, %d)" % sm.size)
-            self._bad_labels = None
+            if rank_and_world()[1] > 1:
+                labels = labels.clamp(0, sm.size - 1)    # the in-place kernel indexes the logits row with the label
             logits, stats, ld = sm.logits_and_stats(h_top)
             with profiler.region("train_xent", 0.0, 8.0 * M * ld):
                 _lib.check(L.slk_softmax_xent_grad_f32(logits.data_ptr(), ld, stats.data_ptr(), labels.data_ptr(),
@@ -415,8 +434,7 @@ class TrainingStep(object):
             tapes[k] = None
         # ---- data-parallel average --------------------------------------------------------------------------------------
         self.gscale = allreduce_mean_(self.grad)
-        if self.gscale != 1.0:
-            allreduce_mean_(sc[:2])
+        allreduce_step_scalars_(sc)
 
     def _softmax_grad_two_pass(self, h_top, labels, weights, rows):
         """(d loss / d logits [M][ld], ld) with the rows' loss and accuracy terms in rows[0], rows[1] -- or (None, None) where the
@@ -658,8 +676,14 @@ class TrainingStep(object):
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
         with profiler.region("train_dx", 6.0 * M * n * i_sz, 4.0 * M * (3 * n + i_sz)):
             below, self._below = self._below, None
-            if below is not None and (tuple(below[0].shape) != (T, B, i_sz) or below[0].stride(2) != 1):
-                below = None
+            # the fused product reads the layer below's OUTPUT row by row with one row stride: only if it is the very tensor this Gru
+            # consumed (same memory, rows a uniform distance apart); a copied or converted input, or rows of uneven pitch, take the
+            # separate slk_act_backward_f32 pass instead
+            if below is not None:
+                yb = below[0]
+                if (tuple(yb.shape) != (T, B, i_sz) or yb.stride(2) != 1 or yb.stride(0) != B * yb.stride(1)
+                        or yb.data_ptr() != xin.data_ptr() or tuple(yb.stride()) != tuple(xin.stride())):
+                    below = None
             self._dpre_ready = _dx_gemm(da.data_ptr(), 3 * n, iW.t().contiguous(), dx.data_ptr(), i_sz, M, "gru dx", below=below)
         return dx
 

@@ -108,6 +108,36 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _flag_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from sloika_amd import train
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # [loss sum, accuracy sum, sum of squared parameters (the same on every rank), bad-label flag]: only rank 1 saw a bad label
+    sc = torch.tensor([1.5 + rank, 10.0 * (rank + 1), 7.0, float(rank == 1)], dtype=torch.float64)
+    train.allreduce_step_scalars_(sc)
+    np.save(os.path.join(out_dir, "sc%d.npy" % rank), sc.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bad_label_flag_reaches_every_rank(tmp_path):
+    """A label out of range on ONE rank must make EVERY rank raise before its update (the rank that saw it has already sent a garbage
+    gradient into the all-reduce): the flag is summed over the ranks together with the loss and accuracy sums."""
+    import torch
+    import torch.multiprocessing as mp
+    from sloika_amd import train
+    sc = torch.tensor([1.0, 2.0, 3.0, 0.0], dtype=torch.float64)
+    assert train.allreduce_step_scalars_(sc).tolist() == [1.0, 2.0, 3.0, 0.0]      # not initialised: a no-op
+    port = _free_port()
+    mp.spawn(_flag_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), "sc%d.npy" % rank))
+        assert got.tolist() == [1.5 + 2.5, 10.0 + 20.0, 7.0, 1.0]                     # sums, the parameter term untouched, flag set
+
+
 def test_two_rank_gradient_average_equals_whole_batch(tmp_path):
     import torch
     import torch.multiprocessing as mp

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--T", type=int, default=800)
     ap.add_argument("--B", type=int, default=1024)
     ap.add_argument("--n", type=int, default=96)
-    ap.add_argument("--what", default="gru,gruf,gemm,softmax,viterbi")
+    ap.add_argument("--what", default="gru,gemm,softmax,viterbi")
     a = ap.parse_args()
     L = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
@@ -44,77 +44,7 @@ def main():
                                                            n, 0, 1, 2, generic, st))
             fl = 6.0 * T * B * n * n
             print("gru_recurrent n=%d B=%d T=%d generic=%d: %.3f ms  %.1f TF  %.0f ns/step" % (n, B, T, generic, ms, fl / ms / 1e9, ms * 1e6 / T))
-    if "gruf16" in what:
-        import ctypes
-        I = n
-        x = torch.randn(T, B, I, device="cuda")
-        iW = torch.randn(3 * n, I, device="cuda") / np.sqrt(I + n)
-        bb = torch.randn(3 * n, device="cuda")
-        sW = torch.randn(2 * n, n, device="cuda") / np.sqrt(2 * n)
-        sW2 = torch.randn(n, n, device="cuda") / np.sqrt(2 * n)
-        y = torch.empty(T, B, n, device="cuda")
-        call = lambda rev: L.slk_gru_fused16_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(),
-                                                 y.data_ptr(), n, T, B, I, n, rev, 1, 2, None, None, st)
-        assert call(0) == 0
-        for rnd in range(2):
-            ms = timeit(lambda: call(0))
-            print("gru_fused16 n=%d B=%d T=%d: %.3f ms  %.0f ns/step = %.0f cycles at 2.39 GHz" % (n, B, T, ms, ms * 1e6 / T, ms * 1e6 / T * 2.39))
-        for code, nm in ((2, "no chain MFMAs"), (3, "polls never wait"), (4, "cheap activations"), (5, "projection idle"),
-                         (6, "no MFMAs + no waits"), (7, "no MFMAs, no waits, cheap act"), (8, "all four"), (9, "no waits + projection idle")):
-            ms = timeit(lambda: call(2 * code))
-            print("   ablation %-32s %.3f ms  %.0f cycles/step" % (nm, ms, ms * 1e6 / T * 2.39))
-        ms = timeit(lambda: call(2))
-        torch.cuda.synchronize()
-        stp = (ctypes.c_ulonglong * 16)()
-        L.slk_debug_read_stamps16.argtypes = [ctypes.c_void_p]
-        L.slk_debug_read_stamps16(stp)
-        names = ["loop top -> (vI prefetch wait etc.)", "own-block r|z MFMAs + wait for h", "r|z others + r epilogue + publish",
-                 "own c MFMAs + z epilogue + wait for r*h", "c others + vI prefetch issue", "c epilogue + writes + publish"]
-        names = ["loop top", "own-block r|z MFMAs + wait for h", "r|z others + r epilogue + publish",
-                 "own c MFMAs + z epilogue + wait for r*h", "c others + vI prefetch issue", "split/writes/publish",
-                 "wait for vI(s+1)", "tanh + blend (waits for the c MFMAs)"]
-        tot = sum(stp[i] for i in range(8))
-        print("diag launch %.3f ms; cycles per step (wave 0 of workgroup 0): total %.0f" % (ms, tot / T))
-        for i, nm in enumerate(names):
-            print("   %-44s %7.0f" % (nm, stp[i] / T))
-        print("   poll retries per step: h %.2f  r*h %.2f  vI/flush %.2f" % (stp[8] / T, stp[9] / T, stp[10] / T))
-        L.slk_debug_read_pstamps16.argtypes = [ctypes.c_void_p]
-        for code, nm in ((1, "normal run"), (10, "chain neither computes nor waits")):
-            timeit(lambda: call(2 * code), reps=2, warm=1)
-            torch.cuda.synchronize()
-            pst = (ctypes.c_ulonglong * 64)()
-            L.slk_debug_read_pstamps16(pst)
-            print("   projection waves, %s: cycles per GROUP of 4 steps [x-block/flush | x split + MFMAs | wait ring slot | store+publish | loop]" % nm)
-            for wv in range(8):
-                v = [pst[wv * 8 + i] / (T / 4) for i in range(5)]
-                if sum(v) > 0:
-                    print("      wave %d: %7.0f %7.0f %7.0f %7.0f %7.0f   total %7.0f" % (wv, v[1], v[2], v[3], v[4], v[0], sum(v)))
-    if "gruf" in what:
-        I = n
-        x = torch.randn(T, B, I, device="cuda")
-        iW = torch.randn(3 * n, I, device="cuda") / np.sqrt(I + n)
-        bb = torch.randn(3 * n, device="cuda")
-        sW = torch.randn(2 * n, n, device="cuda") / np.sqrt(2 * n)
-        sW2 = torch.randn(n, n, device="cuda") / np.sqrt(2 * n)
-        y = torch.empty(T, B, n, device="cuda")
-        rc = L.slk_gru_fused_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B, I, n, 0, 1, 2, st)
-        assert rc == 0, rc
-        fl = 6.0 * T * B * n * n + 6.0 * T * B * n * I
-        for rnd in range(2):
-            for variant in (0, 1, 3):
-                ms = timeit(lambda: L.slk_gru_fused_f32(x.data_ptr(), I, iW.data_ptr(), sW.data_ptr(), sW2.data_ptr(), bb.data_ptr(), y.data_ptr(), n, T, B, I, n, variant * 2, 1, 2, st))
-                import ctypes
-                clk = (ctypes.c_ulonglong * 2)()
-                L.slk_debug_read_clock.argtypes = [ctypes.c_void_p]
-                L.slk_debug_read_clock(clk)
-                ghz = clk[0] / (clk[1] * 10.0) if clk[1] else 0.0
-                if variant & 1:
-                    stp = (ctypes.c_ulonglong * 16)()
-                    L.slk_debug_read_stamps.argtypes = [ctypes.c_void_p]
-                    L.slk_debug_read_stamps(stp)
-                    names = ["top", "wait h, reads A", "mfma A+sum", "gates+publish", "wait rh, reads B", "mfma B+sum", "tanh+update+publish"]
-                    print("   per-step cycles (wave0/wg0): " + ", ".join("%s=%.0f" % (nm, stp[i] / T) for i, nm in enumerate(names)))
-                print("gru_fused v%d I=%d n=%d B=%d T=%d: %.3f ms  %.1f TF  %.0f ns/step | wg0: %d cycles, %.2f GHz, %.0f cycles/step" % (variant, I, n, B, T, ms, fl / ms / 1e9, ms * 1e6 / T, clk[0], ghz, clk[0] / T))
+    # (the "gruf16" / "gruf" sections timed csrc/gru_fused16.hip / gru_fused.hip, which left the library in round 4: tools/experiments/)
     if "gemm" in what:
         for (K, N) in ((n, 3 * n), (n, 1025)):
             M = T * B

@@ -6,6 +6,12 @@ from oracle import oracle as orc, oracle_np
 from sloika_amd import _lib
 orc.build()
 L = _lib.lib()
+try:
+    L.slk_gru_fused16_f32
+except AttributeError:
+    import sys
+    sys.exit('slk_gru_fused16_f32 left libsloika_amd.so in round 4 (csrc/gru_fused16.hip -> tools/experiments/): build a library from there (tools/experiments/build_gf16_variants.sh) and load it instead')
+
 s = torch.cuda.current_stream().cuda_stream
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 for (I, n, T, B, scale, seed) in [(96, 96, 23, 9, 2.0, 215), (96, 96, 200, 16, 2.0, 1), (96, 96, 800, 16, 1.0, 2), (96, 96, 800, 16, 3.0, 3), (64, 64, 200, 8, 2.0, 4)]:

@@ -4,6 +4,12 @@ import numpy as np, torch
 from oracle import oracle_np
 from sloika_amd import _lib
 L = _lib.lib()
+try:
+    L.slk_gru_fused16_f32
+except AttributeError:
+    import sys
+    sys.exit('slk_gru_fused16_f32 left libsloika_amd.so in round 4 (csrc/gru_fused16.hip -> tools/experiments/): build a library from there (tools/experiments/build_gf16_variants.sh) and load it instead')
+
 s = torch.cuda.current_stream().cuda_stream
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 I, n, T, B, scale, seed = 96, 96, 200, 16, 2.0, 1
