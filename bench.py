@@ -173,39 +173,114 @@ def cpu_baseline_train(model_name, chunk_len, nchunk=48):
 # ----------------------------------------------------------------------------------------------------------------------
 # helpers shared by the legs
 # ----------------------------------------------------------------------------------------------------------------------
-def roofline_of(stages, traffic_by_stage, note=None):
-    """The dominant stage (by device time) of a pass timed with HIP events: algorithmic work per launch / average launch
-    duration, against the peak of the pipe it runs on (matrix stages: the fp32 part at the fp32 MFMA peak, the part evaluated
-    as a 3-term fp16 split at three fp16 MFMAs per product, the part whose lo half rides in spare MFMA columns at two; the others
-    against HBM)."""
-    if not stages:
-        return None
-    dom = max(stages, key=lambda k: stages[k]["ms_total"])
-    d = stages[dom]
-    if dom in MFMA_STAGES and d["flops"] > 0:
-        flops = d["flops"] / d["calls"]
-        f16 = d.get("f16x3_flops", 0.0) / d["calls"]
-        f16x2 = d.get("f16x2_flops", 0.0) / d["calls"]
+def price_stage(name, d, traffic=None, hbm_stage=False):
+    """One stage of a pass timed with HIP events against the peak of the pipe it runs on: algorithmic work per launch / average
+    launch duration.  Matrix stages: the fp32 part at the fp32 MFMA peak, the part evaluated as a 3-term fp16 split at three fp16
+    MFMAs per product, the part whose lo half rides in spare MFMA columns (or that is split in two terms) at two -- i.e. what the
+    kernel really issues (`mix`); the others, and the stages named in TRAIN_HBM_STAGES, against HBM on their ALGORITHMIC bytes.
+    `traffic` = HBM bytes per launch by the PMC counters (or None)."""
+    calls = d["calls"]
+    flops = d["flops"] / calls
+    if name in MFMA_STAGES and flops > 0 and not hbm_stage:
+        f16 = d.get("f16x3_flops", 0.0) / calls
+        f16x2 = d.get("f16x2_flops", 0.0) / calls
         t_min = (flops - f16 - f16x2) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + (3.0 * f16 + 2.0 * f16x2) / (F16_MFMA_PEAK_TFLOPS * 1e12)
         ach = flops / (d["ms_avg"] * 1e-3) / 1e12
         peak = flops / t_min / 1e12
-        out = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-               "traffic": traffic_by_stage.get(dom), "ms_per_launch": d["ms_avg"], "launches": d["calls"],
+        out = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+               "traffic": traffic, "ms_per_launch": d["ms_avg"], "launches": calls,
                "mix": {"fp32_mfma_flops": flops - f16 - f16x2, "f16x3_flops": f16, "f16x2_flops": f16x2,
                        "fp32_peak": FP32_MFMA_PEAK_TFLOPS, "f16_peak": F16_MFMA_PEAK_TFLOPS},
                # SURVEY 8(d)'s yardstick for the NN stage (all flops at the fp32 MFMA peak), for comparison only
                "frac_vs_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS}
     else:
-        ach = d["bytes"] / d["calls"] / (d["ms_avg"] * 1e-3) / 1e9
-        out = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-               "traffic": traffic_by_stage.get(dom), "ms_per_launch": d["ms_avg"], "launches": d["calls"]}
+        ach = d["bytes"] / calls / (d["ms_avg"] * 1e-3) / 1e9
+        out = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+               "traffic": traffic, "ms_per_launch": d["ms_avg"], "launches": calls}
+        if flops > 0:
+            out["matrix_side"] = {"tflops": flops / (d["ms_avg"] * 1e-3) / 1e12}
+    # north_star: "rocprof HBM GB/s + MFMA utilisation reported against chip peak"
+    out["hbm_gbs"] = (traffic / (d["ms_avg"] * 1e-3) / 1e9) if traffic else None    # PMC bytes per launch / HIP-event duration
+    out["hbm_frac_of_peak"] = (out["hbm_gbs"] / HBM_PEAK_GBS) if traffic else None
+    return out
+
+
+def roofline_of(stages, traffic_by_stage, note=None, hbm_stages=()):
+    """The dominant stage (by device time), priced by price_stage."""
+    if not stages:
+        return None
+    dom = max(stages, key=lambda k: stages[k]["ms_total"])
+    out = price_stage(dom, stages[dom], traffic_by_stage.get(dom), dom in hbm_stages)
     if note:
         out["note"] = note
-    # north_star: "rocprof HBM GB/s + MFMA utilisation reported against chip peak"
-    tr = traffic_by_stage.get(dom)
-    out["hbm_gbs"] = (tr / (d["ms_avg"] * 1e-3) / 1e9) if tr else None          # PMC bytes per launch / HIP-event duration
-    out["hbm_frac_of_peak"] = (out["hbm_gbs"] / HBM_PEAK_GBS) if tr else None
     return out
+
+
+def roofline_by_stage(stages, traffic_by_stage, util_of, min_share=0.10, hbm_stages=()):
+    """Every stage that takes at least `min_share` of the step's device time, priced like `roofline` (so that the line does not depend on
+    which of two stages wins by a tenth of a millisecond), each with its unit counters (`util_of(stage)` or None)."""
+    if not stages:
+        return None
+    total = sum(v["ms_total"] for v in stages.values())
+    out = {}
+    for name in sorted(stages, key=lambda k: -stages[k]["ms_total"]):
+        d = stages[name]
+        if d["ms_total"] < min_share * total:
+            continue
+        ent = price_stage(name, d, traffic_by_stage.get(name), name in hbm_stages)
+        ent["share_of_step"] = d["ms_total"] / total
+        u = util_of(name) if util_of else None
+        ent["unit_utilisation"] = u
+        ent["mfma_util"] = (u or {}).get("MfmaUtil")
+        out[name] = ent
+    return out
+
+
+def csrc_tree_hash():
+    """`git rev-parse HEAD:sloika_amd/csrc` when the working tree's csrc/ is what HEAD has, else a hash of the files' contents -- what the
+    committed counter files are stamped with (tools/stamp_profiles.py); None outside a git checkout without the files."""
+    import hashlib
+    import subprocess
+    try:
+        dirty = subprocess.run(["git", "status", "--porcelain", "--", "sloika_amd/csrc"], cwd=ROOT, stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, text=True, timeout=10)
+        if dirty.returncode == 0 and not dirty.stdout.strip():
+            r = subprocess.run(["git", "rev-parse", "HEAD:sloika_amd/csrc"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                               text=True, timeout=10)
+            if r.returncode == 0 and r.stdout.strip():
+                return "git:" + r.stdout.strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return content_hash_of_csrc()
+
+
+def content_hash_of_csrc():
+    """sha256 over the names and contents of sloika_amd/csrc/* (the form that also works on the GPU box, which has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sloika_amd", "csrc")
+    try:
+        names = sorted(os.listdir(d))
+    except OSError:
+        return None
+    for n in names:
+        if n.endswith((".hip", ".h")):
+            h.update(n.encode())
+            with open(os.path.join(d, n), "rb") as fh:
+                h.update(fh.read())
+    return "sha256:" + h.hexdigest()[:16]
+
+
+def counters_stale(table):
+    """True when a committed counter file was taken on other kernels than the ones being run (its `csrc` stamp differs from the tree's);
+    None when the file carries no stamp."""
+    stamp = (table or {}).get("csrc")
+    if not stamp:
+        return None
+    if isinstance(stamp, dict):                       # {"git": ..., "sha256": ...}: compare what this checkout can compute
+        mine = content_hash_of_csrc()
+        return None if mine is None else stamp.get("sha256") != mine.split(":", 1)[1]
+    return stamp != content_hash_of_csrc()
 
 
 def unit_utilisation(model, batch, chunk_len, kernel_substr, streams=1):
@@ -221,7 +296,8 @@ def unit_utilisation(model, batch, chunk_len, kernel_substr, streams=1):
         if ent.get("workload") == [model, batch, chunk_len, streams]:
             for name, c in ent.get("kernels", {}).items():
                 if kernel_substr in name:
-                    return {"kernel": name, "source": ent.get("source"),
+                    # "stale": the passes were taken on other kernels than the ones running now (the file's csrc stamp against the tree's)
+                    return {"kernel": name, "source": ent.get("source"), "stale": counters_stale(ent if ent.get("csrc") else table),
                             **{k: c[k] for k in ("MfmaUtil", "VALUBusy", "LdsUtil", "LDSBankConflict") if k in c}}
     return None
 
@@ -242,10 +318,26 @@ def pmc_traffic(model, batch, chunk_len):
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 pmc = json.load(fh)
             if pmc.get("workload") == [model, batch, chunk_len]:
+                PMC_STALE[(model, batch, chunk_len)] = counters_stale(pmc)
                 return pmc.get("stage_bytes_per_launch", {})
         except (OSError, ValueError):
             pass
     return {}
+
+
+#: (model, batch, chunk_len) -> whether the PMC traffic file quoted for it was taken on other kernels than the tree's (None: no stamp)
+PMC_STALE = {}
+
+
+def attach_counters(roof, model, batch, chunk_len, streams=1, tag=None):
+    """Unit counters and the freshness of every looked-up figure for a priced stage (`roof` from price_stage)."""
+    if roof is None:
+        return None
+    k = roof["kernel"]
+    roof["unit_utilisation"] = unit_utilisation(tag or model, batch, chunk_len, STAGE_KERNEL.get(k, k), streams)
+    roof["mfma_util"] = (roof["unit_utilisation"] or {}).get("MfmaUtil")
+    roof["traffic_stale"] = PMC_STALE.get((model, batch, chunk_len)) if roof.get("traffic") else None
+    return roof
 
 
 class Runner(object):
@@ -424,12 +516,12 @@ def leg_batch256(args, torch):
         profiler.stop()
         st1 = rec1.summary()
         ent["stages_ms_per_step"] = {k: v["ms_total"] / n for k, v in sorted(st1.items())}
-        ent["roofline"] = roofline_of(st1, pmc_traffic(mname, B1, L),
-                                      "one batch at a time: %d workgroups of 4 chunks on 256 CUs" % (B1 // 4))
-        if ent["roofline"] is not None:
-            k = ent["roofline"]["kernel"]
-            ent["roofline"]["unit_utilisation"] = unit_utilisation(mname, B1, L, STAGE_KERNEL.get(k, k))
-            ent["roofline"]["mfma_util"] = (ent["roofline"]["unit_utilisation"] or {}).get("MfmaUtil")
+        tr1 = pmc_traffic(mname, B1, L)
+        ent["roofline"] = attach_counters(roofline_of(st1, tr1, "one batch at a time: %d workgroups of 4 chunks on 256 CUs" % (B1 // 4)),
+                                          mname, B1, L)
+        ent["roofline_by_stage"] = roofline_by_stage(st1, tr1, None)
+        for v in (ent["roofline_by_stage"] or {}).values():
+            attach_counters(v, mname, B1, L)
         r1.set_in_flight(nfl)
         for i in range(2 * nfl):
             r1.step(i, nfl)
@@ -499,7 +591,7 @@ def main_train(args, as_field=False, torch=None, dist=None):
             v["per_step"] = v["ms_total"] / ns
     roofline = None
     # HBM bytes per step of every stage from the committed PMC passes of this same workload (tools/collect_pmc.sh --train)
-    stage_traffic = {}
+    stage_traffic, pmc = {}, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic_train.json")) as fh:
             pmc = json.load(fh)
@@ -507,35 +599,26 @@ def main_train(args, as_field=False, torch=None, dist=None):
             stage_traffic = pmc.get("stage_bytes_per_step", {})
     except (OSError, ValueError):
         pass
+    by_stage = None
     if stages:
-        dom = max(stages, key=lambda k: stages[k]["ms_total"])
-        d = stages[dom]
-        per_launch = stage_traffic[dom] * ns / d["calls"] if dom in stage_traffic else None
-        if dom in TRAIN_HBM_STAGES:
-            # the contractions of the backward pass stream their operands once and are bound by those loads (six bf16 MFMA terms per
-            # product would take a quarter of the time at the matrix peak): priced against HBM on their ALGORITHMIC bytes
-            ach = d["bytes"] / d["calls"] / (d["ms_avg"] * 1e-3) / 1e9
-            flops = d["flops"] / d["calls"]
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": per_launch, "ms_per_launch": d["ms_avg"], "launches": d["calls"],
-                        "matrix_side": {"tflops": flops / (d["ms_avg"] * 1e-3) / 1e12,
-                                        "frac_of_bf16_peak_at_six_terms": 6.0 * flops / (d["ms_avg"] * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS}}
-        else:
-            flops = d["flops"] / d["calls"]
-            f16 = d.get("f16x3_flops", 0.0) / d["calls"]
-            t_min = (flops - f16) / (FP32_MFMA_PEAK_TFLOPS * 1e12) + 3.0 * f16 / (F16_MFMA_PEAK_TFLOPS * 1e12)
-            ach = flops / (d["ms_avg"] * 1e-3) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": flops / t_min / 1e12, "unit": "TFLOP/s",
-                        "frac": ach / (flops / t_min / 1e12), "traffic": per_launch, "ms_per_launch": d["ms_avg"],
-                        "launches": d["calls"]}
-        roofline["hbm_gbs"] = (per_launch / (d["ms_avg"] * 1e-3) / 1e9) if per_launch else None
-        roofline["unit_utilisation"] = unit_utilisation(args.model + ":train", B, L, STAGE_KERNEL.get(dom, dom))
-        roofline["mfma_util"] = (roofline["unit_utilisation"] or {}).get("MfmaUtil")
+        # the contractions of the backward pass (TRAIN_HBM_STAGES) stream their operands once and are bound by those loads (six bf16 MFMA
+        # terms per product would take a quarter of the time at the matrix peak): priced against HBM on their ALGORITHMIC bytes; the scans
+        # and the softmax layer on the matrix pipe at the number of MFMAs per product the kernels issue (train_gru_scan: two fp16 terms)
+        per_launch = {k: stage_traffic[k] * ns / stages[k]["calls"] for k in stages if k in stage_traffic}
+        tag = args.model + ":train"
+        stale_tr = counters_stale(pmc) if stage_traffic else None
+        roofline = roofline_of(stages, per_launch, hbm_stages=TRAIN_HBM_STAGES)
+        by_stage = roofline_by_stage(stages, per_launch, None, hbm_stages=TRAIN_HBM_STAGES)
+        for v in [roofline] + list((by_stage or {}).values()):
+            attach_counters(v, args.model, B, L, tag=tag)
+            v["traffic_stale"] = stale_tr if v.get("traffic") else None
+            if v["bound"] == "hbm" and "matrix_side" in v:
+                v["matrix_side"]["frac_of_bf16_peak_at_six_terms"] = 6.0 * v["matrix_side"]["tflops"] / F16_MFMA_PEAK_TFLOPS
     hbm_per_step = {k: stage_traffic[k] for k in sorted(stages) if k in stage_traffic} or None
     if as_field:
         return {"workload": "%s training step (forward, backward, ADAMski), %d-sample chunks, batch %d" % (args.model, L, B),
                 "ms_per_step": dt / steps * 1e3, "value": world * B * L * steps / dt, "unit": "samples/s", "steps": steps,
-                "final_loss": float(loss), "roofline": roofline,
+                "final_loss": float(loss), "roofline": roofline, "roofline_by_stage": by_stage,
                 "stages_ms_per_step": {k: v["per_step"] for k, v in sorted(stages.items())},
                 "stages_hbm_bytes_per_step": hbm_per_step,
                 "hbm_bytes_per_step": sum(hbm_per_step.values()) if hbm_per_step else None}
@@ -550,7 +633,7 @@ def main_train(args, as_field=False, torch=None, dist=None):
                                    "klen 5 (1025 states), drop 20" % (args.model, L, B),
                        "model": args.model, "chunk_len": L, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "data parallel over %d GPU(s), one all-reduce of the flat gradient per step" % world},
-            "roofline": roofline,
+            "roofline": roofline, "roofline_by_stage": by_stage,
             "cpu_baseline": cpu_baseline_train(args.model, L) if (world == 1 and args.cpu_chunks > 0) else None,
             "final_loss": loss,
             "stages_ms_per_step": {k: v["per_step"] for k, v in sorted(stages.items())},
@@ -672,7 +755,7 @@ def main():
         per_rank_ms = [float(t.item()) for t in tl]
 
     # ---- the same steps once more with HIP events around every C-ABI call: per-stage times and the roofline ----
-    stages, roofline, ms_profiled = {}, None, None
+    stages, roofline, ms_profiled, by_stage = {}, None, None, None
     if not args.no_stage_timing and args.stage_steps > 0 and not stub:
         rec = profiler.start()
         dts = timed(lambda i: run.step(i, nstream), args.stage_steps)
@@ -682,12 +765,13 @@ def main():
         roofline = roofline_of(stages, pmc_traffic(args.model, B, L),
                                "latency-bound serial scan; %d chunks per CU, whose hi and lo state halves fill 8 of the 16 MFMA columns (twice over)" % max(1, B // 256)
                                if args.model == "raw_0.98_rgrgr" and B <= 1024 else None)
+        by_stage = roofline_by_stage(stages, pmc_traffic(args.model, B, L), None)
         if roofline is not None:
             roofline["measured"] = "HIP events on the launch stream over %d steps issued right after the timed region " \
                                    "(the timed region itself carries no events)" % args.stage_steps
-            roofline["unit_utilisation"] = unit_utilisation(args.model, B, L, STAGE_KERNEL.get(roofline["kernel"], roofline["kernel"]),
-                                                            nstream)
-            roofline["mfma_util"] = (roofline["unit_utilisation"] or {}).get("MfmaUtil")
+            attach_counters(roofline, args.model, B, L, nstream)
+            for v in (by_stage or {}).values():
+                attach_counters(v, args.model, B, L, nstream)
 
     def release():
         """torch's allocator caches device memory per stream; a leg that ran on side streams leaves tens of gigabytes reserved for
@@ -910,6 +994,8 @@ def main():
                        "model": args.model, "chunk_len": L, "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": "chunks sharded over %d GPU(s), no collective" % world, "streams_per_gpu": nstream},
             "roofline": roofline,
+            "roofline_by_stage": by_stage,
+            "csrc_tree": csrc_tree_hash(),
             "per_rank_ms": per_rank_ms,
             "device_of_rank0": bound,
             "shader_clock_mhz_before_after": None if edge_probe is None else edge_probe.result(),

@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libsloika_amd.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Werror", "-Wno-unused-function",
+         "-Wno-unused-command-line-argument",          # (hipcc's own --hip-link when a test compiles to ISA only)
          "-fno-fast-math", "-ffp-contract=off", "-fvisibility=hidden"]
 # -fvisibility=hidden: the library exports what include/sloika_amd.h declares (SLK_API) and nothing else.
 # IEEE divide/sqrt, no reassociation, and NO implicit fma contraction (hipcc's default is -ffp-contract=fast, and
@@ -36,6 +37,30 @@ VGPR_FORM = ("gru_bar16.hip", "gru_bar16d.hip", "gru_bar16q.hip")
 def flags_for(src):
     """Compile flags of one source file of csrc/."""
     return FLAGS + (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.path.basename(src) in VGPR_FORM else [])
+
+
+#: The hipcc the hand-counted wait states of the scan kernels and the static ISA screens (tests/test_isa_hygiene.py) were validated on.
+#: A kernel that reads MFMA results or writes MFMA operands from inline asm depends on the instruction schedule the compiler emits around
+#: it (design/gru_round4.md 1, 7; -amdgpu-mfma-vgpr-form is an internal flag): another compiler is another schedule, so the build says so
+#: loudly and tests/test_isa_hygiene.py::test_hipcc_is_the_validated_one fails until the screens have been re-run and this updated.
+VALIDATED_HIPCC = "roc-7.2.0"
+
+
+def hipcc_version():
+    """First line of `hipcc --version` that names the compiler build (e.g. "AMD clang version 22.0.0git (... roc-7.2.0 ...)")."""
+    try:
+        out = subprocess.run([hipcc(), "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError, RuntimeError):
+        return None
+    for ln in out.splitlines():
+        if "clang version" in ln:
+            return ln.strip()
+    return out.strip().splitlines()[0] if out.strip() else None
+
+
+def hipcc_is_validated():
+    v = hipcc_version()
+    return bool(v and VALIDATED_HIPCC in v)
 
 
 def hipcc():
@@ -82,8 +107,16 @@ def build(force=False, verbose=False):
         cmd, rc, out = run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs)
         if rc != 0:
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), out))
+        # which compiler built it, next to the library (read by tests/test_isa_hygiene.py and printed by `python -m sloika_amd.build`)
+        with open(os.path.join(OUT, "hipcc_version.txt"), "w") as fh:
+            fh.write("%s\nvalidated: %s (%s)\n" % (hipcc_version(), VALIDATED_HIPCC, "yes" if hipcc_is_validated() else "NO"))
+    if not hipcc_is_validated():
+        sys.stderr.write("sloika_amd.build: WARNING: this hipcc (%s) is not the one the hand-scheduled kernels' wait states were validated "
+                         "on (%s): run tests/test_isa_hygiene.py and the GPU suite before trusting the library\n"
+                         % (hipcc_version(), VALIDATED_HIPCC))
     return LIB
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print("hipcc:", hipcc_version(), "| validated:", "yes" if hipcc_is_validated() else "NO (%s)" % VALIDATED_HIPCC)

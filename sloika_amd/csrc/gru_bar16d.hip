@@ -701,18 +701,6 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
                 }
             }
         };
-        // accumulator of one tile (no drain): accumulation-register weights through asm, the rest through the builtin
-        auto tile_acc = [&](auto TC, auto SC) {
-            constexpr int t = decltype(TC)::value, sset = decltype(SC)::value;
-            if constexpr (t < NA) {
-                return tile_mfma_acc<KBLK>(pa_hi[t], pa_lo[t], xh[sset], xl[sset]);
-            } else {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kb = 0; kb < KBLK; kb++) acc = mfma3(pw_hi[t - NA][kb], pw_lo[t - NA][kb], xh[sset][kb], xl[sset][kb], acc);
-                return acc;
-            }
-        };
         // one tile for both sets: the output constants are requested first, then all MFMAs (the matrix pipe stays busy through
         // the LDS round trip) with `hook` in their issue gaps, one drain, then the outputs
         auto project_tile = [&](auto T0, int G1, auto &&hook) {

@@ -575,8 +575,12 @@ class TrainingStep(object):
         M = T * B
         rc = _lib.SLK_ERR_UNSUPPORTED
         if layers.RECURRENT_F16:            # projection and recurrence as fp16 splits (csrc/gru_bar16.hip)
+            # (as layers.Gru.run prices it: the projection three fp16 MFMAs per product, the recurrent products two up to eight chunks
+            #  per workgroup -- training batches of up to 2048 chunks on 256 CUs -- and three on the sixteen-chunk plan)
+            two_term_fw = (B + 7) // 8 <= torch.cuda.get_device_properties(x.device).multi_processor_count
             with profiler.region("gru_fused", 6.0 * M * n * (n + layer.insize), 4.0 * M * (layer.insize + 3 * n),
-                                 f16x3_flops=6.0 * M * n * (n + layer.insize)) as reg:
+                                 f16x3_flops=6.0 * M * n * (layer.insize if two_term_fw else n + layer.insize),
+                                 f16x2_flops=6.0 * M * n * n if two_term_fw else 0.0) as reg:
                 rc = layers.gru_f16_entry()(x.data_ptr(), layers._row_stride(x), layer.iW.dev().data_ptr(),
                                             layer.sW.dev().data_ptr(), layer.sW2.dev().data_ptr(),
                                             layer.b.dev().data_ptr(), y.data_ptr(), n, T, B, layer.insize, n, int(rev),
@@ -653,7 +657,10 @@ class TrainingStep(object):
         # the candidate is not recomputed by a GEMM: the scan recovers it from the layer's own output (csrc/train.hip)
         da = torch.empty((M, 3 * n), dtype=torch.float32, device=dev)
         rh = torch.empty((M, n), dtype=torch.float32, device=dev)
-        with profiler.region("train_gru_scan", 6.0 * M * n * n, 4.0 * M * 9 * n):
+        # gru_bwd16_kernel issues TWO fp16 MFMAs per product (v_mfma_f32_16x16x32_f16, hi and lo halves of the operand in different
+        # column groups): the region says so, and bench.py prices it on the fp16 pipe at two instructions per product
+        two_term = layers.SPLIT_F16 and layers.RECURRENT_F16
+        with profiler.region("train_gru_scan", 6.0 * M * n * n, 4.0 * M * 9 * n, f16x2_flops=6.0 * M * n * n if two_term else 0.0) as reg_scan:
             rc = _lib.SLK_ERR_UNSUPPORTED
             if layers.SPLIT_F16 and layers.RECURRENT_F16:     # the two products of a step as fp16 splits (csrc/gru_bwd16.hip: n <= 128)
                 rc = L.slk_gru_backward16_f32(dy.data_ptr(), layers._row_stride(dy), hp_ptr, ldhp, zr.data_ptr(),

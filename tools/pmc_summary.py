@@ -39,8 +39,11 @@ def stage_file(summary_path, workload):
         tot = sum(v["hbm_bytes_per_launch"] for k, v in d["kernels"].items() if any(s in k for s in keys))
         if tot:
             out[stage] = tot
-    json.dump({"workload": workload, "source": summary_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-               "tools/collect_pmc.sh; FETCH doubled per the gfx950 correction)", "stage_bytes_per_launch": out}, sys.stdout, indent=1)
+    res = {"workload": workload, "source": summary_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+           "tools/collect_pmc.sh; FETCH doubled per the gfx950 correction)", "stage_bytes_per_launch": out}
+    if d.get("csrc"):
+        res["csrc"] = d["csrc"]                      # tools/stamp_profiles.py: the kernels the passes were taken on
+    json.dump(res, sys.stdout, indent=1)
 
 
 TRAIN_STAGES = {      # bench.py --train stage -> substrings of the kernels it launches
@@ -65,9 +68,12 @@ def train_stage_file(summary_path, workload, steps_sampled=3):
         if ks:
             out[stage] = sum(v["hbm_bytes_per_launch"] * v["launches_sampled"] / steps_sampled for v in ks)
             launches[stage] = sum(v["launches_sampled"] / steps_sampled for v in ks)
-    json.dump({"workload": workload, "source": summary_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
-               "tools/collect_pmc.sh --train; FETCH doubled per the gfx950 correction)", "stage_bytes_per_step": out,
-               "kernel_launches_per_step": launches}, sys.stdout, indent=1)
+    res = {"workload": workload, "source": summary_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+           "tools/collect_pmc.sh --train; FETCH doubled per the gfx950 correction)", "stage_bytes_per_step": out,
+           "kernel_launches_per_step": launches}
+    if d.get("csrc"):
+        res["csrc"] = d["csrc"]
+    json.dump(res, sys.stdout, indent=1)
 
 
 def main():
