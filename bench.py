@@ -376,6 +376,12 @@ class Runner(object):
         self.pinned_in = None
         self.upload_buf = None
 
+    def set_deterministic(self, flag):
+        """Basecaller(deterministic=...): True (the default) keeps every call on the plans that compute the same bits; False lets the
+        sixteen-chunk Gru plan in where it is the faster one (four batches in flight, calls of more than 2048 chunks)."""
+        for bc in self.bcs:
+            bc.deterministic = bool(flag)
+
     def set_in_flight(self, n):
         for bc in self.bcs:
             bc.in_flight = n
@@ -442,6 +448,9 @@ class StubRunner(object):
         self.rank = rank
 
     def set_in_flight(self, n):
+        pass
+
+    def set_deterministic(self, flag):
         pass
 
     def step(self, i, nact=1, src=None):
@@ -810,6 +819,17 @@ def main():
                 d = timed(lambda i: run.step(i, nact), n)
                 infl[key] = {"ms_per_step": d / n * 1e3, "value": B * L * n / d, "unit": "samples/s", "steps": n,
                              "streams_per_gpu": nact}
+                if nact == 4:
+                    # the price of "one set of bits per chunk whatever the plan" (Basecaller(deterministic=True), the default): the same leg
+                    # with the sixteen-chunk Gru plan allowed (states equal to float32 rounding, up to 2 % of chunks called differently)
+                    run.set_deterministic(False)
+                    for i in range(2 * nact):
+                        run.step(i, nact)
+                    d = timed(lambda i: run.step(i, nact), n)
+                    run.set_deterministic(True)
+                    infl[key + "_not_deterministic"] = {"ms_per_step": d / n * 1e3, "value": B * L * n / d, "unit": "samples/s",
+                                                        "steps": n, "streams_per_gpu": nact,
+                                                        "note": "Basecaller(deterministic=False): sixteen chunks per Gru workgroup"}
             run.set_in_flight(1)
             if not args.with_bases:
                 for mult, key in ((2, "two_as_one_batch"), (4, "four_as_one_batch")):
@@ -949,9 +969,10 @@ def main():
         # back-to-back steps, the shader clock sampled between steps ----
         if args.sustained_seconds > 0 and not args.with_bases:
             sus = {}
-            for nact, key in ((1, "one_at_a_time"), (4, "four_in_flight")):
+            for nact, key in ((1, "one_at_a_time"), (4, "four_in_flight"), (4, "four_in_flight_not_deterministic")):
                 if nact > nslot:
                     continue
+                run.set_deterministic(not key.endswith("not_deterministic"))     # (see in_flight: the sixteen-chunk Gru plan)
                 run.set_in_flight(nact)
                 for i in range(2 * nact):
                     run.step(i, nact)
@@ -972,6 +993,7 @@ def main():
                 sus[key] = {"seconds": d, "steps": n, "ms_per_step": d / n * 1e3, "value": B * L * n / d, "unit": "samples/s",
                             "shader_clock_mhz": probe.result()}
             run.set_in_flight(1)
+            run.set_deterministic(True)
             line_extra["sustained"] = sus
 
 

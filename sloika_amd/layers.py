@@ -130,7 +130,8 @@ LSTM_FUSED = "no_lstm_fused" not in _DEBUG
 
 class _PlanHints(__import__("threading").local):
     """Execution-plan hints of the forward pass that is running ON THIS HOST THREAD (a Basecaller per thread may run with its
-    own `in_flight`: two threads no longer race on a module global).  Results never depend on them, only speed.
+    own `in_flight`: two threads no longer race on a module global).  With `deterministic` set results never depend on them, only speed;
+    without it the sixteen-chunk Gru plan may be chosen, whose states agree with the other plans' to float32 rounding only.
 
     gru_plan_bits  bits 8-9 of the `reverse` argument of slk_gru_bar16_f32 (0 = plan by batch size, 2 / 3 = eight / sixteen
                    chunks per workgroup): set by Parallel while it runs the directions of a birnn side by side at a batch where
@@ -140,6 +141,10 @@ class _PlanHints(__import__("threading").local):
                    device's CUs together"""
     gru_plan_bits = 0
     in_flight = 1
+    #: pipeline.Basecaller(deterministic=True), the default: never the sixteen-chunk Gru plan (csrc/gru_bar16q.hip), the only plan whose
+    #: hidden states differ from the others' (three-term recurrent products where they take two: agreement to float32 rounding, up to 2 %
+    #: of chunks called differently) -- so that what a chunk is called does not depend on batch size or batches in flight
+    deterministic = False
 
 
 _HINTS = _PlanHints()
@@ -955,11 +960,19 @@ class Gru(RNN):
     def _plan_bits(self, x, B):
         """Bits 8-9 of `reverse` for slk_gru_bar16_f32: what Parallel decided for its side-by-side sub-layers, else eight chunks
         per workgroup when that is what lets the batches in flight share the chip."""
-        if _HINTS.gru_plan_bits or _HINTS.in_flight <= 1:
-            return _HINTS.gru_plan_bits
         import torch
-        return _gru_plan_for(B, _HINTS.in_flight, torch.cuda.get_device_properties(x.device).multi_processor_count,
-                             2 if max(self.size, self.insize) <= 64 else 1)
+        ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+        if _HINTS.gru_plan_bits or _HINTS.in_flight <= 1:
+            bits = _HINTS.gru_plan_bits
+        else:
+            bits = _gru_plan_for(B, _HINTS.in_flight, ncu, 2 if max(self.size, self.insize) <= 64 else 1)
+        if _HINTS.deterministic:
+            # one set of bits per chunk whatever the plan: four and eight chunks per workgroup (and two four-chunk workgroups per CU) compute
+            # the same bits, sixteen do not -- where that plan would be chosen (here, or by bar16_auto_plan in the library for a batch
+            # whose eight-chunk workgroups outnumber the CUs) the eight-chunk one runs, in as many rounds as it takes
+            if (bits & 3) == 3 or (bits == 0 and (B + 7) // 8 > ncu):
+                bits = 2
+        return bits
 
     def _padded(self):
         """Zero-padded copy of this layer with input and output sizes rounded up to multiples of 16 (what the MFMA

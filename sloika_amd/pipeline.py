@@ -21,13 +21,21 @@ FUSED_DECODE = "no_fused_decode" not in layers._DEBUG
 
 class Basecaller(object):
     def __init__(self, network, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, normalisation='per-chunk', in_flight=1,
-                 fused_decode=None):
+                 fused_decode=None, deterministic=True):
         """skip default 0.0 is the CLI default (bin/basecall_network.py:38).
 
         in_flight: how many batches the caller keeps in flight at a time, each on a HIP stream of its own (one Basecaller
         per stream).  With two or more, a Gru layer runs eight chunks per workgroup (csrc/gru_bar16d.hip) whenever that lets
         the layers of all the batches share the chip -- batch 1024, two in flight: 2 x 128 workgroups on 256 CUs -- instead of
-        one workgroup per four chunks each taking the whole device in turn."""
+        one workgroup per four chunks each taking the whole device in turn.
+
+        deterministic (default): a chunk is called the same whatever the batch size and however many batches are in flight (the
+        reference calls one read at a time: one read, one answer, basecall.py:88-121).  Every execution plan but one computes the same
+        bits; the exception is the sixteen-chunk Gru plan (csrc/gru_bar16q.hip, three-term recurrent products: states equal to float32
+        rounding, up to 2 % of chunks called differently), which calls of more than 2048 chunks and four batches in flight would take.
+        With deterministic=True they run eight chunks per workgroup instead; deterministic=False lets the faster plan in (the
+        price of the switch is in the bench line: `in_flight.deterministic`)."""
+        self.deterministic = bool(deterministic)
         if not isinstance(network, layers.Layer):
             raise TypeError("network must be a sloika_amd.layers.Layer")
         self.network = network
@@ -67,13 +75,13 @@ class Basecaller(object):
         else:
             x = batch.normalise_chunks(cd, self.normalisation, out_layout='network')
             rest = seq[:upto]
-        keep = layers._HINTS.in_flight                   # (thread local: one forward pass per host thread at a time)
-        layers._HINTS.in_flight = self.in_flight
+        keep = layers._HINTS.in_flight, layers._HINTS.deterministic       # (thread local: one forward pass per host thread at a time)
+        layers._HINTS.in_flight, layers._HINTS.deterministic = self.in_flight, self.deterministic
         try:
             for layer in rest:
                 x = layer._forward(x, None, False)
         finally:
-            layers._HINTS.in_flight = keep
+            layers._HINTS.in_flight, layers._HINTS.deterministic = keep
         return x
 
     def posteriors(self, chunks):
@@ -162,10 +170,10 @@ class Basecaller(object):
         normalisation, network and decoder with per-read lengths.  -> (scores, paths, lens) on the device."""
         net = self.network
         B = padded.shape[0]
-        keep = layers._HINTS.in_flight
+        keep = layers._HINTS.in_flight, layers._HINTS.deterministic
         # ragged batches side by side keep the four-chunk plan: their workgroups queue for the CUs and a batch of short reads hands its
         # CUs on early, which a plan that packs more chunks into fewer, slower workgroups would not let it do
-        layers._HINTS.in_flight = 1
+        layers._HINTS.in_flight, layers._HINTS.deterministic = 1, self.deterministic
         try:
             with layers.ragged(nsamp) as ctx:
                 x = batch.normalise_reads_ragged(padded, ctx.lengths)      # per-read normalisation (basecall.py:117-118)
@@ -180,7 +188,7 @@ class Basecaller(object):
                 elif packed[1] != hid.shape[2]:
                     hid = hid.as_strided((hid.shape[0], hid.shape[1], packed[1]), hid.stride())
         finally:
-            layers._HINTS.in_flight = keep
+            layers._HINTS.in_flight, layers._HINTS.deterministic = keep
         T = hid.shape[0]
         if pack is not None:
             return decode.viterbi_fused_batch(hid, pack, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,

@@ -198,23 +198,31 @@ def test_full_size_batch_properties():
 
 
 def test_double_batch_equals_two_batches():
-    """Two batches of 1024 chunks as ONE call take other kernels than each on its own (csrc/gru_bar16d.hip: eight chunks per
-    workgroup, the same two-MFMA products in the same order) -- and must give the same bits: paths, lengths and scores.  Four batches
-    as one call run sixteen chunks per workgroup (csrc/gru_bar16q.hip, no column group to spare: three-term products): hidden
-    states agree to float32 rounding, so scores agree to 1e-5 relative and the calls except where two paths score within rounding
-    of each other."""
+    """One set of bits per chunk, whatever the plan.  Two batches of 1024 chunks as ONE call take other kernels than each on its own
+    (csrc/gru_bar16d.hip: eight chunks per workgroup, the same two-MFMA products in the same order) and give the same bits: paths,
+    lengths and scores.  Four batches as one call would run sixteen chunks per workgroup (csrc/gru_bar16q.hip, no column group to
+    spare: three-term products, states equal to float32 rounding only); the default Basecaller (deterministic=True) keeps them on
+    the eight-chunk plan, so they too give the SAME bits.  Basecaller(deterministic=False) lets the faster plan in: scores agree to
+    1e-5 relative and the calls except where two paths score within rounding of each other."""
     torch = need_gpu()
     from sloika_amd import models, pipeline
     net = models.randomise_zero_layers(models.build_model("raw_0.98_rgrgr", klen=5, sd=0.5, seed=21))
     bc = pipeline.Basecaller(net)
     chunks = dev(pipeline.synthetic_chunks(4096, chunk_len=2000, seed=5))
-    s4, p4, l4 = bc.call_chunks(chunks)                      # four batches as one call: sixteen chunks per workgroup
+    s4, p4, l4 = bc.call_chunks(chunks)                      # four batches as one call: still eight chunks per workgroup (two rounds)
     s2, p2, l2 = bc.call_chunks(chunks[:2048])               # two: eight
     for lo in (0, 1024):
         s1, p1, l1 = bc.call_chunks(chunks[lo:lo + 1024])    # one: four
         assert torch.equal(p1, p2[lo:lo + 1024]) and torch.equal(l1, l2[lo:lo + 1024]) and torch.equal(s1, s2[lo:lo + 1024])
-    assert torch.allclose(s2, s4[:2048], rtol=1e-5, atol=0.0)
-    same = ((p2 == p4[:2048]).all(dim=1) & (l2 == l4[:2048])).float().mean().item()
+    assert torch.equal(p2, p4[:2048]) and torch.equal(l2, l4[:2048]) and torch.equal(s2, s4[:2048])
+    # ... and four batches in flight on streams of their own (the hint that used to select the sixteen-chunk plan)
+    s1f, p1f, l1f = pipeline.Basecaller(net, in_flight=4).call_chunks(chunks[:1024])
+    assert torch.equal(p1f, p4[:1024]) and torch.equal(l1f, l4[:1024]) and torch.equal(s1f, s4[:1024])
+    # the faster plan, on request: agreement to rounding
+    fast = pipeline.Basecaller(net, deterministic=False)
+    sq, pq, lq = fast.call_chunks(chunks)                    # sixteen chunks per workgroup
+    assert torch.allclose(s2, sq[:2048], rtol=1e-5, atol=0.0)
+    same = ((p2 == pq[:2048]).all(dim=1) & (l2 == lq[:2048])).float().mean().item()
     assert same > 0.98, same                                 # whole chunks called identically
 
 
