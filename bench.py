@@ -43,7 +43,10 @@ HBM_PEAK_GBS = 8000.0              # spec; ~6300 achievable
 
 # stages whose work is matrix products (priced against the MFMA peaks); the others against HBM
 MFMA_STAGES = ("gru_fused", "gru_recurrent", "gru_input_gemm", "lstm_fused", "lstm_recurrent", "lstm_input_gemm", "softmax_gemm",
-               "gemm_bias_act", "conv1d", "softmax_viterbi")
+               "gemm_bias_act", "conv1d", "softmax_viterbi",
+               # the training step's scans and softmax layer (its weight-gradient and dL/dx contractions are priced against HBM:
+               # TRAIN_HBM_STAGES)
+               "train_gru_scan", "train_lstm_scan", "train_softmax_xent", "train_gates", "train_wgrad", "train_dx")
 
 
 def parse():

@@ -189,6 +189,27 @@ def gru_plan(insize, size, fun, gatefun):
     return "scan"
 
 
+def gru_pad_shape(insize, size, fun, gatefun):
+    """(insize, size) of the zero-padded twin a Gru layer runs as, or its own shape when it runs as it is.  The reference's Gru takes
+    any (insize, size) (layers.py:952-977, every model factory has a `size=` argument); the kernels exist for a table of shapes.  A
+    padding neuron has zero weights and zero bias: its state stays exactly 0 (h(-1) = 0, candidate fun(0) = 0 for tanh / linear) and
+    padded input columns meet zero weights, so the leading `size` outputs are those of the unpadded layer.
+      * up to 96 wide with up to 128 inputs: the next shape of the one-kernel plan (GRU_LAYER_SHAPES: smallest width first, then the
+        fewest inputs) -- Gru(80, 80) runs as 96 -> 96, Gru(40, 72) as 64 -> 96, Gru(20, 20) as 48 -> 32;
+      * up to 144 wide: the next multiple of 16 (csrc/gru_scan1t.hip / gru_scan16.hip: 112, 128, 144);
+      * sizes that are not multiples of 16 otherwise: the next multiple (the MFMA scan of csrc/recurrent.hip)."""
+    if activation.act_name(fun) not in ("tanh", "linear"):
+        return insize, size
+    tanh_sigmoid = fun is activation.tanh and gatefun is activation.sigmoid
+    if SPLIT_F16 and RECURRENT_F16 and tanh_sigmoid:
+        fits = sorted((n, i) for (i, n) in GRU_LAYER_SHAPES if n >= size and i >= insize)
+        if fits:
+            return fits[0][1], fits[0][0]
+    if size <= 144 and ((size % 16) or (insize % 16 and size > 16)):
+        return (insize + 15) // 16 * 16, (size + 15) // 16 * 16
+    return insize, size
+
+
 #: widest Lstm on the fp16-split scan (csrc/lstm_scan16.hip: every multiple of 16 up to this, zero-padded to the next instantiation)
 LSTM_SCAN16_MAX = 128
 
@@ -974,19 +995,20 @@ class Gru(RNN):
                 bits = 2
         return bits
 
-    def _padded(self):
-        """Zero-padded copy of this layer with input and output sizes rounded up to multiples of 16 (what the MFMA
-        kernels are instantiated for).  Padding neurons see zero weights and zero bias, so their state stays exactly 0
-        (h0 = 0, candidate = fun(0) = 0 for tanh-like fun) and padded input columns multiply zero weights: the first
-        `size` outputs are those of the unpadded layer.  Cached until a parameter changes."""
+    def _padded(self, shape=None):
+        """Zero-padded copy of this layer with `shape` = (insize, size) (default: both rounded up to multiples of 16, what the MFMA
+        kernels are instantiated for; gru_pad_shape names the shape a layer runs as).  Padding neurons see zero weights and zero
+        bias, so their state stays exactly 0 (h0 = 0, candidate = fun(0) = 0 for tanh-like fun) and padded input columns multiply
+        zero weights: the first `size` outputs are those of the unpadded layer.  Cached until a parameter changes."""
         # the cache holds the device tensors themselves (an id() of a freed tensor can be reused by its successor) and the
         # parameters' versions (set_value on a buffer the optimiser owns writes in place: same tensor, new contents)
+        n, i = self.size, self.insize
+        i16, n16 = shape if shape is not None else ((i + 15) // 16 * 16, (n + 15) // 16 * 16)
         key = tuple((p.dev(), getattr(p, "_version", 0)) for p in (self.iW, self.sW, self.sW2, self.b))
         cache = getattr(self, "_pad_cache", None)
-        if cache is not None and all(a[0] is b[0] and a[1] == b[1] for a, b in zip(cache[0], key)):
+        if (cache is not None and all(a[0] is b[0] and a[1] == b[1] for a, b in zip(cache[0], key))
+                and (cache[1].insize, cache[1].size) == (i16, n16)):
             return cache[1]
-        n, i = self.size, self.insize
-        n16, i16 = (n + 15) // 16 * 16, (i + 15) // 16 * 16
         twin = Gru(i16, n16, has_bias=True, fun=self.fun, gatefun=self.gatefun, name=self.name)
         iW = np.zeros((3, n16, i16), dtype=sloika_dtype)
         iW[:, :n, :i] = self.iW.get_value().reshape(3, n, i)
@@ -1010,9 +1032,11 @@ class Gru(RNN):
         import torch
         T, B, _ = x.shape
         n = self.size
-        if ((n % 16) or (self.insize % 16 and n > 16)) and n <= 144 and activation.act_name(self.fun) in ("tanh", "linear"):
-            # odd sizes (e.g. models/raw_1.00_rGr.py: 110 / 142): run the padded twin on the MFMA kernels
-            twin = self._padded()
+        target = gru_pad_shape(self.insize, n, self.fun, self.gatefun)
+        if target != (self.insize, n):
+            # shapes without a kernel of their own (e.g. models/raw_1.00_rGr.py: 110 / 142; Gru(80, 80); size= arguments of the model
+            # factories): the zero-padded twin runs on the shape that has one
+            twin = self._padded(target)
             if twin.insize != self.insize:
                 xp = torch.zeros((T, B, twin.insize), dtype=torch.float32, device=x.device)
                 xp[:, :, :self.insize] = x

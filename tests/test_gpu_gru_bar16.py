@@ -296,3 +296,33 @@ def test_eight_chunk_plan_is_bit_identical(I, n):
                 for other in got[2:]:
                     assert (got[0][0] - other[0]).abs().max().item() < 3e-6 and (got[0][1] - other[1]).abs().max().item() < 3e-6, \
                         (T, B, reverse, lp is not None)
+
+
+@pytest.mark.parametrize("I,n", [(80, 80), (40, 72), (20, 20), (7, 5), (100, 64), (1, 96), (128, 90), (96, 100), (60, 130)])
+def test_any_gru_shape_runs_on_the_fast_plans(oracle, I, n):
+    """The reference's Gru takes any (insize, size) (layers.py:952-977; every model factory has a `size=` argument, e.g.
+    models/baseline_raw_gru.py:4).  Shapes without a kernel of their own run zero-padded on the next shape that has one
+    (layers.gru_pad_shape): up to 96 wide with up to 128 inputs on the one-kernel plan, up to 144 wide on the fp16-split scan -- never
+    on the float32 two-kernel path ("scan") -- and compute what the oracle computes for the unpadded layer, forward and reversed."""
+    need_gpu()
+    from sloika_amd import activation, layers
+    if _entry_is_not_default():
+        pytest.skip("layer-level test: once is enough")
+    rs = np.random.RandomState(100 * I + n)
+    iW, sW, sW2, b = _params(rs, I, n)
+    Ip, npad = layers.gru_pad_shape(I, n, activation.tanh, activation.sigmoid)
+    assert layers.gru_plan(Ip, npad, activation.tanh, activation.sigmoid) in ("layer", "scan16"), (I, n, Ip, npad)
+    if n <= 96 and I <= 128:
+        assert layers.gru_plan(Ip, npad, activation.tanh, activation.sigmoid) == "layer"
+    x = rs.normal(size=(19, 6, I)).astype(np.float32)
+    g = layers.Gru(I, n, has_bias=True)
+    g.set_params({"iW": iW.reshape(3, n, I), "sW": sW.reshape(2, n, n), "sW2": sW2, "b": b.reshape(3, n)})
+    y = g.compile()(x)
+    assert y.shape == (19, 6, n)
+    np.testing.assert_allclose(y, oracle.run_network(g.spec(), x), atol=TOL)
+    r = layers.Reverse(g)
+    np.testing.assert_allclose(r.compile()(x), oracle.run_network(r.spec(), x), atol=TOL)
+
+
+def _entry_is_not_default():
+    return PLAN != 0
