@@ -87,7 +87,7 @@ def parse():
                          "barriers, max over ranks, one line from rank 0 -- on the gloo backend with a Runner that sleeps; no GPU, "
                          "no kernel, and the line says so")
     ap.add_argument("--quick", action="store_true", help="only the main region, the stage pass and the CPU baseline")
-    ap.add_argument("--only", default=None, choices=["batch256"],
+    ap.add_argument("--only", default=None, choices=["batch256", "model1024"],
                     help="run ONE leg and print its JSON (bench.py starts itself with this as a child process)")
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (BASELINE.json configs[4]: forward + backward + ADAMski, "
@@ -495,7 +495,7 @@ def synthetic_reads(n, seed=0x5eed):
     return [np.ascontiguousarray(pool[rs.randint(0, len(pool))][rs.randint(0, 5000):][:ln]) for ln in lens]
 
 
-def leg_batch256(args, torch):
+def leg_batch256(args, torch, B1=256, nfl=8):
     """The batch north_star quotes (256 chunks): BASELINE.json configs[1] and the metric's own model, one batch at a time and
     eight in flight, each with the roofline of its dominant kernel (HIP events, one batch at a time)."""
     from sloika_amd import profiler
@@ -511,11 +511,11 @@ def leg_batch256(args, torch):
 
     small = {}
     for mname in (args.model,):                      # one model per child process (see the caller)
-        B1, nfl = 256, 8
-        r1 = Runner(torch, mname, B1, L, nfl)
+        r1 = Runner(torch, mname, B1, L, max(1, nfl))
         ent = {"workload": "%s inference, %d-sample chunks, batch %d%s" % (
-            mname, L, B1, " (BASELINE.json configs[1])" if mname == "baseline_raw_gru" else " (the metric's model at the "
-            "north star's batch)")}
+            mname, L, B1, " (BASELINE.json configs[1])" if mname == "baseline_raw_gru" and B1 == 256 else
+            " (the architecture of the reference's only TRAINED model, models/pretrained.pkl: Conv 128 . Rev Gru 112 . Gru 144 . Rev Gru "
+            "112; random weights)" if mname == "pretrained" else " (the metric's model at the north star's batch)")}
         r1.set_in_flight(1)
         for i in range(3):
             r1.step(i, 1)
@@ -531,6 +531,11 @@ def leg_batch256(args, torch):
         tr1 = pmc_traffic(mname, B1, L)
         ent["roofline"] = attach_counters(roofline_of(st1, tr1, "one batch at a time: %d workgroups of 4 chunks on 256 CUs" % (B1 // 4)),
                                           mname, B1, L)
+        if nfl <= 1:
+            ent["roofline_by_stage"] = roofline_by_stage(st1, tr1, None)
+            small[mname] = ent
+            del r1, rec1, st1
+            continue
         ent["roofline_by_stage"] = roofline_by_stage(st1, tr1, None)
         for v in (ent["roofline_by_stage"] or {}).values():
             attach_counters(v, mname, B1, L)
@@ -686,6 +691,11 @@ def main():
         from sloika_amd import _lib as _l
         _l.require_gpu()
         print(json.dumps(leg_batch256(args, torch)))
+        return
+    if args.only == "model1024":
+        from sloika_amd import _lib as _l
+        _l.require_gpu()
+        print(json.dumps(leg_batch256(args, torch, B1=args.batch, nfl=1)))
         return
     from sloika_amd import shard
     rank, world, local_rank = shard.dist_info()
@@ -925,6 +935,19 @@ def main():
                     line_extra["batch256"].update(json.loads(r.stdout.strip().split("\n")[-1]))
                 except (ValueError, IndexError):
                     line_extra["batch256"][mname] = {"error": "child process failed (exit code %d)" % r.returncode}
+
+        # ---- the architecture of the reference's only trained model (models/pretrained.pkl), one batch of 1024 chunks at a time: the
+        # widths (112 / 144) that run projection GEMM + fp16-split scan instead of the one-kernel plan ----
+        if args.small_batch_steps > 0 and args.model == "raw_0.98_rgrgr" and B == 1024 and not args.with_bases:
+            import subprocess
+            torch.cuda.synchronize()
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only", "model1024", "--model", "pretrained", "--batch", "1024",
+                                "--small-batch-steps", str(2 * args.small_batch_steps), "--chunk-len", str(L)],
+                               stdout=subprocess.PIPE, text=True)
+            try:
+                line_extra["pretrained"] = json.loads(r.stdout.strip().split("\n")[-1])["pretrained"]
+            except (ValueError, IndexError, KeyError):
+                line_extra["pretrained"] = {"error": "child process failed (exit code %d)" % r.returncode}
 
         # ---- whole reads (the reference's inference mode), bucketed by length, ragged batches in flight ----
         if args.whole_reads > 0 and not args.with_bases:

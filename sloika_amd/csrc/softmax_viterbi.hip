@@ -63,6 +63,9 @@
 #ifndef SV_ORDER
 #define SV_ORDER 0
 #endif
+#ifndef SV_AHEAD
+#define SV_AHEAD 4              /* positions between the LDS request of a pair's A images and its first MFMA */
+#endif
 #ifndef SV_MIX
 #define SV_MIX 6                /* vector instructions the scheduler is asked to place behind every MFMA (SV_ORDER 2) */
 #endif
@@ -79,6 +82,13 @@
 #endif
 
 template <int K> using ic = std::integral_constant<int, K>;
+template <int B_, int E_, class F> __device__ __forceinline__ void static_for_sv(F &&f)
+{
+    if constexpr (B_ < E_) {
+        f(ic<B_>{});
+        static_for_sv<B_ + 1, E_>(f);
+    }
+}
 // two float32 values per vector instruction (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): a wave64 vector instruction takes
 // four cycles of its SIMD whatever it does, so the element-wise passes over the logits are written on pairs
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -289,6 +299,19 @@ template <int KS> struct SvSched {
     // for the barrier, and so that the two waves of a SIMD, which run the same program in lock step, do not ask the matrix pipe for
     // sixteen MFMAs within the 250 cycles of the chunks; position q takes MFMAs [q MPS / NPOS, (q + 1) MPS / NPOS) of the step
     static constexpr int NPOS = 12;
+#ifndef SV_EDGE
+#define SV_EDGE 0
+#endif
+    // first MFMA (of the step's MPS) at position q.  SV_EDGE: all of them in two bursts, right behind the programme's LDS requests and
+    // right behind its writes -- while MFMAs execute the SIMD issues one vector instruction per ~4.75 cycles for BOTH its waves instead
+    // of one per wave (tools/probes/coissue_probe.hip: a wave beside an MFMA-issuing partner runs at half rate), so the MFMAs belong
+    // where both waves only wait (LDS round trip, barrier), not between the chunks of the programme
+    static constexpr int slot_lo(int q)
+    {
+        if (SV_EDGE) return q <= 0 ? 0 : (q < NPOS - 1 ? MPS / 2 : (q == NPOS - 1 ? MPS / 2 : MPS));
+        return (q * MPS) / NPOS;
+    }
+    static constexpr int slot_hi(int q) { return q >= NPOS - 1 ? MPS : slot_lo(q + 1); }
     static constexpr int mf_step(int m) { return m / MPS; }
     static constexpr int fin_step(int n) { return mf_step(3 * KS * (n + 1) - 1) + 1; }
     static constexpr int E0 = fin_step(3) + 1, SUM_K = E0 + 3, ROW_K = SUM_K + 1, LOADX_K = MMA_LAST + 2;
@@ -462,6 +485,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     auto mfma_m = [&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value;
         if constexpr (m < Sched::NMF && !(SV_ABL & 1)) {
+            if constexpr (SV_ABL & 128) { if (wave >= 4) return; }          // (timing only: the MFMAs of one wave half alone)
             constexpr int p = m / 3, term = m % 3, n = p / KS;
             constexpr bool zero = (p % KS == 0) && term == 0;
             const half8 a = term == 0 ? al[p] : ah[p];
@@ -485,7 +509,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         constexpr int k = decltype(kc)::value, c8 = decltype(cc_)::value;
         if constexpr (k <= Sched::MMA_LAST) {
             constexpr int base = k * Sched::MPS;
-            mfma_run(ic<base + (c8 * Sched::MPS) / Sched::NPOS>{}, ic<base + ((c8 + 1) * Sched::MPS) / Sched::NPOS>{}, mfma_run);
+            mfma_run(ic<base + Sched::slot_lo(c8)>{}, ic<base + Sched::slot_hi(c8)>{}, mfma_run);
         }
     };
     // the pairs whose first MFMA lies in chunk c8 of step k: their A images are requested a chunk earlier (at the top of the step for
@@ -501,8 +525,14 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         constexpr int k = decltype(kc)::value, c8 = decltype(cc_)::value;
         if constexpr (k <= Sched::MMA_LAST && c8 < Sched::NPOS) {
             constexpr int base = k * Sched::MPS;
-            aload_run(ic<base + (c8 * Sched::MPS) / Sched::NPOS>{}, ic<base + ((c8 + 1) * Sched::MPS) / Sched::NPOS>{}, apar, aload_run);
+            aload_run(ic<base + Sched::slot_lo(c8)>{}, ic<base + Sched::slot_hi(c8)>{}, apar, aload_run);
         }
+    };
+    // the A images for position P of the block's linear position count (step P / NPOS, position P % NPOS): requested SV_AHEAD positions
+    // before the MFMA that opens the pair -- an LDS read takes 64 - 130 cycles, a position ~35, and the MFMA behind a late read waits
+    auto aload_pos = [&](auto Pc, int apar) __attribute__((always_inline)) {
+        constexpr int P = decltype(Pc)::value;
+        if constexpr (P >= 0 && P / Sched::NPOS <= Sched::MMA_LAST) aload_for(ic<P / Sched::NPOS>{}, ic<P % Sched::NPOS>{}, apar);
     };
     auto wload_first = [&](auto pc, auto &&self) __attribute__((always_inline)) {
         constexpr int p = decltype(pc)::value;
@@ -711,21 +741,23 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         }
         if constexpr (PROD) {
             if constexpr (k == 0) {                             // (the images of a block are made in the last steps of the period before)
-                aload_for(kc, ic<0>{}, apar);
-                aload_for(kc, ic<1>{}, apar);
-                aload_for(kc, ic<2>{}, apar);
+                static_for_sv<0, SV_AHEAD>([&](auto qc) { aload_pos(ic<decltype(qc)::value>{}, apar); });
             }
             mfma_slot(kc, ic<0>{}, apar);
+            aload_pos(ic<k * Sched::NPOS + 0 + SV_AHEAD>{}, apar);
             mfma_slot(kc, ic<1>{}, apar);
-            aload_for(kc, ic<3>{}, apar);
+            aload_pos(ic<k * Sched::NPOS + 1 + SV_AHEAD>{}, apar);
         }
         if constexpr (DP) {
             l0 = ln0; l1 = ln1; l2 = ln2; l3 = ln3;             // made at the end of the step before (J)
             if constexpr (k == 0) { ls0 = l0; ls1 = l1; ls2 = l2; ls3 = l3; }
         }
-        if constexpr (PROD) side(kc, nb);
+        if constexpr (PROD) {
+            if constexpr (SV_ABL & 64) { if (wave < 4) side(kc, nb); }       // (timing only: what the side work costs one wave half alone)
+            else side(kc, nb);
+        }
         // ---- D1 ----
-        if constexpr (PROD) { mfma_slot(kc, ic<2>{}, apar); aload_for(kc, ic<4>{}, apar); }
+        if constexpr (PROD) { mfma_slot(kc, ic<2>{}, apar); aload_pos(ic<k * Sched::NPOS + 2 + SV_AHEAD>{}, apar); }
         if constexpr (DP)
             asm volatile("v_max3_f32 %[t0], %[vs0], %[vs1], %[vs2]\n\t"
                          "v_max3_f32 %[t1], %[vk0], %[vk1], %[vk2]\n\t"
@@ -738,7 +770,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
                          : [vs0] "v"(vs0), [vs1] "v"(vs1), [vs2] "v"(vs2), [vs3] "v"(vs3), [vk0] "v"(vk0), [vk1] "v"(vk1), [vk2] "v"(vk2),
                            [vk3] "v"(vk3), [lp0] "v"(lp0));
         // ---- D2 ----
-        if constexpr (PROD) { mfma_slot(kc, ic<3>{}, apar); aload_for(kc, ic<5>{}, apar); }
+        if constexpr (PROD) { mfma_slot(kc, ic<3>{}, apar); aload_pos(ic<k * Sched::NPOS + 3 + SV_AHEAD>{}, apar); }
         if constexpr (DP)
             asm volatile("v_cmp_eq_f32 %[sA], %[vs2], %[t0]\n\t"
                          "v_max_f32_dpp %[t2], %[t1], %[t1] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -749,7 +781,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
                          : [sA] "=&s"(sA), [sB] "=&s"(sB), [sC] "=&s"(sC), [t2] "=&v"(t2r), [o3] "+v"(o3)
                          : [vs0] "v"(vs0), [vs1] "v"(vs1), [vs2] "v"(vs2), [t0] "v"(t0r), [t1] "v"(t1r), [lp0] "v"(lp0));
         // ---- D3 ----  (vs2 becomes the step argument, vs3 the skip score)
-        if constexpr (PROD) { mfma_slot(kc, ic<4>{}, apar); aload_for(kc, ic<6>{}, apar); }
+        if constexpr (PROD) { mfma_slot(kc, ic<4>{}, apar); aload_pos(ic<k * Sched::NPOS + 4 + SV_AHEAD>{}, apar); }
         if constexpr (DP)
             asm volatile("v_cmp_eq_f32 %[sD], %[vk2], %[t1]\n\t"
                          "v_cmp_eq_f32 %[sE], %[vk1], %[t1]\n\t"
@@ -762,7 +794,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
                          : [vk0] "v"(vk0), [vk1] "v"(vk1), [vk2] "v"(vk2), [t1] "v"(t1r), [t2] "v"(t2r), [sA] "s"(sA), [sB] "s"(sB),
                            [pen] "s"(skip_pen));
         // ---- D4 ----  (t2 becomes mx, vk2 my first skip maximum's a*4, sA "by step")
-        if constexpr (PROD) { mfma_slot(kc, ic<5>{}, apar); aload_for(kc, ic<7>{}, apar); }
+        if constexpr (PROD) { mfma_slot(kc, ic<5>{}, apar); aload_pos(ic<k * Sched::NPOS + 5 + SV_AHEAD>{}, apar); }
         if constexpr (DP)
             asm volatile("v_max_f32 %[t2], %[t0], %[vs3]\n\t"                                                   // mx
                          "v_cndmask_b32 %[vk2], 12, 8, %[sD]\n\t"
@@ -774,7 +806,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
                          : [t2] "=&v"(t2r), [vk2] "=&v"(vk2), [sA] "=&s"(sA), [vs2] "+v"(vs2), [l0] "+v"(l0)
                          : [t0] "v"(t0r), [vs3] "v"(vs3), [sC] "s"(sC), [sD] "s"(sD), [sE] "s"(sE), [sF] "s"(sF));
         // ---- D5 ----
-        if constexpr (PROD) { mfma_slot(kc, ic<6>{}, apar); aload_for(kc, ic<8>{}, apar); }
+        if constexpr (PROD) { mfma_slot(kc, ic<6>{}, apar); aload_pos(ic<k * Sched::NPOS + 6 + SV_AHEAD>{}, apar); }
         if constexpr (DP)
             asm volatile("v_add_f32 %[l1], %[l1], %[t2]\n\t"
                          "v_or_b32 %[vk2], %[vk2], %[cc]\n\t"                                                   // a*4 + b of my first maximum
@@ -786,7 +818,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
                          : [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [vk2] "+v"(vk2), [sB] "=&s"(sB), [sC] "=&s"(sC)
                          : [t2] "v"(t2r), [cc] "v"(cc), [sG] "s"(sG), [l0] "v"(l0), [o0] "v"(o0), [o1] "v"(o1));
         // ---- D6 ----
-        if constexpr (PROD) { mfma_slot(kc, ic<7>{}, apar); aload_for(kc, ic<9>{}, apar); }
+        if constexpr (PROD) { mfma_slot(kc, ic<7>{}, apar); aload_pos(ic<k * Sched::NPOS + 7 + SV_AHEAD>{}, apar); }
         if constexpr (DP)
             asm volatile("v_min_i32_dpp %[vk2], %[vk2], %[vk2] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                          "v_cmp_gt_f32 %[sD], %[l2], %[o2]\n\t"
@@ -797,7 +829,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
                          : [vk2] "+v"(vk2), [sD] "=&s"(sD), [sE] "=&s"(sE), [o0] "+v"(o0), [o1] "+v"(o1)
                          : [l0] "v"(l0), [l1] "v"(l1), [l2] "v"(l2), [l3] "v"(l3), [o2] "v"(o2), [o3] "v"(o3));
         // ---- D7 ----  (l0 .. l3 become the move bits)
-        if constexpr (PROD) { mfma_slot(kc, ic<8>{}, apar); aload_for(kc, ic<10>{}, apar); }
+        if constexpr (PROD) { mfma_slot(kc, ic<8>{}, apar); aload_pos(ic<k * Sched::NPOS + 8 + SV_AHEAD>{}, apar); }
         if constexpr (DP) {
             asm volatile("v_cndmask_b32 %[l0], 0, 1, %[sB]\n\t"
                          "v_cndmask_b32 %[l1], 0, 4, %[sC]\n\t"
@@ -815,7 +847,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             vnew[0] = o0; vnew[1] = o1; vnew[2] = o2; vnew[3] = o3;
         }
         // ---- D8 ----
-        if constexpr (PROD) { mfma_slot(kc, ic<9>{}, apar); aload_for(kc, ic<11>{}, apar); }
+        if constexpr (PROD) { mfma_slot(kc, ic<9>{}, apar); aload_pos(ic<k * Sched::NPOS + 9 + SV_AHEAD>{}, apar); }
         if constexpr (DP) {
             asm volatile("v_or3_b32 %[l0], %[l0], %[l1], %[l2]\n\t"
                          "v_lshlrev_b32 %[vk2], 10, %[vk2]\n\t"
@@ -834,12 +866,9 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         }
         if constexpr (PROD) {                                   // behind the writes: the wave would only wait for them and the barrier
             mfma_slot(kc, ic<10>{}, apar);
+            aload_pos(ic<k * Sched::NPOS + 10 + SV_AHEAD>{}, apar);
             mfma_slot(kc, ic<11>{}, apar);
-            if constexpr (k + 1 <= Sched::MMA_LAST) {           // the A images the next step's first positions open (same block: same parity)
-                aload_for(ic<k + 1>{}, ic<0>{}, apar);
-                aload_for(ic<k + 1>{}, ic<1>{}, apar);
-                aload_for(ic<k + 1>{}, ic<2>{}, apar);
-            }
+            aload_pos(ic<k * Sched::NPOS + 11 + SV_AHEAD>{}, apar);
         }
     };
     // rows of block blk (staged with parity par) -> HBM: per chunk BS rows of 512 bytes, contiguous on both sides

@@ -1082,7 +1082,10 @@ class Gru(RNN):
         nbytes = L.slk_gru_workspace_bytes(T, B, n)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 3 * n, "gru_input_gemm", "Gru")
-        with profiler.region("gru_recurrent", 6.0 * rows * n * n, 4.0 * rows * 4 * n):
+        # (roofline bookkeeping: the fp16-split scans take two MFMAs per recurrent product, the state's halves in different column groups;
+        #  the float32 scan one fp32 MFMA)
+        with profiler.region("gru_recurrent", 6.0 * rows * n * n, 4.0 * rows * 4 * n,
+                             f16x2_flops=6.0 * rows * n * n if plan == "scan16" else 0.0):
             rc = _lib.SLK_ERR_UNSUPPORTED
             if plan == "scan16":
                 # n = 112 / 128 / 144: the barrier-stepped scan on the fp16 split (csrc/gru_scan16.hip, gru_scan1t.hip; unsupported:

@@ -8,11 +8,11 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
-enum Body { IDLE = 0, VALU, VALU_DEP, SALU, CMPSEL, TRANS, PK, LDSR, LDSW, NOP, MAXDPP, NBODY };
+enum Body { IDLE = 0, VALU, VALU_DEP, SALU, CMPSEL, TRANS, PK, LDSR, LDSW, NOP, MAXDPP, MFMA, MFMA7, MFMA14, NBODY };
 static const char *names[NBODY] = {"idle", "valu(indep)", "valu(dep)", "salu", "cmp+cndmask", "trans", "pk_fma", "ds_read_b32",
-                                   "ds_write_b32", "s_nop", "max_dpp"};
+                                   "ds_write_b32", "s_nop", "max_dpp", "mfma32x32x16", "mfma+7valu", "mfma+14valu"};
 // instructions per loop iteration of each body (for the per-instruction figure)
-static const int per_iter[NBODY] = {1, 64, 64, 64, 64, 64, 64, 32, 32, 64, 32};
+static const int per_iter[NBODY] = {1, 64, 64, 64, 64, 64, 64, 32, 32, 64, 32, 8, 8, 8};      // (MFMA bodies: per MFMA, its fillers included)
 
 template <int BODY>
 __device__ __forceinline__ void body(float (&v)[8], float &lds_v, float *lds, int lane, unsigned &sacc)
@@ -66,6 +66,25 @@ __device__ __forceinline__ void body(float (&v)[8], float &lds_v, float *lds, in
     } else if constexpr (BODY == NOP) {
 #pragma unroll
         for (int r = 0; r < 64; r++) asm volatile("s_nop 0");
+    } else if constexpr (BODY == MFMA || BODY == MFMA7 || BODY == MFMA14) {
+        // eight dependent v_mfma_f32_32x32x16_f16 (one accumulator), with 0 / 7 / 14 independent vector instructions behind each
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        typedef float f16v __attribute__((ext_vector_type(16)));
+        static_assert(sizeof(h8) == 16, "");
+        h8 a, b;
+        for (int i = 0; i < 8; i++) { a[i] = (_Float16)v[i]; b[i] = (_Float16)lds_v; }
+        f16v acc;
+        for (int i = 0; i < 16; i++) acc[i] = v[i & 7];
+        asm volatile("" : "+v"(acc), "+v"(a), "+v"(b));
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+            constexpr int NF = BODY == MFMA ? 0 : (BODY == MFMA7 ? 7 : 14);
+#pragma unroll
+            for (int i = 0; i < NF; i++) asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[i & 7]) : "v"(lds_v));
+        }
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
+        v[0] += acc[0];
     } else if constexpr (BODY == MAXDPP) {
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -154,5 +173,11 @@ int main()
     run<VALU, MAXDPP>(out, cyc);
     run<MAXDPP, MAXDPP>(out, cyc);
     run<SALU, CMPSEL>(out, cyc);
+    run<MFMA, MFMA>(out, cyc);
+    run<MFMA7, MFMA7>(out, cyc);
+    run<MFMA14, MFMA14>(out, cyc);
+    run<MFMA7, VALU>(out, cyc);
+    run<MFMA14, VALU>(out, cyc);
+    run<VALU, MFMA7>(out, cyc);
     return 0;
 }
