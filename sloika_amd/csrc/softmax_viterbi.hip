@@ -415,48 +415,92 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         xr1 = *reinterpret_cast<const float4 *>(src + 4);
     };
     // x rows of block blk -> fp16 hi/lo A-operand images, row scales, blank logits (all double buffered by block parity)
+    // (Round 5: one hand-scheduled sequence.  hipcc's version of the same arithmetic -- two 16-lane row reductions through DPP moves with
+    //  canonicalised maxima and wait states, element-wise conversions -- kept a wave ~1030 cycles, alone on its SIMD; the row maximum
+    //  and the blank column's dot product are independent chains and interleave here, the split is f16split.h's four instructions per
+    //  pair.  Same values bit for bit: the dot product is the same single fused chain, the row sum takes the partners in the same order.)
+    const float pa_actf = pa_act ? 1.0f : 0.0f;
     auto prepare_a = [&](int blk) __attribute__((always_inline)) {
         const int par = blk & 1;
-        float xv[8] = {xr0.x, xr0.y, xr0.z, xr0.w, xr1.x, xr1.y, xr1.z, xr1.w};
-#pragma unroll
-        for (int i = 0; i < 8; i++) xv[i] = pa_act ? xv[i] : 0.0f;
-        float amax = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; i++) amax = fmaxf(amax, fabsf(xv[i]));
-        // (no sv_max here: a DPP instruction that reads a register needs two wait states after the vector instruction that
-        // wrote it, and the compiler pads only behind instructions it emitted itself -- never feed its DPP from inline asm)
-        amax = sv_row_allreduce<false>(amax);
-        float inv;
-        const float sc = pow2_scale(amax, inv);
         const float *w0 = reinterpret_cast<const float *>(smem + OFF_W0);
         const float4 wa = *reinterpret_cast<const float4 *>(w0 + 8 * min(kb, 2 * KS - 1));
         const float4 wb = *reinterpret_cast<const float4 *>(w0 + 8 * min(kb, 2 * KS - 1) + 4);
-        float dot = xv[0] * wa.x;
-        dot = fmaf(xv[1], wa.y, dot);
-        dot = fmaf(xv[2], wa.z, dot);
-        dot = fmaf(xv[3], wa.w, dot);
-        dot = fmaf(xv[4], wb.x, dot);
-        dot = fmaf(xv[5], wb.y, dot);
-        dot = fmaf(xv[6], wb.z, dot);
-        dot = fmaf(xv[7], wb.w, dot);
-        dot = sv_row_allreduce<true>(dot);
-        half8 hi, lo;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            float v = xv[i] * sc;
-            keepf(v);
-            const _Float16 hv = (_Float16)v;
-            hi[i] = hv;
-            lo[i] = (_Float16)(v - (float)hv);
-        }
+        const float b0 = w0[16 * KS];                           // the blank column's bias (requested with the weights: one LDS round trip)
+        float x0 = xr0.x, x1 = xr0.y, x2 = xr0.z, x3 = xr0.w, x4 = xr1.x, x5 = xr1.y, x6 = xr1.z, x7 = xr1.w;
+        float a0, a1, a2, a3, am, dot, inv, sc;
+        unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+        asm volatile("v_max_f32 %[a0], |%[x0]|, |%[x1]|\n\t"
+                     "v_mul_f32 %[dot], %[x0], %[w0]\n\t"
+                     "v_max_f32 %[a1], |%[x2]|, |%[x3]|\n\t"
+                     "v_fma_f32 %[dot], %[x1], %[w1], %[dot]\n\t"
+                     "v_max_f32 %[a2], |%[x4]|, |%[x5]|\n\t"
+                     "v_fma_f32 %[dot], %[x2], %[w2], %[dot]\n\t"
+                     "v_max_f32 %[a3], |%[x6]|, |%[x7]|\n\t"
+                     "v_fma_f32 %[dot], %[x3], %[w3], %[dot]\n\t"
+                     "v_max3_f32 %[am], %[a0], %[a1], %[a2]\n\t"
+                     "v_fma_f32 %[dot], %[x4], %[w4], %[dot]\n\t"
+                     "v_max_f32 %[am], %[am], %[a3]\n\t"
+                     "v_fma_f32 %[dot], %[x5], %[w5], %[dot]\n\t"
+                     "v_mul_f32 %[am], %[am], %[act]\n\t"                                     // lanes beyond K: 0
+                     "v_fma_f32 %[dot], %[x6], %[w6], %[dot]\n\t"
+                     "s_nop 0\n\t"
+                     "v_fma_f32 %[dot], %[x7], %[w7], %[dot]\n\t"
+                     "v_max_f32_dpp %[am], %[am], %[am] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_mul_f32 %[dot], %[dot], %[act]\n\t"
+                     "s_nop 0\n\t"
+                     "v_max_f32_dpp %[am], %[am], %[am] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %[dot], %[dot], %[dot] row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 0\n\t"
+                     "v_max_f32_dpp %[am], %[am], %[am] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %[dot], %[dot], %[dot] row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                     "s_nop 0\n\t"
+                     "v_max_f32_dpp %[am], %[am], %[am] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"  // the row's largest magnitude
+                     "v_add_f32_dpp %[dot], %[dot], %[dot] row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_bfe_u32 %[inv], %[am], 23, 8\n\t"                                     // pow2_scale (f16split.h)
+                     "s_nop 0\n\t"
+                     "v_add_f32_dpp %[dot], %[dot], %[dot] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"  // the row's blank-column product
+                     "v_med3_u32 %[inv], %[inv], 27, %[c227]\n\t"
+                     "v_lshlrev_b32 %[inv], 23, %[inv]\n\t"
+                     "v_sub_u32 %[sc], 0x7f000000, %[inv]\n\t"
+                     "v_mul_f32 %[sc], %[sc], %[act]\n\t"
+                     "v_mul_f32 %[x0], %[x0], %[sc]\n\t"
+                     "v_mul_f32 %[x1], %[x1], %[sc]\n\t"
+                     "v_mul_f32 %[x2], %[x2], %[sc]\n\t"
+                     "v_mul_f32 %[x3], %[x3], %[sc]\n\t"
+                     "v_mul_f32 %[x4], %[x4], %[sc]\n\t"
+                     "v_mul_f32 %[x5], %[x5], %[sc]\n\t"
+                     "v_mul_f32 %[x6], %[x6], %[sc]\n\t"
+                     "v_mul_f32 %[x7], %[x7], %[sc]\n\t"
+                     "v_cvt_pk_f16_f32 %[h0], %[x0], %[x1]\n\t"
+                     "v_cvt_pk_f16_f32 %[h1], %[x2], %[x3]\n\t"
+                     "v_cvt_pk_f16_f32 %[h2], %[x4], %[x5]\n\t"
+                     "v_cvt_pk_f16_f32 %[h3], %[x6], %[x7]\n\t"
+                     "v_fma_mix_f32 %[x0], %[h0], -1.0, %[x0] op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mix_f32 %[x1], %[h0], -1.0, %[x1] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mix_f32 %[x2], %[h1], -1.0, %[x2] op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mix_f32 %[x3], %[h1], -1.0, %[x3] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mix_f32 %[x4], %[h2], -1.0, %[x4] op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mix_f32 %[x5], %[h2], -1.0, %[x5] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mix_f32 %[x6], %[h3], -1.0, %[x6] op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mix_f32 %[x7], %[h3], -1.0, %[x7] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+                     "v_cvt_pk_f16_f32 %[l0], %[x0], %[x1]\n\t"
+                     "v_cvt_pk_f16_f32 %[l1], %[x2], %[x3]\n\t"
+                     "v_cvt_pk_f16_f32 %[l2], %[x4], %[x5]\n\t"
+                     "v_cvt_pk_f16_f32 %[l3], %[x6], %[x7]"
+                     : [x0] "+v"(x0), [x1] "+v"(x1), [x2] "+v"(x2), [x3] "+v"(x3), [x4] "+v"(x4), [x5] "+v"(x5), [x6] "+v"(x6),
+                       [x7] "+v"(x7), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [am] "=&v"(am), [dot] "=&v"(dot),
+                       [inv] "=&v"(inv), [sc] "=&v"(sc), [h0] "=&v"(h0), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3), [l0] "=&v"(l0),
+                       [l1] "=&v"(l1), [l2] "=&v"(l2), [l3] "=&v"(l3)
+                     : [w0] "v"(wa.x), [w1] "v"(wa.y), [w2] "v"(wa.z), [w3] "v"(wa.w), [w4] "v"(wb.x), [w5] "v"(wb.y), [w6] "v"(wb.z),
+                       [w7] "v"(wb.w), [act] "v"(pa_actf), [c227] "s"(227));
         if (pa_act) {
             uint8_t *dst = smem + OFF_A + par * KS * 2048 + (kb >> 1) * 2048 + (rho + 32 * (kb & 1)) * 16;
-            *reinterpret_cast<half8 *>(dst) = hi;
-            *reinterpret_cast<half8 *>(dst + 1024) = lo;
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(h0, h1, h2, h3);
+            *reinterpret_cast<uint4 *>(dst + 1024) = make_uint4(l0, l1, l2, l3);
         }
         if (kb == 0) {
             reinterpret_cast<float *>(smem + OFF_XINV)[par * 32 + pa_half * 16 + pa_i] = inv;
-            reinterpret_cast<float *>(smem + OFF_L0)[par * 32 + pa_half * 16 + pa_i] = (dot + w0[16 * KS]) * SV_LOG2E;
+            reinterpret_cast<float *>(smem + OFF_L0)[par * 32 + pa_half * 16 + pa_i] = (dot + b0) * SV_LOG2E;
         }
     };
     auto wload = [&](auto pc) __attribute__((always_inline)) {
@@ -752,10 +796,15 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             l0 = ln0; l1 = ln1; l2 = ln2; l3 = ln3;             // made at the end of the step before (J)
             if constexpr (k == 0) { ls0 = l0; ls1 = l1; ls2 = l2; ls3 = l3; }
         }
+        [[maybe_unused]] const int cb = nb - 1;                 // (SV_STAMP2 names it)
+        if constexpr (k == 14) SV_STAMP2(0);
+        if constexpr (k == 15) SV_STAMP2(4);
         if constexpr (PROD) {
             if constexpr (SV_ABL & 64) { if (wave < 4) side(kc, nb); }       // (timing only: what the side work costs one wave half alone)
             else side(kc, nb);
         }
+        if constexpr (k == 14) SV_STAMP2(1);
+        if constexpr (k == 15) SV_STAMP2(5);
         // ---- D1 ----
         if constexpr (PROD) { mfma_slot(kc, ic<2>{}, apar); aload_pos(ic<k * Sched::NPOS + 2 + SV_AHEAD>{}, apar); }
         if constexpr (DP)
@@ -860,6 +909,8 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
                          : "memory");
             tbs[((par * NCH + hch) * BS + k) * 256 + j] = (uint16_t)__float_as_uint(l0);
         }
+        if constexpr (k == 14) SV_STAMP2(2);
+        if constexpr (k == 15) SV_STAMP2(6);
         if constexpr (DP) {                                     // J for the next step's row
             if constexpr (k < 15) jit_log(ecur[0][k + 1], ecur[1][k + 1], ecur[2][k + 1], ecur[3][k + 1], fac, t0 + k + 1);
             else if constexpr (PROD) jit_log(acc[0][0], acc[1][0], acc[2][0], acc[3][0], fac, t0 + 16);    // row 0 of the block just finished
@@ -870,6 +921,8 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
             mfma_slot(kc, ic<11>{}, apar);
             aload_pos(ic<k * Sched::NPOS + 11 + SV_AHEAD>{}, apar);
         }
+        if constexpr (k == 14) SV_STAMP2(3);
+        if constexpr (k == 15) SV_STAMP2(7);
     };
     // rows of block blk (staged with parity par) -> HBM: per chunk BS rows of 512 bytes, contiguous on both sides
     auto flush_tb = [&](int blk, int par) __attribute__((always_inline)) {

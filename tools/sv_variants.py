@@ -84,7 +84,16 @@ def main():
             full = dbg.cpu().numpy()
             s1 = full[:nper * 16].reshape(-1, 16)[6:nper - 3]
             s2 = full[4096:4096 + nper * 16].reshape(-1, 16)[6:nper - 3]
-            if s2[:, :9].min() > 0:
+            if os.environ.get("SV_SUB"):
+                # round 5: sub-step stamps of steps 14 and 15 (wave 0): top of the step (LDS requests issued), after the vector side
+                # work, after the programme's chunks, at the end (J, tail MFMAs), then the barrier
+                def md(a):
+                    return int(np.median(a))
+                for st, base in ((14, 0), (15, 4)):
+                    print("    step %d: barrier->top %d, side work %d, chunks D1-D8 %d, J + tail %d, to the barrier stamp %d" % (
+                        st, md(s2[:, base] - s1[:, st - 1]), md(s2[:, base + 1] - s2[:, base]), md(s2[:, base + 2] - s2[:, base + 1]),
+                        md(s2[:, base + 3] - s2[:, base + 2]), md(s1[:, st] - s2[:, base + 3])))
+            elif s2[:, :9].min() > 0:
                 def md(a):
                     return int(np.median(a))
                 print("    after step 11 -> before flush %d, flush %d, to end of step 12 %d (exp_sum alone %d, from step start %d)" % (
