@@ -661,14 +661,19 @@ __global__ void __launch_bounds__(256) viterbi_forward4_wave_kernel(const float 
 // ------------------------------------------------------------------------------------------------------
 #define VBT_RING 3
 #define VBT_BLOCK 12288            /* bytes; a multiple of 3 KiB (three stager waves) and of every 4^k k-mer count <= 4096 */
-// PACKED: the traceback of viterbi_forward4_kernel (one 16-bit word per four states and step) instead of a byte per state
-template <int NB, bool PACKED>
+// FMT 0: a byte per state.  FMT 1: the traceback of viterbi_forward4_kernel, one 16-bit word per four states and step (two bits per
+// to-state: 0 stay, 1 step, 2 skip; the step argument at bit 8, the skip argument at bit 10).  FMT 2 (round 5, the fused kernel of
+// softmax_viterbi.hip): ONE BYTE per four states -- bits 0-3 "to-state n moves", bit 4 "by step" (else by skip), bits 5-6 the step
+// argument, bit 7 bit (j & 3) of the skip argument, which the four lanes of a quad share: 256 bytes per step and chunk instead of
+// 512, half the traffic of this kernel (which is bound by reading it) and of the forward kernel's traceback stores.
+template <int NB, int FMT>
 __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *__restrict__ tb,
                                                                 const int32_t *__restrict__ best, int T, int nkmer,
                                                                 int tblk, int dma, int32_t *__restrict__ path_out,
                                                                 int32_t *__restrict__ len_out, const int *__restrict__ lens)
 {
-    const int rowbytes = PACKED ? nkmer / 2 : nkmer;
+    constexpr bool PACKED = FMT == 1;
+    const int rowbytes = FMT == 2 ? nkmer / 4 : (PACKED ? nkmer / 2 : nkmer);
     constexpr int NB2 = NB * NB;
     constexpr int PER_WAVE = VBT_BLOCK / 1024 / 3;
     const int Tpad = T;                                        // row strides of tb / path_out; T = this chunk's own length
@@ -697,7 +702,17 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
         // dependent chain to the scalar unit
         int cur = __builtin_amdgcn_readfirstlane(sh_cur), pos = __builtin_amdgcn_readfirstlane(sh_pos);
         for (int t = t1 - 1; t >= t0; t--) {
-            if constexpr (PACKED) {
+            if constexpr (FMT == 2) {
+                // the quad's four bytes (states 16 (cur >> 4) .. + 15): mine is byte (cur >> 2) & 3, bit 7 of byte i is bit i of the skip argument
+                const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane(
+                    (int)reinterpret_cast<const uint32_t *>(rows)[(t - t0) * (nkmer / 16) + (cur >> 4)]);
+                const unsigned w = (q >> (8 * ((cur >> 2) & 3))) & 0xffu;
+                if ((w >> (cur & 3)) & 1u) {
+                    const unsigned karg = ((q >> 7) & 1u) | ((q >> 14) & 2u) | ((q >> 21) & 4u) | ((q >> 28) & 8u);
+                    cur = (w & 16u) ? (int)((w >> 5) & 3u) * nrem1 + cur / NB : (int)karg * nrem2 + cur / NB2;
+                    path[--pos] = cur;                         // decode.py:88-90
+                }
+            } else if constexpr (PACKED) {
                 const int w = __builtin_amdgcn_readfirstlane(
                     (int)reinterpret_cast<const uint16_t *>(rows)[(t - t0) * (nkmer / 4) + (cur >> 2)]);
                 const int how = (w >> (2 * (cur & 3))) & 3;        // 0 stay, 1 step, 2 skip
@@ -848,10 +863,10 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
     const int dma = (VBT_BLOCK % rowbytes == 0) && (rowbytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
     if (tblk > T) tblk = T;
     if (packed_tb)
-        hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, true>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+        hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, 1>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
                            len_out, lens);
     else
-        hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, false>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+        hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, 0>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
                            len_out, lens);
     return slk_launch_status();
 }
@@ -864,7 +879,21 @@ int slk_backtrace_packed4(const uint8_t *tb, const int32_t *best, int T, int B, 
     if (tblk < 1) return SLK_ERR_UNSUPPORTED;
     const int dma = (VBT_BLOCK % rowbytes == 0) && (rowbytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
     if (tblk > T) tblk = T;
-    hipLaunchKernelGGL((viterbi_backtrace_kernel<4, true>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+    hipLaunchKernelGGL((viterbi_backtrace_kernel<4, 1>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+                       len_out, lens);
+    return slk_launch_status();
+}
+
+// the one-byte-per-four-states traceback of softmax_viterbi.hip (FMT 2 above)
+int slk_backtrace_packed8(const uint8_t *tb, const int32_t *best, int T, int B, int nkmer, int32_t *path_out, int32_t *len_out,
+                          const int *lens, hipStream_t s)
+{
+    const int rowbytes = nkmer / 4;
+    int tblk = VBT_BLOCK / rowbytes;
+    if (tblk < 1 || (nkmer & 15)) return SLK_ERR_UNSUPPORTED;
+    const int dma = (VBT_BLOCK % rowbytes == 0) && (rowbytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
+    if (tblk > T) tblk = T;
+    hipLaunchKernelGGL((viterbi_backtrace_kernel<4, 2>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
                        len_out, lens);
     return slk_launch_status();
 }

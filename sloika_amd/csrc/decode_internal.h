@@ -7,3 +7,8 @@
 __attribute__((visibility("hidden"))) int slk_backtrace_packed4(const uint8_t *tb, const int32_t *best, int T, int B, int nkmer,
                                                                 int32_t *path_out, int32_t *len_out, const int *lens,
                                                                 hipStream_t s);
+
+// ... on the one-byte-per-four-states traceback of the fused kernel (softmax_viterbi.hip; decode.hip: viterbi_backtrace_kernel FMT 2)
+__attribute__((visibility("hidden"))) int slk_backtrace_packed8(const uint8_t *tb, const int32_t *best, int T, int B, int nkmer,
+                                                                int32_t *path_out, int32_t *len_out, const int *lens,
+                                                                hipStream_t s);

@@ -24,8 +24,8 @@
 //     the exponentials into log-posteriors.
 //   * the blank column (state 0) is a float32 dot product on the vector unit (one row per 16-lane DPP row).
 //   * the DP itself is viterbi_forward4_kernel's (decode.hip): ping-pong score vectors in LDS (bank-conflict-free padding),
-//     one barrier per step, quad-DPP skip arg-max, first-maximum tie rules of np.argmax, packed 16-bit traceback staged in
-//     LDS and written as 8-KB runs.  Given its log-posteriors the paths and float32 scores are bit-identical to the
+//     one barrier per step, quad-DPP skip arg-max, first-maximum tie rules of np.argmax, the traceback packed into ONE BYTE per
+//     four states (round 5: 256 bytes per step and chunk, half of round 4's) staged in LDS and written as 4-KB runs.  Given its log-posteriors the paths and float32 scores are bit-identical to the
 //     reference's; the log-posteriors themselves can be dumped (lp_dump) so that tests decode THEM with the oracle.
 #include "f16split.h"
 #include <type_traits>
@@ -336,8 +336,8 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     using Sched = SvSched<KS>;
     constexpr int NP = Sched::NP;
     constexpr int OFF_V = 0;                                    // [chunk NCH][parity 2][SV_VP] float
-    constexpr int OFF_TBS = OFF_V + NCH * 2 * SV_VP * 4;        // [parity 2][chunk NCH][step BS][256] uint16
-    constexpr int OFF_A = OFF_TBS + 2 * 16 * 1024;              // [parity 2][KS][hi, lo][64 lanes][16 B]
+    constexpr int OFF_TBS = OFF_V + NCH * 2 * SV_VP * 4;        // [parity 2][chunk NCH][step BS][256] uint8: the traceback of a block
+    constexpr int OFF_A = OFF_TBS + 2 * 8 * 1024;               // [parity 2][KS][hi, lo][64 lanes][16 B]
     constexpr int OFF_CINV = OFF_A + 2 * KS * 2048;             // [1024] float
     constexpr int OFF_CBIAS = OFF_CINV + 4096;                  // [1024] float
     constexpr int OFF_W0 = OFF_CBIAS + 4096;                    // [16 KS] float, then the blank bias
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
     // decode.py:36 and :56: log(min_prob + (1 - min_prob) p + 1e-10) as log(fma(e, factor (1 - min_prob), min_prob + 1e-10))
     const float mp_eta = __fadd_rn(min_prob, SV_ETA);
 
-    uint16_t *const tbs = reinterpret_cast<uint16_t *>(smem + OFF_TBS);
+    uint8_t *const tbs = smem + OFF_TBS;
     const float *const lp0b = reinterpret_cast<const float *>(smem + OFF_LP0) + hch * 16;
     const int o_step = j + 8 * (j >> 6), o_skip = cc * 72 + q;
     const int o_own = (j >> 6) * SV_AS + 4 * (j & 63) + 8 * ((j & 63) >> 4);     // states 4j .. 4j+3: block a = j >> 6
@@ -881,12 +881,12 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         if constexpr (PROD) { mfma_slot(kc, ic<8>{}, apar); aload_pos(ic<k * Sched::NPOS + 8 + SV_AHEAD>{}, apar); }
         if constexpr (DP) {
             asm volatile("v_cndmask_b32 %[l0], 0, 1, %[sB]\n\t"
-                         "v_cndmask_b32 %[l1], 0, 4, %[sC]\n\t"
+                         "v_cndmask_b32 %[l1], 0, 2, %[sC]\n\t"
                          "v_max_f32 %[o2], %[l2], %[o2]\n\t"
                          "v_max_f32 %[o3], %[l3], %[o3]\n\t"
-                         "v_cndmask_b32 %[l2], 0, 16, %[sD]\n\t"
-                         "v_cndmask_b32 %[l3], 0, 64, %[sE]\n\t"
-                         "v_cndmask_b32 %[t0], 1, 0, %[sA]"                                                     // by skip: the move bits one place up
+                         "v_cndmask_b32 %[l2], 0, 4, %[sD]\n\t"
+                         "v_cndmask_b32 %[l3], 0, 8, %[sE]\n\t"
+                         "v_cndmask_b32 %[t0], 0, 16, %[sA]"                                                    // bit 4: by step (else by skip)
                          : [l0] "=&v"(l0), [l1] "=&v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [o2] "+v"(o2), [o3] "+v"(o3), [t0] "=&v"(t0r)
                          : [sA] "s"(sA), [sB] "s"(sB), [sC] "s"(sC), [sD] "s"(sD), [sE] "s"(sE));
             if constexpr (k == 0) {                                 // t = 0: v = lpost[0][1:] (decode.py:57)
@@ -898,16 +898,17 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         // ---- D8 ----
         if constexpr (PROD) { mfma_slot(kc, ic<9>{}, apar); aload_pos(ic<k * Sched::NPOS + 9 + SV_AHEAD>{}, apar); }
         if constexpr (DP) {
+            // the traceback byte of this lane's four to-states (decode.hip: viterbi_backtrace_kernel FMT 2): bits 0-3 moves, bit 4 by step,
+            // bits 5-6 the step argument, bit 7 = bit cc of the skip argument (the quad's four lanes hold the same one: a bit each)
             asm volatile("v_or3_b32 %[l0], %[l0], %[l1], %[l2]\n\t"
-                         "v_lshlrev_b32 %[vk2], 10, %[vk2]\n\t"
-                         "v_or_b32 %[l0], %[l0], %[l3]\n\t"
-                         "v_lshl_or_b32 %[vk2], %[vs2], 8, %[vk2]\n\t"
-                         "v_lshlrev_b32 %[l0], %[t0], %[l0]\n\t"
-                         "v_or_b32 %[l0], %[l0], %[vk2]"
-                         : [l0] "+v"(l0), [vk2] "+v"(vk2)
-                         : [l1] "v"(l1), [l2] "v"(l2), [l3] "v"(l3), [vs2] "v"(vs2), [t0] "v"(t0r)
+                         "v_lshl_or_b32 %[l3], %[vs2], 5, %[l3]\n\t"
+                         "v_bfe_u32 %[vk2], %[vk2], %[cc], 1\n\t"
+                         "v_or3_b32 %[l0], %[l0], %[l3], %[t0]\n\t"
+                         "v_lshl_or_b32 %[l0], %[vk2], 7, %[l0]"
+                         : [l0] "+v"(l0), [vk2] "+v"(vk2), [l3] "+v"(l3)
+                         : [l1] "v"(l1), [l2] "v"(l2), [vs2] "v"(vs2), [t0] "v"(t0r), [cc] "v"(cc)
                          : "memory");
-            tbs[((par * NCH + hch) * BS + k) * 256 + j] = (uint16_t)__float_as_uint(l0);
+            tbs[((par * NCH + hch) * BS + k) * 256 + j] = (uint8_t)__float_as_uint(l0);
         }
         if constexpr (k == 14) SV_STAMP2(2);
         if constexpr (k == 15) SV_STAMP2(6);
@@ -924,18 +925,15 @@ __global__ void __launch_bounds__(SV_THREADS) softmax_viterbi_kernel(const float
         if constexpr (k == 14) SV_STAMP2(3);
         if constexpr (k == 15) SV_STAMP2(7);
     };
-    // rows of block blk (staged with parity par) -> HBM: per chunk BS rows of 512 bytes, contiguous on both sides
+    // rows of block blk (staged with parity par) -> HBM: per chunk BS rows of 256 bytes, contiguous on both sides (8 KB: 16 bytes per thread)
     auto flush_tb = [&](int blk, int par) __attribute__((always_inline)) {
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++) {
-            constexpr int PER_CHUNK = BS * 512;                     // bytes
-            const int off = pass * 8192 + tid * 16;
-            const int ch = off / PER_CHUNK, rest = off % PER_CHUNK, t = BS * blk + rest / 512;
-            const int tc = ch ? Tcs[1] : Tcs[0];
-            uint8_t *dst = tb + ((size_t)(b0 + ch) * Tpad + BS * blk) * (SV_NK / 2) + rest;
-            if (t >= 1 && t < tc)
-                *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(smem + OFF_TBS + par * 16384 + off);
-        }
+        constexpr int PER_CHUNK = BS * 256;                         // bytes
+        const int off = tid * 16;
+        const int ch = off / PER_CHUNK, rest = off % PER_CHUNK, t = BS * blk + rest / 256;
+        const int tc = ch ? Tcs[1] : Tcs[0];
+        uint8_t *dst = tb + ((size_t)(b0 + ch) * Tpad + BS * blk) * (SV_NK / 4) + rest;
+        if (t >= 1 && t < tc)
+            *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(smem + OFF_TBS + par * 8192 + off);
     };
 
     auto period = [&](auto dpc, auto prodc, int cb) __attribute__((always_inline)) {
@@ -1104,6 +1102,6 @@ extern "C" int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pac
 #ifdef SV_NO_BACKTRACE
     return rc;
 #else
-    return slk_backtrace_packed4(tb, best, T, B, SV_NK, path_out, len_out, lens, s);
+    return slk_backtrace_packed8(tb, best, T, B, SV_NK, path_out, len_out, lens, s);
 #endif
 }
