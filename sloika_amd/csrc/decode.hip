@@ -701,6 +701,30 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
         // one lane walks: keeping the state in scalar registers (readfirstlane) moves the index arithmetic of this
         // dependent chain to the scalar unit
         int cur = __builtin_amdgcn_readfirstlane(sh_cur), pos = __builtin_amdgcn_readfirstlane(sh_pos);
+        if constexpr (FMT == 2) {
+            // The walk is a chain of dependent scalar instructions around one LDS read per row (~340 cycles per row on paths that move
+            // at almost every row: latency, not the traffic the one-byte format halved), so the arithmetic per row is kept minimal:
+            // unsigned state (a shift per division), the bit positions of this state's byte recomputed only when the state changes,
+            // the four bits of the skip argument gathered by one multiplication ((q & 0x80808080) * 0x204081 puts bits 7, 15, 23, 31
+            // at bits 28 .. 31: the partial products are distinct powers of two, nothing carries into them).
+            unsigned ucur = (unsigned)cur;
+            const int sh1 = __builtin_ctz((unsigned)nrem1), sh2 = __builtin_ctz((unsigned)nrem2);      // nkmer = 4^k: powers of two
+            unsigned bmove = ((ucur << 1) & 24u) + (ucur & 3u);      // bit of "to-state (cur & 3) moves" in the quad's word
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(rows) + (t1 - 1 - t0) * (nkmer / 16);
+            for (int t = t1 - 1; t >= t0; t--, row -= nkmer / 16) {
+                const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane((int)row[ucur >> 4]);
+                if ((q >> bmove) & 1u) {
+                    const unsigned b8 = bmove & 24u;
+                    if ((q >> (b8 + 4)) & 1u) ucur = (((q >> (b8 + 5)) & 3u) << sh1) + (ucur >> 2);      // by step
+                    else ucur = ((((q & 0x80808080u) * 0x204081u) >> 28) << sh2) + (ucur >> 4);         // by skip
+                    bmove = ((ucur << 1) & 24u) + (ucur & 3u);
+                    path[--pos] = (int)ucur;                   // decode.py:88-90
+                }
+            }
+            sh_cur = (int)ucur;
+            sh_pos = pos;
+            return;
+        }
         for (int t = t1 - 1; t >= t0; t--) {
             if constexpr (FMT == 2) {
                 // the quad's four bytes (states 16 (cur >> 4) .. + 15): mine is byte (cur >> 2) & 3, bit 7 of byte i is bit i of the skip argument
