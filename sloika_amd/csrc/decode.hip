@@ -818,6 +818,124 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
     if (tid == 0) len_out[b] = len;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Backtrace of the one-byte traceback (FMT 2) of 4^5 k-mers with the rows in REGISTERS: a row is 256 bytes = one dword per lane,
+// so a wave keeps sixteen rows in sixteen registers (and the next sixteen on their way from memory) and reads "the word of state
+// cur" with v_readlane instead of a dependent LDS read.  One wave per chunk, four per workgroup (= one per SIMD: as workgroups of
+// one wave, four chunks landed on one SIMD and took 90 us instead of 57), no LDS, no barrier, no stager waves.
+// The walk is a serial chain and what it costs is the NUMBER of instructions on it (a wave issues a scalar instruction per ~7
+// cycles here, a taken branch costs ~30): the kernel above spends ~31 instructions and three taken branches per moving row.  Here
+// a row is one asm statement of twenty instructions without a branch; the state is kept as the five values the next row needs
+// (cur, cur >> 2, the lane cur >> 4, the byte's shift, cur & 3).  The path is collected in a register (v_writelane at lane
+// pos & 63) and stored at most once per sixteen rows, right-aligned as above, then shifted left and padded with -1 by the same
+// wave (program order: the loads of the shift follow the stores they read).  1024 chunks x 800 rows: 102 -> ~50 us.
+// ------------------------------------------------------------------------------------------------------
+#define VBR_ROWS 16
+__global__ void __launch_bounds__(256) viterbi_backtrace_rows_kernel(const uint8_t *__restrict__ tb, const int32_t *__restrict__ best,
+                                                                    int T, int B, int nkmer, int32_t *path_out,
+                                                                    int32_t *__restrict__ len_out, const int *__restrict__ lens)
+{
+    // four chunks per workgroup, one per wave: the four waves of a workgroup go to the four SIMDs of a CU
+    const int b = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int Tpad = T;                                        // row strides of tb / path_out; T = this chunk's own length
+    if (lens) T = min(max(lens[b], 1), Tpad);
+    T = __builtin_amdgcn_readfirstlane(T);
+    const int rowdw = nkmer / 16;                              // dwords per row: 64
+    const uint32_t *tbb = reinterpret_cast<const uint32_t *>(tb + (size_t)b * Tpad * (nkmer / 4));
+    int32_t *path = path_out + (size_t)b * Tpad;
+    unsigned ucur = (unsigned)__builtin_amdgcn_readfirstlane(best[b]);
+    unsigned u2 = ucur >> 2, idx = ucur >> 4, b8 = (ucur << 1) & 24u, n = ucur & 3u;
+    int pos = T - 1;                                           // path[pos .. T) is known
+    int done = T;                                              // path[done .. T) is in memory
+    int buf = (int)ucur;                                       // lane (p & 63): path[p], pos <= p < done (at most 64 of them)
+    auto flush = [&]() {
+        const int p = pos + ((lane - pos) & 63);
+        if (p < done) path[p] = buf;
+        done = pos;
+    };
+    // every lane loads, every row: rows below 1 and lanes past the row are clamped to valid addresses (conditional loads would
+    // cost the compiler its count of the loads in flight: it then waits for the block it has just asked for)
+    const int lcl = lane < rowdw ? lane : rowdw - 1;
+    auto load = [&](uint32_t (&r)[VBR_ROWS], int ttop) {
+#pragma unroll
+        for (int k = 0; k < VBR_ROWS; k++) r[k] = tbb[(size_t)max(ttop - k, 1) * rowdw + lcl];
+    };
+    auto row = [&](uint32_t rk) {                              // decode.py:84-91, one row
+        unsigned q, t, g, a;
+        // No branch: both targets are computed and one selected (a staying row writes path[pos] = cur once more).  Measured against
+        // a version that branches around the 16 instructions of a move (four instructions and a taken branch per staying row):
+        // 57 / 56 us (random weights / blank-dominated, 740 / 349 moves in 800 rows) against 62 / 51 -- a taken branch costs what
+        // ten scalar instructions do.  1024 k-mers: the step argument (bits 5-6) goes to bits 8-9, the skip argument (bit 7 of the
+        // four bytes) to bits 6-9 -- the high half of a product with 2^31 + 2^24 + 2^17 + 2^10 (sixteen distinct partial products).
+        asm volatile("v_readlane_b32 %[q], %[r], %[idx]\n\t"
+                     "s_lshr_b32 %[t], %[q], %[b8]\n\t"                 // the byte of cur's group of four at bit 0
+                     "s_and_b32 %[g], %[q], 0x80808080\n\t"
+                     "s_and_b32 %[a], %[t], 0x60\n\t"
+                     "s_mul_hi_u32 %[g], %[g], 0x81020400\n\t"
+                     "s_lshl3_add_u32 %[a], %[a], %[u2]\n\t"            // by step: (arg << 8) + (cur >> 2)
+                     "s_and_b32 %[g], %[g], 0x3c0\n\t"
+                     "s_add_u32 %[g], %[g], %[idx]\n\t"                 // by skip: (arg << 6) + (cur >> 4)
+                     "s_bitcmp1_b32 %[t], 4\n\t"
+                     "s_cselect_b32 %[a], %[a], %[g]\n\t"
+                     "s_bitcmp1_b32 %[t], %[n]\n\t"
+                     "s_cselect_b32 %[cur], %[a], %[cur]\n\t"
+                     "s_subb_u32 %[pos], %[pos], 0\n\t"                 // pos -= moves
+                     "s_lshr_b32 %[idx], %[cur], 4\n\t"
+                     "s_mov_b32 m0, %[pos]\n\t"
+                     "s_lshl_b32 %[b8], %[cur], 1\n\t"
+                     "s_lshr_b32 %[u2], %[cur], 2\n\t"
+                     "v_writelane_b32 %[buf], %[cur], m0\n\t"
+                     "s_and_b32 %[b8], %[b8], 24\n\t"
+                     "s_and_b32 %[n], %[cur], 3"
+                     : [q] "=&s"(q), [t] "=&s"(t), [g] "=&s"(g), [a] "=&s"(a), [cur] "+s"(ucur), [u2] "+s"(u2), [idx] "+s"(idx),
+                       [b8] "+s"(b8), [n] "+s"(n), [pos] "+s"(pos), [buf] "+v"(buf)
+                     : [r] "v"(rk)
+                     : "scc");        // and m0, which hipcc will not take as a clobber (reserved); nothing else in this kernel uses it
+                                      // (no LDS-DMA, no s_movrel, no message): tests/test_isa_hygiene.py::test_backtrace_rows_kernel_owns_m0
+    };
+    uint32_t ra[VBR_ROWS], rb[VBR_ROWS];
+    int ttop = T - 1;
+    load(ra, ttop);
+    load(rb, ttop - VBR_ROWS);
+    while (ttop >= 2 * VBR_ROWS) {                             // rows ttop .. ttop - 31 are all >= 1
+#pragma unroll
+        for (int k = 0; k < VBR_ROWS; k++) row(ra[k]);
+        load(ra, ttop - 2 * VBR_ROWS);
+        if (done - pos > 64 - VBR_ROWS) flush();
+#pragma unroll
+        for (int k = 0; k < VBR_ROWS; k++) row(rb[k]);
+        load(rb, ttop - 3 * VBR_ROWS);
+        if (done - pos > 64 - VBR_ROWS) flush();
+        ttop -= 2 * VBR_ROWS;
+    }
+#pragma unroll
+    for (int k = 0; k < VBR_ROWS; k++)
+        if (ttop - k >= 1) row(ra[k]);
+    if (done - pos > 64 - VBR_ROWS) flush();
+#pragma unroll
+    for (int k = 0; k < VBR_ROWS; k++)
+        if (ttop - VBR_ROWS - k >= 1) row(rb[k]);
+    flush();
+    // shift left by pos, pad with -1: eight batches of 64 entries are read, then written (dst <= src, ascending: a group reads
+    // nothing an earlier one wrote; one memory round trip per group instead of one per batch)
+    const int len = T - pos;
+    for (int base = 0; base < Tpad; base += 8 * 64) {
+        int32_t val[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = base + 64 * k + lane;
+            val[k] = path[pos + min(i, len - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = base + 64 * k + lane;
+            if (i < Tpad) path[i] = i < len ? val[k] : -1;
+        }
+    }
+    if (lane == 0) len_out[b] = len;
+}
+
 static bool vit_dims(int nbase, int klen, int *nkmer_out)
 {
     if (klen < 3 || nbase < 2) return false;
@@ -915,6 +1033,10 @@ int slk_backtrace_packed8(const uint8_t *tb, const int32_t *best, int T, int B, 
     const int rowbytes = nkmer / 4;
     int tblk = VBT_BLOCK / rowbytes;
     if (tblk < 1 || (nkmer & 15)) return SLK_ERR_UNSUPPORTED;
+    if (nkmer == 1024 && (reinterpret_cast<uintptr_t>(tb) & 3) == 0) {      // a row is one register per lane (the constants of its asm are 4^5's)
+        hipLaunchKernelGGL(viterbi_backtrace_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tb, best, T, B, nkmer, path_out, len_out, lens);
+        return slk_launch_status();
+    }
     const int dma = (VBT_BLOCK % rowbytes == 0) && (rowbytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
     if (tblk > T) tblk = T;
     hipLaunchKernelGGL((viterbi_backtrace_kernel<4, 2>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,

@@ -166,7 +166,8 @@ def viterbi_fused_batch(x, pack, klen, skip_pen=0.0, nbase=4, min_prob=1e-5, wor
     if lp_dump is not None and (lp_dump.dtype != torch.float32 or lp_dump.numel() != T * B * S or not lp_dump.is_contiguous()):
         raise ValueError("lp_dump must be a contiguous float32 device tensor [T, B, nstate]")
     rows = float(T) * B
-    with profiler.region("softmax_viterbi", 2.0 * rows * K * S, rows * (4.0 * K + 1.0 * (nbase ** klen)),
+    # bytes: the rows of x in, one traceback byte per four k-mers out (csrc/softmax_viterbi.hip, D8) and at most the same again for the walk
+    with profiler.region("softmax_viterbi", 2.0 * rows * K * S, rows * (4.0 * K + 0.5 * (nbase ** klen)),
                          f16x3_flops=2.0 * rows * K * S):
         rc = L.slk_softmax_viterbi_f32(x.data_ptr(), x.stride(1), pack.data_ptr(), K, T, B, nbase, klen, float(skip_pen),
                                        float(min_prob), lengths.data_ptr() if lengths is not None else None, int(plan), ws.data_ptr(),

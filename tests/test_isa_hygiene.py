@@ -122,3 +122,21 @@ def test_hipcc_is_the_validated_one():
     and the GPU suite on the new compiler, then update build.VALIDATED_HIPCC."""
     from sloika_amd import build
     assert build.hipcc_is_validated(), "hipcc is %r, validated on %r" % (build.hipcc_version(), build.VALIDATED_HIPCC)
+
+
+def test_backtrace_rows_kernel_owns_m0():
+    """viterbi_backtrace_rows_kernel (csrc/decode.hip) sets m0 inside its asm rows (the lane v_writelane writes) without naming it as
+    a clobber -- hipcc refuses reserved registers there.  That is sound as long as the compiler itself has no use for m0 in that
+    kernel: every mention of m0 in its ISA must be one of the two instructions of the asm."""
+    out = _isa("decode.hip")
+    inside, seen = False, 0
+    for ln in open(out):
+        if ln.startswith("_Z29viterbi_backtrace_rows_kernel"):
+            inside = True
+        elif inside and "s_endpgm" in ln:
+            break
+        elif inside and "m0" in ln.split(";")[0]:
+            ins = ln.split()[0]
+            assert ins in ("s_mov_b32", "v_writelane_b32"), ln
+            seen += 1
+    assert inside and seen >= 2

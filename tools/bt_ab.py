@@ -5,9 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from sloika_amd import _lib
 _lib.require_gpu()
-libs = [C.CDLL(sys.argv[1]), C.CDLL(_lib.LIB_PATH)]
+libs = [C.CDLL(sys.argv[1]), C.CDLL(os.environ.get("BT_LIB", _lib.LIB_PATH))]
 vp = C.c_void_p
-T, B, K, S = 800, 1024, 96, 1025
+T, B, K, S = int(os.environ.get("BT_T", "800")), int(os.environ.get("BT_B", "1024")), 96, 1025
 rs = np.random.RandomState(3)
 x = torch.tanh(torch.randn((T, B, K), device="cuda"))
 for name, blank_bias in (("random weights (bench)", 0.0), ("blank-dominated (trained-like)", 6.0)):
