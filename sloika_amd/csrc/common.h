@@ -55,10 +55,14 @@ __device__ __forceinline__ float slk_tanh(float x)
 // 1.0 (6e-8), i.e. no relative accuracy left for tiny |x| -- and training multiplies by y + 1 and feeds small gradients through
 // it.  Above -2^-6 the series x + x^2 (1/2 + x/6) is exact to float32 (the next term is < 2e-7 of x) and below it the
 // hardware form is within 4e-6 relative; expm1f itself costs ~25 instructions per value.
+// Both forms are evaluated and one selected (the same values as branching between them: v_exp_f32 of x log2 e is what __expf
+// compiles to): with branches a wave pays three exec-mask updates on the scalar unit per value, ~8 cycles each.
 __device__ __forceinline__ float slk_elu(float x)
 {
-    if (x > 0.0f) return x;
-    return x > -0.015625f ? fmaf(x * x, fmaf(x, 0.16666667f, 0.5f), x) : __expf(x) - 1.0f;
+    const float e = __builtin_amdgcn_exp2f(x * 1.4426950216293335f) - 1.0f;       // 0x3fb8aa3b
+    const float ser = fmaf(x * x, fmaf(x, 0.16666667f, 0.5f), x);
+    const float neg = x > -0.015625f ? ser : e;
+    return x > 0.0f ? x : neg;
 }
 
 template <int ACT>

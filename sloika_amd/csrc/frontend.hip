@@ -561,7 +561,13 @@ __global__ void __launch_bounds__(256) conv1d_cin1_kernel(const float *__restric
 // features of one position, 64 / (Cout/4) positions are computed side by side, and a row segment leaves as one 16-byte
 // store (the one-feature-per-lane kernel above issues a dword store per lane and row: store-issue bound at ~1 TB/s).
 // The 128 samples a run needs are parked in LDS (one 512-byte slot per wave); every tap is a broadcast ds_read.
-template <int WMAX, int ACT>
+// WL > 0: the window length at compile time (WMAX = WL): no branch per tap (the run-time form tests `k < winlen` sixteen times per
+// position group).  The kernel is bound by the instructions it issues per position, not by its 331 MB: with the window length
+// fixed, elu without exec-mask updates (common.h) and the samples of the next run requested a run ahead, 1024 chunks x 4000 samples
+// -> 96 features take 82 us instead of 118 (64 features: 43 instead of 76, 4.9 TB/s).  Six features per lane (Cout = 96 then
+// fills all 64 lanes: four positions of sixteen lanes instead of two of 24) measured 84: its second, 8-byte store costs what the
+// idle lanes do.
+template <int WMAX, int ACT, int WL>
 __global__ void __launch_bounds__(256) conv1d_cin1_vec4_kernel(const float *__restrict__ x, long xs_t, long xs_b,
                                                                const float *__restrict__ W, const float *__restrict__ bias,
                                                                float *__restrict__ y, int T, int B, int Cout, int winlen,
@@ -570,54 +576,65 @@ __global__ void __launch_bounds__(256) conv1d_cin1_vec4_kernel(const float *__re
     __shared__ float xs[4][128];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int FQ = Cout >> 2, PP = 64 / FQ;                        // feature quads, positions side by side
+    constexpr int FPL = 4;                                         // features per lane
+    const int FQ = Cout / FPL, PP = 64 / FQ;                       // feature groups, positions side by side
     const int fq = lane % FQ, pp = lane / FQ;
     const bool lane_ok = pp < PP;
-    float w[4][WMAX];
+    auto feat = [&](int i) { return 4 * fq + i; };
+    float w[FPL][WMAX];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < FPL; i++) {
 #pragma unroll
-        for (int k = 0; k < WMAX; k++) w[i][k] = k < winlen ? W[(size_t)(4 * fq + i) * winlen + k] : 0.0f;
+        for (int k = 0; k < WMAX; k++) w[i][k] = (WL > 0 || k < winlen) ? W[(size_t)feat(i) * winlen + k] : 0.0f;
     }
-    float bv[4];
+    float bv[FPL];
 #pragma unroll
-    for (int i = 0; i < 4; i++) bv[i] = bias ? bias[4 * fq + i] : 0.0f;
+    for (int i = 0; i < FPL; i++) bv[i] = bias ? bias[feat(i)] : 0.0f;
     const unsigned runs_per_chunk = (unsigned)((Tout + npos_run - 1) / npos_run);
     const unsigned nrun = runs_per_chunk * (unsigned)B, nwave = gridDim.x * 4u;
     float *xw = xs[wave];
-    for (unsigned run = blockIdx.x * 4u + wave; run < nrun; run += nwave) {
-        // consecutive runs walk the batch first so that neighbouring waves write neighbouring rows of y
+    const size_t rowpitch = (size_t)B * Cout;                      // floats between two output steps of one chunk
+    // the 128 samples of a run are requested one run ahead (a run is ~2 us of arithmetic, about the latency of the load)
+    auto fetch = [&](unsigned run, float &v0, float &v1) {
         const int b = (int)(run % (unsigned)B), to0 = (int)(run / (unsigned)B) * npos_run;
         const int t0 = to0 * stride - pad_l;                       // input sample of tap 0 of the first position
         const float *xb = x + (size_t)b * xs_b;
         const int ta = t0 + lane, tb2 = t0 + 64 + lane;
-        const float v0 = (ta >= 0 && ta < T) ? xb[(size_t)ta * xs_t] : 0.0f;
-        const float v1 = (tb2 >= 0 && tb2 < T) ? xb[(size_t)tb2 * xs_t] : 0.0f;
+        v0 = (ta >= 0 && ta < T) ? xb[(size_t)ta * xs_t] : 0.0f;
+        v1 = (tb2 >= 0 && tb2 < T) ? xb[(size_t)tb2 * xs_t] : 0.0f;
+    };
+    float v0 = 0.0f, v1 = 0.0f;
+    if (blockIdx.x * 4u + wave < nrun) fetch(blockIdx.x * 4u + wave, v0, v1);
+    for (unsigned run = blockIdx.x * 4u + wave; run < nrun; run += nwave) {
+        // consecutive runs walk the batch first so that neighbouring waves write neighbouring rows of y
+        const int b = (int)(run % (unsigned)B), to0 = (int)(run / (unsigned)B) * npos_run;
         xw[lane] = v0;                                             // same wave writes and reads: in-order LDS, no barrier
         xw[64 + lane] = v1;
+        if (run + nwave < nrun) fetch(run + nwave, v0, v1);
         const int npos = min(npos_run, Tout - to0);
-        for (int j0 = 0; j0 < npos; j0 += PP) {
+        float *yp = y + ((size_t)(to0 + pp) * B + b) * Cout;                   // the row of this lane's first position
+        for (int j0 = 0; j0 < npos; j0 += PP, yp += (size_t)PP * rowpitch) {
             const int j = j0 + pp;
             const float *xp = xw + (lane_ok && j < npos ? j : 0) * stride;
-            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float s[FPL];
+#pragma unroll
+            for (int i = 0; i < FPL; i++) s[i] = 0.0f;
 #pragma unroll
             for (int k = 0; k < WMAX; k++) {
-                if (k < winlen) {
+                if (WL > 0 || k < winlen) {
                     const float xv = xp[k];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) s[i] = fmaf(xv, w[i][k], s[i]);
+                    for (int i = 0; i < FPL; i++) s[i] = fmaf(xv, w[i][k], s[i]);
                 }
             }
             // taps first, bias last, as conv.py:107-110 (same order as the one-feature-per-lane kernel)
             if (lane_ok && j < npos) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) s[i] += bv[i];
-                float4 o;
-                o.x = ACT >= 0 ? slk_act_t<ACT>(s[0]) : slk_act(act, s[0]);
-                o.y = ACT >= 0 ? slk_act_t<ACT>(s[1]) : slk_act(act, s[1]);
-                o.z = ACT >= 0 ? slk_act_t<ACT>(s[2]) : slk_act(act, s[2]);
-                o.w = ACT >= 0 ? slk_act_t<ACT>(s[3]) : slk_act(act, s[3]);
-                *reinterpret_cast<float4 *>(&y[((size_t)(to0 + j) * B + b) * Cout + 4 * fq]) = o;
+                for (int i = 0; i < FPL; i++) {
+                    s[i] += bv[i];
+                    s[i] = ACT >= 0 ? slk_act_t<ACT>(s[i]) : slk_act(act, s[i]);
+                }
+                *reinterpret_cast<float4 *>(yp + 4 * fq) = make_float4(s[0], s[1], s[2], s[3]);
             }
         }
     }
@@ -648,9 +665,14 @@ extern "C" int slk_conv1d_f32(const float *x, long x_t_stride, long x_b_stride, 
         if (Cout % 4 == 0 && Cout <= 256 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
             const dim3 grid((unsigned)blocks), block(256);
             hipStream_t st = slk_stream(stream);
-#define CONV_VEC4(A)                                                                                                    \
-    hipLaunchKernelGGL((conv1d_cin1_vec4_kernel<16, A>), grid, block, 0, st, x, x_t_stride, x_b_stride, W, bias, y, T, B, \
+#define CONV_VEC4_(A, WM, WL)                                                                                             \
+    hipLaunchKernelGGL((conv1d_cin1_vec4_kernel<WM, A, WL>), grid, block, 0, st, x, x_t_stride, x_b_stride, W, bias, y, T, B, \
                        Cout, winlen, stride, pad_l, Tout, act, npos_run)
+#define CONV_VEC4(A)                                                                                                    \
+    do {                                                                                                                \
+        if (winlen == 11) CONV_VEC4_(A, 11, 11); /* the shipped raw models */                                           \
+        else CONV_VEC4_(A, 16, 0);                                                                                      \
+    } while (0)
             switch (act) {
             case SLK_ACT_TANH: CONV_VEC4(SLK_ACT_TANH); break;
             case SLK_ACT_ELU: CONV_VEC4(SLK_ACT_ELU); break;
@@ -658,6 +680,7 @@ extern "C" int slk_conv1d_f32(const float *x, long x_t_stride, long x_b_stride, 
             case SLK_ACT_LINEAR: CONV_VEC4(SLK_ACT_LINEAR); break;
             default: CONV_VEC4(-1); break;
             }
+#undef CONV_VEC4_
 #undef CONV_VEC4
             return slk_launch_status();
         }
