@@ -90,6 +90,15 @@ def test_fused_decode_against_oracle_on_its_log_posteriors(oracle, T, B, K, skip
     _check(oracle, np.random.RandomState(1000 * T + B), T, B, K, skip, ragged)
 
 
+@pytest.mark.parametrize("T", [15, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 66, 95, 97, 129, 161])
+def test_fused_decode_backtrace_block_edges(oracle, T):
+    """viterbi_backtrace_rows_kernel (csrc/decode.hip) walks sixteen rows per register block, two blocks per loop iteration, and
+    stores the path in windows of 64 entries: chunk lengths on either side of every one of those boundaries, full and ragged,
+    six chunks (one and a half workgroups of four waves)."""
+    _check(oracle, np.random.RandomState(7000 + T), T, 6, 64, 0.0, False)
+    _check(oracle, np.random.RandomState(8000 + T), T, 6, 64, 2.0, True)
+
+
 def test_fused_decode_operand_ranges(oracle):
     """Row scaling of x and column scaling of W: large weights (the trained pickle reaches 6), tiny and huge activations."""
     # logits of magnitude ~50: one float32 ulp of the logit is 4e-6, and so is the posterior's absolute error
