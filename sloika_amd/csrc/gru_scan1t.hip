@@ -5,8 +5,11 @@
 // the other, with one tile per wave two waves share a SIMD and fill each other's waits (csrc/gru_bwd16.hip measured the same
 // trade: 3350 against 2330 cycles per step).  Measured on whole layers (projection + scan, B = 1024, T' = 800): n = 112 1.11-1.19 ms
 // against 1.21-1.28 for gru_scan16.hip, n = 128 1.19-1.22 against 1.23-1.26; `pretrained` architecture 709 -> 740 M samples/s.
-// n = 144 would be nine waves of 168 registers with 120 of them weights: with the candidate's weights fetched from LDS every step it
-// spilled and ran 2.09 ms against 1.93 -- that size stays with gru_scan16.hip's ninth tile.
+// n = 144 is nine waves, three of them on one SIMD: 168 registers each.  As five K blocks of 32 the weights alone are 120 of them
+// (round 3 fetched the candidate's from LDS every step instead: it spilled and ran 2.09 ms against 1.93 for gru_scan16.hip's ninth
+// tile).  Round 5: 144 = four K blocks of 32 and ONE OF 16 -- v_mfma_f32_16x16x16_f16 for neurons 128 .. 143, whose halves the ninth
+// wave writes side by side in the image so that one 8-byte LDS read is the B operand -- 108 registers of weights, no scratch:
+// a 144-wide layer's scan 1.36 -> ~0.7 ms.
 //
 // A wave's recurrent weights are 3 gates x ceil(n / 32) K blocks x (hi, lo) x 4 registers = 96 of the 256 registers a wave has when
 // two share a SIMD.
@@ -24,14 +27,22 @@ __device__ __forceinline__ void g1_mma(f32x4 &acc, const half8 &wa, const half8 
     if constexpr (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(wa), "v"(bm));
     else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wa), "v"(bm));
 }
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+// the K block of 16 (n = 144): lane (g, .) holds k = 4 g + i, i = 0 .. 3, of A's row and of B's column
+__device__ __forceinline__ void g1_mma16(f32x4 &acc, const half4 &wa, const half4 &bm)
+{
+    asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(wa), "v"(bm));
+}
 
 template <int N>
 __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__restrict__ vI, long ldv, const float *__restrict__ sW,
                                                               const float *__restrict__ sW2, float *__restrict__ h_out, long ldh, int T,
                                                               int B, int n, int reverse, const int *__restrict__ lens)
 {
-    static_assert(N % 16 == 0 && N <= 128, "one wave per 16 neurons, at most eight waves (two per SIMD)");
-    constexpr int NW = N / 16, KBS = (N + 31) / 32, NTH = 64 * NW, KP = 32 * KBS;
+    static_assert(N % 16 == 0 && N <= 144, "one wave per 16 neurons, at most nine waves");
+    // KBS K blocks of 32 as MFMA operands; HALF: one more of 16 (the image keeps a whole block for it)
+    constexpr bool HALF = N == 144;
+    constexpr int NW = N / 16, KBS = HALF ? N / 32 : (N + 31) / 32, KBI = KBS + (HALF ? 1 : 0), NTH = 64 * NW, KP = 32 * KBI;
 
     // state images: [hi image | lo image], each KP x 4 chunks halves; element (k block kb, k group g, chunk c, r) = dword
     // ((kb*4+g)*4+c)*4 + r holds neuron 32kb+4g+r (low half) and 32kb+16+4g+r (high half) of chunk c
@@ -47,13 +58,23 @@ __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__res
     const int c = lane & 3, q = (lane >> 2) & 3, g = lane >> 4;
     // A operands: row = neuron 16w + (lane & 15), element (kb, e) = W[row][k] with k = 32kb + 16(e&1) + 4g + (e>>1); rows scaled to [1, 2)
     half8 wz_hi[KBS], wz_lo[KBS], wr_hi[KBS], wr_lo[KBS], wc_hi[KBS], wc_lo[KBS];
+    half4 wzh_hi = {}, wzh_lo = {}, wrh_hi = {}, wrh_lo = {}, wch_hi = {}, wch_lo = {};      // HALF: k = 32 KBS + 4 g + i
     float inv_z, inv_r, inv_c;
     {
         const int unit = 16 * w + (lane & 15);
         const bool uk = unit < n;
-        auto prep = [&](const float *row, half8 *wh, half8 *wl, float &invq) {
+        auto prep = [&](const float *row, half8 *wh, half8 *wl, half4 &whh, half4 &wlh, float &invq) {
             float v[KBS][8];
+            float vh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             float m = 0.0f;
+            if constexpr (HALF) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int k = 32 * KBS + 4 * g + e;
+                    vh[e] = (uk && k < n) ? row[k] : 0.0f;
+                    m = fmaxf(m, fabsf(vh[e]));
+                }
+            }
 #pragma unroll
             for (int kb = 0; kb < KBS; kb++)
 #pragma unroll
@@ -78,19 +99,32 @@ __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__res
                 wh[kb] = hi;
                 wl[kb] = lo;
             }
+            if constexpr (HALF) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float a = vh[e] * sc;
+                    const _Float16 hh = (_Float16)a;
+                    whh[e] = hh;
+                    wlh[e] = (_Float16)(a - (float)hh);
+                }
+            }
         };
         const int ur = uk ? unit : 0;
-        prep(sW + (size_t)ur * n, wz_hi, wz_lo, inv_z);
-        prep(sW + (size_t)(n + ur) * n, wr_hi, wr_lo, inv_r);
-        prep(sW2 + (size_t)ur * n, wc_hi, wc_lo, inv_c);
+        prep(sW + (size_t)ur * n, wz_hi, wz_lo, wzh_hi, wzh_lo, inv_z);
+        prep(sW + (size_t)(n + ur) * n, wr_hi, wr_lo, wrh_hi, wrh_lo, inv_r);
+        prep(sW2 + (size_t)ur * n, wc_hi, wc_lo, wch_hi, wch_lo, inv_c);
     }
     int moff[KBS];
 #pragma unroll
     for (int kb = 0; kb < KBS; kb++) moff[kb] = (q >> 1) * LO + ((kb * 4 + g) * 4 + c) * 4;      // my column group's image, in dwords
+    const int moffh = (q >> 1) * LO + ((KBS * 4 + g) * 4 + c) * 4;                                // HALF: the block of 16
+    auto ldH4 = [](const unsigned *img, int off) { return *reinterpret_cast<const half4 *>(img + off); };
     // my neuron u = 16w + 4g + q -> K block w >> 1, half w & 1, k group g, r = q
     const int u0 = 16 * w + 4 * g + q;
     const bool uok = u0 < n;
-    const int wpos = ((((w >> 1) * 4 + g) * 4 + c) * 4 + q) * 2 + (w & 1);                          // in halves
+    // in halves; the wave of the block of 16 (HALF, w = 2 KBS) writes its four r side by side: one 8-byte read is the K = 16 operand
+    const int wpos = (HALF && w == 2 * KBS) ? ((((w >> 1) * 4 + g) * 4 + c) * 4) * 2 + q
+                                            : ((((w >> 1) * 4 + g) * 4 + c) * 4 + q) * 2 + (w & 1);
     // my chunk's rows (ragged batch: chunk bc is Tc <= T steps long; a reversed scan starts at ITS last step)
     const int bc = b0 + c;
     const bool live = bc < B;
@@ -127,6 +161,8 @@ __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__res
         half8 bh[KBS];
 #pragma unroll
         for (int kb = 0; kb < KBS; kb++) bh[kb] = ldH(h_img, moff[kb]);
+        half4 bhh = {};
+        if constexpr (HALF) bhh = ldH4(h_img, moffh);
         load_vi(vs[(ph + 3) & 3]);
         f32x4 accR, accZ;
         static_for<0, KBS>([&](auto KC) {
@@ -136,6 +172,15 @@ __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__res
             g1_mma<false>(accR, wr_hi[kb], bh[kb]);
             g1_mma<false>(accZ, wz_hi[kb], bh[kb]);
         });
+        if constexpr (HALF) {
+            // an MFMA of another shape reading an accumulator is a READER like any vector instruction: seven wait states behind the
+            // 16x16x32 that wrote it (tools/mfma_result_hazard_scan.py; one MFMA in between is four)
+            asm volatile("s_nop 2" : "+v"(accR), "+v"(accZ));
+            g1_mma16(accR, wrh_lo, bhh);
+            g1_mma16(accZ, wzh_lo, bhh);
+            g1_mma16(accR, wrh_hi, bhh);
+            g1_mma16(accZ, wzh_hi, bhh);
+        }
         asm volatile("s_waitcnt vmcnt(9)" ::: "memory");   // this step's vI: the loads of the three younger steps may be outstanding
         asm volatile("" : "+v"(cur.z), "+v"(cur.r), "+v"(cur.c));
         mfma_drain2(accR, accZ);                         // pick_mix reads the accumulators from asm
@@ -156,13 +201,25 @@ __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__res
         half8 bm[KBS];
 #pragma unroll
         for (int kb = 0; kb < KBS; kb++) bm[kb] = ldH(rh_img, moff[kb]);
+        half4 bmh = {};
+        if constexpr (HALF) bmh = ldH4(rh_img, moffh);
         f32x4 accC;
         static_for<0, KBS>([&](auto KC) {
             constexpr int kb = decltype(KC)::value;
             g1_mma<kb == 0>(accC, wc_lo[kb], bm[kb]);
             g1_mma<false>(accC, wc_hi[kb], bm[kb]);
         });
+        f32x4 accCh;
+        if constexpr (HALF) {
+            // its own accumulator (the candidate has no second gate to put between the two shapes), added behind the drain
+            asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, 0" : "=&v"(accCh) : "v"(wch_lo), "v"(bmh));
+            g1_mma16(accCh, wch_hi, bmh);
+        }
         mfma_drain(accC);
+        if constexpr (HALF) {
+            asm volatile("" : "+v"(accCh));
+            accC += accCh;
+        }
         // layers.py:1017-1021
         const float hb = tanh5(fmaf(pick_mix(accC), inv_c, cur.c));
         const float hn = uok ? fmaf(1.0f - zg, hb, zg * hold) : 0.0f;
@@ -204,7 +261,7 @@ static size_t scan1t_exclusive_lds()
 extern "C" int slk_gru_scan1t_launch(const float *vI, long ldv, const float *sW, const float *sW2, float *y, long ldy, int T, int B, int n,
                                      int reverse, const int32_t *lens, hipStream_t s)
 {
-    if (n % 16 || n > 128) return SLK_ERR_UNSUPPORTED;
+    if (n % 16 || n > 144) return SLK_ERR_UNSUPPORTED;
 #define G1_LAUNCH(NN)                                                                                                        \
     {                                                                                                                        \
         const size_t dyn = SLK_PER_DEVICE(size_t, scan1t_exclusive_lds<NN>());                                               \
@@ -213,6 +270,8 @@ extern "C" int slk_gru_scan1t_launch(const float *vI, long ldv, const float *sW,
         return slk_launch_status();                                                                                          \
     }
     if (n <= 112) G1_LAUNCH(112)
-    G1_LAUNCH(128)
+    if (n <= 128) G1_LAUNCH(128)
+    if (n != 144) return SLK_ERR_UNSUPPORTED;              // (the block of 16 of <144> is neurons 128 .. 143)
+    G1_LAUNCH(144)
 #undef G1_LAUNCH
 }

@@ -3,13 +3,14 @@ that read (tools/probes/mfma_read_hazard_probe.hip: the finished product is ther
 pads for instructions it generates but counts an inline-asm statement as one wait state whatever is inside, and csrc/bar16_common.h
 reads accumulators from asm (pick_mix).  Rule checked here: between the MFMA and the first vector instruction that reads one of its
 destination registers there must be at least `need` wait states, counting one per instruction and N+1 per `s_nop N`, four per MFMA
-issued in between (an MFMA holds the issue port of its wave for its first pass).  Dependent MFMAs (the destination read as C) are the
-hardware's own business and not counted as readers.
+issued in between (an MFMA holds the issue port of its wave for its first pass).  Dependent MFMAs OF THE SAME SHAPE (the destination
+read as C) are the hardware's own business and not counted as readers; an MFMA of another shape (csrc/gru_scan1t.hip mixes 16x16x32
+and 16x16x16) is a reader like any vector instruction.
     python tools/mfma_result_hazard_scan.py file.s ..."""
 import re
 import sys
 
-MFMA = re.compile(r'\s*(v_mfma_f32_16x16x32_\S+)\s+([av])\[(\d+):(\d+)\],')
+MFMA = re.compile(r'\s*(v_mfma_f32_16x16x(?:32|16)_\S+)\s+([av])\[(\d+):(\d+)\],')
 REGS = re.compile(r'\b([av])(\d+)\b|\b([av])\[(\d+):(\d+)\]')
 
 
@@ -55,9 +56,11 @@ def scan(path, need=7):
             continue
         op = st.split()[0]
         m = MFMA.match(text)
-        if op.startswith("v_") and not m:             # a vector reader?
+        if op.startswith("v_"):                       # a vector reader?  (an MFMA is one of MFMAs of another shape)
             rd = _reads(st)
             for p in pending:
+                if m and p[5].split()[0] == op:
+                    continue
                 if p[3] < need and any(t == p[0] and not (hi < p[1] or lo > p[2]) for t, lo, hi in rd):
                     bad.append((ln, st, p[4], p[5], p[3]))
         if op.startswith(("global_store", "ds_write", "buffer_store")):
