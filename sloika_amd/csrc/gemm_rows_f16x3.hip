@@ -331,6 +331,13 @@ __global__ void __launch_bounds__(GH_THREADS) gemm_rows_f16x3_kernel(const float
                     *reinterpret_cast<float4 *>(yrow + nt * GH_BN + 8 * q) =
                         make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
             }
+        } else if (rowok && vec_ok && (N & 3) == 0 && XM != 2) {
+            // the partial last tile of a row length that is a multiple of four (a Gru projection: 3 n columns): a lane's four
+            // consecutive columns exist together or not at all -- one 16-byte store instead of four guarded dword stores
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (cbase + 8 * q < N)
+                    *reinterpret_cast<float4 *>(yrow + nt * GH_BN + 8 * q) = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
         } else if (rowok) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
