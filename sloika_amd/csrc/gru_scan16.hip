@@ -469,7 +469,7 @@ extern "C" int slk_gru_scan16_f32(const float *vI, long ldv, const float *sW, co
     if ((unsigned long long)T * B * ldv * sizeof(float) >= (1ull << 32)) return SLK_ERR_UNSUPPORTED;       // 32-bit lane offsets
     // one tile per wave (gru_scan1t.hip) is the faster plan at every width (a layer of 112 at B = 1024, T' = 800: 1.11-1.19 ms against
     // 1.21-1.28 with its projection, 128: 1.19-1.22 against 1.23-1.26; 144, nine waves with its last 16 neurons as a K block of 16:
-    // scan alone ~0.7 against 1.36).  SLOIKA_AMD_SCAN1T=0 / 1: never / always, for comparisons.
+    // scan alone 0.94 against 1.37).  SLOIKA_AMD_SCAN1T=0 / 1: never / always, for comparisons.
     static const int plan1t = getenv("SLOIKA_AMD_SCAN1T") ? atoi(getenv("SLOIKA_AMD_SCAN1T")) : -1;
     if (plan1t == 1 || plan1t < 0) {
         const int rc = slk_gru_scan1t_launch(vI, ldv, sW, sW2, y, ldy, T, B, n, reverse, lens, slk_stream(stream));

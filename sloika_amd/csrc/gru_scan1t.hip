@@ -9,7 +9,7 @@
 // (round 3 fetched the candidate's from LDS every step instead: it spilled and ran 2.09 ms against 1.93 for gru_scan16.hip's ninth
 // tile).  Round 5: 144 = four K blocks of 32 and ONE OF 16 -- v_mfma_f32_16x16x16_f16 for neurons 128 .. 143, whose halves the ninth
 // wave writes side by side in the image so that one 8-byte LDS read is the B operand -- 108 registers of weights, no scratch:
-// a 144-wide layer's scan 1.36 -> ~0.7 ms.
+// a 144-wide layer's scan 1.37 -> 0.94 ms (B = 1024, T' = 800, tools/scan_ab.py).
 //
 // A wave's recurrent weights are 3 gates x ceil(n / 32) K blocks x (hi, lo) x 4 registers = 96 of the 256 registers a wave has when
 // two share a SIMD.
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_scan1t_kernel(const float *__res
 {
     static_assert(N % 16 == 0 && N <= 144, "one wave per 16 neurons, at most nine waves");
     // KBS K blocks of 32 as MFMA operands; HALF: one more of 16 (the image keeps a whole block for it)
-    constexpr bool HALF = N == 144;
+    constexpr bool HALF = N == 144;                       // (112 = 3 x 32 + 16 as well, but measured 658 us against 628 as four blocks of 32)
     constexpr int NW = N / 16, KBS = HALF ? N / 32 : (N + 31) / 32, KBI = KBS + (HALF ? 1 : 0), NTH = 64 * NW, KP = 32 * KBI;
 
     // state images: [hi image | lo image], each KP x 4 chunks halves; element (k block kb, k group g, chunk c, r) = dword
