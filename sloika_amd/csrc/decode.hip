@@ -661,19 +661,16 @@ __global__ void __launch_bounds__(256) viterbi_forward4_wave_kernel(const float 
 // ------------------------------------------------------------------------------------------------------
 #define VBT_RING 3
 #define VBT_BLOCK 12288            /* bytes; a multiple of 3 KiB (three stager waves) and of every 4^k k-mer count <= 4096 */
-// FMT 0: a byte per state.  FMT 1: the traceback of viterbi_forward4_kernel, one 16-bit word per four states and step (two bits per
-// to-state: 0 stay, 1 step, 2 skip; the step argument at bit 8, the skip argument at bit 10).  FMT 2 (round 5, the fused kernel of
-// softmax_viterbi.hip): ONE BYTE per four states -- bits 0-3 "to-state n moves", bit 4 "by step" (else by skip), bits 5-6 the step
-// argument, bit 7 bit (j & 3) of the skip argument, which the four lanes of a quad share: 256 bytes per step and chunk instead of
-// 512, half the traffic of this kernel (which is bound by reading it) and of the forward kernel's traceback stores.
-template <int NB, int FMT>
+// PACKED false: a byte per state.  true: the traceback of viterbi_forward4_kernel, one 16-bit word per four states and step (two bits
+// per to-state: 0 stay, 1 step, 2 skip; the step argument at bit 8, the skip argument at bit 10).  (The fused kernel of
+// softmax_viterbi.hip writes a third format, one byte per four states, that viterbi_backtrace_rows_kernel below walks.)
+template <int NB, bool PACKED>
 __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *__restrict__ tb,
                                                                 const int32_t *__restrict__ best, int T, int nkmer,
                                                                 int tblk, int dma, int32_t *__restrict__ path_out,
                                                                 int32_t *__restrict__ len_out, const int *__restrict__ lens)
 {
-    constexpr bool PACKED = FMT == 1;
-    const int rowbytes = FMT == 2 ? nkmer / 4 : (PACKED ? nkmer / 2 : nkmer);
+    const int rowbytes = PACKED ? nkmer / 2 : nkmer;
     constexpr int NB2 = NB * NB;
     constexpr int PER_WAVE = VBT_BLOCK / 1024 / 3;
     const int Tpad = T;                                        // row strides of tb / path_out; T = this chunk's own length
@@ -701,42 +698,8 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
         // one lane walks: keeping the state in scalar registers (readfirstlane) moves the index arithmetic of this
         // dependent chain to the scalar unit
         int cur = __builtin_amdgcn_readfirstlane(sh_cur), pos = __builtin_amdgcn_readfirstlane(sh_pos);
-        if constexpr (FMT == 2) {
-            // The walk is a chain of dependent scalar instructions around one LDS read per row (~340 cycles per row on paths that move
-            // at almost every row: latency, not the traffic the one-byte format halved), so the arithmetic per row is kept minimal:
-            // unsigned state (a shift per division), the bit positions of this state's byte recomputed only when the state changes,
-            // the four bits of the skip argument gathered by one multiplication ((q & 0x80808080) * 0x204081 puts bits 7, 15, 23, 31
-            // at bits 28 .. 31: the partial products are distinct powers of two, nothing carries into them).
-            unsigned ucur = (unsigned)cur;
-            const int sh1 = __builtin_ctz((unsigned)nrem1), sh2 = __builtin_ctz((unsigned)nrem2);      // nkmer = 4^k: powers of two
-            unsigned bmove = ((ucur << 1) & 24u) + (ucur & 3u);      // bit of "to-state (cur & 3) moves" in the quad's word
-            const uint32_t *row = reinterpret_cast<const uint32_t *>(rows) + (t1 - 1 - t0) * (nkmer / 16);
-            for (int t = t1 - 1; t >= t0; t--, row -= nkmer / 16) {
-                const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane((int)row[ucur >> 4]);
-                if ((q >> bmove) & 1u) {
-                    const unsigned b8 = bmove & 24u;
-                    if ((q >> (b8 + 4)) & 1u) ucur = (((q >> (b8 + 5)) & 3u) << sh1) + (ucur >> 2);      // by step
-                    else ucur = ((((q & 0x80808080u) * 0x204081u) >> 28) << sh2) + (ucur >> 4);         // by skip
-                    bmove = ((ucur << 1) & 24u) + (ucur & 3u);
-                    path[--pos] = (int)ucur;                   // decode.py:88-90
-                }
-            }
-            sh_cur = (int)ucur;
-            sh_pos = pos;
-            return;
-        }
         for (int t = t1 - 1; t >= t0; t--) {
-            if constexpr (FMT == 2) {
-                // the quad's four bytes (states 16 (cur >> 4) .. + 15): mine is byte (cur >> 2) & 3, bit 7 of byte i is bit i of the skip argument
-                const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane(
-                    (int)reinterpret_cast<const uint32_t *>(rows)[(t - t0) * (nkmer / 16) + (cur >> 4)]);
-                const unsigned w = (q >> (8 * ((cur >> 2) & 3))) & 0xffu;
-                if ((w >> (cur & 3)) & 1u) {
-                    const unsigned karg = ((q >> 7) & 1u) | ((q >> 14) & 2u) | ((q >> 21) & 4u) | ((q >> 28) & 8u);
-                    cur = (w & 16u) ? (int)((w >> 5) & 3u) * nrem1 + cur / NB : (int)karg * nrem2 + cur / NB2;
-                    path[--pos] = cur;                         // decode.py:88-90
-                }
-            } else if constexpr (PACKED) {
+            if constexpr (PACKED) {
                 const int w = __builtin_amdgcn_readfirstlane(
                     (int)reinterpret_cast<const uint16_t *>(rows)[(t - t0) * (nkmer / 4) + (cur >> 2)]);
                 const int how = (w >> (2 * (cur & 3))) & 3;        // 0 stay, 1 step, 2 skip
@@ -819,12 +782,15 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_kernel(const uint8_t *_
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Backtrace of the one-byte traceback (FMT 2) of 4^5 k-mers with the rows in REGISTERS: a row is 256 bytes = one dword per lane,
+// Backtrace of the fused kernel's traceback of 4^5 k-mers -- ONE BYTE per four states: bits 0-3 "to-state n moves", bit 4 "by step"
+// (else by skip), bits 5-6 the step argument, bit 7 bit (j & 3) of the skip argument, which the four lanes of a quad share; 256 bytes
+// per step and chunk -- with the rows in REGISTERS: a row is 256 bytes = one dword per lane,
 // so a wave keeps sixteen rows in sixteen registers (and the next sixteen on their way from memory) and reads "the word of state
 // cur" with v_readlane instead of a dependent LDS read.  One wave per chunk, four per workgroup (= one per SIMD: as workgroups of
 // one wave, four chunks landed on one SIMD and took 90 us instead of 57), no LDS, no barrier, no stager waves.
 // The walk is a serial chain and what it costs is the NUMBER of instructions on it (a wave issues a scalar instruction per ~7
-// cycles here, a taken branch costs ~30): the kernel above spends ~31 instructions and three taken branches per moving row.  Here
+// cycles here, a taken branch costs ~30): the same walk in the style of the kernel above (a dependent LDS read, ~31 instructions and three taken
+// branches per moving row) took 102 us.  Here
 // a row is one asm statement of twenty instructions without a branch; the state is kept as the five values the next row needs
 // (cur, cur >> 2, the lane cur >> 4, the byte's shift, cur & 3).  The path is collected in a register (v_writelane at lane
 // pos & 63) and stored at most once per sixteen rows, right-aligned as above, then shifted left and padded with -1 by the same
@@ -857,9 +823,10 @@ __global__ void __launch_bounds__(256) viterbi_backtrace_rows_kernel(const uint8
     // every lane loads, every row: rows below 1 and lanes past the row are clamped to valid addresses (conditional loads would
     // cost the compiler its count of the loads in flight: it then waits for the block it has just asked for)
     const int lcl = lane < rowdw ? lane : rowdw - 1;
+    const int tlo = Tpad > 1 ? 1 : 0;                          // (a traceback of ONE row has no row 1: nothing is walked, row 0 is what there is to read)
     auto load = [&](uint32_t (&r)[VBR_ROWS], int ttop) {
 #pragma unroll
-        for (int k = 0; k < VBR_ROWS; k++) r[k] = tbb[(size_t)max(ttop - k, 1) * rowdw + lcl];
+        for (int k = 0; k < VBR_ROWS; k++) r[k] = tbb[(size_t)max(ttop - k, tlo) * rowdw + lcl];
     };
     auto row = [&](uint32_t rk) {                              // decode.py:84-91, one row
         unsigned q, t, g, a;
@@ -1005,10 +972,10 @@ static int launch_viterbi(const float *post, const float *stats, long ld, int T,
     const int dma = (VBT_BLOCK % rowbytes == 0) && (rowbytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
     if (tblk > T) tblk = T;
     if (packed_tb)
-        hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, 1>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+        hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, true>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
                            len_out, lens);
     else
-        hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, 0>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+        hipLaunchKernelGGL((viterbi_backtrace_kernel<NB, false>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
                            len_out, lens);
     return slk_launch_status();
 }
@@ -1021,26 +988,17 @@ int slk_backtrace_packed4(const uint8_t *tb, const int32_t *best, int T, int B, 
     if (tblk < 1) return SLK_ERR_UNSUPPORTED;
     const int dma = (VBT_BLOCK % rowbytes == 0) && (rowbytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
     if (tblk > T) tblk = T;
-    hipLaunchKernelGGL((viterbi_backtrace_kernel<4, 1>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
+    hipLaunchKernelGGL((viterbi_backtrace_kernel<4, true>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
                        len_out, lens);
     return slk_launch_status();
 }
 
-// the one-byte-per-four-states traceback of softmax_viterbi.hip (FMT 2 above)
+// the one-byte-per-four-states traceback of softmax_viterbi.hip: 4^5 k-mers (a row is one register per lane), a 4-byte aligned buffer
 int slk_backtrace_packed8(const uint8_t *tb, const int32_t *best, int T, int B, int nkmer, int32_t *path_out, int32_t *len_out,
                           const int *lens, hipStream_t s)
 {
-    const int rowbytes = nkmer / 4;
-    int tblk = VBT_BLOCK / rowbytes;
-    if (tblk < 1 || (nkmer & 15)) return SLK_ERR_UNSUPPORTED;
-    if (nkmer == 1024 && (reinterpret_cast<uintptr_t>(tb) & 3) == 0) {      // a row is one register per lane (the constants of its asm are 4^5's)
-        hipLaunchKernelGGL(viterbi_backtrace_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tb, best, T, B, nkmer, path_out, len_out, lens);
-        return slk_launch_status();
-    }
-    const int dma = (VBT_BLOCK % rowbytes == 0) && (rowbytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(tb) & 15) == 0);
-    if (tblk > T) tblk = T;
-    hipLaunchKernelGGL((viterbi_backtrace_kernel<4, 2>), dim3(B), dim3(256), 0, s, tb, best, T, nkmer, tblk, dma, path_out,
-                       len_out, lens);
+    if (nkmer != 1024 || (reinterpret_cast<uintptr_t>(tb) & 3) != 0) return SLK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(viterbi_backtrace_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tb, best, T, B, nkmer, path_out, len_out, lens);
     return slk_launch_status();
 }
 
