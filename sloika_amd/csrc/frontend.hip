@@ -200,8 +200,9 @@ extern "C" int slk_med_mad_normalise_ragged_f32(const float *signal, int nread, 
 // two bits per round: count the keys below three candidate prefixes (register compares, a wave reduction, one exchange
 // through LDS) and keep the largest prefix that at most `rank` keys lie below.  16 rounds give the exact key of rank n/2-1;
 // its upper neighbour (rank n/2) is either the same key (duplicates) or the smallest larger key -- one more count and a
-// minimum.  The MAD repeats this on the keys of |x - med|.  ~10 us for 1024 chunks against 140 us for the LDS bitonic
-// sort (which moves 32 KB through LDS in each of its 78 stages).
+// minimum.  The MAD repeats this on the keys of |x - med|.  33 us for 1024 chunks of 4000 samples (7 of them the loads and stores;
+// round 5: counts on the vector unit 45 -> 40, the lower 16 bits on the collected keys -> 33; tools/mm_ab.py) against 140 us
+// for the LDS bitonic sort (which moves 32 KB through LDS in each of its 78 stages).
 // ------------------------------------------------------------------------------------------------------
 template <int EPT>
 struct KeySet {
@@ -268,18 +269,69 @@ __device__ __forceinline__ void count_below3(const KeySet<EPT> &ks, unsigned c1,
     n3 = b;
 }
 
-// keys of rank r and r+1 (0-based) of the workgroup's keys; r + 1 < number of real keys when `need_next`
+// keys of rank r and r+1 (0-based) of the workgroup's keys; r + 1 < number of real keys when `need_next`.
+// After eight rounds (the upper 16 bits of the answer) the keys that share them -- a percent or two of a
+// chunk of signal -- are collected in LDS (`cand`, SEL_CAP + 2 words) and wave 0 finishes the lower 16 bits on them alone, four keys
+// per lane, no barrier per round; a chunk with more than SEL_CAP such keys (constant or coarsely quantised signal) goes on as before.
+#define SEL_CAP 256
 template <int EPT>
-__device__ void select_pair(const KeySet<EPT> &ks, unsigned r, bool need_next, unsigned *xch, unsigned &key_r, unsigned &key_next)
+__device__ void select_pair(const KeySet<EPT> &ks, unsigned r, bool need_next, unsigned *xch, unsigned *cand, unsigned &key_r,
+                            unsigned &key_next)
 {
-    unsigned prefix = 0;
-#pragma unroll 1
-    for (int round = 0; round < 16; round++) {
+    unsigned prefix = 0, below = 0;              // below = keys < prefix
+    constexpr int SPLIT = 8;
+    auto full_round = [&](int round) {
         const int sh = 30 - 2 * round;
         unsigned n1, n2, n3;
         count_below3<EPT>(ks, prefix | (1u << sh), prefix | (2u << sh), prefix | (3u << sh), xch, round, n1, n2, n3);
         const unsigned d = n3 <= r ? 3u : (n2 <= r ? 2u : (n1 <= r ? 1u : 0u));
+        below = d == 3u ? n3 : (d == 2u ? n2 : (d == 1u ? n1 : below));
         prefix |= d << sh;
+    };
+#pragma unroll 1
+    for (int round = 0; round < SPLIT; round++) full_round(round);
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (threadIdx.x == 0) cand[SEL_CAP] = 0u;
+        __syncthreads();
+        const unsigned top = prefix >> 16;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            if ((ks.k[i] >> 16) == top) {
+                const unsigned pos = atomicAdd(&cand[SEL_CAP], 1u);
+                if (pos < SEL_CAP) cand[pos] = ks.k[i];
+            }
+        }
+        __syncthreads();
+        const unsigned cnt = cand[SEL_CAP];
+        if (cnt <= SEL_CAP) {                    // (uniform)
+            if (wave == 0) {
+                unsigned ck[SEL_CAP / 64];
+#pragma unroll
+                for (int j = 0; j < SEL_CAP / 64; j++) ck[j] = (unsigned)(lane + 64 * j) < cnt ? cand[lane + 64 * j] : 0xffffffffu;
+                const unsigned rr = r - below;   // the rank among them: every key below `prefix` has smaller upper bits
+#pragma unroll 1
+                for (int round = SPLIT; round < 16; round++) {
+                    const int sh = 30 - 2 * round;
+                    const unsigned c1 = prefix | (1u << sh), c2 = prefix | (2u << sh), c3 = prefix | (3u << sh);
+                    unsigned n1 = 0, n2 = 0, n3 = 0;
+#pragma unroll
+                    for (int j = 0; j < SEL_CAP / 64; j++) {
+                        n1 += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ck[j] < c1));
+                        n2 += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ck[j] < c2));
+                        n3 += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ck[j] < c3));
+                    }
+                    const unsigned d = n3 <= rr ? 3u : (n2 <= rr ? 2u : (n1 <= rr ? 1u : 0u));
+                    prefix |= d << sh;
+                }
+                if (lane == 0) cand[SEL_CAP + 1] = prefix;
+            }
+            __syncthreads();
+            prefix = cand[SEL_CAP + 1];
+        } else {
+#pragma unroll 1
+            for (int round = SPLIT; round < 16; round++) full_round(round);
+        }
     }
     key_r = prefix;
     key_next = prefix;
@@ -312,6 +364,7 @@ __global__ void __launch_bounds__(256) med_mad_select_kernel(const float *__rest
                                                              float *__restrict__ mad_out)
 {
     __shared__ unsigned xch[24];
+    __shared__ unsigned cand[SEL_CAP + 2];
     const int c = blockIdx.x, tid = threadIdx.x, n = chunk_len;
     const float *sig = signal + (size_t)c * chunk_len;
     float x[EPT];
@@ -325,14 +378,14 @@ __global__ void __launch_bounds__(256) med_mad_select_kernel(const float *__rest
     const bool even = (n & 1) == 0;
     const unsigned r = even ? (unsigned)(n >> 1) - 1 : (unsigned)(n >> 1);
     unsigned ka, kb;
-    select_pair<EPT>(ks, r, even, xch, ka, kb);
+    select_pair<EPT>(ks, r, even, xch, cand, ka, kb);
     const float med = even ? (key2f(ka) + key2f(kb)) / 2.0f : key2f(ka);   // numpy: mean of the two middle samples in float32
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
         const int idx = tid + 256 * i;
         ks.k[i] = idx < n ? f2key(fabsf(x[i] - med)) : 0xffffffffu;
     }
-    select_pair<EPT>(ks, r, even, xch, ka, kb);
+    select_pair<EPT>(ks, r, even, xch, cand, ka, kb);
     const float dm = even ? (key2f(ka) + key2f(kb)) / 2.0f : key2f(ka);
     const float mad = 1.4826f * dm;
     float *o = out + (size_t)c * out_chunk_stride;

@@ -40,11 +40,12 @@ def test_normalise_ragged_sizes_vs_oracle(oracle, n, clen):
 
 
 @pytest.mark.parametrize("clen", [1024, 1025, 2047, 2048, 2049, 3000, 3999, 4000, 4001, 4095, 4096])
-@pytest.mark.parametrize("kind", ["normal", "rounded", "two-valued", "negative"])
+@pytest.mark.parametrize("kind", ["normal", "rounded", "two-valued", "negative", "constant", "hundredths", "wide"])
 def test_normalise_by_selection_vs_oracle(oracle, clen, kind):
     """Chunks of 1024..4096 samples take med_mad_select_kernel (order statistics by bitwise selection on register-resident
     keys): odd and even lengths, both register footprints, heavy duplication (the upper median neighbour is then the same
-    key), signals of both signs -- median, MAD and the normalised samples bit for bit."""
+    key), signals of both signs, both ways the lower 16 bits are finished (on the collected keys / on all of them) -- median, MAD
+    and the normalised samples bit for bit."""
     need_gpu()
     from sloika_amd import batch
     rs = np.random.RandomState(clen)
@@ -56,6 +57,13 @@ def test_normalise_by_selection_vs_oracle(oracle, clen, kind):
         x[:, 0] = 5.0
     elif kind == "negative":
         x = (x - 90.0).astype(np.float32)
+    elif kind == "constant":                                            # every key shares every bit: the selection's collected keys overflow
+        x[:] = 93.25
+        x[1, ::7] = 93.5
+    elif kind == "hundredths":                                          # a few hundred keys share the answer's upper 16 bits
+        x = (np.round(x * 100) / 100).astype(np.float32)
+    elif kind == "wide":                                                # magnitudes over twelve octaves: few keys share upper bits
+        x = (x * np.exp2(rs.randint(-6, 7, size=x.shape))).astype(np.float32)
     with np.errstate(all="ignore"):
         ref, rmed, rmad = oracle.med_mad_normalise(x, return_stats=True)
     out, med, mad = batch.normalise_chunks(x, 'per-chunk', return_stats=True)
