@@ -90,20 +90,34 @@ class Basecaller(object):
         n = len(net.layers) if isinstance(net, layers.Serial) else 1
         return self._hidden(chunks, n)
 
+    #: row widths csrc/softmax_viterbi.hip is instantiated for; any narrower Softmax input is decoded from rows with zero columns up to
+    #: the next of them (free when the rows come out of a zero-padded Gru twin, otherwise one padded copy of the hidden state: 0.3 ms
+    #: at B = 1024 against the 2 ms of the projection + logits decoder pair)
+    FUSED_WIDTHS = (64, 96, 112, 128)
+
     def _fused_pack(self, last, hid):
-        """(the Softmax layer's weights packed for csrc/softmax_viterbi.hip, the row width the kernel reads), or None when that
-        kernel does not apply."""
-        if not self.fused_decode or hid.stride(1) % 4 or hid.data_ptr() % 16:
+        """(the Softmax layer's weights packed for csrc/softmax_viterbi.hip, the hidden state with the row width the kernel reads), or
+        None when that kernel does not apply."""
+        import torch
+        if not self.fused_decode or hid.stride(2) != 1 or hid.stride(0) != hid.shape[1] * hid.stride(1):
             return None
-        if hid.stride(2) != 1 or hid.stride(0) != hid.shape[1] * hid.stride(1):
+        kp = next((k for k in self.FUSED_WIDTHS if k >= last.insize), None)
+        if kp is None:
             return None
-        if last.insize % 16:
-            # an odd width straight out of a zero-padded Gru twin (layers.Gru._forward): decode the padded rows
-            kp = (last.insize + 15) // 16 * 16
-            if getattr(hid, "_slk_zero_padded", 0) < kp or hid.stride(1) < kp:
+        if kp == last.insize:
+            if hid.stride(1) % 4 or hid.data_ptr() % 16:
                 return None
-            return last.viterbi_pack(self.nbase, self.kmer_len, kpad=kp), kp
-        return last.viterbi_pack(self.nbase, self.kmer_len), last.insize
+            pack = last.viterbi_pack(self.nbase, self.kmer_len)
+            return None if pack is None else (pack, hid)
+        pack = last.viterbi_pack(self.nbase, self.kmer_len, kpad=kp)
+        if pack is None:
+            return None
+        if getattr(hid, "_slk_zero_padded", 0) >= kp and hid.stride(1) >= kp and hid.stride(1) % 4 == 0 and hid.data_ptr() % 16 == 0:
+            # straight out of a zero-padded Gru twin (layers.Gru._forward): the columns behind insize exist and are zero
+            return pack, hid.as_strided((hid.shape[0], hid.shape[1], kp), hid.stride())
+        wide = torch.zeros((hid.shape[0], hid.shape[1], kp), dtype=hid.dtype, device=hid.device)
+        wide[:, :, :last.insize] = hid
+        return pack, wide
 
     def call_chunks(self, chunks, lp_dump=None):
         """-> device tensors (scores float32 [B], paths int32 [B, T'] (-1 padded), lens int32 [B]).
@@ -118,11 +132,8 @@ class Basecaller(object):
         if type(last) is layers.Softmax and len(net.layers) > 1:
             hid = self._hidden(chunks, len(net.layers) - 1)
             packed = self._fused_pack(last, hid)
-            pack = packed[0] if packed is not None else None
-            if pack is not None:
-                if packed[1] != hid.shape[2]:
-                    hid = hid.as_strided((hid.shape[0], hid.shape[1], packed[1]), hid.stride())
-                return decode.viterbi_fused_batch(hid, pack, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
+            if packed is not None:
+                return decode.viterbi_fused_batch(packed[1], packed[0], self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
                                                   min_prob=self.min_prob, workspace=self._ws, lp_dump=lp_dump)
             if lp_dump is not None:
                 raise ValueError("lp_dump needs the fused decoder (csrc/softmax_viterbi.hip does not cover this network)")
@@ -185,8 +196,8 @@ class Basecaller(object):
                 pack = packed[0] if packed is not None else None
                 if pack is None:
                     logits, stats, ld = net.layers[-1].logits_and_stats(hid)
-                elif packed[1] != hid.shape[2]:
-                    hid = hid.as_strided((hid.shape[0], hid.shape[1], packed[1]), hid.stride())
+                else:
+                    hid = packed[1]
         finally:
             layers._HINTS.in_flight, layers._HINTS.deterministic = keep
         T = hid.shape[0]

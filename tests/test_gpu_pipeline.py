@@ -69,8 +69,9 @@ def _check_fused_decode(oracle, net, cd, lp_two_kernel, klen=5, skip=0.0, pick=N
     from sloika_amd import pipeline
     bcf = pipeline.Basecaller(net, kmer_len=klen, skip=skip)
     last = net.layers[-1]
-    kp = (last.insize + 15) // 16 * 16                               # an odd width (raw_1.00_rGr: 110) is decoded from the zero-padded rows
-    if last.viterbi_pack(4, klen, kpad=None if kp == last.insize else kp) is None:
+    # a width between the kernel's own (raw_1.00_rGr: 110; 80; 72) is decoded from rows with zero columns up to the next of them
+    kp = next((k for k in pipeline.Basecaller.FUSED_WIDTHS if k >= last.insize), None)
+    if kp is None or last.viterbi_pack(4, klen, kpad=None if kp == last.insize else kp) is None:
         return                                                       # shape outside the fused kernel: nothing more to check
     T, B = lp_two_kernel.shape[0], cd.shape[0]
     dump = torch.empty((T, B, last.size), dtype=torch.float32, device="cuda")
@@ -92,6 +93,30 @@ def test_raw_models_end_to_end(oracle, name, nchunk, chunk_len):
     from sloika_amd import models, pipeline
     net = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=21))
     chunks = pipeline.synthetic_chunks(nchunk, chunk_len=chunk_len, seed=3)
+    _check_end_to_end(oracle, net, chunks)
+
+
+@pytest.mark.parametrize("width,feed", [(80, False), (72, True), (100, False), (120, True)])
+def test_fused_decode_takes_any_width_up_to_128(oracle, width, feed):
+    """A Softmax layer whose input is not 64 / 96 / 112 / 128 wide is still decoded by the fused kernel: from the zero-padded rows
+    of the Gru twin that made them (no copy), or -- behind a FeedForward layer -- from one padded copy of the hidden state."""
+    torch = need_gpu()
+    from sloika_amd import layers, activation, pipeline
+    rs = np.random.RandomState(width)
+    init = lambda shape: (rs.normal(size=shape) * 0.3).astype(np.float32)
+    stack = [layers.Convolution(1, 48, 11, 5, init=init, has_bias=True, fun=activation.tanh),
+             layers.Gru(48, width, init=init, has_bias=True, fun=activation.tanh)]
+    if feed:
+        stack.append(layers.FeedForward(width, width, init=init, has_bias=True, fun=activation.tanh))
+    stack.append(layers.Softmax(width, 1025, init=init, has_bias=True))
+    net = layers.Serial(stack)
+    chunks = pipeline.synthetic_chunks(5, chunk_len=600, seed=width)
+    bcf = pipeline.Basecaller(net, kmer_len=5)
+    cd = dev(chunks)
+    hid = bcf._hidden(cd, len(net.layers) - 1)
+    packed = bcf._fused_pack(net.layers[-1], hid)
+    assert packed is not None and packed[1].shape[2] in pipeline.Basecaller.FUSED_WIDTHS       # the fused kernel is what runs
+    assert (packed[1].data_ptr() == hid.data_ptr()) == (not feed)                                # ... without a copy behind a Gru
     _check_end_to_end(oracle, net, chunks)
 
 
