@@ -109,7 +109,10 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
     constexpr int NA = ST < NACAP ? ST : NACAP;
     static_assert(NCW * CT + NSW * ST == NT16, "tile assignment");
     static_assert(KBLK <= 4 && ST <= 21, "interval plan");
-    constexpr int OPIMG = GS * KBLK * 64;                // dwords of one operand image: [step][k block][k group][chunk][8 halves]
+    // dwords of one operand image: [step][k block][k group][chunk][8 halves]; the steps 32 banks apart (gru_bar16.hip: the 16-lane groups
+    // of a ds_read_b128 -- lanes of two k groups and two steps each -- then find their pieces on different banks)
+    constexpr int OPSTEP = KBLK * 64 + 32;
+    constexpr int OPIMG = GS * OPSTEP;
     constexpr int VSTEP = NT16 * 64;                     // floats of one step's vI of a set: [tile][g][chunk][r]
 
     __shared__ __attribute__((aligned(16))) unsigned xop_hi[2 * 2 * OPIMG], xop_lo[2 * 2 * OPIMG];      // [group & 1][set]
@@ -117,8 +120,11 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
     __shared__ __attribute__((aligned(16))) float vbuf[R * 2 * VSTEP];                                   // [step % R][set]
     constexpr bool MIX = BAR16D_MIX != 0;
     static_assert(!MIX || (!BAR16D_ZHOOK && !BAR16D_CACC), "the two-term products are written for the default schedule only");
-    __shared__ __attribute__((aligned(16))) unsigned h_img[2 * 4 * N], rh_img[2 * 4 * N];          // hi image [set], then lo image [set]
-    unsigned *const h_hi = h_img, *const h_lo = h_img + 4 * N, *const rh_hi = rh_img, *const rh_lo = rh_img + 4 * N;
+    // hi image [set], then lo image [set], the lo image 32 banks behind the hi image (gru_bar16.hip: on the same banks a ds_read_b128 of
+    // the mixed operand, whose lane quartets read both, takes two passes -- LDSBankConflict 7.8 % of this kernel's LDS cycles in round 4)
+    constexpr int IMG = 4 * N + (4 * N % 64 == 0 ? 32 : 4 * N % 64 == 32 ? 0 : 4);
+    __shared__ __attribute__((aligned(16))) unsigned h_img[2 * IMG], rh_img[2 * IMG];
+    unsigned *const h_hi = h_img, *const h_lo = h_img + IMG, *const rh_hi = rh_img, *const rh_lo = rh_img + IMG;
     __shared__ __attribute__((aligned(16))) float bias_lds[3 * N], invw_lds[3 * N];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -130,7 +136,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
     // ---------------- projection pieces shared by both kinds of wave ----------------
     const int pcol = lane & 15, kg = lane >> 4;          // operand row / column and k group of this lane
     const int pstep = pcol >> 2, pc = pcol & 3;          // as a B column: (step in group, chunk of the set)
-    const int poff = pstep * (KBLK * 64) + kg * 16 + pc * 4;            // + 64 kb: my 16 bytes of an operand image, in dwords
+    const int poff = pstep * OPSTEP + kg * 16 + pc * 4;                 // + 64 kb: my 16 bytes of an operand image, in dwords
     auto ldH = [](const unsigned *img, int off) { return *reinterpret_cast<const half8 *>(img + off); };
     auto opimg = [&](int grp, int set) { return ((grp & 1) * 2 + set) * OPIMG + poff; };
     // iW tile -> A operands (lane: row pcol of the tile, k = 32 kb + 8 kg + 0..7), row scale remembered in invw_lds
@@ -251,7 +257,7 @@ __global__ void __launch_bounds__(256, 1) gru_bar16d_kernel(const float *__restr
         for (int i = 0; i < KBS; i++) boff[i] = set * 2 * N + ((((w + i) % KBS) * 4 + g) * 4 + c) * 4;        // in dwords
         int moff[KBS];                                   // MIX: my copy's image (q & 1 = 0: hi, 1: lo)
 #pragma unroll
-        for (int i = 0; i < KBS; i++) moff[i] = qh * 4 * N + boff[i];
+        for (int i = 0; i < KBS; i++) moff[i] = qh * IMG + boff[i];
         const int wd = set * 2 * N + ((w * 4 + g) * 4 + c) * 4 + 2 * qh;                         // my two packed pairs, in dwords
         const int n0 = 32 * w + 4 * g + 2 * qh;                                                  // my neurons n0, n0+1 of tile 2w (+16: 2w+1)
         const int voff = (g * 4 + c) * 4 + 2 * qh;                                               // my two elements of a vI tile
