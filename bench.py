@@ -52,11 +52,12 @@ MFMA_STAGES = ("gru_fused", "gru_recurrent", "gru_input_gemm", "lstm_fused", "ls
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 0.4 s of timed steps behind 0.6 s of warm-up.  A fresh process needs about a hundred steps to reach its steady state
-    # (torch's caching allocator still grows while result tensors wait for their copies; measured on one box, same clock both times:
-    # 100 steps behind 10 of warm-up 4.14-4.21 ms per step, behind 200 3.91-3.92 -- the figure the 10-second `sustained` leg confirms)
+    # a step allocates nothing (Basecaller(borrow=True): every buffer out of the Basecaller's own arena), so a handful of warm-up steps
+    # is enough: the first call sizes the arena and builds the weight packs, the rest run like the thousandth (up to round 5 every layer
+    # asked torch's caching allocator for its output and a fresh process needed ~100 steps to settle: 4.14-4.21 ms behind 10 warm-up
+    # steps against 3.91 behind 200)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=150)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="raw_0.98_rgrgr")
     ap.add_argument("--batch", type=int, default=1024, help="chunks per GPU per step")
     ap.add_argument("--chunk-len", type=int, default=4000)
@@ -371,7 +372,9 @@ class Runner(object):
         from sloika_amd import models, pipeline
         self.torch, self.B, self.L, self.with_bases = torch, B, L, with_bases
         self.net = models.randomise_zero_layers(models.build_model(model_name, klen=5, sd=0.5, seed=11))
-        self.bcs = [pipeline.Basecaller(self.net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0) for _ in range(nslot)]
+        # borrow=True: every buffer of a call comes out of the Basecaller's own arena (the reference compiles its networks with
+        # borrow=True, layers.py:34-36) -- a step allocates nothing, so the first steps run like the thousandth
+        self.bcs = [pipeline.Basecaller(self.net, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, borrow=True) for _ in range(nslot)]
         self.streams = ([torch.cuda.current_stream()] if main_stream else []) + \
             [torch.cuda.Stream() for _ in range(nslot - (1 if main_stream else 0))]
         self.nbuf = 2
@@ -388,6 +391,7 @@ class Runner(object):
         self.out_host = [torch.empty((B, self.tout), dtype=torch.int32).pin_memory() for _ in range(nslot)]
         self.copy_stream = torch.cuda.Stream()
         self.copied = [None] * nslot
+        self.copied_before = [None] * nslot
         self.klen = 5
         if with_bases:
             self.bases_dev = [torch.empty((B, 5 * self.tout), dtype=torch.uint8, device="cuda") for _ in range(nslot)]
@@ -411,14 +415,16 @@ class Runner(object):
 
     def step(self, i, nact=1, src=None):
         """The results leave for the host on a copy stream of their own: the next step's kernels do not queue behind a PCIe
-        transfer.  `paths` is a fresh tensor every step (record_stream keeps the allocator from reusing it before the copy has
-        run); the persistent base buffers are protected by the copy's event."""
+        transfer.  `paths` alternates between the two result sets of the Basecaller's arena (device.Arena): the call that will
+        overwrite this step's set is the next but one on this slot, and it waits for this step's copy (an event that has long
+        fired by then); the persistent base buffers are protected by the copy's event."""
         torch = self.torch
         from sloika_amd import _lib, profiler
         k = i % nact
         with torch.cuda.stream(self.streams[k]):
+            if self.copied_before[k] is not None:
+                self.streams[k].wait_event(self.copied_before[k])     # the copy of the call whose result set this call reuses
             scores, paths, lens = self.bcs[k].call_chunks(self.dev[i % self.nbuf] if src is None else src)
-            paths.record_stream(self.copy_stream)
             if self.with_bases:                                                 # base sequences, still on the device
                 if self.copied[k] is not None:
                     self.streams[k].wait_event(self.copied[k])
@@ -435,6 +441,7 @@ class Runner(object):
             if self.with_bases:                                                      # ... and so do the base sequences
                 self.bases_host[k].copy_(self.bases_dev[k], non_blocking=True)
                 self.nbases_host[k].copy_(self.nbases_dev[k], non_blocking=True)
+            self.copied_before[k] = self.copied[k]
             self.copied[k] = torch.cuda.Event()
             self.copied[k].record(self.copy_stream)
 
@@ -571,6 +578,22 @@ def leg_batch256(args, torch, B1=256, nfl=8):
     return small
 
 
+def devices_of_ranks(torch, dist, bound, stub=False):
+    """What every rank is bound to, in rank order: device name and PCI bus id (N ranks on N different GPUs show N different bus ids;
+    the length of the list is the number of ranks the collective saw)."""
+    if stub:
+        mine = "stub:%d" % bound
+    else:
+        p = torch.cuda.get_device_properties(bound)
+        bus = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+        mine = "%s@%s" % (p.name, bus)
+    if dist is None:
+        return [mine]
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, mine)
+    return box
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 def main_train(args, as_field=False, torch=None, dist=None):
     """One step = wrap_network's fg(x, labels, weights, rate) on one batch per GPU (bin/train_network.py:308).  With `as_field`
@@ -610,10 +633,26 @@ def main_train(args, as_field=False, torch=None, dist=None):
         loss, acc = fg(x, labels, weights, 1e-3 / (1.0 + i / 5000.0))
     barrier()
     dt = time.perf_counter() - t0
+    allreduce_ms = None
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # the step's one exchange by itself: the all-reduce of a flat float32 gradient of this network's size (train.allreduce_mean_),
+        # back to back, max over ranks
+        flat = torch.zeros(sum(int(np.prod(p.get_value().shape)) for p in net.params()), dtype=torch.float32, device="cuda")
+        for _ in range(3):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        barrier()
+        ta = time.perf_counter()
+        nar = 50
+        for _ in range(nar):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        tar = torch.tensor([(time.perf_counter() - ta) / nar * 1e3], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tar, op=dist.ReduceOp.MAX)
+        allreduce_ms = float(tar.item())
+    devices = None if as_field else devices_of_ranks(torch, dist, torch.cuda.current_device())
     # per-stage HIP events in a pass of their own
     stages = {}
     if not args.no_stage_timing:
@@ -660,7 +699,7 @@ def main_train(args, as_field=False, torch=None, dist=None):
                 "stages_hbm_bytes_per_step": hbm_per_step,
                 "hbm_bytes_per_step": sum(hbm_per_step.values()) if hbm_per_step else None}
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "raw-signal samples/sec trained", "value": world * B * L * steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -672,11 +711,115 @@ def main_train(args, as_field=False, torch=None, dist=None):
                        "parallelism": "data parallel over %d GPU(s), one all-reduce of the flat gradient per step" % world},
             "roofline": roofline, "roofline_by_stage": by_stage,
             "cpu_baseline": cpu_baseline_train(args.model, L) if (world == 1 and args.cpu_chunks > 0) else None,
-            "final_loss": loss,
+            "final_loss": float(loss),
+            "devices": devices, "rccl_ranks_seen": len(devices) if dist is not None else None,
+            "allreduce_ms_per_step": allreduce_ms,
+            "gradient_floats": None if dist is None else int(flat.numel()),
             "stages_ms_per_step": {k: v["per_step"] for k, v in sorted(stages.items())},
-            "stages_hbm_bytes_per_step": hbm_per_step}))
+            "stages_hbm_bytes_per_step": hbm_per_step,
+            "hbm_bytes_per_step": sum(hbm_per_step.values()) if hbm_per_step else None})
     if dist is not None:
         dist.destroy_process_group()
+
+
+#: what the driver keeps of this script's stdout is a few kilobytes of its tail: the LAST line is the record and stays under this
+COMPACT_LINE_MAX = 4096
+
+
+def _r(v, nd=5):
+    """Floats of the compact line rounded to `nd` significant digits (22 KB of the round-5 line were 17-digit floats)."""
+    if isinstance(v, float):
+        return float("%.*g" % (nd, v))
+    if isinstance(v, dict):
+        return {k: _r(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, nd) for x in v]
+    return v
+
+
+def compact_line(line):
+    """The record: the contract's fields, the dominant stage's `roofline`, `cpu_baseline` and a dozen scalars of the other legs; every
+    other figure of the run is in the detail file (`detail`)."""
+    def g(d, *path):
+        for p in path:
+            if not isinstance(d, dict) or d.get(p) is None:
+                return None
+            d = d[p]
+        return d
+    roof = line.get("roofline")
+    if roof:
+        keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_launch", "launches", "hbm_gbs", "mfma_util",
+                "traffic_stale", "frac_vs_fp32_mfma_peak")
+        u = roof.get("unit_utilisation") or {}
+        roof = dict({k: roof.get(k) for k in keep}, stale=u.get("stale"),
+                    units={k: u[k] for k in ("VALUBusy", "LdsUtil", "LDSBankConflict") if k in u} or None)
+    cpu = line.get("cpu_baseline")
+    if cpu:
+        cpu = {"value": cpu.get("value"), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+               "sample": cpu.get("sample"), "single_core": g(cpu, "single_core", "value")}
+    cfg = dict(line["config"])
+    out = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    out["config"] = cfg
+    out["roofline"] = roof
+    out["cpu_baseline"] = cpu
+    out["per_rank_ms"] = line.get("per_rank_ms")
+    out["devices"] = line.get("devices")
+    out["rccl_ranks_seen"] = line.get("rccl_ranks_seen")
+    out["clock_mhz"] = g(line, "shader_clock_mhz_before_after", "mean")
+    out["stages_ms"] = line.get("stages_ms_per_step")
+    # one scalar per leg (samples/s unless the name says ms)
+    out["sustained_one"] = g(line, "sustained", "one_at_a_time", "value")
+    out["sustained_one_ms"] = g(line, "sustained", "one_at_a_time", "ms_per_step")
+    out["four_in_flight_det"] = g(line, "sustained", "four_in_flight", "value")
+    out["four_in_flight_nondet"] = g(line, "sustained", "four_in_flight_not_deterministic", "value")
+    out["exact_f32"] = g(line, "exact_f32", "value")
+    out["with_upload"] = g(line, "with_upload", "value")
+    out["train_ms"] = g(line, "train", "ms_per_step")
+    out["train_hbm_gb_per_step"] = (g(line, "train", "hbm_bytes_per_step") or line.get("hbm_bytes_per_step") or 0) / 1e9 or None
+    out["pretrained"] = g(line, "pretrained", "one_at_a_time", "value")
+    out["b256_baseline_raw_gru_one"] = g(line, "batch256", "baseline_raw_gru", "one_at_a_time", "value")
+    out["b256_baseline_raw_gru_in_flight"] = g(line, "batch256", "baseline_raw_gru", "in_flight_sustained", "value") or \
+        g(line, "batch256", "baseline_raw_gru", "eight_in_flight", "value")
+    out["b256_rgrgr_one"] = g(line, "batch256", "raw_0.98_rgrgr", "one_at_a_time", "value")
+    out["b256_rgrgr_in_flight"] = g(line, "batch256", "raw_0.98_rgrgr", "in_flight_sustained", "value") or \
+        g(line, "batch256", "raw_0.98_rgrgr", "eight_in_flight", "value")
+    out["whole_reads_resident"] = g(line, "whole_reads", "value")
+    out["whole_reads_from_host"] = g(line, "whole_reads", "from_host_arrays", "value")
+    out["allreduce_ms_per_step"] = line.get("allreduce_ms_per_step")
+    out["csrc_tree"] = line.get("csrc_tree")
+    out["detail"] = line.get("detail")
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline")
+    out = _r({k: v for k, v in out.items() if v is not None or k in contract})
+    s = json.dumps(out, separators=(",", ":"))
+    if len(s) >= COMPACT_LINE_MAX:                      # never let the record outgrow what the driver keeps: shed the optional parts
+        for k in ("stages_ms", "clock_mhz", "csrc_tree", "per_rank_ms"):
+            out.pop(k, None)
+            s = json.dumps(out, separators=(",", ":"))
+            if len(s) < COMPACT_LINE_MAX:
+                break
+    return s
+
+
+def emit(line):
+    """Every figure of the run goes to `bench_detail.json` (beside this script, and into gpurun_out/ when that exists); stdout gets ONE
+    line, the compact record, last."""
+    paths = [os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as fh:
+                json.dump(line, fh, indent=1)
+            written = written or os.path.relpath(p, ROOT)
+        except OSError:
+            pass
+    line["detail"] = written
+    sys.stdout.flush()
+    print(compact_line(line))
+    sys.stdout.flush()
 
 
 def launch_ranks(args):
@@ -796,6 +939,7 @@ def main():
         dist.all_gather(tl, torch.tensor([per_rank_ms[0]], dtype=torch.float64, device=dev))
         per_rank_ms = [float(t.item()) for t in tl]
 
+    devices = devices_of_ranks(torch, dist, bound, stub)
     # ---- the same steps once more with HIP events around every C-ABI call: per-stage times and the roofline ----
     stages, roofline, ms_profiled, by_stage = {}, None, None, None
     if not args.no_stage_timing and args.stage_steps > 0 and not stub:
@@ -869,14 +1013,20 @@ def main():
                     big = torch.cat([run.dev[i % run.nbuf] for i in range(mult)], dim=0)
                     outb = torch.empty((mult * B, run.tout), dtype=torch.int32).pin_memory()
 
-                    def step_big(_i, big=big, outb=outb):
+                    copies = []
+
+                    def step_big(_i, big=big, outb=outb, copies=copies):
+                        if len(copies) >= 2:
+                            torch.cuda.current_stream().wait_event(copies[-2])   # (the result set this call reuses: device.Arena)
                         scores, paths, lens = run.bcs[0].call_chunks(big)
-                        paths.record_stream(run.copy_stream)
                         done = torch.cuda.Event()
                         done.record(torch.cuda.current_stream())
                         with torch.cuda.stream(run.copy_stream):
                             run.copy_stream.wait_event(done)
                             outb[:, : paths.shape[1]].copy_(paths, non_blocking=True)
+                            copies.append(torch.cuda.Event())
+                            copies[-1].record(run.copy_stream)
+                            del copies[:-2]
                     step_big(0)
                     n = max(1, args.overlap_steps // mult)
                     d = timed(step_big, n)
@@ -1073,10 +1223,12 @@ def main():
             "e2e_algorithmic_tflops": (gemm_flops / (dt / args.steps) / 1e12) if stages else None,
         }
         line.update(line_extra)
+        line["devices"] = devices
+        line["rccl_ranks_seen"] = len(devices) if dist is not None else None
         if stub:
             line["data"] = "none: --stub-device (rank plumbing only, no GPU, no kernel)"
             line["value"] = None
-        print(json.dumps(line))
+        emit(line)
     elif stub:
         sys.stderr.write("bench.py: rank %d bound to device %d\n" % (rank, bound))
     if dist is not None:

@@ -331,11 +331,13 @@ SLK_API int slk_log_post_logits_f32(const float *logits, long ld, const float *s
  *          not depend on it
  *   lp_dump : NULL, or [T][B][nstate] floats that receive the log-posteriors the dynamic programme consumed (tests decode
  *          THESE with the oracle: paths and scores are bit-exact functions of them)
- *   workspace: slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen)
+ *   workspace: slk_softmax_viterbi_workspace_bytes(T, B, nbase, klen) bytes, 16-byte aligned (one traceback byte per four
+ *          k-mers and step: a quarter of slk_viterbi_kmer_workspace_bytes, which is also accepted)
  * Products are 3-term fp16 splits with float32 accumulation like slk_linear_rowstats_f16x3.  This build has the kernel for
  * nbase 4, klen 5 and K in {64, 96, 112, 128}; anything else returns SLK_ERR_UNSUPPORTED (pack_bytes returns 0) and the
  * caller uses slk_linear_rowstats_* + slk_viterbi_kmer_logits_f32.                                                        */
 SLK_API size_t slk_softmax_viterbi_pack_bytes(int K, int nbase, int klen);
+SLK_API size_t slk_softmax_viterbi_workspace_bytes(int T, int B, int nbase, int klen);   /* 0: shape outside the fused kernel */
 SLK_API int slk_softmax_viterbi_pack_f32(const float *W, const float *bias, int K, int nbase, int klen, void *pack,
                                  slk_stream_t stream);
 SLK_API int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pack, int K, int T, int B, int nbase, int klen,

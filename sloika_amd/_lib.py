@@ -52,6 +52,7 @@ PROTOTYPES = {
     "slk_viterbi_kmer_logits_f32": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _f, _f, _vp, _sz, _vp, _vp, _vp, _vp]),
     "slk_viterbi_kmer_logits_ragged_f32": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _sz, _vp, _vp, _vp, _vp]),
     "slk_softmax_viterbi_pack_bytes": (_sz, [_i, _i, _i]),
+    "slk_softmax_viterbi_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "slk_softmax_viterbi_pack_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "slk_softmax_viterbi_f32": (_i, [_vp, _l, _vp, _i, _i, _i, _i, _i, _f, _f, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "slk_gru_recurrent_ragged_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _vp, _vp]),

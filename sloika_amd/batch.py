@@ -45,11 +45,11 @@ def normalise_chunks(chunks, normalisation='per-chunk', out_layout='chunk', retu
         n_units, unit_len = 1, ml * chunk_len
     else:
         n_units, unit_len = ml, chunk_len
-    med = torch.empty(n_units, dtype=torch.float32, device=cd.device)
-    mad = torch.empty(n_units, dtype=torch.float32, device=cd.device)
+    med = D.scratch(n_units, torch.float32, cd.device)
+    mad = D.scratch(n_units, torch.float32, cd.device)
     with profiler.region("normalise", 0.0, 8.0 * ml * chunk_len):
         if out_layout == 'chunk':
-            out = torch.empty((ml, chunk_len), dtype=torch.float32, device=cd.device)
+            out = D.scratch((ml, chunk_len), torch.float32, cd.device)
             rc = L.slk_med_mad_normalise_f32(cd.data_ptr(), n_units, unit_len, out.data_ptr(), unit_len, 1,
                                              med.data_ptr(), mad.data_ptr(), D.stream_ptr())
         else:
@@ -59,7 +59,7 @@ def normalise_chunks(chunks, normalisation='per-chunk', out_layout='chunk', retu
                                                  med.data_ptr(), mad.data_ptr(), D.stream_ptr())
                 out = tmp.t().contiguous()[:, :, None]
             else:
-                out = torch.empty((chunk_len, ml, 1), dtype=torch.float32, device=cd.device)
+                out = D.scratch((chunk_len, ml, 1), torch.float32, cd.device)
                 rc = L.slk_med_mad_normalise_f32(cd.data_ptr(), ml, chunk_len, out.data_ptr(), 1, ml,
                                                  med.data_ptr(), mad.data_ptr(), D.stream_ptr())
     _lib.check(rc, "normalise_chunks")
@@ -250,7 +250,7 @@ def normalise_reads_ragged(padded, lengths):
     import torch
     from . import device as D
     B, lmax = padded.shape
-    out = torch.zeros((lmax, B, 1), dtype=torch.float32, device=padded.device)
+    out = D.scratch((lmax, B, 1), torch.float32, padded.device).zero_()
     with profiler.region("normalise", 0.0, 8.0 * B * lmax):
         rc = _lib.lib().slk_med_mad_normalise_ragged_f32(padded.data_ptr(), B, padded.stride(0), lengths.data_ptr(), out.data_ptr(),
                                                          1, B, None, None, D.stream_ptr())

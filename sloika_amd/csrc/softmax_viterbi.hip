@@ -1067,6 +1067,14 @@ static int sv_launch(const float *x, long ldx, int T, int B, const uint8_t *pack
     return slk_launch_status();
 }
 
+// the fused path's own workspace: one traceback byte per FOUR k-mers (256 B per step and chunk), then best[B]
+extern "C" size_t slk_softmax_viterbi_workspace_bytes(int T, int B, int nbase, int klen)
+{
+    if (T < 1 || B < 1 || nbase != 4 || klen != 5) return 0;
+    const size_t tb = ((size_t)B * T * (SV_NK / 4) + 255) & ~(size_t)255;
+    return tb + sizeof(int32_t) * (size_t)B + 256;
+}
+
 extern "C" int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pack, int K, int T, int B, int nbase, int klen,
                                        float skip_pen, float min_prob, const int32_t *lens, int plan, void *workspace,
                                        size_t workspace_bytes, float *score_out, int32_t *path_out, int32_t *len_out,
@@ -1079,10 +1087,10 @@ extern "C" int slk_softmax_viterbi_f32(const float *x, long ldx, const void *pac
     // cycles whichever of its waves it comes from, and that plan only moved instructions from one wave to the other -- and was removed
     if (plan == 4) return SLK_ERR_UNSUPPORTED;
     if (!sv_shape_ok(K, nbase, klen) || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return SLK_ERR_UNSUPPORTED;
-    const size_t need = slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen);
-    if (!workspace || workspace_bytes < need) return SLK_ERR_WORKSPACE;
+    const size_t need = slk_softmax_viterbi_workspace_bytes(T, B, nbase, klen);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SLK_ERR_WORKSPACE;
     uint8_t *tb = static_cast<uint8_t *>(workspace);
-    const size_t tbbytes = ((size_t)B * T * SV_NK + 255) & ~(size_t)255;
+    const size_t tbbytes = ((size_t)B * T * (SV_NK / 4) + 255) & ~(size_t)255;
     int32_t *best = reinterpret_cast<int32_t *>(tb + tbbytes);
     const uint8_t *pk = static_cast<const uint8_t *>(pack);
     hipStream_t s = slk_stream(stream);

@@ -87,9 +87,9 @@ def viterbi_batch(post, klen, skip_pen=0.0, log=False, nbase=4, min_prob=None, w
     if nbytes == 0:
         raise ValueError("unsupported klen/nbase for the Viterbi kernel")
     ws = (workspace or ViterbiWorkspace()).get(nbytes, pd.device)
-    scores = torch.empty(B, dtype=torch.float32, device=pd.device)
-    paths = torch.empty((B, T), dtype=torch.int32, device=pd.device)
-    lens = torch.empty(B, dtype=torch.int32, device=pd.device)
+    scores = D.scratch(B, torch.float32, pd.device, result=True)
+    paths = D.scratch((B, T), torch.int32, pd.device, result=True)
+    lens = D.scratch(B, torch.int32, pd.device, result=True)
     nk = nbase ** klen
     with profiler.region("viterbi", 0.0, float(T) * B * (4.0 * S + 2.0 * nk)):
         rc = L.slk_viterbi_kmer_f32(pd.data_ptr(), T, B, nbase, klen, float(skip_pen), mode,
@@ -118,9 +118,9 @@ def viterbi_logits_batch(logits, stats, klen, T, B, ld=None, skip_pen=0.0, nbase
     if nbytes == 0:
         raise ValueError("unsupported klen/nbase for the Viterbi kernel")
     ws = (workspace or ViterbiWorkspace()).get(nbytes, logits.device)
-    scores = torch.empty(B, dtype=torch.float32, device=logits.device)
-    paths = torch.empty((B, T), dtype=torch.int32, device=logits.device)
-    lens = torch.empty(B, dtype=torch.int32, device=logits.device)
+    scores = D.scratch(B, torch.float32, logits.device, result=True)
+    paths = D.scratch((B, T), torch.int32, logits.device, result=True)
+    lens = D.scratch(B, torch.int32, logits.device, result=True)
     nk = nbase ** klen
     with profiler.region("viterbi", 0.0, float(T) * B * (4.0 * S + 2.0 * nk)):
         if lengths is None:
@@ -154,13 +154,13 @@ def viterbi_fused_batch(x, pack, klen, skip_pen=0.0, nbase=4, min_prob=1e-5, wor
     T, B, K = x.shape
     S = sv.nstate(klen, transducer=True, nbase=nbase)
     L = _lib.lib()
-    nbytes = L.slk_viterbi_kmer_workspace_bytes(T, B, nbase, klen)
+    nbytes = L.slk_softmax_viterbi_workspace_bytes(T, B, nbase, klen)      # one traceback byte per four k-mers: 256 B per (step, chunk)
     if nbytes == 0:
-        raise ValueError("unsupported klen/nbase for the Viterbi kernel")
+        raise ValueError("unsupported klen/nbase for the fused softmax + Viterbi kernel")
     ws = (workspace or ViterbiWorkspace()).get(nbytes, x.device)
-    scores = torch.empty(B, dtype=torch.float32, device=x.device)
-    paths = torch.empty((B, T), dtype=torch.int32, device=x.device)
-    lens = torch.empty(B, dtype=torch.int32, device=x.device)
+    scores = D.scratch(B, torch.float32, x.device, result=True)
+    paths = D.scratch((B, T), torch.int32, x.device, result=True)
+    lens = D.scratch(B, torch.int32, x.device, result=True)
     if lengths is not None and (lengths.dtype != torch.int32 or lengths.numel() != B or not lengths.is_cuda):
         raise ValueError("lengths must be an int32 device tensor with one entry per chunk")
     if lp_dump is not None and (lp_dump.dtype != torch.float32 or lp_dump.numel() != T * B * S or not lp_dump.is_contiguous()):

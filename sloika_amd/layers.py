@@ -94,6 +94,12 @@ def _extract(x, shape=None):
     return xv.tolist()
 
 
+def _scratch(shape, dtype, dev):
+    """Uninitialised device memory for the forward pass in progress (device.scratch: out of the caller's Arena when one is active)."""
+    from . import device as D
+    return D.scratch(shape, dtype, dev)
+
+
 def _stream():
     from . import device as D
     return D.stream_ptr()
@@ -363,7 +369,7 @@ def _alloc_out(x, T, B, size, out):
     if out is not None:
         assert out.shape == (T, B, size) and out.stride(2) == 1 and out.stride(0) == B * out.stride(1)
         return out
-    return torch.empty((T, B, size), dtype=torch.float32, device=x.device)
+    return _scratch((T, B, size), torch.float32, x.device)
 
 
 class Param(object):
@@ -631,15 +637,15 @@ class Softmax(Layer):
                                                       _stream()), "softmax_viterbi_pack")
             return pack
 
-        return _derived_cache(self, "_svpack" if K == self.insize else "_svpack_p", (self.W, self.b), build)
+        return _derived_cache(self, "_svpack" if K == self.insize else "_svpack_p%d" % K, (self.W, self.b), build)
 
     def _logits(self, x, ld):
         """tmp = x.W^T + b (layers.py:310) with rows `ld` floats apart, and per-row (max, 1/sum exp) [T*B,2]."""
         import torch
         T, B, _ = x.shape
         rows, L = T * B, _lib.lib()
-        y = torch.empty((rows, ld), dtype=torch.float32, device=x.device)
-        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        y = _scratch((rows, ld), torch.float32, x.device)
+        stats = _scratch((rows, 2), torch.float32, x.device)
         use_f16 = self.split_f16 and self.insize <= 128 and self.size <= 2048
         with profiler.region("softmax_gemm", 2.0 * rows * self.insize * self.size,
                              4.0 * rows * (self.insize + self.size),
@@ -734,7 +740,7 @@ class Window(Layer):
         import torch
         T, B, F = x.shape                      # symmetric padding: commutes with time reversal
         x = x.contiguous()
-        y = torch.empty((T, B, self.size), dtype=torch.float32, device=x.device)
+        y = _scratch((T, B, self.size), torch.float32, x.device)
         _lib.check(_lib.lib().slk_window_f32(x.data_ptr(), y.data_ptr(), T, B, F, self.w, _stream()), "Window")
         if out is not None:
             out.copy_(y)
@@ -795,7 +801,7 @@ class Convolution(Layer):
         """Convolve input addressed as x[t*x_t_stride + b*x_b_stride + c] (lets the chunk front end hand over
         chunk-major signal without a transpose)."""
         import torch
-        y = torch.empty((self.out_len(T), B, self.size), dtype=torch.float32, device=device)
+        y = _scratch((self.out_len(T), B, self.size), torch.float32, device)
         with profiler.region("conv1d", 2.0 * y.numel() * self.insize * self.winlen,
                              4.0 * (y.numel() + T * B * self.insize)):
             rc = _lib.lib().slk_conv1d_f32(x_ptr, x_t_stride, x_b_stride, self.W.dev().data_ptr(),
@@ -905,7 +911,7 @@ class Lstm(RNN):
                 return y
             plan = "scan16"
         nbytes = L.slk_lstm_workspace_bytes(T, B, n)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        ws = _scratch(nbytes, torch.uint8, x.device)
         # the two halves of slk_lstm_f32, timed separately: projection GEMM into the workspace, then the recurrence
         _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 4 * n, "lstm_input_gemm", "Lstm")
         with profiler.region("lstm_recurrent", 8.0 * rows * n * n, 4.0 * rows * 5 * n):
@@ -1080,7 +1086,7 @@ class Gru(RNN):
             plan = "scan"
         # projection GEMM into a workspace, then the scan
         nbytes = L.slk_gru_workspace_bytes(T, B, n)
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        ws = _scratch(nbytes, torch.uint8, x.device)
         _projection(self, x, self.iW, self.b, ws.data_ptr(), rows, self.insize, 3 * n, "gru_input_gemm", "Gru")
         # (roofline bookkeeping: the fp16-split scans take two MFMAs per recurrent product, the state's halves in different column groups;
         #  the float32 scan one fp32 MFMA)
@@ -1183,7 +1189,7 @@ class Parallel(Layer):
         T, B, _ = x.shape
         if all(_keeps_time(layer) for layer in self.layers):
             # every sub-layer writes its slice of the concatenated tensor directly (row stride = self.size)
-            outs = out if out is not None else torch.empty((T, B, self.size), dtype=torch.float32, device=x.device)
+            outs = out if out is not None else _scratch((T, B, self.size), torch.float32, x.device)
             streams = self._side_streams(x, B)
             off = 0
             if streams is None:

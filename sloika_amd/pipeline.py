@@ -21,7 +21,7 @@ FUSED_DECODE = "no_fused_decode" not in layers._DEBUG
 
 class Basecaller(object):
     def __init__(self, network, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0, normalisation='per-chunk', in_flight=1,
-                 fused_decode=None, deterministic=True):
+                 fused_decode=None, deterministic=True, borrow=False):
         """skip default 0.0 is the CLI default (bin/basecall_network.py:38).
 
         in_flight: how many batches the caller keeps in flight at a time, each on a HIP stream of its own (one Basecaller
@@ -36,6 +36,15 @@ class Basecaller(object):
         With deterministic=True they run eight chunks per workgroup instead; deterministic=False lets the faster plan in (the
         price of the switch is in the bench line: `in_flight.deterministic`)."""
         self.deterministic = bool(deterministic)
+        # borrow: the reference compiles its networks with In(borrow=True) / Out(borrow=True) (layers.py:34-36): what a call returns
+        # may be overwritten by a later call, the caller consumes or copies it first.  Here: every buffer of a call (layer outputs,
+        # workspaces, results) comes out of an arena this Basecaller keeps, so a call whose shapes repeat allocates nothing, and what a
+        # call returns stays intact until TWO further calls have been issued on this Basecaller (device.Arena).  One Basecaller = one
+        # stream of work: issue its calls in order on one stream.
+        self._arena = None
+        if borrow:
+            from . import device as D
+            self._arena = D.Arena(generations=2)
         if not isinstance(network, layers.Layer):
             raise TypeError("network must be a sloika_amd.layers.Layer")
         self.network = network
@@ -127,6 +136,12 @@ class Basecaller(object):
         device tensor [T', B, nstate], then receives the log-posteriors the dynamic programme consumed (tests).  Otherwise
         (and with fused_decode=False) the decoder consumes the layer's logits + row statistics, bit-identical to decoding
         `posteriors()`."""
+        if self._arena is None:
+            return self._call_chunks(chunks, lp_dump)
+        with self._arena:
+            return self._call_chunks(chunks, lp_dump)
+
+    def _call_chunks(self, chunks, lp_dump):
         net = self.network
         last = net.layers[-1] if isinstance(net, layers.Serial) else None
         if type(last) is layers.Softmax and len(net.layers) > 1:
@@ -179,6 +194,12 @@ class Basecaller(object):
     def _call_padded(self, padded, nsamp):
         """One padded batch of trimmed reads resident on the device ([B, Lmax], read b in its first nsamp[b] samples): per-read
         normalisation, network and decoder with per-read lengths.  -> (scores, paths, lens) on the device."""
+        if self._arena is None:
+            return self._call_padded_pass(padded, nsamp)
+        with self._arena:
+            return self._call_padded_pass(padded, nsamp)
+
+    def _call_padded_pass(self, padded, nsamp):
         net = self.network
         B = padded.shape[0]
         keep = layers._HINTS.in_flight, layers._HINTS.deterministic

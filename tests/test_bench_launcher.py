@@ -60,7 +60,41 @@ def test_eight_ranks_rank_plumbing_on_gloo():
         assert "rank %d of 8 starting" % rank in r.stderr
         if rank:
             assert "rank %d bound to device %d" % (rank, rank) in r.stderr
-    assert d["device_of_rank0"] == 0
+    # what the driver's record needs on the day the 8-GPU run is not skipped: who the ranks were, how many the collective saw
+    assert d["devices"] == ["stub:%d" % r_ for r_ in range(8)] and d["rccl_ranks_seen"] == 8
+    # the record is the LAST line of stdout and short enough for the driver's capture (round 5's 22 KB line was cut: parsed = null)
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert last == lines[0] and len(last) < 4096
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    with open(os.path.join(ROOT, d["detail"])) as fh:
+        full = json.load(fh)
+    assert full["n_gpus"] == 8 and len(full["per_rank_ms"]) == 8
+
+
+def test_compact_line_of_a_full_run_stays_under_four_kilobytes():
+    """Round 5's own 22 KB line (profiles/r05f_bench.json) through compact_line: the contract's fields, `roofline` with traffic and
+    MfmaUtil, `cpu_baseline` and the legs' scalars survive, in under 4 KB."""
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05f_bench.json")) as fh:
+        full = json.loads(fh.read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 15000
+    full["devices"], full["rccl_ranks_seen"], full["detail"] = ["AMD Instinct MI355X@0000:05:00"] * 8, 8, "bench_detail.json"
+    full["per_rank_ms"] = [3.7512345678] * 8
+    s = bench.compact_line(full)
+    assert len(s) < 4096, len(s)
+    d = json.loads(s)
+    assert abs(d["value"] - full["value"]) / full["value"] < 1e-3 and abs(d["ms_per_step"] - full["ms_per_step"]) < 1e-2
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "mfma_util", "hbm_gbs", "stale"):
+        assert k in d["roofline"], k
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["traffic"] > 0
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert d["cpu_baseline"][k] is not None
+    for k in ("sustained_one", "four_in_flight_det", "train_ms", "pretrained", "b256_rgrgr_one", "whole_reads_from_host"):
+        assert d.get(k), k
+    assert d["config"]["workload"] and d["dtype"] and d["vs_baseline"] is None
 
 
 def test_a_failing_rank_fails_the_launch():

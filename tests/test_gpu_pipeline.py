@@ -311,3 +311,37 @@ def test_event_model_through_the_basecaller(oracle):
         bc.call_chunks(pipeline.synthetic_chunks(2, chunk_len=200, seed=1))
     with pytest.raises(ValueError):
         bc.call_chunks(torch.zeros((10, 2, 3), device="cuda"))
+
+
+def test_borrow_mode_allocates_nothing_after_the_first_call_and_changes_no_bit():
+    """Basecaller(borrow=True): the reference compiles its networks with borrow=True (layers.py:34-36) -- what a call returns may be
+    overwritten by a later one.  Here every buffer of a call comes out of the Basecaller's arena (device.Arena): the second call of the
+    same shape allocates NOTHING (neither the arena nor torch's caching allocator grows), the results are those of the default
+    Basecaller bit for bit, and what a call returned stays intact through the NEXT call (two result sets) -- the bench copies paths to
+    the host while the next call already runs."""
+    torch = need_gpu()
+    from sloika_amd import models, pipeline
+    for name, B, L in (("raw_0.98_rgrgr", 256, 2000), ("baseline_raw_gru", 64, 1000), ("pretrained", 128, 1500)):
+        net = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=31))
+        a = dev(pipeline.synthetic_chunks(B, chunk_len=L, seed=7))
+        b = dev(pipeline.synthetic_chunks(B, chunk_len=L, seed=8))
+        ref_a = [t.clone() for t in pipeline.Basecaller(net).call_chunks(a)]
+        ref_b = [t.clone() for t in pipeline.Basecaller(net).call_chunks(b)]
+        bc = pipeline.Basecaller(net, borrow=True)
+        ra = bc.call_chunks(a)
+        rb = bc.call_chunks(b)                       # second result set: ra is still intact
+        torch.cuda.synchronize()
+        for x, y in zip(ra, ref_a):
+            assert torch.equal(x, y)
+        for x, y in zip(rb, ref_b):
+            assert torch.equal(x, y)
+        grown, reserved, nalloc = bc._arena.grown, torch.cuda.memory_reserved(), torch.cuda.memory_stats()["allocation.all.allocated"]
+        for _ in range(3):
+            rc = bc.call_chunks(a)
+        torch.cuda.synchronize()
+        assert bc._arena.grown == grown and torch.cuda.memory_reserved() == reserved
+        assert torch.cuda.memory_stats()["allocation.all.allocated"] == nalloc, name       # not one allocator request in three calls
+        for x, y in zip(rc, ref_a):
+            assert torch.equal(x, y)
+        assert rc[1].data_ptr() == rb[1].data_ptr() or rc[1].data_ptr() == ra[1].data_ptr()   # ... the two sets alternate
+        del bc, ra, rb, rc
