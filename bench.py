@@ -388,7 +388,10 @@ class Runner(object):
         self.dev = [torch.from_numpy(h).cuda() for h in self.host_in]
         first = self.net.layers[0]
         self.tout = first.out_len(L) if hasattr(first, "out_len") else L
-        self.out_host = [torch.empty((B, self.tout), dtype=torch.int32).pin_memory() for _ in range(nslot)]
+        # two pinned result buffers per slot: the host reads the paths of call i - 2 of a slot (waits for that copy) before it issues
+        # call i, whose copy then lands in the buffer just read
+        self.out_host = [[torch.empty((B, self.tout), dtype=torch.int32).pin_memory() for _ in range(2)] for _ in range(nslot)]
+        self.ncall = [0] * nslot
         self.copy_stream = torch.cuda.Stream()
         self.copied = [None] * nslot
         self.copied_before = [None] * nslot
@@ -415,15 +418,18 @@ class Runner(object):
 
     def step(self, i, nact=1, src=None):
         """The results leave for the host on a copy stream of their own: the next step's kernels do not queue behind a PCIe
-        transfer.  `paths` alternates between the two result sets of the Basecaller's arena (device.Arena): the call that will
-        overwrite this step's set is the next but one on this slot, and it waits for this step's copy (an event that has long
-        fired by then); the persistent base buffers are protected by the copy's event."""
+        transfer.  The host is a consumer: before it issues call i of a slot it waits until the paths of call i - 2 of that slot
+        are in pinned memory (where a caller reads them) -- which is also what makes reusing that call's result set (the
+        Basecaller's arena keeps two, device.Arena) and its host buffer safe.  One whole step is always queued behind the running
+        one, so the device never waits for the host; the host never runs more than two steps per slot ahead (measured,
+        tools/warmup_curve.py: with the host ten steps ahead, every other of a fresh process's first twenty steps took 1 ms longer
+        -- cross-stream waits on events that are far from firing -- and the first 25 steps averaged 3.95 ms against 3.70)."""
         torch = self.torch
         from sloika_amd import _lib, profiler
         k = i % nact
         with torch.cuda.stream(self.streams[k]):
             if self.copied_before[k] is not None:
-                self.streams[k].wait_event(self.copied_before[k])     # the copy of the call whose result set this call reuses
+                self.copied_before[k].synchronize()                   # the host has the paths of call i - 2 of this slot
             scores, paths, lens = self.bcs[k].call_chunks(self.dev[i % self.nbuf] if src is None else src)
             if self.with_bases:                                                 # base sequences, still on the device
                 if self.copied[k] is not None:
@@ -437,7 +443,8 @@ class Runner(object):
             done.record(self.streams[k])
         with torch.cuda.stream(self.copy_stream):
             self.copy_stream.wait_event(done)
-            self.out_host[k][:, : paths.shape[1]].copy_(paths, non_blocking=True)     # paths end up on the host
+            self.out_host[k][self.ncall[k] & 1][:, : paths.shape[1]].copy_(paths, non_blocking=True)     # paths end up on the host
+            self.ncall[k] += 1
             if self.with_bases:                                                      # ... and so do the base sequences
                 self.bases_host[k].copy_(self.bases_dev[k], non_blocking=True)
                 self.nbases_host[k].copy_(self.nbases_dev[k], non_blocking=True)
@@ -494,8 +501,12 @@ class ClockProbe(object):
         from sloika_amd import _lib
         self.torch, self.lib = torch, _lib.lib()
         self.stream = torch.cuda.Stream(priority=-1)
-        self.buf = torch.zeros((nmax, 2), dtype=torch.int64, device="cuda")
+        self.buf = torch.zeros((nmax + 1, 2), dtype=torch.int64, device="cuda")
         self.n, self.nmax = 0, nmax
+        # the stream's hardware queue is created at its first launch (milliseconds of host time during which the device runs dry, and a
+        # few milliseconds without work cost the next steps: see main): first launch here, into a row of its own
+        self.lib.slk_clock_probe(self.buf[nmax].data_ptr(), 1, self.stream.cuda_stream)
+        self.stream.synchronize()
 
     def sample(self):
         if self.n < self.nmax:
@@ -921,13 +932,17 @@ def main():
         return reduce_max(time.perf_counter() - t)     # ... and the job's: until the last rank is through
 
     # ---- the main region: W warm-up steps, then exactly K timed steps (no events inside) ----
-    for i in range(args.warmup):
-        run.step(i, nstream)
+    # (the device's power management: a few milliseconds WITHOUT work cost the next ~50 launches up to 12 % -- tools/warmup_kernel_only.py:
+    # a pause of 5 ms behind 100 back-to-back launches of the Gru kernel, 572 ... 602 ... 525 us over the next 40 against 520 steady -- so
+    # nothing sits between the warm-up steps and the timed region but the contract's barrier: the clock probe of the region's leading
+    # edge is a launch on a stream of its own beside the last warm-up step, not a synchronise - probe - synchronise of its own)
     edge_probe = None if stub else ClockProbe(torch, nmax=4)
-    if edge_probe is not None:
-        sync()
-        edge_probe.sample()                  # the shader clock right in front of the timed region (a launch of its own, waited for) ...
-        sync()
+    for i in range(args.warmup):
+        if edge_probe is not None and i == args.warmup - 1:
+            edge_probe.sample()              # the shader clock right in front of the timed region ...
+        run.step(i, nstream)
+    if edge_probe is not None and args.warmup < 1:
+        edge_probe.sample()
     dt = timed(lambda i: run.step(i, nstream), args.steps)
     if edge_probe is not None:
         edge_probe.sample()                  # ... and right behind it

@@ -94,6 +94,20 @@ def _extract(x, shape=None):
     return xv.tolist()
 
 
+_CU_COUNT = {}
+
+
+def _cu_count(dev):
+    """Compute units of `dev`, asked once per device (torch's first get_device_properties initialises amdsmi: 26 ms on the host, which
+    used to sit in the first forward pass; pipeline.Basecaller asks at construction)."""
+    import torch
+    key = (dev.type, dev.index)
+    n = _CU_COUNT.get(key)
+    if n is None:
+        n = _CU_COUNT[key] = torch.cuda.get_device_properties(dev).multi_processor_count
+    return n
+
+
 def _scratch(shape, dtype, dev):
     """Uninitialised device memory for the forward pass in progress (device.scratch: out of the caller's Arena when one is active)."""
     from . import device as D
@@ -988,7 +1002,7 @@ class Gru(RNN):
         """Bits 8-9 of `reverse` for slk_gru_bar16_f32: what Parallel decided for its side-by-side sub-layers, else eight chunks
         per workgroup when that is what lets the batches in flight share the chip."""
         import torch
-        ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+        ncu = _cu_count(x.device)
         if _HINTS.gru_plan_bits or _HINTS.in_flight <= 1:
             bits = _HINTS.gru_plan_bits
         else:
@@ -1070,7 +1084,7 @@ class Gru(RNN):
             # gru_bar16d.hip / gru_bar16q.hip).  Roofline bookkeeping: up to eight chunks per workgroup the recurrent products
             # take two MFMAs each, the projection three; the sixteen-chunk plan three everywhere (bar16_auto_plan)
             bits = self._plan_bits(x, B)
-            ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+            ncu = _cu_count(x.device)
             two_term = bits in (1, 2, 5) or (bits == 0 and (B + 7) // 8 <= ncu)
             with profiler.region("gru_fused", 6.0 * rows * n * (n + self.insize), 4.0 * rows * (self.insize + n),
                                  f16x3_flops=6.0 * rows * n * (self.insize if two_term else n + self.insize),
@@ -1239,7 +1253,7 @@ class Parallel(Layer):
             inner = layer.layer if isinstance(layer, Reverse) else layer
             if not isinstance(inner, (Gru, Lstm)):
                 return None
-        ncu = torch.cuda.get_device_properties(x.device).multi_processor_count
+        ncu = _cu_count(x.device)
         self._side_plan = 0
         share = len(self.layers) * max(1, _HINTS.in_flight)
         inners = [l.layer if isinstance(l, Reverse) else l for l in self.layers]

@@ -57,6 +57,12 @@ class Basecaller(object):
         self.fused_decode = FUSED_DECODE if fused_decode is None else bool(fused_decode)
         self._ws = decode.ViterbiWorkspace()
         _lib.lib()
+        try:                                   # one-time host work that does not belong into the first call (layers._cu_count)
+            import torch
+            if torch.cuda.is_available():
+                layers._cu_count(torch.device("cuda", torch.cuda.current_device()))
+        except (ImportError, RuntimeError):
+            pass
 
     def _hidden(self, chunks, upto):
         """Run the network on [B, chunk_len] device signal up to (not including) layer index `upto`."""

@@ -577,7 +577,7 @@ class TrainingStep(object):
         if layers.RECURRENT_F16:            # projection and recurrence as fp16 splits (csrc/gru_bar16.hip)
             # (as layers.Gru.run prices it: the projection three fp16 MFMAs per product, the recurrent products two up to eight chunks
             #  per workgroup -- training batches of up to 2048 chunks on 256 CUs -- and three on the sixteen-chunk plan)
-            two_term_fw = (B + 7) // 8 <= torch.cuda.get_device_properties(x.device).multi_processor_count
+            two_term_fw = (B + 7) // 8 <= layers._cu_count(x.device)
             with profiler.region("gru_fused", 6.0 * M * n * (n + layer.insize), 4.0 * M * (layer.insize + 3 * n),
                                  f16x3_flops=6.0 * M * n * (layer.insize if two_term_fw else n + layer.insize),
                                  f16x2_flops=6.0 * M * n * n if two_term_fw else 0.0) as reg:
