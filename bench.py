@@ -1161,8 +1161,11 @@ def main():
                             "own" % len(reads),
                 "value": sum(nsamp) / d_dev, "unit": "samples/s", "seconds": d_dev, "reads_per_s": len(reads) / d_dev,
                 "note": "`value`: padded batches resident in HBM when the clock starts (like the chunks of the main region), paths "
-                        "on the host when it stops; `from_host_arrays` adds open-pore trimming, bucketing, packing and the upload",
-                "from_host_arrays": {"value": sum(nsamp) / d_all, "unit": "samples/s", "seconds": d_all},
+                        "on the host when it stops; `from_host_arrays`: the reads as numpy arrays on the host when the clock starts -- "
+                        "bucketed by raw length, packed and uploaded bucket by bucket while the device runs the buckets before, "
+                        "open-pore trimming on the device in the bucket's own stream (Basecaller._call_reads_streamed)",
+                "from_host_arrays": {"value": sum(nsamp) / d_all, "unit": "samples/s", "seconds": d_all,
+                                     "streamed": bool(wst.get("streamed"))},
                 "batches": wst["batches"], "padded_step_waste": wst["padded_step_waste"],
                 "bases_called": int(sum(len(p) for p in paths))}
             del batches, paths2, lanes, scores, paths, scores2

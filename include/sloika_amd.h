@@ -116,6 +116,17 @@ SLK_API int slk_pack_reads_f32(const float *src, const int64_t *start, const int
                        slk_stream_t stream);
 SLK_API int slk_reads_nonfinite_f32(const float *src, const int64_t *start, const int32_t *len, int nread, int max_len, int32_t *flags,
                             slk_stream_t stream);
+/* batch.trim_open_pore(signal, max_op_fraction=0) + util.trim_array for every read of an uploaded set, without a round trip to the host
+ * (sloika/batch.py:194-220 with the CLI's default fraction, bin/basecall_network.py:71: np.percentile(., 0) is the minimum; then
+ * sloika/basecall.py:111-112).  spread: the per-window spreads of ALL reads (MAD or std of every `window` samples, as
+ * slk_med_mad_normalise_f32 / slk_window_std_f32 leave them); read r owns windows first_win[r] .. first_win[r] + nwin[r] (whole windows
+ * only, as the reference's reshape) and starts at sample first_sample[r] of the set.  Out: start[r] (sample index in the set) and len[r]
+ * of the trimmed read.  flags[r]: bit 0 set by the caller = the read holds a sample that is not finite; on return bit 1 = the reference's
+ * function fails on the read (no whole window, or no window livelier than the minimum), bit 2 = nothing left after trimming; a read with
+ * any bit set gets len 0 (the reference's worker reports it and goes on, sloika/basecall.py:103-115).                              */
+SLK_API int slk_open_pore_trim_f32(const float *spread, const int64_t *first_win, const int32_t *nwin, const int64_t *first_sample,
+                           int nread, int window, int trim0, int trim1, int64_t *start, int32_t *len, int32_t *flags,
+                           slk_stream_t stream);
 /* Standard deviation of each of nwin consecutive windows of `win` samples (population form, numpy's .std()):
  * batch.trim_open_pore(var_method='std'), sloika/batch.py:210-211.  out:[nwin].                                    */
 SLK_API int slk_window_std_f32(const float *signal, int nwin, int win, float *out, slk_stream_t stream);

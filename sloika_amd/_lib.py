@@ -39,6 +39,7 @@ PROTOTYPES = {
     "slk_linear_rowstats_f32": (_i, [_vp, _l, _vp, _vp, _vp, _l, _l, _i, _i, _vp, _vp]),
     "slk_pack_reads_f32": (_i, [_vp, _vp, _vp, _i, _vp, _l, _vp]),
     "slk_reads_nonfinite_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "slk_open_pore_trim_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "slk_split_f16x2_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "slk_linear_rowstats_f16x3": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _vp, _vp]),
     "slk_pack_bf16x3_bytes": (_sz, [_i, _i]),

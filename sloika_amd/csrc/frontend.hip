@@ -3,6 +3,8 @@
 //   * Convolution.run                       (sloika/layers.py:417-419, sloika/conv.py:66-111)
 //   * Window.run                            (sloika/layers.py:346-351)
 // All three are HBM/latency-bound byte movers: coalesced loads/stores, filter taps and sort keys staged in LDS.
+#include <limits.h>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------------
@@ -506,6 +508,65 @@ extern "C" int slk_reads_nonfinite_f32(const float *src, const int64_t *start, c
     if (nread > 65535) return SLK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(reads_nonfinite_kernel, dim3((max_len + 4095) / 4096, nread), dim3(256), 0, slk_stream(stream), src,
                        reinterpret_cast<const long long *>(start), len, flags);
+    return slk_launch_status();
+}
+
+// batch.trim_open_pore with max_op_fraction 0 (the CLI's default, bin/basecall_network.py:71) for every read of an uploaded set, on the
+// device: np.percentile(spread, 0) is the minimum, the read runs from its first to its last window livelier than that (batch.py:213-220),
+// then util.trim_array takes `trim0` / `trim1` samples off the ends (basecall.py:111-112).  One wave per read (a read has a few hundred to
+// ~1200 windows).  flags[r]: bit 0 on entry = the read holds a sample that is not finite (slk_reads_nonfinite_f32); on exit bit 1 = no
+// whole window or no window livelier than the minimum (the reference's function fails on such a read), bit 2 = nothing left after
+// trimming.  A read with any bit set gets length 0.
+__global__ void __launch_bounds__(64) open_pore_trim_kernel(const float *__restrict__ spread, const long long *__restrict__ first_win,
+                                                            const int *__restrict__ nwin, const long long *__restrict__ first_sample,
+                                                            int nread, int window, int trim0, int trim1, long long *__restrict__ start,
+                                                            int *__restrict__ len, int *__restrict__ flags)
+{
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= nread) return;
+    const int n = nwin[r];
+    const float *sp = spread + first_win[r];
+    float mn = __builtin_inff();
+    for (int w = lane; w < n; w += 64) mn = fminf(mn, sp[w]);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+    int first = INT_MAX, last = -1;
+    for (int w = lane; w < n; w += 64)
+        if (sp[w] > mn) {
+            first = min(first, w);
+            last = max(last, w);
+        }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        first = min(first, __shfl_xor(first, o));
+        last = max(last, __shfl_xor(last, o));
+    }
+    if (lane == 0) {
+        int f = flags[r] & 1;
+        long long lo = 0, hi = 0;
+        if (n < 1 || last < 0) f |= 2;
+        else {
+            lo = (long long)first * window + trim0;
+            hi = ((long long)last + 1) * window - trim1;
+            if (hi - lo < 1) f |= 4;
+        }
+        const bool ok = f == 0;
+        start[r] = first_sample[r] + (ok ? lo : 0);
+        len[r] = ok ? (int)(hi - lo) : 0;
+        flags[r] = f;
+    }
+}
+
+extern "C" int slk_open_pore_trim_f32(const float *spread, const int64_t *first_win, const int32_t *nwin, const int64_t *first_sample,
+                                      int nread, int window, int trim0, int trim1, int64_t *start, int32_t *len, int32_t *flags,
+                                      slk_stream_t stream)
+{
+    if (!spread || !first_win || !nwin || !first_sample || !start || !len || !flags || nread < 0 || window < 1 || trim0 < 0 || trim1 < 0)
+        return SLK_ERR_INVALID_ARG;
+    if (nread == 0) return SLK_OK;
+    hipLaunchKernelGGL(open_pore_trim_kernel, dim3(nread), dim3(64), 0, slk_stream(stream), spread,
+                       reinterpret_cast<const long long *>(first_win), nwin, reinterpret_cast<const long long *>(first_sample), nread,
+                       window, trim0, trim1, reinterpret_cast<long long *>(start), len, flags);
     return slk_launch_status();
 }
 

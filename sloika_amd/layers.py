@@ -350,7 +350,13 @@ class ragged(object, metaclass=_RaggedMeta):
     def __init__(self, lengths):
         import torch
         from . import device as D
-        self.lengths = torch.as_tensor(np.ascontiguousarray(lengths, dtype=np.int32)).to(D.device())
+        if isinstance(lengths, torch.Tensor) and lengths.is_cuda:
+            # lengths that were computed on the device (pipeline.Basecaller's streamed whole-read mode) stay there
+            if lengths.dtype != torch.int32 or lengths.dim() != 1:
+                raise ValueError("ragged lengths on the device must be a 1-D int32 tensor")
+            self.lengths = lengths.contiguous()
+        else:
+            self.lengths = torch.as_tensor(np.ascontiguousarray(lengths, dtype=np.int32)).to(D.device())
 
     def __enter__(self):
         self.saved, ragged.current = ragged.current, self.lengths

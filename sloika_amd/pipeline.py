@@ -271,7 +271,8 @@ class Basecaller(object):
         return buckets
 
     @classmethod
-    def prepare_read_batches(cls, network, signals, trim=(0, 0), open_pore_fraction=0.0, max_batch=256, max_waste=0.08, **kwargs):
+    def prepare_read_batches(cls, network, signals, trim=(0, 0), open_pore_fraction=0.0, max_batch=256, max_waste=0.08, ids=None,
+                             **kwargs):
         """Preparation of the whole-read mode: the read set goes to the device in one upload, trimming bounds come from one launch over
         all windows (basecall.py:111-112), reads are bucketed by length and every bucket becomes a zero-padded device batch (one launch
         per bucket).  -> (batches, nsamp): batches = [(read indices, padded device tensor [B, Lmax], their sample counts)], nsamp =
@@ -298,7 +299,7 @@ class Basecaller(object):
             if nsamp[-1] < 1:
                 why = "samples that are not finite" if bad[r] else ("too short to trim the open pore" if bd is None else
                                                                     "nothing left after trimming")
-                sys.stderr.write("Failure calling read {}: {}\n".format(r, why))
+                sys.stderr.write("Failure calling read {}: {}\n".format(r if ids is None else ids[r], why))
         good = [r for r in range(len(nsamp)) if nsamp[r] > 0]
         batches = []
         L = _lib.lib()
@@ -326,14 +327,23 @@ class Basecaller(object):
         pairs to reuse (read_lanes(); torch's allocator caches device memory per stream, so a server that keeps its lanes does
         not pay for gigabytes of fresh allocations on every call).  -> (scores [N] float32, list of N int32 path arrays) on the
         host; a read that is in no batch (failed_reads) has score NaN and path None."""
-        import torch
         if lanes is None:
             lanes = cls.read_lanes(network, max(1, min(8, len(batches)) if in_flight is None else in_flight), **kwargs)
+        scores = np.full(nreads, np.nan, dtype=np.float32)
+        paths = [None] * nreads
+        cls._collect_read_batches(cls._launch_read_batches(lanes, batches), scores, paths)
+        return scores, paths
+
+    @staticmethod
+    def _launch_read_batches(lanes, batches, first_lane=0):
+        """Queue every prepared batch on its lane (batch k on lane (first_lane + k) % lanes) and its results' way to the host behind it;
+        nothing here waits for the device.  -> pending [(read indices, host tensors, event, device tensors)]."""
+        import torch
         nfl = len(lanes)
         cur = torch.cuda.current_stream()
         pending = []
         for k, (idx, padded, ns) in enumerate(batches):
-            bc, s = lanes[k % nfl]
+            bc, s = lanes[(first_lane + k) % nfl]
             s.wait_stream(cur)
             with torch.cuda.stream(s):
                 padded.record_stream(s)
@@ -342,15 +352,18 @@ class Basecaller(object):
                 ev = torch.cuda.Event()
                 ev.record(s)
             pending.append((idx, host, ev, res))
-        scores = np.full(nreads, np.nan, dtype=np.float32)
-        paths = [None] * nreads
+        return pending
+
+    @staticmethod
+    def _collect_read_batches(pending, scores, paths, ids=None):
+        """Wait for the queued batches and file their results under the reads' indices (`ids`: slice-local index -> index in the set)."""
         for idx, host, ev, res in pending:
             ev.synchronize()
             sc, pa, le = (h.numpy() for h in host)
             for j, i in enumerate(idx):
-                scores[i] = sc[j]
-                paths[i] = pa[j, :le[j]].copy()
-        return scores, paths
+                g = i if ids is None else ids[i]
+                scores[g] = sc[j]
+                paths[g] = pa[j, :le[j]].copy()
 
     @classmethod
     def read_lanes(cls, network, n, **kwargs):
@@ -360,19 +373,136 @@ class Basecaller(object):
 
     @classmethod
     def call_reads_bucketed(cls, network, signals, trim=(0, 0), open_pore_fraction=0.0, max_batch=256, max_waste=0.08, in_flight=None,
-                            lanes=None, **kwargs):
+                            lanes=None, stream_buckets=True, **kwargs):
         """Whole-read mode for MANY reads (what bin/basecall_network.py does with a pool of workers, basecall_network.py:100-104):
         reads are bucketed by length (length_buckets), every bucket is one padded ragged batch, and the buckets run side by side
         on streams of their own (one Basecaller each, sharing the network).  Each read gets bit for bit what call_reads([read])
         gives.  -> (scores [N] float32, list of N int32 path arrays, sample counts [N], stats) all on the host; stats holds the
         padded-step waste and the indices of the reads that could not be called (`failed`: score NaN, path None, sample count 0 --
         each reported on stderr as the reference's worker reports a read it skips, basecall.py:103-115)."""
+        if open_pore_fraction == 0 and len(signals) > 2 * max_batch and stream_buckets:
+            return cls._call_reads_streamed(network, signals, trim, max_batch, max_waste, in_flight, lanes, **kwargs)
         batches, nsamp = cls.prepare_read_batches(network, signals, trim, open_pore_fraction, max_batch, max_waste, **kwargs)
         scores, paths = cls.run_read_batches(network, batches, len(nsamp), in_flight, lanes, **kwargs)
         used = sum(nsamp)
         padded = sum(ns[0] * len(idx) for idx, _, ns in batches)
         stats = {"reads": len(nsamp), "batches": len(batches), "samples": used, "padded_samples": padded,
                  "padded_step_waste": 1.0 - used / float(max(padded, 1)), "failed": cls.failed_reads(nsamp)}
+        return scores, paths, nsamp, stats
+
+    _UPLOAD_STREAMS = {}
+
+    @classmethod
+    def _call_reads_streamed(cls, network, signals, trim, max_batch, max_waste, in_flight, lanes, window_size=100, **kwargs):
+        """call_reads_bucketed for a big set with the CLI's open-pore fraction of 0 (bin/basecall_network.py:71), WITHOUT a round trip to
+        the host between the upload of a read and its call: reads are bucketed by their RAW lengths (what the host knows without touching
+        a sample; trimming takes at most a few windows off); bucket after bucket the host packs the reads into pinned memory and queues
+        the upload on a copy stream, and the bucket's lane does the rest in stream order -- the check for samples that are not finite,
+        the window spreads, trim_open_pore + trim_array on the device (slk_open_pore_trim_f32), the zero-padded batch, normalisation,
+        network, decoder, results and trimmed lengths to the host.  The host packs bucket k + 1 while the device runs bucket k: what is
+        left in front of the network is the first bucket's upload (round 5: 85 ms of packing, upload and trimming for 4096 reads before
+        the first network kernel).  A read that fails keeps its place in its bucket with length 0 (columns of a batch never mix), is
+        reported on stderr like the reference's worker does (basecall.py:103-115) and comes back with score NaN and path None."""
+        import sys
+        import torch
+        from . import device as D
+        L = _lib.lib()
+        dev = D.device()
+        nread = len(signals)
+        raw = [len(s) for s in signals]
+        buckets = cls.length_buckets(raw, max_batch, max_waste)
+        if lanes is None:
+            lanes = cls.read_lanes(network, max(1, min(8, len(buckets))) if in_flight is None else in_flight, **kwargs)
+        up = cls._UPLOAD_STREAMS.get(dev.index)
+        if up is None:
+            up = cls._UPLOAD_STREAMS[dev.index] = torch.cuda.Stream()
+        # one pinned staging area for the whole set (grow-only, kept per host thread: batch._staging), bucket after bucket
+        strides = [-(-n // window_size) * window_size for n in raw]
+        bsize = [sum(strides[i] for i in idx) for idx in buckets]
+        total = sum(bsize)
+        st = batch._staging
+        if getattr(st, "buf", None) is None or st.buf.numel() < total:
+            st.buf = torch.empty(max(total, 1 << 20), dtype=torch.float32).pin_memory()
+            st.event = None
+        if st.event is not None:
+            st.event.synchronize()
+        hv = st.buf.numpy()
+        assert trim[0] >= 0 and trim[1] >= 0
+        import concurrent.futures
+        pool = concurrent.futures.ThreadPoolExecutor(min(8, os.cpu_count() or 1))
+        pending, base = [], 0
+        try:
+            for k, idx in enumerate(buckets):
+                n = len(idx)
+                off = np.concatenate([[0], np.cumsum([strides[i] for i in idx])]).astype(np.int64)
+
+                def pack(lo, hi, idx=idx, off=off, base=base):
+                    for j in range(lo, hi):
+                        i = idx[j]
+                        hv[base + off[j]: base + off[j] + raw[i]] = signals[i]
+                        hv[base + off[j] + raw[i]: base + off[j + 1]] = 0.0
+                step = max(1, -(-n // 8))
+                list(pool.map(lambda a: pack(*a), [(lo, min(n, lo + step)) for lo in range(0, n, step)]))
+                # [first sample | first window | raw length | whole windows] of every read, one small upload
+                meta = torch.empty((4, n), dtype=torch.int64).pin_memory()
+                mv = meta.numpy()
+                mv[0], mv[1], mv[2], mv[3] = off[:n], off[:n] // window_size, [raw[i] for i in idx], [raw[i] // window_size for i in idx]
+                with torch.cuda.stream(up):
+                    sig = st.buf[base: base + bsize[k]].to(dev, non_blocking=True)
+                    meta_d = meta.to(dev, non_blocking=True)
+                    uploaded = torch.cuda.Event()
+                    uploaded.record(up)
+                base += bsize[k]
+                bc, lane = lanes[k % len(lanes)]
+                with torch.cuda.stream(lane):
+                    lane.wait_event(uploaded)
+                    sig.record_stream(lane)
+                    meta_d.record_stream(lane)
+                    first_sample, first_win = meta_d[0], meta_d[1]
+                    rawlen, nwin = meta_d[2].to(torch.int32), meta_d[3].to(torch.int32)
+                    flags = torch.zeros((n,), dtype=torch.int32, device=dev)
+                    _lib.check(L.slk_reads_nonfinite_f32(sig.data_ptr(), first_sample.data_ptr(), rawlen.data_ptr(), n,
+                                                         int(max(raw[i] for i in idx)), flags.data_ptr(), lane.cuda_stream), "reads_nonfinite")
+                    _, _, spread = batch.normalise_chunks(sig.view(-1, window_size), 'per-chunk', return_stats=True)
+                    start = torch.empty((n,), dtype=torch.int64, device=dev)
+                    ln = torch.empty((n,), dtype=torch.int32, device=dev)
+                    _lib.check(L.slk_open_pore_trim_f32(spread.data_ptr(), first_win.data_ptr(), nwin.data_ptr(), first_sample.data_ptr(),
+                                                        n, window_size, int(trim[0]), int(trim[1]), start.data_ptr(), ln.data_ptr(),
+                                                        flags.data_ptr(), lane.cuda_stream), "open_pore_trim")
+                    lmax = max(raw[i] for i in idx)                    # (an upper bound of the trimmed lengths: the batch's row width)
+                    padded = torch.empty((n, lmax), dtype=torch.float32, device=dev)
+                    _lib.check(L.slk_pack_reads_f32(sig.data_ptr(), start.data_ptr(), ln.data_ptr(), n, padded.data_ptr(), lmax,
+                                                    lane.cuda_stream), "pack_reads")
+                    # a failed read (length 0) runs as one zero sample: its column is garbage nobody reads
+                    res = bc._call_padded(padded, ln.clamp(min=1))
+                    host = tuple(t.to("cpu", non_blocking=True) for t in res + (ln, flags))
+                    ev = torch.cuda.Event()
+                    ev.record(lane)
+                pending.append((idx, host, ev, res, lmax))
+            st.event = torch.cuda.Event()
+            st.event.record(up)
+        finally:
+            pool.shutdown(wait=True)
+        scores = np.full(nread, np.nan, dtype=np.float32)
+        paths = [None] * nread
+        nsamp = [0] * nread
+        padded_total = 0
+        for idx, host, ev, res, lmax in pending:
+            ev.synchronize()
+            sc, pa, le, ns, fl = (h.numpy() for h in host)
+            padded_total += lmax * len(idx)
+            for j, i in enumerate(idx):
+                if fl[j]:
+                    why = "samples that are not finite" if fl[j] & 1 else ("too short to trim the open pore" if fl[j] & 2 else
+                                                                            "nothing left after trimming")
+                    sys.stderr.write("Failure calling read {}: {}\n".format(i, why))
+                    continue
+                nsamp[i] = int(ns[j])
+                scores[i] = sc[j]
+                paths[i] = pa[j, :le[j]].copy()
+        used = sum(nsamp)
+        stats = {"reads": nread, "batches": len(buckets), "samples": used, "padded_samples": padded_total,
+                 "padded_step_waste": 1.0 - used / float(max(padded_total, 1)), "failed": cls.failed_reads(nsamp), "streamed": True}
         return scores, paths, nsamp, stats
 
     def call_chunks_host(self, chunks):

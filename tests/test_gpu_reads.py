@@ -163,7 +163,9 @@ def test_bucketed_whole_read_mode_equals_single_reads():
     reads = [np.ascontiguousarray(base[i % 4][rs.randint(0, 900):][:n]) for i, n in enumerate(lens)]
     scores, paths, nsamp, stats = pipeline.Basecaller.call_reads_bucketed(net, reads, max_batch=6, max_waste=0.1, in_flight=2,
                                                                           kmer_len=5, skip=0.0)
-    assert stats["reads"] == 23 and stats["batches"] >= 4 and 0.0 <= stats["padded_step_waste"] <= 0.1
+    # (the streamed flow buckets by RAW length: the bound holds for those, trimming then takes up to two windows off a read -- a lot
+    #  for reads this short, next to nothing for real ones)
+    assert stats["reads"] == 23 and stats["batches"] >= 4 and 0.0 <= stats["padded_step_waste"] <= 0.1 + 200.0 / 900.0
     buckets = pipeline.Basecaller.length_buckets(nsamp, 6, 0.1)
     assert sorted(i for b in buckets for i in b) == list(range(23)) and max(len(b) for b in buckets) <= 6
     bc = pipeline.Basecaller(net, kmer_len=5, skip=0.0)
@@ -172,10 +174,24 @@ def test_bucketed_whole_read_mode_equals_single_reads():
         assert n1[0] == nsamp[i]
         assert p1.cpu().numpy()[0, :int(l1[0])].tolist() == paths[i].tolist(), i
         assert float(s1[0]) == float(scores[i]), i
+    # that was the streamed flow (buckets by raw length, trimming on the device, no round trip to the host in front of the network);
+    # the flow that trims first and buckets by trimmed length forms other batches and gives the same bits
+    assert stats.get("streamed")
+    s3, p3, n3, st3 = pipeline.Basecaller.call_reads_bucketed(net, reads, max_batch=6, max_waste=0.1, in_flight=2, stream_buckets=False,
+                                                              kmer_len=5, skip=0.0)
+    assert not st3.get("streamed") and st3["batches"] >= 4 and list(n3) == list(nsamp) and st3["padded_step_waste"] <= 0.1
+    assert np.array_equal(s3, scores) and all(a.tolist() == b.tolist() for a, b in zip(p3, paths))
+    # ... and with samples trimmed off both ends (util.trim_array, basecall.py:112) the two flows agree as well
+    s4, p4, n4, _ = pipeline.Basecaller.call_reads_bucketed(net, reads, trim=(37, 112), max_batch=6, max_waste=0.1, kmer_len=5, skip=0.0)
+    s5, p5, n5, _ = pipeline.Basecaller.call_reads_bucketed(net, reads, trim=(37, 112), max_batch=6, max_waste=0.1, kmer_len=5, skip=0.0,
+                                                            stream_buckets=False)
+    assert list(n4) == list(n5) and n4[0] < nsamp[0] and np.array_equal(s4, s5)
+    assert all(a.tolist() == b.tolist() for a, b in zip(p4, p5))
 
 
+@pytest.mark.parametrize("stream_buckets", [True, False])
 @pytest.mark.parametrize("fraction", [0.0, 0.3])
-def test_a_read_that_fails_is_skipped_and_the_others_are_unaffected(fraction, capsys):
+def test_a_read_that_fails_is_skipped_and_the_others_are_unaffected(fraction, stream_buckets, capsys):
     """sloika/basecall.py:103-115: the reference's worker reports a read it cannot call and returns None; the pool goes on.  Here
     such a read (a NaN or an infinity among its samples, fewer samples than one open-pore window) must not poison the ragged batch it
     would have shared: it is left out, reported, and every other read gets bit for bit what it gets without it."""
@@ -191,8 +207,9 @@ def test_a_read_that_fails_is_skipped_and_the_others_are_unaffected(fraction, ca
     inf_read[7] = np.inf
     reads = good[:3] + [nan_read] + good[3:6] + [good[0][:60]] + good[6:] + [inf_read]
     bad_idx = [3, 7, len(reads) - 1]
-    kw = dict(max_batch=4, max_waste=0.2, in_flight=2, kmer_len=5, skip=0.0, open_pore_fraction=fraction)
+    kw = dict(max_batch=4, max_waste=0.2, in_flight=2, kmer_len=5, skip=0.0, open_pore_fraction=fraction, stream_buckets=stream_buckets)
     scores, paths, nsamp, stats = pipeline.Basecaller.call_reads_bucketed(net, reads, **kw)
+    assert bool(stats.get("streamed")) == (stream_buckets and fraction == 0.0)
     assert stats["failed"] == bad_idx and pipeline.Basecaller.failed_reads(nsamp) == bad_idx
     err = capsys.readouterr().err
     for i in bad_idx:
