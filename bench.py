@@ -549,7 +549,7 @@ def leg_batch256(args, torch, B1=256, nfl=8):
 
     small = {}
     for mname in (args.model,):                      # one model per child process (see the caller)
-        r1 = Runner(torch, mname, B1, L, max(1, nfl))
+        r1 = Runner(torch, mname, B1, L, 1)
         ent = {"workload": "%s inference, %d-sample chunks, batch %d%s" % (
             mname, L, B1, " (BASELINE.json configs[1])" if mname == "baseline_raw_gru" and B1 == 256 else
             " (the architecture of the reference's only TRAINED model, models/pretrained.pkl: Conv 128 . Rev Gru 112 . Gru 144 . Rev Gru "
@@ -577,13 +577,38 @@ def leg_batch256(args, torch, B1=256, nfl=8):
         ent["roofline_by_stage"] = roofline_by_stage(st1, tr1, None)
         for v in (ent["roofline_by_stage"] or {}).values():
             attach_counters(v, mname, B1, L)
-        r1.set_in_flight(nfl)
-        for i in range(2 * nfl):
-            r1.step(i, nfl)
-        n8 = args.small_batch_steps * nfl
-        d = timed(lambda i: r1.step(i, nfl), n8)
+        # ---- batches in flight, through the product's own API for a stream of batches (pipeline.Basecaller.call_batches: a fixed set of
+        # streams, a Basecaller(borrow=True) per slot, the host a consumer): a short leg, then >= N seconds with the shader clock
+        # sampled every 64 batches.  (Up to round 5 this leg drove eight Basecallers by hand; its 17 streams plus the API's 17 would be
+        # more than the runtime's 32 hardware queues, and every queue of the process would be time-sliced.) ----
+        from sloika_amd import pipeline
+        r1.bcs = None                                     # (one at a time is done: its arena goes back)
+        slots = pipeline.Basecaller.batch_slots(r1.net, nfl, kmer_len=5, nbase=4, min_prob=1e-5, skip=0.0)   # kept over the legs, as a server would
+        kwb = dict(copy=False, slots=slots)
+
+        def run_batches(nb=None, secs=None, probe=None):
+            count = [0]
+            t0 = time.perf_counter()
+
+            def feed():
+                while (count[0] < nb) if nb is not None else (time.perf_counter() - t0 < secs):
+                    if probe is not None and count[0] % 64 == 63:
+                        probe.sample()
+                    count[0] += 1
+                    yield r1.dev[count[0] % r1.nbuf]
+            nres = sum(1 for _res in pipeline.Basecaller.call_batches(r1.net, feed(), **kwb))
+            torch.cuda.synchronize()
+            return nres, time.perf_counter() - t0
+        run_batches(nb=2 * nfl)                          # first use: arenas, packs, streams
+        n8, d = run_batches(nb=args.small_batch_steps * nfl)
         ent["eight_in_flight"] = {"ms_per_step": d / n8 * 1e3, "value": B1 * L * n8 / d, "unit": "samples/s", "steps": n8,
-                                  "streams_per_gpu": nfl}
+                                  "streams_per_gpu": nfl, "api": "pipeline.Basecaller.call_batches"}
+        if args.sustained_seconds > 0:
+            probe = ClockProbe(torch)
+            nres, d = run_batches(secs=min(args.sustained_seconds, 10.0), probe=probe)
+            ent["in_flight_sustained"] = {"seconds": d, "batches": nres, "ms_per_batch": d / nres * 1e3, "value": B1 * L * nres / d,
+                                          "unit": "samples/s", "in_flight": nfl, "api": "pipeline.Basecaller.call_batches",
+                                          "shader_clock_mhz": probe.result()}
         small[mname] = ent
         del r1, rec1, st1
     return small
@@ -1114,7 +1139,8 @@ def main():
             line_extra["batch256"] = {}
             for mname in ("baseline_raw_gru", "raw_0.98_rgrgr"):
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only", "batch256", "--model", mname,
-                                    "--small-batch-steps", str(args.small_batch_steps), "--chunk-len", str(L)],
+                                    "--small-batch-steps", str(args.small_batch_steps), "--chunk-len", str(L),
+                                    "--sustained-seconds", str(args.sustained_seconds)],
                                    stdout=subprocess.PIPE, text=True)
                 try:
                     line_extra["batch256"].update(json.loads(r.stdout.strip().split("\n")[-1]))

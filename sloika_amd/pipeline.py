@@ -166,6 +166,93 @@ class Basecaller(object):
         return decode.viterbi_batch(post, self.kmer_len, skip_pen=self.skip, nbase=self.nbase,
                                     min_prob=self.min_prob, workspace=self._ws)
 
+    _BATCH_STREAMS = {}
+
+    @classmethod
+    def batch_slots(cls, network, in_flight=8, **kwargs):
+        """The slots of call_batches, for reuse over several streams of batches: (Basecallers with arenas of their own, their pinned
+        result buffers -- two sets per slot, like the arena's two device sets)."""
+        nslot = max(1, int(in_flight))
+        return [cls(network, in_flight=nslot, borrow=True, **kwargs) for _ in range(nslot)], [[None, None] for _ in range(nslot)]
+
+    @classmethod
+    def call_batches(cls, network, batches, in_flight=8, copy=True, slots=None, **kwargs):
+        """A stream of batches with `in_flight` of them on the device at a time: generator over `batches` (an iterable of [B, chunk_len]
+        signal batches -- device tensors, or host arrays that are uploaded -- or [T, B, features] tensors for event models), yielding
+        (scores float32 [B], paths int32 [B, T'] (-1 padded), lens int32 [B]) as numpy arrays ON THE HOST, one per batch, in the order
+        of the input.
+
+        What the reference does with a pool of worker processes (bin/basecall_network.py:100-104, one read per call) a GPU does with
+        batches side by side: at the north star's batch of 256 chunks one batch fills 64 of 256 CUs, so several must run at once.  The
+        set of streams is FIXED: `in_flight` slots, each with a Basecaller(borrow=True) (a call allocates nothing), a stream (plus the
+        side stream the directions of a birnn share their batch's stream with, layers.Parallel), pinned result buffers, and ONE copy
+        stream; batch i runs in slot i % in_flight.  Before slot k takes batch i the generator hands out batch i - in_flight (waits for
+        its copy): the host is a consumer, at most `in_flight` batches are queued, the device is never without work.  8 slots use 17
+        streams: below the 32 hardware queues sloika_amd asks for (device.want_hw_queues), so no queue is time-sliced.
+
+        copy=False yields views of the slot's pinned buffers instead of copies: valid until `in_flight` further batches have been
+        yielded.  slots: what batch_slots(network, in_flight, ...) returned, for a caller that runs stream after stream (a server): the
+        Basecallers keep their arenas and the pinned buffers between the streams, so a later stream allocates nothing at all."""
+        import torch
+        from . import device as D
+        if slots is None:
+            slots = cls.batch_slots(network, in_flight, **kwargs)
+        bcs, host = slots
+        nslot = len(bcs)
+        D.want_hw_queues(2 * nslot + 1)
+        # the streams are kept per device and slot count: torch hands out streams from a pool of 32 round robin, and a process that has
+        # USED more streams than the runtime has hardware queues (32) gets every queue time-sliced (measured: baseline_raw_gru, eight in
+        # flight, 640 M samples/s with 17 streams used, 150-210 M once another leg's 17 had been used before)
+        key = (torch.cuda.current_device(), nslot)
+        if key not in cls._BATCH_STREAMS:
+            cls._BATCH_STREAMS[key] = ([torch.cuda.Stream() for _ in range(nslot)], torch.cuda.Stream())
+        streams, copy_stream = cls._BATCH_STREAMS[key]
+        pending = [None] * nslot
+        ncall = [0] * nslot
+
+        def collect(k):
+            ev, bufs, B, T = pending[k]
+            pending[k] = None
+            ev.synchronize()
+            sc, pa, le = bufs[0][:B].numpy(), bufs[1][:B, :T].numpy(), bufs[2][:B].numpy()
+            return (sc.copy(), pa.copy(), le.copy()) if copy else (sc, pa, le)
+
+        for i, chunks in enumerate(batches):
+            k = i % nslot
+            if pending[k] is not None:
+                yield collect(k)
+            cur = torch.cuda.current_stream()
+            s = streams[k]
+            s.wait_stream(cur)                             # (whatever produced the batch on the caller's stream)
+            with torch.cuda.stream(s):
+                cd = D.to_dev(chunks)
+                if isinstance(chunks, torch.Tensor) and chunks.is_cuda:
+                    chunks.record_stream(s)
+                scores, paths, lens = bcs[k].call_chunks(cd)
+                done = torch.cuda.Event()
+                done.record(s)
+            B, T = paths.shape
+            g = ncall[k] & 1
+            ncall[k] += 1
+            bufs = host[k][g]
+            if bufs is None or bufs[1].shape[0] < B or bufs[1].shape[1] < T:
+                bufs = host[k][g] = (torch.empty((B,), dtype=torch.float32).pin_memory(),
+                                     torch.empty((B, T), dtype=torch.int32).pin_memory(),
+                                     torch.empty((B,), dtype=torch.int32).pin_memory())
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(done)
+                bufs[0][:B].copy_(scores, non_blocking=True)
+                bufs[1][:B, :T].copy_(paths, non_blocking=True)
+                bufs[2][:B].copy_(lens, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            pending[k] = (ev, bufs, B, T)
+        # the batches still on the device, oldest first
+        n = sum(ncall)
+        for i in range(n - min(n, nslot), n):
+            if pending[i % nslot] is not None:
+                yield collect(i % nslot)
+
     def call_bases(self, chunks, alphabet='ACGT'):
         """call_chunks + states -> bases on the device (what basecall.SeqPrinter.write does per read, basecall.py:157-163,
         with always_move as for a transducer model): -> (scores device [B], list of B base strings)."""

@@ -345,3 +345,39 @@ def test_borrow_mode_allocates_nothing_after_the_first_call_and_changes_no_bit()
             assert torch.equal(x, y)
         assert rc[1].data_ptr() == rb[1].data_ptr() or rc[1].data_ptr() == ra[1].data_ptr()   # ... the two sets alternate
         del bc, ra, rb, rc
+
+
+@pytest.mark.parametrize("name,B,L,nbatch,nfl", [("baseline_raw_gru", 64, 1000, 7, 3), ("raw_0.98_rgrgr", 128, 1500, 5, 8),
+                                                 ("raw_0.98_rgrgr", 96, 1000, 9, 2)])
+def test_call_batches_keeps_order_and_bits(name, B, L, nbatch, nfl):
+    """pipeline.Basecaller.call_batches: a stream of batches with `nfl` of them in flight on a fixed set of streams (what the reference
+    does with a pool of workers, bin/basecall_network.py:100-104).  One result per batch, in input order, on the host, bit for bit what
+    call_chunks gives for that batch alone -- with more slots than batches, with fewer, from device tensors and from host arrays."""
+    torch = need_gpu()
+    from sloika_amd import models, pipeline
+    net = models.randomise_zero_layers(models.build_model(name, klen=5, sd=0.5, seed=41))
+    host_batches = [pipeline.synthetic_chunks(B if i % 3 else B - 8, chunk_len=L, seed=100 + i) for i in range(nbatch)]
+    ref = []
+    bc = pipeline.Basecaller(net)
+    for hb in host_batches:
+        s, p, l = bc.call_chunks(dev(hb))
+        ref.append((s.cpu().numpy(), p.cpu().numpy(), l.cpu().numpy()))
+    for source in ("device", "host"):
+        feed = (dev(hb) if source == "device" else hb for hb in host_batches)
+        got = list(pipeline.Basecaller.call_batches(net, feed, in_flight=nfl))
+        assert len(got) == nbatch
+        for (s, p, l), (rs, rp, rl) in zip(got, ref):
+            assert np.array_equal(l, rl) and np.array_equal(p, rp) and np.array_equal(s, rs), source
+    assert list(pipeline.Basecaller.call_batches(net, iter(()), in_flight=nfl)) == []
+    # a server keeps its slots over several streams of batches: the second stream allocates nothing and gives the same bits
+    slots = pipeline.Basecaller.batch_slots(net, nfl)
+    for rnd in range(5):                     # (a slot is warm once it has filled both of its result sets)
+        if rnd == 4:
+            torch.cuda.synchronize()
+            before = torch.cuda.memory_stats()["allocation.all.allocated"]
+        got = list(pipeline.Basecaller.call_batches(net, (dev(hb) for hb in host_batches[:3] * 2), slots=slots))
+        for j, (s, p, l) in enumerate(got):
+            assert np.array_equal(p, ref[j % 3][1]) and np.array_equal(s, ref[j % 3][0])
+    torch.cuda.synchronize()
+    # (the uploads of the host batches are the caller's: 6 tensors; the calls themselves add none)
+    assert torch.cuda.memory_stats()["allocation.all.allocated"] - before <= 6
