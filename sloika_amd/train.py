@@ -660,9 +660,28 @@ class TrainingStep(object):
         # gru_bwd16_kernel issues TWO fp16 MFMAs per product (v_mfma_f32_16x16x32_f16, hi and lo halves of the operand in different
         # column groups): the region says so, and bench.py prices it on the fp16 pipe at two instructions per product
         two_term = layers.SPLIT_F16 and layers.RECURRENT_F16
+        # dL/dx out of the scan itself (csrc/gru_bwd16.hip, DX: the operand images of a step are da of that step, so the product costs the
+        # pass 18 MFMAs per wave and step and no second reading of da) -- unless the layer below hands its activation's derivative to the
+        # product's epilogue (slk_gemm_dact_bf16x6), which the separate GEMM keeps
+        dx = None
+        if need_dx and two_term and self._below is None and "no_scan_dx" not in layers._DEBUG:
+            dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
+            with profiler.region("train_gru_scan", 6.0 * M * n * (n + i_sz), 4.0 * M * (9 * n + i_sz),
+                                 f16x2_flops=6.0 * M * n * (n + i_sz)) as reg_dx:
+                rc = L.slk_gru_backward16_dx_f32(dy.data_ptr(), layers._row_stride(dy), hp_ptr, ldhp, zr.data_ptr(), h.data_ptr(),
+                                                 layers._row_stride(h), sW.data_ptr(), sW2.data_ptr(), iW.data_ptr(), da.data_ptr(),
+                                                 rh.data_ptr(), dx.data_ptr(), i_sz, T, B, n, i_sz, int(rev), act, gact, st())
+                if rc == _lib.SLK_ERR_UNSUPPORTED and reg_dx is not None:
+                    reg_dx.cancel()
+            if rc == _lib.SLK_ERR_UNSUPPORTED:
+                dx = None
+            else:
+                _lib.check(rc, "gru_backward (with dx)")
         with profiler.region("train_gru_scan", 6.0 * M * n * n, 4.0 * M * 9 * n, f16x2_flops=6.0 * M * n * n if two_term else 0.0) as reg_scan:
-            rc = _lib.SLK_ERR_UNSUPPORTED
-            if layers.SPLIT_F16 and layers.RECURRENT_F16:     # the two products of a step as fp16 splits (csrc/gru_bwd16.hip: n <= 128)
+            rc = _lib.SLK_OK if dx is not None else _lib.SLK_ERR_UNSUPPORTED
+            if dx is not None and reg_scan is not None:
+                reg_scan.cancel()
+            if dx is None and layers.SPLIT_F16 and layers.RECURRENT_F16:     # the two products of a step as fp16 splits (csrc/gru_bwd16.hip: n <= 128)
                 rc = L.slk_gru_backward16_f32(dy.data_ptr(), layers._row_stride(dy), hp_ptr, ldhp, zr.data_ptr(),
                                               h.data_ptr(), layers._row_stride(h), sW.data_ptr(), sW2.data_ptr(), da.data_ptr(),
                                               rh.data_ptr(), T, B, n, int(rev), act, gact, st())
@@ -680,6 +699,8 @@ class TrainingStep(object):
                            (da.data_ptr() + f4 * 2 * n, 3 * n, rh.data_ptr(), n, gsW2.data_ptr(), n, n, n, None)], M)
         if not need_dx:
             return None
+        if dx is not None:
+            return dx
         dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
         with profiler.region("train_dx", 6.0 * M * n * i_sz, 4.0 * M * (3 * n + i_sz)):
             below, self._below = self._below, None

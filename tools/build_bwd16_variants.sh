@@ -7,7 +7,7 @@ V=tools/_build/variants; mkdir -p $V
 objs=(); i=0
 for flags in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=off -Iinclude $flags \
-      -Dslk_gru_backward16_f32=slk_gw_v$i -Dgru_bwd16_kernel=gru_gw_k$i -c sloika_amd/csrc/gru_bwd16.hip -o $V/gw_$i.o &
+      -Dslk_gru_backward16_f32=slk_gw_v$i -Dslk_gru_backward16_dx_f32=slk_gwdx_v$i -Dgru_bwd16_kernel=gru_gw_k$i -Dgru_bwd16_entry=gru_gw_e$i -c sloika_amd/csrc/gru_bwd16.hip -o $V/gw_$i.o &
   objs+=($V/gw_$i.o); i=$((i+1))
 done
 wait
