@@ -486,10 +486,13 @@ SLK_API int slk_gru_backward16_f32(const float *dy, long lddy, const float *hpre
 /* ... and with the layer's dL/dx = da . iW (updates.py:67: th.grad through the projection of layers.py:1011, iW:[3n][insize]) formed in
  * the same pass from the operand images of each step (they ARE da of that step as fp16 pairs): dx:[T][B] rows of insize floats, lddx
  * apart, float32-grade like the pass's own products.  n a multiple of 16 up to 96, insize <= 64 (n <= 64) or 96; SLK_ERR_UNSUPPORTED
- * otherwise (-> slk_gru_backward16_f32 + slk_gemm_bf16x6_f32 on da). */
+ * otherwise (-> slk_gru_backward16_f32 + slk_gemm_bf16x6_f32 on da).  yref (or NULL): the OUTPUT of the element-wise activation `dact`
+ * whose result is this layer's input, rows ldyref apart -- dx then leaves multiplied by fun'(.), i.e. as dL/d(pre-activation) of the
+ * layer below (what slk_gemm_dact_bf16x6 does for the separate product). */
 SLK_API int slk_gru_backward16_dx_f32(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h,
                               long ldh, const float *sW, const float *sW2, const float *iW, float *da, float *rh, float *dx,
-                              long lddx, int T, int B, int n, int insize, int reverse, int act, int gate_act, slk_stream_t stream);
+                              long lddx, int T, int B, int n, int insize, int reverse, int act, int gate_act, const float *yref,
+                              long ldyref, int dact, slk_stream_t stream);
 /* Lstm (layers.py:677-697) in the reverse pass.  sum:[M][4n] = [x_t | out_{t-1}] . [iW | sW]^T + b (a GEMM over
  * slk_train_pack_xh_f32 rows), gate rows interleaved j*4 + gate as the reference stores them.
  *   slk_lstm_gates_f32: the element-wise cell recursion -> gates:[M][4n] = (candidate, input, forget, output) activated,

@@ -90,7 +90,8 @@ PROTOTYPES = {
     "slk_train_pack_xrh_f32": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
     "slk_gru_backward_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_gru_backward16_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "slk_gru_backward16_dx_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "slk_gru_backward16_dx_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _i, _i, _vp, _l, _i,
+                                       _vp]),
     "slk_lstm_gates_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "slk_lstm_backward_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "slk_lstm_backward16_f32": (_i, [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

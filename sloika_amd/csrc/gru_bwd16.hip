@@ -66,17 +66,32 @@ __device__ __forceinline__ float gw_chunk_max(float mx)
 // DX: the layer's dL/dx = da . iW (rows [daz | dar | dac] of da against iW[3n][insize]) comes out of the same pass: the two operand images
 // of a step ARE da of that step as fp16 hi/lo pairs, so the product costs a wave the MFMAs of its own 16 inputs (transposed iW as A
 // operands, 2 x 9 K blocks at n = 96) and nothing else -- no second pass over da (944 MB per layer read back by a separate GEMM).
-template <int N, bool DX>
+// DA (with DX): the product leaves multiplied by fun'(.) of the layer BELOW, evaluated on that layer's output yref (the Gru's own input):
+// it is dL/d(pre-activation) of that layer, what slk_gemm_dact_bf16x6 hands down (one more load per lane and step).
+__device__ __forceinline__ float gw_dact(float v, int act)
+{
+    switch (act) {                                       // activation.py:8-57, as act_backward_kernel (csrc/train.hip)
+    case SLK_ACT_TANH: return 1.0f - v * v;
+    case SLK_ACT_SIGMOID: return v * (1.0f - v);
+    case SLK_ACT_RELU: return v > 0.0f ? 1.0f : 0.0f;
+    case SLK_ACT_ELU: return v > 0.0f ? 1.0f : v + 1.0f;
+    default: return 1.0f;
+    }
+}
+
+template <int N, bool DX, bool DA>
 __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__restrict__ dy, long lddy, const float *__restrict__ hprev,
                                                              long ldhp, const float *__restrict__ zr, const float *__restrict__ hout,
                                                              long ldh, const float *__restrict__ sW, const float *__restrict__ sW2,
                                                              float *__restrict__ da, float *__restrict__ rh, int T, int B, int n,
                                                              int reverse, const float *__restrict__ iW, float *__restrict__ dx,
-                                                             long lddx, int insize)
+                                                             long lddx, int insize, const float *__restrict__ yref, long ldyref,
+                                                             int dact)
 {
+    static_assert(DX || !DA, "the activation's derivative rides on the dx product");
     static_assert(N % 32 == 0 && N <= 128, "K blocks of 32; one wave per 16 units, at most eight waves");
     constexpr int NW = N / 16, KB1 = N / 32, KB2 = 2 * N / 32, NTH = 64 * NW;
-    constexpr int LPS = 5;                               // loads per step and lane
+    constexpr int LPS = DA ? 6 : 5;                      // loads per step and lane
 
     // operand images: [hi image | lo image], each K x 4 chunks halves; element (k block kb, k group g, chunk c, r) = dword
     // ((kb*4+g)*4+c)*4 + r holds k = 32kb+4g+r (low half) and 32kb+16+4g+r (high half) of chunk c
@@ -178,13 +193,15 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
     // rows of scan step s: (reverse ? T-1-s : s) * B + chunk; the pass walks s = T-1 .. 0 (request i is scan step T-1-i)
     const long rstep = reverse ? (long)B : -(long)B;
     const long row0 = (long)(reverse ? 0 : T - 1) * B + bcc;
-    struct Ops { float dy, z, r, ht, hp; };
+    struct Ops { float dy, z, r, ht, hp, yb; };
     Ops vs[5];                                           // five register sets: requests run four steps ahead
     unsigned o_dy = (unsigned)((row0 * lddy + uu) * (long)sizeof(float)), o_z = (unsigned)((row0 * 2L * n + uu) * (long)sizeof(float));
     unsigned o_ht = (unsigned)((row0 * ldh + uu) * (long)sizeof(float)), o_hp = (unsigned)((row0 * ldhp + uu) * (long)sizeof(float));
     const unsigned st_dy = (unsigned)(rstep * lddy * (long)sizeof(float)), st_z = (unsigned)(rstep * 2L * n * (long)sizeof(float));
     const unsigned st_ht = (unsigned)(rstep * ldh * (long)sizeof(float)), st_hp = (unsigned)(rstep * ldhp * (long)sizeof(float));
     const unsigned r_off = (unsigned)(n * (int)sizeof(float));
+    unsigned o_yb = DA ? (unsigned)((row0 * ldyref + (u0 < insize ? u0 : 0)) * (long)sizeof(float)) : 0u;
+    const unsigned st_yb = DA ? (unsigned)(rstep * ldyref * (long)sizeof(float)) : 0u;
     int vnext = 0;
     auto load_v = [&](Ops &v) {                          // (requests past the first scan step re-read it: the count per step is fixed)
         gw_gload1(v.dy, o_dy, dy);
@@ -192,8 +209,9 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
         gw_gload1(v.r, o_z + r_off, zr);
         gw_gload1(v.ht, o_ht, hout);
         gw_gload1(v.hp, o_hp, hprev);
+        if constexpr (DA) gw_gload1(v.yb, o_yb, yref);
         vnext++;
-        if (vnext < T) { o_dy += st_dy; o_z += st_z; o_ht += st_ht; o_hp += st_hp; }
+        if (vnext < T) { o_dy += st_dy; o_z += st_z; o_ht += st_ht; o_hp += st_hp; o_yb += st_yb; }
     };
     load_v(vs[0]);
     load_v(vs[1]);
@@ -207,6 +225,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
     float *dxp = DX ? dx + (row0 * lddx + (xok ? u0 : 0)) : nullptr;
     const long dxstep = rstep * lddx;
     float dxc_kept = 0.0f;                               // the dac half of the step before, already unscaled
+    float yb_prev = 0.0f;                                // (DA) the layer below's output at the step before
     float keep = 0.0f;
     float invs2 = 1.0f;                                  // inverse of the scale the [daz | dar] image in LDS carries
     // before the first step: max |dy| of the first request (keep = 0, no image yet)
@@ -260,6 +279,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
         // the operands of this step and dy of the next one have arrived once only the three youngest requests are outstanding
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
         asm volatile("" : "+v"(cur.dy), "+v"(cur.z), "+v"(cur.r), "+v"(cur.ht), "+v"(cur.hp), "+v"(nxt.dy));
+        if constexpr (DA) asm volatile("" : "+v"(cur.yb));
         // the [daz | dar] half of dx of the step before, on the operands just fetched: GW_DXPOS 0 right behind the chain's MFMAs (its sum
         // a2 is complete before these), 1 behind the dac image's write, under that write's way to LDS and the wait at barrier Y
         f32x4 xz;
@@ -307,7 +327,11 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
         mfma_drain(a1);
         if constexpr (DX) {
             // dx of the step before: its dac half (kept) + its [daz | dar] half (xz, long complete: a barrier and this step's first half ago)
-            const float dxv = fmaf(pick_mix(xz) * inv3, invs2_prev, dxc_kept);
+            float dxv = fmaf(pick_mix(xz) * inv3, invs2_prev, dxc_kept);
+            if constexpr (DA) {
+                dxv *= gw_dact(yb_prev, dact);
+                yb_prev = cur.yb;
+            }
 #if !(GW_ABL & 1)
             if (live && xok && !first_step) dxp[-dxstep] = dxv;
 #else
@@ -375,48 +399,51 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
         f32x4 xz;
         dx_zr(xz, bz);
         mfma_drain(xz);
-        const float dxv = fmaf(pick_mix(xz) * inv3, invs2, dxc_kept);
+        float dxv = fmaf(pick_mix(xz) * inv3, invs2, dxc_kept);
+        if constexpr (DA) dxv *= gw_dact(yb_prev, dact);
         if (live && xok) dxp[-dxstep] = dxv;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing of mine may land in registers after the wave has ended
 }
 
-template <int N, bool DX>
+template <int N, bool DX, bool DA>
 static size_t gru_bwd16_exclusive_lds()
 {
     hipFuncAttributes attr;
-    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(gru_bwd16_kernel<N, DX>)) != hipSuccess) return 0;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(gru_bwd16_kernel<N, DX, DA>)) != hipSuccess) return 0;
     const size_t half_cu = 80 * 1024 + 512;
     const size_t dyn = attr.sharedSizeBytes >= half_cu ? 0 : half_cu - attr.sharedSizeBytes;
-    if (dyn && hipFuncSetAttribute(reinterpret_cast<const void *>(gru_bwd16_kernel<N, DX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (dyn && hipFuncSetAttribute(reinterpret_cast<const void *>(gru_bwd16_kernel<N, DX, DA>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)dyn) != hipSuccess)
         return 0;
     return dyn;
 }
 
-template <int N, bool DX>
+template <int N, bool DX, bool DA = false>
 static int gru_bwd16_launch(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h, long ldh,
                             const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n, int reverse, const float *iW,
-                            float *dx, long lddx, int insize, hipStream_t s)
+                            float *dx, long lddx, int insize, const float *yref, long ldyref, int dact, hipStream_t s)
 {
-    const size_t dyn = SLK_PER_DEVICE(size_t, (gru_bwd16_exclusive_lds<N, DX>()));
-    hipLaunchKernelGGL((gru_bwd16_kernel<N, DX>), dim3((B + 3) / 4), dim3(4 * N), dyn, s, dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da,
-                       rh, T, B, n, reverse & 1, iW, dx, lddx, insize);
+    const size_t dyn = SLK_PER_DEVICE(size_t, (gru_bwd16_exclusive_lds<N, DX, DA>()));
+    hipLaunchKernelGGL((gru_bwd16_kernel<N, DX, DA>), dim3((B + 3) / 4), dim3(4 * N), dyn, s, dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2,
+                       da, rh, T, B, n, reverse & 1, iW, dx, lddx, insize, yref, ldyref, dact);
     return slk_launch_status();
 }
 
 static int gru_bwd16_entry(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h, long ldh,
                            const float *sW, const float *sW2, float *da, float *rh, int T, int B, int n, int reverse, int act,
-                           int gate_act, const float *iW, float *dx, long lddx, int insize, slk_stream_t stream)
+                           int gate_act, const float *iW, float *dx, long lddx, int insize, const float *yref, long ldyref, int dact,
+                           slk_stream_t stream)
 {
     if (!dy || !hprev || !zr || !h || !sW || !sW2 || !da || !rh || T < 1 || B < 1 || n < 1 || lddy < n || ldh < n || ldhp < n)
         return SLK_ERR_INVALID_ARG;
     if (dx && (!iW || insize < 1 || lddx < insize)) return SLK_ERR_INVALID_ARG;
+    if (yref && (!dx || ldyref < insize || !slk_act_valid(dact))) return SLK_ERR_INVALID_ARG;
     if (act != SLK_ACT_TANH || gate_act != SLK_ACT_SIGMOID) return SLK_ERR_UNSUPPORTED;
     if (n % 16 || n > 128) return SLK_ERR_UNSUPPORTED;
     const unsigned long long rows = (unsigned long long)T * B, lim = 1ull << 32;
     if (rows * 3 * n * sizeof(float) >= lim || rows * lddy * sizeof(float) >= lim || rows * ldh * sizeof(float) >= lim ||
-        rows * ldhp * sizeof(float) >= lim)
+        rows * ldhp * sizeof(float) >= lim || (yref && rows * ldyref * sizeof(float) >= lim))
         return SLK_ERR_UNSUPPORTED;                      // 32-bit lane offsets
     hipStream_t s = slk_stream(stream);
     if (dx) {
@@ -424,12 +451,14 @@ static int gru_bwd16_entry(const float *dy, long lddy, const float *hprev, long 
         // width), and the weights of both products in a wave's 256 registers (n <= 96)
         const int N = n <= 64 ? 64 : 96;
         if (n > 96 || insize > N) return SLK_ERR_UNSUPPORTED;
-        if (n <= 64) return gru_bwd16_launch<64, true>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, iW, dx, lddx, insize, s);
-        return gru_bwd16_launch<96, true>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, iW, dx, lddx, insize, s);
+#define GW_GO(NN, DAF) gru_bwd16_launch<NN, true, DAF>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, iW, dx, lddx, insize, yref, ldyref, dact, s)
+        if (n <= 64) return yref ? GW_GO(64, true) : GW_GO(64, false);
+        return yref ? GW_GO(96, true) : GW_GO(96, false);
+#undef GW_GO
     }
-    if (n <= 64) return gru_bwd16_launch<64, false>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, nullptr, nullptr, 0, 0, s);
-    if (n <= 96) return gru_bwd16_launch<96, false>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, nullptr, nullptr, 0, 0, s);
-    return gru_bwd16_launch<128, false>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, nullptr, nullptr, 0, 0, s);
+    if (n <= 64) return gru_bwd16_launch<64, false>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, nullptr, nullptr, 0, 0, nullptr, 0, 0, s);
+    if (n <= 96) return gru_bwd16_launch<96, false>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, nullptr, nullptr, 0, 0, nullptr, 0, 0, s);
+    return gru_bwd16_launch<128, false>(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, nullptr, nullptr, 0, 0, nullptr, 0, 0, s);
 }
 
 // include/sloika_amd.h
@@ -438,15 +467,15 @@ extern "C" int slk_gru_backward16_f32(const float *dy, long lddy, const float *h
                                       int reverse, int act, int gate_act, slk_stream_t stream)
 {
     return gru_bwd16_entry(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, act, gate_act, nullptr, nullptr, 0, 0,
-                           stream);
+                           nullptr, 0, 0, stream);
 }
 
 extern "C" int slk_gru_backward16_dx_f32(const float *dy, long lddy, const float *hprev, long ldhp, const float *zr, const float *h,
                                          long ldh, const float *sW, const float *sW2, const float *iW, float *da, float *rh, float *dx,
                                          long lddx, int T, int B, int n, int insize, int reverse, int act, int gate_act,
-                                         slk_stream_t stream)
+                                         const float *yref, long ldyref, int dact, slk_stream_t stream)
 {
     if (!dx || !iW) return SLK_ERR_INVALID_ARG;
     return gru_bwd16_entry(dy, lddy, hprev, ldhp, zr, h, ldh, sW, sW2, da, rh, T, B, n, reverse, act, gate_act, iW, dx, lddx, insize,
-                           stream);
+                           yref, ldyref, dact, stream);
 }

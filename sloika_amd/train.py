@@ -664,19 +664,32 @@ class TrainingStep(object):
         # pass 18 MFMAs per wave and step and no second reading of da) -- unless the layer below hands its activation's derivative to the
         # product's epilogue (slk_gemm_dact_bf16x6), which the separate GEMM keeps
         dx = None
-        if need_dx and two_term and self._below is None and "no_scan_dx" not in layers._DEBUG:
+        if need_dx and two_term and "no_scan_dx" not in layers._DEBUG:
+            # the layer below's activation (a Convolution / FeedForward layer whose OUTPUT is the very tensor this Gru consumed: same
+            # memory, rows a uniform distance apart -- the condition of the separate product's fused form further down)
+            yb_ptr, ldyb, dact = None, 0, 0
+            if self._below is not None:
+                yb = self._below[0]
+                if (tuple(yb.shape) == (T, B, i_sz) and yb.stride(2) == 1 and yb.stride(0) == B * yb.stride(1)
+                        and yb.data_ptr() == xin.data_ptr() and tuple(yb.stride()) == tuple(xin.stride())):
+                    yb_ptr, ldyb, dact = yb.data_ptr(), layers._row_stride(yb), self._below[1]
             dx = torch.empty((T, B, i_sz), dtype=torch.float32, device=dev)
             with profiler.region("train_gru_scan", 6.0 * M * n * (n + i_sz), 4.0 * M * (9 * n + i_sz),
                                  f16x2_flops=6.0 * M * n * (n + i_sz)) as reg_dx:
-                rc = L.slk_gru_backward16_dx_f32(dy.data_ptr(), layers._row_stride(dy), hp_ptr, ldhp, zr.data_ptr(), h.data_ptr(),
-                                                 layers._row_stride(h), sW.data_ptr(), sW2.data_ptr(), iW.data_ptr(), da.data_ptr(),
-                                                 rh.data_ptr(), dx.data_ptr(), i_sz, T, B, n, i_sz, int(rev), act, gact, st())
+                rc = _lib.SLK_ERR_UNSUPPORTED              # (a layer below whose output is not this Gru's input tensor: the separate pair)
+                if self._below is None or yb_ptr is not None:
+                    rc = L.slk_gru_backward16_dx_f32(dy.data_ptr(), layers._row_stride(dy), hp_ptr, ldhp, zr.data_ptr(), h.data_ptr(),
+                                                     layers._row_stride(h), sW.data_ptr(), sW2.data_ptr(), iW.data_ptr(), da.data_ptr(),
+                                                     rh.data_ptr(), dx.data_ptr(), i_sz, T, B, n, i_sz, int(rev), act, gact, yb_ptr, ldyb,
+                                                     dact, st())
                 if rc == _lib.SLK_ERR_UNSUPPORTED and reg_dx is not None:
                     reg_dx.cancel()
             if rc == _lib.SLK_ERR_UNSUPPORTED:
                 dx = None
             else:
                 _lib.check(rc, "gru_backward (with dx)")
+                if yb_ptr is not None:
+                    self._below, self._dpre_ready = None, True         # what leaves IS dL/d(pre-activation) of the layer below
         with profiler.region("train_gru_scan", 6.0 * M * n * n, 4.0 * M * 9 * n, f16x2_flops=6.0 * M * n * n if two_term else 0.0) as reg_scan:
             rc = _lib.SLK_OK if dx is not None else _lib.SLK_ERR_UNSUPPORTED
             if dx is not None and reg_scan is not None:

@@ -36,9 +36,9 @@ def run(k, rev):
                              da.data_ptr(), rh.data_ptr(), T, B, n, rev, 1, 2, st)
     else:
         f = getattr(V, "slk_gwdx_v%d" % k)
-        f.restype, f.argtypes = i, [vp, l, vp, l, vp, vp, l, vp, vp, vp, vp, vp, vp, l, i, i, i, i, i, i, i, vp]
+        f.restype, f.argtypes = i, [vp, l, vp, l, vp, vp, l, vp, vp, vp, vp, vp, vp, l, i, i, i, i, i, i, i, vp, l, i, vp]
         call = lambda: f(dy.data_ptr(), n, hprev.data_ptr(), n, z.data_ptr(), hout.data_ptr(), n, sW.data_ptr(), sW2.data_ptr(), iW.data_ptr(),
-                         da.data_ptr(), rh.data_ptr(), dx.data_ptr(), isz, T, B, n, isz, rev, 1, 2, st)
+                         da.data_ptr(), rh.data_ptr(), dx.data_ptr(), isz, T, B, n, isz, rev, 1, 2, None, 0, 0, st)
     rc = call()
     assert rc == 0, rc
     torch.cuda.synchronize()
