@@ -111,6 +111,24 @@ def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
     orc.build()
     net = models.randomise_zero_layers(models.build_model(model_name, klen=5, sd=0.5, seed=11))
     spec = net.spec()
+    # the baseline runs the build made for THIS box's cores (-O3 -march=native, oracle/Makefile `native`; same arithmetic flags), once it
+    # has reproduced the portable build's bits on a few chunks; the portable build (-O2 -march=x86-64-v2) otherwise
+    build_kind = "portable (-O2 -march=x86-64-v2)"
+    if net.insize == 1:
+        probe = pipeline.synthetic_chunks(4, chunk_len=min(chunk_len, 500), seed=77)
+        xin = np.ascontiguousarray(orc.med_mad_normalise(probe).T)[:, :, None]
+        want = orc.run_network(spec, xin)
+        native = orc.build_native()
+        if native is not None:
+            orc.use_library(native)
+            try:
+                same = np.array_equal(orc.run_network(spec, xin), want)
+            except OSError:
+                same = False
+            if same:
+                build_kind = "native (-O3 -march=native, bits equal to the portable build's)"
+            else:
+                orc.use_library(None)
     cores = orc.num_threads()
     # every thread gets the same number of chunks (static OpenMP schedule over chunks): a slab is a multiple of the thread count, at
     # least four chunks per thread -- round 4's 256-chunk slabs gave 128 threads two chunks each and left the logarithm of the posteriors
@@ -148,7 +166,7 @@ def cpu_baseline(model_name, chunk_len, slab, budget_s=12.0, max_slabs=16):
             break
     out = {"value": done * chunk_len / spent, "unit": "samples/s", "cores": cores, "kind": "port",
            "sample": "%d chunks x %d samples of the same synthetic workload through the oracle C port "
-                     "(OpenMP over chunks, %d threads), %.1f s" % (done, chunk_len, cores, spent)}
+                     "(OpenMP over chunks, %d threads), %.1f s" % (done, chunk_len, cores, spent), "build": build_kind}
     # the same port on ONE core (SURVEY.md 8d asks for both): a dozen chunks, ~5 s
     try:
         orc.set_num_threads(1)
@@ -555,11 +573,14 @@ def leg_batch256(args, torch, B1=256, nfl=8):
             " (the architecture of the reference's only TRAINED model, models/pretrained.pkl: Conv 128 . Rev Gru 112 . Gru 144 . Rev Gru "
             "112; random weights)" if mname == "pretrained" else " (the metric's model at the north star's batch)")}
         r1.set_in_flight(1)
-        for i in range(3):
+        # (a child process starts on a device that has been idle: ~50 launches pass before the device's power management lets the
+        #  kernels run at their steady rate -- tools/warmup_kernel_only.py -- so the leg warms up for a dozen steps, and says so)
+        nwarm = 12
+        for i in range(nwarm):
             r1.step(i, 1)
         n = args.small_batch_steps
         d = timed(lambda i: r1.step(i, 1), n)
-        ent["one_at_a_time"] = {"ms_per_step": d / n * 1e3, "value": B1 * L * n / d, "unit": "samples/s", "steps": n,
+        ent["one_at_a_time"] = {"ms_per_step": d / n * 1e3, "value": B1 * L * n / d, "unit": "samples/s", "steps": n, "warmup": nwarm,
                                 "streams_per_gpu": 1}
         rec1 = profiler.start()
         timed(lambda i: r1.step(i, 1), n)

@@ -21,7 +21,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+#: SLOIKA_ORACLE_LIB: another build of the same source (oracle/Makefile: `asan`, `native`)
+_LIB_PATH = os.environ.get("SLOIKA_ORACLE_LIB") or os.path.join(_HERE, "_build", "liboracle.so")
 
 ACTIVATIONS = ["linear", "tanh", "sigmoid", "elu", "relu", "relu_smooth", "softplus", "exp", "erf", "L1mL2",
                "fair", "retu", "tanh_pm", "sigmoid_pm", "bounded_linear", "sin", "cauchy", "geman_mcclure",
@@ -36,6 +37,23 @@ def build(force=False):
             os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(_LIB_PATH)):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     return _LIB_PATH
+
+
+def build_native():
+    """oracle/_build/liboracle_native.so: the same source compiled -O3 -march=native ON THIS MACHINE (always rebuilt: the file of another
+    machine may not run here).  For the CPU baseline of bench.py only; None when the compiler is missing."""
+    try:
+        subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "native"])
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return os.path.join(_HERE, "_build", "liboracle_native.so")
+
+
+def use_library(path=None):
+    """Switch the build of the oracle this process calls (None: the default portable build)."""
+    global _lib, _LIB_PATH
+    _LIB_PATH = path or os.path.join(_HERE, "_build", "liboracle.so")
+    _lib = None
 
 
 _lib = None
