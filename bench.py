@@ -348,7 +348,7 @@ def unit_utilisation(model, batch, chunk_len, kernel_substr, streams=1):
 TRAIN_HBM_STAGES = ("train_wgrad", "train_dx", "train_xent")
 #: the kernel a stage's time is spent in (for the utilisation lookup)
 STAGE_KERNEL = {"gru_fused": "gru_bar16", "softmax_viterbi": "softmax_viterbi_kernel", "lstm_fused": "lstm_fused16_kernel",
-                "gru_recurrent": "gru_scan", "train_wgrad": "gemm_tn_bf16_multi", "train_gru_scan": "gru_bwd16_kernel",
+                "gru_recurrent": "gru_scan", "gru_input_gemm": "gemm_rows_f16x3_kernel", "train_wgrad": "gemm_tn_bf16_multi", "train_gru_scan": "gru_bwd16_kernel",
                 "train_dx": "gemm_bf16x6_kernel", "train_softmax_xent": "gemm_rows_f16x3_kernel"}
 
 
@@ -592,6 +592,8 @@ def leg_batch256(args, torch, B1=256, nfl=8):
                                           mname, B1, L)
         if nfl <= 1:
             ent["roofline_by_stage"] = roofline_by_stage(st1, tr1, None)
+            for v in (ent["roofline_by_stage"] or {}).values():
+                attach_counters(v, mname, B1, L)
             small[mname] = ent
             del r1, rec1, st1
             continue

@@ -28,7 +28,12 @@ STAGES = {            # bench.py stage -> substrings of the kernels it launches 
     "gemm_bias_act": ("gemm_bias_act_kernel", "gemm_rows_f16x3_kernel"),
     "conv1d": ("conv1d_",),
     "normalise": ("med_mad_",),
+    # layers that run projection GEMM + scan (the `pretrained` architecture: 112 / 144 wide)
+    "gru_input_gemm": ("gemm_rows_f16x3_kernel",),
+    "gru_recurrent": ("gru_scan1t_kernel", "gru_scan16_kernel"),
 }
+#: stages whose launches of a step are DIFFERENT kernels (template instances): bytes per launch = launch-weighted mean over them
+MEAN_STAGES = ("gru_input_gemm", "gru_recurrent")
 
 
 def stage_file(summary_path, workload):
@@ -36,7 +41,11 @@ def stage_file(summary_path, workload):
     d = json.load(open(summary_path))
     out = {}
     for stage, keys in STAGES.items():
-        tot = sum(v["hbm_bytes_per_launch"] for k, v in d["kernels"].items() if any(s in k for s in keys))
+        ks = [v for k, v in d["kernels"].items() if any(s in k for s in keys)]
+        tot = sum(v["hbm_bytes_per_launch"] for v in ks)
+        if tot and stage in MEAN_STAGES:
+            n = sum(v.get("launches_sampled", 1) for v in ks)
+            tot = sum(v["hbm_bytes_per_launch"] * v.get("launches_sampled", 1) for v in ks) / max(1, n)
         if tot:
             out[stage] = tot
     res = {"workload": workload, "source": summary_path + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "

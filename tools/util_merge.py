@@ -8,7 +8,7 @@ tag = sys.argv[1]
 root = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
 WORKLOADS = {"b1024": ["raw_0.98_rgrgr", 1024, 4000, 1], "b1024x4": ["raw_0.98_rgrgr", 1024, 4000, 4],
              "b256_rgrgr": ["raw_0.98_rgrgr", 256, 4000, 1], "b256_baseline": ["baseline_raw_gru", 256, 4000, 1],
-             "train": ["raw_0.98_rgrgr:train", 1024, 4000, 1]}
+             "train": ["raw_0.98_rgrgr:train", 1024, 4000, 1], "pretrained": ["pretrained", 1024, 4000, 1]}
 out = {"note": "rocprofv3 derived counters (MfmaUtil, VALUBusy, LdsUtil, LDSBankConflict: percent of the kernel's duration), one pass "
                "per counter with --kernel-trace only (tools/r05_measure.sh <tag> util); workload = [model, batch, chunk_len, streams]",
        "workloads": []}
