@@ -98,3 +98,47 @@ def test_gru_bwd16_unsupported_shapes_are_refused():
                                         z.data_ptr(), z.data_ptr(), 1, 1, n, 0, act, gate, stream()) == _lib.SLK_ERR_UNSUPPORTED
     assert L.slk_gru_backward16_f32(None, 64, z.data_ptr(), 64, z.data_ptr(), z.data_ptr(), 64, z.data_ptr(), z.data_ptr(),
                                     z.data_ptr(), z.data_ptr(), 1, 1, 64, 0, 1, 2, stream()) == _lib.SLK_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("n,insize", [(96, 96), (96, 32), (64, 64), (48, 16), (32, 64), (96, 80), (16, 16)])
+@pytest.mark.parametrize("T,B,reverse,scale,dact", [(23, 9, False, 1.0, None), (61, 5, True, 1e-4, "elu"), (1, 1, True, 1.0, "tanh"),
+                                                    (200, 33, False, 1e-2, None), (8, 4, True, 1e-9, "relu")])
+def test_gru_bwd16_with_dx_inside(n, insize, T, B, reverse, scale, dact):
+    """slk_gru_backward16_dx_f32: the layer's dL/dx = da . iW formed in the reverse pass itself (updates.py:67's gradient through the
+    projection of layers.py:1011).  da and rh are those of the plain pass BIT FOR BIT; dx agrees with the float64 product of that da
+    with iW to float32 rounding of a chunk's largest entry -- times fun'(.) of the layer below's output when one is handed over."""
+    torch = need_gpu()
+    from sloika_amd import _lib, activation
+    L = _lib.lib()
+    rs = np.random.RandomState(n + insize + T)
+    dy, zr, hout, hprev, sW, sW2 = _inputs(rs, T, B, n, scale)
+    dy, zr, hout, hprev = _flip([dy, zr, hout, hprev], reverse)
+    args = [dev(a.reshape(T * B, -1)) for a in (dy, zr, hout, hprev)] + [dev(sW), dev(sW2)]
+    iW = (2.0 * rs.normal(size=(3 * n, insize)) / np.sqrt(n + insize)).astype(np.float32)
+    yb = np.tanh(rs.normal(size=(T * B, insize))).astype(np.float32)
+    rc0, want, wantr = _run(L, "slk_gru_backward16_f32", *args, T, B, n, reverse)
+    da = torch.full((T * B, 3 * n), float("nan"), device="cuda")
+    rh = torch.full((T * B, n), float("nan"), device="cuda")
+    ldx = insize + 3                                                    # rows of dx need not be dense
+    dx = torch.full((T * B, ldx), float("nan"), device="cuda")
+    iWd, ybd = dev(iW), dev(yb)
+    act_id = activation.act_id(getattr(activation, dact)) if dact else 0
+    rc = L.slk_gru_backward16_dx_f32(args[0].data_ptr(), n, args[3].data_ptr(), n, args[1].data_ptr(), args[2].data_ptr(), n,
+                                     args[4].data_ptr(), args[5].data_ptr(), iWd.data_ptr(), da.data_ptr(), rh.data_ptr(), dx.data_ptr(),
+                                     ldx, T, B, n, insize, int(reverse), 1, 2, ybd.data_ptr() if dact else None, insize, act_id, stream())
+    kernel_width = 64 if n <= 64 else 96
+    if insize > kernel_width:
+        assert rc == _lib.SLK_ERR_UNSUPPORTED                           # (more inputs than a wave per 16 units can form)
+        return
+    assert rc0 == 0 and rc == 0
+    assert torch.equal(da, want) and torch.equal(rh, wantr)
+    got = dx.cpu().numpy()
+    assert np.isnan(got[:, insize:]).all()                              # nothing written past a row's insize floats
+    ref = want.cpu().numpy().astype(np.float64) @ iW.astype(np.float64)
+    if dact:
+        y64 = yb.astype(np.float64)
+        ref *= {"tanh": 1.0 - y64 * y64, "elu": np.where(y64 > 0, 1.0, y64 + 1.0), "relu": (y64 > 0).astype(np.float64)}[dact]
+    g, w = got[:, :insize].reshape(T, B, insize), ref.reshape(T, B, insize)
+    assert np.isfinite(g).all()
+    top = np.maximum(np.abs(w).max(axis=(0, 2), keepdims=True), 1e-35)
+    assert (np.abs(g - w) <= 2e-6 * top).all(), float((np.abs(g - w) / top).max())
