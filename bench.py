@@ -80,7 +80,7 @@ def parse():
     # 4096: with 1024 reads the longest read's own chain (115 000 samples through five sequential layers) takes longer than the whole
     # set would at the chunk-mode rate -- no schedule can do better than 0.68 x -- so a set that small measures the read, not the path
     ap.add_argument("--whole-reads", type=int, default=4096, help="synthetic whole reads of 50k-115k samples (0 = skip)")
-    ap.add_argument("--train-steps", type=int, default=5, help="training steps for the `train` field (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=10, help="training steps for the `train` field (0 = skip)")
     ap.add_argument("--host-feed-steps", type=int, default=10,
                     help="steps of the leg that uploads EIGHT ranks' raw signal per step from pinned host memory (0 = skip)")
     ap.add_argument("--stub-device", action="store_true",
@@ -677,7 +677,7 @@ def main_train(args, as_field=False, torch=None, dist=None):
     labels = torch.from_numpy(rs.randint(0, net.size, size=(To, B)).astype(np.int32)).cuda()
     weights = torch.ones((To, B), dtype=torch.float32, device="cuda")
     steps = args.train_steps if as_field else args.steps
-    warm = 2 if as_field else args.warmup
+    warm = 5 if as_field else args.warmup         # (a leg behind others: the device's power management again needs a few steps)
 
     def barrier():
         if dist is not None:
@@ -881,6 +881,34 @@ def emit(line):
     sys.stdout.flush()
 
 
+def children_first(args):
+    """The legs that need a process of their own, run BEFORE this process has touched the device (no HIP call, no library load yet):
+    the batch north_star quotes (256 chunks: BASELINE.json configs[1] and the metric's model, eight batches in flight through
+    pipeline.Basecaller.call_batches) and the architecture of the reference's only trained model (models/pretrained.pkl: the widths 112 /
+    144 that run projection GEMM + fp16-split scan).  A process of their own because eight batches in flight with the side streams of a
+    birnn use 18 hardware queues; and FIRST because the queues of two processes add up: beside a parent that had used ~20 streams
+    (in-flight legs, whole-read lanes, clock probes) baseline_raw_gru's eight batches in flight read 433-454 M samples/s, alone on the
+    device 683-717 M (profiles/r06a_*, tools measured in one call).  -> {"batch256": ..., "pretrained": ...}"""
+    import subprocess
+    out = {"batch256": {}}
+    me = os.path.abspath(__file__)
+    for mname in ("baseline_raw_gru", "raw_0.98_rgrgr"):
+        r = subprocess.run([sys.executable, me, "--only", "batch256", "--model", mname, "--small-batch-steps", str(args.small_batch_steps),
+                            "--chunk-len", str(args.chunk_len), "--sustained-seconds", str(args.sustained_seconds)],
+                           stdout=subprocess.PIPE, text=True)
+        try:
+            out["batch256"].update(json.loads(r.stdout.strip().split("\n")[-1]))
+        except (ValueError, IndexError):
+            out["batch256"][mname] = {"error": "child process failed (exit code %d)" % r.returncode}
+    r = subprocess.run([sys.executable, me, "--only", "model1024", "--model", "pretrained", "--batch", "1024", "--small-batch-steps",
+                        str(2 * args.small_batch_steps), "--chunk-len", str(args.chunk_len)], stdout=subprocess.PIPE, text=True)
+    try:
+        out["pretrained"] = json.loads(r.stdout.strip().split("\n")[-1])["pretrained"]
+    except (ValueError, IndexError, KeyError):
+        out["pretrained"] = {"error": "child process failed (exit code %d)" % r.returncode}
+    return out
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` outside a launcher: start N ranks of this script under torch.distributed.run (one process
     per GPU, rendezvous on 127.0.0.1) as a CHILD process and exit with its return code.  Nothing here has touched the GPU
@@ -922,6 +950,10 @@ def main():
     from sloika_amd import shard
     rank, world, local_rank = shard.dist_info()
     stub = args.stub_device
+    children = {}
+    if (world == 1 and max(1, args.streams) == 1 and not args.quick and not stub and args.small_batch_steps > 0
+            and args.model == "raw_0.98_rgrgr" and args.batch == 1024 and not args.with_bases):
+        children = children_first(args)              # (nothing in this process has touched the device yet)
     if stub:
         # the rank plumbing alone (tests): gloo, host tensors, a Runner that sleeps; `device` records what a real run would bind
         ndev = int(os.environ.get("SLOIKA_AMD_STUB_DEVICES", "8"))
@@ -1047,6 +1079,7 @@ def main():
                                   "projection + decoder on the logits; a correctness fallback, not a performance path"}
             finally:
                 _layers.SPLIT_F16, _layers.Softmax.split_f16 = keep
+            release()                                # (its 3.4 GB logits blocks would otherwise sit in the allocator's cache: see release)
 
         # ---- batches in flight ----
         if args.overlap_steps > 0:
@@ -1152,36 +1185,9 @@ def main():
             del pinned, land
             release()
 
-        # ---- the batch north_star quotes (256 chunks), in a CHILD process: eight batches in flight, each with side streams for
-        # the directions of a birnn, create more HIP streams than the device has hardware queues, and from then on every queue
-        # of the process is time-sliced (measured: the legs behind this one ran at half speed).  A child gets queues of its own
-        # and gives them back when it exits; the parent's queues idle meanwhile. ----
-        if args.small_batch_steps > 0 and args.model == "raw_0.98_rgrgr" and B == 1024 and not args.with_bases:
-            import subprocess
-            torch.cuda.synchronize()
-            line_extra["batch256"] = {}
-            for mname in ("baseline_raw_gru", "raw_0.98_rgrgr"):
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only", "batch256", "--model", mname,
-                                    "--small-batch-steps", str(args.small_batch_steps), "--chunk-len", str(L),
-                                    "--sustained-seconds", str(args.sustained_seconds)],
-                                   stdout=subprocess.PIPE, text=True)
-                try:
-                    line_extra["batch256"].update(json.loads(r.stdout.strip().split("\n")[-1]))
-                except (ValueError, IndexError):
-                    line_extra["batch256"][mname] = {"error": "child process failed (exit code %d)" % r.returncode}
-
-        # ---- the architecture of the reference's only trained model (models/pretrained.pkl), one batch of 1024 chunks at a time: the
-        # widths (112 / 144) that run projection GEMM + fp16-split scan instead of the one-kernel plan ----
-        if args.small_batch_steps > 0 and args.model == "raw_0.98_rgrgr" and B == 1024 and not args.with_bases:
-            import subprocess
-            torch.cuda.synchronize()
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--only", "model1024", "--model", "pretrained", "--batch", "1024",
-                                "--small-batch-steps", str(2 * args.small_batch_steps), "--chunk-len", str(L)],
-                               stdout=subprocess.PIPE, text=True)
-            try:
-                line_extra["pretrained"] = json.loads(r.stdout.strip().split("\n")[-1])["pretrained"]
-            except (ValueError, IndexError, KeyError):
-                line_extra["pretrained"] = {"error": "child process failed (exit code %d)" % r.returncode}
+        # (the batch-256 legs and the `pretrained` architecture ran in child processes BEFORE this process touched the device:
+        #  children_first)
+        line_extra.update(children)
 
         # ---- whole reads (the reference's inference mode), bucketed by length, ragged batches in flight ----
         if args.whole_reads > 0 and not args.with_bases:
