@@ -56,8 +56,8 @@ __device__ __forceinline__ float gw_chunk_max(float mx)
     return mx;
 }
 
-#ifndef GW_DXPOS
-#define GW_DXPOS 1                                       // where the dx MFMAs of a step sit (see the step)
+#ifndef GW_ABL_SKIP
+#define GW_ABL_SKIP 0                                    // timing experiments (results are garbage): waves >= this skip their dx MFMAs
 #endif
 #ifndef GW_ABL
 #define GW_ABL 0                                         // timing experiments only (results are garbage): 1 no stores, 2 no loads, 4 fixed scales
@@ -235,6 +235,9 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
 
     auto dx_zr = [&](f32x4 &xz, const half8 *bz) __attribute__((always_inline)) {
         if constexpr (DX) {
+#if GW_ABL_SKIP
+            if (w >= GW_ABL_SKIP) { xz = f32x4{0.f, 0.f, 0.f, 0.f}; return; }      // timing experiment: the waves that share a SIMD skip their tile
+#endif
             static_for<0, KB2>([&](auto KC) {
                 constexpr int kb = decltype(KC)::value;
                 gw_mma<kb == 0>(xz, w3l[kb], bz[kb]);
@@ -244,6 +247,9 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
     };
     auto dx_c = [&](f32x4 &xc, const half8 *bm) __attribute__((always_inline)) {
         if constexpr (DX) {
+#if GW_ABL_SKIP
+            if (w >= GW_ABL_SKIP) { xc = f32x4{0.f, 0.f, 0.f, 0.f}; return; }
+#endif
             static_for<0, KB1>([&](auto KC) {
                 constexpr int kb = decltype(KC)::value;
                 gw_mma<kb == 0>(xc, w4l[kb], bm[kb]);
@@ -280,10 +286,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPS) : "memory");
         asm volatile("" : "+v"(cur.dy), "+v"(cur.z), "+v"(cur.r), "+v"(cur.ht), "+v"(cur.hp), "+v"(nxt.dy));
         if constexpr (DA) asm volatile("" : "+v"(cur.yb));
-        // the [daz | dar] half of dx of the step before, on the operands just fetched: GW_DXPOS 0 right behind the chain's MFMAs (its sum
-        // a2 is complete before these), 1 behind the dac image's write, under that write's way to LDS and the wait at barrier Y
-        f32x4 xz;
-        if constexpr (GW_DXPOS == 0) dx_zr(xz, bz);
+        f32x4 xz;                                        // the [daz | dar] half of dx of the step before (formed in front of barrier Y)
         mfma_drain(a2);                                  // pick_mix reads the accumulator from asm
         float invs1;
         const float sc1 = gw_pow2_top(Gb, invs1);
@@ -310,7 +313,9 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
             reinterpret_cast<unsigned short *>(&c_img[0])[wpos] = __builtin_bit_cast(unsigned short, h16);
             reinterpret_cast<unsigned short *>(&c_img[CI])[wpos] = __builtin_bit_cast(unsigned short, l16);
         }
-        if constexpr (GW_DXPOS == 1) dx_zr(xz, bz);
+        // the [daz | dar] half of dx of the step before, on the operands fetched behind barrier X: its MFMAs behind the dac image's
+        // write, under that write's way to LDS and the wait at barrier Y (right behind the chain's own MFMAs they cost 80 cycles more)
+        dx_zr(xz, bz);
         // ---- barrier Y: the dac image and max |g| are there ----
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         half8 bm[KB1];
@@ -323,21 +328,7 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
             gw_mma<false>(a1, w1h[kb], bm[kb]);
         });
         f32x4 xc;
-        if constexpr (GW_DXPOS == 0) dx_c(xc, bm);
         mfma_drain(a1);
-        if constexpr (DX) {
-            // dx of the step before: its dac half (kept) + its [daz | dar] half (xz, long complete: a barrier and this step's first half ago)
-            float dxv = fmaf(pick_mix(xz) * inv3, invs2_prev, dxc_kept);
-            if constexpr (DA) {
-                dxv *= gw_dact(yb_prev, dact);
-                yb_prev = cur.yb;
-            }
-#if !(GW_ABL & 1)
-            if (live && xok && !first_step) dxp[-dxstep] = dxv;
-#else
-            if (live && xok && T < 0) dxp[0] = dxv;
-#endif
-        }
         const float sc2 = gw_pow2_top(Gb * D2, invs2);
         const float drh = uok ? pick_mix(a1) * inv1 * invs1 : 0.0f;
         const float dar = drh * h * r * (1.0f - r);
@@ -352,11 +343,6 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
 #endif
         dap += dstep;
         rhp += rhstep;
-        if constexpr (DX && GW_DXPOS == 0) {
-            mfma_drain(xc);
-            dxc_kept = pick_mix(xc) * inv4 * invs1;          // this step's dac half, unscaled (invs1: the scale of this step's dac image)
-            dxp += dxstep;
-        }
         {
 #if !(GW_ABL & 4)
             // |g| of the next step <= max_u |dy + keep| + C1 max_u |dzr| <= 2 max_u (|dy + keep| + C1 |dzr|): ONE number per chunk and
@@ -375,10 +361,24 @@ __global__ void __launch_bounds__(4 * N, 1) gru_bwd16_kernel(const float *__rest
             ih[wpos + KB1 * 128] = __builtin_bit_cast(unsigned short, h1);              // k = N + u: KB1 K blocks further
             il[wpos + KB1 * 128] = __builtin_bit_cast(unsigned short, l1);
         }
-        if constexpr (DX && GW_DXPOS == 1) {
-            dx_c(xc, bm);                                  // under the [daz | dar] image's way to LDS
+        if constexpr (DX) {
+            // (behind the chain's own work of this half: the image write above is on its way to LDS meanwhile)
+            // dx of the step before: its dac half (kept) + its [daz | dar] half (xz, long complete: a barrier and this step's first half ago)
+            float dxv = fmaf(pick_mix(xz) * inv3, invs2_prev, dxc_kept);
+            if constexpr (DA) {
+                dxv *= gw_dact(yb_prev, dact);
+                yb_prev = cur.yb;
+            }
+#if !(GW_ABL & 1)
+            if (live && xok && !first_step) dxp[-dxstep] = dxv;
+#else
+            if (live && xok && T < 0) dxp[0] = dxv;
+#endif
+        }
+        if constexpr (DX) {
+            dx_c(xc, bm);                                  // this step's dac half, under the [daz | dar] image's way to LDS
             mfma_drain(xc);
-            dxc_kept = pick_mix(xc) * inv4 * invs1;
+            dxc_kept = pick_mix(xc) * inv4 * invs1;        // ... unscaled (invs1: the scale of this step's dac image)
             dxp += dxstep;
         }
     };
