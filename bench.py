@@ -1194,14 +1194,24 @@ def main():
             reads = synthetic_reads(args.whole_reads)
             kw = dict(kmer_len=5, skip=0.0)
             lanes = pipeline.Basecaller.read_lanes(run.net, 8, **kw)          # kept across calls, as a serving process would
-            pipeline.Basecaller.call_reads_bucketed(run.net, reads, max_batch=256, max_waste=0.08, lanes=lanes, **kw)   # warm-up
+            # two warm-up calls: torch's allocator caches device memory per stream, and the SECOND call of a process still asks the device
+            # for memory (tools/whole_reads_alloc.py: 72 device allocations in the first call, 11 in the second -- the host runs ahead
+            # differently once the first call's stalls are gone -- none from the third on; `allocator_during_the_call` says what the
+            # timed call did).  A serving process is in that state after its first two read sets.
+            for _ in range(2):
+                pipeline.Basecaller.call_reads_bucketed(run.net, reads, max_batch=256, max_waste=0.08, lanes=lanes, **kw)
             torch.cuda.synchronize()
             # (1) from host arrays: trimming, bucketing, packing, upload, network, decoder, paths back on the host
+            ms0 = torch.cuda.memory_stats()
             t0 = time.perf_counter()
             scores, paths, nsamp, wst = pipeline.Basecaller.call_reads_bucketed(run.net, reads, max_batch=256, max_waste=0.08,
                                                                                 lanes=lanes, **kw)
             torch.cuda.synchronize()
             d_all = time.perf_counter() - t0
+            ms1 = torch.cuda.memory_stats()
+            alloc_delta = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries",
+                                                                            "allocation.all.allocated")}
+            alloc_delta["reserved_gb"] = round(ms1.get("reserved_bytes.all.current", 0) / 1e9, 1)
             # (2) the prepared batches resident in HBM (as the chunks of the main region are): network + decoder + paths to host
             batches, nsamp = pipeline.Basecaller.prepare_read_batches(run.net, reads, max_batch=256, max_waste=0.08, **kw)
             torch.cuda.synchronize()
@@ -1220,7 +1230,7 @@ def main():
                         "bucketed by raw length, packed and uploaded bucket by bucket while the device runs the buckets before, "
                         "open-pore trimming on the device in the bucket's own stream (Basecaller._call_reads_streamed)",
                 "from_host_arrays": {"value": sum(nsamp) / d_all, "unit": "samples/s", "seconds": d_all,
-                                     "streamed": bool(wst.get("streamed"))},
+                                     "streamed": bool(wst.get("streamed")), "allocator_during_the_call": alloc_delta},
                 "batches": wst["batches"], "padded_step_waste": wst["padded_step_waste"],
                 "bases_called": int(sum(len(p) for p in paths))}
             del batches, paths2, lanes, scores, paths, scores2
