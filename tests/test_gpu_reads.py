@@ -227,3 +227,56 @@ def test_a_read_that_fails_is_skipped_and_the_others_are_unaffected(fraction, st
         fast = batch.open_pore_bounds_many(dev, off, lens, 0.0)
         slow = batch.open_pore_bounds_many(dev, off, lens, 1e-12)          # the general path; same threshold for all practical purposes
         assert fast == slow
+
+
+def test_open_pore_trim_kernel_equals_numpy_percentile_zero():
+    """slk_open_pore_trim_f32 through the C ABI against the reference's arithmetic done in numpy (sloika/batch.py:213-220 with
+    max_op_fraction 0: np.percentile(spread, 0) is the minimum; then util.trim_array, basecall.py:112): spreads with ties at the minimum,
+    reads whose windows are all equal, reads shorter than a window, trims that leave nothing, a read flagged as not finite."""
+    torch = need_gpu()
+    from sloika_amd import _lib
+    from tests.gpu_util import stream
+    L = _lib.lib()
+    rs = np.random.RandomState(11)
+    window = 100
+    nwin = np.array([0, 1, 2, 5, 17, 64, 65, 400, 1150, 3, 3, 9, 30, 7], dtype=np.int32)
+    first_win = np.concatenate([[0], np.cumsum(nwin)[:-1]]).astype(np.int64)
+    spread = rs.gamma(2.0, size=int(nwin.sum())).astype(np.float32)
+    sp = lambda r: spread[first_win[r]: first_win[r] + nwin[r]]
+    sp(3)[:] = 1.5                                                       # all windows equal: no window livelier than the minimum
+    sp(4)[[0, 3, 16]] = sp(4).min()                                      # ties at the minimum, at both ends
+    sp(9)[:] = [2.0, 1.0, 2.0]
+    sp(10)[:] = [1.0, 2.0, 1.0]                                          # one lively window in the middle
+    first_sample = (first_win * window + 7 * np.arange(len(nwin))).astype(np.int64)      # reads need not be packed tightly
+    flags_in = np.zeros(len(nwin), dtype=np.int32)
+    flags_in[12] = 1                                                     # the caller found a sample that is not finite
+    for trim in ((0, 0), (37, 112), (250, 250)):
+        d = lambda a: torch.from_numpy(a).cuda()
+        start = torch.full((len(nwin),), -1, dtype=torch.int64, device="cuda")
+        ln = torch.full((len(nwin),), -1, dtype=torch.int32, device="cuda")
+        flags = d(flags_in.copy())
+        sd, fw, nw, fs = d(spread), d(first_win), d(nwin), d(first_sample)
+        rc = L.slk_open_pore_trim_f32(sd.data_ptr(), fw.data_ptr(), nw.data_ptr(), fs.data_ptr(), len(nwin), window, trim[0], trim[1],
+                                      start.data_ptr(), ln.data_ptr(), flags.data_ptr(), stream())
+        assert rc == 0
+        start, ln, flags = start.cpu().numpy(), ln.cpu().numpy(), flags.cpu().numpy()
+        for r in range(len(nwin)):
+            want_flag, lo, hi = int(flags_in[r]), 0, 0
+            s = sp(r)
+            lively = np.flatnonzero(s > np.percentile(s, 0)) if len(s) else np.zeros(0, dtype=np.int64)
+            if len(lively) == 0:
+                want_flag |= 2                                           # the reference's function raises on such a read
+            else:
+                lo, hi = int(lively[0]) * window + trim[0], (int(lively[-1]) + 1) * window - trim[1]
+                if hi - lo < 1:
+                    want_flag |= 4
+            assert flags[r] == want_flag, (r, trim, flags[r], want_flag)
+            if want_flag:
+                assert ln[r] == 0 and start[r] == first_sample[r]
+            else:
+                assert ln[r] == hi - lo and start[r] == first_sample[r] + lo, (r, trim)
+    z = torch.zeros(4, dtype=torch.int64, device="cuda")
+    assert L.slk_open_pore_trim_f32(None, z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, 100, 0, 0, z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                                    stream()) == _lib.SLK_ERR_INVALID_ARG
+    assert L.slk_open_pore_trim_f32(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 1, 100, -1, 0, z.data_ptr(), z.data_ptr(),
+                                    z.data_ptr(), stream()) == _lib.SLK_ERR_INVALID_ARG
