@@ -53,7 +53,10 @@ class Arena(object):
         n = 1
         for v in shape:
             n *= v
-        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        esz = _ESIZE.get(dtype)
+        if esz is None:
+            esz = _ESIZE[dtype] = torch.empty((), dtype=dtype).element_size()
+        nbytes = n * esz
         pool = self.res[self.gen] if result else self.bufs
         k = self.rcursor if result else self.cursor
         if result:
@@ -82,6 +85,7 @@ class Arena(object):
 
 import threading  # noqa: E402
 _ARENA = threading.local()
+_ESIZE = {}                                  # dtype -> bytes per element
 
 
 def scratch(shape, dtype=torch.float32, dev=None, result=False):
