@@ -186,8 +186,10 @@ class Basecaller(object):
         batches side by side: at the north star's batch of 256 chunks one batch fills 64 of 256 CUs, so several must run at once.  The
         set of streams is FIXED: `in_flight` slots, each with a Basecaller(borrow=True) (a call allocates nothing), a stream (plus the
         side stream the directions of a birnn share their batch's stream with, layers.Parallel), pinned result buffers, and ONE copy
-        stream; batch i runs in slot i % in_flight.  Before slot k takes batch i the generator hands out batch i - in_flight (waits for
-        its copy): the host is a consumer, at most `in_flight` batches are queued, the device is never without work.  8 slots use 17
+        stream; batch i runs in slot i % in_flight.  Once batch i is queued in its slot the generator hands out batch i - in_flight, the
+        slot's batch before (waits for its copy; the slot's two result sets, on the device and on the host, take turns): the host is a
+        consumer, a slot holds the batch that runs and at most one queued behind it, the device is never without work -- not even with
+        one slot.  8 slots use 17
         streams: below the 32 hardware queues sloika_amd asks for (device.want_hw_queues), so no queue is time-sliced.
 
         copy=False yields views of the slot's pinned buffers instead of copies: valid until `in_flight` further batches have been
@@ -210,17 +212,15 @@ class Basecaller(object):
         pending = [None] * nslot
         ncall = [0] * nslot
 
-        def collect(k):
-            ev, bufs, B, T = pending[k]
-            pending[k] = None
+        def collect(p):
+            ev, bufs, B, T = p
             ev.synchronize()
             sc, pa, le = bufs[0][:B].numpy(), bufs[1][:B, :T].numpy(), bufs[2][:B].numpy()
             return (sc.copy(), pa.copy(), le.copy()) if copy else (sc, pa, le)
 
         for i, chunks in enumerate(batches):
             k = i % nslot
-            if pending[k] is not None:
-                yield collect(k)
+            before = pending[k]                            # batch i - in_flight: handed out once batch i is queued behind it
             cur = torch.cuda.current_stream()
             s = streams[k]
             s.wait_stream(cur)                             # (whatever produced the batch on the caller's stream)
@@ -247,11 +247,14 @@ class Basecaller(object):
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             pending[k] = (ev, bufs, B, T)
+            if before is not None:
+                yield collect(before)
         # the batches still on the device, oldest first
         n = sum(ncall)
         for i in range(n - min(n, nslot), n):
             if pending[i % nslot] is not None:
-                yield collect(i % nslot)
+                yield collect(pending[i % nslot])
+                pending[i % nslot] = None
 
     def call_bases(self, chunks, alphabet='ACGT'):
         """call_chunks + states -> bases on the device (what basecall.SeqPrinter.write does per read, basecall.py:157-163,
